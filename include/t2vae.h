@@ -1,0 +1,106 @@
+/* libt2vae_hip — C ABI of the MI355X-native Tacotron2-VAE hot path.
+ *
+ * The reference (jinhan/tacotron2-vae) has no FFI of its own: its hot path sits behind Python
+ * module names.  This header is the boundary our host-side mirror
+ * (the Python modules under tacotron2-vae_amd/) binds with ctypes; each entry point cites the reference code it
+ * replaces.  All pointers are DEVICE pointers owned by the caller (PyTorch's allocator in our
+ * host code); the library allocates nothing, launches asynchronously on `stream`
+ * (a hipStream_t passed as void*), and returns 0 or a negative t2v error code.
+ * Layouts are row-major fp32 unless stated; LSTM gates are stacked i,f,g,o (PyTorch order).
+ */
+#ifndef T2VAE_H
+#define T2VAE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T2V_OK 0
+#define T2V_ERR_DIMS -1     /* geometry differs from the compiled default hparams */
+#define T2V_ERR_ARG -2      /* null pointer / bad size */
+#define T2V_ERR_LAUNCH -3   /* hipGetLastError() != hipSuccess after a launch */
+
+const char* t2v_version(void);
+/* last HIP error string recorded by a failing call (thread-local) */
+const char* t2v_last_error(void);
+
+/* ------------------------------------------------------------------ weight packing
+ * Re-lays the two decoder LSTM cells' weights into MFMA-fragment order for the per-step
+ * weight-streaming kernels.  Replaces nothing in the reference (cuDNN/cuBLAS choose their own
+ * layouts); inputs follow nn.LSTMCell (model.py:224-235).
+ *   wcat_att : (4096, k_att)  = [weight_hh | weight_ih[:,256:768] (| weight_ih[:,0:256])]
+ *              k_att = 1536 (training; prenet term hoisted) or 1792 (inference)
+ *   wcat_dec : (4096, 2560)   = [weight_ih (h_att|ctx) | weight_hh]
+ *   packF_*  : forward tiles,  same element count as the source
+ *   packB_*  : transposed tiles for the backward data-gradient GEMV (may be NULL) */
+int t2v_pack_lstm_weights(const float* wcat_att, int k_att, const float* wcat_dec,
+                          float* packF_att, float* packF_dec,
+                          float* packB_att, float* packB_dec, void* stream);
+
+typedef struct t2v_dec_weights {
+    const float* packF_att;   /* from t2v_pack_lstm_weights */
+    const float* packF_dec;
+    const float* packB_att;   /* NULL for inference */
+    const float* packB_dec;
+    const float* bias_att;    /* (4096) bias_ih+bias_hh; used only when gpre == NULL */
+    const float* bias_dec;    /* (4096) bias_ih+bias_hh */
+    const float* wqT;         /* (1024,128) query_layer weight, transposed (model.py:35) */
+    const float* loc_conv;    /* (32,2,31)  location_conv weight (model.py:17-20) */
+    const float* loc_dense;   /* (128,32)   location_dense weight (model.py:21-22) */
+    const float* v;           /* (128)      attention v (model.py:39) */
+} t2v_dec_weights;
+
+/* Saved-activation arena of one teacher-forced decoder pass (caller allocates; rows marked
+ * "row 0 = 0" must be zeroed by the caller before t2v_decoder_train_fwd). */
+typedef struct t2v_dec_train_bufs {
+    const float* gpre;      /* (T,B,4096)  prenet(x_t)·W_ih[:, :256]^T + b_ih + b_hh */
+    const float* memory;    /* (B,T_in,512) encoder outputs + style */
+    const float* pm;        /* (B,T_in,128) memory_layer(memory) (model.py:290) */
+    const int32_t* lengths; /* (B) valid encoder positions; NULL = no mask */
+    float* XS;    /* (T+2,B,2560) XS[t+1] = [h_att_t | ctx_t | h_dec_{t-1}]; row 0 = 0 */
+    float* CA;    /* (T+1,B,1024) pre-dropout cell of attention_rnn; row 0 = 0 */
+    float* CD;    /* (T+1,B,1024) pre-dropout cell of decoder_rnn;   row 0 = 0 */
+    float* GA;    /* (T,B,4096) gate activations i,f,g,o of attention_rnn */
+    float* GD;    /* (T,B,4096) gate activations of decoder_rnn */
+    float* QP;    /* (B,256,128) scratch: per-workgroup partial queries */
+    float* AL;    /* (T+1,B,T_in) AL[t+1] = attention weights of step t; row 0 = 0 */
+    float* ACUM;  /* (T+1,B,T_in) cumulative weights; row 0 = 0 */
+    float* S;     /* (T,B,T_in,128) tanh(...) of the energies; overwritten with dpre by bwd */
+    float* CONV;  /* (T,B,32,T_in) location_conv outputs */
+} t2v_dec_train_bufs;
+
+/* Decoder.forward's time loop (model.py:415-421 → Decoder.decode 346-389 → Attention.forward
+ * 67-88), teacher forced, both LSTM cells + location-sensitive attention.  The 80-mel/gate
+ * projection (model.py:385-388) is hoisted out of the loop: it reads [h_dec_t | ctx_t] from XS.
+ * Dropout on the LSTM states (model.py:361-364,378-381) uses a counter-based RNG keyed by
+ * (seed, stream, t, b, unit); p = 0 disables it. */
+int t2v_decoder_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
+                          int B, int T_in, int T_out, float p_att, float p_dec,
+                          uint64_t seed, void* stream);
+
+typedef struct t2v_dec_bwd_bufs {
+    const float* dHC;  /* (T,B,1536) grad wrt [h_dec_t | ctx_t] coming from the projection */
+    float* DGA;   /* (T,B,4096) out: grad wrt attention_rnn pre-activations (== grad of gpre) */
+    float* DGD;   /* (T,B,4096) out: grad wrt decoder_rnn pre-activations */
+    float* DQ;    /* (T,B,128)  out: grad wrt processed query */
+    float* DCTX;  /* (T,B,512)  out: grad wrt attention context */
+    float* DC;    /* (T,B,32,T_in) out: grad wrt location_conv outputs */
+    float* YD;    /* (B,2560) scratch, zeroed by the call */
+    float* YA;    /* (B,1536) scratch, zeroed by the call */
+    float* DCA;   /* (B,1024) scratch */
+    float* DCD;   /* (B,1024) scratch */
+    float* GPREV; /* (B,T_in) scratch */
+    float* GCUM;  /* (B,T_in) scratch */
+    float* DV;    /* (B,128) out: per-item grad of attention v (sum over b = dv) */
+} t2v_dec_bwd_bufs;
+
+/* Hand-written BPTT of the loop above (what autograd does for the reference at train.py:225).
+ * On return S holds dpre = grad wrt (q + loc + pm) per (t,b,j,d). */
+int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
+                          const t2v_dec_bwd_bufs* g, int B, int T_in, int T_out,
+                          float p_att, float p_dec, uint64_t seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,57 @@
+// Shared device helpers for libt2vae_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Model geometry of the decoder path at the reference's default hparams
+// (reference hparams.py:81-101).  The C API rejects anything else.
+#define T2V_H 1024      // attention_rnn_dim == decoder_rnn_dim
+#define T2V_E 512       // encoder_embedding_dim
+#define T2V_PRE 256     // prenet_dim
+#define T2V_A 128       // attention_dim
+#define T2V_F 32        // attention_location_n_filters
+#define T2V_KS 31       // attention_location_kernel_size
+#define T2V_NMEL 80
+#define T2V_G (4 * T2V_H)                 // 4096 gate rows
+#define T2V_XW (T2V_H + T2V_E + T2V_H)    // 2560: [h_att | ctx | h_dec]
+#define T2V_KATT (T2V_H + T2V_E)          // 1536: recurrent K of the attention LSTM
+#define T2V_KATT_INF (T2V_KATT + T2V_PRE) // 1792: + prenet columns (inference)
+#define T2V_NWG 256                       // one workgroup per CU
+
+// v_mfma_f32_16x16x4_f32: D(16x16) += A(16x4) * B(4x16); lane l holds A[l&15][l>>4],
+// B[l>>4][l&15]; D: col = l&15, row = 4*(l>>4)+r.
+__device__ __forceinline__ f32x4 mfma16x4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Counter-based RNG (splitmix64 finaliser) for dropout keep-masks: a pure function of
+// (seed, stream, t, idx) so the backward pass regenerates the forward's masks.
+__device__ __forceinline__ uint32_t t2v_rng_u32(uint64_t seed, uint32_t stream, uint32_t t, uint32_t idx) {
+    uint64_t x = seed ^ ((uint64_t)stream << 58) ^ ((uint64_t)t << 32) ^ (uint64_t)idx;
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (uint32_t)(x >> 32);
+}
+// returns the multiplicative dropout factor: 0 or 1/(1-p)
+__device__ __forceinline__ float t2v_drop_scale(uint64_t seed, uint32_t stream, uint32_t t, uint32_t idx, float p) {
+    if (p <= 0.0f) return 1.0f;
+    const float u = (float)(t2v_rng_u32(seed, stream, t, idx) >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

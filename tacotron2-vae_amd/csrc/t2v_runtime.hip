@@ -1,0 +1,17 @@
+// Library-level plumbing: version string, error recording.
+#include "t2v_common.h"
+#include "t2v_kernels.h"
+#include <string.h>
+
+static thread_local char g_err[256] = "";
+
+int t2v_check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        strncpy(g_err, hipGetErrorString(e), sizeof(g_err) - 1);
+        return T2V_ERR_LAUNCH;
+    }
+    return T2V_OK;
+}
+extern "C" const char* t2v_version(void) { return "t2vae-hip 0.1 (gfx950)"; }
+extern "C" const char* t2v_last_error(void) { return g_err; }

@@ -1,0 +1,103 @@
+"""Plain-Python hyper-parameter bag for the MI355X Tacotron2-VAE path.
+
+Mirrors the attribute names/defaults of the reference's TF1 `HParams` object
+(reference hparams.py:6-117) and its "k=v,k=v" override string
+(hparams.py:119-121), without the tensorflow dependency.
+"""
+
+_GROUPS = {
+    'experiment': dict(
+        epochs=300, iters_per_checkpoint=500, seed=1234, dynamic_loss_scaling=True,
+        fp16_run=False, distributed_run=False, dist_backend="nccl",
+        dist_url="tcp://localhost:54321", cudnn_enabled=True, cudnn_benchmark=True),
+    'data': dict(
+        load_mel_from_disk=False, training_files='filelists/ms_kor_train.txt',
+        validation_files='filelists/ms_kor_val.txt', text_cleaners=['korean_cleaners'],
+        sort_by_length=False),
+    'audio': dict(
+        max_wav_value=32768.0, sampling_rate=16000, filter_length=1024, hop_length=256,
+        win_length=1024, n_mel_channels=80, mel_fmin=0.0, mel_fmax=8000.0),
+    'text_encoder': dict(
+        n_symbols=80, symbols_embedding_dim=512, encoder_kernel_size=5,
+        encoder_n_convolutions=3, encoder_embedding_dim=512),
+    'labels': dict(n_speakers=1, speaker_embedding_dim=16, n_emotions=4,
+                   emotion_embedding_dim=16),
+    'vae': dict(
+        E=512, ref_enc_filters=[32, 32, 64, 64, 128, 128], ref_enc_size=[3, 3],
+        ref_enc_strides=[2, 2], ref_enc_pad=[1, 1], ref_enc_gru_size=256,
+        z_latent_dim=32, anneal_function='logistic', anneal_k=0.0025, anneal_x0=10000,
+        anneal_upper=0.2, anneal_lag=50000),
+    'prosody_unused': dict(
+        prosody_n_convolutions=6, prosody_conv_dim_in=[1, 32, 32, 64, 64, 128],
+        prosody_conv_dim_out=[32, 32, 64, 64, 128, 128], prosody_conv_kernel=3,
+        prosody_conv_stride=2, prosody_embedding_dim=128),
+    'decoder': dict(
+        n_frames_per_step=1, decoder_rnn_dim=1024, prenet_dim=256, max_decoder_steps=1000,
+        gate_threshold=0.5, p_attention_dropout=0.1, p_decoder_dropout=0.1,
+        attention_rnn_dim=1024, attention_dim=128, attention_location_n_filters=32,
+        attention_location_kernel_size=31),
+    'postnet': dict(postnet_embedding_dim=512, postnet_kernel_size=5,
+                    postnet_n_convolutions=5),
+    'optim': dict(use_saved_learning_rate=False, learning_rate=1e-3, weight_decay=1e-6,
+                  grad_clip_thresh=1.0, batch_size=64, mask_padding=True),
+}
+
+
+def _coerce(old, text):
+    if isinstance(old, bool):
+        return text.strip().lower() in ('true', '1')
+    if isinstance(old, int):
+        return int(text)
+    if isinstance(old, float):
+        return float(text)
+    if isinstance(old, (list, tuple)):
+        raise ValueError("list-valued hparams cannot be overridden from a string")
+    return text
+
+
+class HParams(object):
+    """Attribute bag with `.parse("a=1,b=x")` and `.values()`."""
+
+    def __init__(self, **kw):
+        object.__setattr__(self, '_store', {})
+        for k, v in kw.items():
+            self._store[k] = v
+
+    def __getattr__(self, k):
+        store = object.__getattribute__(self, '_store')
+        if k in store:
+            return store[k]
+        raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self._store[k] = v
+
+    def __contains__(self, k):
+        return k in self._store
+
+    def values(self):
+        return dict(self._store)
+
+    def parse(self, spec):
+        for item in filter(None, (s.strip() for s in spec.split(','))):
+            if '=' not in item:
+                raise ValueError("bad hparams item %r (want name=value)" % item)
+            k, v = (s.strip() for s in item.split('=', 1))
+            if k not in self._store:
+                raise ValueError("unknown hparam %r" % k)
+            self._store[k] = _coerce(self._store[k], v)
+        return self
+
+
+def create_hparams(hparams_string=None, verbose=False):
+    """Same call signature as reference hparams.py:3."""
+    flat = {}
+    for grp in _GROUPS.values():
+        for k, v in grp.items():
+            flat[k] = list(v) if isinstance(v, list) else v
+    hp = HParams(**flat)
+    if hparams_string:
+        hp.parse(hparams_string)
+    if verbose:
+        print('hparams:', hp.values())
+    return hp

@@ -1,0 +1,241 @@
+"""Tacotron2-VAE boundary modules for MI355X.
+
+Same attribute tree, `state_dict` keys (142) and call surface as the reference's model.py
+(`Tacotron2` 467-547, `Encoder` 151-203, `Decoder` 206-464, `Attention` 31-88,
+`LocationLayer` 12-28, `Prenet` 91-102, `Postnet` 105-148) so `load_model()`, checkpoints
+and the synthesizer call sequence stay drop-in.  The modules only hold parameters (created by
+the same stock containers in the same order, so seed 1234 reproduces the reference's step-0
+weights) and dispatch the work to the HIP path: the decoder time loop — ≈95 % of the step —
+runs in libt2vae_hip (t2v_hip.DecoderCore); there is no CPU fallback.
+"""
+from math import sqrt
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+import t2v_hip
+from layers import ConvNorm, LinearNorm
+from modules import VAE_GST
+from utils import get_mask_from_lengths, to_gpu
+
+drop_rate = 0.5   # module-level like reference model.py:11 (read at call time)
+
+
+class LocationLayer(nn.Module):
+    def __init__(self, attention_n_filters, attention_kernel_size, attention_dim):
+        super().__init__()
+        self.location_conv = ConvNorm(2, attention_n_filters, kernel_size=attention_kernel_size,
+                                      padding=(attention_kernel_size - 1) // 2, bias=False, stride=1,
+                                      dilation=1)
+        self.location_dense = LinearNorm(attention_n_filters, attention_dim, bias=False, w_init_gain='tanh')
+
+
+class Attention(nn.Module):
+    """Parameter holder; the arithmetic of reference model.py:45-88 lives in k_attn_fwd/k_attn_bwd."""
+
+    def __init__(self, attention_rnn_dim, embedding_dim, attention_dim, attention_location_n_filters,
+                 attention_location_kernel_size):
+        super().__init__()
+        self.query_layer = LinearNorm(attention_rnn_dim, attention_dim, bias=False, w_init_gain='tanh')
+        self.memory_layer = LinearNorm(embedding_dim, attention_dim, bias=False, w_init_gain='tanh')
+        self.v = LinearNorm(attention_dim, 1, bias=False)
+        self.location_layer = LocationLayer(attention_location_n_filters, attention_location_kernel_size,
+                                            attention_dim)
+        self.score_mask_value = -float("inf")
+
+
+class Prenet(nn.Module):
+    def __init__(self, in_dim, sizes):
+        super().__init__()
+        self.layers = nn.ModuleList([LinearNorm(i, o, bias=False) for i, o in zip([in_dim] + sizes[:-1], sizes)])
+
+    def forward(self, x):
+        # dropout stays on at inference too (reference model.py:101 hard-codes training=True)
+        for linear in self.layers:
+            x = F.dropout(F.relu(linear(x)), p=drop_rate, training=True)
+        return x
+
+
+def _conv_bn(cin, cout, k, gain):
+    return nn.Sequential(ConvNorm(cin, cout, kernel_size=k, stride=1, padding=(k - 1) // 2, dilation=1,
+                                  w_init_gain=gain), nn.BatchNorm1d(cout))
+
+
+class Postnet(nn.Module):
+    def __init__(self, hparams):
+        super().__init__()
+        n, d, k = hparams.postnet_n_convolutions, hparams.postnet_embedding_dim, hparams.postnet_kernel_size
+        blocks = [_conv_bn(hparams.n_mel_channels, d, k, 'tanh')]
+        blocks += [_conv_bn(d, d, k, 'tanh') for _ in range(1, n - 1)]
+        blocks.append(_conv_bn(d, hparams.n_mel_channels, k, 'linear'))
+        self.convolutions = nn.ModuleList(blocks)
+
+    def forward(self, x):
+        last = len(self.convolutions) - 1
+        for i, block in enumerate(self.convolutions):
+            x = block(x)
+            if i < last:
+                x = torch.tanh(x)
+            x = F.dropout(x, drop_rate, self.training)
+        return x
+
+
+class Encoder(nn.Module):
+    def __init__(self, hparams):
+        super().__init__()
+        d, k = hparams.encoder_embedding_dim, hparams.encoder_kernel_size
+        self.convolutions = nn.ModuleList([_conv_bn(d, d, k, 'relu') for _ in range(hparams.encoder_n_convolutions)])
+        self.lstm = nn.LSTM(d, d // 2, 1, batch_first=True, bidirectional=True)
+
+    def _convs(self, x):
+        for block in self.convolutions:
+            x = F.dropout(F.relu(block(x)), drop_rate, self.training)
+        return x.transpose(1, 2)
+
+    def forward(self, x, input_lengths):
+        x = self._convs(x)
+        packed = nn.utils.rnn.pack_padded_sequence(x, input_lengths.cpu(), batch_first=True)
+        self.lstm.flatten_parameters()
+        outputs, _ = self.lstm(packed)
+        outputs, _ = nn.utils.rnn.pad_packed_sequence(outputs, batch_first=True)
+        return outputs
+
+    def inference(self, x):
+        x = self._convs(x)
+        self.lstm.flatten_parameters()
+        outputs, _ = self.lstm(x)
+        return outputs
+
+
+class Decoder(nn.Module):
+    def __init__(self, hparams):
+        super().__init__()
+        self.n_mel_channels = hparams.n_mel_channels
+        self.n_frames_per_step = hparams.n_frames_per_step
+        self.encoder_embedding_dim = hparams.encoder_embedding_dim
+        self.attention_rnn_dim = hparams.attention_rnn_dim
+        self.decoder_rnn_dim = hparams.decoder_rnn_dim
+        self.prenet_dim = hparams.prenet_dim
+        self.max_decoder_steps = hparams.max_decoder_steps
+        self.gate_threshold = hparams.gate_threshold
+        self.p_attention_dropout = hparams.p_attention_dropout
+        self.p_decoder_dropout = hparams.p_decoder_dropout
+        if self.n_frames_per_step != 1:
+            raise NotImplementedError("n_frames_per_step=1 only (as the reference, hparams.py:88)")
+
+        self.prenet = Prenet(hparams.n_mel_channels * hparams.n_frames_per_step,
+                             [hparams.prenet_dim, hparams.prenet_dim])
+        self.attention_rnn = nn.LSTMCell(hparams.prenet_dim + self.encoder_embedding_dim, hparams.attention_rnn_dim)
+        self.attention_layer = Attention(hparams.attention_rnn_dim, self.encoder_embedding_dim,
+                                         hparams.attention_dim, hparams.attention_location_n_filters,
+                                         hparams.attention_location_kernel_size)
+        self.decoder_rnn = nn.LSTMCell(hparams.attention_rnn_dim + self.encoder_embedding_dim,
+                                       hparams.decoder_rnn_dim, 1)
+        self.linear_projection = LinearNorm(hparams.decoder_rnn_dim + self.encoder_embedding_dim,
+                                            hparams.n_mel_channels * hparams.n_frames_per_step)
+        self.gate_layer = LinearNorm(hparams.decoder_rnn_dim + self.encoder_embedding_dim, 1, bias=True,
+                                     w_init_gain='sigmoid')
+        self.dropout_seed = hparams.seed
+        self._calls = 0
+
+    # -- helpers kept for the reference's call sequence (synthesizer.py:135-156)
+    def get_go_frame(self, memory):
+        return memory.new_zeros(memory.size(0), self.n_mel_channels * self.n_frames_per_step)
+
+    def parse_decoder_inputs(self, decoder_inputs):
+        x = decoder_inputs.transpose(1, 2)
+        x = x.reshape(x.size(0), x.size(1) // self.n_frames_per_step, -1)
+        return x.transpose(0, 1)
+
+    def parse_decoder_outputs(self, mel_outputs, gate_outputs, alignments):
+        alignments = torch.stack(alignments).transpose(0, 1)
+        gate_outputs = torch.stack(gate_outputs)
+        if gate_outputs.dim() == 1:
+            gate_outputs = gate_outputs.unsqueeze(1)
+        gate_outputs = gate_outputs.transpose(0, 1).contiguous()
+        mel_outputs = torch.stack(mel_outputs).transpose(0, 1).contiguous()
+        mel_outputs = mel_outputs.view(mel_outputs.size(0), -1, self.n_mel_channels).transpose(1, 2)
+        return mel_outputs, gate_outputs, alignments
+
+    def _core_weights(self):
+        a, att, dec = self.attention_layer, self.attention_rnn, self.decoder_rnn
+        return (att.weight_ih, att.weight_hh, dec.weight_ih, dec.weight_hh, dec.bias_ih + dec.bias_hh,
+                a.query_layer.weight, a.location_layer.location_conv.conv.weight,
+                a.location_layer.location_dense.weight, a.v.weight)
+
+    def forward(self, memory, decoder_inputs, memory_lengths):
+        """Teacher-forced pass (reference model.py:391-426).  Returns mel (B,80,T), gate (B,T),
+        alignments (B,T,T_in)."""
+        B, T_in = memory.size(0), memory.size(1)
+        frames = self.parse_decoder_inputs(decoder_inputs)                       # (T,B,80)
+        T = frames.size(0)
+        x = torch.cat((self.get_go_frame(memory).unsqueeze(0), frames), 0)       # go frame first
+        pre = self.prenet(x)[:T]                                                  # (T,B,256)
+        att = self.attention_rnn
+        gpre = F.linear(pre, att.weight_ih[:, :self.prenet_dim], att.bias_ih + att.bias_hh)
+        pm = self.attention_layer.memory_layer(memory)
+        lengths = memory_lengths.to(device=memory.device, dtype=torch.int32)
+        training = self.training
+        p_att = self.p_attention_dropout if training else 0.0
+        p_dec = self.p_decoder_dropout if training else 0.0
+        self._calls += 1
+        seed = (int(self.dropout_seed) * 1000003 + self._calls) & 0x7FFFFFFFFFFFFFFF
+        hc, alignments = t2v_hip.DecoderCore.apply(gpre, memory, pm, lengths, *self._core_weights(),
+                                                   p_att, p_dec, seed)
+        mel = self.linear_projection(hc).permute(1, 2, 0).contiguous()           # (B,80,T)
+        gate = self.gate_layer(hc).squeeze(-1).transpose(0, 1).contiguous()      # (B,T)
+        return mel, gate, alignments
+
+
+class Tacotron2(nn.Module):
+    def __init__(self, hparams):
+        super().__init__()
+        self.mask_padding = hparams.mask_padding
+        self.fp16_run = hparams.fp16_run
+        self.n_mel_channels = hparams.n_mel_channels
+        self.n_frames_per_step = hparams.n_frames_per_step
+        self.transcript_embedding = nn.Embedding(hparams.n_symbols, hparams.symbols_embedding_dim)
+        self.speaker_embedding = LinearNorm(hparams.n_speakers, hparams.speaker_embedding_dim, bias=True,
+                                            w_init_gain='tanh')     # constructed, never used (B-7)
+        self.emotion_embedding = LinearNorm(hparams.n_emotions, hparams.emotion_embedding_dim, bias=True,
+                                            w_init_gain='tanh')     # constructed, never used (B-7)
+        val = sqrt(3.0) * sqrt(2.0 / (hparams.n_symbols + hparams.symbols_embedding_dim))
+        self.transcript_embedding.weight.data.uniform_(-val, val)
+        self.encoder = Encoder(hparams)
+        self.decoder = Decoder(hparams)
+        self.postnet = Postnet(hparams)
+        self.vae_gst = VAE_GST(hparams)
+
+    def parse_batch(self, batch):
+        text, input_lengths, mel, gate, output_lengths, speakers, emotions = batch
+        text = to_gpu(text).long()
+        speakers, emotions = to_gpu(speakers).float(), to_gpu(emotions).float()
+        input_lengths = to_gpu(input_lengths).long()
+        max_len = int(torch.max(input_lengths).item())
+        mel, gate = to_gpu(mel).float(), to_gpu(gate).float()
+        output_lengths = to_gpu(output_lengths).long()
+        return ((text, input_lengths, mel, max_len, output_lengths, speakers, emotions), (mel, gate))
+
+    def parse_input(self, inputs):
+        return inputs
+
+    def parse_output(self, outputs, output_lengths=None):
+        """In-place on .data exactly like reference model.py:509-520 (Appendix B-5: the Postnet's
+        first conv therefore sees the zero-masked decoder mel in its weight gradient)."""
+        if self.mask_padding and output_lengths is not None:
+            pad = ~get_mask_from_lengths(output_lengths, outputs[0].size(2))
+            outputs[0].data.masked_fill_(pad.unsqueeze(1), 0.0)
+            outputs[1].data.masked_fill_(pad.unsqueeze(1), 0.0)
+            outputs[2].data.masked_fill_(pad, 1e3)
+        return outputs
+
+    def forward(self, inputs):
+        text, input_lengths, targets, _, output_lengths, speakers, emotions = self.parse_input(inputs)
+        embedded = self.transcript_embedding(text).transpose(1, 2)
+        transcript = self.encoder(embedded, input_lengths)
+        style, mu, logvar, z = self.vae_gst(targets)
+        memory = transcript + style.unsqueeze(1)
+        mel, gate, alignments = self.decoder(memory, targets, memory_lengths=input_lengths)
+        mel_post = mel + self.postnet(mel)
+        return self.parse_output([mel, mel_post, gate, alignments, mu, logvar, z, emotions], output_lengths)

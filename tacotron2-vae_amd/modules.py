@@ -1,0 +1,64 @@
+"""VAE / GST reference encoder (reference modules.py:8-85)."""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from CoordConv import CoordConv2d
+
+
+class ReferenceEncoder(nn.Module):
+    """mel (N,80,T) → last GRU state (N, E/2).  modules.py:67 reinterprets the (80,T) block as
+    (T,80) rows without a transpose; we keep that."""
+
+    def __init__(self, hparams):
+        super().__init__()
+        filters = [1] + list(hparams.ref_enc_filters)
+        K = len(hparams.ref_enc_filters)
+        convs = [CoordConv2d(filters[0], filters[1], kernel_size=(3, 3), stride=(2, 2), padding=(1, 1),
+                             with_r=True)]
+        convs += [nn.Conv2d(filters[i], filters[i + 1], kernel_size=(3, 3), stride=(2, 2), padding=(1, 1))
+                  for i in range(1, K)]
+        self.convs = nn.ModuleList(convs)
+        self.bns = nn.ModuleList([nn.BatchNorm2d(hparams.ref_enc_filters[i]) for i in range(K)])
+        width = self.calculate_channels(hparams.n_mel_channels, 3, 2, 1, K)
+        self.gru = nn.GRU(input_size=hparams.ref_enc_filters[-1] * width, hidden_size=hparams.E // 2,
+                          batch_first=True)
+        self.n_mels = hparams.n_mel_channels
+
+    @staticmethod
+    def calculate_channels(L, kernel_size, stride, pad, n_convs):
+        for _ in range(n_convs):
+            L = (L - kernel_size + 2 * pad) // stride + 1
+        return L
+
+    def forward(self, inputs):
+        n = inputs.size(0)
+        out = inputs.contiguous().view(n, 1, -1, self.n_mels)
+        for conv, bn in zip(self.convs, self.bns):
+            out = F.relu(bn(conv(out)))
+        out = out.transpose(1, 2)
+        out = out.contiguous().view(n, out.size(1), -1)
+        _, last = self.gru(out)
+        return last.squeeze(0)
+
+
+class VAE_GST(nn.Module):
+    def __init__(self, hparams):
+        super().__init__()
+        self.ref_encoder = ReferenceEncoder(hparams)
+        self.fc1 = nn.Linear(hparams.ref_enc_gru_size, hparams.z_latent_dim)
+        self.fc2 = nn.Linear(hparams.ref_enc_gru_size, hparams.z_latent_dim)
+        self.fc3 = nn.Linear(hparams.z_latent_dim, hparams.E)
+        self.eps_override = None   # test hook: inject the reparameterisation noise
+
+    def reparameterize(self, mu, logvar):
+        if not self.training:
+            return mu
+        eps = self.eps_override if self.eps_override is not None else torch.randn_like(mu)
+        return eps * torch.exp(0.5 * logvar) + mu
+
+    def forward(self, inputs):
+        enc_out = self.ref_encoder(inputs)
+        mu, logvar = self.fc1(enc_out), self.fc2(enc_out)
+        z = self.reparameterize(mu, logvar)
+        return self.fc3(z), mu, logvar, z

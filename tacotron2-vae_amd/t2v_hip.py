@@ -1,0 +1,204 @@
+"""ctypes binding of libt2vae_hip.so (C ABI in include/t2vae.h) + the autograd wrappers
+the boundary modules in model.py call.
+
+There is no CPU fallback: every op raises `T2VHipError` when the shared library or a GPU
+is missing, so a silent eager path can never stand in for the HIP kernels.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'libt2vae_hip.so')
+_lib = None
+
+H, E, PRE, A, F_LOC, KS, XW, KATT, KATT_INF, G4 = 1024, 512, 256, 128, 32, 31, 2560, 1536, 1792, 4096
+
+
+class T2VHipError(RuntimeError):
+    pass
+
+
+class _DecWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        'packF_att', 'packF_dec', 'packB_att', 'packB_dec', 'bias_att', 'bias_dec', 'wqT',
+        'loc_conv', 'loc_dense', 'v')]
+
+
+class _DecTrainBufs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        'gpre', 'memory', 'pm', 'lengths', 'XS', 'CA', 'CD', 'GA', 'GD', 'QP', 'AL', 'ACUM',
+        'S', 'CONV')]
+
+
+class _DecBwdBufs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        'dHC', 'DGA', 'DGD', 'DQ', 'DCTX', 'DC', 'YD', 'YA', 'DCA', 'DCD', 'GPREV', 'GCUM', 'DV')]
+
+
+EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decoder_train_fwd',
+           't2v_decoder_train_bwd')
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen the in-tree library (no compute); raises T2VHipError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(_LIB_PATH):
+        raise T2VHipError("libt2vae_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(or make -C tacotron2-vae_amd/csrc)")
+    lib = C.CDLL(_LIB_PATH)
+    lib.t2v_version.restype = C.c_char_p
+    lib.t2v_last_error.restype = C.c_char_p
+    lib.t2v_pack_lstm_weights.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.t2v_decoder_train_fwd.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecTrainBufs), C.c_int, C.c_int,
+                                          C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]
+    lib.t2v_decoder_train_bwd.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecTrainBufs),
+                                          C.POINTER(_DecBwdBufs), C.c_int, C.c_int, C.c_int, C.c_float,
+                                          C.c_float, C.c_uint64, C.c_void_p]
+    for name in EXPORTS:
+        getattr(lib, name)
+    _lib = lib
+    return lib
+
+
+def _require_gpu(*tensors):
+    lib = load_library()
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise T2VHipError("HIP op called with a CPU tensor; this path has no CPU fallback")
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise T2VHipError("%s failed: rc=%d (%s)" % (what, rc, load_library().t2v_last_error().decode()))
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t):
+    assert t.dtype == torch.float32
+    return t.contiguous()
+
+
+class DecoderCore(torch.autograd.Function):
+    """Teacher-forced decoder recurrence (reference Decoder.forward loop, model.py:415-421).
+
+    inputs : gpre (T,B,4096), memory (B,T_in,512), pm (B,T_in,128), lengths int32 (B) | None,
+             attention_rnn weight_ih/weight_hh, decoder_rnn weight_ih/weight_hh, bias_dec (4096),
+             query weight (128,1024), location conv (32,2,31), location dense (128,32), v (1,128)
+    outputs: HC (T,B,1536) = [h_dec_t | ctx_t],  alignments (B,T,T_in)
+    """
+
+    @staticmethod
+    def forward(ctx, gpre, memory, pm, lengths, w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, bias_dec,
+                wq, loc_conv, loc_dense, v, p_att, p_dec, seed):
+        lib = _require_gpu(gpre, memory, pm, w_ih_att)
+        T, B, _ = gpre.shape
+        T_in = memory.shape[1]
+        dev = gpre.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        gpre, memory, pm = _f32c(gpre), _f32c(memory), _f32c(pm)
+        need_grad = any(ctx.needs_input_grad)
+
+        wcat_att = torch.cat((w_hh_att, w_ih_att[:, PRE:]), 1).contiguous()       # (4096,1536)
+        wcat_dec = torch.cat((w_ih_dec, w_hh_dec), 1).contiguous()                 # (4096,2560)
+        packF_att = torch.empty_like(wcat_att)
+        packF_dec = torch.empty_like(wcat_dec)
+        packB_att = torch.empty_like(wcat_att) if need_grad else None
+        packB_dec = torch.empty_like(wcat_dec) if need_grad else None
+        _check(lib.t2v_pack_lstm_weights(_p(wcat_att), KATT, _p(wcat_dec), _p(packF_att), _p(packF_dec),
+                                         _p(packB_att), _p(packB_dec), _stream()), 't2v_pack_lstm_weights')
+        wqT = wq.t().contiguous()
+        bias_dec = _f32c(bias_dec)
+        loc_conv, loc_dense, vv = _f32c(loc_conv), _f32c(loc_dense), _f32c(v).view(-1)
+
+        XS = torch.empty(T + 2, B, XW, **f32); XS[0].zero_(); XS[1, :, KATT:].zero_()
+        CA = torch.empty(T + 1, B, H, **f32); CA[0].zero_()
+        CD = torch.empty(T + 1, B, H, **f32); CD[0].zero_()
+        GA = torch.empty(T, B, G4, **f32)
+        GD = torch.empty(T, B, G4, **f32)
+        QP = torch.empty(B, 256, A, **f32)
+        AL = torch.empty(T + 1, B, T_in, **f32); AL[0].zero_()
+        ACUM = torch.empty(T + 1, B, T_in, **f32); ACUM[0].zero_()
+        S = torch.empty(T, B, T_in, A, **f32) if need_grad else None
+        CONV = torch.empty(T, B, F_LOC, T_in, **f32) if need_grad else None
+
+        W = _DecWeights(_p(packF_att), _p(packF_dec), _p(packB_att), _p(packB_dec), None, _p(bias_dec),
+                        _p(wqT), _p(loc_conv), _p(loc_dense), _p(vv))
+        Sb = _DecTrainBufs(_p(gpre), _p(memory), _p(pm), _p(lengths), _p(XS), _p(CA), _p(CD), _p(GA), _p(GD),
+                           _p(QP), _p(AL), _p(ACUM), _p(S), _p(CONV))
+        _check(lib.t2v_decoder_train_fwd(C.byref(W), C.byref(Sb), B, T_in, T, float(p_att), float(p_dec),
+                                         int(seed), _stream()), 't2v_decoder_train_fwd')
+        HC = torch.cat((XS[2:T + 2, :, KATT:], XS[1:T + 1, :, H:KATT]), 2)
+        align = AL[1:].permute(1, 0, 2)
+        ctx.dims = (B, T_in, T, float(p_att), float(p_dec), int(seed))
+        ctx.keep = (gpre, memory, pm, lengths, packF_att, packF_dec, packB_att, packB_dec, bias_dec, wqT,
+                    loc_conv, loc_dense, vv, XS, CA, CD, GA, GD, QP, AL, ACUM, S, CONV)
+        ctx.mark_non_differentiable(align)
+        return HC, align
+
+    @staticmethod
+    def backward(ctx, dHC, _dalign):
+        lib = load_library()
+        B, T_in, T, p_att, p_dec, seed = ctx.dims
+        (gpre, memory, pm, lengths, packF_att, packF_dec, packB_att, packB_dec, bias_dec, wqT, loc_conv,
+         loc_dense, vv, XS, CA, CD, GA, GD, QP, AL, ACUM, S, CONV) = ctx.keep
+        dev = gpre.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        dHC = _f32c(dHC)
+        DGA = torch.empty(T, B, G4, **f32)
+        DGD = torch.empty(T, B, G4, **f32)
+        DQ = torch.empty(T, B, A, **f32)
+        DCTX = torch.empty(T, B, E, **f32)
+        DC = torch.empty(T, B, F_LOC, T_in, **f32)
+        YD = torch.empty(B, XW, **f32); YA = torch.empty(B, KATT, **f32)
+        DCA = torch.empty(B, H, **f32); DCD = torch.empty(B, H, **f32)
+        GPREV = torch.empty(B, T_in, **f32); GCUM = torch.empty(B, T_in, **f32)
+        DV = torch.empty(B, A, **f32)
+        W = _DecWeights(_p(packF_att), _p(packF_dec), _p(packB_att), _p(packB_dec), None, _p(bias_dec),
+                        _p(wqT), _p(loc_conv), _p(loc_dense), _p(vv))
+        Sb = _DecTrainBufs(_p(gpre), _p(memory), _p(pm), _p(lengths), _p(XS), _p(CA), _p(CD), _p(GA), _p(GD),
+                           _p(QP), _p(AL), _p(ACUM), _p(S), _p(CONV))
+        Gb = _DecBwdBufs(_p(dHC), _p(DGA), _p(DGD), _p(DQ), _p(DCTX), _p(DC), _p(YD), _p(YA), _p(DCA),
+                         _p(DCD), _p(GPREV), _p(GCUM), _p(DV))
+        _check(lib.t2v_decoder_train_bwd(C.byref(W), C.byref(Sb), C.byref(Gb), B, T_in, T, p_att, p_dec, seed,
+                                         _stream()), 't2v_decoder_train_bwd')
+        TB = T * B
+        dga2, dgd2 = DGA.view(TB, G4), DGD.view(TB, G4)
+        # time-batched weight-gradient GEMMs (plain library GEMMs)
+        x_prev = XS[0:T].reshape(TB, XW)          # [h_att_{t-1} | ctx_{t-1} | .]
+        x_cur = XS[1:T + 1].reshape(TB, XW)       # [h_att_t | ctx_t | h_dec_{t-1}]
+        dw_att = dga2.t() @ x_prev[:, :KATT]      # (4096,1536) = [dW_hh | dW_ih[:,256:]]
+        d_w_hh_att = dw_att[:, :H].contiguous()
+        d_w_ih_att = torch.zeros(G4, PRE + E, **f32)
+        d_w_ih_att[:, PRE:] = dw_att[:, H:]
+        dw_dec = dgd2.t() @ x_cur                 # (4096,2560) = [dW_ih | dW_hh]
+        d_w_ih_dec = dw_dec[:, :KATT].contiguous()
+        d_w_hh_dec = dw_dec[:, KATT:].contiguous()
+        d_bias_dec = dgd2.sum(0)
+        d_wq = DQ.view(TB, A).t() @ x_cur[:, :H]
+        d_memory = torch.bmm(AL[1:].permute(1, 2, 0), DCTX.permute(1, 0, 2))
+        dpre = S                                   # overwritten in place by the backward kernels
+        d_pm = dpre.sum(0)
+        d_loc_dense = dpre.view(-1, A).t() @ CONV.permute(0, 1, 3, 2).reshape(-1, F_LOC)
+        d_v = DV.sum(0).view(1, A)
+        apad = torch.nn.functional.pad(torch.stack((AL[0:T], ACUM[0:T]), 2), (15, 15))   # (T,B,2,T_in+30)
+        d_loc_conv = torch.einsum('nfj,ncjk->fck', DC.view(TB, F_LOC, T_in),
+                                  apad.view(TB, 2, T_in + 30).unfold(2, KS, 1))
+        return (DGA, d_memory, d_pm, None, d_w_ih_att, d_w_hh_att, d_w_ih_dec, d_w_hh_dec, d_bias_dec,
+                d_wq, d_loc_conv, d_loc_dense, d_v, None, None, None)

@@ -1,0 +1,92 @@
+"""GPU parity: HIP decoder recurrence (forward + hand-written BPTT) vs the CPU oracle."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(B, T_in, T_out, lens_in, seed=0):
+    import hparams as HP
+    import model as M
+    hp = HP.create_hparams()
+    torch.manual_seed(seed)
+    M.drop_rate = 0.0
+    dec = M.Decoder(hp)
+    g = torch.Generator().manual_seed(seed + 1)
+    memory = torch.randn(B, T_in, 512, generator=g) * 0.5
+    mels = torch.randn(B, 80, T_out, generator=g)
+    lengths = torch.tensor(lens_in, dtype=torch.long)
+    wm = torch.randn(B, 80, T_out, generator=g)
+    wg = torch.randn(B, T_out, generator=g)
+    return hp, M, dec, memory, mels, lengths, wm, wg
+
+
+def _oracle(dec, memory, mels, lengths, wm, wg):
+    import t2v_oracle as O
+    sd = {'decoder.' + k: v.detach().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+    mem = memory.clone().requires_grad_(True)
+    mel, gate, align = O.decoder_forward(sd, mem, mels, lengths, p_att=0.0, p_dec=0.0)
+    loss = (mel * wm).sum() + (gate * wg).sum()
+    loss.backward()
+    return mel, gate, align, sd, mem
+
+
+@pytest.mark.parametrize("B,T_in,T_out,lens", [(3, 20, 12, [20, 17, 9]), (6, 84, 24, [84, 80, 71, 66, 50, 37]),
+                                               (1, 33, 7, [33])])
+def test_decoder_core_matches_oracle(B, T_in, T_out, lens):
+    hp, M, dec, memory, mels, lengths, wm, wg = _setup(B, T_in, T_out, lens)
+    o_mel, o_gate, o_align, o_sd, o_mem = _oracle(dec, memory, mels, lengths, wm, wg)
+
+    dev = torch.device('cuda:0')
+    dec = dec.to(dev).train()
+    dec.p_attention_dropout = 0.0
+    dec.p_decoder_dropout = 0.0
+    mem = memory.to(dev).requires_grad_(True)
+    mel, gate, align = dec(mem, mels.to(dev), lengths.to(dev))
+    loss = (mel * wm.to(dev)).sum() + (gate * wg.to(dev)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+
+    # forward tolerance: fp32, different summation order through T_out recurrent steps
+    assert (mel.cpu() - o_mel).abs().max().item() < 2e-4
+    assert (gate.cpu() - o_gate).abs().max().item() < 2e-4
+    assert (align.cpu() - o_align).abs().max().item() < 2e-5
+    # gradients: compare relative to the largest gradient entry of each tensor
+    worst = 0.0
+    for name, p in dec.named_parameters():
+        og = o_sd['decoder.' + name].grad
+        assert p.grad is not None, name
+        d = (p.grad.cpu() - og).abs().max().item()
+        s = og.abs().max().item()
+        rel = d / (s + 1e-6)
+        worst = max(worst, rel)
+        assert rel < 2e-3, (name, d, s)
+    dm = (mem.grad.cpu() - o_mem.grad).abs().max().item() / (o_mem.grad.abs().max().item() + 1e-6)
+    assert dm < 2e-3, dm
+
+
+def test_decoder_core_deterministic():
+    hp, M, dec, memory, mels, lengths, wm, wg = _setup(3, 20, 12, [20, 17, 9])
+    dev = torch.device('cuda:0')
+    dec = dec.to(dev).train()
+    outs = []
+    for _ in range(2):
+        dec._calls = 0
+        mem = memory.to(dev).requires_grad_(True)
+        mel, gate, align = dec(mem, mels.to(dev), lengths.to(dev))
+        (mel.sum() + gate.sum()).backward()
+        outs.append((mel.detach().clone(), mem.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_decoder_dropout_statistics():
+    """State dropout p=0.1 on h and c (model.py:361-364): keep-rate and 1/(1-p) scaling."""
+    import t2v_hip
+    hp, M, dec, memory, mels, lengths, wm, wg = _setup(6, 40, 30, [40] * 6)
+    dev = torch.device('cuda:0')
+    dec = dec.to(dev).train()
+    dec.p_attention_dropout = 0.5
+    with torch.no_grad():
+        mel, gate, align = dec(memory.to(dev), mels.to(dev), lengths.to(dev))
+    assert torch.isfinite(mel).all()
