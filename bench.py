@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""bench.py — Tacotron2-VAE training-step throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one full training iteration of the reference loop (train.py:208-229): H2D of the
+batch, forward, loss, backward, [gradient all-reduce over RCCL], clip + Adam — on the
+BASELINE.json configs[1] workload: batch 6 per GPU, fixed shape T_in=84 symbols / T_out=400
+frames (SURVEY.md §8(d) cfg-2 "train-fixed"), fp32, dropout on, synthetic data, random-init
+weights from seed 1234.  Multi-GPU is weak scaling (6 utterances per rank).
+
+The single JSON line also carries:
+  roofline     — the dominant kernel (k_lstm_fwd: both decoder LSTM gate GEMVs, weights streamed
+                 every time step).  Algorithmic bytes per launch = fp32 weights of the two cells
+                 (4096×1536 + 4096×2560)×4 B = 67.1 MB; duration = events on the launch stream
+                 around a replay of exactly that kernel's T+1 launches.
+  cpu_baseline — the oracle (oracle/t2v_oracle.py, a port of the reference's algorithm with
+                 stock torch CPU ops) timed on this box's host cores on the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'tacotron2-vae_amd'))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+B_PER_GPU, T_IN, T_OUT = 6, 84, 400
+LSTM_WEIGHT_BYTES = (4096 * 1536 + 4096 * 2560) * 4
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_batch(B, T_in, T_out, seed, lens_in=None, lens_out=None):
+    """Collate-layout 7-tuple (reference data_utils.py:88-137) of synthetic data, CPU tensors."""
+    g = torch.Generator().manual_seed(seed)
+    lens_in = lens_in or [T_in] * B
+    lens_out = lens_out or [T_out] * B
+    text = torch.zeros(B, T_in, dtype=torch.long)
+    mel = torch.zeros(B, 80, T_out)
+    gate = torch.zeros(B, T_out)
+    for i in range(B):
+        text[i, :lens_in[i]] = torch.randint(2, 80, (lens_in[i],), generator=g)
+        text[i, lens_in[i] - 1] = 1
+        m = torch.randn(80, lens_out[i], generator=g) * 2.0 - 4.0
+        mel[i, :, :lens_out[i]] = m.clamp(min=-11.5129, max=2.5)
+        gate[i, lens_out[i] - 1:] = 1
+    emotions = torch.zeros(B, 4, dtype=torch.long)
+    emotions[torch.arange(B), torch.randint(0, 4, (B,), generator=g)] = 1
+    return (text, torch.tensor(lens_in), mel, gate, torch.tensor(lens_out), torch.zeros(B, 1, dtype=torch.long),
+            emotions)
+
+
+def cpu_baseline(steps=2, warmup=1):
+    """Oracle train step (fwd+loss+bwd+clip+Adam) on host cores, same workload, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import t2v_oracle as O
+    import hparams as HP
+    import model as M
+    hp = HP.create_hparams()
+    torch.manual_seed(hp.seed)
+    sd = {k: v.clone() for k, v in M.Tacotron2(hp).state_dict().items()}
+    names = [k for k, v in sd.items() if v.dtype == torch.float32 and 'running_' not in k]
+    for k in names:
+        sd[k].requires_grad_(True)
+    mstate = {k: (torch.zeros_like(sd[k]), torch.zeros_like(sd[k])) for k in names}
+    text, lin, mel, gate, lout, _, _ = synthetic_batch(B_PER_GPU, T_IN, T_OUT, 1234)
+    g = torch.Generator().manual_seed(7)
+    times = []
+    for it in range(warmup + steps):
+        t0 = time.perf_counter()
+        drop = {}
+        for i in range(3):
+            drop['enc%d' % i] = torch.rand(B_PER_GPU, 512, T_IN, generator=g) >= 0.5
+        for i in range(5):
+            drop['post%d' % i] = torch.rand(B_PER_GPU, 512 if i < 4 else 80, T_OUT, generator=g) >= 0.5
+        drop['prenet0'] = torch.rand(T_OUT + 1, B_PER_GPU, 256, generator=g) >= 0.5
+        drop['prenet1'] = torch.rand(T_OUT + 1, B_PER_GPU, 256, generator=g) >= 0.5
+        drop['lstm'] = [{k: torch.rand(B_PER_GPU, 1024, generator=g) >= 0.1 for k in ('att_h', 'att_c', 'dec_h', 'dec_c')}
+                        for _ in range(T_OUT)]
+        out = O.tacotron2_forward(sd, text, lin, mel, lout, True, None, 0.1, 0.1, drop, 0.5, 0.5)
+        loss = O.loss_forward(out, mel, gate, it, 'constant')[0]
+        grads = torch.autograd.grad(loss, [sd[k] for k in names], allow_unused=True)
+        live = [(k, gr) for k, gr in zip(names, grads) if gr is not None]
+        clipped, _ = O.clip_grad_norm([gr for _, gr in live], 1.0)
+        with torch.no_grad():
+            for (k, _), gr in zip(live, clipped):
+                p, m, v = O.adam_step(sd[k], gr, mstate[k][0], mstate[k][1], it + 1)
+                sd[k].copy_(p)
+                mstate[k] = (m, v)
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[warmup:])[len(times[warmup:]) // 2]
+    return {"value": round(B_PER_GPU * T_OUT / t, 2), "unit": "mel-frames/s", "cores": torch.get_num_threads(),
+            "kind": "port", "s_per_it": round(t, 3),
+            "sample": "%d timed train steps (after %d warm-up) of the same B=6,T_in=84,T_out=400 workload, "
+                      "oracle/t2v_oracle.py with stock torch CPU fp32 ops, dropout on" % (steps, warmup)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank)
+
+    import hparams as HP
+    import t2v_hip
+    import train as TR
+    t2v_hip.load_library()
+    hp = HP.create_hparams("batch_size=%d,anneal_function=constant%s" % (
+        B_PER_GPU, ",distributed_run=True" if world > 1 else ""))
+    torch.manual_seed(hp.seed)
+    torch.cuda.manual_seed(hp.seed)
+    engine = TR.TrainEngine(hp, world_size=world)
+    batch = synthetic_batch(B_PER_GPU, T_IN, T_OUT, 1234 + rank)
+    batch = tuple(t.pin_memory() for t in batch)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(args.warmup):
+        engine.step(batch, it)
+        it += 1
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = engine.step(batch, it)[0]
+        it += 1
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final_loss = float(loss.item())
+
+    ms_per_step = 1000.0 * elapsed / args.steps
+    frames = B_PER_GPU * T_OUT * world
+    value = frames / (elapsed / args.steps)
+
+    out = {
+        "metric": "mel-frames/s (train step, batch=6, 80-mel)", "value": round(value, 1), "unit": "mel-frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: Tacotron2-VAE fp32 train step (fwd+loss+bwd+clip+Adam), "
+                               "B=6/GPU fixed shape T_in=84 T_out=400, dropout on, random-init seed 1234",
+                   "global_batch": B_PER_GPU * world, "frames_per_step": frames,
+                   "parallelism": "dp%d" % world},
+        "final_loss": round(final_loss, 5),
+    }
+
+    if rank == 0:
+        # ---- roofline leg: replay only k_lstm_fwd's T+1 launches of the last forward, events on
+        # the launch stream (torch's current stream is the stream the library launches on).
+        reps = 3
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t2v_hip.replay_fwd_kernels(1)
+        torch.cuda.synchronize()
+        ev0.record()
+        n = 0
+        for _ in range(reps):
+            n += t2v_hip.replay_fwd_kernels(1)
+        ev1.record()
+        torch.cuda.synchronize()
+        us = 1000.0 * ev0.elapsed_time(ev1) / n
+        achieved = LSTM_WEIGHT_BYTES / (us * 1e-6) / 1e9
+        out["roofline"] = {"kernel": "k_lstm_fwd", "bound": "hbm", "achieved": round(achieved, 1),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                           "traffic": None, "avg_launch_us": round(us, 3),
+                           "algorithmic_bytes_per_launch": LSTM_WEIGHT_BYTES, "launches_timed": n}
+        e2e_bytes = 58.9e9   # compulsory bytes of one cfg-2 iteration
+        out["roofline"]["end_to_end_frac"] = round(e2e_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(steps=args.cpu_steps)
+            out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

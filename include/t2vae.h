@@ -78,6 +78,14 @@ int t2v_decoder_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
                           int B, int T_in, int T_out, float p_att, float p_dec,
                           uint64_t seed, void* stream);
 
+/* Measurement aid for bench.py: re-issues only the selected kernels of a finished forward pass on
+ * its saved arena (bit0 = k_lstm_fwd, the weight-streaming GEMV+cell kernel; bit1 = k_attn_fwd),
+ * so their average launch duration can be bracketed with events on `stream`.  Results are
+ * bit-identical to the first pass (the kernels are pure functions of the arena). */
+int t2v_decoder_replay_fwd_kernels(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
+                                   int B, int T_in, int T_out, float p_att, float p_dec,
+                                   uint64_t seed, int kernel_mask, void* stream);
+
 typedef struct t2v_dec_bwd_bufs {
     const float* dHC;  /* (T,B,1536) grad wrt [h_dec_t | ctx_t] coming from the projection */
     float* DGA;   /* (T,B,4096) out: grad wrt attention_rnn pre-activations (== grad of gpre) */
@@ -99,6 +107,17 @@ typedef struct t2v_dec_bwd_bufs {
 int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
                           const t2v_dec_bwd_bufs* g, int B, int T_in, int T_out,
                           float p_att, float p_dec, uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------ optimiser
+ * clip_grad_norm_(params, max_norm) + Adam.step() of the reference loop (train.py:226-229,
+ * Adam built at train.py:171-172) fused over one flat fp32 arena.  `grads` holds the SUM over
+ * ranks after the all-reduce; inv_world = 1/world_size applies the averaging of
+ * distributed.py:162.  partials: (1024) scratch; norm_out[0] receives the pre-clip global
+ * L2 norm (the value the reference logs as grad.norm).  All four arenas 16-byte aligned. */
+int t2v_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, uint64_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay,
+                       float max_norm, float inv_world, int step, float* partials,
+                       float* norm_out, void* stream);
 
 #ifdef __cplusplus
 }

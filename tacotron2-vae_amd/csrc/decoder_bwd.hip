@@ -14,7 +14,8 @@
     ACC = mfma16x4((WV).z, (XV).z, ACC);    \
     ACC = mfma16x4((WV).w, (XV).w, ACC)
 
-__global__ __launch_bounds__(256) void k_lstm_bwd(LstmBwdArgs a) {
+#define LSTM_WAVES 16
+__global__ __launch_bounds__(1024) void k_lstm_bwd(LstmBwdArgs a) {
     const int w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = lane & 15, g = lane >> 4;
     const bool dec = w < T2V_XW / 16;
@@ -22,36 +23,46 @@ __global__ __launch_bounds__(256) void k_lstm_bwd(LstmBwdArgs a) {
     const float* kv = dec ? a.dgd_t : a.dga_n;
     if (!kv) return;   // block-uniform
     const bool bvalid = b < a.B;
-    __shared__ f32x4 red[4][64];
-    const float4* p = (dec ? a.packBD : a.packBA) + (size_t)wt * 256 * 64 + lane;
+    __shared__ f32x4 red[LSTM_WAVES][64];
+    const int ntile = dec ? T2V_XW / 16 : T2V_KATT / 16;
+    const float4* p = (dec ? a.packBD : a.packBA) + (size_t)wt * 64 + lane;   // + kb * ntile * 64
     const float* xrow = kv + (size_t)(bvalid ? b : 0) * T2V_G + 4 * g;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int kb0 = 64 * wave;
-#pragma unroll 8
-    for (int i = 0; i < 64; ++i) {
-        const int kb = kb0 + i;
-        const float4 x = bvalid ? *(const float4*)(xrow + 16 * kb) : z4;
-        const float4 wv = p[(size_t)kb * 64];
-        MFMA4(acc, wv, x);
+    const int kb0 = 16 * wave;     // 256 k-blocks / 16 waves
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float4 wv[8], xv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            wv[i] = p[(size_t)(kb0 + 8 * h + i) * ntile * 64];
+            xv[i] = *(const float4*)(xrow + 16 * (kb0 + 8 * h + i));   // lanes b>=B read row 0 (unused D columns)
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { MFMA4(acc, wv[i], xv[i]); }
     }
     red[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && bvalid) {
-        const f32x4 s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        f32x4 s = red[0][lane];
+#pragma unroll
+        for (int i = 1; i < LSTM_WAVES; ++i) s += red[i][lane];
         float* y = dec ? a.YD + (size_t)b * T2V_XW : a.YA + (size_t)b * T2V_KATT;
         *(float4*)(y + 16 * wt + 4 * g) = make_float4(s[0], s[1], s[2], s[3]);
     }
 }
 
-// LDS carve (floats): dctx[512] | alpha[TpR] | dal[TpR] | de[TpR] | dpre[Tp*128] | dcs[32*DS] | scr[512]
+// attention(t) backward.  grid = B, 512 threads, JP = ceil(T_in/4) register rows.
+// LDS carve (floats): dctx[512] | alpha[TpR] | dal[TpR] | de[TpR] | dpre[Tp*128] | dcs[32*DS] | wcl[32*63] | scr[1024]
+#define ATB_THREADS 512
+#define ATB_R (ATB_THREADS / 128)
 static __host__ __device__ inline int attn_bwd_ds(int Tp) { return (Tp + 30) | 1; }
 size_t t2v_attn_bwd_lds(int Tp) {
     const int TpR = (Tp + 3) & ~3;
-    return sizeof(float) * (T2V_E + 3 * TpR + (size_t)Tp * T2V_A + T2V_F * attn_bwd_ds(Tp) + 512);
+    return sizeof(float) * (T2V_E + 3 * TpR + (size_t)Tp * T2V_A + T2V_F * attn_bwd_ds(Tp) + T2V_F * 63 + 1024);
 }
 
-__global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
+template <int JP>
+__global__ __launch_bounds__(ATB_THREADS) void k_attn_bwd(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Tp = a.T_in, TpR = (Tp + 3) & ~3, DS = attn_bwd_ds(Tp);
@@ -61,86 +72,126 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
     float* de = dal + TpR;
     float* dpre = de + TpR;
     float* dcs = dpre + (size_t)Tp * T2V_A;
-    float* scr = dcs + T2V_F * DS;
+    float* wcl = dcs + T2V_F * DS;
+    float* scr = wcl + T2V_F * 63;
+    const int d = tid & (T2V_A - 1), j4 = tid >> 7;
 
+    // ---- entry: issue the global reads
+    float sreg[JP];
+    {
+        const float* sp = a.S_t + (size_t)b * Tp * T2V_A + d;
+#pragma unroll
+        for (int i = 0; i < JP; ++i) {
+            const int j = j4 + ATB_R * i;
+            sreg[i] = j < Tp ? sp[(size_t)j * T2V_A] : 0.f;
+        }
+    }
+    const float vd = a.v[d];
     // 1. total gradient of the context of step t
-    for (int e = tid; e < T2V_E; e += 256) {
+    for (int e = tid; e < T2V_E; e += ATB_THREADS) {
         const float v = a.dHC_t[(size_t)b * (T2V_H + T2V_E) + T2V_H + e] + a.YD[(size_t)b * T2V_XW + T2V_H + e] +
                         a.YA[(size_t)b * T2V_KATT + T2V_H + e];
         dctx[e] = v;
         a.DCTX_t[(size_t)b * T2V_E + e] = v;
     }
-    for (int j = tid; j < Tp; j += 256) alpha[j] = a.al_cur[(size_t)b * Tp + j];
-    for (int i = tid; i < T2V_F * DS; i += 256) dcs[i] = 0.f;
-    __syncthreads();
-
-    // 2. d alpha[j] = dctx . memory[j] + (grad via prev-channel of step t+1) + (grad via cumulative)
-    for (int j = wave; j < Tp; j += 4) {
-        const float* mrow = a.memory + ((size_t)b * Tp + j) * T2V_E;
-        float acc = 0.f;
+    for (int j = tid; j < Tp; j += ATB_THREADS) {
+        alpha[j] = a.al_cur[(size_t)b * Tp + j];
+        dal[j] = a.GPREV[(size_t)b * Tp + j] + a.GCUM[(size_t)b * Tp + j];
+    }
+    for (int i = tid; i < T2V_F * DS; i += ATB_THREADS) dcs[i] = 0.f;
+    if (tid < T2V_F * 62 / 4) {
+        const float4 w4 = ((const float4*)a.loc_conv)[tid];
+        const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-        for (int c = lane * 4; c < T2V_E; c += 256) {
-            const float4 m = *(const float4*)(mrow + c);
-            const float4 dd = *(const float4*)(dctx + c);
-            acc = fmaf(m.x, dd.x, acc);
-            acc = fmaf(m.y, dd.y, acc);
-            acc = fmaf(m.z, dd.z, acc);
-            acc = fmaf(m.w, dd.w, acc);
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) dal[j] = acc + a.GPREV[(size_t)b * Tp + j] + a.GCUM[(size_t)b * Tp + j];
+        for (int c = 0; c < 4; ++c) { const int i = 4 * tid + c; wcl[(i / 62) * 63 + (i % 62)] = wv[c]; }
     }
     __syncthreads();
 
-    // 3. softmax backward
+    // 2. d alpha[j] += dctx . memory[j]   (wave per row, 8 rows in flight per wave)
+    {
+        const float4 d0 = *(const float4*)(dctx + lane * 4), d1 = *(const float4*)(dctx + 256 + lane * 4);
+        constexpr int NW = ATB_THREADS / 64, NB = 8;
+        for (int base = wave; base < Tp; base += NW * NB) {
+            float4 m0[NB], m1[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                const int j = base + NW * r;
+                const float* mrow = a.memory + ((size_t)b * Tp + (j < Tp ? j : 0)) * T2V_E + lane * 4;
+                m0[r] = *(const float4*)mrow;
+                m1[r] = *(const float4*)(mrow + 256);
+            }
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                const int j = base + NW * r;
+                float acc = m0[r].x * d0.x;
+                acc = fmaf(m0[r].y, d0.y, acc); acc = fmaf(m0[r].z, d0.z, acc); acc = fmaf(m0[r].w, d0.w, acc);
+                acc = fmaf(m1[r].x, d1.x, acc); acc = fmaf(m1[r].y, d1.y, acc);
+                acc = fmaf(m1[r].z, d1.z, acc); acc = fmaf(m1[r].w, d1.w, acc);
+                acc = wave_sum(acc);
+                if (lane == 0 && j < Tp) dal[j] += acc;
+            }
+        }
+    }
+    __syncthreads();
+    // location_dense column f for phase 5 (loads overlap phases 3-4)
+    float dreg[T2V_A];
+    {
+        const int f = tid & 31;
+#pragma unroll
+        for (int dd = 0; dd < T2V_A; ++dd) dreg[dd] = a.loc_dense[dd * T2V_F + f];
+    }
+
+    // 3. softmax backward (every wave reduces redundantly)
     {
         float part = 0.f;
-        for (int j = tid; j < Tp; j += 256) part = fmaf(alpha[j], dal[j], part);
-        part = wave_sum(part);
-        if (lane == 0) scr[wave] = part;
-        __syncthreads();
-        const float dot = (scr[0] + scr[1]) + (scr[2] + scr[3]);
-        for (int j = tid; j < Tp; j += 256) de[j] = alpha[j] * (dal[j] - dot);
-        __syncthreads();
+        for (int j = lane; j < Tp; j += 64) part = fmaf(alpha[j], dal[j], part);
+        const float dot = wave_sum(part);
+        for (int j = tid; j < Tp; j += ATB_THREADS) de[j] = alpha[j] * (dal[j] - dot);
     }
+    __syncthreads();
 
     // 4. through v . tanh(.)
     {
-        const int d = tid & (T2V_A - 1), jh = tid >> 7;
-        const float vd = a.v[d];
         float* sp = a.S_t + (size_t)b * Tp * T2V_A + d;
         float dq = 0.f, dv = 0.f;
-        for (int j = jh; j < Tp; j += 2) {
-            const float s = sp[(size_t)j * T2V_A];
-            const float dej = de[j];
-            const float dp = dej * vd * (1.0f - s * s);
-            dpre[j * T2V_A + d] = dp;
-            sp[(size_t)j * T2V_A] = dp;
-            dq += dp;
-            dv = fmaf(dej, s, dv);
+#pragma unroll
+        for (int i = 0; i < JP; ++i) {
+            const int j = j4 + ATB_R * i;
+            if (j < Tp) {
+                const float s = sreg[i];
+                const float dej = de[j];
+                const float dp = dej * vd * (1.0f - s * s);
+                dpre[j * T2V_A + d] = dp;
+                sp[(size_t)j * T2V_A] = dp;
+                dq += dp;
+                dv = fmaf(dej, s, dv);
+            }
         }
         scr[tid] = dq;
-        scr[256 + tid] = dv;
+        scr[ATB_THREADS + tid] = dv;
         __syncthreads();
         if (tid < T2V_A) {
-            a.DQ_t[(size_t)b * T2V_A + tid] = scr[tid] + scr[tid + 128];
-            a.DV[(size_t)b * T2V_A + tid] += scr[256 + tid] + scr[256 + tid + 128];
+            float q = 0.f, v = 0.f;
+#pragma unroll
+            for (int i = 0; i < ATB_R; ++i) { q += scr[i * T2V_A + tid]; v += scr[ATB_THREADS + i * T2V_A + tid]; }
+            a.DQ_t[(size_t)b * T2V_A + tid] = q;
+            a.DV[(size_t)b * T2V_A + tid] += v;
         }
     }
 
     // 5. through location_dense: dc[f][j] = sum_d D[d][f] dpre[j][d]
     {
-        const int f = tid & 31, jg = tid >> 5;
-        float dreg[T2V_A];
-#pragma unroll
-        for (int d = 0; d < T2V_A; ++d) dreg[d] = a.loc_dense[d * T2V_F + f];
-        for (int j = jg; j < Tp; j += 8) {
-            const float* dp = dpre + j * T2V_A;
+        const int f = tid & 31;
+        for (int j = tid >> 5; j < Tp; j += ATB_THREADS / 32) {
+            const float4* dp = (const float4*)(dpre + j * T2V_A);
             float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
-            for (int d = 0; d < T2V_A; d += 2) {
-                acc0 = fmaf(dreg[d], dp[d], acc0);
-                acc1 = fmaf(dreg[d + 1], dp[d + 1], acc1);
+            for (int dd = 0; dd < T2V_A / 4; ++dd) {
+                const float4 x = dp[dd];
+                acc0 = fmaf(dreg[4 * dd], x.x, acc0);
+                acc1 = fmaf(dreg[4 * dd + 1], x.y, acc1);
+                acc0 = fmaf(dreg[4 * dd + 2], x.z, acc0);
+                acc1 = fmaf(dreg[4 * dd + 3], x.w, acc1);
             }
             const float acc = acc0 + acc1;
             dcs[f * DS + 15 + j] = acc;
@@ -151,19 +202,15 @@ __global__ __launch_bounds__(256) void k_attn_bwd(AttnBwdArgs a) {
 
     // 6. through location_conv (transposed): dcat[ch][j] = sum_{f,k} Wc[f][ch][k] dc[f][j+15-k]
     {
-        const int f = tid & 31, grp = tid >> 5;
-        float wc[2][T2V_KS];
-#pragma unroll
-        for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-            for (int k = 0; k < T2V_KS; ++k) wc[ch][k] = a.loc_conv[(f * 2 + ch) * T2V_KS + k];
+        const int f = tid & 31;
+        const float* wr = wcl + f * 63;
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            for (int j = grp; j < Tp; j += 8) {
+            for (int j = tid >> 5; j < Tp; j += ATB_THREADS / 32) {
                 const float* row = dcs + f * DS + j;   // dcs index (15 + j + 15 - k) = j + 30 - k
                 float acc = 0.f;
 #pragma unroll
-                for (int k = 0; k < T2V_KS; ++k) acc = fmaf(wc[ch][k], row[30 - k], acc);
+                for (int k = 0; k < T2V_KS; ++k) acc = fmaf(wr[ch * T2V_KS + k], row[30 - k], acc);
 #pragma unroll
                 for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
                 if (f == 0) {
@@ -186,7 +233,7 @@ __global__ __launch_bounds__(256) void k_cell_bwd(CellBwdArgs a) {
         const float* wq = a.wqT + (size_t)U * T2V_A;
         const float* dq = a.DQ_t + (size_t)b * T2V_A;
         float dot0 = 0.f, dot1 = 0.f;
-#pragma unroll 8
+#pragma unroll 16
         for (int d = 0; d < T2V_A; d += 4) {
             const float4 w4 = *(const float4*)(wq + d);
             const float4 q4 = *(const float4*)(dq + d);
@@ -200,7 +247,7 @@ __global__ __launch_bounds__(256) void k_cell_bwd(CellBwdArgs a) {
         const float fc = t2v_drop_scale(a.seed, T2V_RNG_ATT_C, t, idx, a.p_att);
         const float* ga = a.GA_t + (size_t)b * T2V_G + U;
         const float gi = ga[0], gf = ga[T2V_H], gg = ga[2 * T2V_H], go = ga[3 * T2V_H];
-        const float tc = tanhf(a.CA_cur[bu]);
+        const float tc = tanhf_(a.CA_cur[bu]);
         const float dht = dh * fh;
         const float dct = a.DCA[bu] * fc + dht * go * (1.0f - tc * tc);
         float cprev = a.CA_prev[bu];
@@ -219,7 +266,7 @@ __global__ __launch_bounds__(256) void k_cell_bwd(CellBwdArgs a) {
         const float fc = t2v_drop_scale(a.seed, T2V_RNG_DEC_C, td, idx, a.p_dec);
         const float* gd = a.GD_p + (size_t)b * T2V_G + U;
         const float gi = gd[0], gf = gd[T2V_H], gg = gd[2 * T2V_H], go = gd[3 * T2V_H];
-        const float tc = tanhf(a.CD_cur[bu]);
+        const float tc = tanhf_(a.CD_cur[bu]);
         const float dht = dh * fh;
         const float dct = a.DCD[bu] * fc + dht * go * (1.0f - tc * tc);
         float cprev = a.CD_prev[bu];
@@ -241,8 +288,13 @@ extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_tra
     if (!w->packB_att || !w->packB_dec) return T2V_ERR_ARG;
     const size_t lds = t2v_attn_bwd_lds(T_in);
     if (lds > 160 * 1024) return T2V_ERR_ARG;
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)k_attn_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (T_in > 256) return T2V_ERR_ARG;
+#define ATB_LAUNCH(JPV)                                                                                   \
+    do {                                                                                                  \
+        if (lds > 64 * 1024)                                                                              \
+            (void)hipFuncSetAttribute((const void*)k_attn_bwd<JPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        k_attn_bwd<JPV><<<B, ATB_THREADS, lds, stream>>>(f);                                              \
+    } while (0)
     (void)hipMemsetAsync(g->YD, 0, sizeof(float) * B * T2V_XW, stream);
     (void)hipMemsetAsync(g->YA, 0, sizeof(float) * B * T2V_KATT, stream);
     (void)hipMemsetAsync(g->DCA, 0, sizeof(float) * B * T2V_H, stream);
@@ -262,7 +314,7 @@ extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_tra
             l.YD = g->YD;
             l.YA = g->YA;
             l.B = B;
-            k_lstm_bwd<<<T2V_NWG, 256, 0, stream>>>(l);
+            k_lstm_bwd<<<T2V_NWG, 1024, 0, stream>>>(l);
 
             AttnBwdArgs f;
             f.dHC_t = g->dHC + (size_t)t * B * HC;
@@ -281,7 +333,9 @@ extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_tra
             f.GCUM = g->GCUM;
             f.DV = g->DV;
             f.T_in = T_in;
-            k_attn_bwd<<<B, 256, lds, stream>>>(f);
+            if (T_in <= 22 * ATB_R) ATB_LAUNCH(22);
+            else if (T_in <= 32 * ATB_R) ATB_LAUNCH(32);
+            else ATB_LAUNCH(64);
         }
         CellBwdArgs c;
         c.YD = g->YD;

@@ -17,23 +17,24 @@ __global__ void k_pack_fwd(const float* __restrict__ W, int K, float4* __restric
     const size_t total = (size_t)T2V_NWG * nkb * 64;
     if (idx >= total) return;
     const int lane = idx & 63;
-    const int kb = (idx >> 6) % nkb;
-    const int w = (idx >> 6) / nkb;
-    const int arow = lane & 15, g = lane >> 4;
+    const int kb = (idx >> 6) % nkb;         // tile-major: a workgroup streams one contiguous
+    const int w = (idx >> 6) / nkb;          // 96/112/160 KiB region (tile stride is NOT a power of
+    const int arow = lane & 15, g = lane >> 4;   // two, so L2/HBM channels are evenly loaded)
     const int row = (arow & 3) * T2V_H + 4 * w + (arow >> 2);
     const float* src = W + (size_t)row * K + 16 * kb + 4 * g;
     P[idx] = make_float4(src[0], src[1], src[2], src[3]);
 }
 // Backward (transposed) tile n-tile w' of W^T (N = K columns of W become rows), reduction dim
-// = 4096 gate rows:  PB[w'][kb][lane][i] = W[16kb + 4(lane>>4) + i][16w' + (lane&15)]
+// = 4096 gate rows:  PB[kb][w'][lane][i] = W[16kb + 4(lane>>4) + i][16w' + (lane&15)]
 __global__ void k_pack_bwd(const float* __restrict__ W, int K, int ncols, float4* __restrict__ P) {
     const int nkb = T2V_G / 16;   // 256
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)(ncols / 16) * nkb * 64;
     if (idx >= total) return;
     const int lane = idx & 63;
-    const int kb = (idx >> 6) % nkb;
-    const int wt = (idx >> 6) / nkb;
+    const int ntile = ncols / 16;
+    const int wt = (idx >> 6) % ntile;
+    const int kb = (idx >> 6) / ntile;
     const int n = 16 * wt + (lane & 15);
     const int k0 = 16 * kb + 4 * (lane >> 4);
     P[idx] = make_float4(W[(size_t)(k0 + 0) * K + n], W[(size_t)(k0 + 1) * K + n],
@@ -47,192 +48,208 @@ __global__ void k_pack_bwd(const float* __restrict__ W, int K, int ncols, float4
     ACC = mfma16x4((WV).z, (XV).z, ACC);    \
     ACC = mfma16x4((WV).w, (XV).w, ACC)
 
-__global__ __launch_bounds__(256) void k_lstm_fwd(LstmFwdArgs a) {
+// 16 waves per workgroup: the K dimension of both gate GEMVs is split 16 ways so that every
+// wave issues ALL of its weight/x loads (26 x 1 KiB) before the first MFMA — the kernel is a
+// pure weight stream (262 KB per CU per launch) and needs the bytes in flight, not occupancy.
+#define LSTM_WAVES 16
+__global__ __launch_bounds__(1024) void k_lstm_fwd(LstmFwdArgs a) {
     const int w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = lane & 15, g = lane >> 4;
     const bool bvalid = b < a.B;
-    __shared__ f32x4 red[2][4][64];
+    __shared__ f32x4 red[2][LSTM_WAVES][64];
     __shared__ float hs[16][4];
 
-    const int nkbA = a.k_att / 16;                       // 96 (train) or 112 (inference)
-    const float4* pa = a.packA + ((size_t)w * nkbA) * 64 + lane;
+        const float4* pa = a.packA + ((size_t)w * (a.k_att / 16)) * 64 + lane;
     const float4* pd = a.packD + ((size_t)w * (T2V_XW / 16)) * 64 + lane;
     const float* xrow = a.xs_prev + (size_t)(bvalid ? b : 0) * T2V_XW + 4 * g;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // ---- tail operands are fetched FIRST so the serial epilogue never waits on global memory:
+    // waves 0/1 own the cell update of attention_rnn(t) / decoder_rnn(t-1) for (unit g, item b)
+    const int which = wave;                               // meaningful for wave < 2 only
+    const bool cell_on = wave < 2 && bvalid && (which == 0 ? a.do_att : a.do_dec);
+    const int U = 4 * w + g;
+    float addv[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+    if (cell_on) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (which == 0) addv[r] = a.gpre_t ? a.gpre_t[(size_t)b * T2V_G + r * T2V_H + U] : a.bias_att[r * T2V_H + U];
+            else addv[r] = a.bias_dec[r * T2V_H + U];
+        }
+        cprev = (which == 0 ? a.ca_prev : a.cd_prev)[(size_t)b * T2V_H + U];
+    }
+    // query partial: thread (bb = tid>>7, d = tid&127) for bb < B
+    float wqr[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool q_on = a.do_att && (tid >> 7) < a.B;
+    if (q_on) {
+        const float* wq = a.wqT + (size_t)(4 * w) * T2V_A + (tid & (T2V_A - 1));
+        wqr[0] = wq[0]; wqr[1] = wq[T2V_A]; wqr[2] = wq[2 * T2V_A]; wqr[3] = wq[3 * T2V_A];
+    }
+
     f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accD = {0.f, 0.f, 0.f, 0.f};
-    // shared-x region: k-blocks [0,96) = [h_att | ctx]; this wave owns 24 of them
+    // shared-x region: k-blocks [0,96) = [h_att | ctx] (6 per wave); decoder_rnn recurrent part:
+    // k-blocks [96,160) = h_dec (4 per wave)
+    float4 xs[6], wa[6], wd[6], xr[4], wr[4];
     {
-        const int kb0 = 24 * wave;
-        if (a.do_att && a.do_dec) {
-#pragma unroll 6
-            for (int i = 0; i < 24; ++i) {
-                const int kb = kb0 + i;
-                const float4 x = bvalid ? *(const float4*)(xrow + 16 * kb) : z4;
-                const float4 wa = pa[(size_t)kb * 64];
-                const float4 wd = pd[(size_t)kb * 64];
-                MFMA4(accA, wa, x);
-                MFMA4(accD, wd, x);
-            }
-        } else if (a.do_att) {
-#pragma unroll 8
-            for (int i = 0; i < 24; ++i) {
-                const int kb = kb0 + i;
-                const float4 x = bvalid ? *(const float4*)(xrow + 16 * kb) : z4;
-                const float4 wa = pa[(size_t)kb * 64];
-                MFMA4(accA, wa, x);
-            }
-        } else {
-#pragma unroll 8
-            for (int i = 0; i < 24; ++i) {
-                const int kb = kb0 + i;
-                const float4 x = bvalid ? *(const float4*)(xrow + 16 * kb) : z4;
-                const float4 wd = pd[(size_t)kb * 64];
-                MFMA4(accD, wd, x);
-            }
+        const int kb0 = 6 * wave, kr0 = 96 + 4 * wave;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            xs[i] = *(const float4*)(xrow + 16 * (kb0 + i));   // lanes b>=B read row 0: their D columns are never used
+            wa[i] = pa[(size_t)(kb0 + i) * 64];   // unconditional: both cells are always computed,
+            wd[i] = pd[(size_t)(kb0 + i) * 64];   // do_att/do_dec only gate the cell update (t=0 / t=T)
         }
-    }
-    if (a.do_dec) {   // decoder_rnn recurrent part: k-blocks [96,160) = h_dec
-        const int kb0 = 96 + 16 * wave;
-#pragma unroll 8
-        for (int i = 0; i < 16; ++i) {
-            const int kb = kb0 + i;
-            const float4 x = bvalid ? *(const float4*)(xrow + 16 * kb) : z4;
-            const float4 wd = pd[(size_t)kb * 64];
-            MFMA4(accD, wd, x);
-        }
-    }
-    if (a.do_att && a.pre_t) {   // inference: prenet columns are part of K (k-blocks [96,112))
-        const float* prow = a.pre_t + (size_t)(bvalid ? b : 0) * T2V_PRE + 4 * g;
-        const int kb0 = 96 + 4 * wave;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int kb = kb0 + i;
-            const float4 x = bvalid ? *(const float4*)(prow + 16 * (kb - 96)) : z4;
-            const float4 wa = pa[(size_t)kb * 64];
-            MFMA4(accA, wa, x);
+            xr[i] = *(const float4*)(xrow + 16 * (kr0 + i));
+            wr[i] = pd[(size_t)(kr0 + i) * 64];
         }
     }
+    float4 xp = z4, wp = z4;
+    if (a.do_att && a.pre_t) {   // inference: prenet columns are part of K (k-blocks [96,112))
+        const float* prow = a.pre_t + (size_t)(bvalid ? b : 0) * T2V_PRE + 4 * g;
+        xp = *(const float4*)(prow + 16 * wave);
+        wp = pa[(size_t)(96 + wave) * 64];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { MFMA4(accA, wa[i], xs[i]); MFMA4(accD, wd[i], xs[i]); }
+    if (a.pre_t) { MFMA4(accA, wp, xp); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { MFMA4(accD, wr[i], xr[i]); }
     red[0][wave][lane] = accA;
     red[1][wave][lane] = accD;
     __syncthreads();
 
     // cell update: wave 0 -> attention_rnn(t), wave 1 -> decoder_rnn(t-1).
     // lane = (unit u = lane>>4, item b = lane&15); acc[r] = gate r (i,f,g,o) of unit 4w+u.
-    if (wave < 2) {
-        const int which = wave;
-        const bool on = which == 0 ? a.do_att : a.do_dec;
-        if (on && bvalid) {
-            const f32x4 s = red[which][0][lane] + red[which][1][lane] + red[which][2][lane] + red[which][3][lane];
-            const int U = 4 * w + g;
-            const int tt = which == 0 ? a.t : a.t - 1;            // time index of this cell
-            const float p = which == 0 ? a.p_att : a.p_dec;
-            const uint32_t st_h = which == 0 ? T2V_RNG_ATT_H : T2V_RNG_DEC_H;
-            const uint32_t st_c = which == 0 ? T2V_RNG_ATT_C : T2V_RNG_DEC_C;
-            float pre[4];
+    if (cell_on) {
+        f32x4 s = red[which][0][lane];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float add;
-                if (which == 0) add = a.gpre_t ? a.gpre_t[(size_t)b * T2V_G + r * T2V_H + U] : a.bias_att[r * T2V_H + U];
-                else add = a.bias_dec[r * T2V_H + U];
-                pre[r] = s[r] + add;
-            }
-            const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = tanhf(pre[2]), go = sigmoidf_(pre[3]);
-            const float* cprev_p = which == 0 ? a.ca_prev : a.cd_prev;
-            float* ccur_p = which == 0 ? a.ca_cur : a.cd_cur;
-            const uint32_t idx = (uint32_t)b * T2V_H + U;
-            float cprev = cprev_p[(size_t)b * T2V_H + U];
-            if (tt > 0) cprev *= t2v_drop_scale(a.seed, st_c, tt - 1, idx, p);
-            const float c = gf * cprev + gi * gg;
-            const float h = go * tanhf(c);
-            ccur_p[(size_t)b * T2V_H + U] = c;
-            float* gsave = which == 0 ? a.ga_t : a.gd_t;
-            if (gsave) {
-                gsave[(size_t)b * T2V_G + 0 * T2V_H + U] = gi;
-                gsave[(size_t)b * T2V_G + 1 * T2V_H + U] = gf;
-                gsave[(size_t)b * T2V_G + 2 * T2V_H + U] = gg;
-                gsave[(size_t)b * T2V_G + 3 * T2V_H + U] = go;
-            }
-            const float hd = h * t2v_drop_scale(a.seed, st_h, tt, idx, p);
-            a.xs_next[(size_t)b * T2V_XW + (which == 0 ? U : T2V_KATT + U)] = hd;
-            if (which == 0) hs[b][g] = hd;
+        for (int i = 1; i < LSTM_WAVES; ++i) s += red[which][i][lane];
+        const int tt = which == 0 ? a.t : a.t - 1;            // time index of this cell
+        const float p = which == 0 ? a.p_att : a.p_dec;
+        const uint32_t st_h = which == 0 ? T2V_RNG_ATT_H : T2V_RNG_DEC_H;
+        const uint32_t st_c = which == 0 ? T2V_RNG_ATT_C : T2V_RNG_DEC_C;
+        const float gi = sigmoidf_(s[0] + addv[0]), gf = sigmoidf_(s[1] + addv[1]);
+        const float gg = tanhf_(s[2] + addv[2]), go = sigmoidf_(s[3] + addv[3]);
+        float* ccur_p = which == 0 ? a.ca_cur : a.cd_cur;
+        const uint32_t idx = (uint32_t)b * T2V_H + U;
+        if (tt > 0) cprev *= t2v_drop_scale(a.seed, st_c, tt - 1, idx, p);
+        const float c = gf * cprev + gi * gg;
+        const float h = go * tanhf_(c);
+        ccur_p[(size_t)b * T2V_H + U] = c;
+        float* gsave = which == 0 ? a.ga_t : a.gd_t;
+        if (gsave) {
+            gsave[(size_t)b * T2V_G + 0 * T2V_H + U] = gi;
+            gsave[(size_t)b * T2V_G + 1 * T2V_H + U] = gf;
+            gsave[(size_t)b * T2V_G + 2 * T2V_H + U] = gg;
+            gsave[(size_t)b * T2V_G + 3 * T2V_H + U] = go;
         }
+        const float hd = h * t2v_drop_scale(a.seed, st_h, tt, idx, p);
+        a.xs_next[(size_t)b * T2V_XW + (which == 0 ? U : T2V_KATT + U)] = hd;
+        if (which == 0) hs[b][g] = hd;
     }
     __syncthreads();
-    if (a.do_att) {   // partial processed query of this workgroup's 4 hidden units
-        for (int idx = tid; idx < a.B * T2V_A; idx += 256) {
-            const int bb = idx >> 7, d = idx & (T2V_A - 1);
-            const float* wq = a.wqT + (size_t)(4 * w) * T2V_A + d;
-            const float q = wq[0] * hs[bb][0] + wq[T2V_A] * hs[bb][1] + wq[2 * T2V_A] * hs[bb][2] + wq[3 * T2V_A] * hs[bb][3];
-            a.qp[((size_t)bb * T2V_NWG + w) * T2V_A + d] = q;
-        }
+    if (q_on) {   // partial processed query of this workgroup's 4 hidden units
+        const int bb = tid >> 7, d = tid & (T2V_A - 1);
+        const float q = wqr[0] * hs[bb][0] + wqr[1] * hs[bb][1] + wqr[2] * hs[bb][2] + wqr[3] * hs[bb][3];
+        a.qp[((size_t)bb * T2V_NWG + w) * T2V_A + d] = q;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// Attention step.  grid = (B, SE): every workgroup of an item recomputes the (cheap) energies
-// and softmax; workgroup `se` produces context columns [se*512/SE, (se+1)*512/SE).
-// LDS carve (floats): q[128] | ap[2][Tp+30] | cs[32][Tp] | e[Tp] | scr[512]
-__global__ __launch_bounds__(256) void k_attn_fwd(AttnFwdArgs a) {
+// Attention step.  grid = (B, SE), 1024 threads: every workgroup of an item recomputes the
+// energies and softmax; workgroup `se` produces context columns [se*512/SE, (se+1)*512/SE).
+// All global reads (256 query partials, pm, memory slice, weights) are issued at kernel entry
+// so their latencies overlap; the phases then run out of registers / LDS.
+// JP = ceil(T_in/ATT_R) upper bound (per-thread register rows).
+// LDS carve (floats): q[128] | ap[2][Tp+30] | cs[32][Tp] | e[TpR] | wcl[32*63] | scr[512+8*Tp]
+#define ATT_THREADS 512
+#define ATT_R (ATT_THREADS / 128)      // row phases: thread = (d = tid&127, j8 = tid>>7)
+template <int JP>
+__global__ __launch_bounds__(ATT_THREADS) void k_attn_fwd(AttnFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, se = blockIdx.y, SE = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Tp = a.T_in, TpH = Tp + 30;
+    const int Tp = a.T_in, TpH = Tp + 30, TpR = (Tp + 3) & ~3;
     float* q = smem;
     float* ap = q + T2V_A;
     float* cs = ap + 2 * TpH;
     float* e = cs + T2V_F * Tp;
-    float* scr = e + ((Tp + 3) & ~3);
+    float* wcl = e + TpR;
+    float* scr = wcl + T2V_F * 63;
     const int len = a.lengths ? a.lengths[b] : Tp;
+    const int d = tid & (T2V_A - 1), j8 = tid >> 7;     // (column, row-phase) mapping used by 1/3/5
 
+    // ---- issue every global read up front
+    constexpr int NQ = T2V_NWG / ATT_R;
+    float qpart[NQ];
+    {
+        const float* p = a.qp + ((size_t)b * T2V_NWG + NQ * j8) * T2V_A + d;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) qpart[i] = p[(size_t)i * T2V_A];
+    }
+    float pmr[JP];
+    const int ES = T2V_E / SE;                         // context columns of this workgroup (128)
+    {
+        const float* pmb = a.pm + (size_t)b * Tp * T2V_A + d;
+#pragma unroll
+        for (int i = 0; i < JP; ++i) {
+            const int j = j8 + ATT_R * i;
+            pmr[i] = j < Tp ? pmb[(size_t)j * T2V_A] : 0.f;
+        }
+    }
+    const float vd = a.v[d];
+    {   // location_conv weights (1984 floats = 496 float4) -> padded LDS rows; prev/cum weights
+        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < T2V_F * 62 / 4) w4 = ((const float4*)a.loc_conv)[tid];
+        float av[2] = {0.f, 0.f};
+        if (tid < Tp) { av[0] = a.al_prev[(size_t)b * Tp + tid]; av[1] = a.acum_prev[(size_t)b * Tp + tid]; }
+        for (int i = tid; i < 2 * TpH; i += ATT_THREADS) ap[i] = 0.f;          // halos (and body) zero
+        if (tid < T2V_F * 62 / 4) {
+            const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const int i = 4 * tid + c; wcl[(i / 62) * 63 + (i % 62)] = wv[c]; }
+        }
+        __syncthreads();
+        if (tid < Tp) { ap[15 + tid] = av[0]; ap[TpH + 15 + tid] = av[1]; }
+    }
     // ---- 1. processed query = sum of the 256 per-workgroup partials (fixed order)
     {
-        const int d = tid & (T2V_A - 1), hh = tid >> 7;
-        const float* p = a.qp + ((size_t)b * T2V_NWG + 128 * hh) * T2V_A + d;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll 8
-        for (int i = 0; i < 128; i += 4) {
-            s0 += p[(size_t)(i + 0) * T2V_A];
-            s1 += p[(size_t)(i + 1) * T2V_A];
-            s2 += p[(size_t)(i + 2) * T2V_A];
-            s3 += p[(size_t)(i + 3) * T2V_A];
-        }
+#pragma unroll
+        for (int i = 0; i < NQ; i += 4) { s0 += qpart[i]; s1 += qpart[i + 1]; s2 += qpart[i + 2]; s3 += qpart[i + 3]; }
         scr[tid] = (s0 + s1) + (s2 + s3);
     }
-    // ---- previous / cumulative weights with a 15-wide zero halo
-    for (int i = tid; i < 2 * TpH; i += 256) {
-        const int ch = i / TpH, jj = i - ch * TpH - 15;
-        float v = 0.f;
-        if (jj >= 0 && jj < Tp) v = (ch == 0 ? a.al_prev : a.acum_prev)[(size_t)b * Tp + jj];
-        ap[i] = v;
-    }
+    float dw[T2V_F];
+#pragma unroll
+    for (int f = 0; f < T2V_F; ++f) dw[f] = a.loc_dense[d * T2V_F + f];
     __syncthreads();
-    if (tid < T2V_A) q[tid] = scr[tid] + scr[tid + 128];
+    if (tid < T2V_A) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < ATT_R; ++i) s += scr[i * T2V_A + tid];
+        q[tid] = s;
+    }
 
-    // ---- 2. location conv: cs[f][j] = sum_{ch,k} Wc[f][ch][k] * ap[ch][j+k]
+    // ---- 2. location conv: cs[f][j] = sum_{ch,k} Wc[f][ch][k] * ap[ch][j+k]; thread = (f, 4 j's)
     {
         const int f = tid & 31;
-        float wc[2][T2V_KS];
-#pragma unroll
-        for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-            for (int k = 0; k < T2V_KS; ++k) wc[ch][k] = a.loc_conv[(f * 2 + ch) * T2V_KS + k];
-        const int njb = (Tp + 3) >> 2;
-        for (int jb = tid >> 5; jb < njb; jb += 8) {
-            const int j0 = 4 * jb;
+        for (int j0 = 4 * (tid >> 5); j0 < Tp; j0 += 4 * (ATT_THREADS / 32)) {
             float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
                 const float* apc = ap + ch * TpH + j0;
+                const float* wr = wcl + f * 63 + ch * T2V_KS;
                 float win[T2V_KS + 3];
 #pragma unroll
                 for (int k = 0; k < T2V_KS + 3; ++k) win[k] = (j0 + k < TpH) ? apc[k] : 0.f;
 #pragma unroll
                 for (int k = 0; k < T2V_KS; ++k) {
-                    o0 = fmaf(wc[ch][k], win[k], o0);
-                    o1 = fmaf(wc[ch][k], win[k + 1], o1);
-                    o2 = fmaf(wc[ch][k], win[k + 2], o2);
-                    o3 = fmaf(wc[ch][k], win[k + 3], o3);
+                    const float wk = wr[k];
+                    o0 = fmaf(wk, win[k], o0);
+                    o1 = fmaf(wk, win[k + 1], o1);
+                    o2 = fmaf(wk, win[k + 2], o2);
+                    o3 = fmaf(wk, win[k + 3], o3);
                 }
             }
             if (j0 + 0 < Tp) cs[f * Tp + j0 + 0] = o0;
@@ -241,83 +258,82 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnFwdArgs a) {
             if (j0 + 3 < Tp) cs[f * Tp + j0 + 3] = o3;
         }
     }
+    float memr[JP];
+    {
+        const float* mb = a.memory + (size_t)b * Tp * T2V_E + se * ES + d;
+#pragma unroll
+        for (int i = 0; i < JP; ++i) {
+            const int j = j8 + ATT_R * i;
+            memr[i] = j < len ? mb[(size_t)j * T2V_E] : 0.f;
+        }
+    }
     __syncthreads();
     if (se == 0 && a.conv_save) {
         float* dst = a.conv_save + (size_t)b * T2V_F * Tp;
-        for (int i = tid; i < T2V_F * Tp; i += 256) dst[i] = cs[i];
+        for (int i = tid; i < T2V_F * Tp; i += ATT_THREADS) dst[i] = cs[i];
     }
 
     // ---- 3. energies e[j] = sum_d v[d] * tanh(q[d] + pm[j][d] + sum_f D[d][f] cs[f][j])
     {
-        const int d = tid & (T2V_A - 1), jh = tid >> 7;
-        float dw[T2V_F];
-#pragma unroll
-        for (int f = 0; f < T2V_F; ++f) dw[f] = a.loc_dense[d * T2V_F + f];
-        const float qd = q[d], vd = a.v[d];
-        const float* pmb = a.pm + (size_t)b * Tp * T2V_A + d;
+        const float qd = q[d];
         float* ssave = (se == 0 && a.s_save) ? a.s_save + (size_t)b * Tp * T2V_A + d : nullptr;
-        for (int j = jh; j < Tp; j += 2) {
-            float acc = 0.f;
 #pragma unroll
-            for (int f = 0; f < T2V_F; ++f) acc = fmaf(dw[f], cs[f * Tp + j], acc);
-            const float s = tanhf(qd + acc + pmb[(size_t)j * T2V_A]);
-            if (ssave) ssave[(size_t)j * T2V_A] = s;
-            const float part = wave_sum(vd * s);   // 64 of the 128 d's
-            if (lane == 0) scr[256 + 2 * j + (wave & 1)] = part;
+        for (int i = 0; i < JP; ++i) {
+            const int j = j8 + ATT_R * i;
+            if (j < Tp) {            // wave-uniform (j8 is per pair of waves)
+                float acc = 0.f;
+#pragma unroll
+                for (int f = 0; f < T2V_F; ++f) acc = fmaf(dw[f], cs[f * Tp + j], acc);
+                const float s = tanhf_(qd + acc + pmr[i]);
+                if (ssave) ssave[(size_t)j * T2V_A] = s;
+                const float part = row16_sum(vd * s);   // 16 of the 128 d's (DPP, no LDS)
+                if ((lane & 15) == 0) scr[ATT_THREADS + 8 * j + 4 * (wave & 1) + (lane >> 4)] = part;
+            }
         }
     }
     __syncthreads();
-    for (int j = tid; j < Tp; j += 256) {
-        const float ev = scr[256 + 2 * j] + scr[256 + 2 * j + 1];
+    for (int j = tid; j < Tp; j += ATT_THREADS) {
+        const float* pp = scr + ATT_THREADS + 8 * j;
+        const float ev = ((pp[0] + pp[1]) + (pp[2] + pp[3])) + ((pp[4] + pp[5]) + (pp[6] + pp[7]));
         e[j] = j < len ? ev : -INFINITY;
     }
     __syncthreads();
 
-    // ---- 4. softmax over j (max-subtracted, masked -> exactly 0)
-    float m = -INFINITY;
-    for (int j = tid; j < Tp; j += 256) m = fmaxf(m, e[j]);
-    m = wave_max(m);
-    if (lane == 0) scr[wave] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(scr[0], scr[1]), fmaxf(scr[2], scr[3]));
-    __syncthreads();
-    float sum = 0.f;
-    for (int j = tid; j < Tp; j += 256) {
-        const float ex = expf(e[j] - m);
-        e[j] = ex;
-        sum += ex;
-    }
-    sum = wave_sum(sum);
-    if (lane == 0) scr[4 + wave] = sum;
-    __syncthreads();
-    sum = (scr[4] + scr[5]) + (scr[6] + scr[7]);
-    const float inv = 1.0f / sum;
-    __syncthreads();
-    for (int j = tid; j < Tp; j += 256) {
-        const float al = e[j] * inv;
-        e[j] = al;
-        if (se == 0) {
-            a.al_cur[(size_t)b * Tp + j] = al;
-            a.acum_cur[(size_t)b * Tp + j] = ap[TpH + 15 + j] + al;
+    // ---- 4. softmax over j (max-subtracted, masked -> exactly 0); every wave reduces redundantly
+    {
+        float m = -INFINITY;
+        for (int j = lane; j < Tp; j += 64) m = fmaxf(m, e[j]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int j = lane; j < Tp; j += 64) sum += expf(e[j] - m);
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        __syncthreads();
+        for (int j = tid; j < Tp; j += ATT_THREADS) {
+            const float al = expf(e[j] - m) * inv;
+            e[j] = al;
+            if (se == 0) {
+                a.al_cur[(size_t)b * Tp + j] = al;
+                a.acum_cur[(size_t)b * Tp + j] = ap[TpH + 15 + j] + al;
+            }
         }
     }
     __syncthreads();
 
-    // ---- 5. context slice: ctx[c] = sum_j alpha[j] * memory[b][j][c]
+    // ---- 5. context slice: ctx[c] = sum_j alpha[j] * memory[b][j][c]   (thread = (c=d, j8))
     {
-        const int ES = T2V_E / SE;              // columns per workgroup
-        const int parts = 256 / ES;             // j-partitions (>=1)
-        const int c = tid % ES, part = tid / ES;
         float acc = 0.f;
-        if (part < parts) {
-            const float* mb = a.memory + (size_t)b * Tp * T2V_E + se * ES + c;
-            for (int j = part; j < len; j += parts) acc = fmaf(e[j], mb[(size_t)j * T2V_E], acc);
+#pragma unroll
+        for (int i = 0; i < JP; ++i) {
+            const int j = j8 + ATT_R * i;
+            if (j < len) acc = fmaf(e[j], memr[i], acc);
         }
         scr[tid] = acc;
         __syncthreads();
         if (tid < ES) {
             float tot = 0.f;
-            for (int pp = 0; pp < parts; ++pp) tot += scr[pp * ES + tid];
+#pragma unroll
+            for (int pp = 0; pp < ATT_R; ++pp) tot += scr[pp * T2V_A + tid];
             a.xs_next[(size_t)b * T2V_XW + T2V_H + se * ES + tid] = tot;
         }
     }
@@ -349,20 +365,25 @@ extern "C" int t2v_pack_lstm_weights(const float* wcat_att, int k_att, const flo
     return t2v_check_launch();
 }
 
+#define ATT_THREADS_HOST 512
 size_t t2v_attn_fwd_lds(int T_in) {
     const int TpH = T_in + 30;
-    return sizeof(float) * (T2V_A + 2 * TpH + T2V_F * T_in + ((T_in + 3) & ~3) + 256 + 2 * T_in + 8);
+    return sizeof(float) * (T2V_A + 2 * TpH + T2V_F * T_in + ((T_in + 3) & ~3) + T2V_F * 63 + ATT_THREADS + 8 * T_in + 8);
 }
 
-extern "C" int t2v_decoder_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
-                                     int B, int T_in, int T_out, float p_att, float p_dec,
-                                     uint64_t seed, void* stream_) {
+static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s, int B, int T_in, int T_out,
+                            float p_att, float p_dec, uint64_t seed, void* stream_, int mask) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!w || !s || B < 1 || B > 16 || T_in < 1 || T_out < 1) return T2V_ERR_ARG;
     const size_t lds = t2v_attn_fwd_lds(T_in);
     if (lds > 160 * 1024) return T2V_ERR_ARG;
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)k_attn_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (T_in > 256) return T2V_ERR_ARG;   // register rows of k_attn_fwd are instantiated up to 4*64
+#define ATF_LAUNCH(JPV)                                                                                   \
+    do {                                                                                                  \
+        if (lds > 64 * 1024)                                                                              \
+            (void)hipFuncSetAttribute((const void*)k_attn_fwd<JPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        k_attn_fwd<JPV><<<dim3(B, SE), ATT_THREADS, lds, stream>>>(f);                                    \
+    } while (0)
     const int SE = 4;
     for (int t = 0; t <= T_out; ++t) {
         LstmFwdArgs a;
@@ -390,8 +411,8 @@ extern "C" int t2v_decoder_train_fwd(const t2v_dec_weights* w, const t2v_dec_tra
         a.p_att = p_att;
         a.p_dec = p_dec;
         a.seed = seed;
-        k_lstm_fwd<<<T2V_NWG, 256, 0, stream>>>(a);
-        if (t < T_out) {
+        if (mask & 1) k_lstm_fwd<<<T2V_NWG, 1024, 0, stream>>>(a);
+        if (t < T_out && (mask & 2)) {
             AttnFwdArgs f;
             f.qp = s->QP;
             f.al_prev = s->AL + (size_t)t * B * T_in;
@@ -408,8 +429,22 @@ extern "C" int t2v_decoder_train_fwd(const t2v_dec_weights* w, const t2v_dec_tra
             f.s_save = s->S ? s->S + (size_t)t * B * T_in * T2V_A : nullptr;
             f.conv_save = s->CONV ? s->CONV + (size_t)t * B * T2V_F * T_in : nullptr;
             f.T_in = T_in;
-            k_attn_fwd<<<dim3(B, SE), 256, lds, stream>>>(f);
+            if (T_in <= 22 * ATT_R) ATF_LAUNCH(22);
+            else if (T_in <= 32 * ATT_R) ATF_LAUNCH(32);
+            else ATF_LAUNCH(64);
         }
     }
     return t2v_check_launch();
+}
+
+extern "C" int t2v_decoder_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
+                                     int B, int T_in, int T_out, float p_att, float p_dec,
+                                     uint64_t seed, void* stream_) {
+    return launch_train_fwd(w, s, B, T_in, T_out, p_att, p_dec, seed, stream_, 3);
+}
+
+extern "C" int t2v_decoder_replay_fwd_kernels(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
+                                              int B, int T_in, int T_out, float p_att, float p_dec,
+                                              uint64_t seed, int kernel_mask, void* stream_) {
+    return launch_train_fwd(w, s, B, T_in, T_out, p_att, p_dec, seed, stream_, kernel_mask & 3);
 }

@@ -1,0 +1,102 @@
+// Fused multi-tensor optimiser step over ONE flat fp32 arena (params / grads / exp_avg /
+// exp_avg_sq laid out back to back in reference parameter order).
+// Replaces torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step of the reference train loop
+// (train.py:226-229; Adam(lr, weight_decay) at train.py:171-172 — L2-in-grad weight decay).
+// HBM-bound: 16 B read + 12 B written per element, two launches regardless of tensor count.
+#include "t2v_common.h"
+#include "t2v_kernels.h"
+
+#define T2V_NORM_BLOCKS 1024
+
+__global__ __launch_bounds__(256) void k_sumsq(const float4* __restrict__ g, size_t n4, const float* __restrict__ tail,
+                                               int ntail, float inv_world, float* __restrict__ partials) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 v = g[i];
+        v.x *= inv_world; v.y *= inv_world; v.z *= inv_world; v.w *= inv_world;
+        acc = fmaf(v.x, v.x, acc);
+        acc = fmaf(v.y, v.y, acc);
+        acc = fmaf(v.z, v.z, acc);
+        acc = fmaf(v.w, v.w, acc);
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) { const float t = tail[threadIdx.x] * inv_world; acc = fmaf(t, t, acc); }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+struct AdamArgs {
+    float* p; float* g; float* m; float* v;
+    size_t n;
+    const float* partials;
+    float* norm_out;          // [0] = total grad norm (after the 1/world scaling)
+    float lr, b1, b2, eps, wd, max_norm, inv_world, bc1, bc2s;   // bc1 = 1-b1^t, bc2s = sqrt(1-b2^t)
+};
+
+__global__ __launch_bounds__(256) void k_clip_adam(AdamArgs a) {
+    __shared__ float red[4];
+    __shared__ float s_coef;
+    // every block re-reduces the 1024 partials in the same order -> identical clip coefficient
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < T2V_NORM_BLOCKS; i += 256) acc += a.partials[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float total = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+        float coef = a.max_norm / (total + 1e-6f);
+        coef = coef < 1.0f ? coef : 1.0f;
+        if (a.max_norm <= 0.f) coef = 1.0f;
+        s_coef = coef * a.inv_world;
+        if (blockIdx.x == 0) a.norm_out[0] = total;
+    }
+    __syncthreads();
+    const float gs = s_coef;
+    const float step_size = a.lr / a.bc1;
+    const size_t n4 = a.n >> 2;
+    float4* p4 = (float4*)a.p; const float4* g4 = (const float4*)a.g; float4* m4 = (float4*)a.m; float4* v4 = (float4*)a.v;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 p = p4[i], g = g4[i], m = m4[i], v = v4[i];
+#define UPD(c)                                                        \
+        {                                                             \
+            const float gg = fmaf(a.wd, p.c, g.c * gs);              \
+            m.c = a.b1 * m.c + (1.0f - a.b1) * gg;                    \
+            v.c = a.b2 * v.c + (1.0f - a.b2) * gg * gg;               \
+            p.c -= step_size * (m.c / (sqrtf(v.c) / a.bc2s + a.eps)); \
+        }
+        UPD(x) UPD(y) UPD(z) UPD(w)
+#undef UPD
+        p4[i] = p; m4[i] = m; v4[i] = v;
+    }
+    if (blockIdx.x == 0) {
+        for (size_t i = (n4 << 2) + threadIdx.x; i < a.n; i += 256) {
+            const float gg = fmaf(a.wd, a.p[i], a.g[i] * gs);
+            const float m = a.b1 * a.m[i] + (1.0f - a.b1) * gg;
+            const float v = a.b2 * a.v[i] + (1.0f - a.b2) * gg * gg;
+            a.m[i] = m; a.v[i] = v;
+            a.p[i] -= step_size * (m / (sqrtf(v) / a.bc2s + a.eps));
+        }
+    }
+}
+
+extern "C" int t2v_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, uint64_t n,
+                                  float lr, float beta1, float beta2, float eps, float weight_decay,
+                                  float max_norm, float inv_world, int step, float* partials,
+                                  float* norm_out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !partials || !norm_out || step < 1) return T2V_ERR_ARG;
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return T2V_ERR_ARG;
+    const size_t n4 = n >> 2;
+    k_sumsq<<<T2V_NORM_BLOCKS, 256, 0, stream>>>((const float4*)grads, n4, grads + (n4 << 2), (int)(n & 3), inv_world, partials);
+    AdamArgs a;
+    a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
+    a.partials = partials; a.norm_out = norm_out;
+    a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay; a.max_norm = max_norm;
+    a.inv_world = inv_world;
+    a.bc1 = 1.0f - powf(beta1, (float)step);
+    a.bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    k_clip_adam<<<2048, 256, 0, stream>>>(a);
+    return t2v_check_launch();
+}

@@ -26,7 +26,23 @@ __device__ __forceinline__ f32x4 mfma16x4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// exp via v_exp_f32 (2^x, ~1 ulp) and v_rcp_f32: absolute error of sigmoid/tanh ~1e-7, which is
+// what the fp32 parity budget (mel-L1 < 1e-4 through 400 recurrent steps) needs; far cheaper
+// than the libm tanhf/expf call sequences.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return fast_rcp(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * fast_rcp(1.0f + __expf(2.0f * x)); }
+
+// 16-lane row sum with DPP (no LDS crossbar): every lane of a row ends with the row's sum.
+#define T2V_DPP_ADD(v, CTRL) \
+    ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (CTRL), 0xF, 0xF, true)))
+__device__ __forceinline__ float row16_sum(float v) {
+    v = T2V_DPP_ADD(v, 0xB1);    // quad_perm [1,0,3,2]
+    v = T2V_DPP_ADD(v, 0x4E);    // quad_perm [2,3,0,1]
+    v = T2V_DPP_ADD(v, 0x141);   // row_half_mirror
+    v = T2V_DPP_ADD(v, 0x140);   // row_mirror
+    return v;
+}
 
 // Counter-based RNG (splitmix64 finaliser) for dropout keep-masks: a pure function of
 // (seed, stream, t, idx) so the backward pass regenerates the forward's masks.
@@ -46,8 +62,9 @@ __device__ __forceinline__ float t2v_drop_scale(uint64_t seed, uint32_t stream, 
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = row16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {

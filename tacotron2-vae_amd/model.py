@@ -96,14 +96,12 @@ class Encoder(nn.Module):
     def forward(self, x, input_lengths):
         x = self._convs(x)
         packed = nn.utils.rnn.pack_padded_sequence(x, input_lengths.cpu(), batch_first=True)
-        self.lstm.flatten_parameters()
         outputs, _ = self.lstm(packed)
         outputs, _ = nn.utils.rnn.pad_packed_sequence(outputs, batch_first=True)
         return outputs
 
     def inference(self, x):
         x = self._convs(x)
-        self.lstm.flatten_parameters()
         outputs, _ = self.lstm(x)
         return outputs
 

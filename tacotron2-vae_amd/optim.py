@@ -1,0 +1,125 @@
+"""Flat-arena optimiser state for the MI355X training loop.
+
+All trainable tensors live in ONE fp32 arena (parameter order), with matching arenas for
+gradients, exp_avg and exp_avg_sq: the gradient all-reduce is a zero-copy collective on the
+arena and clip-by-global-norm + Adam is two HIP launches (csrc/optim.hip) instead of ~400
+small kernels.  `state_dict()` / `load_state_dict()` speak torch.optim.Adam's format so the
+checkpoint dict of reference train.py:113-119 stays interchangeable.
+"""
+import ctypes as C
+import math
+
+import torch
+
+import t2v_hip
+
+# tensors the reference constructs but never uses in forward: they get no
+# gradient there, are skipped by Adam and by the all-reduce, and must not be touched here either.
+DEAD_PARAM_PREFIXES = ('speaker_embedding.', 'emotion_embedding.')
+DEAD_PARAM_NAMES = ('vae_gst.ref_encoder.convs.0.weight', 'vae_gst.ref_encoder.convs.0.bias')
+
+
+def is_dead_param(name):
+    return name.startswith(DEAD_PARAM_PREFIXES) or name in DEAD_PARAM_NAMES
+
+
+class FlatAdam(object):
+    """clip_grad_norm_ + Adam over a flat arena.  Mirrors the bits of torch.optim.Adam the
+    reference loop touches: `.param_groups[i]['lr']`, `.step()`, `.state_dict()`,
+    `.load_state_dict()`; plus `.zero_grad()` (the loop's `model.zero_grad()` also works) and
+    `.grad_norm` (device scalar written by the last step)."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_clip_thresh=1.0,
+                 world_size=1):
+        named = list(model.named_parameters())
+        self._all_names = [n for n, _ in named]
+        self._live = [(i, n, p) for i, (n, p) in enumerate(named) if not is_dead_param(n)]
+        if not self._live:
+            raise ValueError("no trainable parameters")
+        dev = self._live[0][2].device
+        if dev.type != 'cuda':
+            raise t2v_hip.T2VHipError("FlatAdam needs the model on a GPU (no CPU fallback)")
+        t2v_hip.load_library()
+        offs, total = [], 0
+        for _, _, p in self._live:
+            offs.append(total)
+            total += (p.numel() + 3) & ~3          # 16-byte aligned slots
+        self.numel = total
+        self._offsets = offs
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.params = torch.zeros(total, **f32)
+        self.grads = torch.zeros(total, **f32)
+        self.exp_avg = torch.zeros(total, **f32)
+        self.exp_avg_sq = torch.zeros(total, **f32)
+        self._partials = torch.zeros(1024, **f32)
+        self.grad_norm = torch.zeros(1, **f32)
+        for (i, n, p), o in zip(self._live, offs):
+            view = self.params[o:o + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view                                   # parameter now lives in the arena
+            p.grad = self.grads[o:o + p.numel()].view_as(p)  # autograd accumulates in place
+        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay,
+                                  amsgrad=False, maximize=False)]
+        self.grad_clip_thresh = grad_clip_thresh
+        self.world_size = world_size
+        self.step_count = 0
+
+    # -- loop API
+    def zero_grad(self, set_to_none=False):
+        self.grads.zero_()
+
+    def rebind_grads(self):
+        """Re-attach arena views if something (e.g. model.zero_grad(set_to_none=True)) dropped them."""
+        for (i, n, p), o in zip(self._live, self._offsets):
+            if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * o:
+                p.grad = self.grads[o:o + p.numel()].view_as(p)
+
+    def step(self):
+        g = self.param_groups[0]
+        self.step_count += 1
+        lib = t2v_hip.load_library()
+        rc = lib.t2v_clip_adam_step(
+            C.c_void_p(self.params.data_ptr()), C.c_void_p(self.grads.data_ptr()),
+            C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()),
+            C.c_uint64(self.numel), C.c_float(g['lr']), C.c_float(g['betas'][0]), C.c_float(g['betas'][1]),
+            C.c_float(g['eps']), C.c_float(g['weight_decay']),
+            C.c_float(self.grad_clip_thresh if self.grad_clip_thresh else 0.0),
+            C.c_float(1.0 / self.world_size), C.c_int(self.step_count),
+            C.c_void_p(self._partials.data_ptr()), C.c_void_p(self.grad_norm.data_ptr()),
+            C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise t2v_hip.T2VHipError("t2v_clip_adam_step rc=%d" % rc)
+        return self.grad_norm
+
+    # -- checkpoint interchange with torch.optim.Adam (reference train.py:100-119)
+    def state_dict(self):
+        state = {}
+        if self.step_count > 0:
+            for (i, n, p), o in zip(self._live, self._offsets):
+                k = p.numel()
+                state[i] = dict(step=torch.tensor(float(self.step_count)),
+                                exp_avg=self.exp_avg[o:o + k].view_as(p).clone(),
+                                exp_avg_sq=self.exp_avg_sq[o:o + k].view_as(p).clone())
+        group = dict(self.param_groups[0])
+        group.update(foreach=None, capturable=False, differentiable=False, fused=None,
+                     params=list(range(len(self._all_names))))
+        return dict(state=state, param_groups=[group])
+
+    def load_state_dict(self, sd):
+        grp = sd['param_groups'][0]
+        for k in ('lr', 'betas', 'eps', 'weight_decay'):
+            if k in grp:
+                self.param_groups[0][k] = tuple(grp[k]) if k == 'betas' else grp[k]
+        steps = set()
+        for (i, n, p), o in zip(self._live, self._offsets):
+            st = sd['state'].get(i, sd['state'].get(str(i)))
+            if st is None:
+                continue
+            k = p.numel()
+            self.exp_avg[o:o + k].view_as(p).copy_(st['exp_avg'])
+            self.exp_avg_sq[o:o + k].view_as(p).copy_(st['exp_avg_sq'])
+            steps.add(int(float(st['step'])))
+        if len(steps) > 1:
+            raise ValueError("per-parameter Adam step counts differ: %s" % sorted(steps))
+        self.step_count = steps.pop() if steps else 0
+

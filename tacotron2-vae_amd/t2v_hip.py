@@ -38,7 +38,7 @@ class _DecBwdBufs(C.Structure):
 
 
 EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decoder_train_fwd',
-           't2v_decoder_train_bwd')
+           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels')
 
 
 def lib_path():
@@ -63,6 +63,12 @@ def load_library():
     lib.t2v_decoder_train_bwd.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecTrainBufs),
                                           C.POINTER(_DecBwdBufs), C.c_int, C.c_int, C.c_int, C.c_float,
                                           C.c_float, C.c_uint64, C.c_void_p]
+    lib.t2v_decoder_replay_fwd_kernels.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecTrainBufs), C.c_int,
+                                                   C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_int,
+                                                   C.c_void_p]
+    lib.t2v_clip_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float,
+                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     for name in EXPORTS:
         getattr(lib, name)
     _lib = lib
@@ -95,6 +101,16 @@ def _f32c(t):
     return t.contiguous()
 
 
+def replay_fwd_kernels(kernel_mask):
+    """Re-issue the k_lstm_fwd (mask 1) / k_attn_fwd (mask 2) launches of the most recent
+    DecoderCore.forward on its saved arena (bench.py roofline leg)."""
+    W, Sb, (B, T_in, T, p_att, p_dec, seed), _keep = DecoderCore.last_call
+    _check(load_library().t2v_decoder_replay_fwd_kernels(C.byref(W), C.byref(Sb), B, T_in, T, p_att, p_dec,
+                                                         seed, int(kernel_mask), _stream()),
+           't2v_decoder_replay_fwd_kernels')
+    return T + 1 if kernel_mask == 1 else T
+
+
 class DecoderCore(torch.autograd.Function):
     """Teacher-forced decoder recurrence (reference Decoder.forward loop, model.py:415-421).
 
@@ -103,6 +119,7 @@ class DecoderCore(torch.autograd.Function):
              query weight (128,1024), location conv (32,2,31), location dense (128,32), v (1,128)
     outputs: HC (T,B,1536) = [h_dec_t | ctx_t],  alignments (B,T,T_in)
     """
+    last_call = None
 
     @staticmethod
     def forward(ctx, gpre, memory, pm, lengths, w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, bias_dec,
@@ -150,6 +167,7 @@ class DecoderCore(torch.autograd.Function):
         ctx.keep = (gpre, memory, pm, lengths, packF_att, packF_dec, packB_att, packB_dec, bias_dec, wqT,
                     loc_conv, loc_dense, vv, XS, CA, CD, GA, GD, QP, AL, ACUM, S, CONV)
         ctx.mark_non_differentiable(align)
+        DecoderCore.last_call = (W, Sb, ctx.dims, ctx.keep)
         return HC, align
 
     @staticmethod

@@ -1,0 +1,184 @@
+"""Training driver for the MI355X Tacotron2-VAE path.
+
+Same CLI flags, function names and checkpoint dict as the reference's train.py
+(`load_model` 80-89, `warm_start_model` 92-97, `load_checkpoint` 100-110, `save_checkpoint`
+113-119, `validate` 122-147, `train` 150-250, argparse 252-285); the loop body is re-hosted on
+the HIP kernels: flat-arena gradients, one RCCL all-reduce on the arena, fused clip+Adam.
+Launch multi-GPU runs as `python -m torch.distributed.run --nproc-per-node N train.py ...
+--hparams=distributed_run=True` (replaces multiproc.py); the reference's `--n_gpus/--rank`
+flags still work with hparams.dist_url.
+"""
+import argparse
+import math
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+import distributed as t2v_dist
+from hparams import create_hparams
+from loss_function import Tacotron2Loss_VAE
+from model import Tacotron2
+from optim import FlatAdam
+
+
+def load_model(hparams):
+    """reference train.py:80-89.  fp16_run (apex-style fp16) is replaced by the bf16 path and is
+    rejected here instead of silently running something else."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("load_model needs a GPU: the Tacotron2-VAE path here is HIP-only")
+    if hparams.fp16_run:
+        raise NotImplementedError("fp16_run is replaced by the bf16 configuration; use fp32 for now")
+    model = Tacotron2(hparams).cuda()
+    if hparams.distributed_run:
+        model = t2v_dist.apply_gradient_allreduce(model)
+    return model
+
+
+def warm_start_model(checkpoint_path, model):
+    assert os.path.isfile(checkpoint_path)
+    print("Warm starting model from checkpoint '{}'".format(checkpoint_path))
+    ckpt = torch.load(checkpoint_path, map_location='cpu')
+    model.load_state_dict(ckpt['state_dict'])
+    return model
+
+
+def load_checkpoint(checkpoint_path, model, optimizer):
+    assert os.path.isfile(checkpoint_path)
+    print("Loading checkpoint '{}'".format(checkpoint_path))
+    ckpt = torch.load(checkpoint_path, map_location='cpu')
+    model.load_state_dict(ckpt['state_dict'])
+    optimizer.load_state_dict(ckpt['optimizer'])
+    print("Loaded checkpoint '{}' from iteration {}".format(checkpoint_path, ckpt['iteration']))
+    return model, optimizer, ckpt['learning_rate'], ckpt['iteration']
+
+
+def save_checkpoint(model, optimizer, learning_rate, iteration, filepath):
+    """dict layout of reference train.py:116-119 (tensors cloned out of the arena)."""
+    print("Saving model and optimizer state at iteration {} to {}".format(iteration, filepath))
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    torch.save({'iteration': iteration, 'state_dict': state, 'optimizer': optimizer.state_dict(),
+                'learning_rate': learning_rate}, filepath)
+
+
+class TrainEngine(object):
+    """One rank's training state: model + criterion + flat-arena optimiser (+ arena all-reduce)."""
+
+    def __init__(self, hparams, world_size=1):
+        self.hparams = hparams
+        self.model = load_model(hparams)
+        self.criterion = Tacotron2Loss_VAE(hparams)
+        self.optimizer = FlatAdam(self.model, lr=hparams.learning_rate, weight_decay=hparams.weight_decay,
+                                  grad_clip_thresh=hparams.grad_clip_thresh, world_size=world_size)
+        self.allreduce = t2v_dist.ArenaAllReduce(self.optimizer.grads) if world_size > 1 else None
+        self.model.train()
+
+    def step(self, batch, iteration, learning_rate=None):
+        """Body of reference train.py:208-229.  Returns (loss, recon, kl, kl_weight, grad_norm) as
+        device tensors / floats without forcing a host sync."""
+        opt = self.optimizer
+        if learning_rate is not None:
+            opt.param_groups[0]['lr'] = learning_rate
+        opt.zero_grad()
+        x, y = self.model.parse_batch(batch)
+        y_pred = self.model(x)
+        loss, recon, kl, w = self.criterion(y_pred, y, iteration)
+        loss.backward()
+        if self.allreduce is not None:
+            self.allreduce()
+        grad_norm = opt.step()
+        return loss.detach(), recon.detach(), kl.detach(), w, grad_norm
+
+
+def prepare_dataloaders(hparams):
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    from data_utils import TextMelCollate, TextMelLoader
+    trainset = TextMelLoader(hparams.training_files, hparams)
+    valset = TextMelLoader(hparams.validation_files, hparams)
+    collate_fn = TextMelCollate(hparams.n_frames_per_step)
+    sampler = DistributedSampler(trainset) if hparams.distributed_run else None
+    loader = DataLoader(trainset, num_workers=0, shuffle=False, sampler=sampler, batch_size=hparams.batch_size,
+                        pin_memory=False, drop_last=True, collate_fn=collate_fn)
+    return loader, valset, collate_fn
+
+
+def validate(model, criterion, valset, iteration, batch_size, n_gpus, collate_fn, logger, distributed_run, rank):
+    """reference train.py:122-147, including its habit of reporting the LAST batch's loss (B-13)."""
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    model.eval()
+    reduced = float('nan')
+    with torch.no_grad():
+        sampler = DistributedSampler(valset) if distributed_run else None
+        loader = DataLoader(valset, sampler=sampler, num_workers=0, shuffle=False, batch_size=batch_size,
+                            pin_memory=False, collate_fn=collate_fn)
+        for batch in loader:
+            x, y = model.parse_batch(batch)
+            loss, _, _, _ = criterion(model(x), y, iteration)
+            reduced = (t2v_dist.reduce_tensor(loss.data, n_gpus) if distributed_run else loss).item()
+    model.train()
+    if rank == 0:
+        print("Validation loss {}: {:9f}  ".format(iteration, reduced))
+    return reduced
+
+
+def train(output_directory, log_directory, checkpoint_path, warm_start, n_gpus, rank, group_name, hparams):
+    if hparams.distributed_run:
+        t2v_dist.init_distributed(hparams, n_gpus, rank, group_name)
+        n_gpus, rank = dist.get_world_size(), dist.get_rank()
+    torch.manual_seed(hparams.seed)
+    torch.cuda.manual_seed(hparams.seed)
+    engine = TrainEngine(hparams, world_size=n_gpus if hparams.distributed_run else 1)
+    model, optimizer, criterion = engine.model, engine.optimizer, engine.criterion
+    learning_rate = hparams.learning_rate
+    if rank == 0 and output_directory and not os.path.isdir(output_directory):
+        os.makedirs(output_directory)
+    train_loader, valset, collate_fn = prepare_dataloaders(hparams)
+
+    iteration, epoch_offset = 0, 0
+    if checkpoint_path is not None:
+        if warm_start:
+            warm_start_model(checkpoint_path, model)
+        else:
+            _, _, saved_lr, iteration = load_checkpoint(checkpoint_path, model, optimizer)
+            if hparams.use_saved_learning_rate:
+                learning_rate = saved_lr
+            iteration += 1
+            epoch_offset = max(0, int(iteration / len(train_loader)))
+
+    for epoch in range(epoch_offset, hparams.epochs):
+        print("Epoch: {}".format(epoch))
+        for batch in train_loader:
+            start = time.perf_counter()
+            loss, recon, kl, kl_w, grad_norm = engine.step(batch, iteration, learning_rate)
+            reduced = (t2v_dist.reduce_tensor(loss, n_gpus) if hparams.distributed_run else loss).item()
+            if not math.isnan(reduced) and rank == 0:
+                duration = time.perf_counter() - start
+                print("Train loss {} {:.6f} Grad Norm {:.6f} {:.2f}s/it".format(
+                    iteration, reduced, grad_norm.item(), duration))
+            if iteration % hparams.iters_per_checkpoint == 0:
+                validate(model, criterion, valset, iteration, hparams.batch_size, n_gpus, collate_fn, None,
+                         hparams.distributed_run, rank)
+                if rank == 0:
+                    save_checkpoint(model, optimizer, learning_rate, iteration,
+                                    os.path.join(output_directory, "checkpoint_{}".format(iteration)))
+            iteration += 1
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('-o', '--output_directory', type=str, help='directory to save checkpoints')
+    ap.add_argument('-l', '--log_directory', type=str, help='directory to save tensorboard logs')
+    ap.add_argument('-c', '--checkpoint_path', type=str, default=None, required=False, help='checkpoint path')
+    ap.add_argument('--warm_start', action='store_true', help='load the model only (warm start)')
+    ap.add_argument('--n_gpus', type=int, default=1, required=False, help='number of gpus')
+    ap.add_argument('--rank', type=int, default=0, required=False, help='rank of current gpu')
+    ap.add_argument('--group_name', type=str, default='group_name', required=False, help='Distributed group name')
+    ap.add_argument('--hparams', type=str, required=False, help='comma separated name=value pairs')
+    args = ap.parse_args()
+    hp = create_hparams(args.hparams)
+    print("Distributed Run:", hp.distributed_run)
+    train(args.output_directory, args.log_directory, args.checkpoint_path, args.warm_start, args.n_gpus,
+          args.rank, args.group_name, hp)
