@@ -24,6 +24,10 @@ const char* t2v_version(void);
 /* last HIP error string recorded by a failing call (thread-local) */
 const char* t2v_last_error(void);
 
+/* Tracing aid: device buffer of 32 uint64 that the attention kernels fill with s_memtime stamps at
+ * their phase boundaries (forward slots 0..7, backward 16..23); NULL (default) disables it. */
+void t2v_set_phase_profile(unsigned long long* dev_buf32);
+
 /* ------------------------------------------------------------------ weight packing
  * Re-lays the two decoder LSTM cells' weights into MFMA-fragment order for the per-step
  * weight-streaming kernels.  Replaces nothing in the reference (cuDNN/cuBLAS choose their own

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(1024) void k_lstm_bwd(LstmBwdArgs a) {
         float4 wv[8], xv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            wv[i] = p[(size_t)(kb0 + 8 * h + i) * ntile * 64];
+            wv[i] = ld_nt(p + (size_t)(kb0 + 8 * h + i) * ntile * 64);
             xv[i] = *(const float4*)(xrow + 16 * (kb0 + 8 * h + i));   // lanes b>=B read row 0 (unused D columns)
         }
 #pragma unroll
@@ -52,30 +52,34 @@ __global__ __launch_bounds__(1024) void k_lstm_bwd(LstmBwdArgs a) {
 }
 
 // attention(t) backward.  grid = B, 512 threads, JP = ceil(T_in/4) register rows.
-// LDS carve (floats): dctx[512] | alpha[TpR] | dal[TpR] | de[TpR] | dpre[Tp*128] | dcs[32*DS] | wcl[32*63] | scr[1024]
+// LDS carve (floats): dctx[512] | alpha[TpR] | dal[TpR] | de[TpR] | dpT[128*TpP] | dcs[32*DS] | wcl[32*63] | scr[1024]
+//   dpT = dpre transposed [d][TpP] (TpP odd -> conflict-free column writes, MFMA B reads along j)
 #define ATB_THREADS 512
 #define ATB_R (ATB_THREADS / 128)
-static __host__ __device__ inline int attn_bwd_ds(int Tp) { return (Tp + 30) | 1; }
+static __host__ __device__ inline int attn_bwd_ds(int Tp) { return (16 * ((Tp + 15) / 16) + 46) | 1; }
+static __host__ __device__ inline int attn_bwd_tpp(int Tp) { return (16 * ((Tp + 15) / 16)) | 1; }
 size_t t2v_attn_bwd_lds(int Tp) {
     const int TpR = (Tp + 3) & ~3;
-    return sizeof(float) * (T2V_E + 3 * TpR + (size_t)Tp * T2V_A + T2V_F * attn_bwd_ds(Tp) + T2V_F * 63 + 1024);
+    return sizeof(float) * (T2V_E + 3 * TpR + (size_t)T2V_A * attn_bwd_tpp(Tp) + T2V_F * attn_bwd_ds(Tp) + T2V_F * 63 + 1024);
 }
 
 template <int JP>
 __global__ __launch_bounds__(ATB_THREADS) void k_attn_bwd(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Tp = a.T_in, TpR = (Tp + 3) & ~3, DS = attn_bwd_ds(Tp);
+    const int Tp = a.T_in, TpR = (Tp + 3) & ~3, DS = attn_bwd_ds(Tp), TpP = attn_bwd_tpp(Tp);
     float* dctx = smem;
     float* alpha = dctx + T2V_E;
     float* dal = alpha + TpR;
     float* de = dal + TpR;
-    float* dpre = de + TpR;
-    float* dcs = dpre + (size_t)Tp * T2V_A;
+    float* dpT = de + TpR;
+    float* dcs = dpT + (size_t)T2V_A * TpP;
     float* wcl = dcs + T2V_F * DS;
     float* scr = wcl + T2V_F * 63;
     const int d = tid & (T2V_A - 1), j4 = tid >> 7;
+    const int g = lane >> 4, c16 = lane & 15;
 
+    T2V_STAMP(a, 0);
     // ---- entry: issue the global reads
     float sreg[JP];
     {
@@ -107,6 +111,7 @@ __global__ __launch_bounds__(ATB_THREADS) void k_attn_bwd(AttnBwdArgs a) {
     }
     __syncthreads();
 
+    T2V_STAMP(a, 1);
     // 2. d alpha[j] += dctx . memory[j]   (wave per row, 8 rows in flight per wave)
     {
         const float4 d0 = *(const float4*)(dctx + lane * 4), d1 = *(const float4*)(dctx + 256 + lane * 4);
@@ -133,14 +138,15 @@ __global__ __launch_bounds__(ATB_THREADS) void k_attn_bwd(AttnBwdArgs a) {
         }
     }
     __syncthreads();
-    // location_dense column f for phase 5 (loads overlap phases 3-4)
-    float dreg[T2V_A];
+    // location_dense as the MFMA A operand of phase 5: A[f = f0+c16][k = d = 4st+g]
+    float areg[32];
     {
-        const int f = tid & 31;
+        const int f0 = 16 * (wave & 1);
 #pragma unroll
-        for (int dd = 0; dd < T2V_A; ++dd) dreg[dd] = a.loc_dense[dd * T2V_F + f];
+        for (int st = 0; st < 32; ++st) areg[st] = a.loc_dense[(4 * st + g) * T2V_F + f0 + c16];
     }
 
+    T2V_STAMP(a, 2);
     // 3. softmax backward (every wave reduces redundantly)
     {
         float part = 0.f;
@@ -150,6 +156,7 @@ __global__ __launch_bounds__(ATB_THREADS) void k_attn_bwd(AttnBwdArgs a) {
     }
     __syncthreads();
 
+    T2V_STAMP(a, 3);
     // 4. through v . tanh(.)
     {
         float* sp = a.S_t + (size_t)b * Tp * T2V_A + d;
@@ -161,12 +168,14 @@ __global__ __launch_bounds__(ATB_THREADS) void k_attn_bwd(AttnBwdArgs a) {
                 const float s = sreg[i];
                 const float dej = de[j];
                 const float dp = dej * vd * (1.0f - s * s);
-                dpre[j * T2V_A + d] = dp;
+                dpT[d * TpP + j] = dp;
                 sp[(size_t)j * T2V_A] = dp;
                 dq += dp;
                 dv = fmaf(dej, s, dv);
             }
         }
+        // columns j in [Tp, 16*ceil(Tp/16)) feed discarded MFMA columns: keep them finite
+        for (int j = Tp + j4; j < TpP - 1; j += ATB_R) dpT[d * TpP + j] = 0.f;
         scr[tid] = dq;
         scr[ATB_THREADS + tid] = dv;
         __syncthreads();
@@ -179,47 +188,64 @@ __global__ __launch_bounds__(ATB_THREADS) void k_attn_bwd(AttnBwdArgs a) {
         }
     }
 
-    // 5. through location_dense: dc[f][j] = sum_d D[d][f] dpre[j][d]
+    T2V_STAMP(a, 4);
+    // 5. through location_dense on MFMA: dc[f][j] = sum_d D[d][f] dpre[j][d]; tile = 16 f x 16 j, K = 128
     {
-        const int f = tid & 31;
-        for (int j = tid >> 5; j < Tp; j += ATB_THREADS / 32) {
-            const float4* dp = (const float4*)(dpre + j * T2V_A);
-            float acc0 = 0.f, acc1 = 0.f;
+        const int f0 = 16 * (wave & 1);
+        const int NJ = (Tp + 15) >> 4;
+        for (int jt = wave >> 1; jt < NJ; jt += ATB_THREADS / 128) {
+            const int j = 16 * jt + c16;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int dd = 0; dd < T2V_A / 4; ++dd) {
-                const float4 x = dp[dd];
-                acc0 = fmaf(dreg[4 * dd], x.x, acc0);
-                acc1 = fmaf(dreg[4 * dd + 1], x.y, acc1);
-                acc0 = fmaf(dreg[4 * dd + 2], x.z, acc0);
-                acc1 = fmaf(dreg[4 * dd + 3], x.w, acc1);
-            }
-            const float acc = acc0 + acc1;
-            dcs[f * DS + 15 + j] = acc;
-            a.DC_t[((size_t)b * T2V_F + f) * Tp + j] = acc;
-        }
-    }
-    __syncthreads();
-
-    // 6. through location_conv (transposed): dcat[ch][j] = sum_{f,k} Wc[f][ch][k] dc[f][j+15-k]
-    {
-        const int f = tid & 31;
-        const float* wr = wcl + f * 63;
+            for (int st = 0; st < 32; ++st) acc = mfma16x4(areg[st], dpT[(4 * st + g) * TpP + j], acc);
+            if (j < Tp) {
 #pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-            for (int j = tid >> 5; j < Tp; j += ATB_THREADS / 32) {
-                const float* row = dcs + f * DS + j;   // dcs index (15 + j + 15 - k) = j + 30 - k
-                float acc = 0.f;
-#pragma unroll
-                for (int k = 0; k < T2V_KS; ++k) acc = fmaf(wr[ch * T2V_KS + k], row[30 - k], acc);
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-                if (f == 0) {
-                    if (ch == 0) a.GPREV[(size_t)b * Tp + j] = acc;
-                    else a.GCUM[(size_t)b * Tp + j] += acc;
+                for (int r = 0; r < 4; ++r) {
+                    const int f = f0 + 4 * g + r;
+                    dcs[f * DS + 15 + j] = acc[r];
+                    a.DC_t[((size_t)b * T2V_F + f) * Tp + j] = acc[r];
                 }
             }
         }
     }
+    __syncthreads();
+
+    T2V_STAMP(a, 5);
+    // 6. through location_conv (transposed): dcat[ch][j] = sum_{f,k} Wc[f][ch][k] dc[f][j+15-k]
+    //    thread = (f, block of 6 consecutive j): sliding window in registers, then a 32-lane sum over f
+    {
+        const int f = tid & 31;
+        float wc[2][T2V_KS];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+            for (int k = 0; k < T2V_KS; ++k) wc[ch][k] = wcl[f * 63 + ch * T2V_KS + k];
+        for (int j0 = 6 * (tid >> 5); j0 < Tp; j0 += 6 * (ATB_THREADS / 32)) {
+            float win[36];
+            const float* row = dcs + f * DS + j0;      // dcs index of dc[f][jj] is 15 + jj
+#pragma unroll
+            for (int i = 0; i < 36; ++i) win[i] = row[i];   // dc[f][j0-15 .. j0+20]
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < T2V_KS; ++k)
+#pragma unroll
+                    for (int jj = 0; jj < 6; ++jj) acc[jj] = fmaf(wc[ch][k], win[jj + 30 - k], acc[jj]);
+#pragma unroll
+                for (int jj = 0; jj < 6; ++jj) {
+                    float v = row16_sum(acc[jj]);
+                    v += __shfl_xor(v, 16, 64);
+                    const int j = j0 + jj;
+                    if (f == 0 && j < Tp) {
+                        if (ch == 0) a.GPREV[(size_t)b * Tp + j] = v;
+                        else a.GCUM[(size_t)b * Tp + j] += v;
+                    }
+                }
+            }
+        }
+    }
+    T2V_STAMP(a, 6);
 }
 
 // grid = 64 blocks x 256 threads; thread = (unit U, item b)
@@ -333,6 +359,7 @@ extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_tra
             f.GCUM = g->GCUM;
             f.DV = g->DV;
             f.T_in = T_in;
+            f.prof = g_t2v_prof ? g_t2v_prof + 16 : nullptr;
             if (T_in <= 22 * ATB_R) ATB_LAUNCH(22);
             else if (T_in <= 32 * ATB_R) ATB_LAUNCH(32);
             else ATB_LAUNCH(64);

@@ -52,6 +52,7 @@ __global__ void k_pack_bwd(const float* __restrict__ W, int K, int ncols, float4
 // wave issues ALL of its weight/x loads (26 x 1 KiB) before the first MFMA — the kernel is a
 // pure weight stream (262 KB per CU per launch) and needs the bytes in flight, not occupancy.
 #define LSTM_WAVES 16
+template <bool INFER>
 __global__ __launch_bounds__(1024) void k_lstm_fwd(LstmFwdArgs a) {
     const int w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = lane & 15, g = lane >> 4;
@@ -78,13 +79,6 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(LstmFwdArgs a) {
         }
         cprev = (which == 0 ? a.ca_prev : a.cd_prev)[(size_t)b * T2V_H + U];
     }
-    // query partial: thread (bb = tid>>7, d = tid&127) for bb < B
-    float wqr[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool q_on = a.do_att && (tid >> 7) < a.B;
-    if (q_on) {
-        const float* wq = a.wqT + (size_t)(4 * w) * T2V_A + (tid & (T2V_A - 1));
-        wqr[0] = wq[0]; wqr[1] = wq[T2V_A]; wqr[2] = wq[2 * T2V_A]; wqr[3] = wq[3 * T2V_A];
-    }
 
     f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accD = {0.f, 0.f, 0.f, 0.f};
     // shared-x region: k-blocks [0,96) = [h_att | ctx] (6 per wave); decoder_rnn recurrent part:
@@ -95,28 +89,36 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(LstmFwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             xs[i] = *(const float4*)(xrow + 16 * (kb0 + i));   // lanes b>=B read row 0: their D columns are never used
-            wa[i] = pa[(size_t)(kb0 + i) * 64];   // unconditional: both cells are always computed,
-            wd[i] = pd[(size_t)(kb0 + i) * 64];   // do_att/do_dec only gate the cell update (t=0 / t=T)
+            wa[i] = ld_nt(pa + (size_t)(kb0 + i) * 64);   // unconditional: both cells are always computed,
+            wd[i] = ld_nt(pd + (size_t)(kb0 + i) * 64);   // do_att/do_dec only gate the cell update (t=0 / t=T)
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             xr[i] = *(const float4*)(xrow + 16 * (kr0 + i));
-            wr[i] = pd[(size_t)(kr0 + i) * 64];
+            wr[i] = ld_nt(pd + (size_t)(kr0 + i) * 64);
         }
     }
     float4 xp = z4, wp = z4;
-    if (a.do_att && a.pre_t) {   // inference: prenet columns are part of K (k-blocks [96,112))
+    if (INFER) {   // inference: prenet columns are part of K (k-blocks [96,112))
         const float* prow = a.pre_t + (size_t)(bvalid ? b : 0) * T2V_PRE + 4 * g;
         xp = *(const float4*)(prow + 16 * wave);
-        wp = pa[(size_t)(96 + wave) * 64];
+        wp = ld_nt(pa + (size_t)(96 + wave) * 64);
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) { MFMA4(accA, wa[i], xs[i]); MFMA4(accD, wd[i], xs[i]); }
-    if (a.pre_t) { MFMA4(accA, wp, xp); }
+    if (INFER) { MFMA4(accA, wp, xp); }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { MFMA4(accD, wr[i], xr[i]); }
     red[0][wave][lane] = accA;
     red[1][wave][lane] = accD;
+    // query partial: thread (bb = tid>>7, d = tid&127) for bb < B; its 4 query-weight values are
+    // fetched here so the latency hides under the reduction + cell update
+    float wqr[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool q_on = a.do_att && (tid >> 7) < a.B;
+    if (q_on) {
+        const float* wq = a.wqT + (size_t)(4 * w) * T2V_A + (tid & (T2V_A - 1));
+        wqr[0] = wq[0]; wqr[1] = wq[T2V_A]; wqr[2] = wq[2 * T2V_A]; wqr[3] = wq[3 * T2V_A];
+    }
     __syncthreads();
 
     // cell update: wave 0 -> attention_rnn(t), wave 1 -> decoder_rnn(t-1).
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(LstmFwdArgs a) {
 // LDS carve (floats): q[128] | ap[2][Tp+30] | cs[32][Tp] | e[TpR] | wcl[32*63] | scr[512+8*Tp]
 #define ATT_THREADS 512
 #define ATT_R (ATT_THREADS / 128)      // row phases: thread = (d = tid&127, j8 = tid>>7)
-template <int JP>
+template <int JP, int NJT>
 __global__ __launch_bounds__(ATT_THREADS) void k_attn_fwd(AttnFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, se = blockIdx.y, SE = gridDim.y;
@@ -180,6 +182,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_fwd(AttnFwdArgs a) {
     const int len = a.lengths ? a.lengths[b] : Tp;
     const int d = tid & (T2V_A - 1), j8 = tid >> 7;     // (column, row-phase) mapping used by 1/3/5
 
+    T2V_STAMP(a, 0);
     // ---- issue every global read up front
     constexpr int NQ = T2V_NWG / ATT_R;
     float qpart[NQ];
@@ -188,17 +191,19 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_fwd(AttnFwdArgs a) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) qpart[i] = p[(size_t)i * T2V_A];
     }
-    float pmr[JP];
+    // pm in the MFMA output layout of phase 3: lane (g, c16) of wave w holds (j = 16jt+4g+r, d = 16w+c16)
+    float pmr[NJT][4];
     const int ES = T2V_E / SE;                         // context columns of this workgroup (128)
     {
-        const float* pmb = a.pm + (size_t)b * Tp * T2V_A + d;
+        const float* pmb = a.pm + (size_t)b * Tp * T2V_A + 16 * wave + (lane & 15);
 #pragma unroll
-        for (int i = 0; i < JP; ++i) {
-            const int j = j8 + ATT_R * i;
-            pmr[i] = j < Tp ? pmb[(size_t)j * T2V_A] : 0.f;
-        }
+        for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * jt + 4 * (lane >> 4) + r;
+                pmr[jt][r] = j < Tp ? pmb[(size_t)j * T2V_A] : 0.f;
+            }
     }
-    const float vd = a.v[d];
     {   // location_conv weights (1984 floats = 496 float4) -> padded LDS rows; prev/cum weights
         float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tid < T2V_F * 62 / 4) w4 = ((const float4*)a.loc_conv)[tid];
@@ -220,9 +225,9 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_fwd(AttnFwdArgs a) {
         for (int i = 0; i < NQ; i += 4) { s0 += qpart[i]; s1 += qpart[i + 1]; s2 += qpart[i + 2]; s3 += qpart[i + 3]; }
         scr[tid] = (s0 + s1) + (s2 + s3);
     }
-    float dw[T2V_F];
+    float dw[8];     // location_dense as the MFMA B operand of phase 3: D[16w + c16][4st + g]
 #pragma unroll
-    for (int f = 0; f < T2V_F; ++f) dw[f] = a.loc_dense[d * T2V_F + f];
+    for (int st = 0; st < 8; ++st) dw[st] = a.loc_dense[(16 * wave + (lane & 15)) * T2V_F + 4 * st + (lane >> 4)];
     __syncthreads();
     if (tid < T2V_A) {
         float s = 0.f;
@@ -231,31 +236,33 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_fwd(AttnFwdArgs a) {
         q[tid] = s;
     }
 
-    // ---- 2. location conv: cs[f][j] = sum_{ch,k} Wc[f][ch][k] * ap[ch][j+k]; thread = (f, 4 j's)
+    T2V_STAMP(a, 1);
+    // ---- 2. location conv as an MFMA GEMM: cs[f][j] = sum_kk Wc[f][kk] * im2col(ap)[kk][j],
+    //         kk = 32*ch + k (k = 31 is a zero pad) -> K = 64 = 16 k-steps; tile = 16 f x 16 j.
+    const int g = lane >> 4, c16 = lane & 15;
     {
-        const int f = tid & 31;
-        for (int j0 = 4 * (tid >> 5); j0 < Tp; j0 += 4 * (ATT_THREADS / 32)) {
-            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+        const int f0 = 16 * (wave & 1);
+        float areg[16];
 #pragma unroll
-            for (int ch = 0; ch < 2; ++ch) {
-                const float* apc = ap + ch * TpH + j0;
-                const float* wr = wcl + f * 63 + ch * T2V_KS;
-                float win[T2V_KS + 3];
+        for (int st = 0; st < 16; ++st) {
+            const int kk = 4 * st + g, ch = kk >> 5, k = kk & 31;
+            areg[st] = k < T2V_KS ? wcl[(f0 + c16) * 63 + ch * T2V_KS + k] : 0.f;
+        }
+        const int NJ = (Tp + 15) >> 4;
+        for (int jt = wave >> 1; jt < NJ; jt += ATT_THREADS / 128) {
+            const int j = 16 * jt + c16;
+            const int jc = j < Tp ? j : Tp - 1;            // keep LDS reads in range; column discarded
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < T2V_KS + 3; ++k) win[k] = (j0 + k < TpH) ? apc[k] : 0.f;
-#pragma unroll
-                for (int k = 0; k < T2V_KS; ++k) {
-                    const float wk = wr[k];
-                    o0 = fmaf(wk, win[k], o0);
-                    o1 = fmaf(wk, win[k + 1], o1);
-                    o2 = fmaf(wk, win[k + 2], o2);
-                    o3 = fmaf(wk, win[k + 3], o3);
-                }
+            for (int st = 0; st < 16; ++st) {
+                const int kk = 4 * st + g, ch = kk >> 5, k = kk & 31;
+                const float bv = ap[ch * TpH + jc + (k < T2V_KS ? k : T2V_KS - 1)];
+                acc = mfma16x4(areg[st], bv, acc);
             }
-            if (j0 + 0 < Tp) cs[f * Tp + j0 + 0] = o0;
-            if (j0 + 1 < Tp) cs[f * Tp + j0 + 1] = o1;
-            if (j0 + 2 < Tp) cs[f * Tp + j0 + 2] = o2;
-            if (j0 + 3 < Tp) cs[f * Tp + j0 + 3] = o3;
+            if (j < Tp) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cs[(f0 + 4 * g + r) * Tp + j] = acc[r];
+            }
         }
     }
     float memr[JP];
@@ -273,21 +280,32 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_fwd(AttnFwdArgs a) {
         for (int i = tid; i < T2V_F * Tp; i += ATT_THREADS) dst[i] = cs[i];
     }
 
-    // ---- 3. energies e[j] = sum_d v[d] * tanh(q[d] + pm[j][d] + sum_f D[d][f] cs[f][j])
+    T2V_STAMP(a, 2);
+    // ---- 3. energies: loc[j][d] = sum_f cs[f][j] D[d][f] on MFMA (wave = 16 d's, tile = 16 j x 16 d),
+    //         s = tanh(q[d] + loc + pm[j][d]),  e[j] = sum_d v[d] s
     {
-        const float qd = q[d];
-        float* ssave = (se == 0 && a.s_save) ? a.s_save + (size_t)b * Tp * T2V_A + d : nullptr;
+        const int d0 = 16 * wave, dd = d0 + c16;
+        float breg[8];
 #pragma unroll
-        for (int i = 0; i < JP; ++i) {
-            const int j = j8 + ATT_R * i;
-            if (j < Tp) {            // wave-uniform (j8 is per pair of waves)
-                float acc = 0.f;
+        for (int st = 0; st < 8; ++st) breg[st] = dw[st];
+        const float qd = q[dd], vdd = a.v[dd];
+        float* ssave = (se == 0 && a.s_save) ? a.s_save + (size_t)b * Tp * T2V_A + dd : nullptr;
 #pragma unroll
-                for (int f = 0; f < T2V_F; ++f) acc = fmaf(dw[f], cs[f * Tp + j], acc);
-                const float s = tanhf_(qd + acc + pmr[i]);
-                if (ssave) ssave[(size_t)j * T2V_A] = s;
-                const float part = row16_sum(vd * s);   // 16 of the 128 d's (DPP, no LDS)
-                if ((lane & 15) == 0) scr[ATT_THREADS + 8 * j + 4 * (wave & 1) + (lane >> 4)] = part;
+        for (int jt = 0; jt < NJT; ++jt) {
+            const int j0 = 16 * jt;
+            if (j0 < Tp) {
+                const int jc = (j0 + c16) < Tp ? (j0 + c16) : Tp - 1;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < 8; ++st) acc = mfma16x4(cs[(4 * st + g) * Tp + jc], breg[st], acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = j0 + 4 * g + r;
+                    const float sv = tanhf_(qd + acc[r] + pmr[jt][r]);
+                    if (ssave && j < Tp) ssave[(size_t)j * T2V_A] = sv;
+                    const float part = row16_sum(vdd * sv);          // over this wave's 16 d's
+                    if (c16 == 0 && j < Tp) scr[ATT_THREADS + 8 * j + wave] = part;
+                }
             }
         }
     }
@@ -299,6 +317,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_fwd(AttnFwdArgs a) {
     }
     __syncthreads();
 
+    T2V_STAMP(a, 3);
     // ---- 4. softmax over j (max-subtracted, masked -> exactly 0); every wave reduces redundantly
     {
         float m = -INFINITY;
@@ -320,6 +339,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_fwd(AttnFwdArgs a) {
     }
     __syncthreads();
 
+    T2V_STAMP(a, 4);
     // ---- 5. context slice: ctx[c] = sum_j alpha[j] * memory[b][j][c]   (thread = (c=d, j8))
     {
         float acc = 0.f;
@@ -337,6 +357,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_fwd(AttnFwdArgs a) {
             a.xs_next[(size_t)b * T2V_XW + T2V_H + se * ES + tid] = tot;
         }
     }
+    T2V_STAMP(a, 5);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -378,11 +399,11 @@ static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
     const size_t lds = t2v_attn_fwd_lds(T_in);
     if (lds > 160 * 1024) return T2V_ERR_ARG;
     if (T_in > 256) return T2V_ERR_ARG;   // register rows of k_attn_fwd are instantiated up to 4*64
-#define ATF_LAUNCH(JPV)                                                                                   \
+#define ATF_LAUNCH(JPV, NJV)                                                                              \
     do {                                                                                                  \
         if (lds > 64 * 1024)                                                                              \
-            (void)hipFuncSetAttribute((const void*)k_attn_fwd<JPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        k_attn_fwd<JPV><<<dim3(B, SE), ATT_THREADS, lds, stream>>>(f);                                    \
+            (void)hipFuncSetAttribute((const void*)k_attn_fwd<JPV, NJV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        k_attn_fwd<JPV, NJV><<<dim3(B, SE), ATT_THREADS, lds, stream>>>(f);                               \
     } while (0)
     const int SE = 4;
     for (int t = 0; t <= T_out; ++t) {
@@ -411,7 +432,7 @@ static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
         a.p_att = p_att;
         a.p_dec = p_dec;
         a.seed = seed;
-        if (mask & 1) k_lstm_fwd<<<T2V_NWG, 1024, 0, stream>>>(a);
+        if (mask & 1) k_lstm_fwd<false><<<T2V_NWG, 1024, 0, stream>>>(a);
         if (t < T_out && (mask & 2)) {
             AttnFwdArgs f;
             f.qp = s->QP;
@@ -429,9 +450,10 @@ static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
             f.s_save = s->S ? s->S + (size_t)t * B * T_in * T2V_A : nullptr;
             f.conv_save = s->CONV ? s->CONV + (size_t)t * B * T2V_F * T_in : nullptr;
             f.T_in = T_in;
-            if (T_in <= 22 * ATT_R) ATF_LAUNCH(22);
-            else if (T_in <= 32 * ATT_R) ATF_LAUNCH(32);
-            else ATF_LAUNCH(64);
+            f.prof = g_t2v_prof;
+            if (T_in <= 22 * ATT_R) ATF_LAUNCH(22, 6);
+            else if (T_in <= 32 * ATT_R) ATF_LAUNCH(32, 8);
+            else ATF_LAUNCH(64, 16);
         }
     }
     return t2v_check_launch();

@@ -30,6 +30,12 @@ __device__ __forceinline__ f32x4 mfma16x4(float a, float b, f32x4 c) {
 // what the fp32 parity budget (mel-L1 < 1e-4 through 400 recurrent steps) needs; far cheaper
 // than the libm tanhf/expf call sequences.
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// streamed-once weights: non-temporal so the 67 MB per-step stream does not evict the small
+// recurrent state / attention operands from the XCD L2s
+__device__ __forceinline__ float4 ld_nt(const float4* p) {
+    const f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return fast_rcp(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * fast_rcp(1.0f + __expf(2.0f * x)); }
 
@@ -72,3 +78,10 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// phase stamp for the optional in-kernel profile (one thread of one workgroup)
+#define T2V_STAMP(ARGS, I)                                                                          \
+    do {                                                                                            \
+        if ((ARGS).prof && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)                 \
+            (ARGS).prof[(I)] = __builtin_readcyclecounter();                                        \
+    } while (0)

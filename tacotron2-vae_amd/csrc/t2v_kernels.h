@@ -7,7 +7,8 @@
 enum { T2V_RNG_ATT_H = 1, T2V_RNG_ATT_C = 2, T2V_RNG_DEC_H = 3, T2V_RNG_DEC_C = 4,
        T2V_RNG_PRENET0 = 5, T2V_RNG_PRENET1 = 6 };
 
-int t2v_check_launch();                 // records hipGetLastError() for t2v_last_error()
+int t2v_check_launch();
+extern unsigned long long* g_t2v_prof;   // device buffer of 32 u64 or NULL (t2v_set_phase_profile)                 // records hipGetLastError() for t2v_last_error()
 size_t t2v_attn_fwd_lds(int T_in);
 
 struct LstmFwdArgs {
@@ -49,6 +50,7 @@ struct AttnFwdArgs {
     float* s_save;
     float* conv_save;
     int T_in;
+    unsigned long long* prof;   // optional phase stamps (s_memtime) from workgroup (0,0) thread 0
 };
 
 struct LstmBwdArgs {
@@ -78,6 +80,7 @@ struct AttnBwdArgs {
     float* GCUM;
     float* DV;
     int T_in;
+    unsigned long long* prof;
 };
 
 struct CellBwdArgs {

@@ -15,3 +15,8 @@ int t2v_check_launch() {
 }
 extern "C" const char* t2v_version(void) { return "t2vae-hip 0.1 (gfx950)"; }
 extern "C" const char* t2v_last_error(void) { return g_err; }
+
+unsigned long long* g_t2v_prof = nullptr;
+// Tracing aid: when set, k_attn_fwd / k_attn_bwd write s_memtime stamps at their phase boundaries
+// (fwd -> slots 0..7, bwd -> slots 16..23).  NULL disables it.
+extern "C" void t2v_set_phase_profile(unsigned long long* dev_buf32) { g_t2v_prof = dev_buf32; }
