@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""Generate tests/golden/* by RUNNING THE REAL REFERENCE (container-only, test infrastructure).
+
+    python oracle/gen_golden.py            # needs /root/reference (read-only) + oracle/ref_shims
+
+Every fixture is data: seeded inputs and the outputs the reference's own code produced for them
+on CPU (torch fp32).  Model weights are never stored — they are re-created from
+`torch.manual_seed(1234)` + the reference's constructor order, which our boundary modules
+reproduce bit-for-bit (pinned here by per-tensor digests of the initial state_dict).
+Dropout is switched off (model.drop_rate = 0, p_attention_dropout = p_decoder_dropout = 0) and the
+VAE noise is injected, exactly as SURVEY.md §8(c) prescribes for parity runs.
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, 'tests', 'golden')
+sys.path.insert(0, HERE)
+import _refimport  # noqa: E402
+
+TEXTS = [
+    "감정있는 한국어 목소리 생성",                      # README.md:19-23 known-answer sentence
+    "안녕하세요. 만나서 반갑습니다!",
+    "오늘 날씨가 정말 좋네요, 그렇죠?",
+    "이것은 테스트 문장입니다.",
+    "닫았다 닫 라면 랄 바보 밥 아잉 앙",                  # tail ᆮ / ᆼ (duplicate-symbol quirk B-8)
+    "나는 3시에 10마리 강아지를 봤다",
+    "지금은 -12.35%였고 종류는 5가지와 19가지, 그리고 55가지였다",
+    "JTBC는 TH와 K 양이 2017년 9월 12일 오후 12시에 24살이 된다",
+    "mp3 파일을 홈페이지에서 다운로드 받으시기 바랍니다.",
+    "제 전화번호는 01012345678이에요.",
+    "값이 1,234,567원입니다",
+    "키는 180cm이고 몸무게는 75kg이다",
+    "LG와 KTX, 그리고 DVD",
+    "꽃잎이 흩날리는 봄밤; 값없이: 괜찮아",
+    "읽다 읊다 앉다 않다 핥다 밟다 삶 넓다 없다",
+    "왜 그래? 뭐라고! (정말)",
+]
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def digest(t):
+    t = t.detach().double()
+    return [float(t.sum()), float(t.abs().sum()), float((t * t).sum())]
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    m = _refimport.load()
+    R, RL, RD, RT = m['model'], m['layers'], m['data'], m['text']
+    hp = m['hparams'].create_hparams()
+
+    # ------------------------------------------------------------------ (a) text front end KATs
+    kat = [{"text": t, "ids": RT.text_to_sequence(t, ['korean_cleaners'])} for t in TEXTS]
+    with open(os.path.join(ROOT, 'filelists_probe.tmp'), 'w') as f:
+        pass
+    os.remove(os.path.join(ROOT, 'filelists_probe.tmp'))
+    fl = os.path.join(_refimport.REF, 'filelists', 'koemo_spk_emo_all_train.txt')
+    if os.path.isfile(fl):
+        with open(fl, encoding='utf-8') as f:
+            lines = [ln.strip().split('|') for ln in f]
+        for ln in lines[::700][:14]:
+            if "'" in ln[1] or '"' in ln[1]:
+                continue   # quoted spans need nltk
+            kat.append({"text": ln[1], "ids": RT.text_to_sequence(ln[1], ['korean_cleaners'])})
+    with open(os.path.join(OUT, 'text_kat.json'), 'w', encoding='utf-8') as f:
+        json.dump(kat, f, ensure_ascii=False, indent=0)
+
+    # ------------------------------------------------------------------ (b) STFT -> mel
+    stft = RL.TacotronSTFT(hp.filter_length, hp.hop_length, hp.win_length, hp.n_mel_channels, hp.sampling_rate,
+                           hp.mel_fmin, hp.mel_fmax)
+    from scipy.io.wavfile import read
+    sr, wav = read(os.path.join(_refimport.REF, 'samples', 'refs', 'ref_hap.wav'))
+    assert sr == 16000
+    full_mel = stft.mel_spectrogram(torch.from_numpy(wav.astype(np.float32) / 32768.0)[None])
+    clip = wav[20000:20000 + 8192].astype(np.int16)                       # 0.5 s of real speech
+    g = torch.Generator().manual_seed(0)
+    noise = (torch.clamp(0.1 * torch.randn(6000, generator=g), -1, 1) * 32767).to(torch.int16).numpy()
+    mels = {}
+    for name, x in (('speech', clip), ('noise', noise)):
+        mels[name] = _np(stft.mel_spectrogram(torch.from_numpy(x.astype(np.float32) / 32768.0)[None]))[0]
+    np.savez_compressed(os.path.join(OUT, 'mel_frontend.npz'), speech_wav=clip, noise_wav=noise,
+                        speech_mel=mels['speech'], noise_mel=mels['noise'],
+                        mel_basis=_np(stft.mel_basis), ref_hap_shape=np.array(full_mel.shape),
+                        ref_hap_minmax=np.array([float(full_mel.min()), float(full_mel.max())]))
+
+    # ------------------------------------------------------------------ (c) one training step
+    torch.manual_seed(hp.seed)
+    R.drop_rate = 0.0
+    hp.p_attention_dropout = 0.0
+    hp.p_decoder_dropout = 0.0
+    hp.anneal_function = 'constant'
+    model = R.Tacotron2(hp)
+    model.train()
+    init_digest = {k: digest(v) for k, v in model.state_dict().items()}
+    manifest = [[k, list(v.shape), str(v.dtype).replace('torch.', '')] for k, v in model.state_dict().items()]
+
+    B, T_in, T_out = 2, 20, 40
+    lens_in, lens_out = [20, 13], [40, 29]
+    g = torch.Generator().manual_seed(11)
+    text = torch.zeros(B, T_in, dtype=torch.long)
+    mel = torch.zeros(B, 80, T_out)
+    gate = torch.zeros(B, T_out)
+    for i in range(B):
+        text[i, :lens_in[i]] = torch.randint(2, 80, (lens_in[i],), generator=g)
+        text[i, lens_in[i] - 1] = 1
+        mel[i, :, :lens_out[i]] = (torch.randn(80, lens_out[i], generator=g) * 2 - 4).clamp(-11.5129, 2.5)
+        gate[i, lens_out[i] - 1:] = 1
+    eps = torch.randn(B, 32, generator=g)
+    m['modules'].torch.randn_like = lambda x: eps.clone()
+    speakers = torch.zeros(B, 1, dtype=torch.long)
+    emotions = torch.tensor([[0, 1, 0, 0], [0, 0, 0, 1]])
+    batch = (text, torch.tensor(lens_in), mel, gate, torch.tensor(lens_out), speakers, emotions)
+    crit = m['loss'].Tacotron2Loss_VAE(hp)
+    opt = torch.optim.Adam(model.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
+    losses, gnorms = [], []
+    step_out = None
+    grads0 = None
+    for it in range(2):
+        model.zero_grad()
+        x, y = model.parse_batch(batch)
+        y_pred = model(x)
+        loss, recon, kl, w = crit(y_pred, y, it)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), hp.grad_clip_thresh)
+        if it == 0:
+            step_out = [_np(t) for t in y_pred[:7]]
+            scal = [float(loss), float(recon), float(kl), float(w)]
+            # gradients AFTER clipping are what Adam consumes; store digests of the raw ones
+            coef = min(1.0, hp.grad_clip_thresh / (float(gn) + 1e-6))
+            grads0 = {k: (digest(p.grad / coef), _np((p.grad / coef).reshape(-1)[:8]))
+                      for k, p in model.named_parameters() if p.grad is not None}
+            nograd = [k for k, p in model.named_parameters() if p.grad is None]
+        opt.step()
+        losses.append(float(loss))
+        gnorms.append(float(gn))
+    after2 = {k: digest(v) for k, v in model.state_dict().items()}
+    np.savez_compressed(
+        os.path.join(OUT, 'train_step.npz'), text=_np(text), input_lengths=np.array(lens_in), mel=_np(mel),
+        gate=_np(gate), output_lengths=np.array(lens_out), eps=_np(eps), emotions=_np(emotions),
+        out_mel=step_out[0], out_post=step_out[1], out_gate=step_out[2], out_align=step_out[3],
+        out_mu=step_out[4], out_logvar=step_out[5], out_z=step_out[6], scalars=np.array(scal),
+        losses=np.array(losses), grad_norms=np.array(gnorms))
+    with open(os.path.join(OUT, 'train_step_digests.json'), 'w') as f:
+        json.dump({"init": init_digest, "after_2_steps": after2, "no_grad_params": nograd,
+                   "grads_step0": {k: {"digest": v[0], "head": [float(x) for x in v[1]]} for k, v in grads0.items()}},
+                  f, indent=0)
+
+    # checkpoint dict layout (train.py:113-119) written by the reference's own save_checkpoint
+    import train as r_train
+    with tempfile.TemporaryDirectory() as td:
+        pth = os.path.join(td, 'checkpoint_1')
+        r_train.save_checkpoint(model, opt, hp.learning_rate, 1, pth)
+        ck = torch.load(pth, map_location='cpu', weights_only=False)
+    osd = ck['optimizer']
+    schema = {
+        "top_keys": list(ck.keys()),
+        "state_dict": manifest,
+        "optimizer_state_indices": sorted(int(k) for k in osd['state'].keys()),
+        "optimizer_state_keys": sorted(next(iter(osd['state'].values())).keys()),
+        "optimizer_param_group": {k: (v if not isinstance(v, (list, tuple)) or k != 'params' else len(v))
+                                  for k, v in osd['param_groups'][0].items()
+                                  if isinstance(v, (int, float, bool, list, tuple, type(None)))},
+        "n_parameters": len(list(model.parameters())),
+    }
+    with open(os.path.join(OUT, 'checkpoint_schema.json'), 'w') as f:
+        json.dump(schema, f, indent=0)
+
+    # ------------------------------------------------------------------ (d) inference (free running)
+    torch.manual_seed(hp.seed)
+    hp.max_decoder_steps = 24
+    model2 = R.Tacotron2(hp)
+    model2.eval()
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(2, 80, (1, 30), generator=g)
+    ids[0, -1] = 1
+    zlat = torch.randn(1, 32, generator=g)
+    with torch.no_grad():
+        emb = model2.transcript_embedding(ids).transpose(1, 2)
+        enc = model2.encoder.inference(emb)
+        style = model2.vae_gst.fc3(zlat)
+        memory = enc + style.unsqueeze(1)
+        mel_o, gate_o, al_o = model2.decoder.inference(memory)
+        post = mel_o + model2.postnet(mel_o)
+    np.savez_compressed(os.path.join(OUT, 'inference.npz'), ids=_np(ids), z=_np(zlat), memory=_np(memory),
+                        mel=_np(mel_o), gate=_np(gate_o), align=_np(al_o), post=_np(post))
+
+    # ------------------------------------------------------------------ (e) collate layout
+    g = torch.Generator().manual_seed(3)
+    items = []
+    for n_txt, n_mel, emo in ((5, 9, 2), (8, 7, 0), (3, 11, 3)):
+        items.append((torch.randint(2, 80, (n_txt,), generator=g).int(), torch.randn(80, n_mel, generator=g),
+                      torch.tensor([1.0]), torch.nn.functional.one_hot(torch.tensor(emo), 4).float()))
+    col = RD.TextMelCollate(1)(items)
+    np.savez_compressed(os.path.join(OUT, 'collate.npz'),
+                        **{'in_text_%d' % i: _np(it[0]) for i, it in enumerate(items)},
+                        **{'in_mel_%d' % i: _np(it[1]) for i, it in enumerate(items)},
+                        **{'in_emo_%d' % i: _np(it[3]) for i, it in enumerate(items)},
+                        **{'out_%d' % i: _np(t) for i, t in enumerate(col)},
+                        out_dtypes=np.array([str(t.dtype) for t in col]))
+
+    # ------------------------------------------------------------------ (f) KL anneal schedule
+    sched = {}
+    for kind in ('logistic', 'linear', 'constant'):
+        sched[kind] = [crit.kl_anneal_function(kind, hp.anneal_lag, s, hp.anneal_k, hp.anneal_x0, hp.anneal_upper)
+                       for s in (0, 1, 5000, 10000, 20000, 50000, 50001, 100000)]
+    with open(os.path.join(OUT, 'kl_anneal.json'), 'w') as f:
+        json.dump(sched, f)
+    hp2 = m['hparams'].create_hparams("batch_size=6,anneal_function=constant,mask_padding=False,learning_rate=0.01")
+    with open(os.path.join(OUT, 'hparams_defaults.json'), 'w') as f:
+        json.dump({"defaults": m['hparams'].create_hparams().values(), "override_string":
+                   "batch_size=6,anneal_function=constant,mask_padding=False,learning_rate=0.01",
+                   "overridden": hp2.values()}, f, indent=0)
+    print('golden fixtures written to', OUT)
+    for fn in sorted(os.listdir(OUT)):
+        print('  %-28s %8d B' % (fn, os.path.getsize(os.path.join(OUT, fn))))
+
+
+if __name__ == '__main__':
+    main()

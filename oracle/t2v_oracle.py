@@ -292,7 +292,8 @@ def tacotron2_forward(sd, text, input_lengths, mels, output_lengths, training=Tr
 def kl_weight(anneal_function, step, lag=50000, k=0.0025, x0=10000, upper=0.2):
     """loss_function.py:15-24."""
     if anneal_function == 'logistic':
-        return float(upper / (upper + math.exp(-k * (step - x0))))
+        import numpy as np
+        return float(upper / (upper + np.exp(-k * (step - x0))))
     if anneal_function == 'linear':
         return min(upper, step / x0) if step > lag else 0
     if anneal_function == 'constant':

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(1024) void k_lstm_bwd(LstmBwdArgs a) {
         float4 wv[8], xv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            wv[i] = ld_nt(p + (size_t)(kb0 + 8 * h + i) * ntile * 64);
+            wv[i] = p[(size_t)(kb0 + 8 * h + i) * ntile * 64];
             xv[i] = *(const float4*)(xrow + 16 * (kb0 + 8 * h + i));   // lanes b>=B read row 0 (unused D columns)
         }
 #pragma unroll

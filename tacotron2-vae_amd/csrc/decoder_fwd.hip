@@ -89,20 +89,20 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(LstmFwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             xs[i] = *(const float4*)(xrow + 16 * (kb0 + i));   // lanes b>=B read row 0: their D columns are never used
-            wa[i] = ld_nt(pa + (size_t)(kb0 + i) * 64);   // unconditional: both cells are always computed,
-            wd[i] = ld_nt(pd + (size_t)(kb0 + i) * 64);   // do_att/do_dec only gate the cell update (t=0 / t=T)
+            wa[i] = pa[(size_t)(kb0 + i) * 64];   // unconditional: both cells are always computed,
+            wd[i] = pd[(size_t)(kb0 + i) * 64];   // do_att/do_dec only gate the cell update (t=0 / t=T)
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             xr[i] = *(const float4*)(xrow + 16 * (kr0 + i));
-            wr[i] = ld_nt(pd + (size_t)(kr0 + i) * 64);
+            wr[i] = pd[(size_t)(kr0 + i) * 64];
         }
     }
     float4 xp = z4, wp = z4;
     if (INFER) {   // inference: prenet columns are part of K (k-blocks [96,112))
         const float* prow = a.pre_t + (size_t)(bvalid ? b : 0) * T2V_PRE + 4 * g;
         xp = *(const float4*)(prow + 16 * wave);
-        wp = ld_nt(pa + (size_t)(96 + wave) * 64);
+        wp = pa[(size_t)(96 + wave) * 64];
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) { MFMA4(accA, wa[i], xs[i]); MFMA4(accD, wd[i], xs[i]); }

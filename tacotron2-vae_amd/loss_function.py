@@ -1,6 +1,5 @@
 """Tacotron2Loss_VAE (reference loss_function.py:6-44): 2×MSE + BCE-with-logits + w(step)·KL."""
-import math
-
+import numpy as np
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -8,7 +7,7 @@ from torch.nn import functional as F
 
 def kl_anneal_weight(kind, step, lag, k, x0, upper):
     if kind == 'logistic':
-        return float(upper / (upper + math.exp(-k * (step - x0))))
+        return float(upper / (upper + np.exp(-k * (step - x0))))   # np.exp like the reference (1-ulp exact)
     if kind == 'linear':
         return min(upper, step / x0) if step > lag else 0
     if kind == 'constant':

@@ -1,0 +1,155 @@
+"""GPU parity of the whole train step against the reference's golden vectors (tests/golden, written
+by oracle/gen_golden.py from the real reference): forward outputs, loss, raw gradients, two
+clip+Adam steps through the fused HIP optimiser, checkpoint interchange."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _digest(t):
+    t = t.detach().double().cpu()
+    return [float(t.sum()), float(t.abs().sum()), float((t * t).sum())]
+
+
+@pytest.fixture(scope='module')
+def run(golden_dir):
+    import hparams as HP
+    import model as M
+    import train as TR
+    g = np.load(os.path.join(golden_dir, 'train_step.npz'))
+    with open(os.path.join(golden_dir, 'train_step_digests.json')) as f:
+        dig = json.load(f)
+    hp = HP.create_hparams("anneal_function=constant,p_attention_dropout=0.0,p_decoder_dropout=0.0")
+    old = M.drop_rate
+    M.drop_rate = 0.0
+    torch.manual_seed(hp.seed)
+    eng = TR.TrainEngine(hp)
+    eng.model.vae_gst.eps_override = torch.from_numpy(g['eps']).cuda()
+    batch = (torch.from_numpy(g['text']), torch.from_numpy(g['input_lengths']), torch.from_numpy(g['mel']),
+             torch.from_numpy(g['gate']), torch.from_numpy(g['output_lengths']),
+             torch.zeros(2, 1, dtype=torch.long), torch.from_numpy(g['emotions']))
+    # step 0 by hand (to look at outputs and raw gradients), then the optimiser
+    opt = eng.optimizer
+    opt.zero_grad()
+    x, y = eng.model.parse_batch(batch)
+    y_pred = eng.model(x)
+    loss, recon, kl, w = eng.criterion(y_pred, y, 0)
+    loss.backward()
+    grads = {n: p.grad.detach().clone().cpu() for n, p in eng.model.named_parameters() if p.grad is not None}
+    gn0 = float(opt.step().item())
+    l1, _, _, _, gn1 = eng.step(batch, 1)
+    torch.cuda.synchronize()
+    res = dict(g=g, dig=dig, eng=eng, y_pred=[t.detach().cpu() for t in y_pred[:7]], loss=float(loss), kl=float(kl),
+               recon=float(recon), grads=grads, gn=[gn0, float(gn1.item())], l1=float(l1.item()), batch=batch, hp=hp)
+    yield res
+    M.drop_rate = old
+
+
+def test_forward_outputs_match_reference(run):
+    g = run['g']
+    tol = dict(out_mel=1e-4, out_post=2e-4, out_gate=1e-4, out_align=2e-5, out_mu=1e-5, out_logvar=1e-5, out_z=1e-5)
+    for i, name in enumerate(['out_mel', 'out_post', 'out_gate', 'out_align', 'out_mu', 'out_logvar', 'out_z']):
+        ref = torch.from_numpy(g[name])
+        d = (run['y_pred'][i] - ref).abs()
+        assert d.max().item() < tol[name], (name, d.max().item())
+    # BASELINE.json: mel-L1 vs the reference CPU path < 1e-4
+    assert (run['y_pred'][0] - torch.from_numpy(g['out_mel'])).abs().mean().item() < 1e-4
+    assert (run['y_pred'][1] - torch.from_numpy(g['out_post'])).abs().mean().item() < 1e-4
+    assert abs(run['loss'] - g['scalars'][0]) < 1e-4 * abs(g['scalars'][0])
+    assert abs(run['kl'] - g['scalars'][2]) < 1e-4 * abs(g['scalars'][2])
+
+
+def test_gradients_match_reference(run):
+    gd = run['dig']['grads_step0']
+    gmax = max(np.sqrt(v['digest'][2]) for v in gd.values())
+    assert set(gd.keys()) <= set(run['grads'].keys())
+    for k, v in gd.items():
+        gr = run['grads'][k]
+        scale = max(np.sqrt(v['digest'][2]), 1e-4 * gmax)
+        head = gr.reshape(-1)[:8].double().numpy()
+        assert np.abs(head - np.array(v['head'])).max() < 2e-3 * scale + 1e-7, k
+        assert abs(np.sqrt(float((gr.double() ** 2).sum())) - np.sqrt(v['digest'][2])) < 2e-3 * scale + 1e-7, k
+    # tensors the reference never touches stay untouched here too (Appendix B-7)
+    for k in run['dig']['no_grad_params']:
+        assert k not in run['grads'] or float(run['grads'][k].abs().max()) == 0.0, k
+
+
+def test_two_optimizer_steps_match_reference(run):
+    g, dig = run['g'], run['dig']
+    assert abs(run['gn'][0] - g['grad_norms'][0]) < 2e-3 * g['grad_norms'][0]
+    assert abs(run['gn'][1] - g['grad_norms'][1]) < 5e-3 * g['grad_norms'][1]
+    assert abs(run['l1'] - g['losses'][1]) < 2e-3 * abs(g['losses'][1])
+    gd = dig['grads_step0']
+    gmax = max(np.sqrt(v['digest'][2]) for v in gd.values())
+    sd = run['eng'].model.state_dict()
+    for k, ref in dig['after_2_steps'].items():
+        if not sd[k].dtype.is_floating_point or 'running_' in k:
+            continue
+        tol = 2e-4 * ref[1] + 1e-6
+        if k in gd and np.sqrt(gd[k]['digest'][2]) < 1e-5 * gmax:
+            tol += 2 * 1e-3 * sd[k].numel()        # zero-gradient conv biases: Adam amplifies fp32 noise
+        assert abs(_digest(sd[k])[1] - ref[1]) <= tol, k
+    for k in dig['no_grad_params']:                 # dead tensors keep their initial value
+        assert _digest(sd[k]) == dig['init'][k], k
+    # BatchNorm buffers: 2 updates with momentum 0.1
+    assert int(sd['postnet.convolutions.0.1.num_batches_tracked']) == 2
+
+
+def test_checkpoint_interchange(run, golden_dir, tmp_path):
+    """save_checkpoint writes the reference's dict; torch.optim.Adam can load our optimizer state and
+    FlatAdam can load it back."""
+    import train as TR
+    with open(os.path.join(golden_dir, 'checkpoint_schema.json')) as f:
+        sch = json.load(f)
+    eng = run['eng']
+    path = str(tmp_path / 'checkpoint_1')
+    TR.save_checkpoint(eng.model, eng.optimizer, 1e-3, 1, path)
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    assert list(ck.keys()) == sch['top_keys']
+    assert [[k, list(v.shape), str(v.dtype).replace('torch.', '')] for k, v in ck['state_dict'].items()] == sch['state_dict']
+    osd = ck['optimizer']
+    assert sorted(osd['state'].keys()) == sch['optimizer_state_indices']
+    assert sorted(next(iter(osd['state'].values())).keys()) == sch['optimizer_state_keys']
+    assert len(osd['param_groups'][0]['params']) == sch['n_parameters']
+    # a stock torch Adam over a reference-layout model accepts it
+    import hparams as HP
+    import model as M
+    m2 = M.Tacotron2(HP.create_hparams())
+    m2.load_state_dict(ck['state_dict'])
+    adam = torch.optim.Adam(m2.parameters(), lr=1e-3, weight_decay=1e-6)
+    adam.load_state_dict(osd)
+    # and our optimiser round-trips its own file
+    before = eng.optimizer.exp_avg.clone()
+    eng.optimizer.exp_avg.zero_()
+    TR.load_checkpoint(path, eng.model, eng.optimizer)
+    assert torch.equal(eng.optimizer.exp_avg, before) and eng.optimizer.step_count == 2
+
+
+def test_fused_adam_matches_oracle_formula():
+    """k_sumsq + k_clip_adam vs the oracle's clip_grad_norm/adam_step on random tensors."""
+    import ctypes as C
+    import t2v_hip
+    import t2v_oracle as O
+    lib = t2v_hip.load_library()
+    n = 1000003
+    g = torch.Generator().manual_seed(0)
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.01
+    m, v = torch.randn(n, generator=g) * 0.01, torch.rand(n, generator=g) * 1e-4
+    clipped, total = O.clip_grad_norm([gr], 1.0)
+    p_ref, m_ref, v_ref = O.adam_step(p, clipped[0], m, v, 3)
+    dp, dg, dm, dv = (t.cuda() for t in (p, gr, m, v))
+    part, norm = torch.zeros(1024, device='cuda'), torch.zeros(1, device='cuda')
+    rc = lib.t2v_clip_adam_step(C.c_void_p(dp.data_ptr()), C.c_void_p(dg.data_ptr()), C.c_void_p(dm.data_ptr()),
+                                C.c_void_p(dv.data_ptr()), n, 1e-3, 0.9, 0.999, 1e-8, 1e-6, 1.0, 1.0, 3,
+                                C.c_void_p(part.data_ptr()), C.c_void_p(norm.data_ptr()),
+                                C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert abs(float(norm) - float(total)) < 1e-5 * float(total)
+    assert (dp.cpu() - p_ref).abs().max() < 2e-6
+    assert (dm.cpu() - m_ref).abs().max() < 1e-7 and (dv.cpu() - v_ref).abs().max() < 1e-9

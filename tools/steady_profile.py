@@ -1,0 +1,21 @@
+"""Aggregate a rocprofv3 kernel_trace.csv over the last N optimiser steps (steady state only)."""
+import csv, sys, collections
+path, nsteps = sys.argv[1], int(sys.argv[2])
+rows = []
+with open(path) as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
+rows.sort()
+adam = [i for i, r in enumerate(rows) if r[2].startswith('k_clip_adam')]
+lo, hi = adam[-nsteps - 1], adam[-1]
+sel = rows[lo + 1:hi + 1]
+agg = collections.defaultdict(lambda: [0, 0])
+for s, e, n in sel:
+    agg[n][0] += e - s
+    agg[n][1] += 1
+wall = (rows[hi][1] - rows[lo][1]) / nsteps / 1e6
+busy = sum(v[0] for v in agg.values()) / nsteps / 1e6
+print("steady state over %d steps: wall %.3f ms/step, GPU busy %.3f ms/step, %d launches/step" % (nsteps, wall, busy, len(sel) // nsteps))
+print("%-64s %8s %10s %9s" % ("kernel", "calls/st", "ms/step", "avg us"))
+for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(sys.argv[3]) if len(sys.argv) > 3 else 40]:
+    print("%-64s %8.1f %10.3f %9.2f" % (n[:64], c / nsteps, t / nsteps / 1e6, t / c / 1e3))
