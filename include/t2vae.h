@@ -123,6 +123,20 @@ int t2v_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_a
                        float max_norm, float inv_world, int step, float* partials,
                        float* norm_out, void* stream);
 
+/* ------------------------------------------------------------------ STFT -> mel front end
+ * TacotronSTFT.mel_spectrogram (layers.py:75-92): reflect pad n_fft/2, periodic-Hann STFT
+ * (stft.py:77-105), magnitude, mel filterbank, log(clamp(.,1e-5)) — batched, per-utterance lengths,
+ * zero fill past T_b = n_samples[b]/hop + 1 (the collate pad value, data_utils.py:126).
+ * Only n_fft = 1024, hop = 256, n_mel = 80 (T2V_ERR_DIMS otherwise).  Exactly one of wav_f32 /
+ * wav_i16 is non-NULL; `scale` multiplies the samples (1/max_wav_value for int16 PCM).
+ * Tables are built by the host mirror (layers.TacotronSTFT): window (1024), tw512 = exp(-2πik/512)
+ * as (512,2), tw1024 = exp(-2πik/1024) as (513,2), mel filter rows in CSR form. */
+int t2v_mel_frontend(const float* wav_f32, const int16_t* wav_i16, const int64_t* n_samples, int B,
+                     int n_stride, float scale, int n_fft, int hop, int n_mel, const float* window,
+                     const float* tw512, const float* tw1024, const int32_t* mel_start,
+                     const int32_t* mel_len, const float* mel_w, int maxw, float* mel_out,
+                     int t_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

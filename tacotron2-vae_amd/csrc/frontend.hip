@@ -1,0 +1,166 @@
+// STFT -> mel front end on device (reference layers.py:75-92 = STFT.transform stft.py:77-105 +
+// mel_basis matmul + dynamic_range_compression audio_processing.py:77-83), for the default
+// geometry n_fft = win = 1024, hop = 256, 80 mels.
+//
+// One wavefront per frame: reflect-padded, Hann-windowed 1024 real samples are packed as 512
+// complex points, transformed by a Stockham radix-8 FFT (3 passes, 64 lanes x 8 points, LDS
+// exchange inside the wave), untangled to the 513-bin real spectrum, |.|, sparse triangular mel
+// filters (CSR rows), log(clamp(.,1e-5)).  A workgroup of 4 waves produces 16 consecutive frames
+// so mel rows leave as 64-byte runs.  HBM-bound scan: 1 KiB of samples in, 320 B out per frame.
+#include "t2v_common.h"
+#include "t2v_kernels.h"
+
+#define FE_NFFT 1024
+#define FE_HOP 256
+#define FE_NMEL 80
+#define FE_FRAMES_PER_WG 16
+#define FE_WAVES 4
+
+struct c32 { float x, y; };
+__device__ __forceinline__ c32 cmul(c32 a, c32 b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ c32 csub(c32 a, c32 b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ c32 mul_mi(c32 a) { return {a.y, -a.x}; }   // a * (-i)
+
+// in-place 8-point DFT (forward, e^{-2 pi i/8}), outputs in natural order
+__device__ __forceinline__ void dft8(c32* v) {
+    const float h = 0.70710678118654752440f;
+    c32 a0 = cadd(v[0], v[4]), a1 = csub(v[0], v[4]);
+    c32 a2 = cadd(v[2], v[6]), a3 = mul_mi(csub(v[2], v[6]));
+    c32 a4 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
+    c32 a6 = cadd(v[3], v[7]), a7 = mul_mi(csub(v[3], v[7]));
+    c32 b0 = cadd(a0, a2), b2 = csub(a0, a2), b1 = cadd(a1, a3), b3 = csub(a1, a3);
+    c32 b4 = cadd(a4, a6), b6 = mul_mi(csub(a4, a6)), b5 = cadd(a5, a7), b7 = csub(a5, a7);
+    // twiddles W8^1 = h(1 - i), W8^3 = -h(1 + i)
+    c32 t5 = {h * (b5.x + b5.y), h * (b5.y - b5.x)};
+    c32 t7 = {h * (-b7.x + b7.y), h * (-b7.y - b7.x)};
+    v[0] = cadd(b0, b4); v[4] = csub(b0, b4);
+    v[2] = cadd(b2, b6); v[6] = csub(b2, b6);
+    v[1] = cadd(b1, t5); v[5] = csub(b1, t5);
+    v[3] = cadd(b3, t7); v[7] = csub(b3, t7);
+}
+
+struct FrontendArgs {
+    const float* wav_f32;        // (B, n_stride) or NULL
+    const int16_t* wav_i16;      // (B, n_stride) or NULL
+    const int64_t* n_samples;    // (B)
+    int n_stride;
+    float scale;                 // applied to the samples (1/32768 for int16 PCM)
+    const float* window;         // (1024) periodic Hann
+    const c32* tw512;            // (512)  exp(-2 pi i k/512)
+    const c32* tw1024;           // (513)  exp(-2 pi i k/1024)
+    const int* mel_start;        // (80)
+    const int* mel_len;          // (80)
+    const float* mel_w;          // (80, maxw)
+    int maxw;
+    float* mel_out;              // (B, 80, t_stride)
+    int t_stride;
+};
+
+__global__ __launch_bounds__(256) void k_mel_frontend(FrontendArgs a) {
+    __shared__ c32 zbuf[FE_WAVES][512];
+    __shared__ float mag[FE_WAVES][516];
+    __shared__ float tile[FE_NMEL][FE_FRAMES_PER_WG + 1];
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t n = a.n_samples[b];
+    const int T = (int)(n / FE_HOP) + 1;
+    const int t0 = blockIdx.x * FE_FRAMES_PER_WG;
+    c32* z = zbuf[wave];
+    float* mg = mag[wave];
+
+    for (int fi = wave; fi < FE_FRAMES_PER_WG; fi += FE_WAVES) {
+        const int t = t0 + fi;
+        if (t >= T) {            // beyond this utterance: the collate pad value is 0.0 (data_utils.py:126)
+            for (int m = lane; m < FE_NMEL; m += 64) tile[m][fi] = 0.f;
+            continue;
+        }
+        // ---- load + reflect pad (F.pad 'reflect' excludes the edge sample) + window, pack z = x[2n] + i x[2n+1]
+        c32 v[8];
+        const int64_t base = (int64_t)t * FE_HOP - FE_NFFT / 2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int nn = lane + 64 * k;
+            float s[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                int64_t p = base + 2 * nn + c;
+                if (p < 0) p = -p;
+                if (p >= n) p = 2 * (n - 1) - p;
+                const size_t off = (size_t)b * a.n_stride + (size_t)p;
+                const float x = a.wav_i16 ? (float)a.wav_i16[off] : a.wav_f32[off];
+                s[c] = x * a.scale * a.window[2 * nn + c];
+            }
+            v[k] = {s[0], s[1]};
+        }
+        // ---- 512-point complex FFT, Stockham radix-8: pass Ns = 1, 8, 64 (thread j = lane)
+        dft8(v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) z[lane * 8 + r] = v[r];            // j0 = j*8, stride Ns = 1
+        // pass 2: Ns = 8
+        {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = z[lane + 64 * r];
+            const int k = lane & 7;
+#pragma unroll
+            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], a.tw512[8 * k * r]);     // W_64^{k r}
+            dft8(v);
+            const int j0 = (lane >> 3) * 64 + k;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) z[j0 + 8 * r] = v[r];
+        }
+        // pass 3: Ns = 64
+        {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = z[lane + 64 * r];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], a.tw512[lane * r]);      // W_512^{k r}
+            dft8(v);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) z[lane + 64 * r] = v[r];
+        }
+        // ---- untangle to the real spectrum X[k], k = 0..512, magnitude
+        for (int k = lane; k <= 512; k += 64) {
+            const c32 zk = z[k & 511];
+            const c32 zc = z[(512 - k) & 511];
+            const c32 e = {0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y)};      // (Z[k] + conj Z[N-k]) / 2
+            const c32 o = {0.5f * (zk.x - zc.x), 0.5f * (zk.y + zc.y)};      // (Z[k] - conj Z[N-k]) / 2
+            const c32 wo = cmul(a.tw1024[k], o);
+            const c32 X = cadd(e, mul_mi(wo));                               // E - i W^k O
+            mg[k] = sqrtf(X.x * X.x + X.y * X.y);
+        }
+        // ---- sparse mel filterbank + log compression
+        for (int m = lane; m < FE_NMEL; m += 64) {
+            const int st = a.mel_start[m], ln = a.mel_len[m];
+            const float* w = a.mel_w + (size_t)m * a.maxw;
+            float acc = 0.f;
+            for (int i = 0; i < ln; ++i) acc = fmaf(w[i], mg[st + i], acc);
+            tile[m][fi] = logf(fmaxf(acc, 1e-5f));
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < FE_NMEL * FE_FRAMES_PER_WG; i += 256) {
+        const int m = i / FE_FRAMES_PER_WG, fi = i % FE_FRAMES_PER_WG;
+        const int t = t0 + fi;
+        if (t < a.t_stride) a.mel_out[((size_t)b * FE_NMEL + m) * a.t_stride + t] = tile[m][fi];
+    }
+}
+
+extern "C" int t2v_mel_frontend(const float* wav_f32, const int16_t* wav_i16, const int64_t* n_samples, int B,
+                                int n_stride, float scale, int n_fft, int hop, int n_mel, const float* window,
+                                const float* tw512, const float* tw1024, const int32_t* mel_start,
+                                const int32_t* mel_len, const float* mel_w, int maxw, float* mel_out,
+                                int t_stride, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_fft != FE_NFFT || hop != FE_HOP || n_mel != FE_NMEL) return T2V_ERR_DIMS;
+    if ((!wav_f32 && !wav_i16) || !n_samples || !window || !tw512 || !tw1024 || !mel_start || !mel_len || !mel_w ||
+        !mel_out || B < 1 || t_stride < 1)
+        return T2V_ERR_ARG;
+    FrontendArgs a;
+    a.wav_f32 = wav_f32; a.wav_i16 = wav_i16; a.n_samples = n_samples; a.n_stride = n_stride; a.scale = scale;
+    a.window = window; a.tw512 = (const c32*)tw512; a.tw1024 = (const c32*)tw1024;
+    a.mel_start = mel_start; a.mel_len = mel_len; a.mel_w = mel_w; a.maxw = maxw;
+    a.mel_out = mel_out; a.t_stride = t_stride;
+    dim3 grid((t_stride + FE_FRAMES_PER_WG - 1) / FE_FRAMES_PER_WG, B);
+    k_mel_frontend<<<grid, 256, 0, stream>>>(a);
+    return t2v_check_launch();
+}

@@ -38,7 +38,7 @@ class _DecBwdBufs(C.Structure):
 
 
 EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decoder_train_fwd',
-           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels')
+           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile')
 
 
 def lib_path():
@@ -69,6 +69,10 @@ def load_library():
     lib.t2v_clip_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float,
                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.t2v_mel_frontend.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,
+                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    lib.t2v_set_phase_profile.argtypes = [C.c_void_p]
     for name in EXPORTS:
         getattr(lib, name)
     _lib = lib
@@ -107,7 +111,7 @@ def replay_fwd_kernels(kernel_mask):
     W, Sb, (B, T_in, T, p_att, p_dec, seed), _keep = DecoderCore.last_call
     _check(load_library().t2v_decoder_replay_fwd_kernels(C.byref(W), C.byref(Sb), B, T_in, T, p_att, p_dec,
                                                          seed, int(kernel_mask), _stream()),
-           't2v_decoder_replay_fwd_kernels')
+           't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile')
     return T + 1 if kernel_mask == 1 else T
 
 
@@ -220,3 +224,24 @@ class DecoderCore(torch.autograd.Function):
                                   apad.view(TB, 2, T_in + 30).unfold(2, KS, 1))
         return (DGA, d_memory, d_pm, None, d_w_ih_att, d_w_hh_att, d_w_ih_dec, d_w_hh_dec, d_bias_dec,
                 d_wq, d_loc_conv, d_loc_dense, d_v, None, None, None)
+
+
+def mel_frontend(wav, n_samples, tables, scale=1.0, t_stride=None):
+    """Batched STFT→mel on device.  wav: (B,N) float32 or int16 CUDA tensor; n_samples: (B) int64.
+    tables: dict from layers.TacotronSTFT (device tensors).  Returns (B,80,T_max) float32."""
+    lib = _require_gpu(wav)
+    B, N = wav.shape
+    wav = wav.contiguous()
+    n_samples = n_samples.to(device=wav.device, dtype=torch.int64).contiguous()
+    if t_stride is None:
+        t_stride = int(n_samples.max().item()) // 256 + 1
+    out = torch.empty(B, 80, t_stride, device=wav.device, dtype=torch.float32)
+    is16 = wav.dtype == torch.int16
+    if not is16 and wav.dtype != torch.float32:
+        raise T2VHipError("mel_frontend takes float32 or int16 samples")
+    _check(lib.t2v_mel_frontend(None if is16 else _p(wav), _p(wav) if is16 else None, _p(n_samples), B, N,
+                                float(scale), 1024, 256, 80, _p(tables['window']), _p(tables['tw512']),
+                                _p(tables['tw1024']), _p(tables['mel_start']), _p(tables['mel_len']),
+                                _p(tables['mel_w']), int(tables['maxw']), _p(out), t_stride, _stream()),
+           't2v_mel_frontend')
+    return out
