@@ -112,6 +112,34 @@ int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
                           const t2v_dec_bwd_bufs* g, int B, int T_in, int T_out,
                           float p_att, float p_dec, uint64_t seed, void* stream);
 
+/* ------------------------------------------------------------------ free-running decode
+ * Decoder.inference (model.py:428-464) == the synthesizer loop (synthesizer.py:139-154): steps
+ * t_begin..t_end-1, each = attention_rnn → attention → decoder_rnn → 80-mel/gate projection → Prenet of
+ * the new frame (dropout p_prenet stays on at inference, model.py:101).  The caller runs chunks and reads
+ * `stop_flag` (first t with sigmoid(gate) > gate_threshold for every item, INT_MAX if none) between
+ * them.  external_prenet != 0: PRE[t] is supplied by the caller for every step (the per-step
+ * `decoder.prenet(x)` + `decoder.decode(x)` call sequence) and no Prenet is evaluated here.
+ * Arena rows as in t2v_dec_train_bufs (XS (Tmax+2,B,2560) rows 0,1 zeroed; CA/CD/AL/ACUM row 0 zeroed);
+ * PRE[0] = Prenet(go frame) is written by the caller.  B <= 8. */
+typedef struct t2v_dec_infer_bufs {
+    const float* memory;     /* (B,T_in,512) */
+    const float* pm;         /* (B,T_in,128) */
+    const int32_t* lengths;  /* NULL at inference (mask=None, model.py:441) */
+    float* XS; float* CA; float* CD; float* QP; float* AL; float* ACUM;
+    float* PRE;              /* (Tmax+1,B,256) prenet outputs */
+    float* MEL;              /* (Tmax,B,80) out */
+    float* GATE;             /* (Tmax,B)    out */
+    int32_t* stop_flag;      /* (1) */
+    const float* prenet_w0;  /* (256,80)  */
+    const float* prenet_w1;  /* (256,256) */
+    const float* proj_w;     /* (81,1536) rows 0..79 = linear_projection, row 80 = gate_layer */
+    const float* proj_b;     /* (81) */
+} t2v_dec_infer_bufs;
+
+int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_infer_bufs* s, int B, int T_in,
+                            int t_begin, int t_end, float gate_threshold, float p_prenet,
+                            int external_prenet, uint64_t seed, void* stream);
+
 /* ------------------------------------------------------------------ optimiser
  * clip_grad_norm_(params, max_norm) + Adam.step() of the reference loop (train.py:226-229,
  * Adam built at train.py:171-172) fused over one flat fp32 arena.  `grads` holds the SUM over

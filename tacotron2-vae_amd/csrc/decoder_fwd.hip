@@ -52,8 +52,9 @@ __global__ void k_pack_bwd(const float* __restrict__ W, int K, int ncols, float4
 // wave issues ALL of its weight/x loads (26 x 1 KiB) before the first MFMA — the kernel is a
 // pure weight stream (262 KB per CU per launch) and needs the bytes in flight, not occupancy.
 #define LSTM_WAVES 16
-template <bool INFER>
+template <int MODE>   // 0: both cells (training, skewed); 1: attention_rnn only, prenet columns in K; 2: decoder_rnn only
 __global__ __launch_bounds__(1024) void k_lstm_fwd(LstmFwdArgs a) {
+    constexpr bool INFER = MODE == 1;
     const int w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = lane & 15, g = lane >> 4;
     const bool bvalid = b < a.B;
@@ -89,13 +90,15 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(LstmFwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             xs[i] = *(const float4*)(xrow + 16 * (kb0 + i));   // lanes b>=B read row 0: their D columns are never used
-            wa[i] = pa[(size_t)(kb0 + i) * 64];   // unconditional: both cells are always computed,
-            wd[i] = pd[(size_t)(kb0 + i) * 64];   // do_att/do_dec only gate the cell update (t=0 / t=T)
+            if (MODE != 2) wa[i] = pa[(size_t)(kb0 + i) * 64];   // training: both cells are always computed,
+            if (MODE != 1) wd[i] = pd[(size_t)(kb0 + i) * 64];   // do_att/do_dec only gate the cell update (t=0 / t=T)
         }
+        if (MODE != 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            xr[i] = *(const float4*)(xrow + 16 * (kr0 + i));
-            wr[i] = pd[(size_t)(kr0 + i) * 64];
+            for (int i = 0; i < 4; ++i) {
+                xr[i] = *(const float4*)(xrow + 16 * (kr0 + i));
+                wr[i] = pd[(size_t)(kr0 + i) * 64];
+            }
         }
     }
     float4 xp = z4, wp = z4;
@@ -105,10 +108,15 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(LstmFwdArgs a) {
         wp = pa[(size_t)(96 + wave) * 64];
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { MFMA4(accA, wa[i], xs[i]); MFMA4(accD, wd[i], xs[i]); }
+    for (int i = 0; i < 6; ++i) {
+        if (MODE != 2) { MFMA4(accA, wa[i], xs[i]); }
+        if (MODE != 1) { MFMA4(accD, wd[i], xs[i]); }
+    }
     if (INFER) { MFMA4(accA, wp, xp); }
+    if (MODE != 1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { MFMA4(accD, wr[i], xr[i]); }
+        for (int i = 0; i < 4; ++i) { MFMA4(accD, wr[i], xr[i]); }
+    }
     red[0][wave][lane] = accA;
     red[1][wave][lane] = accD;
     // query partial: thread (bb = tid>>7, d = tid&127) for bb < B; its 4 query-weight values are
@@ -387,6 +395,9 @@ extern "C" int t2v_pack_lstm_weights(const float* wcat_att, int k_att, const flo
 }
 
 #define ATT_THREADS_HOST 512
+void t2v_launch_lstm_fwd(int mode, const LstmFwdArgs& a, hipStream_t stream);
+void t2v_launch_attn_fwd(const AttnFwdArgs& f, int B, int T_in, hipStream_t stream);
+
 size_t t2v_attn_fwd_lds(int T_in) {
     const int TpH = T_in + 30;
     return sizeof(float) * (T2V_A + 2 * TpH + T2V_F * T_in + ((T_in + 3) & ~3) + T2V_F * 63 + ATT_THREADS + 8 * T_in + 8);
@@ -432,7 +443,7 @@ static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
         a.p_att = p_att;
         a.p_dec = p_dec;
         a.seed = seed;
-        if (mask & 1) k_lstm_fwd<false><<<T2V_NWG, 1024, 0, stream>>>(a);
+        if (mask & 1) k_lstm_fwd<0><<<T2V_NWG, 1024, 0, stream>>>(a);
         if (t < T_out && (mask & 2)) {
             AttnFwdArgs f;
             f.qp = s->QP;
@@ -469,4 +480,17 @@ extern "C" int t2v_decoder_replay_fwd_kernels(const t2v_dec_weights* w, const t2
                                               int B, int T_in, int T_out, float p_att, float p_dec,
                                               uint64_t seed, int kernel_mask, void* stream_) {
     return launch_train_fwd(w, s, B, T_in, T_out, p_att, p_dec, seed, stream_, kernel_mask & 3);
+}
+
+void t2v_launch_lstm_fwd(int mode, const LstmFwdArgs& a, hipStream_t stream) {
+    if (mode == 1) k_lstm_fwd<1><<<T2V_NWG, 1024, 0, stream>>>(a);
+    else if (mode == 2) k_lstm_fwd<2><<<T2V_NWG, 1024, 0, stream>>>(a);
+    else k_lstm_fwd<0><<<T2V_NWG, 1024, 0, stream>>>(a);
+}
+void t2v_launch_attn_fwd(const AttnFwdArgs& f, int B, int T_in, hipStream_t stream) {
+    const size_t lds = t2v_attn_fwd_lds(T_in);
+    const int SE = 4;
+    if (T_in <= 22 * ATT_R) ATF_LAUNCH(22, 6);
+    else if (T_in <= 32 * ATT_R) ATF_LAUNCH(32, 8);
+    else ATF_LAUNCH(64, 16);
 }

@@ -10,6 +10,10 @@ enum { T2V_RNG_ATT_H = 1, T2V_RNG_ATT_C = 2, T2V_RNG_DEC_H = 3, T2V_RNG_DEC_C = 
 int t2v_check_launch();
 extern unsigned long long* g_t2v_prof;   // device buffer of 32 u64 or NULL (t2v_set_phase_profile)                 // records hipGetLastError() for t2v_last_error()
 size_t t2v_attn_fwd_lds(int T_in);
+struct LstmFwdArgs;
+struct AttnFwdArgs;
+void t2v_launch_lstm_fwd(int mode, const LstmFwdArgs& a, hipStream_t stream);
+void t2v_launch_attn_fwd(const AttnFwdArgs& f, int B, int T_in, hipStream_t stream);
 
 struct LstmFwdArgs {
     const float4* packA;

@@ -162,6 +162,71 @@ class Decoder(nn.Module):
                 a.query_layer.weight, a.location_layer.location_conv.conv.weight,
                 a.location_layer.location_dense.weight, a.v.weight)
 
+    # -- free-running decode ------------------------------------------------------------------
+    def _session(self, memory, mask, max_steps):
+        att, dec, al = self.attention_rnn, self.decoder_rnn, self.attention_layer
+        lengths = None if mask is None else (~mask).sum(1).to(device=memory.device, dtype=torch.int32)
+        pm = al.memory_layer(memory)
+        return t2v_hip.InferenceSession(
+            memory, pm, lengths, att.weight_ih, att.weight_hh, att.bias_ih + att.bias_hh, dec.weight_ih,
+            dec.weight_hh, dec.bias_ih + dec.bias_hh, al.query_layer.weight,
+            al.location_layer.location_conv.conv.weight, al.location_layer.location_dense.weight, al.v.weight,
+            self.prenet.layers[0].weight, self.prenet.layers[1].weight, self.linear_projection.weight,
+            self.linear_projection.bias, self.gate_layer.weight, self.gate_layer.bias, max_steps)
+
+    def initialize_decoder_states(self, memory, mask):
+        """reference model.py:260-291 — zero states; stores memory / processed memory / mask."""
+        self._sess = self._session(memory, mask, self.max_decoder_steps)
+        self.memory, self.processed_memory, self.mask = memory, self._sess.pm, mask
+        B = memory.size(0)
+        z = lambda n: memory.new_zeros(B, n)
+        self.attention_hidden, self.attention_cell = z(self.attention_rnn_dim), z(self.attention_rnn_dim)
+        self.decoder_hidden, self.decoder_cell = z(self.decoder_rnn_dim), z(self.decoder_rnn_dim)
+        self.attention_weights, self.attention_weights_cum = z(memory.size(1)), z(memory.size(1))
+        self.attention_context = z(self.encoder_embedding_dim)
+
+    def decode(self, decoder_input):
+        """One step from a prenet output (reference model.py:346-389): returns (mel (B,80), gate (B,1),
+        attention weights (B,T_in)) and refreshes the state attributes the reference exposes."""
+        s = self._sess
+        t = s.t
+        if t >= s.max_steps:
+            raise RuntimeError("decode() called past max_decoder_steps")
+        s.PRE[t].copy_(decoder_input)
+        s.run(t, t + 1, self.gate_threshold, 0.0, True, 0)
+        s.t = t + 1
+        x1, x2 = s.XS[t + 1], s.XS[t + 2]
+        self.attention_hidden, self.attention_context = x1[:, :1024], x1[:, 1024:1536]
+        self.decoder_hidden = x2[:, 1536:]
+        self.attention_cell, self.decoder_cell = s.CA[t + 1], s.CD[t + 1]
+        self.attention_weights, self.attention_weights_cum = s.AL[t + 1], s.ACUM[t + 1]
+        return s.MEL[t], s.GATE[t].unsqueeze(1), s.AL[t + 1]
+
+    def inference(self, memory, chunk=32):
+        """reference model.py:428-464: decode until sigmoid(gate) > gate_threshold or max_decoder_steps.
+        The loop runs on the GPU in chunks of `chunk` frames between stop-flag reads."""
+        self.initialize_decoder_states(memory, mask=None)
+        s = self._sess
+        s.PRE[0].copy_(self.prenet(self.get_go_frame(memory)))
+        self._calls += 1
+        seed = (int(self.dropout_seed) * 1000003 + self._calls) & 0x7FFFFFFFFFFFFFFF
+        n, t = None, 0
+        while t < s.max_steps:
+            t1 = min(s.max_steps, t + chunk)
+            s.run(t, t1, self.gate_threshold, drop_rate, False, seed)
+            stop = int(s.stop.item())
+            if stop < t1:
+                n = stop + 1
+                break
+            t = t1
+        if n is None:
+            print("Warning! Reached max decoder steps")
+            n = s.max_steps
+        s.t = n
+        mel = s.MEL[:n].permute(1, 2, 0).contiguous()           # (B,80,T)
+        gate = s.GATE[:n].transpose(0, 1).unsqueeze(-1).contiguous()   # (B,T,1)
+        return mel, gate, s.AL[1:n + 1].transpose(0, 1)
+
     def forward(self, memory, decoder_inputs, memory_lengths):
         """Teacher-forced pass (reference model.py:391-426).  Returns mel (B,80,T), gate (B,T),
         alignments (B,T,T_in)."""

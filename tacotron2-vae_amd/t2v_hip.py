@@ -37,8 +37,14 @@ class _DecBwdBufs(C.Structure):
         'dHC', 'DGA', 'DGD', 'DQ', 'DCTX', 'DC', 'YD', 'YA', 'DCA', 'DCD', 'GPREV', 'GCUM', 'DV')]
 
 
+class _DecInferBufs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        'memory', 'pm', 'lengths', 'XS', 'CA', 'CD', 'QP', 'AL', 'ACUM', 'PRE', 'MEL', 'GATE', 'stop_flag',
+        'prenet_w0', 'prenet_w1', 'proj_w', 'proj_b')]
+
+
 EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decoder_train_fwd',
-           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile')
+           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps')
 
 
 def lib_path():
@@ -73,6 +79,8 @@ def load_library():
                                      C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.t2v_set_phase_profile.argtypes = [C.c_void_p]
+    lib.t2v_decoder_infer_steps.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecInferBufs), C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_float, C.c_float, C.c_int, C.c_uint64, C.c_void_p]
     for name in EXPORTS:
         getattr(lib, name)
     _lib = lib
@@ -111,7 +119,7 @@ def replay_fwd_kernels(kernel_mask):
     W, Sb, (B, T_in, T, p_att, p_dec, seed), _keep = DecoderCore.last_call
     _check(load_library().t2v_decoder_replay_fwd_kernels(C.byref(W), C.byref(Sb), B, T_in, T, p_att, p_dec,
                                                          seed, int(kernel_mask), _stream()),
-           't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile')
+           't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps')
     return T + 1 if kernel_mask == 1 else T
 
 
@@ -245,3 +253,55 @@ def mel_frontend(wav, n_samples, tables, scale=1.0, t_stride=None):
                                 _p(tables['mel_w']), int(tables['maxw']), _p(out), t_stride, _stream()),
            't2v_mel_frontend')
     return out
+
+
+class InferenceSession(object):
+    """Arena + packed weights of one free-running decode (Decoder.inference / the per-step
+    initialize_decoder_states → prenet → decode call sequence of synthesizer.py:135-154)."""
+    INT_MAX = 2 ** 31 - 1
+
+    def __init__(self, memory, pm, lengths, w_ih_att, w_hh_att, b_att, w_ih_dec, w_hh_dec, b_dec, wq, loc_conv,
+                 loc_dense, v, prenet_w0, prenet_w1, proj_w, proj_b, gate_w, gate_b, max_steps):
+        lib = _require_gpu(memory, pm, w_ih_att)
+        B, T_in, _ = memory.shape
+        if B > 8:
+            raise T2VHipError("free-running decode supports B <= 8")
+        dev = memory.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.B, self.T_in, self.max_steps = B, T_in, int(max_steps)
+        T = self.max_steps
+        self.memory, self.pm, self.lengths = _f32c(memory.detach()), _f32c(pm.detach()), lengths
+        wcat_att = torch.cat((w_hh_att, w_ih_att[:, PRE:], w_ih_att[:, :PRE]), 1).detach().contiguous()   # (4096,1792)
+        wcat_dec = torch.cat((w_ih_dec, w_hh_dec), 1).detach().contiguous()
+        self.packF_att, self.packF_dec = torch.empty_like(wcat_att), torch.empty_like(wcat_dec)
+        _check(lib.t2v_pack_lstm_weights(_p(wcat_att), KATT_INF, _p(wcat_dec), _p(self.packF_att), _p(self.packF_dec),
+                                         None, None, _stream()), 't2v_pack_lstm_weights')
+        self.b_att, self.b_dec = _f32c(b_att.detach()), _f32c(b_dec.detach())
+        self.wqT = wq.detach().t().contiguous()
+        self.loc_conv, self.loc_dense = _f32c(loc_conv.detach()), _f32c(loc_dense.detach())
+        self.v = _f32c(v.detach()).view(-1)
+        self.w0, self.w1 = _f32c(prenet_w0.detach()), _f32c(prenet_w1.detach())
+        self.proj_w = torch.cat((proj_w, gate_w), 0).detach().contiguous()      # (81,1536)
+        self.proj_b = torch.cat((proj_b, gate_b), 0).detach().contiguous()
+        self.XS = torch.empty(T + 2, B, XW, **f32); self.XS[0:2].zero_()
+        self.CA = torch.empty(T + 1, B, H, **f32); self.CA[0].zero_()
+        self.CD = torch.empty(T + 1, B, H, **f32); self.CD[0].zero_()
+        self.QP = torch.empty(B, 256, A, **f32)
+        self.AL = torch.empty(T + 1, B, T_in, **f32); self.AL[0].zero_()
+        self.ACUM = torch.empty(T + 1, B, T_in, **f32); self.ACUM[0].zero_()
+        self.PRE = torch.empty(T + 1, B, PRE, **f32)
+        self.MEL = torch.empty(T, B, 80, **f32)
+        self.GATE = torch.empty(T, B, **f32)
+        self.stop = torch.full((1,), self.INT_MAX, device=dev, dtype=torch.int32)
+        self.W = _DecWeights(_p(self.packF_att), _p(self.packF_dec), None, None, _p(self.b_att), _p(self.b_dec),
+                             _p(self.wqT), _p(self.loc_conv), _p(self.loc_dense), _p(self.v))
+        self.S = _DecInferBufs(_p(self.memory), _p(self.pm), _p(self.lengths), _p(self.XS), _p(self.CA), _p(self.CD),
+                               _p(self.QP), _p(self.AL), _p(self.ACUM), _p(self.PRE), _p(self.MEL), _p(self.GATE),
+                               _p(self.stop), _p(self.w0), _p(self.w1), _p(self.proj_w), _p(self.proj_b))
+        self.t = 0
+
+    def run(self, t0, t1, gate_threshold, p_prenet, external_prenet, seed):
+        _check(load_library().t2v_decoder_infer_steps(C.byref(self.W), C.byref(self.S), self.B, self.T_in, int(t0),
+                                                      int(t1), float(gate_threshold), float(p_prenet),
+                                                      int(bool(external_prenet)), int(seed), _stream()),
+               't2v_decoder_infer_steps')
