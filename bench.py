@@ -55,9 +55,11 @@ def synthetic_batch(B, T_in, T_out, seed, lens_in=None, lens_out=None):
             emotions)
 
 
-def cpu_baseline(steps=2, warmup=1):
+def cpu_baseline(steps=2, warmup=1, threads=None):
     """Oracle train step (fwd+loss+bwd+clip+Adam) on host cores, same workload, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    if threads:
+        torch.set_num_threads(threads)
     import t2v_oracle as O
     import hparams as HP
     import model as M
@@ -100,6 +102,38 @@ def cpu_baseline(steps=2, warmup=1):
                       "oracle/t2v_oracle.py with stock torch CPU fp32 ops, dropout on" % (steps, warmup)}
 
 
+def decode_bench(model, T_in=200, steps=800):
+    """BASELINE.json configs[3]: B=1, 200-symbol utterance, exactly `steps` free-running decoder steps
+    (gate ignored), style = fc3(z), z ~ N(0,I) seed 7.  Secondary figure: frames/s of the decode loop."""
+    import model as M
+    dec = model.decoder
+    g = torch.Generator().manual_seed(1234)
+    ids = torch.randint(2, 80, (1, T_in), generator=g).cuda()
+    z = torch.randn(1, 32, generator=torch.Generator().manual_seed(7)).cuda()
+    was_training = model.training
+    model.eval()
+    old_steps, old_thr = dec.max_decoder_steps, dec.gate_threshold
+    dec.max_decoder_steps, dec.gate_threshold = steps, 1.0          # never stop early
+    try:
+        with torch.no_grad():
+            enc = model.encoder.inference(model.transcript_embedding(ids).transpose(1, 2))
+            memory = enc + model.vae_gst.fc3(z).unsqueeze(1)
+            import contextlib, io
+            with contextlib.redirect_stdout(io.StringIO()):
+                dec.inference(memory, chunk=steps)                  # warm-up
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                mel, _, _ = dec.inference(memory, chunk=steps)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+    finally:
+        dec.max_decoder_steps, dec.gate_threshold = old_steps, old_thr
+        if was_training:
+            model.train()
+    return {"frames_per_s": round(steps / dt, 1), "us_per_frame": round(1e6 * dt / steps, 2), "B": 1, "T_in": T_in,
+            "steps": steps, "note": "decoder loop only (incl. weight packing + memory_layer); encoder/postnet excluded"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -107,6 +141,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-threads', type=int, default=8,
+                    help='torch CPU threads for the baseline leg (the M=6 GEMVs of this model stop scaling\n'
+                         'around 8 threads on this EPYC host: 8 → 3.7 s/it, 16 → 4.2, 32 → 7.4, all cores ≈ 40)')
+    ap.add_argument('--no-decode', action='store_true')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -189,8 +227,10 @@ def main():
                            "algorithmic_bytes_per_launch": LSTM_WEIGHT_BYTES, "launches_timed": n}
         e2e_bytes = 58.9e9   # compulsory bytes of one cfg-2 iteration
         out["roofline"]["end_to_end_frac"] = round(e2e_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if not args.no_decode:
+            out["decode"] = decode_bench(engine.model)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(steps=args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(steps=args.cpu_steps, threads=args.cpu_threads)
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
     if world > 1:

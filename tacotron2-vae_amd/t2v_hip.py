@@ -119,7 +119,7 @@ def replay_fwd_kernels(kernel_mask):
     W, Sb, (B, T_in, T, p_att, p_dec, seed), _keep = DecoderCore.last_call
     _check(load_library().t2v_decoder_replay_fwd_kernels(C.byref(W), C.byref(Sb), B, T_in, T, p_att, p_dec,
                                                          seed, int(kernel_mask), _stream()),
-           't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps')
+           't2v_decoder_replay_fwd_kernels')
     return T + 1 if kernel_mask == 1 else T
 
 
