@@ -140,6 +140,31 @@ int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_infer_bufs* 
                             int t_begin, int t_end, float gate_threshold, float p_prenet,
                             int external_prenet, uint64_t seed, void* stream);
 
+/* ------------------------------------------------------------------ Conv1d + BatchNorm1d + activation
+ * The encoder conv bank (model.py:159-177) and the Postnet (model.py:110-148): stride-1 "same" Conv1d as
+ * an implicit GEMM on fp32 MFMA, BatchNorm1d (train: biased batch statistics over B*T incl. padded frames;
+ * eval: running statistics), tanh / ReLU / none, dropout.  All activations are (B, C, T) fp32.
+ *   t2v_conv1d_fwd : Y = conv(X, W) + bias; stat_part ((t2v_conv1d_stat_blocks(B,T), Cout, 2) or NULL)
+ *                    receives per-column-block partial [sum, sum of squares] per channel.
+ *   t2v_bn_act_fwd : out = dropout(act(BN(y)));  act 0 none / 1 tanh / 2 relu.  training != 0 finalises
+ *                    the statistics from stat_part, writes mean/rstd for the backward and updates the
+ *                    running buffers (momentum, unbiased variance).
+ *   t2v_bn_act_bwd : dy (grad wrt the conv output), dgamma, dbeta from dout.
+ *   t2v_conv1d_bwd : dX (may be NULL; needs Wt_scratch of W's size) and dW (may be NULL). */
+int t2v_conv1d_stat_blocks(int B, int T);
+int t2v_conv1d_fwd(const float* W, const float* X, const float* bias, float* Y, float* stat_part,
+                   int B, int Cin, int T, int Cout, int KS, void* stream);
+int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, float* dX, float* dW, float* Wt_scratch,
+                   int B, int Cin, int T, int Cout, int KS, void* stream);
+int t2v_bn_act_fwd(const float* y, const float* stat_part, int nblk, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float* mean_out, float* rstd_out, float* out,
+                   int B, int M, int T, int act, int training, float p_drop, float momentum, float eps,
+                   uint64_t seed, uint32_t rng_stream, uint32_t rng_t, void* stream);
+int t2v_bn_act_bwd(const float* y, const float* dout, const float* mean, const float* rstd,
+                   const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta,
+                   int B, int M, int T, int act, float p_drop, uint64_t seed, uint32_t rng_stream,
+                   uint32_t rng_t, void* stream);
+
 /* ------------------------------------------------------------------ optimiser
  * clip_grad_norm_(params, max_norm) + Adam.step() of the reference loop (train.py:226-229,
  * Adam built at train.py:171-172) fused over one flat fp32 arena.  `grads` holds the SUM over

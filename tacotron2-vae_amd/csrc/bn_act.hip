@@ -1,0 +1,152 @@
+// BatchNorm1d (+ tanh / ReLU / identity) (+ dropout) around the implicit-GEMM conv, forward and backward.
+// One workgroup per channel: a channel's B*T values are contiguous runs of T floats, the statistics are
+// block reductions in a fixed order (deterministic), nothing is atomically accumulated.
+// Reference semantics: nn.BatchNorm1d in train mode = biased batch variance over (B,T) INCLUDING padded
+// positions, eps 1e-5, running stats momentum 0.1 with unbiased variance;
+// F.dropout(act(bn(conv(x))), 0.5, training) (model.py:143-148, 175-177).
+#include "t2v_common.h"
+#include "t2v_kernels.h"
+
+enum { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2 };
+
+__device__ __forceinline__ float block_sum_256(float v, float* scr) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scr[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (scr[0] + scr[1]) + (scr[2] + scr[3]);
+}
+
+struct BnFwdArgs {
+    const float* y;          // conv output (B,M,T)
+    const float* stat_part;  // (nblk,M,2) from the conv epilogue
+    int nblk;
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var;
+    float* mean_out; float* rstd_out;     // (M) saved for backward
+    float* out;              // (B,M,T)
+    int B, M, T, act, training;
+    float p_drop, momentum, eps;
+    uint64_t seed; uint32_t rng_stream, rng_t;
+};
+
+__global__ __launch_bounds__(256) void k_bn_act_fwd(BnFwdArgs a) {
+    const int m = blockIdx.x, tid = threadIdx.x;
+    float mean, rstd;
+    if (a.training) {
+        // finalize the statistics: every thread sums the partials in the same order
+        double s = 0.0, q = 0.0;
+        for (int i = 0; i < a.nblk; ++i) {
+            s += (double)a.stat_part[((size_t)i * a.M + m) * 2];
+            q += (double)a.stat_part[((size_t)i * a.M + m) * 2 + 1];
+        }
+        const double n = (double)a.B * a.T;
+        const double mu = s / n;
+        double var = q / n - mu * mu;
+        if (var < 0.0) var = 0.0;
+        mean = (float)mu;
+        rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+        if (tid == 0) {
+            a.mean_out[m] = mean;
+            a.rstd_out[m] = rstd;
+            a.running_mean[m] = (1.f - a.momentum) * a.running_mean[m] + a.momentum * mean;
+            a.running_var[m] = (1.f - a.momentum) * a.running_var[m] + a.momentum * (float)(var * n / (n - 1.0));
+        }
+    } else {
+        mean = a.running_mean[m];
+        rstd = 1.0f / sqrtf(a.running_var[m] + a.eps);
+    }
+    const float g = a.gamma[m] * rstd, bt = a.beta[m] - mean * a.gamma[m] * rstd;
+    for (int b = 0; b < a.B; ++b) {
+        const size_t base = ((size_t)b * a.M + m) * a.T;
+        for (int t = tid; t < a.T; t += 256) {
+            float z = fmaf(a.y[base + t], g, bt);
+            if (a.act == ACT_TANH) z = tanhf_(z);
+            else if (a.act == ACT_RELU) z = fmaxf(z, 0.f);
+            if (a.training && a.p_drop > 0.f) z *= t2v_drop_scale(a.seed, a.rng_stream, a.rng_t, (uint32_t)(base + t), a.p_drop);
+            a.out[base + t] = z;
+        }
+    }
+}
+
+struct BnBwdArgs {
+    const float* y;          // conv output (B,M,T)
+    const float* dout;       // grad wrt the block output (B,M,T)
+    const float* mean; const float* rstd; const float* gamma; const float* beta;
+    float* dy;               // grad wrt the conv output (B,M,T)
+    float* dgamma; float* dbeta;   // (M)
+    int B, M, T, act;
+    float p_drop;
+    uint64_t seed; uint32_t rng_stream, rng_t;
+};
+
+__device__ __forceinline__ float bn_dz(const BnBwdArgs& a, size_t idx, float g, float bt, float& xhat, float mean, float rstd) {
+    const float yv = a.y[idx];
+    xhat = (yv - mean) * rstd;
+    float d = a.dout[idx];
+    if (a.p_drop > 0.f) d *= t2v_drop_scale(a.seed, a.rng_stream, a.rng_t, (uint32_t)idx, a.p_drop);
+    const float z = fmaf(yv, g, bt);
+    if (a.act == ACT_TANH) { const float th = tanhf_(z); d *= 1.0f - th * th; }
+    else if (a.act == ACT_RELU) { d = z > 0.f ? d : 0.f; }
+    return d;
+}
+
+__global__ __launch_bounds__(256) void k_bn_act_bwd(BnBwdArgs a) {
+    __shared__ float scr[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const float mean = a.mean[m], rstd = a.rstd[m], gam = a.gamma[m];
+    const float g = gam * rstd, bt = a.beta[m] - mean * gam * rstd;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+        const size_t base = ((size_t)b * a.M + m) * a.T;
+        for (int t = tid; t < a.T; t += 256) {
+            float xhat;
+            const float dz = bn_dz(a, base + t, g, bt, xhat, mean, rstd);
+            s1 += dz;
+            s2 = fmaf(dz, xhat, s2);
+        }
+    }
+    const float S1 = block_sum_256(s1, scr);
+    const float S2 = block_sum_256(s2, scr);
+    if (tid == 0) { a.dbeta[m] = S1; a.dgamma[m] = S2; }
+    const float n = (float)a.B * (float)a.T;
+    const float m1 = S1 / n, m2 = S2 / n;
+    for (int b = 0; b < a.B; ++b) {
+        const size_t base = ((size_t)b * a.M + m) * a.T;
+        for (int t = tid; t < a.T; t += 256) {
+            float xhat;
+            const float dz = bn_dz(a, base + t, g, bt, xhat, mean, rstd);
+            a.dy[base + t] = g * (dz - m1 - xhat * m2);
+        }
+    }
+}
+
+extern "C" int t2v_bn_act_fwd(const float* y, const float* stat_part, int nblk, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float* mean_out, float* rstd_out, float* out,
+                              int B, int M, int T, int act, int training, float p_drop, float momentum, float eps,
+                              uint64_t seed, uint32_t rng_stream, uint32_t rng_t, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!y || !gamma || !beta || !running_mean || !running_var || !out || B < 1 || M < 1 || T < 1) return T2V_ERR_ARG;
+    if (training && (!stat_part || !mean_out || !rstd_out || (long)B * T < 2)) return T2V_ERR_ARG;
+    BnFwdArgs a;
+    a.y = y; a.stat_part = stat_part; a.nblk = nblk; a.gamma = gamma; a.beta = beta;
+    a.running_mean = running_mean; a.running_var = running_var; a.mean_out = mean_out; a.rstd_out = rstd_out;
+    a.out = out; a.B = B; a.M = M; a.T = T; a.act = act; a.training = training; a.p_drop = p_drop;
+    a.momentum = momentum; a.eps = eps; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t;
+    k_bn_act_fwd<<<M, 256, 0, stream>>>(a);
+    return t2v_check_launch();
+}
+
+extern "C" int t2v_bn_act_bwd(const float* y, const float* dout, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta,
+                              int B, int M, int T, int act, float p_drop, uint64_t seed, uint32_t rng_stream,
+                              uint32_t rng_t, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!y || !dout || !mean || !rstd || !gamma || !beta || !dy || !dgamma || !dbeta) return T2V_ERR_ARG;
+    BnBwdArgs a;
+    a.y = y; a.dout = dout; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.dy = dy;
+    a.dgamma = dgamma; a.dbeta = dbeta; a.B = B; a.M = M; a.T = T; a.act = act; a.p_drop = p_drop;
+    a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t;
+    k_bn_act_bwd<<<M, 256, 0, stream>>>(a);
+    return t2v_check_launch();
+}

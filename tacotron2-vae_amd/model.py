@@ -62,6 +62,19 @@ def _conv_bn(cin, cout, k, gain):
                                   w_init_gain=gain), nn.BatchNorm1d(cout))
 
 
+_block_calls = [0]
+
+
+def _conv_bn_act(block, x, act, training, rng_stream):
+    """dropout(act(bn(conv(x)))) of one `_conv_bn` block on the HIP conv/BN kernels."""
+    conv, bn = block[0].conv, block[1]
+    _block_calls[0] += 1
+    if training:
+        bn.num_batches_tracked += 1
+    return t2v_hip.ConvBNAct1d.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                     training, act, drop_rate, 0x5EED, rng_stream, _block_calls[0])
+
+
 class Postnet(nn.Module):
     def __init__(self, hparams):
         super().__init__()
@@ -74,10 +87,7 @@ class Postnet(nn.Module):
     def forward(self, x):
         last = len(self.convolutions) - 1
         for i, block in enumerate(self.convolutions):
-            x = block(x)
-            if i < last:
-                x = torch.tanh(x)
-            x = F.dropout(x, drop_rate, self.training)
+            x = _conv_bn_act(block, x, t2v_hip.ACT_TANH if i < last else t2v_hip.ACT_NONE, self.training, 32 + i)
         return x
 
 
@@ -89,8 +99,8 @@ class Encoder(nn.Module):
         self.lstm = nn.LSTM(d, d // 2, 1, batch_first=True, bidirectional=True)
 
     def _convs(self, x):
-        for block in self.convolutions:
-            x = F.dropout(F.relu(block(x)), drop_rate, self.training)
+        for i, block in enumerate(self.convolutions):
+            x = _conv_bn_act(block, x, t2v_hip.ACT_RELU, self.training, 16 + i)
         return x.transpose(1, 2)
 
     def forward(self, x, input_lengths):

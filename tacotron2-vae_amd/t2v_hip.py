@@ -44,7 +44,8 @@ class _DecInferBufs(C.Structure):
 
 
 EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decoder_train_fwd',
-           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps')
+           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd',
+           't2v_bn_act_fwd', 't2v_bn_act_bwd')
 
 
 def lib_path():
@@ -81,6 +82,14 @@ def load_library():
     lib.t2v_set_phase_profile.argtypes = [C.c_void_p]
     lib.t2v_decoder_infer_steps.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecInferBufs), C.c_int, C.c_int, C.c_int,
                                             C.c_int, C.c_float, C.c_float, C.c_int, C.c_uint64, C.c_void_p]
+    vp = C.c_void_p
+    lib.t2v_conv1d_stat_blocks.argtypes = [C.c_int, C.c_int]
+    lib.t2v_conv1d_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.t2v_conv1d_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.t2v_bn_act_fwd.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, vp]
+    lib.t2v_bn_act_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                   C.c_uint64, C.c_uint32, C.c_uint32, vp]
     for name in EXPORTS:
         getattr(lib, name)
     _lib = lib
@@ -305,3 +314,65 @@ class InferenceSession(object):
                                                       int(t1), float(gate_threshold), float(p_prenet),
                                                       int(bool(external_prenet)), int(seed), _stream()),
                't2v_decoder_infer_steps')
+
+
+ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
+
+
+class ConvBNAct1d(torch.autograd.Function):
+    """dropout(act(BatchNorm1d(Conv1d(x)))) — one block of the encoder conv bank / Postnet
+    (reference model.py:143-148, 175-177) on the HIP implicit-GEMM conv + per-channel BN kernels.
+    `x` is saved by reference: the in-place output masking of reference model.py:515 therefore reaches
+    the first Postnet block's weight gradient exactly like it does in the reference (Appendix B-5)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, act, p_drop, seed,
+                rng_stream, rng_t):
+        lib = _require_gpu(x, weight)
+        x = x if x.is_contiguous() else x.contiguous()
+        B, Cin, T = x.shape
+        Cout, _, KS = weight.shape
+        dev = x.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        y = torch.empty(B, Cout, T, **f32)
+        nblk = lib.t2v_conv1d_stat_blocks(B, T)
+        part = torch.empty(nblk, Cout, 2, **f32) if training else None
+        w = weight.contiguous()
+        _check(lib.t2v_conv1d_fwd(_p(w), _p(x), _p(bias), _p(y), _p(part), B, Cin, T, Cout, KS, _stream()),
+               't2v_conv1d_fwd')
+        mean = torch.empty(Cout, **f32) if training else None
+        rstd = torch.empty(Cout, **f32) if training else None
+        out = torch.empty(B, Cout, T, **f32)
+        _check(lib.t2v_bn_act_fwd(_p(y), _p(part), nblk, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                  _p(mean), _p(rstd), _p(out), B, Cout, T, int(act), int(bool(training)),
+                                  float(p_drop if training else 0.0), 0.1, 1e-5, int(seed), int(rng_stream),
+                                  int(rng_t), _stream()), 't2v_bn_act_fwd')
+        ctx.cfg = (B, Cin, T, Cout, KS, int(act), float(p_drop if training else 0.0), int(seed), int(rng_stream),
+                   int(rng_t), bool(training))
+        ctx.keep = (x, w, y, mean, rstd, gamma, beta, running_mean, running_var)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = load_library()
+        B, Cin, T, Cout, KS, act, p, seed, rs, rt, training = ctx.cfg
+        x, w, y, mean, rstd, gamma, beta, running_mean, running_var = ctx.keep
+        f32 = dict(device=x.device, dtype=torch.float32)
+        if not training:   # eval-mode BN backward: statistics are constants
+            mean = running_mean
+            rstd = torch.rsqrt(running_var + 1e-5)
+            raise T2VHipError("ConvBNAct1d backward is implemented for training-mode BatchNorm only")
+        dout = dout.contiguous()
+        dy = torch.empty(B, Cout, T, **f32)
+        dgamma, dbeta = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
+        _check(lib.t2v_bn_act_bwd(_p(y), _p(dout), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dy), _p(dgamma),
+                                  _p(dbeta), B, Cout, T, act, p, seed, rs, rt, _stream()), 't2v_bn_act_bwd')
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty(B, Cin, T, **f32) if need_dx else None
+        dw = torch.empty_like(w)
+        wt = torch.empty_like(w) if need_dx else None
+        _check(lib.t2v_conv1d_bwd(_p(w), _p(x), _p(dy), _p(dx), _p(dw), _p(wt), B, Cin, T, Cout, KS, _stream()),
+               't2v_conv1d_bwd')
+        # d(bias) of a conv feeding a training-mode BatchNorm is identically zero (dy has zero channel mean)
+        dbias = torch.zeros(Cout, **f32)
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None

@@ -1,0 +1,73 @@
+"""Conv1d+BatchNorm1d+activation HIP kernels (implicit-GEMM MFMA conv, per-channel BN) vs a plain PyTorch
+fp32 CPU reference of the same op, forward and backward, ragged shapes."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, b, gamma, beta, act, training, rm, rv):
+    y = F.conv1d(x, w, b, padding=w.shape[2] // 2)
+    y = F.batch_norm(y, rm, rv, gamma, beta, training, 0.1, 1e-5)
+    if act == 1:
+        y = torch.tanh(y)
+    elif act == 2:
+        y = F.relu(y)
+    return y
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,KS,act", [(6, 80, 512, 400, 5, 1), (6, 512, 512, 84, 5, 2), (3, 512, 80, 37, 5, 0),
+                                                (2, 33, 70, 129, 3, 1), (1, 64, 64, 2, 5, 2)])
+def test_conv_bn_act_matches_torch(B, Cin, Cout, T, KS, act):
+    import t2v_hip
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, KS, generator=g) / (Cin * KS) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    rm, rv = torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5
+    wo = torch.randn(B, Cout, T, generator=g)
+
+    cx, cw, cb, cg, cbt = (t.clone().requires_grad_(True) for t in (x, w, b, gamma, beta))
+    crm, crv = rm.clone(), rv.clone()
+    ref = _ref(cx, cw, cb, cg, cbt, act, True, crm, crv)
+    (ref * wo).sum().backward()
+
+    dev = 'cuda'
+    gx, gw, gb, gg, gbt = (t.clone().to(dev).requires_grad_(True) for t in (x, w, b, gamma, beta))
+    grm, grv = rm.clone().to(dev), rv.clone().to(dev)
+    out = t2v_hip.ConvBNAct1d.apply(gx, gw, gb, gg, gbt, grm, grv, True, act, 0.0, 1, 1, 1)
+    (out * wo.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+
+    assert (out.cpu() - ref).abs().max() < 2e-4
+    assert (grm.cpu() - crm).abs().max() < 1e-5 and (grv.cpu() - crv).abs().max() < 1e-4
+    for name, a, r in (('dx', gx.grad, cx.grad), ('dw', gw.grad, cw.grad), ('dgamma', gg.grad, cg.grad),
+                       ('dbeta', gbt.grad, cbt.grad)):
+        scale = r.abs().max().item() + 1e-6
+        assert (a.cpu() - r).abs().max().item() < 2e-3 * scale, (name, (a.cpu() - r).abs().max().item(), scale)
+    assert gb.grad.abs().max().item() == 0.0 and cb.grad.abs().max().item() < 1e-3 * cw.grad.abs().max().item() + 1e-5
+
+    # eval mode uses the running statistics
+    with torch.no_grad():
+        e_ref = _ref(x, w, b, gamma, beta, act, False, crm, crv)
+        e_out = t2v_hip.ConvBNAct1d.apply(gx, gw, gb, gg, gbt, grm, grv, False, act, 0.5, 1, 1, 1)
+    assert (e_out.cpu() - e_ref).abs().max() < 2e-4
+
+
+def test_dropout_statistics_and_backward_mask():
+    import t2v_hip
+    B, C, T = 4, 64, 256
+    x = torch.randn(B, C, T, device='cuda', requires_grad=True)
+    w = torch.randn(C, C, 5, device='cuda') * 0.05
+    args = (torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'), torch.zeros(C, device='cuda'),
+            torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'))
+    a = t2v_hip.ConvBNAct1d.apply(x, w, *args, True, 0, 0.5, 7, 3, 11)
+    b = t2v_hip.ConvBNAct1d.apply(x, w, *args, True, 0, 0.0, 7, 3, 11)
+    keep = (a != 0).float().mean().item()
+    assert abs(keep - 0.5) < 0.02
+    kept = a != 0
+    assert torch.allclose(a[kept], 2.0 * b[kept], atol=1e-5)        # kept values scaled by 1/(1-p)
+    a.sum().backward()
+    assert torch.isfinite(x.grad).all()
