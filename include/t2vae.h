@@ -165,6 +165,20 @@ int t2v_bn_act_bwd(const float* y, const float* dout, const float* mean, const f
                    int B, int M, int T, int act, float p_drop, uint64_t seed, uint32_t rng_stream,
                    uint32_t rng_t, void* stream);
 
+/* ------------------------------------------------------------------ encoder BiLSTM recurrence
+ * nn.LSTM(512, 256, bidirectional) on a packed sequence (model.py:171-173, 183-190), recurrent part only:
+ * gx (2,B,T,1024) = X·W_ih^T + b_ih + b_hh per direction (time-batched GEMM done by the caller), whh
+ * (2,1024,256).  Persistent cooperative kernels (16 workgroups, W_hh register-resident for all T steps).
+ * y (B,T,512) and dg (2,B,T,1024) must be zeroed by the caller (padded positions stay zero);
+ * hx_scratch (2*2*16*256 floats) / dgx_scratch (2*2*16*1024 floats) are exchange buffers; sync3 = 3 uint32
+ * (zeroed by the call; sync3[2] != 0 afterwards means a bounded spin timed out).  gates/cells (saved
+ * activations) may be NULL for inference.  B <= 16. */
+int t2v_bilstm_fwd(const float* gx, const float* whh, const int32_t* lengths, float* y, float* gates,
+                   float* cells, float* hx_scratch, uint32_t* sync3, int B, int T, void* stream);
+int t2v_bilstm_bwd(const float* whh, const int32_t* lengths, const float* dy, const float* gates,
+                   const float* cells, float* dg, float* dgx_scratch, uint32_t* sync3, int B, int T,
+                   void* stream);
+
 /* ------------------------------------------------------------------ optimiser
  * clip_grad_norm_(params, max_norm) + Adam.step() of the reference loop (train.py:226-229,
  * Adam built at train.py:171-172) fused over one flat fp32 arena.  `grads` holds the SUM over

@@ -1,0 +1,255 @@
+// Encoder BiLSTM(512 -> 256 x 2) recurrence (reference model.py:171-173,183-190: nn.LSTM on a packed
+// sequence), forward and BPTT, as PERSISTENT cooperative kernels: 8 workgroups per direction, each owning
+// 32 hidden units whose recurrent weights (128 gate rows x 256, fp32) stay in VGPRs as
+// v_mfma_f32_16x16x4_f32 A-fragments for all T steps (1 MB per direction = 8 x 4 waves x 128 VGPRs).
+// Per step the workgroups of a direction exchange the new hidden state (forward) / gate gradients
+// (backward) through global memory: write-through (sc1) stores, one arrival counter per direction,
+// relaxed polling, sc1 loads (MI355X guide, Guideline 16 "R1" form).  Every spin is bounded: on a
+// timeout the kernel sets an error word and every workgroup leaves (no hang).
+// The input projection X·W_ih^T + b (time-batched GEMM) is done outside; packing semantics = each
+// sequence runs over its OWN length (reverse direction starts at len_b-1), padded outputs are zero.
+#include "t2v_common.h"
+#include "t2v_kernels.h"
+
+#define BL_H 256
+#define BL_G (4 * BL_H)
+#define BL_NW 8                 // workgroups per direction
+#define BL_UNITS (BL_H / BL_NW) // 32 units per workgroup
+#define BL_SPIN_LIMIT 4000000
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// all workgroups of one direction arrive; returns false on timeout (error word set)
+__device__ __forceinline__ bool group_barrier(unsigned* counter, unsigned target, unsigned* err) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores are out
+    __syncthreads();
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int good = 1;
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > BL_SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                good = 0;
+                break;
+            }
+        }
+        ok = good;
+    }
+    __syncthreads();
+    return ok != 0;
+}
+
+struct BiLstmFwdArgs {
+    const float* gx;        // (2, B, T, 1024) input projections + both biases, gate-major i,f,g,o
+    const float* whh;       // (2, 1024, 256)
+    const int32_t* lengths; // (B)
+    float* y;               // (B, T, 512) outputs [fwd | rev], zero at padded positions (pre-zeroed by caller)
+    float* gates;           // (2, B, T, 1024) saved gate activations (training) or NULL
+    float* cells;           // (2, B, T, 256)  saved cell states (training) or NULL
+    float* hx;              // (2, 2, 16, 256) exchange buffer (double buffered by step parity)
+    unsigned* sync;         // [0..1] arrival counters per direction, [2] error word; zeroed by the launcher
+    int B, T;
+};
+
+__global__ __launch_bounds__(256) void k_bilstm_fwd(BiLstmFwdArgs a) {
+    const int dir = blockIdx.x / BL_NW, j = blockIdx.x % BL_NW;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = lane & 15, g = lane >> 4;
+    const bool bvalid = b < a.B;
+    __shared__ float hbuf[16][BL_H + 4];
+    // recurrent weights of this wave's two 16-row tiles (4 units x 4 gates each) as MFMA A fragments
+    float wreg[2][64];
+    {
+        const float* W = a.whh + (size_t)dir * BL_G * BL_H;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int unit = j * BL_UNITS + (2 * wave + tt) * 4 + ((lane & 15) >> 2);
+            const int row = (lane & 3) * BL_H + unit;
+#pragma unroll
+            for (int s = 0; s < 64; ++s) wreg[tt][s] = W[(size_t)row * BL_H + 4 * s + g];
+        }
+    }
+    for (int i = tid; i < 16 * (BL_H + 4); i += 256) (&hbuf[0][0])[i] = 0.f;
+    const int len = bvalid ? a.lengths[b] : 0;
+    float cst[2] = {0.f, 0.f};
+    __syncthreads();
+
+    for (int step = 0; step < a.T; ++step) {
+        const bool active = step < len;
+        const int t = dir == 0 ? step : len - 1 - step;        // own-length reverse (packed sequence)
+        // input projections for this lane's (unit, item): 4 gates per tile
+        float gxv[2][4];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int U = j * BL_UNITS + (2 * wave + tt) * 4 + g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                gxv[tt][r] = active ? a.gx[(((size_t)dir * a.B + b) * a.T + t) * BL_G + r * BL_H + U] : 0.f;
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float* hrow = &hbuf[b][g];
+#pragma unroll
+        for (int s = 0; s < 64; ++s) {
+            const float hv = hrow[4 * s];
+            acc0 = mfma16x4(wreg[0][s], hv, acc0);
+            acc1 = mfma16x4(wreg[1][s], hv, acc1);
+        }
+        float* hx_w = a.hx + ((size_t)(dir * 2 + (step & 1)) * 16) * BL_H;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const f32x4 acc = tt == 0 ? acc0 : acc1;
+            const int U = j * BL_UNITS + (2 * wave + tt) * 4 + g;
+            if (bvalid) {
+                float hnew = hbuf[b][U];                       // frozen once the sequence has ended
+                if (active) {
+                    const float gi = sigmoidf_(acc[0] + gxv[tt][0]), gf = sigmoidf_(acc[1] + gxv[tt][1]);
+                    const float gg = tanhf_(acc[2] + gxv[tt][2]), go = sigmoidf_(acc[3] + gxv[tt][3]);
+                    const float c = gf * cst[tt] + gi * gg;
+                    cst[tt] = c;
+                    hnew = go * tanhf_(c);
+                    a.y[((size_t)b * a.T + t) * (2 * BL_H) + dir * BL_H + U] = hnew;
+                    if (a.gates) {
+                        float* gs = a.gates + (((size_t)dir * a.B + b) * a.T + t) * BL_G + U;
+                        gs[0] = gi; gs[BL_H] = gf; gs[2 * BL_H] = gg; gs[3 * BL_H] = go;
+                        a.cells[(((size_t)dir * a.B + b) * a.T + t) * BL_H + U] = c;
+                    }
+                }
+                st_sc1(hx_w + (size_t)b * BL_H + U, hnew);
+            }
+        }
+        if (step + 1 == a.T) break;
+        if (!group_barrier(a.sync + dir, (unsigned)(BL_NW * (step + 1)), a.sync + 2)) return;
+        for (int i = tid; i < a.B * BL_H; i += 256) hbuf[i >> 8][i & (BL_H - 1)] = ld_sc1(hx_w + i);
+        __syncthreads();
+    }
+}
+
+struct BiLstmBwdArgs {
+    const float* whh;       // (2, 1024, 256)
+    const int32_t* lengths;
+    const float* dy;        // (B, T, 512)
+    const float* gates;     // (2, B, T, 1024)
+    const float* cells;     // (2, B, T, 256)
+    float* dg;              // (2, B, T, 1024) out: grad wrt gate pre-activations (pre-zeroed by caller)
+    float* dgx;             // (2, 2, 16, 1024) exchange buffer
+    unsigned* sync;
+    int B, T;
+};
+
+__global__ __launch_bounds__(256) void k_bilstm_bwd(BiLstmBwdArgs a) {
+    const int dir = blockIdx.x / BL_NW, j = blockIdx.x % BL_NW;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = lane & 15, g = lane >> 4;
+    __shared__ float dgbuf[16][BL_G + 4];           // all gate gradients of the current step
+    __shared__ f32x4 red[4][2][64];
+    __shared__ float dhrec[16][BL_UNITS + 1];       // dL/dh_{prev} for this workgroup's 32 units
+    // W_hh^T rows of this workgroup's 32 units (2 tiles of 16), K = 1024 split over the 4 waves
+    float wreg[2][64];
+    {
+        const float* W = a.whh + (size_t)dir * BL_G * BL_H;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int col = j * BL_UNITS + tt * 16 + (lane & 15);       // h unit = column of W_hh
+#pragma unroll
+            for (int s = 0; s < 64; ++s) wreg[tt][s] = W[(size_t)(256 * wave + 4 * s + g) * BL_H + col];
+        }
+    }
+    for (int i = tid; i < 16 * (BL_UNITS + 1); i += 256) (&dhrec[0][0])[i] = 0.f;
+    // cell-backward ownership: thread -> (item bb, unit uu) pairs, uu = tid & 31, bb = tid >> 5 (+8)
+    const int uu = tid & 31, U = j * BL_UNITS + uu;
+    float dcrec[2] = {0.f, 0.f};
+    __syncthreads();
+
+    for (int step = a.T - 1; step >= 0; --step) {
+        float* dgx_w = a.dgx + ((size_t)(dir * 2 + (step & 1)) * 16) * BL_G;
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int bb = (tid >> 5) + 8 * rep;
+            if (bb < a.B) {
+                const int len = a.lengths[bb];
+                float di = 0.f, df = 0.f, dgg = 0.f, dob = 0.f;
+                if (step < len) {
+                    const int t = dir == 0 ? step : len - 1 - step;
+                    const size_t idx = ((size_t)dir * a.B + bb) * a.T + t;
+                    const float* gs = a.gates + idx * BL_G + U;
+                    const float gi = gs[0], gf = gs[BL_H], gg = gs[2 * BL_H], go = gs[3 * BL_H];
+                    const float c = a.cells[idx * BL_H + U];
+                    float cprev = 0.f;
+                    if (step > 0) {
+                        const int tp = dir == 0 ? t - 1 : t + 1;
+                        cprev = a.cells[(((size_t)dir * a.B + bb) * a.T + tp) * BL_H + U];
+                    }
+                    const float dh = a.dy[((size_t)bb * a.T + t) * (2 * BL_H) + dir * BL_H + U] + dhrec[bb][uu];
+                    const float tc = tanhf_(c);
+                    const float dct = dcrec[rep] + dh * go * (1.f - tc * tc);
+                    dob = dh * tc * go * (1.f - go);
+                    di = dct * gg * gi * (1.f - gi);
+                    df = dct * cprev * gf * (1.f - gf);
+                    dgg = dct * gi * (1.f - gg * gg);
+                    dcrec[rep] = dct * gf;
+                    float* o = a.dg + idx * BL_G + U;
+                    o[0] = di; o[BL_H] = df; o[2 * BL_H] = dgg; o[3 * BL_H] = dob;
+                }
+                float* x = dgx_w + (size_t)bb * BL_G + U;
+                st_sc1(x, di); st_sc1(x + BL_H, df); st_sc1(x + 2 * BL_H, dgg); st_sc1(x + 3 * BL_H, dob);
+            }
+        }
+        if (step == 0) break;
+        if (!group_barrier(a.sync + dir, (unsigned)(BL_NW * (a.T - step)), a.sync + 2)) return;
+        for (int i = tid; i < a.B * BL_G; i += 256) dgbuf[i >> 10][i & (BL_G - 1)] = ld_sc1(dgx_w + i);
+        __syncthreads();
+        // dh_rec[b][unit] = sum_k W_hh[k][unit] * dgates[b][k]
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float* drow = &dgbuf[b][256 * wave + g];
+#pragma unroll
+        for (int s = 0; s < 64; ++s) {
+            const float dv = drow[4 * s];
+            acc0 = mfma16x4(wreg[0][s], dv, acc0);
+            acc1 = mfma16x4(wreg[1][s], dv, acc1);
+        }
+        red[wave][0][lane] = acc0;
+        red[wave][1][lane] = acc1;
+        __syncthreads();
+        if (wave < 2) {     // wave tt finalises tile tt: lane (col = item b, rows 4g+r = units 16tt+4g+r)
+            const f32x4 s4 = red[0][wave][lane] + red[1][wave][lane] + red[2][wave][lane] + red[3][wave][lane];
+            if (b < a.B) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dhrec[b][16 * wave + 4 * g + r] = s4[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int t2v_bilstm_fwd(const float* gx, const float* whh, const int32_t* lengths, float* y, float* gates,
+                              float* cells, float* hx_scratch, uint32_t* sync3, int B, int T, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!gx || !whh || !lengths || !y || !hx_scratch || !sync3 || B < 1 || B > 16 || T < 1) return T2V_ERR_ARG;
+    if ((gates == nullptr) != (cells == nullptr)) return T2V_ERR_ARG;
+    (void)hipMemsetAsync(sync3, 0, 3 * sizeof(uint32_t), stream);
+    BiLstmFwdArgs a;
+    a.gx = gx; a.whh = whh; a.lengths = lengths; a.y = y; a.gates = gates; a.cells = cells; a.hx = hx_scratch;
+    a.sync = sync3; a.B = B; a.T = T;
+    k_bilstm_fwd<<<2 * BL_NW, 256, 0, stream>>>(a);
+    return t2v_check_launch();
+}
+
+extern "C" int t2v_bilstm_bwd(const float* whh, const int32_t* lengths, const float* dy, const float* gates,
+                              const float* cells, float* dg, float* dgx_scratch, uint32_t* sync3, int B, int T,
+                              void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!whh || !lengths || !dy || !gates || !cells || !dg || !dgx_scratch || !sync3 || B < 1 || B > 16 || T < 1)
+        return T2V_ERR_ARG;
+    (void)hipMemsetAsync(sync3, 0, 3 * sizeof(uint32_t), stream);
+    BiLstmBwdArgs a;
+    a.whh = whh; a.lengths = lengths; a.dy = dy; a.gates = gates; a.cells = cells; a.dg = dg; a.dgx = dgx_scratch;
+    a.sync = sync3; a.B = B; a.T = T;
+    k_bilstm_bwd<<<2 * BL_NW, 256, 0, stream>>>(a);
+    return t2v_check_launch();
+}

@@ -103,17 +103,21 @@ class Encoder(nn.Module):
             x = _conv_bn_act(block, x, t2v_hip.ACT_RELU, self.training, 16 + i)
         return x.transpose(1, 2)
 
+    def _bilstm(self, x, lengths):
+        l = self.lstm
+        return t2v_hip.BiLSTM.apply(x, lengths, l.weight_ih_l0, l.weight_hh_l0, l.bias_ih_l0, l.bias_hh_l0,
+                                    l.weight_ih_l0_reverse, l.weight_hh_l0_reverse, l.bias_ih_l0_reverse,
+                                    l.bias_hh_l0_reverse, torch.is_grad_enabled())
+
     def forward(self, x, input_lengths):
+        """conv bank → BiLSTM over each sequence's own length (packed semantics), zero at padding."""
         x = self._convs(x)
-        packed = nn.utils.rnn.pack_padded_sequence(x, input_lengths.cpu(), batch_first=True)
-        outputs, _ = self.lstm(packed)
-        outputs, _ = nn.utils.rnn.pad_packed_sequence(outputs, batch_first=True)
-        return outputs
+        return self._bilstm(x, input_lengths.to(device=x.device, dtype=torch.int32))
 
     def inference(self, x):
         x = self._convs(x)
-        outputs, _ = self.lstm(x)
-        return outputs
+        lengths = torch.full((x.size(0),), x.size(1), device=x.device, dtype=torch.int32)
+        return self._bilstm(x, lengths)
 
 
 class Decoder(nn.Module):

@@ -45,7 +45,7 @@ class _DecInferBufs(C.Structure):
 
 EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decoder_train_fwd',
            't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd',
-           't2v_bn_act_fwd', 't2v_bn_act_bwd')
+           't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd')
 
 
 def lib_path():
@@ -90,6 +90,8 @@ def load_library():
                                    C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, vp]
     lib.t2v_bn_act_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                    C.c_uint64, C.c_uint32, C.c_uint32, vp]
+    lib.t2v_bilstm_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.t2v_bilstm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     for name in EXPORTS:
         getattr(lib, name)
     _lib = lib
@@ -376,3 +378,58 @@ class ConvBNAct1d(torch.autograd.Function):
         # d(bias) of a conv feeding a training-mode BatchNorm is identically zero (dy has zero channel mean)
         dbias = torch.zeros(Cout, **f32)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+class BiLSTM(torch.autograd.Function):
+    """Encoder BiLSTM over per-sequence lengths (== pack_padded_sequence → nn.LSTM → pad_packed_sequence,
+    reference model.py:183-190).  Input projections / weight gradients are time-batched GEMMs; the
+    recurrence (forward and BPTT) runs in the persistent cooperative kernels of csrc/bilstm.hip."""
+
+    @staticmethod
+    def forward(ctx, x, lengths, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, save):
+        lib = _require_gpu(x, w_ih)
+        B, T, _ = x.shape
+        f32 = dict(device=x.device, dtype=torch.float32)
+        x = _f32c(x)
+        gx = torch.empty(2, B, T, 1024, **f32)
+        torch.addmm(b_ih + b_hh, x.view(B * T, -1), w_ih.t(), out=gx[0].view(B * T, 1024))
+        torch.addmm(b_ih_r + b_hh_r, x.view(B * T, -1), w_ih_r.t(), out=gx[1].view(B * T, 1024))
+        whh = torch.stack((w_hh, w_hh_r)).contiguous()
+        y = torch.zeros(B, T, 512, **f32)
+        gates = torch.empty(2, B, T, 1024, **f32) if save else None
+        cells = torch.empty(2, B, T, 256, **f32) if save else None
+        hx = torch.empty(2 * 2 * 16 * 256, **f32)
+        sync = torch.empty(3, device=x.device, dtype=torch.int32)
+        _check(lib.t2v_bilstm_fwd(_p(gx), _p(whh), _p(lengths), _p(y), _p(gates), _p(cells), _p(hx), _p(sync), B, T,
+                                  _stream()), 't2v_bilstm_fwd')
+        ctx.keep = (x, lengths, w_ih, w_ih_r, whh, y, gates, cells, sync)
+        ctx.dims = (B, T)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load_library()
+        x, lengths, w_ih, w_ih_r, whh, y, gates, cells, sync = ctx.keep
+        B, T = ctx.dims
+        if gates is None:
+            raise T2VHipError("BiLSTM forward ran without saving activations")
+        f32 = dict(device=x.device, dtype=torch.float32)
+        dy = _f32c(dy)
+        dg = torch.zeros(2, B, T, 1024, **f32)
+        dgx = torch.empty(2 * 2 * 16 * 1024, **f32)
+        _check(lib.t2v_bilstm_bwd(_p(whh), _p(lengths), _p(dy), _p(gates), _p(cells), _p(dg), _p(dgx), _p(sync), B, T,
+                                  _stream()), 't2v_bilstm_bwd')
+        BT = B * T
+        d0, d1, x2 = dg[0].view(BT, 1024), dg[1].view(BT, 1024), x.view(BT, -1)
+        dx = (d0 @ w_ih + d1 @ w_ih_r).view(B, T, -1)
+        z = y.new_zeros(B, 1, 256)
+        hp0 = torch.cat((z, y[:, :-1, :256]), 1).reshape(BT, 256)      # h_{t-1} of the forward direction
+        hp1 = torch.cat((y[:, 1:, 256:], z), 1).reshape(BT, 256)       # h_{t+1} of the reverse direction
+        db0, db1 = d0.sum(0), d1.sum(0)
+        return (dx, None, d0.t() @ x2, d0.t() @ hp0, db0, db0, d1.t() @ x2, d1.t() @ hp1, db1, db1, None)
+
+
+def bilstm_check(sync):
+    """Raises if a cooperative kernel reported a barrier timeout (forces a device sync; tests only)."""
+    if int(sync[2].item()) != 0:
+        raise T2VHipError("BiLSTM cooperative kernel timed out on its inter-workgroup barrier")

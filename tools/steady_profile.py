@@ -19,3 +19,18 @@ print("steady state over %d steps: wall %.3f ms/step, GPU busy %.3f ms/step, %d 
 print("%-64s %8s %10s %9s" % ("kernel", "calls/st", "ms/step", "avg us"))
 for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(sys.argv[3]) if len(sys.argv) > 3 else 40]:
     print("%-64s %8.1f %10.3f %9.2f" % (n[:64], c / nsteps, t / nsteps / 1e6, t / c / 1e3))
+
+# ---- idle-gap attribution: GPU idle time between consecutive kernels, charged to the kernel that follows
+gaps = collections.defaultdict(lambda: [0, 0])
+prev_end = None
+for s_, e_, n_ in sel:
+    if prev_end is not None and s_ > prev_end:
+        g = s_ - prev_end
+        if g > 3000:
+            gaps[n_[:50]][0] += g
+            gaps[n_[:50]][1] += 1
+    prev_end = max(prev_end or 0, e_)
+tot = sum(v[0] for v in gaps.values()) / nsteps / 1e6
+print("idle gaps > 3 us: %.3f ms/step; top followers:" % tot)
+for n_, (t_, c_) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:12]:
+    print("   %-50s %7.1f gaps/st %8.3f ms/step  avg %7.1f us" % (n_, c_ / nsteps, t_ / nsteps / 1e6, t_ / c_ / 1e3))
