@@ -29,13 +29,16 @@ __global__ __launch_bounds__(1024) void k_lstm_bwd(LstmBwdArgs a) {
     const float* xrow = kv + (size_t)(bvalid ? b : 0) * T2V_G + 4 * g;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int kb0 = 16 * wave;     // 256 k-blocks / 16 waves
+    // successive launches walk the k-blocks in opposite directions (a.flip): whatever part of the
+    // 67 MB stream the previous launch left in the XCD L2s is requested first, before it is evicted
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         float4 wv[8], xv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            wv[i] = p[(size_t)(kb0 + 8 * h + i) * ntile * 64];
-            xv[i] = *(const float4*)(xrow + 16 * (kb0 + 8 * h + i));   // lanes b>=B read row 0 (unused D columns)
+            const int kb = a.flip ? kb0 + 15 - (8 * h + i) : kb0 + 8 * h + i;
+            wv[i] = p[(size_t)kb * ntile * 64];
+            xv[i] = *(const float4*)(xrow + 16 * kb);   // lanes b>=B read row 0 (unused D columns)
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) { MFMA4(acc, wv[i], xv[i]); }
@@ -340,6 +343,7 @@ extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_tra
             l.YD = g->YD;
             l.YA = g->YA;
             l.B = B;
+            l.flip = t & 1;
             k_lstm_bwd<<<T2V_NWG, 1024, 0, stream>>>(l);
 
             AttnBwdArgs f;

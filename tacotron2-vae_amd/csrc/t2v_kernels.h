@@ -65,6 +65,7 @@ struct LstmBwdArgs {
     float* YD;              // (B,2560)
     float* YA;              // (B,1536)
     int B;
+    int flip;               // walk the k-blocks backwards (alternates per launch for L2 reuse)
 };
 
 struct AttnBwdArgs {
