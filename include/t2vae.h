@@ -94,16 +94,16 @@ typedef struct t2v_dec_bwd_bufs {
     const float* dHC;  /* (T,B,1536) grad wrt [h_dec_t | ctx_t] coming from the projection */
     float* DGA;   /* (T,B,4096) out: grad wrt attention_rnn pre-activations (== grad of gpre) */
     float* DGD;   /* (T,B,4096) out: grad wrt decoder_rnn pre-activations */
-    float* DQ;    /* (T,B,128)  out: grad wrt processed query */
+    float* DQ;    /* (T,B,8,128) out: per-position-slice partials of the grad wrt the processed query (sum over dim 2) */
     float* DCTX;  /* (T,B,512)  out: grad wrt attention context */
     float* DC;    /* (T,B,32,T_in) out: grad wrt location_conv outputs */
     float* YD;    /* (B,2560) scratch, zeroed by the call */
     float* YA;    /* (B,1536) scratch, zeroed by the call */
     float* DCA;   /* (B,1024) scratch */
     float* DCD;   /* (B,1024) scratch */
-    float* GPREV; /* (B,T_in) scratch */
-    float* GCUM;  /* (B,T_in) scratch */
-    float* DV;    /* (B,128) out: per-item grad of attention v (sum over b = dv) */
+    float* GPREV; /* (2,B,8,2,64) scratch: per-slice partial location-conv gradients, parity double-buffered */
+    float* GCUM;  /* (B,8,256) scratch: per-workgroup copies of the cumulative-weights gradient */
+    float* DV;    /* (B,8,128) out: per-item, per-slice grad of attention v (sum over dims 0,1 = dv) */
 } t2v_dec_bwd_bufs;
 
 /* Hand-written BPTT of the loop above (what autograd does for the reference at train.py:225).

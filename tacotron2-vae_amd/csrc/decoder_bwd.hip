@@ -54,232 +54,277 @@ __global__ __launch_bounds__(1024) void k_lstm_bwd(LstmBwdArgs a) {
     }
 }
 
-// attention(t) backward.  grid = B, 512 threads, JP = ceil(T_in/4) register rows.
-// LDS carve (floats): dctx[512] | alpha[TpR] | dal[TpR] | de[TpR] | dpT[128*TpP] | dcs[32*DS] | wcl[32*63] | scr[1024]
-//   dpT = dpre transposed [d][TpP] (TpP odd -> conflict-free column writes, MFMA B reads along j)
-#define ATB_THREADS 512
-#define ATB_R (ATB_THREADS / 128)
-static __host__ __device__ inline int attn_bwd_ds(int Tp) { return (16 * ((Tp + 15) / 16) + 46) | 1; }
-static __host__ __device__ inline int attn_bwd_tpp(int Tp) { return (16 * ((Tp + 15) / 16)) | 1; }
-size_t t2v_attn_bwd_lds(int Tp) {
-    const int TpR = (Tp + 3) & ~3;
-    return sizeof(float) * (T2V_E + 3 * TpR + (size_t)T2V_A * attn_bwd_tpp(Tp) + T2V_F * attn_bwd_ds(Tp) + T2V_F * 63 + 1024);
-}
+// attention(t) backward, split over encoder positions: grid = (B, S), 256 threads; workgroup (b, s) owns
+// positions [s*JS, s*JS + JS), JS = 16 or 32.  The softmax backward needs dot = sum_j alpha_j dalpha_j over ALL
+// positions; since dalpha_j = dctx·memory_j + G_j and sum_j alpha_j memory_j = ctx_t (saved), every
+// workgroup gets it as dot = dctx·ctx_t + sum_j alpha_j G_j without talking to the others.  Gradients that
+// flow to the previous step through the location conv (15-wide halo) are written as per-slice partial rows
+// (parity double-buffered) and re-assembled by every workgroup of step t-1; partial dq / dv rows are summed
+// by the consumers.  No atomics, fixed summation order.
+#define ATB_THREADS 256
+#define ATB_MAXS 8
+static inline int attn_bwd_js(int T_in) { return 16 * ((T_in + 127) / 128); }
 
-template <int JP>
+template <int JS>
 __global__ __launch_bounds__(ATB_THREADS) void k_attn_bwd(AttnBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Tp = a.T_in, TpR = (Tp + 3) & ~3, DS = attn_bwd_ds(Tp), TpP = attn_bwd_tpp(Tp);
-    float* dctx = smem;
-    float* alpha = dctx + T2V_E;
-    float* dal = alpha + TpR;
-    float* de = dal + TpR;
-    float* dpT = de + TpR;
-    float* dcs = dpT + (size_t)T2V_A * TpP;
-    float* wcl = dcs + T2V_F * DS;
-    float* scr = wcl + T2V_F * 63;
-    const int d = tid & (T2V_A - 1), j4 = tid >> 7;
+    constexpr int NJT = JS / 16;           // 16-position MFMA tiles per slice
+    constexpr int PW = JS + 30;            // width of a partial dcat row
+    constexpr int DW = JS + 60;            // zero-padded dc row
+    __shared__ __attribute__((aligned(16))) float dctx[T2V_E];
+    __shared__ float gfull[2][256];        // assembled Gprev / Gcum over all positions
+    __shared__ float alf[256];
+    __shared__ float dal[JS], de[JS];
+    __shared__ float dpT[T2V_A][JS + 1];
+    __shared__ float dcl[T2V_F][DW + 1];
+    __shared__ float wcl[T2V_F * 63];
+    __shared__ f32x4 red[2][2][64];
+    __shared__ float scr[ATB_THREADS * 2 + 8];
+    const int b = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
+    const int Tp = a.T_in, j0 = s * JS;
+    const int nown = min(JS, Tp - j0);     // > 0 by construction of S
 
     T2V_STAMP(a, 0);
-    // ---- entry: issue the global reads
-    float sreg[JP];
+    // ---- entry loads
+    const int d = tid & (T2V_A - 1), jh = tid >> 7;       // (column, row parity) for the tanh phase
+    float sreg[JS / 2];
     {
-        const float* sp = a.S_t + (size_t)b * Tp * T2V_A + d;
+        const float* sp = a.S_t + ((size_t)b * Tp + j0) * T2V_A + d;
 #pragma unroll
-        for (int i = 0; i < JP; ++i) {
-            const int j = j4 + ATB_R * i;
-            sreg[i] = j < Tp ? sp[(size_t)j * T2V_A] : 0.f;
+        for (int i = 0; i < JS / 2; ++i) {
+            const int jl = jh + 2 * i;
+            sreg[i] = jl < nown ? sp[(size_t)jl * T2V_A] : 0.f;
         }
     }
+    float4 m0[JS / 4], m1[JS / 4];                         // this wave's memory rows (wave w: rows w, w+4, ..)
+#pragma unroll
+    for (int r = 0; r < JS / 4; ++r) {
+        const int jl = wave + 4 * r;
+        const float* mrow = a.memory + ((size_t)b * Tp + j0 + (jl < nown ? jl : 0)) * T2V_E + lane * 4;
+        m0[r] = *(const float4*)mrow;
+        m1[r] = *(const float4*)(mrow + 256);
+    }
     const float vd = a.v[d];
-    // 1. total gradient of the context of step t
     for (int e = tid; e < T2V_E; e += ATB_THREADS) {
         const float v = a.dHC_t[(size_t)b * (T2V_H + T2V_E) + T2V_H + e] + a.YD[(size_t)b * T2V_XW + T2V_H + e] +
                         a.YA[(size_t)b * T2V_KATT + T2V_H + e];
         dctx[e] = v;
-        a.DCTX_t[(size_t)b * T2V_E + e] = v;
+        if (s == 0) a.DCTX_t[(size_t)b * T2V_E + e] = v;
     }
-    for (int j = tid; j < Tp; j += ATB_THREADS) {
-        alpha[j] = a.al_cur[(size_t)b * Tp + j];
-        dal[j] = a.GPREV[(size_t)b * Tp + j] + a.GCUM[(size_t)b * Tp + j];
+    const float ctx0 = a.ctx_t[(size_t)b * T2V_XW + tid], ctx1 = a.ctx_t[(size_t)b * T2V_XW + 256 + tid];
+    // assemble G over all positions from the previous reverse step's per-slice partial rows
+    if (tid < Tp) {
+        const int j = tid;
+        float gp = 0.f, gc = a.GC[((size_t)b * ATB_MAXS + s) * 256 + j];
+        float pv[ATB_MAXS][2];
+#pragma unroll
+        for (int sp2 = 0; sp2 < ATB_MAXS; ++sp2) {      // all loads independent (unused slices hold zeros)
+            const int jj = j - sp2 * JS + 15;
+            const bool in = jj >= 0 && jj < PW;
+            const float* row = a.GP_in + (((size_t)b * ATB_MAXS + sp2) * 2) * 64 + (in ? jj : 0);
+            pv[sp2][0] = row[0];
+            pv[sp2][1] = row[64];
+            if (!in) { pv[sp2][0] = 0.f; pv[sp2][1] = 0.f; }
+        }
+#pragma unroll
+        for (int sp2 = 0; sp2 < ATB_MAXS; ++sp2) { gp += pv[sp2][0]; gc += pv[sp2][1]; }
+        a.GC[((size_t)b * ATB_MAXS + s) * 256 + j] = gc;
+        gfull[0][j] = gp;
+        gfull[1][j] = gc;
+        alf[j] = a.al_cur[(size_t)b * Tp + j];
     }
-    for (int i = tid; i < T2V_F * DS; i += ATB_THREADS) dcs[i] = 0.f;
-    if (tid < T2V_F * 62 / 4) {
-        const float4 w4 = ((const float4*)a.loc_conv)[tid];
+    for (int i = tid; i < T2V_F * (DW + 1); i += ATB_THREADS) (&dcl[0][0])[i] = 0.f;
+    for (int q4 = tid; q4 < T2V_F * 62 / 4; q4 += ATB_THREADS) {
+        const float4 w4 = ((const float4*)a.loc_conv)[q4];
         const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const int i = 4 * tid + c; wcl[(i / 62) * 63 + (i % 62)] = wv[c]; }
+        for (int c = 0; c < 4; ++c) { const int i = 4 * q4 + c; wcl[(i / 62) * 63 + (i % 62)] = wv[c]; }
+    }
+    // location_dense as the MFMA A operand of phase 5: wave = (f tile = wave&1, K half = wave>>1)
+    float areg[16];
+    {
+        const int f0 = 16 * (wave & 1), kh = wave >> 1;
+#pragma unroll
+        for (int st = 0; st < 16; ++st) areg[st] = a.loc_dense[(64 * kh + 4 * st + g) * T2V_F + f0 + c16];
     }
     __syncthreads();
 
     T2V_STAMP(a, 1);
-    // 2. d alpha[j] += dctx . memory[j]   (wave per row, 8 rows in flight per wave)
+    // ---- dot = dctx·ctx_t + sum_j alpha_j (Gprev_j + Gcum_j)
+    float dotp = dctx[tid] * ctx0 + dctx[256 + tid] * ctx1;
+    if (tid < Tp) dotp = fmaf(alf[tid], gfull[0][tid] + gfull[1][tid], dotp);
+    dotp = wave_sum(dotp);
+    if (lane == 0) scr[wave] = dotp;
+    // ---- dalpha for the own positions: dctx·memory_j + G_j
     {
         const float4 d0 = *(const float4*)(dctx + lane * 4), d1 = *(const float4*)(dctx + 256 + lane * 4);
-        constexpr int NW = ATB_THREADS / 64, NB = 8;
-        for (int base = wave; base < Tp; base += NW * NB) {
-            float4 m0[NB], m1[NB];
 #pragma unroll
-            for (int r = 0; r < NB; ++r) {
-                const int j = base + NW * r;
-                const float* mrow = a.memory + ((size_t)b * Tp + (j < Tp ? j : 0)) * T2V_E + lane * 4;
-                m0[r] = *(const float4*)mrow;
-                m1[r] = *(const float4*)(mrow + 256);
-            }
-#pragma unroll
-            for (int r = 0; r < NB; ++r) {
-                const int j = base + NW * r;
-                float acc = m0[r].x * d0.x;
-                acc = fmaf(m0[r].y, d0.y, acc); acc = fmaf(m0[r].z, d0.z, acc); acc = fmaf(m0[r].w, d0.w, acc);
-                acc = fmaf(m1[r].x, d1.x, acc); acc = fmaf(m1[r].y, d1.y, acc);
-                acc = fmaf(m1[r].z, d1.z, acc); acc = fmaf(m1[r].w, d1.w, acc);
-                acc = wave_sum(acc);
-                if (lane == 0 && j < Tp) dal[j] += acc;
-            }
+        for (int r = 0; r < JS / 4; ++r) {
+            const int jl = wave + 4 * r;
+            float acc = m0[r].x * d0.x;
+            acc = fmaf(m0[r].y, d0.y, acc); acc = fmaf(m0[r].z, d0.z, acc); acc = fmaf(m0[r].w, d0.w, acc);
+            acc = fmaf(m1[r].x, d1.x, acc); acc = fmaf(m1[r].y, d1.y, acc);
+            acc = fmaf(m1[r].z, d1.z, acc); acc = fmaf(m1[r].w, d1.w, acc);
+            acc = wave_sum(acc);
+            if (lane == 0) dal[jl] = jl < nown ? acc + gfull[0][j0 + jl] + gfull[1][j0 + jl] : 0.f;
         }
     }
     __syncthreads();
-    // location_dense as the MFMA A operand of phase 5: A[f = f0+c16][k = d = 4st+g]
-    float areg[32];
-    {
-        const int f0 = 16 * (wave & 1);
-#pragma unroll
-        for (int st = 0; st < 32; ++st) areg[st] = a.loc_dense[(4 * st + g) * T2V_F + f0 + c16];
-    }
+    const float dot = (scr[0] + scr[1]) + (scr[2] + scr[3]);
+    if (tid < JS) de[tid] = tid < nown ? alf[j0 + tid] * (dal[tid] - dot) : 0.f;
+    __syncthreads();
 
     T2V_STAMP(a, 2);
-    // 3. softmax backward (every wave reduces redundantly)
+    // ---- through v·tanh(.): dpre, partial dq / dv
     {
-        float part = 0.f;
-        for (int j = lane; j < Tp; j += 64) part = fmaf(alpha[j], dal[j], part);
-        const float dot = wave_sum(part);
-        for (int j = tid; j < Tp; j += ATB_THREADS) de[j] = alpha[j] * (dal[j] - dot);
-    }
-    __syncthreads();
-
-    T2V_STAMP(a, 3);
-    // 4. through v . tanh(.)
-    {
-        float* sp = a.S_t + (size_t)b * Tp * T2V_A + d;
+        float* sp = a.S_t + ((size_t)b * Tp + j0) * T2V_A + d;
         float dq = 0.f, dv = 0.f;
 #pragma unroll
-        for (int i = 0; i < JP; ++i) {
-            const int j = j4 + ATB_R * i;
-            if (j < Tp) {
-                const float s = sreg[i];
-                const float dej = de[j];
-                const float dp = dej * vd * (1.0f - s * s);
-                dpT[d * TpP + j] = dp;
-                sp[(size_t)j * T2V_A] = dp;
+        for (int i = 0; i < JS / 2; ++i) {
+            const int jl = jh + 2 * i;
+            float dp = 0.f;
+            if (jl < nown) {
+                const float sv = sreg[i], dej = de[jl];
+                dp = dej * vd * (1.0f - sv * sv);
+                sp[(size_t)jl * T2V_A] = dp;
                 dq += dp;
-                dv = fmaf(dej, s, dv);
+                dv = fmaf(dej, sv, dv);
             }
+            dpT[d][jl] = dp;
         }
-        // columns j in [Tp, 16*ceil(Tp/16)) feed discarded MFMA columns: keep them finite
-        for (int j = Tp + j4; j < TpP - 1; j += ATB_R) dpT[d * TpP + j] = 0.f;
-        scr[tid] = dq;
-        scr[ATB_THREADS + tid] = dv;
+        scr[8 + tid] = dq;
+        scr[8 + ATB_THREADS + tid] = dv;
         __syncthreads();
         if (tid < T2V_A) {
-            float q = 0.f, v = 0.f;
-#pragma unroll
-            for (int i = 0; i < ATB_R; ++i) { q += scr[i * T2V_A + tid]; v += scr[ATB_THREADS + i * T2V_A + tid]; }
-            a.DQ_t[(size_t)b * T2V_A + tid] = q;
-            a.DV[(size_t)b * T2V_A + tid] += v;
+            a.DQ_t[((size_t)b * ATB_MAXS + s) * T2V_A + tid] = scr[8 + tid] + scr[8 + 128 + tid];
+            a.DV[((size_t)b * ATB_MAXS + s) * T2V_A + tid] += scr[8 + ATB_THREADS + tid] + scr[8 + ATB_THREADS + 128 + tid];
         }
     }
 
-    T2V_STAMP(a, 4);
-    // 5. through location_dense on MFMA: dc[f][j] = sum_d D[d][f] dpre[j][d]; tile = 16 f x 16 j, K = 128
+    T2V_STAMP(a, 3);
+    // ---- through location_dense on MFMA: dc[f][j] = sum_d D[d][f] dpre[j][d]; K = 128 split over wave pairs
     {
-        const int f0 = 16 * (wave & 1);
-        const int NJ = (Tp + 15) >> 4;
-        for (int jt = wave >> 1; jt < NJ; jt += ATB_THREADS / 128) {
-            const int j = 16 * jt + c16;
+        const int f0 = 16 * (wave & 1), kh = wave >> 1;
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int st = 0; st < 32; ++st) acc = mfma16x4(areg[st], dpT[(4 * st + g) * TpP + j], acc);
-            if (j < Tp) {
+            for (int st = 0; st < 16; ++st) acc = mfma16x4(areg[st], dpT[64 * kh + 4 * st + g][16 * jt + c16], acc);
+            if (kh == 1) red[jt & 1][wave & 1][lane] = acc;
+            __syncthreads();
+            if (kh == 0) {
+                const f32x4 o = red[jt & 1][wave & 1][lane];
+                const int jl = 16 * jt + c16;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int f = f0 + 4 * g + r;
-                    dcs[f * DS + 15 + j] = acc[r];
-                    a.DC_t[((size_t)b * T2V_F + f) * Tp + j] = acc[r];
+                    const float v = acc[r] + o[r];
+                    dcl[f][30 + jl] = v;
+                    if (jl < nown) a.DC_t[((size_t)b * T2V_F + f) * Tp + j0 + jl] = v;
                 }
             }
         }
     }
     __syncthreads();
 
-    T2V_STAMP(a, 5);
-    // 6. through location_conv (transposed): dcat[ch][j] = sum_{f,k} Wc[f][ch][k] dc[f][j+15-k]
-    //    thread = (f, block of 6 consecutive j): sliding window in registers, then a 32-lane sum over f
+    T2V_STAMP(a, 4);
+    // ---- through location_conv (transposed), scatter form over this slice's dc:
+    //      part[ch][jj] = sum_{f,k} Wc[f][ch][k] dc[f][jj - k],  jj in [0, JS+30)  <->  position j0 - 15 + jj
     {
         const int f = tid & 31;
-        float wc[2][T2V_KS];
+        float* gout = a.GP_out + (((size_t)b * ATB_MAXS + s) * 2) * 64;
 #pragma unroll
-        for (int ch = 0; ch < 2; ++ch)
+        for (int ch = 0; ch < 2; ++ch) {
+            float wc[T2V_KS];
 #pragma unroll
-            for (int k = 0; k < T2V_KS; ++k) wc[ch][k] = wcl[f * 63 + ch * T2V_KS + k];
-        for (int j0 = 6 * (tid >> 5); j0 < Tp; j0 += 6 * (ATB_THREADS / 32)) {
-            float win[36];
-            const float* row = dcs + f * DS + j0;      // dcs index of dc[f][jj] is 15 + jj
+            for (int k = 0; k < T2V_KS; ++k) wc[k] = wcl[f * 63 + ch * T2V_KS + k];
+            // thread = (f, block of 6 consecutive outputs): 36-wide window in registers
+            for (int jb = 6 * (tid >> 5); jb < PW; jb += 6 * (ATB_THREADS / 32)) {
+                float win[36];
+                const float* row = &dcl[f][jb];             // dcl index of dc[f][x] is 30 + x; window covers x = jb-30 .. jb+5
 #pragma unroll
-            for (int i = 0; i < 36; ++i) win[i] = row[i];   // dc[f][j0-15 .. j0+20]
-#pragma unroll
-            for (int ch = 0; ch < 2; ++ch) {
+                for (int i = 0; i < 36; ++i) win[i] = row[i];
                 float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < T2V_KS; ++k)
 #pragma unroll
-                    for (int jj = 0; jj < 6; ++jj) acc[jj] = fmaf(wc[ch][k], win[jj + 30 - k], acc[jj]);
+                    for (int q = 0; q < 6; ++q) acc[q] = fmaf(wc[k], win[30 + q - k], acc[q]);
 #pragma unroll
-                for (int jj = 0; jj < 6; ++jj) {
-                    float v = row16_sum(acc[jj]);
+                for (int q = 0; q < 6; ++q) {
+                    float v = row16_sum(acc[q]);
                     v += __shfl_xor(v, 16, 64);
-                    const int j = j0 + jj;
-                    if (f == 0 && j < Tp) {
-                        if (ch == 0) a.GPREV[(size_t)b * Tp + j] = v;
-                        else a.GCUM[(size_t)b * Tp + j] += v;
-                    }
+                    if (f == 0 && jb + q < PW) gout[ch * 64 + jb + q] = v;
                 }
             }
         }
     }
-    T2V_STAMP(a, 6);
+    T2V_STAMP(a, 5);
 }
 
 // grid = 64 blocks x 256 threads; thread = (unit U, item b)
 __global__ __launch_bounds__(256) void k_cell_bwd(CellBwdArgs a) {
-    const int U = blockIdx.x * 16 + (threadIdx.x >> 4), b = threadIdx.x & 15;
-    if (b >= a.B) return;
+    __shared__ __attribute__((aligned(16))) float wqs[16][T2V_A + 4];
+    __shared__ __attribute__((aligned(16))) float dqs[16][T2V_A + 4];
+    const int tid = threadIdx.x;
+    const int U = blockIdx.x * 16 + (tid >> 4), b = tid & 15;
+    const bool bv = b < a.B;
     const uint32_t idx = (uint32_t)b * T2V_H + U;
     const size_t bu = (size_t)b * T2V_H + U;
+    // everything this thread needs from global memory is requested up front (one latency round)
+    float yd0 = 0.f, ya0 = 0.f, ga[4] = {0, 0, 0, 0}, cac = 0.f, cap = 0.f, dca = 0.f;
+    float hcp = 0.f, yd1 = 0.f, gd[4] = {0, 0, 0, 0}, cdc = 0.f, cdp = 0.f, dcd = 0.f;
+    if (a.do_att) {
+        // stage W_q^T rows of this block's 16 units and dq (= sum of the S per-slice partials)
+        for (int i = tid; i < 16 * T2V_A / 4; i += 256) {
+            const int u = i >> 5, c4 = i & 31;
+            *(float4*)&wqs[u][4 * c4] = *(const float4*)(a.wqT + (size_t)(blockIdx.x * 16 + u) * T2V_A + 4 * c4);
+        }
+        for (int i = tid; i < a.B * T2V_A; i += 256) {
+            const int bb = i >> 7, dd = i & (T2V_A - 1);
+            float pv[8];
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) pv[sl] = a.DQ_t[((size_t)bb * 8 + sl) * T2V_A + dd];   // unused slices are zero
+            dqs[bb][dd] = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
+        }
+        if (bv) {
+            yd0 = a.YD[(size_t)b * T2V_XW + U];
+            ya0 = a.YA[(size_t)b * T2V_KATT + U];
+            const float* gp = a.GA_t + (size_t)b * T2V_G + U;
+            ga[0] = gp[0]; ga[1] = gp[T2V_H]; ga[2] = gp[2 * T2V_H]; ga[3] = gp[3 * T2V_H];
+            cac = a.CA_cur[bu]; cap = a.CA_prev[bu]; dca = a.DCA[bu];
+        }
+    }
+    if (a.do_dec && bv) {
+        hcp = a.dHC_prev[(size_t)b * (T2V_H + T2V_E) + U];
+        yd1 = a.YD[(size_t)b * T2V_XW + T2V_KATT + U];
+        const float* gp = a.GD_p + (size_t)b * T2V_G + U;
+        gd[0] = gp[0]; gd[1] = gp[T2V_H]; gd[2] = gp[2 * T2V_H]; gd[3] = gp[3 * T2V_H];
+        cdc = a.CD_cur[bu]; cdp = a.CD_prev[bu]; dcd = a.DCD[bu];
+    }
+    __syncthreads();
+    if (!bv) return;
     if (a.do_att) {
         const int t = a.t;
-        const float* wq = a.wqT + (size_t)U * T2V_A;
-        const float* dq = a.DQ_t + (size_t)b * T2V_A;
+        const float4* w4 = (const float4*)wqs[tid >> 4];
+        const float4* q4 = (const float4*)dqs[b];
         float dot0 = 0.f, dot1 = 0.f;
-#pragma unroll 16
-        for (int d = 0; d < T2V_A; d += 4) {
-            const float4 w4 = *(const float4*)(wq + d);
-            const float4 q4 = *(const float4*)(dq + d);
-            dot0 = fmaf(w4.x, q4.x, dot0);
-            dot1 = fmaf(w4.y, q4.y, dot1);
-            dot0 = fmaf(w4.z, q4.z, dot0);
-            dot1 = fmaf(w4.w, q4.w, dot1);
+#pragma unroll 8
+        for (int i = 0; i < T2V_A / 4; ++i) {
+            const float4 wv = w4[i], qv = q4[i];
+            dot0 = fmaf(wv.x, qv.x, dot0);
+            dot1 = fmaf(wv.y, qv.y, dot1);
+            dot0 = fmaf(wv.z, qv.z, dot0);
+            dot1 = fmaf(wv.w, qv.w, dot1);
         }
-        const float dh = a.YD[(size_t)b * T2V_XW + U] + a.YA[(size_t)b * T2V_KATT + U] + (dot0 + dot1);
+        const float dh = yd0 + ya0 + (dot0 + dot1);
         const float fh = t2v_drop_scale(a.seed, T2V_RNG_ATT_H, t, idx, a.p_att);
         const float fc = t2v_drop_scale(a.seed, T2V_RNG_ATT_C, t, idx, a.p_att);
-        const float* ga = a.GA_t + (size_t)b * T2V_G + U;
-        const float gi = ga[0], gf = ga[T2V_H], gg = ga[2 * T2V_H], go = ga[3 * T2V_H];
-        const float tc = tanhf_(a.CA_cur[bu]);
+        const float gi = ga[0], gf = ga[1], gg = ga[2], go = ga[3];
+        const float tc = tanhf_(cac);
         const float dht = dh * fh;
-        const float dct = a.DCA[bu] * fc + dht * go * (1.0f - tc * tc);
-        float cprev = a.CA_prev[bu];
+        const float dct = dca * fc + dht * go * (1.0f - tc * tc);
+        float cprev = cap;
         if (t > 0) cprev *= t2v_drop_scale(a.seed, T2V_RNG_ATT_C, t - 1, idx, a.p_att);
         float* o = a.DGA_t + (size_t)b * T2V_G + U;
         o[0] = dct * gg * gi * (1.0f - gi);
@@ -290,15 +335,14 @@ __global__ __launch_bounds__(256) void k_cell_bwd(CellBwdArgs a) {
     }
     if (a.do_dec) {
         const int td = a.t - 1;
-        const float dh = a.dHC_prev[(size_t)b * (T2V_H + T2V_E) + U] + a.YD[(size_t)b * T2V_XW + T2V_KATT + U];
+        const float dh = hcp + yd1;
         const float fh = t2v_drop_scale(a.seed, T2V_RNG_DEC_H, td, idx, a.p_dec);
         const float fc = t2v_drop_scale(a.seed, T2V_RNG_DEC_C, td, idx, a.p_dec);
-        const float* gd = a.GD_p + (size_t)b * T2V_G + U;
-        const float gi = gd[0], gf = gd[T2V_H], gg = gd[2 * T2V_H], go = gd[3 * T2V_H];
-        const float tc = tanhf_(a.CD_cur[bu]);
+        const float gi = gd[0], gf = gd[1], gg = gd[2], go = gd[3];
+        const float tc = tanhf_(cdc);
         const float dht = dh * fh;
-        const float dct = a.DCD[bu] * fc + dht * go * (1.0f - tc * tc);
-        float cprev = a.CD_prev[bu];
+        const float dct = dcd * fc + dht * go * (1.0f - tc * tc);
+        float cprev = cdp;
         if (td > 0) cprev *= t2v_drop_scale(a.seed, T2V_RNG_DEC_C, td - 1, idx, a.p_dec);
         float* o = a.DGD_p + (size_t)b * T2V_G + U;
         o[0] = dct * gg * gi * (1.0f - gi);
@@ -315,22 +359,16 @@ extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_tra
     hipStream_t stream = (hipStream_t)stream_;
     if (!w || !s || !g || B < 1 || B > 16 || T_in < 1 || T_out < 1) return T2V_ERR_ARG;
     if (!w->packB_att || !w->packB_dec) return T2V_ERR_ARG;
-    const size_t lds = t2v_attn_bwd_lds(T_in);
-    if (lds > 160 * 1024) return T2V_ERR_ARG;
     if (T_in > 256) return T2V_ERR_ARG;
-#define ATB_LAUNCH(JPV)                                                                                   \
-    do {                                                                                                  \
-        if (lds > 64 * 1024)                                                                              \
-            (void)hipFuncSetAttribute((const void*)k_attn_bwd<JPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        k_attn_bwd<JPV><<<B, ATB_THREADS, lds, stream>>>(f);                                              \
-    } while (0)
+    const int JS = attn_bwd_js(T_in), S = (T_in + JS - 1) / JS;
     (void)hipMemsetAsync(g->YD, 0, sizeof(float) * B * T2V_XW, stream);
     (void)hipMemsetAsync(g->YA, 0, sizeof(float) * B * T2V_KATT, stream);
     (void)hipMemsetAsync(g->DCA, 0, sizeof(float) * B * T2V_H, stream);
     (void)hipMemsetAsync(g->DCD, 0, sizeof(float) * B * T2V_H, stream);
-    (void)hipMemsetAsync(g->GPREV, 0, sizeof(float) * B * T_in, stream);
-    (void)hipMemsetAsync(g->GCUM, 0, sizeof(float) * B * T_in, stream);
-    (void)hipMemsetAsync(g->DV, 0, sizeof(float) * B * T2V_A, stream);
+    (void)hipMemsetAsync(g->GPREV, 0, sizeof(float) * 2 * B * ATB_MAXS * 2 * 64, stream);   // partial dcat rows x parity
+    (void)hipMemsetAsync(g->GCUM, 0, sizeof(float) * B * ATB_MAXS * 256, stream);          // per-workgroup Gcum copies
+    (void)hipMemsetAsync(g->DV, 0, sizeof(float) * B * ATB_MAXS * T2V_A, stream);
+    (void)hipMemsetAsync(g->DQ, 0, sizeof(float) * (size_t)T_out * B * ATB_MAXS * T2V_A, stream);
 
     const size_t HC = T2V_H + T2V_E;
     for (int t = T_out; t >= 0; --t) {
@@ -356,22 +394,24 @@ extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_tra
             f.loc_dense = w->loc_dense;
             f.v = w->v;
             f.S_t = s->S + (size_t)t * B * T_in * T2V_A;
-            f.DQ_t = g->DQ + (size_t)t * B * T2V_A;
+            f.DQ_t = g->DQ + (size_t)t * B * ATB_MAXS * T2V_A;
+            f.ctx_t = s->XS + (size_t)(t + 1) * B * T2V_XW + T2V_H;
+            f.GP_in = g->GPREV + (size_t)((t + 1) & 1) * B * ATB_MAXS * 2 * 64;
+            f.GP_out = g->GPREV + (size_t)(t & 1) * B * ATB_MAXS * 2 * 64;
+            f.GC = g->GCUM;
             f.DCTX_t = g->DCTX + (size_t)t * B * T2V_E;
             f.DC_t = g->DC + (size_t)t * B * T2V_F * T_in;
-            f.GPREV = g->GPREV;
-            f.GCUM = g->GCUM;
             f.DV = g->DV;
             f.T_in = T_in;
             f.prof = g_t2v_prof ? g_t2v_prof + 16 : nullptr;
-            if (T_in <= 22 * ATB_R) ATB_LAUNCH(22);
-            else if (T_in <= 32 * ATB_R) ATB_LAUNCH(32);
-            else ATB_LAUNCH(64);
+            if (JS == 16) k_attn_bwd<16><<<dim3(B, S), ATB_THREADS, 0, stream>>>(f);
+            else k_attn_bwd<32><<<dim3(B, S), ATB_THREADS, 0, stream>>>(f);
         }
         CellBwdArgs c;
         c.YD = g->YD;
         c.YA = g->YA;
-        c.DQ_t = t < T_out ? g->DQ + (size_t)t * B * T2V_A : nullptr;
+        c.DQ_t = t < T_out ? g->DQ + (size_t)t * B * ATB_MAXS * T2V_A : nullptr;
+        c.S = S;
         c.wqT = w->wqT;
         c.dHC_prev = t >= 1 ? g->dHC + (size_t)(t - 1) * B * HC : nullptr;
         c.GA_t = t < T_out ? s->GA + (size_t)t * B * T2V_G : nullptr;

@@ -81,9 +81,11 @@ struct AttnBwdArgs {
     float* DQ_t;            // (B,128)
     float* DCTX_t;          // (B,512)
     float* DC_t;            // (B,32,T_in)
-    float* GPREV;
-    float* GCUM;
-    float* DV;
+    const float* ctx_t;     // XS[t+1] + 1024: attention context of step t (row stride 2560)
+    const float* GP_in;     // (B,8,2,64) per-slice partial dcat rows written by reverse step t+1
+    float* GP_out;          // (B,8,2,64) ... written by this step (other parity)
+    float* GC;              // (B,8,256) per-workgroup running copies of the cumulative-weights gradient
+    float* DV;              // (B,8,128) per-slice accumulators
     int T_in;
     unsigned long long* prof;
 };
@@ -91,7 +93,8 @@ struct AttnBwdArgs {
 struct CellBwdArgs {
     const float* YD;
     const float* YA;
-    const float* DQ_t;      // (B,128)
+    const float* DQ_t;      // (B,8,128) per-slice partials of step t
+    int S;                  // slices actually written
     const float* wqT;       // (1024,128)
     const float* dHC_prev;  // dHC[t-1] (B,1536)
     const float* GA_t;      // GA[t]

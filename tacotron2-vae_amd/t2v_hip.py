@@ -204,13 +204,13 @@ class DecoderCore(torch.autograd.Function):
         dHC = _f32c(dHC)
         DGA = torch.empty(T, B, G4, **f32)
         DGD = torch.empty(T, B, G4, **f32)
-        DQ = torch.empty(T, B, A, **f32)
+        DQ = torch.empty(T, B, 8, A, **f32)
         DCTX = torch.empty(T, B, E, **f32)
         DC = torch.empty(T, B, F_LOC, T_in, **f32)
         YD = torch.empty(B, XW, **f32); YA = torch.empty(B, KATT, **f32)
         DCA = torch.empty(B, H, **f32); DCD = torch.empty(B, H, **f32)
-        GPREV = torch.empty(B, T_in, **f32); GCUM = torch.empty(B, T_in, **f32)
-        DV = torch.empty(B, A, **f32)
+        GPREV = torch.empty(2, B, 8, 2, 64, **f32); GCUM = torch.empty(B, 8, 256, **f32)
+        DV = torch.empty(B, 8, A, **f32)
         W = _DecWeights(_p(packF_att), _p(packF_dec), _p(packB_att), _p(packB_dec), None, _p(bias_dec),
                         _p(wqT), _p(loc_conv), _p(loc_dense), _p(vv))
         Sb = _DecTrainBufs(_p(gpre), _p(memory), _p(pm), _p(lengths), _p(XS), _p(CA), _p(CD), _p(GA), _p(GD),
@@ -232,12 +232,12 @@ class DecoderCore(torch.autograd.Function):
         d_w_ih_dec = dw_dec[:, :KATT].contiguous()
         d_w_hh_dec = dw_dec[:, KATT:].contiguous()
         d_bias_dec = dgd2.sum(0)
-        d_wq = DQ.view(TB, A).t() @ x_cur[:, :H]
+        d_wq = DQ.sum(2).view(TB, A).t() @ x_cur[:, :H]
         d_memory = torch.bmm(AL[1:].permute(1, 2, 0), DCTX.permute(1, 0, 2))
         dpre = S                                   # overwritten in place by the backward kernels
         d_pm = dpre.sum(0)
         d_loc_dense = dpre.view(-1, A).t() @ CONV.permute(0, 1, 3, 2).reshape(-1, F_LOC)
-        d_v = DV.sum(0).view(1, A)
+        d_v = DV.sum((0, 1)).view(1, A)
         apad = torch.nn.functional.pad(torch.stack((AL[0:T], ACUM[0:T]), 2), (15, 15))   # (T,B,2,T_in+30)
         d_loc_conv = torch.einsum('nfj,ncjk->fck', DC.view(TB, F_LOC, T_in),
                                   apad.view(TB, 2, T_in + 30).unfold(2, KS, 1))

@@ -32,7 +32,7 @@ def _oracle(dec, memory, mels, lengths, wm, wg):
 
 
 @pytest.mark.parametrize("B,T_in,T_out,lens", [(3, 20, 12, [20, 17, 9]), (6, 84, 24, [84, 80, 71, 66, 50, 37]),
-                                               (1, 33, 7, [33])])
+                                               (1, 33, 7, [33]), (2, 150, 6, [150, 97])])
 def test_decoder_core_matches_oracle(B, T_in, T_out, lens):
     hp, M, dec, memory, mels, lengths, wm, wg = _setup(B, T_in, T_out, lens)
     o_mel, o_gate, o_align, o_sd, o_mem = _oracle(dec, memory, mels, lengths, wm, wg)
