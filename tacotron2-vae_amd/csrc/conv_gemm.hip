@@ -18,7 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CG_BM 64
 #define CG_BN 64
-#define CG_BK 16
+#define CG_BK 32
 
 struct ConvGemmArgs {
     const float* W;      // forward: (M, Cin*KS) row-major
@@ -31,7 +31,7 @@ struct ConvGemmArgs {
 };
 
 // MODE 0: forward / data gradient.  MODE 1: weight gradient.
-template <int MODE>
+template <int MODE, int KS>
 __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
     __shared__ float As[2][CG_BK][CG_BM + 1];
     __shared__ float Bs[2][CG_BK][CG_BN + 1];
@@ -39,50 +39,50 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * CG_BM, n0 = blockIdx.x * CG_BN;
-    const int P = a.KS >> 1;
-    const int BT = a.B * a.T, CK = a.Cin * a.KS;
+    constexpr int P = KS >> 1;
+    const int BT = a.B * a.T, CK = a.Cin * KS;
     const int Kdim = MODE == 0 ? CK : BT;
     const int Ndim = MODE == 0 ? BT : CK;
 
-    // each thread stages 4 A elements and 4 B elements per k-tile
-    float ra[4], rb[4];
+    // each thread stages 8 A elements and 8 B elements per k-tile (BK = 32); everything that does not
+    // depend on the k-tile (row / column decomposition) is computed once
+    constexpr int NE = CG_BM * CG_BK / 256;     // 8
+    float ra[NE], rb[NE];
+    // MODE 0:  A: thread -> (mm = e>>5, kk = e&31);  B: thread -> (kb = e>>6, nn = e&63)
+    // MODE 1:  A: (mm = e>>5, kk = e&31) with k=(b,t);  B: (nn = e>>5, kb = e&31)
+    int b_bb = 0, b_t = 0;          // MODE 0: this thread's fixed output column n -> (bb, t)
+    bool b_nok = false;
+    if (MODE == 0) {
+        const int n = n0 + (tid & (CG_BN - 1));
+        b_nok = n < Ndim;
+        b_bb = b_nok ? n / a.T : 0;
+        b_t = n - b_bb * a.T;
+    }
     auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + 256 * i;                       // 0..1023
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + 256 * i;
             if (MODE == 0) {
-                // A[m][k] = W[m][k]: k contiguous -> threads run along k
-                const int kk = e & (CG_BK - 1), mm = e >> 4;
+                const int kk = e & (CG_BK - 1), mm = e >> 5;
                 const int m = m0 + mm, k = k0 + kk;
                 ra[i] = (m < a.M && k < Kdim) ? a.W[(size_t)m * CK + k] : 0.f;
-                // B[k=(c,kx)][n=(b,t)] = X[b][c][t+kx-P]: t contiguous -> threads run along n
-                const int nn = e & (CG_BN - 1), kb = e >> 6;
-                const int n = n0 + nn, k2 = k0 + kb;
+                const int k2 = k0 + (e >> 6);
                 float v = 0.f;
-                if (n < Ndim && k2 < Kdim) {
-                    const int c = k2 / a.KS, kx = k2 - c * a.KS;
-                    const int bb = n / a.T, t = n - bb * a.T;
-                    const int ts = t + kx - P;
-                    if (ts >= 0 && ts < a.T) v = a.X[((size_t)bb * a.Cin + c) * a.T + ts];
+                if (b_nok && k2 < Kdim) {
+                    const int c = k2 / KS, kx = k2 - c * KS;
+                    const int ts = b_t + kx - P;
+                    if (ts >= 0 && ts < a.T) v = a.X[((size_t)b_bb * a.Cin + c) * a.T + ts];
                 }
                 rb[i] = v;
             } else {
-                // A[m][k=(b,t)] = dY[b][m][t]: t contiguous -> threads run along k
-                const int kk = e & (CG_BK - 1), mm = e >> 4;
+                const int kk = e & (CG_BK - 1), mm = e >> 5;
                 const int m = m0 + mm, k = k0 + kk;
-                float v = 0.f;
-                if (m < a.M && k < Kdim) {
-                    const int bb = k / a.T, t = k - bb * a.T;
-                    v = a.dY[((size_t)bb * a.M + m) * a.T + t];
-                }
-                ra[i] = v;
-                // B[k=(b,t)][n=(c,kx)] = X[b][c][t+kx-P]: t contiguous -> threads run along k
-                const int kb = e & (CG_BK - 1), nn = e >> 4;
-                const int n = n0 + nn, k2 = k0 + kb;
+                const int bb = k / a.T, t = k - bb * a.T;
+                ra[i] = (m < a.M && k < Kdim) ? a.dY[((size_t)bb * a.M + m) * a.T + t] : 0.f;
+                const int n = n0 + mm;           // same (kk, mm) decomposition for the B tile
                 float w = 0.f;
-                if (n < Ndim && k2 < Kdim) {
-                    const int c = n / a.KS, kx = n - c * a.KS;
-                    const int bb = k2 / a.T, t = k2 - bb * a.T;
+                if (n < Ndim && k < Kdim) {
+                    const int c = n / KS, kx = n - c * KS;
                     const int ts = t + kx - P;
                     if (ts >= 0 && ts < a.T) w = a.X[((size_t)bb * a.Cin + c) * a.T + ts];
                 }
@@ -92,11 +92,11 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NE; ++i) {
             const int e = tid + 256 * i;
-            As[buf][e & (CG_BK - 1)][e >> 4] = ra[i];
+            As[buf][e & (CG_BK - 1)][e >> 5] = ra[i];
             if (MODE == 0) Bs[buf][e >> 6][e & (CG_BN - 1)] = rb[i];
-            else Bs[buf][e & (CG_BK - 1)][e >> 4] = rb[i];
+            else Bs[buf][e & (CG_BK - 1)][e >> 5] = rb[i];
         }
     };
 
@@ -180,7 +180,9 @@ extern "C" int t2v_conv1d_fwd(const float* W, const float* X, const float* bias,
     a.W = W; a.X = X; a.dY = nullptr; a.bias = bias; a.Y = Y; a.stat_part = stat_part;
     a.B = B; a.Cin = Cin; a.T = T; a.M = Cout; a.KS = KS;
     dim3 grid((B * T + CG_BN - 1) / CG_BN, (Cout + CG_BM - 1) / CG_BM);
-    k_conv_gemm<0><<<grid, 256, 0, stream>>>(a);
+    if (KS == 5) k_conv_gemm<0, 5><<<grid, 256, 0, stream>>>(a);
+    else if (KS == 3) k_conv_gemm<0, 3><<<grid, 256, 0, stream>>>(a);
+    else return T2V_ERR_DIMS;
     return t2v_check_launch();
 }
 
@@ -198,14 +200,18 @@ extern "C" int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, f
         a.W = Wt_scratch; a.X = dY; a.dY = nullptr; a.bias = nullptr; a.Y = dX; a.stat_part = nullptr;
         a.B = B; a.Cin = Cout; a.T = T; a.M = Cin; a.KS = KS;
         dim3 grid((B * T + CG_BN - 1) / CG_BN, (Cin + CG_BM - 1) / CG_BM);
-        k_conv_gemm<0><<<grid, 256, 0, stream>>>(a);
+        if (KS == 5) k_conv_gemm<0, 5><<<grid, 256, 0, stream>>>(a);
+        else if (KS == 3) k_conv_gemm<0, 3><<<grid, 256, 0, stream>>>(a);
+        else return T2V_ERR_DIMS;
     }
     if (dW) {
         ConvGemmArgs a;
         a.W = nullptr; a.X = X; a.dY = dY; a.bias = nullptr; a.Y = dW; a.stat_part = nullptr;
         a.B = B; a.Cin = Cin; a.T = T; a.M = Cout; a.KS = KS;
         dim3 grid((Cin * KS + CG_BN - 1) / CG_BN, (Cout + CG_BM - 1) / CG_BM);
-        k_conv_gemm<1><<<grid, 256, 0, stream>>>(a);
+        if (KS == 5) k_conv_gemm<1, 5><<<grid, 256, 0, stream>>>(a);
+        else if (KS == 3) k_conv_gemm<1, 3><<<grid, 256, 0, stream>>>(a);
+        else return T2V_ERR_DIMS;
     }
     return t2v_check_launch();
 }
