@@ -172,208 +172,6 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(LstmFwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Attention step.  grid = (B, SE), 1024 threads: every workgroup of an item recomputes the
-// energies and softmax; workgroup `se` produces context columns [se*512/SE, (se+1)*512/SE).
-// All global reads (256 query partials, pm, memory slice, weights) are issued at kernel entry
-// so their latencies overlap; the phases then run out of registers / LDS.
-// JP = ceil(T_in/ATT_R) upper bound (per-thread register rows).
-// LDS carve (floats): q[128] | ap[2][Tp+30] | cs[32][Tp] | e[TpR] | wcl[32*63] | scr[512+8*Tp]
-#define ATT_THREADS 512
-#define ATT_R (ATT_THREADS / 128)      // row phases: thread = (d = tid&127, j8 = tid>>7)
-template <int JP, int NJT>
-__global__ __launch_bounds__(ATT_THREADS) void k_attn_fwd(AttnFwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, se = blockIdx.y, SE = gridDim.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Tp = a.T_in, TpH = Tp + 30, TpR = (Tp + 3) & ~3;
-    float* q = smem;
-    float* ap = q + T2V_A;
-    float* cs = ap + 2 * TpH;
-    float* e = cs + T2V_F * Tp;
-    float* wcl = e + TpR;
-    float* scr = wcl + T2V_F * 63;
-    const int len = a.lengths ? a.lengths[b] : Tp;
-    const int d = tid & (T2V_A - 1), j8 = tid >> 7;     // (column, row-phase) mapping used by 1/3/5
-
-    T2V_STAMP(a, 0);
-    // ---- issue every global read up front
-    constexpr int NQ = T2V_NWG / ATT_R;
-    float qpart[NQ];
-    {
-        const float* p = a.qp + ((size_t)b * T2V_NWG + NQ * j8) * T2V_A + d;
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) qpart[i] = p[(size_t)i * T2V_A];
-    }
-    // pm in the MFMA output layout of phase 3: lane (g, c16) of wave w holds (j = 16jt+4g+r, d = 16w+c16)
-    float pmr[NJT][4];
-    const int ES = T2V_E / SE;                         // context columns of this workgroup (128)
-    {
-        const float* pmb = a.pm + (size_t)b * Tp * T2V_A + 16 * wave + (lane & 15);
-#pragma unroll
-        for (int jt = 0; jt < NJT; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = 16 * jt + 4 * (lane >> 4) + r;
-                pmr[jt][r] = j < Tp ? pmb[(size_t)j * T2V_A] : 0.f;
-            }
-    }
-    {   // location_conv weights (1984 floats = 496 float4) -> padded LDS rows; prev/cum weights
-        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < T2V_F * 62 / 4) w4 = ((const float4*)a.loc_conv)[tid];
-        float av[2] = {0.f, 0.f};
-        if (tid < Tp) { av[0] = a.al_prev[(size_t)b * Tp + tid]; av[1] = a.acum_prev[(size_t)b * Tp + tid]; }
-        for (int i = tid; i < 2 * TpH; i += ATT_THREADS) ap[i] = 0.f;          // halos (and body) zero
-        if (tid < T2V_F * 62 / 4) {
-            const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { const int i = 4 * tid + c; wcl[(i / 62) * 63 + (i % 62)] = wv[c]; }
-        }
-        __syncthreads();
-        if (tid < Tp) { ap[15 + tid] = av[0]; ap[TpH + 15 + tid] = av[1]; }
-    }
-    // ---- 1. processed query = sum of the 256 per-workgroup partials (fixed order)
-    {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-        for (int i = 0; i < NQ; i += 4) { s0 += qpart[i]; s1 += qpart[i + 1]; s2 += qpart[i + 2]; s3 += qpart[i + 3]; }
-        scr[tid] = (s0 + s1) + (s2 + s3);
-    }
-    float dw[8];     // location_dense as the MFMA B operand of phase 3: D[16w + c16][4st + g]
-#pragma unroll
-    for (int st = 0; st < 8; ++st) dw[st] = a.loc_dense[(16 * wave + (lane & 15)) * T2V_F + 4 * st + (lane >> 4)];
-    __syncthreads();
-    if (tid < T2V_A) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < ATT_R; ++i) s += scr[i * T2V_A + tid];
-        q[tid] = s;
-    }
-
-    T2V_STAMP(a, 1);
-    // ---- 2. location conv as an MFMA GEMM: cs[f][j] = sum_kk Wc[f][kk] * im2col(ap)[kk][j],
-    //         kk = 32*ch + k (k = 31 is a zero pad) -> K = 64 = 16 k-steps; tile = 16 f x 16 j.
-    const int g = lane >> 4, c16 = lane & 15;
-    {
-        const int f0 = 16 * (wave & 1);
-        float areg[16];
-#pragma unroll
-        for (int st = 0; st < 16; ++st) {
-            const int kk = 4 * st + g, ch = kk >> 5, k = kk & 31;
-            areg[st] = k < T2V_KS ? wcl[(f0 + c16) * 63 + ch * T2V_KS + k] : 0.f;
-        }
-        const int NJ = (Tp + 15) >> 4;
-        for (int jt = wave >> 1; jt < NJ; jt += ATT_THREADS / 128) {
-            const int j = 16 * jt + c16;
-            const int jc = j < Tp ? j : Tp - 1;            // keep LDS reads in range; column discarded
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int st = 0; st < 16; ++st) {
-                const int kk = 4 * st + g, ch = kk >> 5, k = kk & 31;
-                const float bv = ap[ch * TpH + jc + (k < T2V_KS ? k : T2V_KS - 1)];
-                acc = mfma16x4(areg[st], bv, acc);
-            }
-            if (j < Tp) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cs[(f0 + 4 * g + r) * Tp + j] = acc[r];
-            }
-        }
-    }
-    float memr[JP];
-    {
-        const float* mb = a.memory + (size_t)b * Tp * T2V_E + se * ES + d;
-#pragma unroll
-        for (int i = 0; i < JP; ++i) {
-            const int j = j8 + ATT_R * i;
-            memr[i] = j < len ? mb[(size_t)j * T2V_E] : 0.f;
-        }
-    }
-    __syncthreads();
-    if (se == 0 && a.conv_save) {
-        float* dst = a.conv_save + (size_t)b * T2V_F * Tp;
-        for (int i = tid; i < T2V_F * Tp; i += ATT_THREADS) dst[i] = cs[i];
-    }
-
-    T2V_STAMP(a, 2);
-    // ---- 3. energies: loc[j][d] = sum_f cs[f][j] D[d][f] on MFMA (wave = 16 d's, tile = 16 j x 16 d),
-    //         s = tanh(q[d] + loc + pm[j][d]),  e[j] = sum_d v[d] s
-    {
-        const int d0 = 16 * wave, dd = d0 + c16;
-        float breg[8];
-#pragma unroll
-        for (int st = 0; st < 8; ++st) breg[st] = dw[st];
-        const float qd = q[dd], vdd = a.v[dd];
-        float* ssave = (se == 0 && a.s_save) ? a.s_save + (size_t)b * Tp * T2V_A + dd : nullptr;
-#pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) {
-            const int j0 = 16 * jt;
-            if (j0 < Tp) {
-                const int jc = (j0 + c16) < Tp ? (j0 + c16) : Tp - 1;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int st = 0; st < 8; ++st) acc = mfma16x4(cs[(4 * st + g) * Tp + jc], breg[st], acc);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = j0 + 4 * g + r;
-                    const float sv = tanhf_(qd + acc[r] + pmr[jt][r]);
-                    if (ssave && j < Tp) ssave[(size_t)j * T2V_A] = sv;
-                    const float part = row16_sum(vdd * sv);          // over this wave's 16 d's
-                    if (c16 == 0 && j < Tp) scr[ATT_THREADS + 8 * j + wave] = part;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (int j = tid; j < Tp; j += ATT_THREADS) {
-        const float* pp = scr + ATT_THREADS + 8 * j;
-        const float ev = ((pp[0] + pp[1]) + (pp[2] + pp[3])) + ((pp[4] + pp[5]) + (pp[6] + pp[7]));
-        e[j] = j < len ? ev : -INFINITY;
-    }
-    __syncthreads();
-
-    T2V_STAMP(a, 3);
-    // ---- 4. softmax over j (max-subtracted, masked -> exactly 0); every wave reduces redundantly
-    {
-        float m = -INFINITY;
-        for (int j = lane; j < Tp; j += 64) m = fmaxf(m, e[j]);
-        m = wave_max(m);
-        float sum = 0.f;
-        for (int j = lane; j < Tp; j += 64) sum += expf(e[j] - m);
-        sum = wave_sum(sum);
-        const float inv = 1.0f / sum;
-        __syncthreads();
-        for (int j = tid; j < Tp; j += ATT_THREADS) {
-            const float al = expf(e[j] - m) * inv;
-            e[j] = al;
-            if (se == 0) {
-                a.al_cur[(size_t)b * Tp + j] = al;
-                a.acum_cur[(size_t)b * Tp + j] = ap[TpH + 15 + j] + al;
-            }
-        }
-    }
-    __syncthreads();
-
-    T2V_STAMP(a, 4);
-    // ---- 5. context slice: ctx[c] = sum_j alpha[j] * memory[b][j][c]   (thread = (c=d, j8))
-    {
-        float acc = 0.f;
-#pragma unroll
-        for (int i = 0; i < JP; ++i) {
-            const int j = j8 + ATT_R * i;
-            if (j < len) acc = fmaf(e[j], memr[i], acc);
-        }
-        scr[tid] = acc;
-        __syncthreads();
-        if (tid < ES) {
-            float tot = 0.f;
-#pragma unroll
-            for (int pp = 0; pp < ATT_R; ++pp) tot += scr[pp * T2V_A + tid];
-            a.xs_next[(size_t)b * T2V_XW + T2V_H + se * ES + tid] = tot;
-        }
-    }
-    T2V_STAMP(a, 5);
-}
-
-// ------------------------------------------------------------------------------------------
 extern "C" int t2v_pack_lstm_weights(const float* wcat_att, int k_att, const float* wcat_dec,
                                      float* packF_att, float* packF_dec, float* packB_att,
                                      float* packB_dec, void* stream_) {
@@ -400,28 +198,14 @@ extern "C" int t2v_pack_lstm_weights(const float* wcat_att, int k_att, const flo
 }
 
 #define ATT_THREADS_HOST 512
-void t2v_launch_lstm_fwd(int mode, const LstmFwdArgs& a, hipStream_t stream);
-void t2v_launch_attn_fwd(const AttnFwdArgs& f, int B, int T_in, hipStream_t stream);
-
-size_t t2v_attn_fwd_lds(int T_in) {
-    const int TpH = T_in + 30;
-    return sizeof(float) * (T2V_A + 2 * TpH + T2V_F * T_in + ((T_in + 3) & ~3) + T2V_F * 63 + ATT_THREADS + 8 * T_in + 8);
-}
-
 static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s, int B, int T_in, int T_out,
                             float p_att, float p_dec, uint64_t seed, void* stream_, int mask) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!w || !s || B < 1 || B > 16 || T_in < 1 || T_out < 1) return T2V_ERR_ARG;
-    const size_t lds = t2v_attn_fwd_lds(T_in);
-    if (lds > 160 * 1024) return T2V_ERR_ARG;
-    if (T_in > 256) return T2V_ERR_ARG;   // register rows of k_attn_fwd are instantiated up to 4*64
-#define ATF_LAUNCH(JPV, NJV)                                                                              \
-    do {                                                                                                  \
-        if (lds > 64 * 1024)                                                                              \
-            (void)hipFuncSetAttribute((const void*)k_attn_fwd<JPV, NJV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        k_attn_fwd<JPV, NJV><<<dim3(B, SE), ATT_THREADS, lds, stream>>>(f);                               \
-    } while (0)
-    const int SE = 4;
+    if (T_in > 256) return T2V_ERR_ARG;
+    // scratch tail of QP: [0,4096) energy exchange, then 32 uint32 arrival counters / error word
+    float* qp_tail = s->QP + (size_t)B * T2V_NWG * T2V_A;
+    (void)hipMemsetAsync(qp_tail + 4096, 0, 32 * sizeof(uint32_t), stream);
     for (int t = 0; t <= T_out; ++t) {
         LstmFwdArgs a;
         a.packA = (const float4*)w->packF_att;
@@ -467,9 +251,10 @@ static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
             f.conv_save = s->CONV ? s->CONV + (size_t)t * B * T2V_F * T_in : nullptr;
             f.T_in = T_in;
             f.prof = g_t2v_prof;
-            if (T_in <= 22 * ATT_R) ATF_LAUNCH(22, 6);
-            else if (T_in <= 32 * ATT_R) ATF_LAUNCH(32, 8);
-            else ATF_LAUNCH(64, 16);
+            f.ex = qp_tail;
+            f.sync = (unsigned*)(qp_tail + 4096);
+            f.epoch = t + 1;
+            t2v_launch_attn_fwd(f, B, T_in, stream);
         }
     }
     return t2v_check_launch();
@@ -491,11 +276,4 @@ void t2v_launch_lstm_fwd(int mode, const LstmFwdArgs& a, hipStream_t stream) {
     if (mode == 1) k_lstm_fwd<1><<<T2V_NWG, 1024, 0, stream>>>(a);
     else if (mode == 2) k_lstm_fwd<2><<<T2V_NWG, 1024, 0, stream>>>(a);
     else k_lstm_fwd<0><<<T2V_NWG, 1024, 0, stream>>>(a);
-}
-void t2v_launch_attn_fwd(const AttnFwdArgs& f, int B, int T_in, hipStream_t stream) {
-    const size_t lds = t2v_attn_fwd_lds(T_in);
-    const int SE = 4;
-    if (T_in <= 22 * ATT_R) ATF_LAUNCH(22, 6);
-    else if (T_in <= 32 * ATT_R) ATF_LAUNCH(32, 8);
-    else ATF_LAUNCH(64, 16);
 }
