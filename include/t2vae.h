@@ -180,6 +180,15 @@ int t2v_bilstm_bwd(const float* whh, const int32_t* lengths, const float* dy, co
                    const float* cells, float* dg, float* dgx_scratch, uint32_t* sync3, int B, int T,
                    void* stream);
 
+/* ------------------------------------------------------------------ dense layers (time-batched)
+ * C[i][j] (+)= sum_k A[i*sAi + k*sAk] * B[j*sBj + k*sBk] (+ bias[j]), optional ReLU and dropout epilogue
+ * (dropout mask = counter RNG keyed by (seed, rng_stream, rng_t, i*ldc+j)).  Hand-written fp32 MFMA tile
+ * for Prenet (model.py:91-102), memory_layer (model.py:290), the hoisted attention_rnn input term and the
+ * fused linear_projection+gate_layer (model.py:385-388) — forward (NT) and both gradients (NN / TN). */
+int t2v_gemm_f32(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
+                 float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
+                 uint64_t seed, uint32_t rng_stream, uint32_t rng_t, void* stream);
+
 /* ------------------------------------------------------------------ optimiser
  * clip_grad_norm_(params, max_norm) + Adam.step() of the reference loop (train.py:226-229,
  * Adam built at train.py:171-172) fused over one flat fp32 arena.  `grads` holds the SUM over

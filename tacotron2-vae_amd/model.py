@@ -51,9 +51,11 @@ class Prenet(nn.Module):
         self.layers = nn.ModuleList([LinearNorm(i, o, bias=False) for i, o in zip([in_dim] + sizes[:-1], sizes)])
 
     def forward(self, x):
-        # dropout stays on at inference too (reference model.py:101 hard-codes training=True)
-        for linear in self.layers:
-            x = F.dropout(F.relu(linear(x)), p=drop_rate, training=True)
+        # dropout stays on at inference too (reference model.py:101 hard-codes training=True);
+        # Linear + ReLU + dropout is one MFMA GEMM with a fused epilogue
+        _block_calls[0] += 1
+        for i, linear in enumerate(self.layers):
+            x = t2v_hip.LinearHIP.apply(x, linear.weight, None, True, drop_rate, 0x5EED, 48 + i, _block_calls[0])
         return x
 
 
@@ -180,7 +182,7 @@ class Decoder(nn.Module):
     def _session(self, memory, mask, max_steps):
         att, dec, al = self.attention_rnn, self.decoder_rnn, self.attention_layer
         lengths = None if mask is None else (~mask).sum(1).to(device=memory.device, dtype=torch.int32)
-        pm = al.memory_layer(memory)
+        pm = t2v_hip.LinearHIP.apply(memory, al.memory_layer.weight, None, False, 0.0, 0, 0, 0)
         return t2v_hip.InferenceSession(
             memory, pm, lengths, att.weight_ih, att.weight_hh, att.bias_ih + att.bias_hh, dec.weight_ih,
             dec.weight_hh, dec.bias_ih + dec.bias_hh, al.query_layer.weight,
@@ -250,8 +252,9 @@ class Decoder(nn.Module):
         x = torch.cat((self.get_go_frame(memory).unsqueeze(0), frames), 0)       # go frame first
         pre = self.prenet(x)[:T]                                                  # (T,B,256)
         att = self.attention_rnn
-        gpre = F.linear(pre, att.weight_ih[:, :self.prenet_dim], att.bias_ih + att.bias_hh)
-        pm = self.attention_layer.memory_layer(memory)
+        lin = t2v_hip.LinearHIP.apply
+        gpre = lin(pre, att.weight_ih[:, :self.prenet_dim], att.bias_ih + att.bias_hh, False, 0.0, 0, 0, 0)
+        pm = lin(memory, self.attention_layer.memory_layer.weight, None, False, 0.0, 0, 0, 0)
         lengths = memory_lengths.to(device=memory.device, dtype=torch.int32)
         training = self.training
         p_att = self.p_attention_dropout if training else 0.0
@@ -260,8 +263,12 @@ class Decoder(nn.Module):
         seed = (int(self.dropout_seed) * 1000003 + self._calls) & 0x7FFFFFFFFFFFFFFF
         hc, alignments = t2v_hip.DecoderCore.apply(gpre, memory, pm, lengths, *self._core_weights(),
                                                    p_att, p_dec, seed)
-        mel = self.linear_projection(hc).permute(1, 2, 0).contiguous()           # (B,80,T)
-        gate = self.gate_layer(hc).squeeze(-1).transpose(0, 1).contiguous()      # (B,T)
+        # linear_projection and gate_layer as ONE 81-column MFMA tile (reference model.py:385-388)
+        w81 = torch.cat((self.linear_projection.weight, self.gate_layer.weight), 0)
+        b81 = torch.cat((self.linear_projection.bias, self.gate_layer.bias), 0)
+        out = lin(hc, w81, b81, False, 0.0, 0, 0, 0)                              # (T,B,81)
+        mel = out[..., :self.n_mel_channels].permute(1, 2, 0).contiguous()       # (B,80,T)
+        gate = out[..., self.n_mel_channels].transpose(0, 1).contiguous()        # (B,T)
         return mel, gate, alignments
 
 

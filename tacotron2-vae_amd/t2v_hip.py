@@ -45,7 +45,7 @@ class _DecInferBufs(C.Structure):
 
 EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decoder_train_fwd',
            't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd',
-           't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd')
+           't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32')
 
 
 def lib_path():
@@ -92,6 +92,8 @@ def load_library():
                                    C.c_uint64, C.c_uint32, C.c_uint32, vp]
     lib.t2v_bilstm_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.t2v_bilstm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.t2v_gemm_f32.argtypes = [vp, C.c_long, C.c_long, vp, C.c_long, C.c_long, vp, vp, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, vp]
     for name in EXPORTS:
         getattr(lib, name)
     _lib = lib
@@ -433,3 +435,49 @@ def bilstm_check(sync):
     """Raises if a cooperative kernel reported a barrier timeout (forces a device sync; tests only)."""
     if int(sync[2].item()) != 0:
         raise T2VHipError("BiLSTM cooperative kernel timed out on its inter-workgroup barrier")
+
+
+def gemm(A, B, bias=None, out=None, relu=False, accumulate=False, p_drop=0.0, seed=0, rng_stream=0, rng_t=0):
+    """out[i][j] (+)= sum_k A[i][k] * B[j][k] (+ bias[j]) on the HIP MFMA GEMM; A (M,K), B (N,K) may be any
+    2-D strided views (pass W for x·W^T, W.t() for dy·W, dy.t()/x.t() for dy^T·x)."""
+    lib = _require_gpu(A, B)
+    M, K = A.shape
+    N, K2 = B.shape
+    assert K == K2 and A.dtype == torch.float32 and B.dtype == torch.float32
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    assert out.is_contiguous() and out.shape == (M, N)
+    _check(lib.t2v_gemm_f32(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(bias), _p(out), N,
+                            M, N, K, int(relu), int(accumulate), float(p_drop), int(seed), int(rng_stream),
+                            int(rng_t), _stream()), 't2v_gemm_f32')
+    return out
+
+
+class LinearHIP(torch.autograd.Function):
+    """y = dropout(relu?(x·W^T + b)) over the last dimension of x, on t2v_gemm_f32 (forward and both
+    gradients).  The dropout mask is regenerated in the backward from (seed, stream, t)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, p_drop, seed, rng_stream, rng_t):
+        _require_gpu(x, weight)
+        x2 = x.reshape(-1, x.shape[-1])
+        x2 = x2 if x2.dtype == torch.float32 else x2.float()
+        y = gemm(x2, weight, bias, relu=relu, p_drop=p_drop, seed=seed, rng_stream=rng_stream, rng_t=rng_t)
+        ctx.save_for_backward(x2, weight, y if (relu or p_drop > 0) else None)
+        ctx.cfg = (x.shape, bool(relu), float(p_drop), bias is not None)
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, y = ctx.saved_tensors
+        xshape, relu, p, has_bias = ctx.cfg
+        dy2 = dy.reshape(-1, weight.shape[0])
+        if relu or p > 0:
+            # y already carries relu and the 1/(1-p) scaling: d/dpre = dy * [y != 0] * scale
+            scale = 1.0 / (1.0 - p) if p > 0 else 1.0
+            dy2 = dy2 * (y != 0).to(dy2.dtype) * scale
+        dy2 = dy2.contiguous()
+        dx = gemm(dy2, weight.t()) if ctx.needs_input_grad[0] else None          # (N,K) = dy · W
+        dw = gemm(dy2.t(), x2.t())                                                # (M,K) = dy^T · x
+        db = dy2.sum(0) if has_bias else None
+        return (dx.view(xshape) if dx is not None else None), dw, db, None, None, None, None, None

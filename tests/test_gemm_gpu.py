@@ -1,0 +1,51 @@
+"""fp32 MFMA GEMM (t2v_gemm_f32) and the LinearHIP autograd wrapper vs torch fp32 CPU."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,N,K", [(2406, 81, 1536), (2406, 256, 80), (504, 128, 512), (7, 5, 3), (65, 129, 33)])
+def test_gemm_forms(M, N, K):
+    import t2v_hip
+    g = torch.Generator().manual_seed(M + N + K)
+    A, B, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    ref = A @ B.t() + bias
+    dA, dB = A.cuda(), B.cuda()
+    out = t2v_hip.gemm(dA, dB, bias.cuda())
+    tol = 2e-6 * K ** 0.5 * 10
+    assert (out.cpu() - ref).abs().max() < tol * ref.abs().max()
+    # strided operands: NN and TN forms
+    out2 = t2v_hip.gemm(dA, dB.t().contiguous().t())                   # B given column-major
+    assert (out2.cpu() - A @ B.t()).abs().max() < tol * ref.abs().max()
+    At = dA.t().contiguous()                                           # (K,M): A passed as a transposed view
+    out3 = t2v_hip.gemm(At.t(), dB, accumulate=False, relu=True)
+    assert (out3.cpu() - torch.relu(A @ B.t())).abs().max() < tol * ref.abs().max()
+    acc = out3.clone()
+    t2v_hip.gemm(dA, dB, out=acc, accumulate=True)
+    assert (acc.cpu() - (torch.relu(A @ B.t()) + A @ B.t())).abs().max() < 2 * tol * ref.abs().max()
+
+
+def test_linear_autograd_with_relu_dropout():
+    import t2v_hip
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(401, 6, 80, generator=g)
+    w = torch.randn(256, 80, generator=g) * 0.1
+    cx, cw = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    gx, gw = x.clone().cuda().requires_grad_(True), w.clone().cuda().requires_grad_(True)
+    y = t2v_hip.LinearHIP.apply(gx, gw, None, True, 0.5, 123, 48, 7)
+    keep = (y != 0).float().cpu()
+    ref_pre = torch.relu(cx @ cw.t())
+    live = ref_pre > 0
+    assert abs(keep[live].mean().item() - 0.5) < 0.02                   # Bernoulli(0.5) on the active units
+    ref = ref_pre * keep * 2.0                                          # same mask, 1/(1-p) scaling
+    assert (y.cpu() - ref).abs().max() < 1e-4
+    wo = torch.randn(401, 6, 256, generator=g)
+    (y * wo.cuda()).sum().backward()
+    (ref * wo).sum().backward()
+    assert (gx.grad.cpu() - cx.grad).abs().max() < 2e-3 * cx.grad.abs().max()
+    assert (gw.grad.cpu() - cw.grad).abs().max() < 2e-3 * cw.grad.abs().max()
+    # identical (seed, stream, t) ⇒ identical mask; different t ⇒ different mask
+    y2 = t2v_hip.LinearHIP.apply(gx, gw, None, True, 0.5, 123, 48, 7)
+    y3 = t2v_hip.LinearHIP.apply(gx, gw, None, True, 0.5, 123, 48, 8)
+    assert torch.equal(y, y2) and not torch.equal(y, y3)
