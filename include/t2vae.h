@@ -189,6 +189,28 @@ int t2v_gemm_f32(const float* A, long sAi, long sAk, const float* B, long sBj, l
                  float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
                  uint64_t seed, uint32_t rng_stream, uint32_t rng_t, void* stream);
 
+/* ------------------------------------------------------------------ reference encoder / VAE / loss
+ * t2v_conv2d_s2_* : Conv2d 3x3 stride 2 pad 1 of ReferenceEncoder (modules.py:45-57); coord != 0 appends the
+ *                   CoordConv channels xx, yy, rr (CoordConv.py:37-74) to x on the fly (w then has Cx+3 inputs).
+ *                   BatchNorm2d+ReLU = t2v_bn_act_* on the (B, C, H*W) view with stat_part = NULL.
+ * t2v_gru_*       : nn.GRU(256,256) recurrence (modules.py:60-62,78); gi = x·W_ih^T + b_ih outside; hs
+ *                   (B,T+1,256) all hidden states (hs[:,0] = 0), gsave (B,T,4,256); dgi/dgh (B,T,768) gradients
+ *                   wrt the input-side / hidden-side gate pre-activations.
+ * t2v_loss_fwd_bwd: Tacotron2Loss_VAE (loss_function.py:27-44) value + gradients of the total in one launch;
+ *                   out4 = [total, recon, kl, kl_weight]; part192 = 192 floats scratch, ticket = zeroed uint32. */
+int t2v_conv2d_s2_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cx, int H, int W,
+                      int Cout, int coord, void* stream);
+int t2v_conv2d_s2_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, int B, int Cx,
+                      int H, int W, int Cout, int coord, void* stream);
+int t2v_gru_fwd(const float* gi, const float* whh, const float* bhh, float* hs, float* gsave, int B, int T,
+                void* stream);
+int t2v_gru_bwd(const float* whh, const float* hs, const float* gsave, const float* dh_last, float* dgi,
+                float* dgh, int B, int T, void* stream);
+int t2v_loss_fwd_bwd(const float* mel, const float* post, const float* mel_t, const float* gate,
+                     const float* gate_t, const float* mu, const float* logvar, float* dmel, float* dpost,
+                     float* dgate, float* dmu, float* dlogvar, float* part192, float* out4, uint32_t* ticket,
+                     uint64_t n_mel, int n_gate, int n_lat, float kl_weight, void* stream);
+
 /* ------------------------------------------------------------------ optimiser
  * clip_grad_norm_(params, max_norm) + Adam.step() of the reference loop (train.py:226-229,
  * Adam built at train.py:171-172) fused over one flat fp32 arena.  `grads` holds the SUM over

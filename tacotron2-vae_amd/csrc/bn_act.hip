@@ -33,12 +33,24 @@ struct BnFwdArgs {
 __global__ __launch_bounds__(256) void k_bn_act_fwd(BnFwdArgs a) {
     const int m = blockIdx.x, tid = threadIdx.x;
     float mean, rstd;
+    __shared__ float scr[4];
     if (a.training) {
-        // finalize the statistics: every thread sums the partials in the same order
         double s = 0.0, q = 0.0;
-        for (int i = 0; i < a.nblk; ++i) {
-            s += (double)a.stat_part[((size_t)i * a.M + m) * 2];
-            q += (double)a.stat_part[((size_t)i * a.M + m) * 2 + 1];
+        if (a.stat_part) {
+            // finalize the statistics: every thread sums the conv epilogue's partials in the same order
+            for (int i = 0; i < a.nblk; ++i) {
+                s += (double)a.stat_part[((size_t)i * a.M + m) * 2];
+                q += (double)a.stat_part[((size_t)i * a.M + m) * 2 + 1];
+            }
+        } else {
+            // no partials (direct-form conv2d of the reference encoder): reduce the channel here
+            float ls = 0.f, lq = 0.f;
+            for (int b = 0; b < a.B; ++b) {
+                const size_t base = ((size_t)b * a.M + m) * a.T;
+                for (int t = tid; t < a.T; t += 256) { const float v = a.y[base + t]; ls += v; lq = fmaf(v, v, lq); }
+            }
+            s = (double)block_sum_256(ls, scr);
+            q = (double)block_sum_256(lq, scr);
         }
         const double n = (double)a.B * a.T;
         const double mu = s / n;
@@ -127,7 +139,7 @@ extern "C" int t2v_bn_act_fwd(const float* y, const float* stat_part, int nblk, 
                               uint64_t seed, uint32_t rng_stream, uint32_t rng_t, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!y || !gamma || !beta || !running_mean || !running_var || !out || B < 1 || M < 1 || T < 1) return T2V_ERR_ARG;
-    if (training && (!stat_part || !mean_out || !rstd_out || (long)B * T < 2)) return T2V_ERR_ARG;
+    if (training && (!mean_out || !rstd_out || (long)B * T < 2)) return T2V_ERR_ARG;
     BnFwdArgs a;
     a.y = y; a.stat_part = stat_part; a.nblk = nblk; a.gamma = gamma; a.beta = beta;
     a.running_mean = running_mean; a.running_var = running_var; a.mean_out = mean_out; a.rstd_out = rstd_out;

@@ -26,8 +26,14 @@ class Tacotron2Loss_VAE(nn.Module):
         return kl_anneal_weight(anneal_function, step, lag, k, x0, upper)
 
     def forward(self, model_output, targets, step):
-        mel_target, gate_target = targets[0].detach(), targets[1].detach().reshape(-1, 1)
         mel_out, mel_post, gate_out, _, mu, logvar = model_output[:6]
+        w = kl_anneal_weight(self.anneal_function, step, self.lag, self.k, self.x0, self.upper)
+        if mel_out.is_cuda:      # fused value+gradient kernel
+            import t2v_hip
+            total, out4 = t2v_hip.VAELoss.apply(mel_out, mel_post, gate_out, mu, logvar, targets[0].detach(),
+                                                targets[1].detach(), w)
+            return total, out4[1], out4[2], w
+        mel_target, gate_target = targets[0].detach(), targets[1].detach().reshape(-1, 1)
         recon = (F.mse_loss(mel_out, mel_target) + F.mse_loss(mel_post, mel_target)
                  + F.binary_cross_entropy_with_logits(gate_out.reshape(-1, 1), gate_target))
         kl = -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp())   # SUM over batch and latent dims

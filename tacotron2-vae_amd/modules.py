@@ -32,14 +32,19 @@ class ReferenceEncoder(nn.Module):
         return L
 
     def forward(self, inputs):
+        import t2v_hip
         n = inputs.size(0)
-        out = inputs.contiguous().view(n, 1, -1, self.n_mels)
-        for conv, bn in zip(self.convs, self.bns):
-            out = F.relu(bn(conv(out)))
+        out = inputs.contiguous().view(n, 1, -1, self.n_mels)      # raw reinterpretation, no transpose (B-1)
+        for i, (conv, bn) in enumerate(zip(self.convs, self.bns)):
+            c = conv.conv if i == 0 else conv                       # layer 0: the live CoordConv inner conv (B-2)
+            if self.training:
+                bn.num_batches_tracked += 1
+            out = t2v_hip.Conv2dBNReLU.apply(out, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean,
+                                             bn.running_var, self.training, i == 0)
         out = out.transpose(1, 2)
         out = out.contiguous().view(n, out.size(1), -1)
-        _, last = self.gru(out)
-        return last.squeeze(0)
+        g = self.gru
+        return t2v_hip.GRULast.apply(out, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)
 
 
 class VAE_GST(nn.Module):
@@ -58,7 +63,10 @@ class VAE_GST(nn.Module):
         return eps * torch.exp(0.5 * logvar) + mu
 
     def forward(self, inputs):
+        import t2v_hip
+        lin = t2v_hip.LinearHIP.apply
         enc_out = self.ref_encoder(inputs)
-        mu, logvar = self.fc1(enc_out), self.fc2(enc_out)
+        mu = lin(enc_out, self.fc1.weight, self.fc1.bias, False, 0.0, 0, 0, 0)
+        logvar = lin(enc_out, self.fc2.weight, self.fc2.bias, False, 0.0, 0, 0, 0)
         z = self.reparameterize(mu, logvar)
-        return self.fc3(z), mu, logvar, z
+        return lin(z, self.fc3.weight, self.fc3.bias, False, 0.0, 0, 0, 0), mu, logvar, z

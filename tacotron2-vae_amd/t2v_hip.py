@@ -45,7 +45,8 @@ class _DecInferBufs(C.Structure):
 
 EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decoder_train_fwd',
            't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd',
-           't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32')
+           't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd',
+           't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd')
 
 
 def lib_path():
@@ -94,6 +95,11 @@ def load_library():
     lib.t2v_bilstm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.t2v_gemm_f32.argtypes = [vp, C.c_long, C.c_long, vp, C.c_long, C.c_long, vp, vp, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, vp]
+    lib.t2v_conv2d_s2_fwd.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.t2v_conv2d_s2_bwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.t2v_gru_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.t2v_gru_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.t2v_loss_fwd_bwd.argtypes = [vp] * 15 + [C.c_uint64, C.c_int, C.c_int, C.c_float, vp]
     for name in EXPORTS:
         getattr(lib, name)
     _lib = lib
@@ -481,3 +487,111 @@ class LinearHIP(torch.autograd.Function):
         dw = gemm(dy2.t(), x2.t())                                                # (M,K) = dy^T · x
         db = dy2.sum(0) if has_bias else None
         return (dx.view(xshape) if dx is not None else None), dw, db, None, None, None, None, None
+
+
+class Conv2dBNReLU(torch.autograd.Function):
+    """relu(BatchNorm2d(Conv2d 3x3 s2 p1 (x [+ CoordConv channels]))) — one layer of the reference encoder
+    (reference modules.py:68-71) on the direct-form HIP conv + the per-channel BN kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, coord):
+        lib = _require_gpu(x, weight)
+        x = _f32c(x)
+        B, Cx, Hh, Ww = x.shape
+        Cout = weight.shape[0]
+        Ho, Wo = (Hh - 1) // 2 + 1, (Ww - 1) // 2 + 1
+        f32 = dict(device=x.device, dtype=torch.float32)
+        w = weight.contiguous()
+        y = torch.empty(B, Cout, Ho, Wo, **f32)
+        _check(lib.t2v_conv2d_s2_fwd(_p(x), _p(w), _p(bias), _p(y), B, Cx, Hh, Ww, Cout, int(coord), _stream()),
+               't2v_conv2d_s2_fwd')
+        mean = torch.empty(Cout, **f32) if training else None
+        rstd = torch.empty(Cout, **f32) if training else None
+        out = torch.empty_like(y)
+        _check(lib.t2v_bn_act_fwd(_p(y), None, 0, _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(mean),
+                                  _p(rstd), _p(out), B, Cout, Ho * Wo, ACT_RELU, int(bool(training)), 0.0, 0.1, 1e-5,
+                                  0, 0, 0, _stream()), 't2v_bn_act_fwd')
+        ctx.keep = (x, w, y, mean, rstd, gamma, beta)
+        ctx.cfg = (B, Cx, Hh, Ww, Cout, Ho, Wo, int(coord), bool(training))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = load_library()
+        x, w, y, mean, rstd, gamma, beta = ctx.keep
+        B, Cx, Hh, Ww, Cout, Ho, Wo, coord, training = ctx.cfg
+        if not training:
+            raise T2VHipError("Conv2dBNReLU backward needs training-mode BatchNorm")
+        f32 = dict(device=x.device, dtype=torch.float32)
+        dout = dout.contiguous()
+        dy = torch.empty_like(y)
+        dgamma, dbeta = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
+        _check(lib.t2v_bn_act_bwd(_p(y), _p(dout), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dy), _p(dgamma),
+                                  _p(dbeta), B, Cout, Ho * Wo, ACT_RELU, 0.0, 0, 0, 0, _stream()), 't2v_bn_act_bwd')
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        _check(lib.t2v_conv2d_s2_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), B, Cx, Hh, Ww, Cout, coord, _stream()),
+               't2v_conv2d_s2_bwd')
+        return dx, dw, torch.zeros(Cout, **f32), dgamma, dbeta, None, None, None, None
+
+
+class GRULast(torch.autograd.Function):
+    """Last hidden state of nn.GRU(batch_first) (reference modules.py:78-80)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        lib = _require_gpu(x, w_ih)
+        B, T, I = x.shape
+        f32 = dict(device=x.device, dtype=torch.float32)
+        x2 = _f32c(x).view(B * T, I)
+        gi = gemm(x2, w_ih, b_ih)                                   # (B*T,768)
+        hs = torch.empty(B, T + 1, 256, **f32)
+        gsave = torch.empty(B, T, 4, 256, **f32)
+        whh = w_hh.contiguous()
+        _check(lib.t2v_gru_fwd(_p(gi), _p(whh), _p(b_hh), _p(hs), _p(gsave), B, T, _stream()), 't2v_gru_fwd')
+        ctx.keep = (x2, w_ih, whh, hs, gsave)
+        ctx.dims = (B, T, I)
+        return hs[:, T].clone()
+
+    @staticmethod
+    def backward(ctx, dh):
+        lib = load_library()
+        x2, w_ih, whh, hs, gsave = ctx.keep
+        B, T, I = ctx.dims
+        f32 = dict(device=x2.device, dtype=torch.float32)
+        dgi, dgh = torch.empty(B, T, 768, **f32), torch.empty(B, T, 768, **f32)
+        _check(lib.t2v_gru_bwd(_p(whh), _p(hs), _p(gsave), _p(dh.contiguous()), _p(dgi), _p(dgh), B, T, _stream()),
+               't2v_gru_bwd')
+        dgi2, dgh2 = dgi.view(B * T, 768), dgh.view(B * T, 768)
+        dx = gemm(dgi2, w_ih.t()).view(B, T, I)
+        hprev = hs[:, :T].reshape(B * T, 256)
+        return dx, gemm(dgi2.t(), x2.t()), gemm(dgh2.t(), hprev.t()), dgi2.sum(0), dgh2.sum(0)
+
+
+class VAELoss(torch.autograd.Function):
+    """Tacotron2Loss_VAE value + gradient in one HIP launch (reference loss_function.py:27-44)."""
+    _scratch = {}
+
+    @staticmethod
+    def forward(ctx, mel, post, gate, mu, logvar, mel_t, gate_t, kl_weight):
+        lib = _require_gpu(mel, post, gate, mu, logvar)
+        dev = mel.device
+        key = str(dev)
+        if key not in VAELoss._scratch:
+            VAELoss._scratch[key] = (torch.empty(192, device=dev), torch.zeros(1, device=dev, dtype=torch.int32))
+        part, ticket = VAELoss._scratch[key]
+        mel, post, gate, mu, logvar = (_f32c(t) for t in (mel, post, gate, mu, logvar))
+        mel_t, gate_t = _f32c(mel_t), _f32c(gate_t)
+        out = torch.empty(4, device=dev, dtype=torch.float32)
+        grads = [torch.empty_like(t) for t in (mel, post, gate, mu, logvar)]
+        _check(lib.t2v_loss_fwd_bwd(_p(mel), _p(post), _p(mel_t), _p(gate), _p(gate_t), _p(mu), _p(logvar),
+                                    *[_p(g) for g in grads], _p(part), _p(out), _p(ticket), mel.numel(),
+                                    gate.numel(), mu.numel(), float(kl_weight), _stream()), 't2v_loss_fwd_bwd')
+        ctx.grads = grads
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, dtotal, _dout):
+        g = ctx.grads
+        return (g[0] * dtotal, g[1] * dtotal, g[2] * dtotal, g[3] * dtotal, g[4] * dtotal, None, None, None)
