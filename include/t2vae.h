@@ -66,7 +66,7 @@ typedef struct t2v_dec_train_bufs {
     float* CD;    /* (T+1,B,1024) pre-dropout cell of decoder_rnn;   row 0 = 0 */
     float* GA;    /* (T,B,4096) gate activations i,f,g,o of attention_rnn */
     float* GD;    /* (T,B,4096) gate activations of decoder_rnn */
-    float* QP;    /* (B*256*128 + 8192) scratch: per-workgroup partial queries, then the attention kernel's
+    float* QP;    /* (B*256*128 + 40960) scratch: per-workgroup partial queries, then the attention kernel's
                      energy-exchange area and arrival counters */
     float* AL;    /* (T+1,B,T_in) AL[t+1] = attention weights of step t; row 0 = 0 */
     float* ACUM;  /* (T+1,B,T_in) cumulative weights; row 0 = 0 */

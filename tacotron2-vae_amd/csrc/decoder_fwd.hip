@@ -203,9 +203,9 @@ static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
     hipStream_t stream = (hipStream_t)stream_;
     if (!w || !s || B < 1 || B > 16 || T_in < 1 || T_out < 1) return T2V_ERR_ARG;
     if (T_in > 256) return T2V_ERR_ARG;
-    // scratch tail of QP: [0,4096) energy exchange, then 32 uint32 arrival counters / error word
+    // scratch tail of QP: [0,32768) partial-energy exchange, then 32 uint32 arrival counters / error word
     float* qp_tail = s->QP + (size_t)B * T2V_NWG * T2V_A;
-    (void)hipMemsetAsync(qp_tail + 4096, 0, 32 * sizeof(uint32_t), stream);
+    (void)hipMemsetAsync(qp_tail + 32768, 0, 32 * sizeof(uint32_t), stream);
     for (int t = 0; t <= T_out; ++t) {
         LstmFwdArgs a;
         a.packA = (const float4*)w->packF_att;
@@ -252,7 +252,7 @@ static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
             f.T_in = T_in;
             f.prof = g_t2v_prof;
             f.ex = qp_tail;
-            f.sync = (unsigned*)(qp_tail + 4096);
+            f.sync = (unsigned*)(qp_tail + 32768);
             f.epoch = t + 1;
             t2v_launch_attn_fwd(f, B, T_in, stream);
         }

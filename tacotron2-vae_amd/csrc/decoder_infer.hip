@@ -101,7 +101,7 @@ extern "C" int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_i
     if (!w || !s || B < 1 || B > 8 || T_in < 1 || T_in > 256 || t_begin < 0 || t_end <= t_begin) return T2V_ERR_ARG;
     if (!w->bias_att || !w->bias_dec) return T2V_ERR_ARG;
     float* qp_tail = s->QP + (size_t)B * T2V_NWG * T2V_A;
-    if (t_begin == 0) (void)hipMemsetAsync(qp_tail + 4096, 0, 32 * sizeof(uint32_t), stream);
+    if (t_begin == 0) (void)hipMemsetAsync(qp_tail + 32768, 0, 32 * sizeof(uint32_t), stream);
     const float thr = gate_threshold <= 0.f ? -INFINITY : (gate_threshold >= 1.f ? INFINITY : logf(gate_threshold / (1.f - gate_threshold)));
     for (int t = t_begin; t < t_end; ++t) {
         LstmFwdArgs a;
@@ -150,7 +150,7 @@ extern "C" int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_i
         f.T_in = T_in;
         f.prof = nullptr;
         f.ex = qp_tail;
-        f.sync = (unsigned*)(qp_tail + 4096);
+        f.sync = (unsigned*)(qp_tail + 32768);
         f.epoch = t + 1;
         t2v_launch_attn_fwd(f, B, T_in, stream);
 

@@ -55,7 +55,7 @@ struct AttnFwdArgs {
     float* conv_save;
     int T_in;
     unsigned long long* prof;   // optional phase stamps (s_memtime) from workgroup (0,0) thread 0
-    float* ex;                  // (16,8,32) energy exchange between the workgroups of an item
+    float* ex;                  // (B,8,256) partial-energy exchange between the workgroups of an item
     unsigned* sync;             // [b] arrival counters (monotonic over the pass), [31] error word
     int epoch;                  // 1-based launch index within the pass (target = S * epoch)
 };

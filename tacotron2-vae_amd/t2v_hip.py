@@ -180,7 +180,7 @@ class DecoderCore(torch.autograd.Function):
         CD = torch.empty(T + 1, B, H, **f32); CD[0].zero_()
         GA = torch.empty(T, B, G4, **f32)
         GD = torch.empty(T, B, G4, **f32)
-        QP = torch.empty(B * 256 * A + 8192, **f32)
+        QP = torch.empty(B * 256 * A + 40960, **f32)
         AL = torch.empty(T + 1, B, T_in, **f32); AL[0].zero_()
         ACUM = torch.empty(T + 1, B, T_in, **f32); ACUM[0].zero_()
         S = torch.empty(T, B, T_in, A, **f32) if need_grad else None
@@ -305,7 +305,7 @@ class InferenceSession(object):
         self.XS = torch.empty(T + 2, B, XW, **f32); self.XS[0:2].zero_()
         self.CA = torch.empty(T + 1, B, H, **f32); self.CA[0].zero_()
         self.CD = torch.empty(T + 1, B, H, **f32); self.CD[0].zero_()
-        self.QP = torch.empty(B * 256 * A + 8192, **f32)
+        self.QP = torch.empty(B * 256 * A + 40960, **f32)
         self.AL = torch.empty(T + 1, B, T_in, **f32); self.AL[0].zero_()
         self.ACUM = torch.empty(T + 1, B, T_in, **f32); self.ACUM[0].zero_()
         self.PRE = torch.empty(T + 1, B, PRE, **f32)
