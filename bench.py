@@ -221,9 +221,15 @@ def main():
         torch.cuda.synchronize()
         us = 1000.0 * ev0.elapsed_time(ev1) / n
         achieved = LSTM_WEIGHT_BYTES / (us * 1e-6) / 1e9
+        traffic = None      # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, corrected)
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_fetch_size.json')) as f:
+                traffic = json.load(f)["kernels"]["k_lstm_fwd"]["corrected_bytes_per_launch"]
+        except Exception:
+            pass
         out["roofline"] = {"kernel": "k_lstm_fwd", "bound": "hbm", "achieved": round(achieved, 1),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                           "traffic": None, "avg_launch_us": round(us, 3),
+                           "traffic": traffic, "avg_launch_us": round(us, 3),
                            "algorithmic_bytes_per_launch": LSTM_WEIGHT_BYTES, "launches_timed": n}
         e2e_bytes = 58.9e9   # compulsory bytes of one cfg-2 iteration
         out["roofline"]["end_to_end_frac"] = round(e2e_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
