@@ -1,0 +1,75 @@
+"""BASELINE.json configs[0] on the GPU box: two synthetic 16 kHz wavs + random Hangul text through the
+drop-in train.py (TextMelLoader → HIP mel front end → collate → train loop → validate → checkpoint_0),
+then resume from that checkpoint."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_wav(path, n, seed):
+    from scipy.io.wavfile import write
+    g = np.random.RandomState(seed)
+    x = np.clip(0.1 * g.randn(n), -1, 1)
+    write(path, 16000, (x * 32767).astype(np.int16))
+
+
+def test_train_two_steps_and_resume(tmp_path, golden_dir, capsys):
+    import hparams as HP
+    import train as TR
+    wavs = [str(tmp_path / 'a.wav'), str(tmp_path / 'b.wav'), str(tmp_path / 'c.wav'), str(tmp_path / 'd.wav')]
+    for i, (p, n) in enumerate(zip(wavs, (48000, 32000, 40000, 36000))):
+        _write_wav(p, n, i)
+    texts = ["감정있는 한국어 목소리 생성", "안녕하세요 반갑습니다", "오늘 날씨가 좋네요", "테스트 문장입니다"]
+    fl = tmp_path / 'list.txt'
+    fl.write_text("\n".join("%s|%s|0|%d" % (w, t, i % 4) for i, (w, t) in enumerate(zip(wavs, texts))) + "\n", encoding='utf-8')
+    out = str(tmp_path / 'out')
+    hp = HP.create_hparams("batch_size=2,anneal_function=constant,epochs=1,iters_per_checkpoint=2,"
+                           "training_files=%s,validation_files=%s" % (fl, fl))
+    TR.train(out, 'logs', None, False, 1, 0, 'group_name', hp)
+    printed = capsys.readouterr().out
+    assert "Train loss 0 " in printed and "Train loss 1 " in printed and "Validation loss 0:" in printed
+    ck_path = os.path.join(out, 'checkpoint_0')
+    assert os.path.isfile(ck_path)
+    ck = torch.load(ck_path, map_location='cpu', weights_only=False)
+    with open(os.path.join(golden_dir, 'checkpoint_schema.json')) as f:
+        sch = json.load(f)
+    assert list(ck.keys()) == sch['top_keys'] and ck['iteration'] == 0
+    assert [[k, list(v.shape), str(v.dtype).replace('torch.', '')] for k, v in ck['state_dict'].items()] == sch['state_dict']
+    assert sorted(ck['optimizer']['state'].keys()) == sch['optimizer_state_indices']
+    assert all(torch.isfinite(v).all() for v in ck['state_dict'].values() if v.dtype.is_floating_point)
+    # resume (reference train.py:193-199): iteration continues at 1
+    hp2 = HP.create_hparams("batch_size=2,anneal_function=constant,epochs=1,iters_per_checkpoint=100,"
+                            "training_files=%s,validation_files=%s" % (fl, fl))
+    TR.train(out, 'logs', ck_path, False, 1, 0, 'group_name', hp2)
+    printed = capsys.readouterr().out
+    assert "Loaded checkpoint" in printed and "Train loss 1 " in printed and "Train loss 0 " not in printed
+
+
+def test_dataset_item_matches_frontend(tmp_path):
+    import hparams as HP
+    from data_utils import TextMelCollate, TextMelLoader
+    p = str(tmp_path / 'x.wav')
+    _write_wav(p, 20000, 7)
+    fl = tmp_path / 'l.txt'
+    fl.write_text("%s|가나다|0|2\n" % p, encoding='utf-8')
+    hp = HP.create_hparams()
+    ds = TextMelLoader(str(fl), hp)
+    text, mel, spk, emo = ds[0]
+    assert text.dtype == torch.int32 and text[-1] == 1
+    assert mel.shape == (80, 20000 // 256 + 1) and mel.device.type == 'cpu'
+    assert spk.tolist() == [1.0] and emo.tolist() == [0.0, 0.0, 1.0, 0.0]
+    batch = TextMelCollate(1)([ds[0]])
+    assert batch[2].shape == (1, 80, 79) and batch[3][0, -1] == 1 and batch[5].dtype == torch.long
+    # sampling-rate mismatch raises like reference data_utils.py:45-47
+    from scipy.io.wavfile import write
+    bad = str(tmp_path / 'bad.wav')
+    write(bad, 22050, np.zeros(4000, dtype=np.int16))
+    fl2 = tmp_path / 'l2.txt'
+    fl2.write_text("%s|가|0|0\n" % bad, encoding='utf-8')
+    with pytest.raises(ValueError):
+        TextMelLoader(str(fl2), hp)[0]
