@@ -82,9 +82,15 @@ typedef struct t2v_dec_train_bufs {
 int t2v_decoder_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
                           int B, int T_in, int T_out, float p_att, float p_dec,
                           uint64_t seed, void* stream);
+/* 1 when the experimental two-stream schedule is active (env T2V_OVERLAP=1; default is the serial schedule):
+ * decoder_rnn(t-1) runs on a library-owned side stream underneath attention(t) and is joined back before the
+ * call returns.  Measured in round 1: critical path 21.3 vs 23.5 us per step, but event overhead and
+ * contention with the attention kernel eat the gain (32.8 vs 31.5 ms/step), so it is off by default. */
+int t2v_overlap_enabled(void);
 
 /* Measurement aid for bench.py: re-issues only the selected kernels of a finished forward pass on
- * its saved arena (bit0 = k_lstm_fwd, the weight-streaming GEMV+cell kernel; bit1 = k_attn_fwd),
+ * its saved arena (bit0 = fused k_lstm_fwd<0>, bit1 = k_attn_fwd, bit2 = k_lstm_fwd<2> decoder_rnn-only,
+ * bit3 = k_lstm_fwd<3> attention_rnn-only — the two kernels of the overlapped schedule),
  * so their average launch duration can be bracketed with events on `stream`.  Results are
  * bit-identical to the first pass (the kernels are pure functions of the arena). */
 int t2v_decoder_replay_fwd_kernels(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,

@@ -6,6 +6,7 @@
 // Reference semantics: Decoder.decode model.py:346-389, Attention.forward model.py:67-88.
 #include "t2v_common.h"
 #include "t2v_kernels.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------
 // Weight packing.  Forward tile w (16 rows = 4 units x 4 gates, unit-major) of a (4096,K)
@@ -52,9 +53,11 @@ __global__ void k_pack_bwd(const float* __restrict__ W, int K, int ncols, float4
 // wave issues ALL of its weight/x loads (26 x 1 KiB) before the first MFMA — the kernel is a
 // pure weight stream (262 KB per CU per launch) and needs the bytes in flight, not occupancy.
 #define LSTM_WAVES 16
-template <int MODE>   // 0: both cells (training, skewed); 1: attention_rnn only, prenet columns in K; 2: decoder_rnn only
+template <int MODE>   // 0: both cells (skewed); 1: attention_rnn only, prenet columns in K (inference);
+                      // 2: decoder_rnn only; 3: attention_rnn only (training, hoisted prenet term)
 __global__ __launch_bounds__(1024) void k_lstm_fwd(LstmFwdArgs a) {
     constexpr bool INFER = MODE == 1;
+    constexpr bool DO_A = MODE != 2, DO_D = MODE == 0 || MODE == 2;
     const int w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = lane & 15, g = lane >> 4;
     const bool bvalid = b < a.B;
@@ -94,10 +97,10 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(LstmFwdArgs a) {
         for (int i = 0; i < 6; ++i) {
             const int kb = kb0 + (flip ? 5 - i : i);
             xs[i] = *(const float4*)(xrow + 16 * kb);   // lanes b>=B read row 0: their D columns are never used
-            if (MODE != 2) wa[i] = pa[(size_t)kb * 64];   // training: both cells are always computed,
-            if (MODE != 1) wd[i] = pd[(size_t)kb * 64];   // do_att/do_dec only gate the cell update (t=0 / t=T)
+            if (DO_A) wa[i] = pa[(size_t)kb * 64];   // training: both cells are always computed,
+            if (DO_D) wd[i] = pd[(size_t)kb * 64];   // do_att/do_dec only gate the cell update (t=0 / t=T)
         }
-        if (MODE != 1) {
+        if (DO_D) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int kb = kr0 + (flip ? 3 - i : i);
@@ -114,11 +117,11 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(LstmFwdArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        if (MODE != 2) { MFMA4(accA, wa[i], xs[i]); }
-        if (MODE != 1) { MFMA4(accD, wd[i], xs[i]); }
+        if (DO_A) { MFMA4(accA, wa[i], xs[i]); }
+        if (DO_D) { MFMA4(accD, wd[i], xs[i]); }
     }
     if (INFER) { MFMA4(accA, wp, xp); }
-    if (MODE != 1) {
+    if (DO_D) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { MFMA4(accD, wr[i], xr[i]); }
     }
@@ -198,6 +201,54 @@ extern "C" int t2v_pack_lstm_weights(const float* wcat_att, int k_att, const flo
 }
 
 #define ATT_THREADS_HOST 512
+// ---- side stream for the overlapped schedule (created lazily, one per host thread)
+struct T2vSide { hipStream_t stream = nullptr; hipEvent_t ev[8]; hipEvent_t join; bool ok = false; };
+static thread_local T2vSide g_side;
+static bool side_ready() {
+    if (g_side.ok) return true;
+    if (hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking) != hipSuccess) return false;
+    for (int i = 0; i < 8; ++i)
+        if (hipEventCreateWithFlags(&g_side.ev[i], hipEventDisableTiming) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming) != hipSuccess) return false;
+    g_side.ok = true;
+    return true;
+}
+extern "C" int t2v_overlap_enabled(void) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("T2V_OVERLAP"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v;
+}
+
+static void fill_lstm_args(LstmFwdArgs& a, const t2v_dec_weights* w, const t2v_dec_train_bufs* s, int B, int T_out,
+                           int t, float p_att, float p_dec, uint64_t seed) {
+    a.packA = (const float4*)w->packF_att;
+    a.packD = (const float4*)w->packF_dec;
+    a.k_att = T2V_KATT;
+    a.xs_prev = s->XS + (size_t)t * B * T2V_XW;
+    a.xs_next = s->XS + (size_t)(t + 1) * B * T2V_XW;
+    a.gpre_t = t < T_out ? s->gpre + (size_t)t * B * T2V_G : nullptr;
+    a.pre_t = nullptr;
+    a.bias_att = w->bias_att;
+    a.bias_dec = w->bias_dec;
+    a.ca_prev = s->CA + (size_t)t * B * T2V_H;
+    a.ca_cur = s->CA + (size_t)(t + 1) * B * T2V_H;
+    a.cd_prev = t >= 1 ? s->CD + (size_t)(t - 1) * B * T2V_H : nullptr;
+    a.cd_cur = t >= 1 ? s->CD + (size_t)t * B * T2V_H : nullptr;
+    a.ga_t = t < T_out ? s->GA + (size_t)t * B * T2V_G : nullptr;
+    a.gd_t = t >= 1 ? s->GD + (size_t)(t - 1) * B * T2V_G : nullptr;
+    a.wqT = w->wqT;
+    a.qp = s->QP;
+    a.B = B;
+    a.t = t;
+    a.do_att = t < T_out;
+    a.do_dec = t >= 1;
+    a.p_att = p_att;
+    a.p_dec = p_dec;
+    a.seed = seed;
+}
+
+// mask bits: 1 = fused k_lstm_fwd<0> (serial schedule), 2 = k_attn_fwd, 4 = k_lstm_fwd<2> (decoder_rnn only),
+// 8 = k_lstm_fwd<3> (attention_rnn only); 16 = run the overlapped two-stream schedule
 static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s, int B, int T_in, int T_out,
                             float p_att, float p_dec, uint64_t seed, void* stream_, int mask) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -206,33 +257,35 @@ static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
     // scratch tail of QP: [0,32768) partial-energy exchange, then 32 uint32 arrival counters / error word
     float* qp_tail = s->QP + (size_t)B * T2V_NWG * T2V_A;
     (void)hipMemsetAsync(qp_tail + 32768, 0, 32 * sizeof(uint32_t), stream);
+    const bool overlap = (mask & 16) && side_ready();
+    hipStream_t sb = overlap ? g_side.stream : stream;
     for (int t = 0; t <= T_out; ++t) {
         LstmFwdArgs a;
-        a.packA = (const float4*)w->packF_att;
-        a.packD = (const float4*)w->packF_dec;
-        a.k_att = T2V_KATT;
-        a.xs_prev = s->XS + (size_t)t * B * T2V_XW;
-        a.xs_next = s->XS + (size_t)(t + 1) * B * T2V_XW;
-        a.gpre_t = t < T_out ? s->gpre + (size_t)t * B * T2V_G : nullptr;
-        a.pre_t = nullptr;
-        a.bias_att = w->bias_att;
-        a.bias_dec = w->bias_dec;
-        a.ca_prev = s->CA + (size_t)t * B * T2V_H;
-        a.ca_cur = s->CA + (size_t)(t + 1) * B * T2V_H;
-        a.cd_prev = t >= 1 ? s->CD + (size_t)(t - 1) * B * T2V_H : nullptr;
-        a.cd_cur = t >= 1 ? s->CD + (size_t)t * B * T2V_H : nullptr;
-        a.ga_t = t < T_out ? s->GA + (size_t)t * B * T2V_G : nullptr;
-        a.gd_t = t >= 1 ? s->GD + (size_t)(t - 1) * B * T2V_G : nullptr;
-        a.wqT = w->wqT;
-        a.qp = s->QP;
-        a.B = B;
-        a.t = t;
-        a.do_att = t < T_out;
-        a.do_dec = t >= 1;
-        a.p_att = p_att;
-        a.p_dec = p_dec;
-        a.seed = seed;
-        if (mask & 1) k_lstm_fwd<0><<<T2V_NWG, 1024, 0, stream>>>(a);
+        fill_lstm_args(a, w, s, B, T_out, t, p_att, p_dec, seed);
+        if (overlap) {
+            // stream A: attention_rnn(t) -> attention(t); stream B: decoder_rnn(t-1) once attention_rnn(t) is done,
+            // so its 42 MB weight stream runs underneath the latency-bound attention kernel
+            LstmFwdArgs aa = a, ad = a;
+            aa.do_dec = 0;      // each single-cell kernel must not touch the other cell's state
+            ad.do_att = 0;
+            if (t < T_out) {
+                k_lstm_fwd<3><<<T2V_NWG, 1024, 0, stream>>>(aa);
+                (void)hipEventRecord(g_side.ev[t & 7], stream);
+            } else {
+                (void)hipEventRecord(g_side.ev[t & 7], stream);     // after attention(T-1)
+            }
+            if (t >= 1) {
+                (void)hipStreamWaitEvent(sb, g_side.ev[t & 7], 0);
+                k_lstm_fwd<2><<<T2V_NWG, 1024, 0, sb>>>(ad);
+            }
+        } else {
+            if (mask & 1) k_lstm_fwd<0><<<T2V_NWG, 1024, 0, stream>>>(a);
+            LstmFwdArgs aa = a, ad = a;
+            aa.do_dec = 0;
+            ad.do_att = 0;
+            if ((mask & 8) && t < T_out) k_lstm_fwd<3><<<T2V_NWG, 1024, 0, stream>>>(aa);
+            if ((mask & 4) && t >= 1) k_lstm_fwd<2><<<T2V_NWG, 1024, 0, stream>>>(ad);
+        }
         if (t < T_out && (mask & 2)) {
             AttnFwdArgs f;
             f.qp = s->QP;
@@ -257,23 +310,28 @@ static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
             t2v_launch_attn_fwd(f, B, T_in, stream);
         }
     }
+    if (overlap) {
+        (void)hipEventRecord(g_side.join, sb);
+        (void)hipStreamWaitEvent(stream, g_side.join, 0);
+    }
     return t2v_check_launch();
 }
 
 extern "C" int t2v_decoder_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
                                      int B, int T_in, int T_out, float p_att, float p_dec,
                                      uint64_t seed, void* stream_) {
-    return launch_train_fwd(w, s, B, T_in, T_out, p_att, p_dec, seed, stream_, 3);
+    return launch_train_fwd(w, s, B, T_in, T_out, p_att, p_dec, seed, stream_, t2v_overlap_enabled() ? (2 | 16) : 3);
 }
 
 extern "C" int t2v_decoder_replay_fwd_kernels(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
                                               int B, int T_in, int T_out, float p_att, float p_dec,
                                               uint64_t seed, int kernel_mask, void* stream_) {
-    return launch_train_fwd(w, s, B, T_in, T_out, p_att, p_dec, seed, stream_, kernel_mask & 3);
+    return launch_train_fwd(w, s, B, T_in, T_out, p_att, p_dec, seed, stream_, kernel_mask & 15);
 }
 
 void t2v_launch_lstm_fwd(int mode, const LstmFwdArgs& a, hipStream_t stream) {
-    if (mode == 1) k_lstm_fwd<1><<<T2V_NWG, 1024, 0, stream>>>(a);
+    if (mode == 3) k_lstm_fwd<3><<<T2V_NWG, 1024, 0, stream>>>(a);
+    else if (mode == 1) k_lstm_fwd<1><<<T2V_NWG, 1024, 0, stream>>>(a);
     else if (mode == 2) k_lstm_fwd<2><<<T2V_NWG, 1024, 0, stream>>>(a);
     else k_lstm_fwd<0><<<T2V_NWG, 1024, 0, stream>>>(a);
 }

@@ -46,7 +46,7 @@ class _DecInferBufs(C.Structure):
 EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decoder_train_fwd',
            't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd',
            't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd',
-           't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd')
+           't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_overlap_enabled')
 
 
 def lib_path():
