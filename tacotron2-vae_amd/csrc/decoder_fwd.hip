@@ -127,7 +127,7 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(LstmFwdArgs a) {
     }
     red[0][wave][lane] = accA;
     red[1][wave][lane] = accD;
-    // query partial: thread (bb = tid>>7, d = tid&127) for bb < B; its 4 query-weight values are
+    // query partial: thread (d = tid&127) handles items bb = tid>>7, tid>>7 + 8; its 4 query-weight values are
     // fetched here so the latency hides under the reduction + cell update
     float wqr[4] = {0.f, 0.f, 0.f, 0.f};
     const bool q_on = a.do_att && (tid >> 7) < a.B;
@@ -168,9 +168,11 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(LstmFwdArgs a) {
     }
     __syncthreads();
     if (q_on) {   // partial processed query of this workgroup's 4 hidden units
-        const int bb = tid >> 7, d = tid & (T2V_A - 1);
-        const float q = wqr[0] * hs[bb][0] + wqr[1] * hs[bb][1] + wqr[2] * hs[bb][2] + wqr[3] * hs[bb][3];
-        a.qp[((size_t)bb * T2V_NWG + w) * T2V_A + d] = q;
+        const int d = tid & (T2V_A - 1);
+        for (int bb = tid >> 7; bb < a.B; bb += 8) {
+            const float q = wqr[0] * hs[bb][0] + wqr[1] * hs[bb][1] + wqr[2] * hs[bb][2] + wqr[3] * hs[bb][3];
+            a.qp[((size_t)bb * T2V_NWG + w) * T2V_A + d] = q;
+        }
     }
 }
 

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(768) void k_gru_fwd(GruArgs a) {
 __global__ __launch_bounds__(768) void k_gru_bwd(GruArgs a) {
     __shared__ float dh[16][256];
     __shared__ float dg[16][768];
-    __shared__ float part[3][8][256];      // B <= 8 on this path (checked by the launcher)
+    __shared__ float part[3][16][256];
     const int tid = threadIdx.x;
     for (int i = tid; i < a.B * 256; i += 768) dh[i >> 8][i & 255] = a.dh_last[i];
     __syncthreads();
@@ -265,7 +265,7 @@ extern "C" int t2v_gru_fwd(const float* gi, const float* whh, const float* bhh, 
 
 extern "C" int t2v_gru_bwd(const float* whh, const float* hs, const float* gsave, const float* dh_last, float* dgi,
                            float* dgh, int B, int T, void* stream_) {
-    if (!whh || !hs || !gsave || !dh_last || !dgi || !dgh || B < 1 || B > 8 || T < 1) return T2V_ERR_ARG;
+    if (!whh || !hs || !gsave || !dh_last || !dgi || !dgh || B < 1 || B > 16 || T < 1) return T2V_ERR_ARG;
     GruArgs a;
     a.gi = nullptr; a.whh = whh; a.bhh = nullptr; a.hs = (float*)hs; a.gsave = (float*)gsave; a.dh_last = dh_last;
     a.dgi = dgi; a.dgh = dgh; a.B = B; a.T = T;

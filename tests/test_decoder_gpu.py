@@ -32,7 +32,8 @@ def _oracle(dec, memory, mels, lengths, wm, wg):
 
 
 @pytest.mark.parametrize("B,T_in,T_out,lens", [(3, 20, 12, [20, 17, 9]), (6, 84, 24, [84, 80, 71, 66, 50, 37]),
-                                               (1, 33, 7, [33]), (2, 150, 6, [150, 97])])
+                                               (1, 33, 7, [33]), (2, 150, 6, [150, 97]),
+                                               (16, 40, 3, list(range(40, 24, -1))), (2, 256, 2, [256, 130]), (3, 17, 1, [17, 5, 1])])
 def test_decoder_core_matches_oracle(B, T_in, T_out, lens):
     hp, M, dec, memory, mels, lengths, wm, wg = _setup(B, T_in, T_out, lens)
     o_mel, o_gate, o_align, o_sd, o_mem = _oracle(dec, memory, mels, lengths, wm, wg)
@@ -80,13 +81,35 @@ def test_decoder_core_deterministic():
     assert torch.equal(outs[0][1], outs[1][1])
 
 
-def test_decoder_dropout_statistics():
-    """State dropout p=0.1 on h and c (model.py:361-364): keep-rate and 1/(1-p) scaling."""
+def test_decoder_state_dropout_statistics_and_backward():
+    """State dropout on h and c (model.py:361-364,378-381): keep-rate p, kept values scaled by 1/(1-p), the
+    backward regenerates the same masks (finite, deterministic gradients), eval mode switches it off."""
     import t2v_hip
     hp, M, dec, memory, mels, lengths, wm, wg = _setup(6, 40, 30, [40] * 6)
     dev = torch.device('cuda:0')
     dec = dec.to(dev).train()
     dec.p_attention_dropout = 0.5
+    dec.p_decoder_dropout = 0.25
+    grads = []
+    for _ in range(2):
+        dec._calls = 0
+        mem = memory.to(dev).requires_grad_(True)
+        mel, gate, align = dec(mem, mels.to(dev), lengths.to(dev))
+        (mel.sum() + gate.sum()).backward()
+        grads.append(mem.grad.clone())
+    assert torch.isfinite(mel).all() and torch.isfinite(grads[0]).all()
+    assert torch.equal(grads[0], grads[1])                  # same seed/call index ⇒ same masks in fwd and bwd
+    XS = t2v_hip.DecoderCore.last_call[3][13]               # (T+2,B,2560): [h_att | ctx | h_dec] rows
+    h_att, h_dec = XS[1:31, :, :1024], XS[2:32, :, 1536:]
+    assert abs((h_att == 0).float().mean().item() - 0.5) < 0.02
+    assert abs((h_dec == 0).float().mean().item() - 0.25) < 0.02
+    dec._calls = 0
+    mel2 = dec(memory.to(dev), mels.to(dev), lengths.to(dev))[0]
+    dec._calls = 5
+    mel3 = dec(memory.to(dev), mels.to(dev), lengths.to(dev))[0]
+    assert torch.equal(mel, mel2) and not torch.equal(mel, mel3)     # masks are a function of (seed, call)
+    dec.eval()
     with torch.no_grad():
-        mel, gate, align = dec(memory.to(dev), mels.to(dev), lengths.to(dev))
-    assert torch.isfinite(mel).all()
+        mel_e = dec(memory.to(dev), mels.to(dev), lengths.to(dev))[0]
+        XSe = t2v_hip.DecoderCore.last_call[3][13]
+    assert (XSe[1:31, :, :1024] == 0).float().mean().item() < 0.01

@@ -73,3 +73,23 @@ def test_dataset_item_matches_frontend(tmp_path):
     fl2.write_text("%s|가|0|0\n" % bad, encoding='utf-8')
     with pytest.raises(ValueError):
         TextMelLoader(str(fl2), hp)[0]
+
+
+def test_engine_step_batch16_ragged():
+    """B=16 (the per-GPU batch of BASELINE.json configs[4]) with ragged lengths: one full optimiser step."""
+    import sys
+    import hparams as HP
+    import train as TR
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic_batch
+    hp = HP.create_hparams("batch_size=16,anneal_function=constant")
+    torch.manual_seed(hp.seed)
+    eng = TR.TrainEngine(hp)
+    lens_in = sorted([37 - i for i in range(16)], reverse=True)
+    lens_out = [60 - 2 * i for i in range(16)]
+    batch = synthetic_batch(16, 37, 60, 5, lens_in=lens_in, lens_out=lens_out)
+    l0 = eng.step(batch, 0)
+    l1 = eng.step(batch, 1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(l0[0]).item() and torch.isfinite(l1[0]).item() and torch.isfinite(l1[4]).all().item()
+    assert float(l1[0]) < float(l0[0]) * 1.5
