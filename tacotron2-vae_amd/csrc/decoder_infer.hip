@@ -22,75 +22,119 @@ struct ProjPrenetArgs {
     int B, t;
     float gate_logit_thr, p_prenet;
     uint64_t seed;
+    float* xchg;            // [0,768) mel exchange (8 x 96), [1024,3072) layer-0 exchange (8 x 256)
+    unsigned* sync;         // [0] arrival counter (monotonic over the pass), [15] error word
+    int epoch;              // 1-based frame index within the pass
 };
 
-// one workgroup, 1024 threads (16 waves); B <= 8
-__global__ __launch_bounds__(1024) void k_proj_prenet(ProjPrenetArgs a) {
-    __shared__ float hc[8][T2V_H + T2V_E];
-    __shared__ float melv[8][T2V_NMEL + 1];
-    __shared__ float p0[8][T2V_PRE];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int HC = T2V_H + T2V_E;
-    for (int i = tid; i < a.B * HC; i += 1024) {
-        const int b = i / HC, k = i - b * HC;
-        hc[b][k] = k < T2V_H ? a.xs_next[(size_t)b * T2V_XW + T2V_KATT + k] : a.xs_cur[(size_t)b * T2V_XW + k];
-    }   // note k in [1024,1536) indexes ctx at the same offset inside the XS row
+// 16 cooperating workgroups x 256 threads (B <= 8): the 0.83 MB of projection + Prenet weights touched per frame
+// are spread over 16 CUs (a single CU pulls only ~40 GB/s of non-local data), with two bounded-spin group
+// barriers between the three dependent stages: [80-mel + gate projection] -> [Prenet layer 0] -> [Prenet layer 1].
+#define PP_NWG 16
+__device__ __forceinline__ bool pp_barrier(unsigned* cnt, unsigned* err, unsigned target, int* ok_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // projection: wave per output row
-    for (int o = wave; o < T2V_NMEL + 1; o += 16) {
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int good = 1;
+        unsigned spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > 4000000u || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                good = 0;
+                break;
+            }
+        }
+        *ok_flag = good;
+    }
+    __syncthreads();
+    return *ok_flag != 0;
+}
+
+__global__ __launch_bounds__(256) void k_proj_prenet(ProjPrenetArgs a) {
+    __shared__ __attribute__((aligned(16))) float xin[8][T2V_PRE];     // stage input: mel (80) or layer-0 output (256)
+    __shared__ int ok_flag;
+    const int gidx = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int HC = T2V_H + T2V_E;
+    // ---- stage 1: outputs o = gidx, gidx+16, ... of the 81-row projection; one wave per output row
+    for (int o = gidx + PP_NWG * wave; o < T2V_NMEL + 1; o += PP_NWG * 4) {
         const float4* wr = (const float4*)(a.proj_w + (size_t)o * HC);
         float4 wv[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) wv[i] = wr[lane + 64 * i];
         for (int b = 0; b < a.B; ++b) {
-            const float4* x = (const float4*)hc[b];
             float acc = 0.f;
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                const float4 xv = x[lane + 64 * i];
+                const int k = 4 * (lane + 64 * i);               // [h_dec_t (1024) | ctx_t (512)]
+                const float* src = k < T2V_H ? a.xs_next + (size_t)b * T2V_XW + T2V_KATT + k : a.xs_cur + (size_t)b * T2V_XW + k;
+                const float4 xv = *(const float4*)src;
                 acc = fmaf(wv[i].x, xv.x, acc); acc = fmaf(wv[i].y, xv.y, acc);
                 acc = fmaf(wv[i].z, xv.z, acc); acc = fmaf(wv[i].w, xv.w, acc);
             }
-            acc = wave_sum(acc);
-            if (lane == 0) melv[b][o] = acc + a.proj_b[o];
+            acc = wave_sum(acc) + a.proj_b[o];
+            if (lane == 0) {
+                if (o < T2V_NMEL) {
+                    a.mel_t[(size_t)b * T2V_NMEL + o] = acc;
+                    if (a.pre_next) __hip_atomic_store(a.xchg + b * 96 + o, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    a.gate_t[b] = acc;
+                    // stop rule sigmoid(gate) > threshold (model.py:453; B == 1 in the reference): all items must fire.
+                    // This wave sees every item's gate in turn, so it can decide alone.
+                    xin[0][b] = acc;
+                }
+            }
         }
-    }
-    __syncthreads();
-    for (int i = tid; i < a.B * (T2V_NMEL + 1); i += 1024) {
-        const int b = i / (T2V_NMEL + 1), o = i - b * (T2V_NMEL + 1);
-        if (o < T2V_NMEL) a.mel_t[(size_t)b * T2V_NMEL + o] = melv[b][o];
-        else a.gate_t[b] = melv[b][o];
-    }
-    if (tid == 0) {   // stop rule sigmoid(gate) > threshold (model.py:453; well defined for B == 1)
-        bool all = true;
-        for (int b = 0; b < a.B; ++b) all = all && (melv[b][T2V_NMEL] > a.gate_logit_thr);
-        if (all) atomicMin(a.stop_flag, a.t);
+        if (o == T2V_NMEL && lane == 0) {
+            bool all = true;
+            for (int b = 0; b < a.B; ++b) all = all && (xin[0][b] > a.gate_logit_thr);
+            if (all) atomicMin(a.stop_flag, a.t);
+        }
     }
     if (!a.pre_next) return;
-    // Prenet of the frame just produced (dropout always on, model.py:101)
-    for (int i = tid; i < a.B * T2V_PRE; i += 1024) {
-        const int b = i >> 8, o = i & 255;
-        const float* w = a.w0 + (size_t)o * T2V_NMEL;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < T2V_NMEL; ++k) acc = fmaf(w[k], melv[b][k], acc);
-        acc = fmaxf(acc, 0.f) * t2v_drop_scale(a.seed, T2V_RNG_PRENET0, a.t + 1, (uint32_t)i, a.p_prenet);
-        p0[b][o] = acc;
+    if (!pp_barrier(a.sync, a.sync + 15, (unsigned)PP_NWG * (2u * (unsigned)a.epoch - 1u), &ok_flag)) return;
+    // ---- stage 2: Prenet layer 0, outputs [16g, 16g+16) (dropout always on, model.py:101)
+    for (int i = tid; i < a.B * T2V_NMEL; i += 256) {
+        const int b = i / T2V_NMEL, k = i - b * T2V_NMEL;
+        xin[b][k] = __hip_atomic_load(a.xchg + b * 96 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    for (int i = tid; i < a.B * T2V_PRE; i += 1024) {
-        const int b = i >> 8, o = i & 255;
-        const float4* w = (const float4*)(a.w1 + (size_t)o * T2V_PRE);
-        const float4* x = (const float4*)p0[b];
-        float acc = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < T2V_PRE / 4; ++k) {
-            const float4 wv = w[k], xv = x[k];
-            acc = fmaf(wv.x, xv.x, acc); acc = fmaf(wv.y, xv.y, acc);
-            acc = fmaf(wv.z, xv.z, acc); acc = fmaf(wv.w, xv.w, acc);
+    {
+        const int o = 16 * gidx + (tid & 15), b = tid >> 4;
+        if (b < a.B) {
+            const float4* w = (const float4*)(a.w0 + (size_t)o * T2V_NMEL);
+            const float4* x = (const float4*)xin[b];
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < T2V_NMEL / 4; ++k) {
+                const float4 wv = w[k], xv = x[k];
+                acc = fmaf(wv.x, xv.x, acc); acc = fmaf(wv.y, xv.y, acc);
+                acc = fmaf(wv.z, xv.z, acc); acc = fmaf(wv.w, xv.w, acc);
+            }
+            acc = fmaxf(acc, 0.f) * t2v_drop_scale(a.seed, T2V_RNG_PRENET0, a.t + 1, (uint32_t)(b * T2V_PRE + o), a.p_prenet);
+            __hip_atomic_store(a.xchg + 1024 + b * T2V_PRE + o, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        acc = fmaxf(acc, 0.f) * t2v_drop_scale(a.seed, T2V_RNG_PRENET1, a.t + 1, (uint32_t)i, a.p_prenet);
-        a.pre_next[(size_t)b * T2V_PRE + o] = acc;
+    }
+    if (!pp_barrier(a.sync, a.sync + 15, (unsigned)PP_NWG * 2u * (unsigned)a.epoch, &ok_flag)) return;
+    // ---- stage 3: Prenet layer 1, outputs [16g, 16g+16)
+    for (int i = tid; i < a.B * T2V_PRE; i += 256)
+        xin[i >> 8][i & 255] = __hip_atomic_load(a.xchg + 1024 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    {
+        const int o = 16 * gidx + (tid & 15), b = tid >> 4;
+        if (b < a.B) {
+            const float4* w = (const float4*)(a.w1 + (size_t)o * T2V_PRE);
+            const float4* x = (const float4*)xin[b];
+            float acc = 0.f;
+#pragma unroll 16
+            for (int k = 0; k < T2V_PRE / 4; ++k) {
+                const float4 wv = w[k], xv = x[k];
+                acc = fmaf(wv.x, xv.x, acc); acc = fmaf(wv.y, xv.y, acc);
+                acc = fmaf(wv.z, xv.z, acc); acc = fmaf(wv.w, xv.w, acc);
+            }
+            acc = fmaxf(acc, 0.f) * t2v_drop_scale(a.seed, T2V_RNG_PRENET1, a.t + 1, (uint32_t)(b * T2V_PRE + o), a.p_prenet);
+            a.pre_next[(size_t)b * T2V_PRE + o] = acc;
+        }
     }
 }
 
@@ -181,7 +225,10 @@ extern "C" int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_i
         p.gate_logit_thr = thr;
         p.p_prenet = p_prenet;
         p.seed = seed;
-        k_proj_prenet<<<1, 1024, 0, stream>>>(p);
+        p.xchg = qp_tail + 32768 + 64;
+        p.sync = (unsigned*)(qp_tail + 32768) + 16;
+        p.epoch = t + 1;
+        k_proj_prenet<<<PP_NWG, 256, 0, stream>>>(p);
     }
     return t2v_check_launch();
 }
