@@ -109,7 +109,7 @@ typedef struct t2v_dec_bwd_bufs {
     float* DCA;   /* (B,1024) scratch */
     float* DCD;   /* (B,1024) scratch */
     float* GPREV; /* (2,B,8,2,64) scratch: per-slice partial location-conv gradients, parity double-buffered */
-    float* GCUM;  /* (B,8,256) scratch: per-workgroup copies of the cumulative-weights gradient */
+    float* GCUM;  /* (B*8*256 + 64) scratch: per-workgroup copies of the cumulative-weights gradient, then sync words */
     float* DV;    /* (B,8,128) out: per-item, per-slice grad of attention v (sum over dims 0,1 = dv) */
 } t2v_dec_bwd_bufs;
 

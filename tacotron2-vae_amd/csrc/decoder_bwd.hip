@@ -66,7 +66,7 @@ __global__ __launch_bounds__(1024) void k_lstm_bwd(LstmBwdArgs a) {
 static inline int attn_bwd_js(int T_in) { return 16 * ((T_in + 127) / 128); }
 
 template <int JS>
-__global__ __launch_bounds__(ATB_THREADS) void k_attn_bwd(AttnBwdArgs a) {
+__device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& a, const int b, const int s, const int S) {
     constexpr int NJT = JS / 16;           // 16-position MFMA tiles per slice
     constexpr int PW = JS + 30;            // width of a partial dcat row
     constexpr int DW = JS + 60;            // zero-padded dc row
@@ -79,7 +79,6 @@ __global__ __launch_bounds__(ATB_THREADS) void k_attn_bwd(AttnBwdArgs a) {
     __shared__ float wcl[T2V_F * 63];
     __shared__ f32x4 red[2][2][64];
     __shared__ float scr[ATB_THREADS * 2 + 8];
-    const int b = blockIdx.x, s = blockIdx.y, S = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
     const int Tp = a.T_in, j0 = s * JS;
@@ -197,9 +196,14 @@ __global__ __launch_bounds__(ATB_THREADS) void k_attn_bwd(AttnBwdArgs a) {
         scr[8 + ATB_THREADS + tid] = dv;
         __syncthreads();
         if (tid < T2V_A) {
-            a.DQ_t[((size_t)b * ATB_MAXS + s) * T2V_A + tid] = scr[8 + tid] + scr[8 + 128 + tid];
+            // write-through: the cell-backward workgroups of the SAME launch consume it after the dq counter
+            __hip_atomic_store(a.DQ_t + ((size_t)b * ATB_MAXS + s) * T2V_A + tid, scr[8 + tid] + scr[8 + 128 + tid],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             a.DV[((size_t)b * ATB_MAXS + s) * T2V_A + tid] += scr[8 + ATB_THREADS + tid] + scr[8 + ATB_THREADS + 128 + tid];
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(a.dq_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     T2V_STAMP(a, 3);
@@ -262,12 +266,15 @@ __global__ __launch_bounds__(ATB_THREADS) void k_attn_bwd(AttnBwdArgs a) {
     T2V_STAMP(a, 5);
 }
 
-// grid = 64 blocks x 256 threads; thread = (unit U, item b)
-__global__ __launch_bounds__(256) void k_cell_bwd(CellBwdArgs a) {
+// 64 workgroups x 256 threads; thread = (unit U, item b).  Inside the merged launch the decoder_rnn(t-1) part and
+// all operand fetches run while the attention workgroups are still busy; only the W_q^T·dq term waits (bounded
+// spin on the dq counter the attention workgroups bump after publishing their partial dq rows).
+__device__ __forceinline__ void cell_bwd_body(const CellBwdArgs& a, const int cblk) {
     __shared__ __attribute__((aligned(16))) float wqs[16][T2V_A + 4];
     __shared__ __attribute__((aligned(16))) float dqs[16][T2V_A + 4];
+    __shared__ int cell_ok;
     const int tid = threadIdx.x;
-    const int U = blockIdx.x * 16 + (tid >> 4), b = tid & 15;
+    const int U = cblk * 16 + (tid >> 4), b = tid & 15;
     const bool bv = b < a.B;
     const uint32_t idx = (uint32_t)b * T2V_H + U;
     const size_t bu = (size_t)b * T2V_H + U;
@@ -278,14 +285,7 @@ __global__ __launch_bounds__(256) void k_cell_bwd(CellBwdArgs a) {
         // stage W_q^T rows of this block's 16 units and dq (= sum of the S per-slice partials)
         for (int i = tid; i < 16 * T2V_A / 4; i += 256) {
             const int u = i >> 5, c4 = i & 31;
-            *(float4*)&wqs[u][4 * c4] = *(const float4*)(a.wqT + (size_t)(blockIdx.x * 16 + u) * T2V_A + 4 * c4);
-        }
-        for (int i = tid; i < a.B * T2V_A; i += 256) {
-            const int bb = i >> 7, dd = i & (T2V_A - 1);
-            float pv[8];
-#pragma unroll
-            for (int sl = 0; sl < 8; ++sl) pv[sl] = a.DQ_t[((size_t)bb * 8 + sl) * T2V_A + dd];   // unused slices are zero
-            dqs[bb][dd] = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
+            *(float4*)&wqs[u][4 * c4] = *(const float4*)(a.wqT + (size_t)(cblk * 16 + u) * T2V_A + 4 * c4);
         }
         if (bv) {
             yd0 = a.YD[(size_t)b * T2V_XW + U];
@@ -302,9 +302,52 @@ __global__ __launch_bounds__(256) void k_cell_bwd(CellBwdArgs a) {
         gd[0] = gp[0]; gd[1] = gp[T2V_H]; gd[2] = gp[2 * T2V_H]; gd[3] = gp[3 * T2V_H];
         cdc = a.CD_cur[bu]; cdp = a.CD_prev[bu]; dcd = a.DCD[bu];
     }
+    // ---- decoder_rnn(t-1): independent of the attention backward -> done first
+    if (a.do_dec && bv) {
+        const int td = a.t - 1;
+        const float dh = hcp + yd1;
+        const float fh = t2v_drop_scale(a.seed, T2V_RNG_DEC_H, td, idx, a.p_dec);
+        const float fc = t2v_drop_scale(a.seed, T2V_RNG_DEC_C, td, idx, a.p_dec);
+        const float gi = gd[0], gf = gd[1], gg = gd[2], go = gd[3];
+        const float tc = tanhf_(cdc);
+        const float dht = dh * fh;
+        const float dct = dcd * fc + dht * go * (1.0f - tc * tc);
+        float cprev = cdp;
+        if (td > 0) cprev *= t2v_drop_scale(a.seed, T2V_RNG_DEC_C, td - 1, idx, a.p_dec);
+        float* o = a.DGD_p + (size_t)b * T2V_G + U;
+        o[0] = dct * gg * gi * (1.0f - gi);
+        o[T2V_H] = dct * cprev * gf * (1.0f - gf);
+        o[2 * T2V_H] = dct * gi * (1.0f - gg * gg);
+        o[3 * T2V_H] = dht * tc * go * (1.0f - go);
+        a.DCD[bu] = dct * gf;
+    }
+    if (!a.do_att) return;
+    // ---- wait for the attention workgroups' partial dq rows, then sum them (fixed order)
+    if (tid == 0) {
+        int good = 1;
+        unsigned spins = 0;
+        while (__hip_atomic_load(a.dq_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.dq_target) {
+            if (++spins > 4000000u || __hip_atomic_load(a.dq_counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(a.dq_counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                good = 0;
+                break;
+            }
+        }
+        cell_ok = good;
+    }
+    __syncthreads();
+    if (!cell_ok) return;
+    for (int i = tid; i < a.B * T2V_A; i += 256) {
+        const int bb = i >> 7, dd = i & (T2V_A - 1);
+        float pv[8];
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl)   // unused slices are zero
+            pv[sl] = __hip_atomic_load(a.DQ_t + ((size_t)bb * 8 + sl) * T2V_A + dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dqs[bb][dd] = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
+    }
     __syncthreads();
     if (!bv) return;
-    if (a.do_att) {
+    {
         const int t = a.t;
         const float4* w4 = (const float4*)wqs[tid >> 4];
         const float4* q4 = (const float4*)dqs[b];
@@ -333,24 +376,14 @@ __global__ __launch_bounds__(256) void k_cell_bwd(CellBwdArgs a) {
         o[3 * T2V_H] = dht * tc * go * (1.0f - go);
         a.DCA[bu] = dct * gf;
     }
-    if (a.do_dec) {
-        const int td = a.t - 1;
-        const float dh = hcp + yd1;
-        const float fh = t2v_drop_scale(a.seed, T2V_RNG_DEC_H, td, idx, a.p_dec);
-        const float fc = t2v_drop_scale(a.seed, T2V_RNG_DEC_C, td, idx, a.p_dec);
-        const float gi = gd[0], gf = gd[1], gg = gd[2], go = gd[3];
-        const float tc = tanhf_(cdc);
-        const float dht = dh * fh;
-        const float dct = dcd * fc + dht * go * (1.0f - tc * tc);
-        float cprev = cdp;
-        if (td > 0) cprev *= t2v_drop_scale(a.seed, T2V_RNG_DEC_C, td - 1, idx, a.p_dec);
-        float* o = a.DGD_p + (size_t)b * T2V_G + U;
-        o[0] = dct * gg * gi * (1.0f - gi);
-        o[T2V_H] = dct * cprev * gf * (1.0f - gf);
-        o[2 * T2V_H] = dct * gi * (1.0f - gg * gg);
-        o[3 * T2V_H] = dht * tc * go * (1.0f - go);
-        a.DCD[bu] = dct * gf;
-    }
+}
+
+// One launch per reverse step: workgroups [0, B*S) = attention backward slices, then 64 cell-backward workgroups.
+template <int JS>
+__global__ __launch_bounds__(256) void k_attn_cell_bwd(AttnBwdArgs a, CellBwdArgs c, int nattn, int S) {
+    const int blk = blockIdx.x;
+    if (blk < nattn) attn_bwd_body<JS>(a, blk / S, blk % S, S);
+    else cell_bwd_body(c, blk - nattn);
 }
 
 extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
@@ -371,7 +404,11 @@ extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_tra
     (void)hipMemsetAsync(g->DQ, 0, sizeof(float) * (size_t)T_out * B * ATB_MAXS * T2V_A, stream);
 
     const size_t HC = T2V_H + T2V_E;
+    unsigned* sync = (unsigned*)(g->GCUM + (size_t)B * ATB_MAXS * 256);     // [0] dq counter, [1] error word
+    (void)hipMemsetAsync(sync, 0, 2 * sizeof(unsigned), stream);
     for (int t = T_out; t >= 0; --t) {
+        bool have_attn = false;
+        AttnBwdArgs fa = {};
         if (t < T_out) {
             LstmBwdArgs l;
             l.packBD = (const float4*)w->packB_dec;
@@ -404,8 +441,9 @@ extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_tra
             f.DV = g->DV;
             f.T_in = T_in;
             f.prof = g_t2v_prof ? g_t2v_prof + 16 : nullptr;
-            if (JS == 16) k_attn_bwd<16><<<dim3(B, S), ATB_THREADS, 0, stream>>>(f);
-            else k_attn_bwd<32><<<dim3(B, S), ATB_THREADS, 0, stream>>>(f);
+            f.dq_counter = sync;
+            have_attn = true;
+            fa = f;
         }
         CellBwdArgs c;
         c.YD = g->YD;
@@ -431,7 +469,11 @@ extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_tra
         c.p_att = p_att;
         c.p_dec = p_dec;
         c.seed = seed;
-        if (c.do_att || c.do_dec) k_cell_bwd<<<T2V_H / 16, 256, 0, stream>>>(c);
+        c.dq_counter = sync;
+        c.dq_target = (unsigned)(B * S) * (unsigned)(T_out - t);      // every attention slice of this and all earlier reverse steps
+        const int nattn = have_attn ? B * S : 0;
+        if (JS == 16) k_attn_cell_bwd<16><<<nattn + T2V_H / 16, 256, 0, stream>>>(fa, c, nattn, S);
+        else k_attn_cell_bwd<32><<<nattn + T2V_H / 16, 256, 0, stream>>>(fa, c, nattn, S);
     }
     return t2v_check_launch();
 }

@@ -36,6 +36,8 @@ struct LstmFwdArgs {
     int B, t, do_att, do_dec;
     float p_att, p_dec;
     uint64_t seed;
+    unsigned* dq_counter;   // [0] arrivals of attention slices (monotonic over the pass), [1] error word
+    unsigned dq_target;
 };
 
 struct AttnFwdArgs {
@@ -89,6 +91,7 @@ struct AttnBwdArgs {
     float* GP_out;          // (B,8,2,64) ... written by this step (other parity)
     float* GC;              // (B,8,256) per-workgroup running copies of the cumulative-weights gradient
     float* DV;              // (B,8,128) per-slice accumulators
+    unsigned* dq_counter;   // bumped once per attention slice after its partial dq row is published
     int T_in;
     unsigned long long* prof;
 };
@@ -113,4 +116,6 @@ struct CellBwdArgs {
     int B, t, do_att, do_dec;
     float p_att, p_dec;
     uint64_t seed;
+    unsigned* dq_counter;   // [0] arrivals of attention slices (monotonic over the pass), [1] error word
+    unsigned dq_target;
 };

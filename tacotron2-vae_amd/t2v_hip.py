@@ -217,7 +217,7 @@ class DecoderCore(torch.autograd.Function):
         DC = torch.empty(T, B, F_LOC, T_in, **f32)
         YD = torch.empty(B, XW, **f32); YA = torch.empty(B, KATT, **f32)
         DCA = torch.empty(B, H, **f32); DCD = torch.empty(B, H, **f32)
-        GPREV = torch.empty(2, B, 8, 2, 64, **f32); GCUM = torch.empty(B, 8, 256, **f32)
+        GPREV = torch.empty(2, B, 8, 2, 64, **f32); GCUM = torch.empty(B * 8 * 256 + 64, **f32)
         DV = torch.empty(B, 8, A, **f32)
         W = _DecWeights(_p(packF_att), _p(packF_dec), _p(packB_att), _p(packB_dec), None, _p(bias_dec),
                         _p(wqT), _p(loc_conv), _p(loc_dense), _p(vv))
