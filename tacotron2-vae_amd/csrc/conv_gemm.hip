@@ -164,6 +164,306 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Tiled kernels for the k=5 convolutions with Cin % 16 == 0 (every conv of the encoder bank and the Postnet).
+// No im2col gather: a workgroup stages the input rows it needs ONCE per channel block ([16 channels][BN+4
+// positions], halo included) and all five taps read shifted windows of it, and the K order inside a tile is
+// tap-major (k' = 16*tap + channel) so that every MFMA operand address is  lane_base + compile-time constant.
+// Output tile 64 x (16*NTW); 4 waves, wave w owns rows 16w..16w+15 and NTW 16x16 accumulators
+// (v_mfma_f32_16x16x4_f32: D row = 4*(lane>>4)+r, col = lane&15).  K tile = 80 (= 16 channels x 5 taps, or 80/96
+// positions for the weight gradient): 20-24 k-steps x NTW MFMAs between barriers, the next tile's global loads
+// in flight meanwhile.  Tiles never straddle utterances (zero padding at utterance edges comes from the halo).
+#define CT_BM 64
+#define CT_AS 80                 // As row stride: 64 + 16 -> the four k-rows of an A read land in disjoint banks
+#define CT_KT 80
+
+struct ConvTiledArgs {
+    const float* W;      // fwd: (M, Cin*5) row-major
+    const float* X;      // (B, Cin, T)
+    const float* dY;     // dW: (B, M, T)
+    const float* bias;
+    float* Y;            // fwd: (B, M, T);  dW: (M, Cin*5)
+    float* stat_part;    // fwd: (gridDim.x, M, 2) or NULL
+    int B, Cin, T, M, tiles_per_item;
+    unsigned long long* prof;   // optional: [0..1] shader-clock stamps, [2..3] 100 MHz stamps of workgroup (0,0)
+};
+
+template <int NTW>
+__global__ __launch_bounds__(256) void k_conv5_fwd(ConvTiledArgs a) {
+    constexpr int BN = 16 * NTW;
+    constexpr int XW = BN + 4;                           // staged positions per channel (2-halo each side)
+    constexpr int XS = (BN == 64) ? 80 : 112;            // row stride, = 16 or 48 mod 64: four k-rows -> disjoint banks
+    constexpr int NX = (16 * XW + 255) / 256;            // X elements staged per thread
+    __shared__ float As[2][CT_KT][CT_AS];
+    __shared__ float Xs[2][16][XS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int kq = lane >> 4, j = lane & 15;
+    const int bb = blockIdx.x / a.tiles_per_item, t0 = (blockIdx.x % a.tiles_per_item) * BN;
+    const int m0 = blockIdx.y * CT_BM;
+    const int CK = a.Cin * 5;
+    const int nkt = a.Cin / 16;
+
+    const bool stamp = a.prof && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0;
+    if (stamp) { a.prof[0] = __builtin_readcyclecounter(); a.prof[2] = wall_clock64(); }
+    // ---- staging plan (everything that does not depend on the k-tile is computed once; no branches around loads:
+    //      rows past M are clamped — their outputs are never stored — and out-of-range positions are selected to 0)
+    float4 ra[5];
+    float rx[NX];
+    const int a_m = tid & 63, w4 = tid >> 6;
+    const float* a_row = a.W + (size_t)min(m0 + a_m, a.M - 1) * CK + 4 * w4;     // + 80*kt + 16*i
+    int a_lds[20];                      // LDS offsets of this thread's 20 A elements: (16*tap + channel)*CT_AS + row
+#pragma unroll
+    for (int q = 0; q < 20; ++q) {
+        const int k = 4 * w4 + 16 * (q >> 2) + (q & 3);       // position in the W row segment: 5*channel + tap
+        const int c = k / 5, kx = k - 5 * c;
+        a_lds[q] = (16 * kx + c) * CT_AS + a_m;
+    }
+    const float* x_item = a.X + (size_t)bb * a.Cin * a.T;
+    int x_goff[NX], x_lds[NX];
+    bool x_ok[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int e = tid + 256 * i;
+        const int c = min(e / XW, 15), jj = e - (e / XW) * XW;
+        const int t = t0 - 2 + jj;
+        x_ok[i] = e < 16 * XW && t >= 0 && t < a.T;
+        x_goff[i] = c * a.T + min(max(t, 0), a.T - 1);
+        x_lds[i] = e < 16 * XW ? c * XS + jj : -1;
+    }
+    auto load_one = [&](int kt, int q) {          // q-th global load of tile kt (q compile-time after unrolling)
+        if (q < 5) {
+            ra[q] = *(const float4*)(a_row + 80 * kt + 16 * q);
+        } else {
+            const float v = x_item[(size_t)16 * kt * a.T + x_goff[q - 5]];
+            rx[q - 5] = x_ok[q - 5] ? v : 0.f;
+        }
+    };
+    auto store_one = [&](int buf, int q) {        // q-th LDS store of the staged tile
+        if (q < 20) {
+            const float4 v4 = ra[q >> 2];
+            const float v = (q & 3) == 0 ? v4.x : (q & 3) == 1 ? v4.y : (q & 3) == 2 ? v4.z : v4.w;
+            (&As[buf][0][0])[a_lds[q]] = v;
+        } else if (q < 20 + NX) {
+            if (x_lds[q - 20] >= 0) (&Xs[buf][0][0])[x_lds[q - 20]] = rx[q - 20];
+        }
+    };
+    constexpr int NLOAD = 5 + NX, NSTORE = 20 + NX;
+    constexpr int S_ST0 = 11;                      // first k-step that carries LDS stores (3 per step)
+    static_assert(NLOAD <= S_ST0 + 1 && NSTORE <= 3 * (20 - S_ST0), "side work must fit the k-steps");
+
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NLOAD; ++q) load_one(0, q);
+#pragma unroll
+    for (int q = 0; q < NSTORE; ++q) store_one(0, q);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        const int kn = min(kt + 1, nkt - 1);       // the last tile re-stages itself (harmless) instead of branching
+        const float* ap = &As[buf][kq][16 * wave + j];
+        const float* xp = &Xs[buf][kq][j];
+        // k' = 4s + kq: tap = s/4, channel = 4*(s%4) + kq.  One wave per SIMD, so everything else is threaded
+        // through the MFMA stream by hand: the LDS operands of k-step s+1 are fetched while step s multiplies,
+        // the global loads of the next tile go out one per step (steps 0..), its LDS stores three per step
+        // (steps 11..19, into the buffer nobody reads during this tile)
+        float av[2], bv[2][NTW];
+        av[0] = ap[0];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) bv[0][n] = xp[16 * n];
+#pragma unroll
+        for (int s = 0; s < 20; ++s) {
+            if (s < NLOAD) load_one(kn, s);
+            if (s + 1 < 20) {
+                av[(s + 1) & 1] = ap[4 * (s + 1) * CT_AS];
+#pragma unroll
+                for (int n = 0; n < NTW; ++n)
+                    bv[(s + 1) & 1][n] = xp[4 * ((s + 1) & 3) * XS + 16 * n + ((s + 1) >> 2)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) acc[n] = mfma16x4(av[s & 1], bv[s & 1][n], acc[n]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s >= S_ST0) {
+#pragma unroll
+                for (int q = 3 * (s - S_ST0); q < 3 * (s - S_ST0) + 3; ++q) store_one(buf ^ 1, q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+    if (stamp) { a.prof[1] = __builtin_readcyclecounter(); a.prof[3] = wall_clock64(); }
+    // epilogue: lane holds rows m0 + 16w + 4kq + r (r = 0..3) of column t0 + 16n + j
+    float psum[4] = {0.f, 0.f, 0.f, 0.f}, psq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 16 * wave + 4 * kq + r;
+        if (m < a.M) {
+            const float bv = a.bias ? a.bias[m] : 0.f;
+            float* yrow = a.Y + ((size_t)bb * a.M + m) * a.T;
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const int t = t0 + 16 * n + j;
+                if (t < a.T) {
+                    const float v = acc[n][r] + bv;
+                    yrow[t] = v;
+                    psum[r] += v;
+                    psq[r] = fmaf(v, v, psq[r]);
+                }
+            }
+        }
+    }
+    if (a.stat_part) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float s1 = row16_sum(psum[r]), s2 = row16_sum(psq[r]);
+            const int m = m0 + 16 * wave + 4 * kq + r;
+            if (j == 0 && m < a.M) {
+                float* dst = a.stat_part + ((size_t)blockIdx.x * a.M + m) * 2;
+                dst[0] = s1;
+                dst[1] = s2;
+            }
+        }
+    }
+}
+
+// weight gradient: dW[m][c][kx] = sum_{b,t} dY[b][m][t] X[b][c][t+kx-2].  Workgroup = 64 rows m x 16 channels
+// (80 columns n = 5c + kx, contiguous in dW); K runs over (utterance, BT positions).
+template <int BT>
+__global__ __launch_bounds__(256) void k_conv5_dw(ConvTiledArgs a) {
+    constexpr int XW = BT + 4;
+    constexpr int XS = (BT == 80) ? 100 : 116;           // rows of 4 consecutive channels -> disjoint 8-bank windows
+    constexpr int NA = BT / 16;                          // float4 of dY per thread (BT*64/4/256)
+    constexpr int NX = (16 * XW + 255) / 256;
+    __shared__ float As[2][BT][CT_AS];
+    __shared__ float Xs[2][16][XS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int kq = lane >> 4, j = lane & 15;
+    const int c0 = blockIdx.x * 16, m0 = blockIdx.y * CT_BM;
+    const int CK = a.Cin * 5;
+    const int tiles = (a.T + BT - 1) / BT, nkt = a.B * tiles;
+    const bool vec = (a.T & 3) == 0;
+
+    float4 ra[NA];
+    float rx[NX];
+    const int a_m = tid & 63;
+    const bool a_ok = m0 + a_m < a.M;
+    auto load_tiles = [&](int kt) {
+        const int bb = kt / tiles, t0 = (kt - bb * tiles) * BT;
+        const float* arow = a.dY + ((size_t)bb * a.M + (a_ok ? m0 + a_m : 0)) * a.T;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int t = t0 + 4 * ((tid >> 6) + 4 * i);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_ok) {
+                if (vec) {
+                    if (t < a.T) v = *(const float4*)(arow + t);
+                } else {
+                    if (t < a.T) v.x = arow[t];
+                    if (t + 1 < a.T) v.y = arow[t + 1];
+                    if (t + 2 < a.T) v.z = arow[t + 2];
+                    if (t + 3 < a.T) v.w = arow[t + 3];
+                }
+            }
+            ra[i] = v;
+        }
+        const float* x_item = a.X + ((size_t)bb * a.Cin + c0) * a.T;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + 256 * i;
+            const int c = e / XW, jj = e - c * XW;
+            const int t = t0 - 2 + jj;
+            rx[i] = (c < 16 && t >= 0 && t < a.T) ? x_item[(size_t)c * a.T + t] : 0.f;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int k = 4 * ((tid >> 6) + 4 * i);
+            As[buf][k][a_m] = ra[i].x;
+            As[buf][k + 1][a_m] = ra[i].y;
+            As[buf][k + 2][a_m] = ra[i].z;
+            As[buf][k + 3][a_m] = ra[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = tid + 256 * i;
+            const int c = e / XW, jj = e - c * XW;
+            if (c < 16) Xs[buf][c][jj] = rx[i];
+        }
+    };
+
+    // column n = 16*nt + j of the 80-wide tile -> (channel, tap); B operand of k-step s: Xs[c][4s + kq + kx]
+    int boff[5];
+#pragma unroll
+    for (int n = 0; n < 5; ++n) {
+        const int nl = 16 * n + j, c = nl / 5, kx = nl - 5 * c;
+        boff[n] = c * XS + kx + kq;
+    }
+    f32x4 acc[5];
+#pragma unroll
+    for (int n = 0; n < 5; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tiles(kt + 1);
+        const float* ap = &As[buf][kq][16 * wave + j];
+        const float* xp = &Xs[buf][0][0];
+        float av[2], bv[2][5];
+        av[0] = ap[0];
+#pragma unroll
+        for (int n = 0; n < 5; ++n) bv[0][n] = xp[boff[n]];
+#pragma unroll
+        for (int s = 0; s < BT / 4; ++s) {
+            if (s + 1 < BT / 4) {
+                av[(s + 1) & 1] = ap[4 * (s + 1) * CT_AS];
+#pragma unroll
+                for (int n = 0; n < 5; ++n) bv[(s + 1) & 1][n] = xp[boff[n] + 4 * (s + 1)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < 5; ++n) acc[n] = mfma16x4(av[s & 1], bv[s & 1][n], acc[n]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kt + 1 < nkt) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 16 * wave + 4 * kq + r;
+        if (m < a.M) {
+            float* drow = a.Y + (size_t)m * CK + 5 * c0;
+#pragma unroll
+            for (int n = 0; n < 5; ++n) drow[16 * n + j] = acc[n][r];
+        }
+    }
+}
+
+static inline int conv5_pick_bn(int T) {      // output positions per workgroup: least padded work, ties -> wider
+    int best = 64, cost = ((T + 63) / 64) * 64;
+    const int c80 = ((T + 79) / 80) * 80, c96 = ((T + 95) / 96) * 96;
+    if (c80 <= cost) { best = 80; cost = c80; }
+    if (c96 <= cost) { best = 96; cost = c96; }
+    return best;
+}
+static inline bool conv5_tiled_ok(int Cin, int KS) { return KS == 5 && Cin % 16 == 0; }
+
+static void launch_conv5_fwd(const float* W, const float* X, const float* bias, float* Y, float* stat_part, int B,
+                             int Cin, int T, int M, hipStream_t stream) {
+    const int BN = conv5_pick_bn(T);
+    ConvTiledArgs a;
+    a.W = W; a.X = X; a.dY = nullptr; a.bias = bias; a.Y = Y; a.stat_part = stat_part;
+    a.B = B; a.Cin = Cin; a.T = T; a.M = M; a.tiles_per_item = (T + BN - 1) / BN;
+    a.prof = g_t2v_prof;
+    dim3 grid(B * a.tiles_per_item, (M + CT_BM - 1) / CT_BM);
+    if (BN == 64) k_conv5_fwd<4><<<grid, 256, 0, stream>>>(a);
+    else if (BN == 80) k_conv5_fwd<5><<<grid, 256, 0, stream>>>(a);
+    else k_conv5_fwd<6><<<grid, 256, 0, stream>>>(a);
+}
+
 // W (M, Cin, KS) -> Wt (Cin, M, KS) with the taps flipped: conv(dY, Wt) is the data gradient
 __global__ void k_conv_flip_weight(const float* __restrict__ W, float* __restrict__ Wt, int M, int Cin, int KS) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -176,6 +476,10 @@ extern "C" int t2v_conv1d_fwd(const float* W, const float* X, const float* bias,
                               int B, int Cin, int T, int Cout, int KS, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!W || !X || !Y || B < 1 || Cin < 1 || T < 1 || Cout < 1 || KS < 1 || !(KS & 1)) return T2V_ERR_ARG;
+    if (conv5_tiled_ok(Cin, KS)) {
+        launch_conv5_fwd(W, X, bias, Y, stat_part, B, Cin, T, Cout, stream);
+        return t2v_check_launch();
+    }
     ConvGemmArgs a;
     a.W = W; a.X = X; a.dY = nullptr; a.bias = bias; a.Y = Y; a.stat_part = stat_part;
     a.B = B; a.Cin = Cin; a.T = T; a.M = Cout; a.KS = KS;
@@ -186,7 +490,10 @@ extern "C" int t2v_conv1d_fwd(const float* W, const float* X, const float* bias,
     return t2v_check_launch();
 }
 
-extern "C" int t2v_conv1d_stat_blocks(int B, int T) { return (B * T + CG_BN - 1) / CG_BN; }
+extern "C" int t2v_conv1d_stat_blocks(int B, int T, int Cin, int KS) {
+    if (conv5_tiled_ok(Cin, KS)) { const int BN = conv5_pick_bn(T); return B * ((T + BN - 1) / BN); }
+    return (B * T + CG_BN - 1) / CG_BN;
+}
 
 extern "C" int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, float* dX, float* dW, float* Wt_scratch,
                               int B, int Cin, int T, int Cout, int KS, void* stream_) {
@@ -196,15 +503,28 @@ extern "C" int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, f
         if (!Wt_scratch) return T2V_ERR_ARG;
         const int n = Cout * Cin * KS;
         k_conv_flip_weight<<<(n + 255) / 256, 256, 0, stream>>>(W, Wt_scratch, Cout, Cin, KS);
-        ConvGemmArgs a;
-        a.W = Wt_scratch; a.X = dY; a.dY = nullptr; a.bias = nullptr; a.Y = dX; a.stat_part = nullptr;
-        a.B = B; a.Cin = Cout; a.T = T; a.M = Cin; a.KS = KS;
-        dim3 grid((B * T + CG_BN - 1) / CG_BN, (Cin + CG_BM - 1) / CG_BM);
-        if (KS == 5) k_conv_gemm<0, 5><<<grid, 256, 0, stream>>>(a);
-        else if (KS == 3) k_conv_gemm<0, 3><<<grid, 256, 0, stream>>>(a);
-        else return T2V_ERR_DIMS;
+        if (conv5_tiled_ok(Cout, KS)) {
+            launch_conv5_fwd(Wt_scratch, dY, nullptr, dX, nullptr, B, Cout, T, Cin, stream);
+        } else {
+            ConvGemmArgs a;
+            a.W = Wt_scratch; a.X = dY; a.dY = nullptr; a.bias = nullptr; a.Y = dX; a.stat_part = nullptr;
+            a.B = B; a.Cin = Cout; a.T = T; a.M = Cin; a.KS = KS;
+            dim3 grid((B * T + CG_BN - 1) / CG_BN, (Cin + CG_BM - 1) / CG_BM);
+            if (KS == 5) k_conv_gemm<0, 5><<<grid, 256, 0, stream>>>(a);
+            else if (KS == 3) k_conv_gemm<0, 3><<<grid, 256, 0, stream>>>(a);
+            else return T2V_ERR_DIMS;
+        }
     }
-    if (dW) {
+    if (dW && conv5_tiled_ok(Cin, KS)) {
+        ConvTiledArgs a;
+        a.W = nullptr; a.X = X; a.dY = dY; a.bias = nullptr; a.Y = dW; a.stat_part = nullptr;
+        a.B = B; a.Cin = Cin; a.T = T; a.M = Cout; a.tiles_per_item = 0;
+        a.prof = nullptr;
+        dim3 grid(Cin / 16, (Cout + CT_BM - 1) / CT_BM);
+        const int c80 = ((T + 79) / 80) * 80, c96 = ((T + 95) / 96) * 96;
+        if (c80 <= c96) k_conv5_dw<80><<<grid, 256, 0, stream>>>(a);
+        else k_conv5_dw<96><<<grid, 256, 0, stream>>>(a);
+    } else if (dW) {
         ConvGemmArgs a;
         a.W = nullptr; a.X = X; a.dY = dY; a.bias = nullptr; a.Y = dW; a.stat_part = nullptr;
         a.B = B; a.Cin = Cin; a.T = T; a.M = Cout; a.KS = KS;

@@ -84,7 +84,7 @@ def load_library():
     lib.t2v_decoder_infer_steps.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecInferBufs), C.c_int, C.c_int, C.c_int,
                                             C.c_int, C.c_float, C.c_float, C.c_int, C.c_uint64, C.c_void_p]
     vp = C.c_void_p
-    lib.t2v_conv1d_stat_blocks.argtypes = [C.c_int, C.c_int]
+    lib.t2v_conv1d_stat_blocks.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.t2v_conv1d_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.t2v_conv1d_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.t2v_bn_act_fwd.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -345,7 +345,7 @@ class ConvBNAct1d(torch.autograd.Function):
         dev = x.device
         f32 = dict(device=dev, dtype=torch.float32)
         y = torch.empty(B, Cout, T, **f32)
-        nblk = lib.t2v_conv1d_stat_blocks(B, T)
+        nblk = lib.t2v_conv1d_stat_blocks(B, T, Cin, KS)
         part = torch.empty(nblk, Cout, 2, **f32) if training else None
         w = weight.contiguous()
         _check(lib.t2v_conv1d_fwd(_p(w), _p(x), _p(bias), _p(y), _p(part), B, Cin, T, Cout, KS, _stream()),
