@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void k_mel_frontend(FrontendArgs a) {
                 int64_t p = base + 2 * nn + c;
                 if (p < 0) p = -p;
                 if (p >= n) p = 2 * (n - 1) - p;
+                p = p < 0 ? 0 : p;      // n <= 512 is rejected by the host wrapper; never read out of bounds anyway
                 const size_t off = (size_t)b * a.n_stride + (size_t)p;
                 const float x = a.wav_i16 ? (float)a.wav_i16[off] : a.wav_f32[off];
                 s[c] = x * a.scale * a.window[2 * nn + c];

@@ -43,6 +43,14 @@ _GROUPS = {
 }
 
 
+# Switches this build adds (not in the reference's HParams; `values()` keeps reporting the reference's set only):
+#   device_frontend : dataset hands over raw int16 audio, ONE batched STFT->mel launch per batch on the GPU
+#   bucket_batches  : length-bucketed batch sampler (low padding waste, balanced DP ranks)
+#   bf16_run        : bf16 MFMA for the Postnet/encoder convolutions and the time-batched linears, fp32
+#                     master weights / accumulation / BatchNorm / recurrent state (replaces fp16_run)
+_EXTENSIONS = dict(device_frontend=False, bucket_batches=False, bf16_run=False)
+
+
 def _coerce(old, text):
     if isinstance(old, bool):
         return text.strip().lower() in ('true', '1')
@@ -76,7 +84,11 @@ class HParams(object):
         return k in self._store
 
     def values(self):
-        return dict(self._store)
+        """the reference's hyper-parameters (build-specific switches excluded)"""
+        return {k: v for k, v in self._store.items() if k not in _EXTENSIONS}
+
+    def extensions(self):
+        return {k: v for k, v in self._store.items() if k in _EXTENSIONS}
 
     def parse(self, spec):
         for item in filter(None, (s.strip() for s in spec.split(','))):
@@ -95,6 +107,7 @@ def create_hparams(hparams_string=None, verbose=False):
     for grp in _GROUPS.values():
         for k, v in grp.items():
             flat[k] = list(v) if isinstance(v, list) else v
+    flat.update(_EXTENSIONS)
     hp = HParams(**flat)
     if hparams_string:
         hp.parse(hparams_string)

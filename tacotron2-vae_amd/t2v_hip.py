@@ -259,6 +259,10 @@ def mel_frontend(wav, n_samples, tables, scale=1.0, t_stride=None):
     lib = _require_gpu(wav)
     B, N = wav.shape
     wav = wav.contiguous()
+    if int(n_samples.min()) <= 512 or int(n_samples.max()) > N:
+        # reflect padding of n_fft/2 needs more than n_fft/2 samples (torch raises for the reference's F.pad too)
+        raise ValueError("mel_frontend: every utterance needs 512 < n_samples <= %d, got [%d, %d]"
+                         % (N, int(n_samples.min()), int(n_samples.max())))
     n_samples = n_samples.to(device=wav.device, dtype=torch.int64).contiguous()
     if t_stride is None:
         t_stride = int(n_samples.max().item()) // 256 + 1

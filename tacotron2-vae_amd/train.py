@@ -91,16 +91,44 @@ class TrainEngine(object):
         return loss.detach(), recon.detach(), kl.detach(), w, grad_norm
 
 
+def prepare_directories_and_logger(output_directory, log_directory, rank):
+    """reference train.py:68-77: rank 0 owns the output directory and the TensorBoard stream."""
+    if rank != 0:
+        return None
+    if output_directory and not os.path.isdir(output_directory):
+        os.makedirs(output_directory)
+        os.chmod(output_directory, 0o775)
+    if not log_directory:
+        return None
+    from logger import Tacotron2Logger
+    return Tacotron2Logger(os.path.join(output_directory or '.', log_directory))
+
+
 def prepare_dataloaders(hparams):
+    """reference train.py:52-65 (DistributedSampler shards, drop_last, the reference's collate layout).
+    Two switches the reference does not have, both off by default:
+      device_frontend=True : the dataset returns raw int16 audio, the collate pads it, and the whole batch goes
+                             through ONE STFT->mel launch on the GPU (data_utils.DeviceFrontendCollate);
+      bucket_batches=True  : batches are drawn from length buckets (data_utils.BucketBatchSampler), so that a
+                             batch wastes few padded frames and DP ranks see similar amounts of work."""
     from torch.utils.data import DataLoader
     from torch.utils.data.distributed import DistributedSampler
-    from data_utils import TextMelCollate, TextMelLoader
-    trainset = TextMelLoader(hparams.training_files, hparams)
-    valset = TextMelLoader(hparams.validation_files, hparams)
-    collate_fn = TextMelCollate(hparams.n_frames_per_step)
-    sampler = DistributedSampler(trainset) if hparams.distributed_run else None
-    loader = DataLoader(trainset, num_workers=0, shuffle=False, sampler=sampler, batch_size=hparams.batch_size,
-                        pin_memory=False, drop_last=True, collate_fn=collate_fn)
+    from data_utils import BucketBatchSampler, DeviceFrontendCollate, TextMelCollate, TextMelLoader
+    device_fe = bool(getattr(hparams, 'device_frontend', False))
+    trainset = TextMelLoader(hparams.training_files, hparams, return_audio=device_fe)
+    valset = TextMelLoader(hparams.validation_files, hparams, return_audio=device_fe)
+    collate_fn = (DeviceFrontendCollate(hparams, stft=trainset.stft) if device_fe
+                  else TextMelCollate(hparams.n_frames_per_step))
+    if getattr(hparams, 'bucket_batches', False):
+        world, rank = (dist.get_world_size(), dist.get_rank()) if hparams.distributed_run else (1, 0)
+        batch_sampler = BucketBatchSampler(trainset.lengths(), hparams.batch_size, world_size=world, rank=rank,
+                                           seed=hparams.seed)
+        loader = DataLoader(trainset, num_workers=0, batch_sampler=batch_sampler, pin_memory=False,
+                            collate_fn=collate_fn)
+    else:
+        sampler = DistributedSampler(trainset) if hparams.distributed_run else None
+        loader = DataLoader(trainset, num_workers=0, shuffle=False, sampler=sampler, batch_size=hparams.batch_size,
+                            pin_memory=False, drop_last=True, collate_fn=collate_fn)
     return loader, valset, collate_fn
 
 
@@ -110,17 +138,21 @@ def validate(model, criterion, valset, iteration, batch_size, n_gpus, collate_fn
     from torch.utils.data.distributed import DistributedSampler
     model.eval()
     reduced = float('nan')
+    y = y_pred = None
     with torch.no_grad():
         sampler = DistributedSampler(valset) if distributed_run else None
         loader = DataLoader(valset, sampler=sampler, num_workers=0, shuffle=False, batch_size=batch_size,
                             pin_memory=False, collate_fn=collate_fn)
         for batch in loader:
             x, y = model.parse_batch(batch)
-            loss, _, _, _ = criterion(model(x), y, iteration)
+            y_pred = model(x)
+            loss, _, _, _ = criterion(y_pred, y, iteration)
             reduced = (t2v_dist.reduce_tensor(loss.data, n_gpus) if distributed_run else loss).item()
     model.train()
     if rank == 0:
         print("Validation loss {}: {:9f}  ".format(iteration, reduced))
+        if logger is not None and y_pred is not None:
+            logger.log_validation(reduced, model, y, y_pred, iteration)
     return reduced
 
 
@@ -133,8 +165,7 @@ def train(output_directory, log_directory, checkpoint_path, warm_start, n_gpus, 
     engine = TrainEngine(hparams, world_size=n_gpus if hparams.distributed_run else 1)
     model, optimizer, criterion = engine.model, engine.optimizer, engine.criterion
     learning_rate = hparams.learning_rate
-    if rank == 0 and output_directory and not os.path.isdir(output_directory):
-        os.makedirs(output_directory)
+    logger = prepare_directories_and_logger(output_directory, log_directory, rank)
     train_loader, valset, collate_fn = prepare_dataloaders(hparams)
 
     iteration, epoch_offset = 0, 0
@@ -150,6 +181,8 @@ def train(output_directory, log_directory, checkpoint_path, warm_start, n_gpus, 
 
     for epoch in range(epoch_offset, hparams.epochs):
         print("Epoch: {}".format(epoch))
+        if hasattr(getattr(train_loader, 'batch_sampler', None), 'set_epoch'):
+            train_loader.batch_sampler.set_epoch(epoch)
         for batch in train_loader:
             start = time.perf_counter()
             loss, recon, kl, kl_w, grad_norm = engine.step(batch, iteration, learning_rate)
@@ -158,13 +191,18 @@ def train(output_directory, log_directory, checkpoint_path, warm_start, n_gpus, 
                 duration = time.perf_counter() - start
                 print("Train loss {} {:.6f} Grad Norm {:.6f} {:.2f}s/it".format(
                     iteration, reduced, grad_norm.item(), duration))
+                if logger is not None:
+                    logger.log_training(reduced, grad_norm.item(), learning_rate, duration, recon.item(), kl.item(),
+                                        kl_w, iteration)
             if iteration % hparams.iters_per_checkpoint == 0:
-                validate(model, criterion, valset, iteration, hparams.batch_size, n_gpus, collate_fn, None,
+                validate(model, criterion, valset, iteration, hparams.batch_size, n_gpus, collate_fn, logger,
                          hparams.distributed_run, rank)
                 if rank == 0:
                     save_checkpoint(model, optimizer, learning_rate, iteration,
                                     os.path.join(output_directory, "checkpoint_{}".format(iteration)))
             iteration += 1
+    if logger is not None:
+        logger.close()
 
 
 if __name__ == '__main__':
