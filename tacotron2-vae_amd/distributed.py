@@ -74,6 +74,87 @@ class ArenaAllReduce(object):
             w.wait()
 
 
+class OverlappedArenaAllReduce(object):
+    """Gradient all-reduce in a few buckets that start as soon as their gradients exist.
+
+    The arena is cut at top-level-module boundaries (parameter order = arena order), so a bucket is one
+    contiguous slice.  Each live parameter carries a post-accumulate-grad hook; when the last one of a bucket
+    has fired, that slice's all-reduce is issued asynchronously — for Tacotron2 the Postnet slice (first to
+    finish in backward) travels over xGMI while the decoder BPTT is still running, the decoder slice while the
+    encoder / reference-encoder backward runs, and only the small remainder is exposed.  `finish()` (after
+    backward) issues whatever has not gone yet — tensors that got no gradient this step never fire — and waits.
+    One collective per bucket on a point-to-point fabric: few, large messages (xGMI rings are per-link bound)."""
+
+    def __init__(self, named_params, offsets, flat, group=None, min_bucket=1 << 16):
+        """named_params: [(name, param)] in arena order; offsets: start of each param inside `flat`."""
+        self.flat, self.group = flat, group
+        groups = []         # [top-level module, lo, hi, [params]] in arena order
+        for (name, p), off in zip(named_params, offsets):
+            top = name.split('.', 1)[0]
+            end = off + ((p.numel() + 3) & ~3)
+            if groups and groups[-1][0] == top:
+                groups[-1][2] = end
+                groups[-1][3].append(p)
+            else:
+                groups.append([top, off, end, [p]])
+        buckets = []
+        for g in groups:    # a tiny group (e.g. the symbol embedding) rides with its arena neighbour
+            if buckets and buckets[-1][2] - buckets[-1][1] < min_bucket:
+                buckets[-1][0] += '+' + g[0]
+                buckets[-1][2] = g[2]
+                buckets[-1][3] += g[3]
+            else:
+                buckets.append(g)
+        if len(buckets) > 1 and buckets[-1][2] - buckets[-1][1] < min_bucket:
+            last = buckets.pop()
+            buckets[-1][0] += '+' + last[0]
+            buckets[-1][2] = last[2]
+            buckets[-1][3] += last[3]
+        if buckets:
+            buckets[-1][2] = flat.numel()
+        self.buckets = [(b[0], b[1], b[2], len(b[3])) for b in buckets]
+        self._pending = [0] * len(buckets)
+        self._works = [None] * len(buckets)
+        self._active = False
+        self.launch_log = []          # (bucket index, launched from a hook i.e. while backward was running)
+        for bi, b in enumerate(buckets):
+            for p in b[3]:
+                p.register_post_accumulate_grad_hook(self._make_hook(bi))
+
+    def _make_hook(self, bi):
+        def hook(_param):
+            if not self._active:
+                return
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0:
+                self._launch(bi, True)
+        return hook
+
+    def _launch(self, bi, from_hook):
+        if self._works[bi] is not None:
+            return
+        _, lo, hi, _ = self.buckets[bi]
+        self._works[bi] = dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.launch_log.append((bi, from_hook))
+
+    def begin(self):
+        """call before backward()"""
+        self._active = dist.is_initialized() and dist.get_world_size(self.group) > 1
+        self._pending = [b[3] for b in self.buckets]
+        self._works = [None] * len(self.buckets)
+        self.launch_log = []
+
+    def finish(self):
+        """call after backward(): everything is reduced (summed) when this returns"""
+        if not self._active:
+            return
+        for bi in range(len(self.buckets)):
+            self._launch(bi, False)
+        for w in self._works:
+            w.wait()
+        self._active = False
+
+
 def reduce_tensor(tensor, n_gpus):
     """reference train.py:31-35 (mean of a scalar over ranks, for logging)."""
     rt = tensor.clone()

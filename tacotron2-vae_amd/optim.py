@@ -64,6 +64,10 @@ class FlatAdam(object):
         self.world_size = world_size
         self.step_count = 0
 
+    def arena_layout(self):
+        """([(name, param)], [offset]) of the live parameters in arena order (for the bucketed all-reduce)"""
+        return [(n, p) for _, n, p in self._live], list(self._offsets)
+
     # -- loop API
     def zero_grad(self, set_to_none=False):
         self.grads.zero_()

@@ -71,7 +71,10 @@ class TrainEngine(object):
         self.criterion = Tacotron2Loss_VAE(hparams)
         self.optimizer = FlatAdam(self.model, lr=hparams.learning_rate, weight_decay=hparams.weight_decay,
                                   grad_clip_thresh=hparams.grad_clip_thresh, world_size=world_size)
-        self.allreduce = t2v_dist.ArenaAllReduce(self.optimizer.grads) if world_size > 1 else None
+        self.allreduce = None
+        if world_size > 1:
+            named, offs = self.optimizer.arena_layout()
+            self.allreduce = t2v_dist.OverlappedArenaAllReduce(named, offs, self.optimizer.grads)
         self.model.train()
 
     def step(self, batch, iteration, learning_rate=None):
@@ -84,9 +87,11 @@ class TrainEngine(object):
         x, y = self.model.parse_batch(batch)
         y_pred = self.model(x)
         loss, recon, kl, w = self.criterion(y_pred, y, iteration)
+        if self.allreduce is not None:
+            self.allreduce.begin()
         loss.backward()
         if self.allreduce is not None:
-            self.allreduce()
+            self.allreduce.finish()
         grad_norm = opt.step()
         return loss.detach(), recon.detach(), kl.detach(), w, grad_norm
 

@@ -58,3 +58,68 @@ def test_arena_chunking_covers_everything():
         ar = D.ArenaAllReduce(torch.empty(n), n_chunks=4)
         assert ar.bounds[0][0] == 0 and ar.bounds[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(ar.bounds, ar.bounds[1:]))
+
+
+def _overlap_worker(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tacotron2-vae_amd'))
+    import distributed as D
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    D.init_distributed(backend='gloo', timeout_s=60)
+    torch.manual_seed(0)
+    # stand-in with Tacotron2's top-level layout: encoder -> decoder -> postnet in forward, so the postnet
+    # gradients are complete first in backward
+    net = torch.nn.ModuleDict(dict(emb=torch.nn.Linear(4, 6), encoder=torch.nn.Linear(6, 300),
+                                   decoder=torch.nn.Linear(300, 300), postnet=torch.nn.Linear(300, 300)))
+    named = list(net.named_parameters())
+    offs, total = [], 0
+    for _, p in named:
+        offs.append(total)
+        total += (p.numel() + 3) & ~3
+    flat = torch.zeros(total)
+    for (_, p), o in zip(named, offs):
+        p.grad = flat[o:o + p.numel()].view_as(p)
+    ar = D.OverlappedArenaAllReduce(named, offs, flat, min_bucket=64)
+    x = torch.randn(5, 4, generator=torch.Generator().manual_seed(10 + rank))
+    def run():
+        flat.zero_()
+        ar.begin()
+        y = net['postnet'](torch.tanh(net['decoder'](torch.tanh(net['encoder'](net['emb'](x))))))
+        y.pow(2).sum().backward()
+        ar.finish()
+    run()
+    first = flat.clone()
+    run()                                               # hooks re-arm every step
+    assert torch.equal(first, flat)
+    if rank == 0:
+        torch.save(dict(flat=flat.clone(), buckets=ar.buckets, log=ar.launch_log, x0=x), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucket_allreduce(tmp_path):
+    world, port = 2, _free_port()
+    out = str(tmp_path / 'r0.pt')
+    mp.spawn(_overlap_worker, args=(world, port, out), nprocs=world, join=True)
+    r = torch.load(out, weights_only=False)
+    names = [b[0] for b in r['buckets']]
+    assert names == ['emb+encoder', 'decoder', 'postnet']                    # the tiny embedding rides with its neighbour
+    assert r['buckets'][0][1] == 0 and r['buckets'][-1][2] == r['flat'].numel()
+    assert all(a[2] == b[1] for a, b in zip(r['buckets'], r['buckets'][1:]))
+    # every bucket was issued from a hook (i.e. during backward), postnet first
+    assert [bi for bi, _ in r['log']] == [2, 1, 0] and all(h for _, h in r['log'])
+    # reduced gradient == sum of the two ranks' single-process gradients
+    torch.manual_seed(0)
+    net = torch.nn.ModuleDict(dict(emb=torch.nn.Linear(4, 6), encoder=torch.nn.Linear(6, 300),
+                                   decoder=torch.nn.Linear(300, 300), postnet=torch.nn.Linear(300, 300)))
+    want = None
+    for rank in range(world):
+        net.zero_grad()
+        x = torch.randn(5, 4, generator=torch.Generator().manual_seed(10 + rank))
+        y = net['postnet'](torch.tanh(net['decoder'](torch.tanh(net['encoder'](net['emb'](x))))))
+        y.pow(2).sum().backward()
+        g = torch.cat([torch.nn.functional.pad(p.grad.reshape(-1), (0, (-p.numel()) % 4)) for p in net.parameters()])
+        want = g.clone() if want is None else want + g
+    assert torch.allclose(r['flat'], want, rtol=1e-5, atol=1e-6)
