@@ -122,3 +122,38 @@ def test_synthesizer_drop_in(tmp_path):
     from scipy.io.wavfile import read
     sr, data = read(wav_path)
     assert sr == 16000 and got['shape'] == (1, 80, mel3.size(2)) and len(data) == 256 * mel3.size(2)
+
+
+def test_bucket_order_on_the_real_model():
+    """1-rank RCCL group on the real model: the Postnet slice of the gradient arena is issued from a hook while
+    backward is still running, before the decoder slice, before the encoder slice."""
+    import socket
+    import sys
+    import torch.distributed as dist
+    import distributed as D
+    import hparams as HP
+    import train as TR
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic_batch
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, world_size=1, rank=0)
+    try:
+        hp = HP.create_hparams("batch_size=2,anneal_function=constant")
+        torch.manual_seed(hp.seed)
+        eng = TR.TrainEngine(hp)
+        named, offs = eng.optimizer.arena_layout()
+        ar = D.OverlappedArenaAllReduce(named, offs, eng.optimizer.grads, force=True)
+        eng.allreduce = ar
+        batch = synthetic_batch(2, 12, 30, 3)
+        eng.step(batch, 0)
+        ref = eng.optimizer.grads.clone()
+        torch.cuda.synchronize()
+        names = [b[0] for b in ar.buckets]
+        assert names == ['transcript_embedding+encoder', 'decoder', 'postnet', 'vae_gst']
+        assert ar.buckets[0][1] == 0 and ar.buckets[-1][2] == eng.optimizer.grads.numel()
+        order = [names[bi] for bi, _ in ar.launch_log]
+        assert order.index('postnet') < order.index('decoder') < order.index('transcript_embedding+encoder')
+        assert all(from_hook for _, from_hook in ar.launch_log)
+        assert torch.isfinite(ref).all()
+    finally:
+        dist.destroy_process_group()
