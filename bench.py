@@ -145,6 +145,8 @@ def main():
                     help='torch CPU threads for the baseline leg (the M=6 GEMVs of this model stop scaling\n'
                          'around 8 threads on this EPYC host: 8 → 3.7 s/it, 16 → 4.2, 32 → 7.4, all cores ≈ 40)')
     ap.add_argument('--no-decode', action='store_true')
+    ap.add_argument('--bf16', action='store_true',
+                    help='BASELINE configs[4] instead of the headline config: bf16_run=True, B=16 per GPU')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -160,8 +162,11 @@ def main():
     import t2v_hip
     import train as TR
     t2v_hip.load_library()
-    hp = HP.create_hparams("batch_size=%d,anneal_function=constant%s" % (
-        B_PER_GPU, ",distributed_run=True" if world > 1 else ""))
+    global B_PER_GPU
+    if args.bf16:
+        B_PER_GPU = 16
+    hp = HP.create_hparams("batch_size=%d,anneal_function=constant%s%s" % (
+        B_PER_GPU, ",distributed_run=True" if world > 1 else "", ",bf16_run=True" if args.bf16 else ""))
     torch.manual_seed(hp.seed)
     torch.cuda.manual_seed(hp.seed)
     engine = TR.TrainEngine(hp, world_size=world)
@@ -196,11 +201,16 @@ def main():
     value = frames / (elapsed / args.steps)
 
     out = {
-        "metric": "mel-frames/s (train step, batch=6, 80-mel)", "value": round(value, 1), "unit": "mel-frames/s",
+        "metric": "mel-frames/s (train step, batch=%d, 80-mel)" % B_PER_GPU, "value": round(value, 1),
+        "unit": "mel-frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: Tacotron2-VAE fp32 train step (fwd+loss+bwd+clip+Adam), "
-                               "B=6/GPU fixed shape T_in=84 T_out=400, dropout on, random-init seed 1234",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.bf16 else "f32",
+        "data": "synthetic",
+        "config": {"workload": ("configs[4]: bf16_run train step (bf16 MFMA wide Conv1d fwd/dx + time-batched linears "
+                                "+ LSTM dW GEMMs; fp32 master/BN/recurrence), B=16/GPU fixed shape T_in=84 T_out=400, "
+                                "dropout on, random-init seed 1234") if args.bf16 else
+                               ("configs[1]: Tacotron2-VAE fp32 train step (fwd+loss+bwd+clip+Adam), "
+                                "B=6/GPU fixed shape T_in=84 T_out=400, dropout on, random-init seed 1234"),
                    "global_batch": B_PER_GPU * world, "frames_per_step": frames,
                    "parallelism": "dp%d" % world},
         "final_loss": round(final_loss, 5),

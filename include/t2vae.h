@@ -163,6 +163,15 @@ int t2v_conv1d_fwd(const float* W, const float* X, const float* bias, float* Y, 
                    int B, int Cin, int T, int Cout, int KS, void* stream);
 int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, float* dX, float* dW, float* Wt_scratch,
                    int B, int Cin, int T, int Cout, int KS, void* stream);
+/* bf16_run variants (BASELINE configs[4]; replace the reference's fp16 path, fp16_optimizer.py / loss_scaler.py):
+ * fp32 tensors in and out, operands rounded to bf16 on the way into LDS, fp32 accumulation on bf16 MFMA.
+ * Wp_scratch: W's element count x 2 bytes.  Forward and data gradient only (dW is computed by the fp32 kernel);
+ * T2V_ERR_DIMS unless KS == 5 and the reduction channel count is a multiple of 16. */
+int t2v_conv1d_fwd_bf16(const float* W, const float* X, const float* bias, float* Y, float* stat_part,
+                        void* Wp_scratch, int B, int Cin, int T, int Cout, int KS, void* stream);
+int t2v_conv1d_bwd_bf16(const float* W, const float* X, const float* dY, float* dX, float* dW,
+                        void* Wp_scratch, int B, int Cin, int T, int Cout, int KS, void* stream);
+
 int t2v_bn_act_fwd(const float* y, const float* stat_part, int nblk, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float* mean_out, float* rstd_out, float* out,
                    int B, int M, int T, int act, int training, float p_drop, float momentum, float eps,
@@ -194,6 +203,11 @@ int t2v_bilstm_bwd(const float* whh, const int32_t* lengths, const float* dy, co
 int t2v_gemm_f32(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
                  float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
                  uint64_t seed, uint32_t rng_stream, uint32_t rng_t, void* stream);
+/* same contract, bf16 operands / fp32 accumulate (bf16_run) */
+int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
+                  float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
+                  uint64_t seed, uint32_t rng_stream, uint32_t rng_t, void* stream);
+
 
 /* ------------------------------------------------------------------ reference encoder / VAE / loss
  * t2v_conv2d_s2_* : Conv2d 3x3 stride 2 pad 1 of ReferenceEncoder (modules.py:45-57); coord != 0 appends the

@@ -442,6 +442,158 @@ __global__ __launch_bounds__(256) void k_conv5_dw(ConvTiledArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// bf16 variant of the tiled forward / data-gradient kernel (hparams bf16_run, BASELINE configs[4]): operands are
+// rounded to bf16 (RNE) on their way into LDS, products accumulate in fp32 on v_mfma_f32_16x16x16_bf16; inputs,
+// outputs, bias and the BatchNorm statistics stay fp32.  One MFMA k-step = one tap x 16 channels.
+//   weights : packed once per call by k_conv5_pack_bf16 into Wp[row][channel block][tap][16] (the data-gradient
+//             flip/transpose is folded into that pass), so a tile's A rows are 160 contiguous bytes;
+//   LDS     : As[tap][row][16 (+8 pad)] and Xt[position][16 (+8 pad)] (channel-contiguous, transposed while
+//             staging): every MFMA operand is one ds_read_b64, rows 48 B apart -> conflict-free.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    bf16x2_t p = {(__bf16)lo, (__bf16)hi};
+    return *(unsigned*)&p;
+}
+#define CB_RS 24     // LDS row stride in bf16 elements (48 B)
+
+// W (M, Cin, 5) fp32 -> Wp bf16.  flipT = 0: rows = M, channels = Cin, Wp[r][cb][kx][c16] = W[r][16cb+c16][kx].
+// flipT = 1 (data gradient): rows = Cin, channels = M, Wp[r][cb][kx][c16] = W[16cb+c16][r][4-kx].
+__global__ void k_conv5_pack_bf16(const float* __restrict__ W, unsigned short* __restrict__ Wp, int M, int Cin, int flipT) {
+    const int R = flipT ? Cin : M, Cc = flipT ? M : Cin;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)R * Cc * 5) return;
+    const int c16 = i & 15, kx = (i >> 4) % 5;
+    const size_t rc = (i >> 4) / 5;
+    const int cb = rc % (Cc / 16), r = rc / (Cc / 16);
+    const int cc = 16 * cb + c16;
+    const float v = flipT ? W[((size_t)cc * Cin + r) * 5 + (4 - kx)] : W[((size_t)r * Cin + cc) * 5 + kx];
+    const __bf16 b = (__bf16)v;
+    Wp[i] = *(const unsigned short*)&b;
+}
+
+struct ConvBf16Args {
+    const unsigned short* Wp;   // (M, Cin/16, 5, 16) bf16
+    const float* X;             // (B, Cin, T)
+    const float* bias;
+    float* Y;                   // (B, M, T)
+    float* stat_part;
+    int B, Cin, T, M, tiles_per_item;
+};
+
+template <int NTW>
+__global__ __launch_bounds__(256) void k_conv5_fwd_bf16(ConvBf16Args a) {
+    constexpr int BN = 16 * NTW;
+    constexpr int XW = BN + 4;
+    constexpr int NXP = (8 * XW + 255) / 256;            // channel PAIRS x positions staged per thread
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][5][CT_BM][CB_RS];
+    __shared__ __attribute__((aligned(16))) unsigned short Xt[2][XW][CB_RS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int kq = lane >> 4, j = lane & 15;
+    const int bb = blockIdx.x / a.tiles_per_item, t0 = (blockIdx.x % a.tiles_per_item) * BN;
+    const int m0 = blockIdx.y * CT_BM;
+    const int ncb = a.Cin / 16;
+
+    // staging plan: A = 640 chunks of 16 B (row = q/10, chunk = q%10 -> tap = chunk/2, half = chunk&1)
+    uint4 ra[3];
+    const unsigned short* a_src[3];
+    int a_lds[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int q = tid + 256 * i;
+        const int row = min(q / 10, CT_BM - 1), ch = q - (q / 10) * 10;
+        a_src[i] = a.Wp + (size_t)min(m0 + row, a.M - 1) * ncb * 80 + ch * 8;      // + 80 * kt
+        a_lds[i] = q < 640 ? (((ch >> 1) * CT_BM + row) * CB_RS + 8 * (ch & 1)) : -1;
+    }
+    float rx[NXP][2];
+    const float* x_item = a.X + (size_t)bb * a.Cin * a.T;
+    int x_goff[NXP], x_lds[NXP];
+    bool x_ok[NXP];
+#pragma unroll
+    for (int i = 0; i < NXP; ++i) {
+        const int e = tid + 256 * i;
+        const int cp = min(e / XW, 7), pos = e - (e / XW) * XW;
+        const int t = t0 - 2 + pos;
+        x_ok[i] = e < 8 * XW && t >= 0 && t < a.T;
+        x_goff[i] = 2 * cp * a.T + min(max(t, 0), a.T - 1);
+        x_lds[i] = e < 8 * XW ? pos * CB_RS + 2 * cp : -1;
+    }
+    auto load_tiles = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ra[i] = *(const uint4*)(a_src[i] + 80 * kt);
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+            const float* px = x_item + (size_t)16 * kt * a.T + x_goff[i];
+            const float v0 = px[0], v1 = px[a.T];
+            rx[i][0] = x_ok[i] ? v0 : 0.f;
+            rx[i][1] = x_ok[i] ? v1 : 0.f;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (a_lds[i] >= 0) *(uint4*)(&As[buf][0][0][0] + a_lds[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NXP; ++i)
+            if (x_lds[i] >= 0) *(unsigned*)(&Xt[buf][0][0] + x_lds[i]) = pack_bf16x2(rx[i][0], rx[i][1]);
+    };
+
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < ncb; ++kt) {
+        const int buf = kt & 1;
+        load_tiles(min(kt + 1, ncb - 1));
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+            const s16x4 av = *(const s16x4*)&As[buf][kx][16 * wave + j][4 * kq];
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const s16x4 bv = *(const s16x4*)&Xt[buf][16 * n + j + kx][4 * kq];
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, acc[n], 0, 0, 0);
+            }
+        }
+        store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    float psum[4] = {0.f, 0.f, 0.f, 0.f}, psq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 16 * wave + 4 * kq + r;
+        if (m < a.M) {
+            const float bv = a.bias ? a.bias[m] : 0.f;
+            float* yrow = a.Y + ((size_t)bb * a.M + m) * a.T;
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const int t = t0 + 16 * n + j;
+                if (t < a.T) {
+                    const float v = acc[n][r] + bv;
+                    yrow[t] = v;
+                    psum[r] += v;
+                    psq[r] = fmaf(v, v, psq[r]);
+                }
+            }
+        }
+    }
+    if (a.stat_part) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float s1 = row16_sum(psum[r]), s2 = row16_sum(psq[r]);
+            const int m = m0 + 16 * wave + 4 * kq + r;
+            if (j == 0 && m < a.M) {
+                float* dst = a.stat_part + ((size_t)blockIdx.x * a.M + m) * 2;
+                dst[0] = s1;
+                dst[1] = s2;
+            }
+        }
+    }
+}
+
 static inline int conv5_pick_bn(int T) {      // output positions per workgroup: least padded work, ties -> wider
     int best = 64, cost = ((T + 63) / 64) * 64;
     const int c80 = ((T + 79) / 80) * 80, c96 = ((T + 95) / 96) * 96;
@@ -462,6 +614,21 @@ static void launch_conv5_fwd(const float* W, const float* X, const float* bias, 
     if (BN == 64) k_conv5_fwd<4><<<grid, 256, 0, stream>>>(a);
     else if (BN == 80) k_conv5_fwd<5><<<grid, 256, 0, stream>>>(a);
     else k_conv5_fwd<6><<<grid, 256, 0, stream>>>(a);
+}
+
+static void launch_conv5_fwd_bf16(const float* W, int flipT, unsigned short* Wp, const float* X, const float* bias,
+                                  float* Y, float* stat_part, int B, int Cin, int T, int M, int W_M, int W_Cin,
+                                  hipStream_t stream) {
+    const size_t n = (size_t)W_M * W_Cin * 5;
+    k_conv5_pack_bf16<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(W, Wp, W_M, W_Cin, flipT);
+    const int BN = conv5_pick_bn(T);
+    ConvBf16Args a;
+    a.Wp = Wp; a.X = X; a.bias = bias; a.Y = Y; a.stat_part = stat_part;
+    a.B = B; a.Cin = Cin; a.T = T; a.M = M; a.tiles_per_item = (T + BN - 1) / BN;
+    dim3 grid(B * a.tiles_per_item, (M + CT_BM - 1) / CT_BM);
+    if (BN == 64) k_conv5_fwd_bf16<4><<<grid, 256, 0, stream>>>(a);
+    else if (BN == 80) k_conv5_fwd_bf16<5><<<grid, 256, 0, stream>>>(a);
+    else k_conv5_fwd_bf16<6><<<grid, 256, 0, stream>>>(a);
 }
 
 // W (M, Cin, KS) -> Wt (Cin, M, KS) with the taps flipped: conv(dY, Wt) is the data gradient
@@ -533,5 +700,30 @@ extern "C" int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, f
         else if (KS == 3) k_conv_gemm<1, 3><<<grid, 256, 0, stream>>>(a);
         else return T2V_ERR_DIMS;
     }
+    return t2v_check_launch();
+}
+
+// ---- bf16_run entry points: same contracts as t2v_conv1d_fwd / t2v_conv1d_bwd, plus a bf16 scratch of W's
+// element count (2 bytes each).  Forward and data gradient run on bf16 MFMA, the weight gradient stays on the
+// fp32 kernel.  T2V_ERR_DIMS when the shape is outside the tiled bf16 path (caller uses the fp32 entry points).
+extern "C" int t2v_conv1d_fwd_bf16(const float* W, const float* X, const float* bias, float* Y, float* stat_part,
+                                   void* Wp_scratch, int B, int Cin, int T, int Cout, int KS, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!W || !X || !Y || !Wp_scratch || B < 1 || Cin < 1 || T < 1 || Cout < 1) return T2V_ERR_ARG;
+    if (!conv5_tiled_ok(Cin, KS)) return T2V_ERR_DIMS;
+    launch_conv5_fwd_bf16(W, 0, (unsigned short*)Wp_scratch, X, bias, Y, stat_part, B, Cin, T, Cout, Cout, Cin, stream);
+    return t2v_check_launch();
+}
+
+extern "C" int t2v_conv1d_bwd_bf16(const float* W, const float* X, const float* dY, float* dX, float* dW,
+                                   void* Wp_scratch, int B, int Cin, int T, int Cout, int KS, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!W || !X || !dY || B < 1 || Cin < 1 || T < 1 || Cout < 1) return T2V_ERR_ARG;
+    if (!conv5_tiled_ok(Cin, KS) || !conv5_tiled_ok(Cout, KS)) return T2V_ERR_DIMS;
+    if (dX) {
+        if (!Wp_scratch) return T2V_ERR_ARG;
+        launch_conv5_fwd_bf16(W, 1, (unsigned short*)Wp_scratch, dY, nullptr, dX, nullptr, B, Cout, T, Cin, Cout, Cin, stream);
+    }
+    if (dW) return t2v_conv1d_bwd(W, X, dY, nullptr, dW, nullptr, B, Cin, T, Cout, KS, stream_);
     return t2v_check_launch();
 }

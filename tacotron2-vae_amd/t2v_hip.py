@@ -44,7 +44,7 @@ class _DecInferBufs(C.Structure):
 
 
 EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decoder_train_fwd',
-           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd',
+           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_gemm_bf16',
            't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd',
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_overlap_enabled')
 
@@ -87,6 +87,8 @@ def load_library():
     lib.t2v_conv1d_stat_blocks.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.t2v_conv1d_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.t2v_conv1d_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.t2v_conv1d_fwd_bf16.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.t2v_conv1d_bwd_bf16.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.t2v_bn_act_fwd.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, vp]
     lib.t2v_bn_act_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
@@ -95,6 +97,7 @@ def load_library():
     lib.t2v_bilstm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.t2v_gemm_f32.argtypes = [vp, C.c_long, C.c_long, vp, C.c_long, C.c_long, vp, vp, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, vp]
+    lib.t2v_gemm_bf16.argtypes = lib.t2v_gemm_f32.argtypes
     lib.t2v_conv2d_s2_fwd.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.t2v_conv2d_s2_bwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.t2v_gru_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
@@ -104,6 +107,29 @@ def load_library():
         getattr(lib, name)
     _lib = lib
     return lib
+
+
+# ---- precision switch (hparams.bf16_run, BASELINE configs[4]).  Off: everything is fp32.  On: the k=5 Conv1d
+# forward / data-gradient kernels, the time-batched linear layers (own GEMM) and the deferred LSTM weight-gradient
+# GEMMs (library) take bf16 operands with fp32 accumulation; master weights, BatchNorm, the recurrent state, the
+# per-step LSTM / attention kernels, loss and Adam stay fp32.
+_BF16 = False
+
+
+def set_bf16(on):
+    global _BF16
+    _BF16 = bool(on)
+
+
+def bf16_enabled():
+    return _BF16
+
+
+def mm_mixed(a, b):
+    """a @ b for the deferred weight-gradient GEMMs: bf16 operands / fp32 result under bf16_run, fp32 otherwise."""
+    if _BF16:
+        return (a.to(torch.bfloat16) @ b.to(torch.bfloat16)).float()
+    return a @ b
 
 
 def _require_gpu(*tensors):
@@ -232,11 +258,11 @@ class DecoderCore(torch.autograd.Function):
         # time-batched weight-gradient GEMMs (plain library GEMMs)
         x_prev = XS[0:T].reshape(TB, XW)          # [h_att_{t-1} | ctx_{t-1} | .]
         x_cur = XS[1:T + 1].reshape(TB, XW)       # [h_att_t | ctx_t | h_dec_{t-1}]
-        dw_att = dga2.t() @ x_prev[:, :KATT]      # (4096,1536) = [dW_hh | dW_ih[:,256:]]
+        dw_att = mm_mixed(dga2.t(), x_prev[:, :KATT])      # (4096,1536) = [dW_hh | dW_ih[:,256:]]
         d_w_hh_att = dw_att[:, :H].contiguous()
         d_w_ih_att = torch.zeros(G4, PRE + E, **f32)
         d_w_ih_att[:, PRE:] = dw_att[:, H:]
-        dw_dec = dgd2.t() @ x_cur                 # (4096,2560) = [dW_ih | dW_hh]
+        dw_dec = mm_mixed(dgd2.t(), x_cur)                 # (4096,2560) = [dW_ih | dW_hh]
         d_w_ih_dec = dw_dec[:, :KATT].contiguous()
         d_w_hh_dec = dw_dec[:, KATT:].contiguous()
         d_bias_dec = dgd2.sum(0)
@@ -352,8 +378,16 @@ class ConvBNAct1d(torch.autograd.Function):
         nblk = lib.t2v_conv1d_stat_blocks(B, T, Cin, KS)
         part = torch.empty(nblk, Cout, 2, **f32) if training else None
         w = weight.contiguous()
-        _check(lib.t2v_conv1d_fwd(_p(w), _p(x), _p(bias), _p(y), _p(part), B, Cin, T, Cout, KS, _stream()),
-               't2v_conv1d_fwd')
+        # bf16 only for the wide layers (the three 512->512 Postnet convs, the encoder bank); the 80-channel first
+        # and last Postnet layers are cheap and stay fp32 (the output layer in particular)
+        use_bf16 = _BF16 and KS == 5 and Cin % 16 == 0 and Cin >= 128 and Cout >= 128
+        if use_bf16:
+            wp = torch.empty(w.numel(), device=dev, dtype=torch.bfloat16)
+            _check(lib.t2v_conv1d_fwd_bf16(_p(w), _p(x), _p(bias), _p(y), _p(part), _p(wp), B, Cin, T, Cout, KS,
+                                           _stream()), 't2v_conv1d_fwd_bf16')
+        else:
+            _check(lib.t2v_conv1d_fwd(_p(w), _p(x), _p(bias), _p(y), _p(part), B, Cin, T, Cout, KS, _stream()),
+                   't2v_conv1d_fwd')
         mean = torch.empty(Cout, **f32) if training else None
         rstd = torch.empty(Cout, **f32) if training else None
         out = torch.empty(B, Cout, T, **f32)
@@ -384,9 +418,14 @@ class ConvBNAct1d(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty(B, Cin, T, **f32) if need_dx else None
         dw = torch.empty_like(w)
-        wt = torch.empty_like(w) if need_dx else None
-        _check(lib.t2v_conv1d_bwd(_p(w), _p(x), _p(dy), _p(dx), _p(dw), _p(wt), B, Cin, T, Cout, KS, _stream()),
-               't2v_conv1d_bwd')
+        if _BF16 and KS == 5 and Cin % 16 == 0 and Cout % 16 == 0 and Cin >= 128 and Cout >= 128:
+            wp = torch.empty(w.numel(), device=x.device, dtype=torch.bfloat16) if need_dx else None
+            _check(lib.t2v_conv1d_bwd_bf16(_p(w), _p(x), _p(dy), _p(dx), _p(dw), _p(wp), B, Cin, T, Cout, KS,
+                                           _stream()), 't2v_conv1d_bwd_bf16')
+        else:
+            wt = torch.empty_like(w) if need_dx else None
+            _check(lib.t2v_conv1d_bwd(_p(w), _p(x), _p(dy), _p(dx), _p(dw), _p(wt), B, Cin, T, Cout, KS, _stream()),
+                   't2v_conv1d_bwd')
         # d(bias) of a conv feeding a training-mode BatchNorm is identically zero (dy has zero channel mean)
         dbias = torch.zeros(Cout, **f32)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
@@ -457,9 +496,10 @@ def gemm(A, B, bias=None, out=None, relu=False, accumulate=False, p_drop=0.0, se
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32)
     assert out.is_contiguous() and out.shape == (M, N)
-    _check(lib.t2v_gemm_f32(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(bias), _p(out), N,
-                            M, N, K, int(relu), int(accumulate), float(p_drop), int(seed), int(rng_stream),
-                            int(rng_t), _stream()), 't2v_gemm_f32')
+    fn = lib.t2v_gemm_bf16 if _BF16 else lib.t2v_gemm_f32
+    _check(fn(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(bias), _p(out), N,
+              M, N, K, int(relu), int(accumulate), float(p_drop), int(seed), int(rng_stream),
+              int(rng_t), _stream()), 't2v_gemm_bf16' if _BF16 else 't2v_gemm_f32')
     return out
 
 

@@ -24,12 +24,16 @@ from optim import FlatAdam
 
 
 def load_model(hparams):
-    """reference train.py:80-89.  fp16_run (apex-style fp16) is replaced by the bf16 path and is
-    rejected here instead of silently running something else."""
+    """reference train.py:80-89.  fp16_run (apex-style fp16, fp16_optimizer.py / loss_scaler.py) is replaced by
+    hparams.bf16_run and is rejected here instead of silently running something else.  The precision switch is
+    process-wide (t2v_hip.set_bf16): the last load_model() call decides."""
     if not torch.cuda.is_available():
         raise RuntimeError("load_model needs a GPU: the Tacotron2-VAE path here is HIP-only")
     if hparams.fp16_run:
-        raise NotImplementedError("fp16_run is replaced by the bf16 configuration; use fp32 for now")
+        raise NotImplementedError("fp16_run (apex-style fp16 + loss scaling) is replaced by bf16_run=True: "
+                                  "bf16 MFMA operands with fp32 master weights, no loss scaling needed")
+    import t2v_hip
+    t2v_hip.set_bf16(bool(getattr(hparams, 'bf16_run', False)))
     model = Tacotron2(hparams).cuda()
     if hparams.distributed_run:
         model = t2v_dist.apply_gradient_allreduce(model)

