@@ -295,14 +295,27 @@ class Tacotron2(nn.Module):
         text, input_lengths, mel, gate, output_lengths, speakers, emotions = batch
         text = to_gpu(text).long()
         speakers, emotions = to_gpu(speakers).float(), to_gpu(emotions).float()
-        input_lengths = to_gpu(input_lengths).long()
+        # max_len is read from the HOST copy: `.item()` on the device tensor (reference model.py:496) would make the
+        # host wait for everything queued so far — i.e. for the previous iteration's backward — every step
         max_len = int(torch.max(input_lengths).item())
+        input_lengths = to_gpu(input_lengths).long()
         mel, gate = to_gpu(mel).float(), to_gpu(gate).float()
         output_lengths = to_gpu(output_lengths).long()
         return ((text, input_lengths, mel, max_len, output_lengths, speakers, emotions), (mel, gate))
 
     def parse_input(self, inputs):
         return inputs
+
+    overlap_branches = True     # class-level switch (tests flip it to compare against the single-stream schedule)
+
+    def _side_stream(self, ref):
+        if not ref.is_cuda:
+            return None
+        st = getattr(self, '_side', None)
+        if st is None or st.device != ref.device:
+            st = torch.cuda.Stream(device=ref.device)
+            object.__setattr__(self, '_side', st)
+        return st
 
     def parse_output(self, outputs, output_lengths=None):
         """In-place on .data exactly like reference model.py:509-520 (Appendix B-5: the Postnet's
@@ -316,9 +329,24 @@ class Tacotron2(nn.Module):
 
     def forward(self, inputs):
         text, input_lengths, targets, _, output_lengths, speakers, emotions = self.parse_input(inputs)
+        # The text encoder and the reference encoder (VAE) are independent until the add below, and both are chains
+        # of small latency-bound kernels (persistent BiLSTM on 16 workgroups, GRU, stride-2 convs): run the VAE
+        # branch on a side stream so the two chains share the chip.  Autograd replays each node on its forward
+        # stream, so the backward passes of the two branches overlap the same way.
+        side = self._side_stream(targets) if self.overlap_branches else None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                style, mu, logvar, z = self.vae_gst(targets)
         embedded = self.transcript_embedding(text).transpose(1, 2)
         transcript = self.encoder(embedded, input_lengths)
-        style, mu, logvar, z = self.vae_gst(targets)
+        if side is not None:
+            main.wait_stream(side)
+            for t in (style, mu, logvar, z):
+                t.record_stream(main)
+        else:
+            style, mu, logvar, z = self.vae_gst(targets)
         memory = transcript + style.unsqueeze(1)
         mel, gate, alignments = self.decoder(memory, targets, memory_lengths=input_lengths)
         mel_post = mel + self.postnet(mel)

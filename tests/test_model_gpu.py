@@ -155,3 +155,37 @@ def test_fused_adam_matches_oracle_formula():
     assert abs(float(norm) - float(total)) < 1e-5 * float(total)
     assert (dp.cpu() - p_ref).abs().max() < 2e-6
     assert (dm.cpu() - m_ref).abs().max() < 1e-7 and (dv.cpu() - v_ref).abs().max() < 1e-9
+
+
+def test_branch_overlap_is_bit_identical_to_single_stream(golden_dir):
+    """encoder ‖ reference-encoder on two streams (model.py forward) vs the single-stream schedule: same bits in
+    the outputs and in every gradient (also a race detector for the cross-stream hand-offs)."""
+    import hparams as HP
+    import model as M
+    import train as TR
+    g = np.load(os.path.join(golden_dir, 'train_step.npz'))
+    old = M.drop_rate
+    M.drop_rate = 0.0
+    res = {}
+    try:
+        for mode in (True, False, True):
+            M.Tacotron2.overlap_branches = mode
+            hp = HP.create_hparams("anneal_function=constant,p_attention_dropout=0.0,p_decoder_dropout=0.0")
+            torch.manual_seed(hp.seed)
+            eng = TR.TrainEngine(hp)
+            eng.model.vae_gst.eps_override = torch.from_numpy(g['eps']).cuda()
+            batch = (torch.from_numpy(g['text']), torch.from_numpy(g['input_lengths']), torch.from_numpy(g['mel']),
+                     torch.from_numpy(g['gate']), torch.from_numpy(g['output_lengths']),
+                     torch.zeros(2, 1, dtype=torch.long), torch.from_numpy(g['emotions']))
+            for it in range(3):
+                out = eng.step(batch, it)
+            torch.cuda.synchronize()
+            cur = (float(out[0]), eng.optimizer.grads.clone(), eng.optimizer.params.clone())
+            if mode in res:
+                assert cur[0] == res[mode][0] and torch.equal(cur[1], res[mode][1])
+            res[mode] = cur
+        assert res[True][0] == res[False][0]
+        assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
+    finally:
+        M.drop_rate = old
+        M.Tacotron2.overlap_branches = True

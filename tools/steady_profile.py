@@ -34,3 +34,16 @@ tot = sum(v[0] for v in gaps.values()) / nsteps / 1e6
 print("idle gaps > 3 us: %.3f ms/step; top followers:" % tot)
 for n_, (t_, c_) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:12]:
     print("   %-50s %7.1f gaps/st %8.3f ms/step  avg %7.1f us" % (n_, c_ / nsteps, t_ / nsteps / 1e6, t_ / c_ / 1e3))
+
+# ---- concurrency: time during which >= 2 kernels were running (multi-stream overlap)
+ev = []
+for s_, e_, n_ in sel:
+    ev.append((s_, 1)); ev.append((e_, -1))
+ev.sort()
+depth, last, over = 0, None, 0
+for t_, d_ in ev:
+    if depth >= 2 and last is not None:
+        over += t_ - last
+    depth += d_
+    last = t_
+print("time with >= 2 kernels in flight: %.3f ms/step" % (over / nsteps / 1e6))
