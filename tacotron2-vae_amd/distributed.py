@@ -85,10 +85,13 @@ class OverlappedArenaAllReduce(object):
     backward) issues whatever has not gone yet — tensors that got no gradient this step never fire — and waits.
     One collective per bucket on a point-to-point fabric: few, large messages (xGMI rings are per-link bound)."""
 
-    def __init__(self, named_params, offsets, flat, group=None, min_bucket=1 << 16, force=False):
+    def __init__(self, named_params, offsets, flat, group=None, min_bucket=1 << 16, force=False, side_streams=None):
         """named_params: [(name, param)] in arena order; offsets: start of each param inside `flat`."""
         self.flat, self.group = flat, group
         self.force = force      # run the hooks and collectives even in a 1-rank group (tests)
+        # callable -> streams other than the current one on which gradients of the model may be produced (the model
+        # runs its reference-encoder branch on a side stream): a bucket waits for them before it goes out
+        self.side_streams = side_streams
         groups = []         # [top-level module, lo, hi, [params]] in arena order
         for (name, p), off in zip(named_params, offsets):
             top = name.split('.', 1)[0]
@@ -135,6 +138,10 @@ class OverlappedArenaAllReduce(object):
         if self._works[bi] is not None:
             return
         _, lo, hi, _ = self.buckets[bi]
+        if self.flat.is_cuda and self.side_streams is not None:
+            cur = torch.cuda.current_stream()
+            for st in self.side_streams():
+                cur.wait_stream(st)
         self._works[bi] = dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.launch_log.append((bi, from_hook))
 

@@ -78,7 +78,10 @@ class TrainEngine(object):
         self.allreduce = None
         if world_size > 1:
             named, offs = self.optimizer.arena_layout()
-            self.allreduce = t2v_dist.OverlappedArenaAllReduce(named, offs, self.optimizer.grads)
+            model = self.model
+            self.allreduce = t2v_dist.OverlappedArenaAllReduce(
+                named, offs, self.optimizer.grads,
+                side_streams=lambda: [st for st in (getattr(model, '_side', None),) if st is not None])
         self.model.train()
 
     def step(self, batch, iteration, learning_rate=None):

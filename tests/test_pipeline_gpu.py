@@ -142,7 +142,8 @@ def test_bucket_order_on_the_real_model():
         torch.manual_seed(hp.seed)
         eng = TR.TrainEngine(hp)
         named, offs = eng.optimizer.arena_layout()
-        ar = D.OverlappedArenaAllReduce(named, offs, eng.optimizer.grads, force=True)
+        ar = D.OverlappedArenaAllReduce(named, offs, eng.optimizer.grads, force=True,
+                                        side_streams=lambda: [st for st in (getattr(eng.model, '_side', None),) if st])
         eng.allreduce = ar
         batch = synthetic_batch(2, 12, 30, 3)
         eng.step(batch, 0)
