@@ -119,6 +119,17 @@ int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
                           const t2v_dec_bwd_bufs* g, int B, int T_in, int T_out,
                           float p_att, float p_dec, uint64_t seed, void* stream);
 
+/* Deferred weight gradients of the location layer (model.py:24-28) reduced over the whole decoder pass in one
+ * streaming kernel + a fixed-order partial sum (what autograd accumulates step by step at train.py:225):
+ *   d_loc_dense (128,32)  = sum_{t,b,j} dpre[t,b,j,:] (x) conv[t,b,:,j]
+ *   d_loc_conv  (32,2,31) = sum_{t,b,j} dc[t,b,:,j] (x) [al[t,b,j+k-15], acum[t,b,j+k-15]]_k
+ * dpre = S after t2v_decoder_train_bwd, conv = CONV, dc = DC, al/acum = rows 0..T-1 of AL/ACUM.
+ * part_scratch: t2v_attn_wgrad_scratch_floats() floats. */
+int t2v_attn_wgrad_scratch_floats(void);
+int t2v_attn_wgrad(const float* dpre, const float* conv, const float* dc, const float* al, const float* acum,
+                   float* part_scratch, float* d_loc_dense, float* d_loc_conv, int B, int T_in, int T, void* stream);
+
+
 /* ------------------------------------------------------------------ free-running decode
  * Decoder.inference (model.py:428-464) == the synthesizer loop (synthesizer.py:139-154): steps
  * t_begin..t_end-1, each = attention_rnn → attention → decoder_rnn → 80-mel/gate projection → Prenet of

@@ -44,7 +44,7 @@ class _DecInferBufs(C.Structure):
 
 
 EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decoder_train_fwd',
-           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_gemm_bf16',
+           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_gemm_bf16', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
            't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd',
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_overlap_enabled')
 
@@ -98,6 +98,8 @@ def load_library():
     lib.t2v_gemm_f32.argtypes = [vp, C.c_long, C.c_long, vp, C.c_long, C.c_long, vp, vp, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, vp]
     lib.t2v_gemm_bf16.argtypes = lib.t2v_gemm_f32.argtypes
+    lib.t2v_attn_wgrad.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.t2v_attn_wgrad_scratch_floats.argtypes = []
     lib.t2v_conv2d_s2_fwd.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.t2v_conv2d_s2_bwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.t2v_gru_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
@@ -270,13 +272,21 @@ class DecoderCore(torch.autograd.Function):
         d_memory = torch.bmm(AL[1:].permute(1, 2, 0), DCTX.permute(1, 0, 2))
         dpre = S                                   # overwritten in place by the backward kernels
         d_pm = dpre.sum(0)
-        d_loc_dense = dpre.view(-1, A).t() @ CONV.permute(0, 1, 3, 2).reshape(-1, F_LOC)
         d_v = DV.sum((0, 1)).view(1, A)
-        apad = torch.nn.functional.pad(torch.stack((AL[0:T], ACUM[0:T]), 2), (15, 15))   # (T,B,2,T_in+30)
-        d_loc_conv = torch.einsum('nfj,ncjk->fck', DC.view(TB, F_LOC, T_in),
-                                  apad.view(TB, 2, T_in + 30).unfold(2, KS, 1))
+        d_loc_dense, d_loc_conv = attn_wgrad(dpre, CONV, DC, AL, ACUM, B, T_in, T)
         return (DGA, d_memory, d_pm, None, d_w_ih_att, d_w_hh_att, d_w_ih_dec, d_w_hh_dec, d_bias_dec,
                 d_wq, d_loc_conv, d_loc_dense, d_v, None, None, None)
+
+
+def attn_wgrad(dpre, CONV, DC, AL, ACUM, B, T_in, T):
+    """location_dense / location_conv weight gradients summed over the whole decoder pass (csrc/attn_wgrad.hip)."""
+    lib = _require_gpu(dpre, CONV, DC, AL, ACUM)
+    f32 = dict(device=dpre.device, dtype=torch.float32)
+    part = torch.empty(lib.t2v_attn_wgrad_scratch_floats(), **f32)
+    d_dense, d_conv = torch.empty(A, F_LOC, **f32), torch.empty(F_LOC, 2, KS, **f32)
+    _check(lib.t2v_attn_wgrad(_p(dpre), _p(CONV), _p(DC), _p(AL), _p(ACUM), _p(part), _p(d_dense), _p(d_conv),
+                              B, T_in, T, _stream()), 't2v_attn_wgrad')
+    return d_dense, d_conv
 
 
 def mel_frontend(wav, n_samples, tables, scale=1.0, t_stride=None):

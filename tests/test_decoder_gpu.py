@@ -113,3 +113,25 @@ def test_decoder_state_dropout_statistics_and_backward():
         mel_e = dec(memory.to(dev), mels.to(dev), lengths.to(dev))[0]
         XSe = t2v_hip.DecoderCore.last_call[3][13]
     assert (XSe[1:31, :, :1024] == 0).float().mean().item() < 0.01
+
+
+@pytest.mark.parametrize("B,T_in,T", [(6, 84, 40), (2, 37, 9), (3, 150, 5), (1, 256, 3)])
+def test_attn_wgrad_matches_torch(B, T_in, T):
+    """location_dense / location_conv weight gradients reduced over the whole pass vs the plain formula."""
+    import t2v_hip
+    g = torch.Generator().manual_seed(B * 100 + T_in)
+    dpre = torch.randn(T, B, T_in, 128, generator=g)
+    conv = torch.randn(T, B, 32, T_in, generator=g)
+    dc = torch.randn(T, B, 32, T_in, generator=g)
+    al = torch.rand(T + 1, B, T_in, generator=g)
+    acum = torch.rand(T + 1, B, T_in, generator=g) * 3
+    dd, dcv = t2v_hip.attn_wgrad(dpre.cuda(), conv.cuda(), dc.cuda(), al.cuda(), acum.cuda(), B, T_in, T)
+    ref_dense = torch.einsum('tbjd,tbfj->df', dpre.double(), conv.double())
+    apad = torch.nn.functional.pad(torch.stack((al[:T], acum[:T]), 2).double(), (15, 15))      # (T,B,2,T_in+30)
+    ref_conv = torch.einsum('tbfj,tbcjk->fck', dc.double(), apad.unfold(3, 31, 1))
+    assert dd.shape == (128, 32) and dcv.shape == (32, 2, 31)
+    assert (dd.cpu().double() - ref_dense).abs().max().item() < 1e-4 * ref_dense.abs().max().item()
+    assert (dcv.cpu().double() - ref_conv).abs().max().item() < 1e-4 * ref_conv.abs().max().item()
+    # deterministic: fixed summation order
+    dd2, dcv2 = t2v_hip.attn_wgrad(dpre.cuda(), conv.cuda(), dc.cuda(), al.cuda(), acum.cuda(), B, T_in, T)
+    assert torch.equal(dd, dd2) and torch.equal(dcv, dcv2)
