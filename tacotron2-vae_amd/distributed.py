@@ -85,13 +85,17 @@ class OverlappedArenaAllReduce(object):
     backward) issues whatever has not gone yet — tensors that got no gradient this step never fire — and waits.
     One collective per bucket on a point-to-point fabric: few, large messages (xGMI rings are per-link bound)."""
 
-    def __init__(self, named_params, offsets, flat, group=None, min_bucket=1 << 16, force=False, side_streams=None):
+    def __init__(self, named_params, offsets, flat, group=None, min_bucket=1 << 16, force=False, side_streams=None,
+                 gather=None):
         """named_params: [(name, param)] in arena order; offsets: start of each param inside `flat`."""
         self.flat, self.group = flat, group
         self.force = force      # run the hooks and collectives even in a 1-rank group (tests)
         # callable -> streams other than the current one on which gradients of the model may be produced (the model
         # runs its reference-encoder branch on a side stream): a bucket waits for them before it goes out
         self.side_streams = side_streams
+        # callable(list of params): bring those parameters' gradients into `flat` (FlatAdam.gather_grads) — the
+        # arena is filled bucket by bucket right before each bucket's collective
+        self.gather = gather
         groups = []         # [top-level module, lo, hi, [params]] in arena order
         for (name, p), off in zip(named_params, offsets):
             top = name.split('.', 1)[0]
@@ -117,6 +121,7 @@ class OverlappedArenaAllReduce(object):
         if buckets:
             buckets[-1][2] = flat.numel()
         self.buckets = [(b[0], b[1], b[2], len(b[3])) for b in buckets]
+        self._bucket_params = [list(b[3]) for b in buckets]
         self._pending = [0] * len(buckets)
         self._works = [None] * len(buckets)
         self._active = False
@@ -142,6 +147,8 @@ class OverlappedArenaAllReduce(object):
             cur = torch.cuda.current_stream()
             for st in self.side_streams():
                 cur.wait_stream(st)
+        if self.gather is not None:
+            self.gather(self._bucket_params[bi])
         self._works[bi] = dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.launch_log.append((bi, from_hook))
 

@@ -53,11 +53,15 @@ class FlatAdam(object):
         self.exp_avg_sq = torch.zeros(total, **f32)
         self._partials = torch.zeros(1024, **f32)
         self.grad_norm = torch.zeros(1, **f32)
+        self._grad_views = []
         for (i, n, p), o in zip(self._live, offs):
             view = self.params[o:o + p.numel()].view_as(p)
             view.copy_(p.data)
             p.data = view                                   # parameter now lives in the arena
-            p.grad = self.grads[o:o + p.numel()].view_as(p)  # autograd accumulates in place
+            p.grad = None
+            self._grad_views.append(self.grads[o:o + p.numel()].view_as(p))
+        self._view_of = {id(p): v for (_, _, p), v in zip(self._live, self._grad_views)}
+        self._gathered = False
         self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay,
                                   amsgrad=False, maximize=False)]
         self.grad_clip_thresh = grad_clip_thresh
@@ -69,16 +73,42 @@ class FlatAdam(object):
         return [(n, p) for _, n, p in self._live], list(self._offsets)
 
     # -- loop API
-    def zero_grad(self, set_to_none=False):
-        self.grads.zero_()
+    def zero_grad(self, set_to_none=True):
+        """Gradients are NOT accumulated into the arena by autograd (that costs one add launch per tensor, ~110 per
+        step): autograd keeps its own `.grad` tensors and `gather_grads()` copies them into the arena with one
+        multi-tensor launch before the all-reduce / the fused clip+Adam."""
+        for _, _, p in self._live:
+            p.grad = None
+        self._gathered = False
+
+    def gather_grads(self, params=None):
+        """copy `.grad` of `params` (default: all live parameters) into their arena slots; a parameter without a
+        gradient gets zeros.  DP buckets call this per bucket from their hooks."""
+        plist = [p for _, _, p in self._live] if params is None else params
+        views, srcs = [], []
+        for p in plist:
+            v = self._view_of[id(p)]
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                views.append(v)
+                srcs.append(p.grad)
+        if views:
+            torch._foreach_copy_(views, srcs)
+        if params is None:
+            self._gathered = True
+
+    def mark_gathered(self):
+        self._gathered = True
 
     def rebind_grads(self):
-        """Re-attach arena views if something (e.g. model.zero_grad(set_to_none=True)) dropped them."""
-        for (i, n, p), o in zip(self._live, self._offsets):
-            if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * o:
-                p.grad = self.grads[o:o + p.numel()].view_as(p)
+        """kept for callers of the earlier API: nothing to re-attach any more"""
+        return None
 
     def step(self):
+        if not self._gathered:
+            self.gather_grads()
+        self._gathered = False
         g = self.param_groups[0]
         self.step_count += 1
         lib = t2v_hip.load_library()

@@ -81,7 +81,8 @@ class TrainEngine(object):
             model = self.model
             self.allreduce = t2v_dist.OverlappedArenaAllReduce(
                 named, offs, self.optimizer.grads,
-                side_streams=lambda: [st for st in (getattr(model, '_side', None),) if st is not None])
+                side_streams=lambda: [st for st in (getattr(model, '_side', None),) if st is not None],
+                gather=self.optimizer.gather_grads)
         self.model.train()
 
     def step(self, batch, iteration, learning_rate=None):
@@ -99,6 +100,7 @@ class TrainEngine(object):
         loss.backward()
         if self.allreduce is not None:
             self.allreduce.finish()
+            opt.mark_gathered()        # every bucket gathered its slice before it went out
         grad_norm = opt.step()
         return loss.detach(), recon.detach(), kl.detach(), w, grad_norm
 

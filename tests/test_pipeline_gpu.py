@@ -143,11 +143,23 @@ def test_bucket_order_on_the_real_model():
         eng = TR.TrainEngine(hp)
         named, offs = eng.optimizer.arena_layout()
         ar = D.OverlappedArenaAllReduce(named, offs, eng.optimizer.grads, force=True,
-                                        side_streams=lambda: [st for st in (getattr(eng.model, '_side', None),) if st])
+                                        side_streams=lambda: [st for st in (getattr(eng.model, '_side', None),) if st],
+                                        gather=eng.optimizer.gather_grads)
         eng.allreduce = ar
         batch = synthetic_batch(2, 12, 30, 3)
-        eng.step(batch, 0)
-        ref = eng.optimizer.grads.clone()
+        opt = eng.optimizer
+        opt.zero_grad()
+        x, y = eng.model.parse_batch(batch)
+        loss = eng.criterion(eng.model(x), y, 0)[0]
+        ar.begin()
+        loss.backward()
+        ar.finish()
+        opt.mark_gathered()
+        ref = opt.grads.clone()
+        # the bucket-by-bucket gather filled the arena with exactly autograd's gradients
+        for (n, p), o in zip(named, offs):
+            assert torch.equal(ref[o:o + p.numel()].view_as(p), p.grad), n
+        opt.step()
         torch.cuda.synchronize()
         names = [b[0] for b in ar.buckets]
         assert names == ['transcript_embedding+encoder', 'decoder', 'postnet', 'vae_gst']
