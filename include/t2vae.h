@@ -231,12 +231,16 @@ int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B, long sBj, 
  *                   out4 = [total, recon, kl, kl_weight]; part192 = 192 floats scratch, ticket = zeroed uint32. */
 int t2v_conv2d_s2_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cx, int H, int W,
                       int Cout, int coord, void* stream);
-int t2v_conv2d_s2_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, int B, int Cx,
-                      int H, int W, int Cout, int coord, void* stream);
-int t2v_gru_fwd(const float* gi, const float* whh, const float* bhh, float* hs, float* gsave, int B, int T,
-                void* stream);
+/* dw_scratch: t2v_conv2d_s2_dw_scratch_floats(...) floats (0 -> may be NULL): position-chunk partials of dW */
+int t2v_conv2d_s2_dw_scratch_floats(int B, int Cx, int H, int W, int Cout, int coord);
+int t2v_conv2d_s2_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* dw_scratch,
+                      int B, int Cx, int H, int W, int Cout, int coord, void* stream);
+/* xchg: 2*16*256 floats (forward) / 2*16*768 floats (backward) exchange buffer of the 8 cooperating workgroups;
+ * sync2: 2 uint32 (zeroed by the call; sync2[1] != 0 afterwards means a bounded spin timed out). */
+int t2v_gru_fwd(const float* gi, const float* whh, const float* bhh, float* hs, float* gsave, float* xchg,
+                uint32_t* sync2, int B, int T, void* stream);
 int t2v_gru_bwd(const float* whh, const float* hs, const float* gsave, const float* dh_last, float* dgi,
-                float* dgh, int B, int T, void* stream);
+                float* dgh, float* xchg, uint32_t* sync2, int B, int T, void* stream);
 int t2v_loss_fwd_bwd(const float* mel, const float* post, const float* mel_t, const float* gate,
                      const float* gate_t, const float* mu, const float* logvar, float* dmel, float* dpost,
                      float* dgate, float* dmu, float* dlogvar, float* part192, float* out4, uint32_t* ticket,

@@ -10,40 +10,12 @@
 // sequence runs over its OWN length (reverse direction starts at len_b-1), padded outputs are zero.
 #include "t2v_common.h"
 #include "t2v_kernels.h"
+#include "t2v_coop.h"
 
 #define BL_H 256
 #define BL_G (4 * BL_H)
 #define BL_NW 8                 // workgroups per direction
 #define BL_UNITS (BL_H / BL_NW) // 32 units per workgroup
-#define BL_SPIN_LIMIT 4000000
-
-typedef __attribute__((address_space(1))) unsigned gu32;
-
-__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// all workgroups of one direction arrive; returns false on timeout (error word set)
-__device__ __forceinline__ bool group_barrier(unsigned* counter, unsigned target, unsigned* err) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores are out
-    __syncthreads();
-    __shared__ int ok;
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int good = 1;
-        unsigned spins = 0;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > BL_SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                good = 0;
-                break;
-            }
-        }
-        ok = good;
-    }
-    __syncthreads();
-    return ok != 0;
-}
 
 struct BiLstmFwdArgs {
     const float* gx;        // (2, B, T, 1024) input projections + both biases, gate-major i,f,g,o

@@ -7,6 +7,7 @@
 // BatchNorm2d + ReLU reuse the per-channel kernels of bn_act.hip on the (B, C, H*W) view.
 #include "t2v_common.h"
 #include "t2v_kernels.h"
+#include "t2v_coop.h"
 
 struct Conv2dArgs {
     const float* x;      // (B, Cx, H, W); with coord != 0 the kernel sees Cx + 3 input channels (xx, yy, rr)
@@ -82,8 +83,11 @@ __global__ __launch_bounds__(256) void k_conv2d_s2_dx(Conv2dArgs a) {
     a.y[((size_t)b * a.Cx + c) * a.H * a.W + r] = acc;
 }
 
-// one workgroup per (co, c): dw[co][c][kh][kw] = sum_{b,ho,wo} dy[b][co][ho][wo] * in[b][c][2ho-1+kh][2wo-1+kw]
-__global__ __launch_bounds__(256) void k_conv2d_s2_dw(Conv2dArgs a) {
+// dw[co][c][kh][kw] = sum_{b,ho,wo} dy[b][co][ho][wo] * in[b][c][2ho-1+kh][2wo-1+kw].  One workgroup per
+// (co, c, position chunk): the early layers have few (co, c) pairs and tens of thousands of positions (layer 0:
+// 128 pairs x 48 000), so the position range is cut into gridDim.y chunks; chunk partials go to `part` and are
+// added in a fixed order by k_conv2d_s2_dw_reduce (deterministic; a single chunk writes dw directly).
+__global__ __launch_bounds__(256) void k_conv2d_s2_dw(Conv2dArgs a, float* part, int chunk) {
     __shared__ float red[4][9];
     const int Cin = a.Cx + (a.coord ? 3 : 0);
     const int co = blockIdx.x / Cin, c = blockIdx.x % Cin;
@@ -92,7 +96,8 @@ __global__ __launch_bounds__(256) void k_conv2d_s2_dw(Conv2dArgs a) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.f;
     const int per = a.Ho * a.Wo;
-    for (int i = tid; i < a.B * per; i += 256) {
+    const int lo = blockIdx.y * chunk, hi = min(a.B * per, lo + chunk);
+    for (int i = lo + tid; i < hi; i += 256) {
         const int b = i / per, r = i - b * per, ho = r / a.Wo, wo = r - ho * a.Wo;
         const float g = a.dy[((size_t)b * a.Cout + co) * per + r];
 #pragma unroll
@@ -106,7 +111,30 @@ __global__ __launch_bounds__(256) void k_conv2d_s2_dw(Conv2dArgs a) {
         if ((tid & 63) == 0) red[tid >> 6][k] = v;
     }
     __syncthreads();
-    if (tid < 9) a.y[((size_t)co * Cin + c) * 9 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (tid < 9) {
+        float* dst = gridDim.y > 1 ? part + (size_t)blockIdx.y * a.Cout * Cin * 9 : a.y;
+        dst[((size_t)co * Cin + c) * 9 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+}
+
+__global__ void k_conv2d_s2_dw_reduce(const float* __restrict__ part, float* __restrict__ dw, int n, int nsplit) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
+    dw[i] = s;
+}
+
+// position chunks for the weight gradient: aim at >= 2048 workgroups, chunks of >= 1024 positions
+static inline int conv2d_dw_splits(int pairs, int positions) {
+    int ns = 1;
+    while (pairs * ns < 2048 && positions / (2 * ns) >= 1024 && ns < 64) ns *= 2;
+    return ns;
+}
+extern "C" int t2v_conv2d_s2_dw_scratch_floats(int B, int Cx, int H, int W, int Cout, int coord) {
+    const int Cin = Cx + (coord ? 3 : 0), Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int ns = conv2d_dw_splits(Cout * Cin, B * Ho * Wo);
+    return ns > 1 ? ns * Cout * Cin * 9 : 0;
 }
 
 extern "C" int t2v_conv2d_s2_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cx, int H, int W,
@@ -122,8 +150,8 @@ extern "C" int t2v_conv2d_s2_fwd(const float* x, const float* w, const float* bi
     return t2v_check_launch();
 }
 
-extern "C" int t2v_conv2d_s2_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, int B, int Cx,
-                                 int H, int W, int Cout, int coord, void* stream_) {
+extern "C" int t2v_conv2d_s2_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw,
+                                 float* dw_scratch, int B, int Cx, int H, int W, int Cout, int coord, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !w || !dy || !dw || B < 1) return T2V_ERR_ARG;
     Conv2dArgs a;
@@ -135,14 +163,28 @@ extern "C" int t2v_conv2d_s2_bwd(const float* x, const float* w, const float* dy
         k_conv2d_s2_dx<<<dim3((H * W + 255) / 256, B * Cx), 256, 0, stream>>>(a);
     }
     a.y = dw;
-    k_conv2d_s2_dw<<<Cout * (Cx + (coord ? 3 : 0)), 256, 0, stream>>>(a);
+    const int Cin = Cx + (coord ? 3 : 0), npos = B * a.Ho * a.Wo;
+    const int ns = conv2d_dw_splits(Cout * Cin, npos);
+    if (ns > 1 && !dw_scratch) return T2V_ERR_ARG;
+    const int chunk = (npos + ns - 1) / ns;
+    k_conv2d_s2_dw<<<dim3(Cout * Cin, ns), 256, 0, stream>>>(a, dw_scratch, chunk);
+    if (ns > 1) k_conv2d_s2_dw_reduce<<<(Cout * Cin * 9 + 255) / 256, 256, 0, stream>>>(dw_scratch, dw, Cout * Cin * 9, ns);
     return t2v_check_launch();
 }
 
 // ------------------------------------------------------------------------------------------------ GRU
 // nn.GRU semantics: r,z,n gates; n = tanh(gi_n + r * (W_hn h + b_hn)); h' = (1-z) n + z h.
-// gi (B,T,768) = x·W_ih^T + b_ih is computed outside.  One workgroup of 768 threads: thread g owns gate row
-// g of W_hh (256 floats streamed from L2 each step); h lives in LDS.  T <= 16 here (T_out / 64 frames).
+// gi (B,T,768) = x·W_ih^T + b_ih is computed outside (time-batched GEMM).  T = T_out/64 steps (<= 16), B <= 16.
+// PERSISTENT cooperative kernels like the encoder BiLSTM: 8 workgroups, each owning 32 hidden units whose three
+// gate rows of W_hh (fp32, 96 x 256) stay in VGPRs as v_mfma_f32_16x16x4_f32 A fragments for all steps; a tile
+// is 4 units x 4 gate slots (slot 3 empty) so the accumulator registers of a lane are (r, z, n) of ONE unit and
+// the gate math is lane-local.  Per step the workgroups exchange the new hidden state (forward) / the gate
+// gradients (backward) with write-through stores + one bounded group barrier (t2v_coop.h).
+#define GRU_H 256
+#define GRU_G (3 * GRU_H)
+#define GRU_NW 8
+#define GRU_UNITS (GRU_H / GRU_NW)   // 32
+
 struct GruArgs {
     const float* gi;      // (B,T,768)
     const float* whh;     // (768,256)
@@ -152,124 +194,182 @@ struct GruArgs {
     const float* dh_last; // bwd: (B,256) gradient of the last hidden state
     float* dgi;           // bwd: (B,T,768) grad wrt gi
     float* dgh;           // bwd: (B,T,768) grad wrt (W_hh h + b_hh) rows
+    float* xchg;          // fwd: (2,16,256) h exchange; bwd: (2,16,768) gate-gradient exchange (step parity)
+    unsigned* sync;       // [0] arrival counter, [1] error word; zeroed by the launcher
     int B, T;
 };
 
-__global__ __launch_bounds__(768) void k_gru_fwd(GruArgs a) {
-    __shared__ float h[16][256];
-    __shared__ float gh[16][768];
-    const int g = threadIdx.x;
-    for (int i = g; i < 16 * 256; i += 768) (&h[0][0])[i] = 0.f;
-    for (int i = g; i < a.B * 256; i += 768) a.hs[((size_t)(i >> 8) * (a.T + 1)) * 256 + (i & 255)] = 0.f;
+__global__ __launch_bounds__(256) void k_gru_fwd(GruArgs a) {
+    const int j = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = lane & 15, g = lane >> 4;
+    const bool bvalid = b < a.B;
+    __shared__ float hbuf[16][GRU_H + 4];
+    // A fragments of this wave's two tiles: row i = lane&15 -> (unit i>>2, gate slot i&3), k = 4s + g
+    float wreg[2][64];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int unit = j * GRU_UNITS + (2 * wave + tt) * 4 + ((lane & 15) >> 2);
+        const int slot = lane & 3;
+#pragma unroll
+        for (int s = 0; s < 64; ++s)
+            wreg[tt][s] = slot < 3 ? a.whh[(size_t)(slot * GRU_H + unit) * GRU_H + 4 * s + g] : 0.f;
+    }
+    float bh[2][3];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int U = j * GRU_UNITS + (2 * wave + tt) * 4 + g;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) bh[tt][r] = a.bhh[r * GRU_H + U];
+        if (bvalid) a.hs[((size_t)b * (a.T + 1)) * GRU_H + U] = 0.f;
+    }
+    for (int i = tid; i < 16 * (GRU_H + 4); i += 256) (&hbuf[0][0])[i] = 0.f;
     __syncthreads();
-    const float4* wrow = (const float4*)(a.whh + (size_t)g * 256);
-    const float bias = a.bhh[g];
+
     for (int t = 0; t < a.T; ++t) {
-        float acc[16];
+        float giv[2][3];
 #pragma unroll
-        for (int b = 0; b < 16; ++b) acc[b] = bias;
-#pragma unroll 8
-        for (int k4 = 0; k4 < 64; ++k4) {
-            const float4 w = wrow[k4];
+        for (int tt = 0; tt < 2; ++tt) {
+            const int U = j * GRU_UNITS + (2 * wave + tt) * 4 + g;
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                if (b < a.B) {
-                    const float4 hv = *(const float4*)&h[b][4 * k4];
-                    acc[b] = fmaf(w.x, hv.x, acc[b]); acc[b] = fmaf(w.y, hv.y, acc[b]);
-                    acc[b] = fmaf(w.z, hv.z, acc[b]); acc[b] = fmaf(w.w, hv.w, acc[b]);
+            for (int r = 0; r < 3; ++r) giv[tt][r] = bvalid ? a.gi[((size_t)b * a.T + t) * GRU_G + r * GRU_H + U] : 0.f;
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float* hrow = &hbuf[b][g];
+#pragma unroll
+        for (int s = 0; s < 64; ++s) {
+            const float hv = hrow[4 * s];
+            acc0 = mfma16x4(wreg[0][s], hv, acc0);
+            acc1 = mfma16x4(wreg[1][s], hv, acc1);
+        }
+        float* hx_w = a.xchg + (size_t)(t & 1) * 16 * GRU_H;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const f32x4 acc = tt == 0 ? acc0 : acc1;
+            const int U = j * GRU_UNITS + (2 * wave + tt) * 4 + g;
+            if (bvalid) {
+                const float r = sigmoidf_(giv[tt][0] + acc[0] + bh[tt][0]);
+                const float z = sigmoidf_(giv[tt][1] + acc[1] + bh[tt][1]);
+                const float hn = acc[2] + bh[tt][2];
+                const float n = tanhf_(giv[tt][2] + r * hn);
+                const float hnew = (1.f - z) * n + z * hbuf[b][U];
+                if (a.gsave) {
+                    float* sv = a.gsave + (((size_t)b * a.T + t) * 4) * GRU_H + U;
+                    sv[0] = r; sv[GRU_H] = z; sv[2 * GRU_H] = n; sv[3 * GRU_H] = hn;
                 }
+                a.hs[((size_t)b * (a.T + 1) + t + 1) * GRU_H + U] = hnew;
+                st_sc1(hx_w + (size_t)b * GRU_H + U, hnew);
             }
         }
-#pragma unroll
-        for (int b = 0; b < 16; ++b) if (b < a.B) gh[b][g] = acc[b];
-        __syncthreads();
-        for (int i = g; i < a.B * 256; i += 768) {
-            const int b = i >> 8, u = i & 255;
-            const float* gi = a.gi + ((size_t)b * a.T + t) * 768;
-            const float r = sigmoidf_(gi[u] + gh[b][u]);
-            const float z = sigmoidf_(gi[256 + u] + gh[b][256 + u]);
-            const float hn = gh[b][512 + u];
-            const float n = tanhf_(gi[512 + u] + r * hn);
-            const float hnew = (1.f - z) * n + z * h[b][u];
-            if (a.gsave) {
-                float* s = a.gsave + (((size_t)b * a.T + t) * 4) * 256 + u;
-                s[0] = r; s[256] = z; s[512] = n; s[768] = hn;
-            }
-            a.hs[((size_t)b * (a.T + 1) + t + 1) * 256 + u] = hnew;
-            h[b][u] = hnew;       // each (b,u) is touched by exactly one thread here
-        }
+        if (t + 1 == a.T) break;
+        if (!group_barrier(a.sync, (unsigned)(GRU_NW * (t + 1)), a.sync + 1)) return;
+        for (int i = tid; i < a.B * GRU_H; i += 256) hbuf[i >> 8][i & (GRU_H - 1)] = ld_sc1(hx_w + i);
         __syncthreads();
     }
 }
 
-// BPTT: thread u (256 threads... launched with 768) -> first the gate gradients of step t for (b,u),
-// then dh_prev[k] = sum_g W_hh[g][k] * dgh[g]: thread k<256 owns column k (coalesced row reads).
-__global__ __launch_bounds__(768) void k_gru_bwd(GruArgs a) {
-    __shared__ float dh[16][256];
-    __shared__ float dg[16][768];
-    __shared__ float part[3][16][256];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < a.B * 256; i += 768) dh[i >> 8][i & 255] = a.dh_last[i];
+// BPTT.  Thread (item bb = tid>>5 (+8), unit uu = tid&31) does the gate gradients of its (item, unit); the
+// transposed recurrent product dh_prev[b][unit] = sum_rows W_hh[row][unit] * dg[b][row] (768 rows split over the
+// four waves) runs on MFMA with W_hh^T fragments resident in VGPRs.
+__global__ __launch_bounds__(256) void k_gru_bwd(GruArgs a) {
+    const int j = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = lane & 15, g = lane >> 4;
+    __shared__ float dgbuf[16][GRU_G + 4];
+    __shared__ f32x4 red[4][2][64];
+    __shared__ float dhrec[16][GRU_UNITS + 1];
+    float wreg[2][48];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int col = j * GRU_UNITS + tt * 16 + (lane & 15);
+#pragma unroll
+        for (int s = 0; s < 48; ++s) wreg[tt][s] = a.whh[(size_t)(192 * wave + 4 * s + g) * GRU_H + col];
+    }
+    const int uu = tid & 31, U = j * GRU_UNITS + uu;
+    for (int i = tid; i < 16 * GRU_UNITS; i += 256) {
+        const int bb = i >> 5, u2 = i & 31;
+        dhrec[bb][u2] = bb < a.B ? a.dh_last[(size_t)bb * GRU_H + j * GRU_UNITS + u2] : 0.f;
+    }
     __syncthreads();
+
     for (int t = a.T - 1; t >= 0; --t) {
-        for (int i = tid; i < a.B * 256; i += 768) {
-            const int b = i >> 8, u = i & 255;
-            const float* s = a.gsave + (((size_t)b * a.T + t) * 4) * 256 + u;
-            const float r = s[0], z = s[256], n = s[512], hn = s[768];
-            const float hprev = a.hs[((size_t)b * (a.T + 1) + t) * 256 + u];
-            const float d = dh[b][u];
-            const float dn = d * (1.f - z) * (1.f - n * n);
-            const float dz = d * (hprev - n) * z * (1.f - z);
-            const float dr = dn * hn * r * (1.f - r);
-            float* gi = a.dgi + ((size_t)b * a.T + t) * 768 + u;
-            gi[0] = dr; gi[256] = dz; gi[512] = dn;
-            float* gh = a.dgh + ((size_t)b * a.T + t) * 768 + u;
-            gh[0] = dr; gh[256] = dz; gh[512] = dn * r;
-            dg[b][u] = dr; dg[b][256 + u] = dz; dg[b][512 + u] = dn * r;
-            dh[b][u] = d * z;                       // direct path h' = ... + z h
-        }
-        __syncthreads();
-        {   // dh_prev[k] += sum_g W_hh[g][k] dg[g]: thread = (k = tid&255, third = tid>>8) sums 256 gate rows
-            const int k = tid & 255, third = tid >> 8;
-            float acc[16];
+        float* dgx_w = a.xchg + (size_t)(t & 1) * 16 * GRU_G;
+        float keep[2] = {0.f, 0.f};
 #pragma unroll
-            for (int b = 0; b < 16; ++b) acc[b] = 0.f;
-            const float* wp = a.whh + (size_t)(256 * third) * 256 + k;
-#pragma unroll 16
-            for (int g = 0; g < 256; ++g) {
-                const float w = wp[(size_t)g * 256];
-#pragma unroll
-                for (int b = 0; b < 16; ++b) if (b < a.B) acc[b] = fmaf(w, dg[b][256 * third + g], acc[b]);
+        for (int rep = 0; rep < 2; ++rep) {
+            const int bb = (tid >> 5) + 8 * rep;
+            if (bb < a.B) {
+                const float* sv = a.gsave + (((size_t)bb * a.T + t) * 4) * GRU_H + U;
+                const float r = sv[0], z = sv[GRU_H], n = sv[2 * GRU_H], hn = sv[3 * GRU_H];
+                const float hprev = a.hs[((size_t)bb * (a.T + 1) + t) * GRU_H + U];
+                const float d = dhrec[bb][uu];
+                const float dn = d * (1.f - z) * (1.f - n * n);
+                const float dz = d * (hprev - n) * z * (1.f - z);
+                const float dr = dn * hn * r * (1.f - r);
+                float* gi = a.dgi + ((size_t)bb * a.T + t) * GRU_G + U;
+                gi[0] = dr; gi[GRU_H] = dz; gi[2 * GRU_H] = dn;
+                float* gh = a.dgh + ((size_t)bb * a.T + t) * GRU_G + U;
+                gh[0] = dr; gh[GRU_H] = dz; gh[2 * GRU_H] = dn * r;
+                float* x = dgx_w + (size_t)bb * GRU_G + U;
+                st_sc1(x, dr); st_sc1(x + GRU_H, dz); st_sc1(x + 2 * GRU_H, dn * r);
+                keep[rep] = d * z;                  // direct path h' = ... + z h
             }
-#pragma unroll
-            for (int b = 0; b < 16; ++b) if (b < a.B) part[third][b][k] = acc[b];
+        }
+        if (t == 0) break;
+        if (!group_barrier(a.sync, (unsigned)(GRU_NW * (a.T - t)), a.sync + 1)) return;
+        for (int i = tid; i < a.B * GRU_G; i += 256) {
+            const int bb = i / GRU_G, q = i - bb * GRU_G;
+            dgbuf[bb][q] = ld_sc1(dgx_w + i);
         }
         __syncthreads();
-        for (int i = tid; i < a.B * 256; i += 768) {
-            const int b = i >> 8, k = i & 255;
-            dh[b][k] += (part[0][b][k] + part[1][b][k]) + part[2][b][k];
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float* drow = &dgbuf[b][192 * wave + g];
+#pragma unroll
+        for (int s = 0; s < 48; ++s) {
+            const float dv = drow[4 * s];
+            acc0 = mfma16x4(wreg[0][s], dv, acc0);
+            acc1 = mfma16x4(wreg[1][s], dv, acc1);
+        }
+        red[wave][0][lane] = acc0;
+        red[wave][1][lane] = acc1;
+        __syncthreads();
+        if (wave < 2) {     // wave tt finalises tile tt: lane (col = item b, rows 4g+r = units 16tt+4g+r)
+            const f32x4 s4 = (red[0][wave][lane] + red[1][wave][lane]) + (red[2][wave][lane] + red[3][wave][lane]);
+            if (b < a.B) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dhrec[b][16 * wave + 4 * g + r] = s4[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int bb = (tid >> 5) + 8 * rep;
+            if (bb < a.B) dhrec[bb][uu] += keep[rep];
         }
         __syncthreads();
     }
 }
 
-extern "C" int t2v_gru_fwd(const float* gi, const float* whh, const float* bhh, float* hs, float* gsave, int B, int T,
-                           void* stream_) {
-    if (!gi || !whh || !bhh || !hs || B < 1 || B > 16 || T < 1) return T2V_ERR_ARG;
+extern "C" int t2v_gru_fwd(const float* gi, const float* whh, const float* bhh, float* hs, float* gsave,
+                           float* xchg, uint32_t* sync2, int B, int T, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!gi || !whh || !bhh || !hs || !xchg || !sync2 || B < 1 || B > 16 || T < 1) return T2V_ERR_ARG;
+    (void)hipMemsetAsync(sync2, 0, 2 * sizeof(uint32_t), stream);
     GruArgs a;
     a.gi = gi; a.whh = whh; a.bhh = bhh; a.hs = hs; a.gsave = gsave; a.dh_last = nullptr; a.dgi = nullptr; a.dgh = nullptr;
-    a.B = B; a.T = T;
-    k_gru_fwd<<<1, 768, 0, (hipStream_t)stream_>>>(a);
+    a.xchg = xchg; a.sync = sync2; a.B = B; a.T = T;
+    k_gru_fwd<<<GRU_NW, 256, 0, stream>>>(a);
     return t2v_check_launch();
 }
 
 extern "C" int t2v_gru_bwd(const float* whh, const float* hs, const float* gsave, const float* dh_last, float* dgi,
-                           float* dgh, int B, int T, void* stream_) {
-    if (!whh || !hs || !gsave || !dh_last || !dgi || !dgh || B < 1 || B > 16 || T < 1) return T2V_ERR_ARG;
+                           float* dgh, float* xchg, uint32_t* sync2, int B, int T, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!whh || !hs || !gsave || !dh_last || !dgi || !dgh || !xchg || !sync2 || B < 1 || B > 16 || T < 1)
+        return T2V_ERR_ARG;
+    (void)hipMemsetAsync(sync2, 0, 2 * sizeof(uint32_t), stream);
     GruArgs a;
     a.gi = nullptr; a.whh = whh; a.bhh = nullptr; a.hs = (float*)hs; a.gsave = (float*)gsave; a.dh_last = dh_last;
-    a.dgi = dgi; a.dgh = dgh; a.B = B; a.T = T;
-    k_gru_bwd<<<1, 768, 0, (hipStream_t)stream_>>>(a);
+    a.dgi = dgi; a.dgh = dgh; a.xchg = xchg; a.sync = sync2; a.B = B; a.T = T;
+    k_gru_bwd<<<GRU_NW, 256, 0, stream>>>(a);
     return t2v_check_launch();
 }
 

@@ -45,7 +45,7 @@ class _DecInferBufs(C.Structure):
 
 EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decoder_train_fwd',
            't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_gemm_bf16', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
-           't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd',
+           't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats',
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_overlap_enabled')
 
 
@@ -101,9 +101,10 @@ def load_library():
     lib.t2v_attn_wgrad.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.t2v_attn_wgrad_scratch_floats.argtypes = []
     lib.t2v_conv2d_s2_fwd.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
-    lib.t2v_conv2d_s2_bwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
-    lib.t2v_gru_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
-    lib.t2v_gru_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.t2v_conv2d_s2_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.t2v_conv2d_s2_dw_scratch_floats.argtypes = [C.c_int] * 6
+    lib.t2v_gru_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.t2v_gru_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.t2v_loss_fwd_bwd.argtypes = [vp] * 15 + [C.c_uint64, C.c_int, C.c_int, C.c_float, vp]
     for name in EXPORTS:
         getattr(lib, name)
@@ -584,8 +585,10 @@ class Conv2dBNReLU(torch.autograd.Function):
                                   _p(dbeta), B, Cout, Ho * Wo, ACT_RELU, 0.0, 0, 0, 0, _stream()), 't2v_bn_act_bwd')
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = torch.empty_like(w)
-        _check(lib.t2v_conv2d_s2_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), B, Cx, Hh, Ww, Cout, coord, _stream()),
-               't2v_conv2d_s2_bwd')
+        nscr = lib.t2v_conv2d_s2_dw_scratch_floats(B, Cx, Hh, Ww, Cout, coord)
+        scr = torch.empty(nscr, **f32) if nscr else None
+        _check(lib.t2v_conv2d_s2_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(scr), B, Cx, Hh, Ww, Cout, coord,
+                                     _stream()), 't2v_conv2d_s2_bwd')
         return dx, dw, torch.zeros(Cout, **f32), dgamma, dbeta, None, None, None, None
 
 
@@ -602,20 +605,23 @@ class GRULast(torch.autograd.Function):
         hs = torch.empty(B, T + 1, 256, **f32)
         gsave = torch.empty(B, T, 4, 256, **f32)
         whh = w_hh.contiguous()
-        _check(lib.t2v_gru_fwd(_p(gi), _p(whh), _p(b_hh), _p(hs), _p(gsave), B, T, _stream()), 't2v_gru_fwd')
-        ctx.keep = (x2, w_ih, whh, hs, gsave)
+        xchg = torch.empty(2 * 16 * 768, **f32)                       # exchange buffer (forward uses 2*16*256 of it)
+        sync = torch.empty(2, device=x.device, dtype=torch.int32)
+        _check(lib.t2v_gru_fwd(_p(gi), _p(whh), _p(b_hh), _p(hs), _p(gsave), _p(xchg), _p(sync), B, T, _stream()),
+               't2v_gru_fwd')
+        ctx.keep = (x2, w_ih, whh, hs, gsave, xchg, sync)
         ctx.dims = (B, T, I)
         return hs[:, T].clone()
 
     @staticmethod
     def backward(ctx, dh):
         lib = load_library()
-        x2, w_ih, whh, hs, gsave = ctx.keep
+        x2, w_ih, whh, hs, gsave, xchg, sync = ctx.keep
         B, T, I = ctx.dims
         f32 = dict(device=x2.device, dtype=torch.float32)
         dgi, dgh = torch.empty(B, T, 768, **f32), torch.empty(B, T, 768, **f32)
-        _check(lib.t2v_gru_bwd(_p(whh), _p(hs), _p(gsave), _p(dh.contiguous()), _p(dgi), _p(dgh), B, T, _stream()),
-               't2v_gru_bwd')
+        _check(lib.t2v_gru_bwd(_p(whh), _p(hs), _p(gsave), _p(dh.contiguous()), _p(dgi), _p(dgh), _p(xchg), _p(sync),
+                               B, T, _stream()), 't2v_gru_bwd')
         dgi2, dgh2 = dgi.view(B * T, 768), dgh.view(B * T, 768)
         dx = gemm(dgi2, w_ih.t()).view(B, T, I)
         hprev = hs[:, :T].reshape(B * T, 256)
