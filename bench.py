@@ -195,6 +195,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     final_loss = float(loss.item())
+    t2v_hip.check_async_errors()     # any bounded-spin timeout inside the timed steps invalidates the run
 
     ms_per_step = 1000.0 * elapsed / args.steps
     frames = B_PER_GPU * T_OUT * world

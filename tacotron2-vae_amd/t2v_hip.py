@@ -135,6 +135,45 @@ def mm_mixed(a, b):
     return a @ b
 
 
+# ---- asynchronous error ledger.  The cooperative kernels (BiLSTM, GRU, attention exchange, reverse-step hand-off)
+# use bounded spins: on a timeout they set an error word and leave instead of hanging.  Reading those words right
+# away would force a device sync per call, so the wrappers copy each word (device-to-device, 4 bytes) into a small
+# per-device pool and `check_async_errors()` — called by the training loop where it syncs anyway (loss.item()),
+# by validate(), bench.py and the tests — reads the pool once and raises if any call reported a timeout.
+_ERR_POOL = {}
+_ERR_SLOTS = 4096
+
+
+def _err_note(label, word):
+    """word: a 1-element int32 device view holding a kernel's error word (valid once the stream reaches it)"""
+    key = str(word.device)
+    if key not in _ERR_POOL:
+        _ERR_POOL[key] = [torch.zeros(_ERR_SLOTS, device=word.device, dtype=torch.int32), 0, {}]
+    pool = _ERR_POOL[key]
+    slot = pool[1] % _ERR_SLOTS
+    pool[0][slot:slot + 1].copy_(word)
+    pool[2][slot] = label
+    pool[1] += 1
+
+
+def check_async_errors():
+    """Raise T2VHipError if any cooperative kernel since the last check reported a barrier timeout (syncs)."""
+    bad = []
+    for key, pool in _ERR_POOL.items():
+        n = min(pool[1], _ERR_SLOTS)
+        if n == 0:
+            continue
+        vals = pool[0][:n].cpu()
+        for i in torch.nonzero(vals).flatten().tolist():
+            bad.append(pool[2].get(i, '?'))
+        pool[0].zero_()
+        pool[1] = 0
+        pool[2].clear()
+    if bad:
+        raise T2VHipError("cooperative kernel barrier timed out (results of that step are invalid): %s"
+                          % ", ".join(sorted(set(bad))))
+
+
 def _require_gpu(*tensors):
     lib = load_library()
     for t in tensors:
@@ -221,6 +260,7 @@ class DecoderCore(torch.autograd.Function):
                            _p(QP), _p(AL), _p(ACUM), _p(S), _p(CONV))
         _check(lib.t2v_decoder_train_fwd(C.byref(W), C.byref(Sb), B, T_in, T, float(p_att), float(p_dec),
                                          int(seed), _stream()), 't2v_decoder_train_fwd')
+        _err_note('decoder forward (attention exchange)', QP.view(torch.int32)[B * 256 * A + 32768 + 31:][:1])
         HC = torch.cat((XS[2:T + 2, :, KATT:], XS[1:T + 1, :, H:KATT]), 2)
         align = AL[1:].permute(1, 0, 2)
         ctx.dims = (B, T_in, T, float(p_att), float(p_dec), int(seed))
@@ -256,6 +296,7 @@ class DecoderCore(torch.autograd.Function):
                          _p(DCD), _p(GPREV), _p(GCUM), _p(DV))
         _check(lib.t2v_decoder_train_bwd(C.byref(W), C.byref(Sb), C.byref(Gb), B, T_in, T, p_att, p_dec, seed,
                                          _stream()), 't2v_decoder_train_bwd')
+        _err_note('decoder backward (dq hand-off)', GCUM.view(torch.int32)[B * 8 * 256 + 1:][:1])
         TB = T * B
         dga2, dgd2 = DGA.view(TB, G4), DGD.view(TB, G4)
         # time-batched weight-gradient GEMMs (plain library GEMMs)
@@ -464,6 +505,7 @@ class BiLSTM(torch.autograd.Function):
         sync = torch.empty(3, device=x.device, dtype=torch.int32)
         _check(lib.t2v_bilstm_fwd(_p(gx), _p(whh), _p(lengths), _p(y), _p(gates), _p(cells), _p(hx), _p(sync), B, T,
                                   _stream()), 't2v_bilstm_fwd')
+        _err_note('BiLSTM forward', sync[2:3])
         ctx.keep = (x, lengths, w_ih, w_ih_r, whh, y, gates, cells, sync)
         ctx.dims = (B, T)
         return y
@@ -481,6 +523,7 @@ class BiLSTM(torch.autograd.Function):
         dgx = torch.empty(2 * 2 * 16 * 1024, **f32)
         _check(lib.t2v_bilstm_bwd(_p(whh), _p(lengths), _p(dy), _p(gates), _p(cells), _p(dg), _p(dgx), _p(sync), B, T,
                                   _stream()), 't2v_bilstm_bwd')
+        _err_note('BiLSTM backward', sync[2:3])
         BT = B * T
         d0, d1, x2 = dg[0].view(BT, 1024), dg[1].view(BT, 1024), x.view(BT, -1)
         dx = (d0 @ w_ih + d1 @ w_ih_r).view(B, T, -1)
@@ -609,6 +652,7 @@ class GRULast(torch.autograd.Function):
         sync = torch.empty(2, device=x.device, dtype=torch.int32)
         _check(lib.t2v_gru_fwd(_p(gi), _p(whh), _p(b_hh), _p(hs), _p(gsave), _p(xchg), _p(sync), B, T, _stream()),
                't2v_gru_fwd')
+        _err_note('GRU forward', sync[1:2])
         ctx.keep = (x2, w_ih, whh, hs, gsave, xchg, sync)
         ctx.dims = (B, T, I)
         return hs[:, T].clone()
@@ -622,6 +666,7 @@ class GRULast(torch.autograd.Function):
         dgi, dgh = torch.empty(B, T, 768, **f32), torch.empty(B, T, 768, **f32)
         _check(lib.t2v_gru_bwd(_p(whh), _p(hs), _p(gsave), _p(dh.contiguous()), _p(dgi), _p(dgh), _p(xchg), _p(sync),
                                B, T, _stream()), 't2v_gru_bwd')
+        _err_note('GRU backward', sync[1:2])
         dgi2, dgh2 = dgi.view(B * T, 768), dgh.view(B * T, 768)
         dx = gemm(dgi2, w_ih.t()).view(B, T, I)
         hprev = hs[:, :T].reshape(B * T, 256)

@@ -66,6 +66,11 @@ def save_checkpoint(model, optimizer, learning_rate, iteration, filepath):
                 'learning_rate': learning_rate}, filepath)
 
 
+def t2v_hip_check():
+    import t2v_hip
+    t2v_hip.check_async_errors()
+
+
 class TrainEngine(object):
     """One rank's training state: model + criterion + flat-arena optimiser (+ arena all-reduce)."""
 
@@ -163,6 +168,7 @@ def validate(model, criterion, valset, iteration, batch_size, n_gpus, collate_fn
             loss, _, _, _ = criterion(y_pred, y, iteration)
             reduced = (t2v_dist.reduce_tensor(loss.data, n_gpus) if distributed_run else loss).item()
     model.train()
+    t2v_hip_check()
     if rank == 0:
         print("Validation loss {}: {:9f}  ".format(iteration, reduced))
         if logger is not None and y_pred is not None:
@@ -201,6 +207,7 @@ def train(output_directory, log_directory, checkpoint_path, warm_start, n_gpus, 
             start = time.perf_counter()
             loss, recon, kl, kl_w, grad_norm = engine.step(batch, iteration, learning_rate)
             reduced = (t2v_dist.reduce_tensor(loss, n_gpus) if hparams.distributed_run else loss).item()
+            t2v_hip_check()      # the .item() above synced: a cooperative-kernel timeout of this step raises here
             if not math.isnan(reduced) and rank == 0:
                 duration = time.perf_counter() - start
                 print("Train loss {} {:.6f} Grad Norm {:.6f} {:.2f}s/it".format(

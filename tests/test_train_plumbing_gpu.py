@@ -93,3 +93,17 @@ def test_engine_step_batch16_ragged():
     torch.cuda.synchronize()
     assert torch.isfinite(l0[0]).item() and torch.isfinite(l1[0]).item() and torch.isfinite(l1[4]).all().item()
     assert float(l1[0]) < float(l0[0]) * 1.5
+
+
+def test_async_error_ledger_reports_and_clears():
+    """A set error word reaches check_async_errors() once (then the ledger is clean); healthy steps leave it clean."""
+    import t2v_hip
+    t2v_hip.check_async_errors()                                   # drain whatever earlier tests left
+    w = torch.zeros(3, dtype=torch.int32, device='cuda')
+    t2v_hip._err_note('healthy', w[2:3])
+    t2v_hip.check_async_errors()
+    w[2] = 1
+    t2v_hip._err_note('synthetic timeout', w[2:3])
+    with pytest.raises(t2v_hip.T2VHipError, match='synthetic timeout'):
+        t2v_hip.check_async_errors()
+    t2v_hip.check_async_errors()
