@@ -189,3 +189,60 @@ def test_branch_overlap_is_bit_identical_to_single_stream(golden_dir):
     finally:
         M.drop_rate = old
         M.Tacotron2.overlap_branches = True
+
+
+def test_koemo_shape_parity_against_oracle():
+    """BASELINE.json configs[1] at its full size with the koemo length profile of SURVEY 8(d) — (T_in,T_out) =
+    (84,400),(80,380),(71,350),(66,300),(50,260),(37,200): HIP forward + loss + backward against the CPU oracle
+    (the validated restatement of the reference) on the same weights, dropout off, same epsilon."""
+    import sys
+    import hparams as HP
+    import model as M
+    import t2v_oracle as O
+    import train as TR
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic_batch
+    lens_in, lens_out = [84, 80, 71, 66, 50, 37], [400, 380, 350, 300, 260, 200]
+    old = M.drop_rate
+    M.drop_rate = 0.0
+    try:
+        hp = HP.create_hparams("batch_size=6,anneal_function=constant,p_attention_dropout=0.0,p_decoder_dropout=0.0")
+        torch.manual_seed(hp.seed)
+        eng = TR.TrainEngine(hp)
+        batch = synthetic_batch(6, 84, 400, 77, lens_in=lens_in, lens_out=lens_out)
+        eps = torch.randn(6, hp.z_latent_dim, generator=torch.Generator().manual_seed(5))
+        eng.model.vae_gst.eps_override = eps.cuda()
+        sd = {k: v.detach().cpu().clone() for k, v in eng.model.state_dict().items()}
+        eng.optimizer.zero_grad()
+        x, y = eng.model.parse_batch(batch)
+        y_pred = eng.model(x)
+        loss = eng.criterion(y_pred, y, 0)[0]
+        loss.backward()
+        torch.cuda.synchronize()
+        # ---- oracle on the host (8 threads: the fastest setting for these M=6 GEMVs on the EPYC host)
+        nthreads = torch.get_num_threads()
+        torch.set_num_threads(8)
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and 'running_' not in k}
+        osd = dict(sd)
+        osd.update(leaves)
+        text, lin, mel, gate, lout = batch[0].long(), batch[1].long(), batch[2].float(), batch[3].float(), batch[4].long()
+        o = O.tacotron2_forward(osd, text, lin, mel, lout, training=True, eps=eps)
+        o_loss = O.loss_forward(o, mel, gate, 0, anneal_function='constant')[0]
+        o_loss.backward()
+        torch.set_num_threads(nthreads)
+        assert abs(float(loss) - float(o_loss)) < 1e-4 * abs(float(o_loss))
+        assert (y_pred[0].detach().cpu() - o[0].detach()).abs().mean().item() < 1e-4          # mel-L1 (BASELINE.json)
+        assert (y_pred[1].detach().cpu() - o[1].detach()).abs().mean().item() < 1e-4
+        assert (y_pred[3].detach().cpu() - o[3].detach()).abs().max().item() < 5e-5           # alignments
+        gmax = max(float(v.grad.norm()) for v in leaves.values() if v.grad is not None)
+        checked = 0
+        for name, p in eng.model.named_parameters():
+            ref = leaves[name].grad if name in leaves else None
+            if ref is None or p.grad is None:
+                continue
+            scale = max(float(ref.norm()), 1e-4 * gmax)
+            assert float((p.grad.cpu() - ref).norm()) < 3e-3 * scale, name
+            checked += 1
+        assert checked >= 90
+    finally:
+        M.drop_rate = old
