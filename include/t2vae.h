@@ -162,17 +162,19 @@ int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_infer_bufs* 
  * The encoder conv bank (model.py:159-177) and the Postnet (model.py:110-148): stride-1 "same" Conv1d as
  * an implicit GEMM on fp32 MFMA, BatchNorm1d (train: biased batch statistics over B*T incl. padded frames;
  * eval: running statistics), tanh / ReLU / none, dropout.  All activations are (B, C, T) fp32.
- *   t2v_conv1d_fwd : Y = conv(X, W) + bias; stat_part ((t2v_conv1d_stat_blocks(B,T,Cin,KS), Cout, 2) or NULL)
+ *   t2v_conv1d_fwd : Y = conv(X, W) + bias; stat_part ((t2v_conv1d_stat_blocks(B,T,Cin,Cout,KS), Cout, 2) or NULL)
  *                    receives per-column-block partial [sum, sum of squares] per channel.
  *   t2v_bn_act_fwd : out = dropout(act(BN(y)));  act 0 none / 1 tanh / 2 relu.  training != 0 finalises
  *                    the statistics from stat_part, writes mean/rstd for the backward and updates the
  *                    running buffers (momentum, unbiased variance).
  *   t2v_bn_act_bwd : dy (grad wrt the conv output), dgamma, dbeta from dout.
  *   t2v_conv1d_bwd : dX (may be NULL; needs Wt_scratch of W's size) and dW (may be NULL). */
-int t2v_conv1d_stat_blocks(int B, int T, int Cin, int KS);
+int t2v_conv1d_stat_blocks(int B, int T, int Cin, int Cout, int KS);
 int t2v_conv1d_fwd(const float* W, const float* X, const float* bias, float* Y, float* stat_part,
                    int B, int Cin, int T, int Cout, int KS, void* stream);
+int t2v_conv1d_dw_scratch_floats(int B, int Cin, int T, int Cout, int KS);   /* 0 -> dw_scratch may be NULL */
 int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, float* dX, float* dW, float* Wt_scratch,
+                   float* dw_scratch,
                    int B, int Cin, int T, int Cout, int KS, void* stream);
 /* bf16_run variants (BASELINE configs[4]; replace the reference's fp16 path, fp16_optimizer.py / loss_scaler.py):
  * fp32 tensors in and out, operands rounded to bf16 on the way into LDS, fp32 accumulation on bf16 MFMA.
@@ -181,7 +183,7 @@ int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, float* dX, f
 int t2v_conv1d_fwd_bf16(const float* W, const float* X, const float* bias, float* Y, float* stat_part,
                         void* Wp_scratch, int B, int Cin, int T, int Cout, int KS, void* stream);
 int t2v_conv1d_bwd_bf16(const float* W, const float* X, const float* dY, float* dX, float* dW,
-                        void* Wp_scratch, int B, int Cin, int T, int Cout, int KS, void* stream);
+                        void* Wp_scratch, float* dw_scratch, int B, int Cin, int T, int Cout, int KS, void* stream);
 
 int t2v_bn_act_fwd(const float* y, const float* stat_part, int nblk, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float* mean_out, float* rstd_out, float* out,

@@ -192,7 +192,7 @@ template <int NTW>
 __global__ __launch_bounds__(256) void k_conv5_fwd(ConvTiledArgs a) {
     constexpr int BN = 16 * NTW;
     constexpr int XW = BN + 4;                           // staged positions per channel (2-halo each side)
-    constexpr int XS = (BN == 64) ? 80 : 112;            // row stride, = 16 or 48 mod 64: four k-rows -> disjoint banks
+    constexpr int XS = BN == 32 ? 48 : BN <= 64 ? 80 : 112;   // row stride >= BN+4, = 16 or 48 mod 64: four k-rows -> disjoint banks
     constexpr int NX = (16 * XW + 255) / 256;            // X elements staged per thread
     __shared__ float As[2][CT_KT][CT_AS];
     __shared__ float Xs[2][16][XS];
@@ -342,7 +342,10 @@ __global__ __launch_bounds__(256) void k_conv5_dw(ConvTiledArgs a) {
     const int kq = lane >> 4, j = lane & 15;
     const int c0 = blockIdx.x * 16, m0 = blockIdx.y * CT_BM;
     const int CK = a.Cin * 5;
-    const int tiles = (a.T + BT - 1) / BT, nkt = a.B * tiles;
+    const int tiles = (a.T + BT - 1) / BT, nkt_all = a.B * tiles;
+    // gridDim.z K-splits (layers with few (row, channel-block) tiles): this workgroup reduces k-tiles [kt_lo, kt_hi)
+    const int per = (nkt_all + gridDim.z - 1) / gridDim.z;
+    const int kt_lo = blockIdx.z * per, kt_hi = min(nkt_all, kt_lo + per);
     const bool vec = (a.T & 3) == 0;
 
     float4 ra[NA];
@@ -404,12 +407,14 @@ __global__ __launch_bounds__(256) void k_conv5_dw(ConvTiledArgs a) {
     f32x4 acc[5];
 #pragma unroll
     for (int n = 0; n < 5; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    load_tiles(0);
-    store_tiles(0);
+    if (kt_lo < kt_hi) {
+        load_tiles(kt_lo);
+        store_tiles(0);
+    }
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tiles(kt + 1);
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+        const int buf = (kt - kt_lo) & 1;
+        if (kt + 1 < kt_hi) load_tiles(kt + 1);
         const float* ap = &As[buf][kq][16 * wave + j];
         const float* xp = &Xs[buf][0][0];
         float av[2], bv[2][5];
@@ -428,14 +433,14 @@ __global__ __launch_bounds__(256) void k_conv5_dw(ConvTiledArgs a) {
             for (int n = 0; n < 5; ++n) acc[n] = mfma16x4(av[s & 1], bv[s & 1][n], acc[n]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (kt + 1 < nkt) store_tiles(buf ^ 1);
+        if (kt + 1 < kt_hi) store_tiles(buf ^ 1);
         __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int m = m0 + 16 * wave + 4 * kq + r;
         if (m < a.M) {
-            float* drow = a.Y + (size_t)m * CK + 5 * c0;
+            float* drow = a.Y + (size_t)blockIdx.z * a.M * CK + (size_t)m * CK + 5 * c0;   // split partials are stacked
 #pragma unroll
             for (int n = 0; n < 5; ++n) drow[16 * n + j] = acc[n][r];
         }
@@ -594,24 +599,54 @@ __global__ __launch_bounds__(256) void k_conv5_fwd_bf16(ConvBf16Args a) {
     }
 }
 
-static inline int conv5_pick_bn(int T) {      // output positions per workgroup: least padded work, ties -> wider
-    int best = 64, cost = ((T + 63) / 64) * 64;
-    const int c80 = ((T + 79) / 80) * 80, c96 = ((T + 95) / 96) * 96;
-    if (c80 <= cost) { best = 80; cost = c80; }
-    if (c96 <= cost) { best = 96; cost = c96; }
+// Output positions per workgroup (BN = 32/48/64/80/96).  Cost model: workgroups run in rounds of one per CU; a
+// workgroup's time per k-tile is its MFMA work (~BN) plus the fixed staging cost (~40 in the same units).  Small
+// problems (encoder bank: 6 x 84 positions; 80-row layers) therefore take narrow tiles — more workgroups in the one
+// round they need — and the big Postnet layers the width that divides T (80 for T=400: 240 workgroups).
+// fixed-order sum of the K-split partials of the weight gradient
+__global__ void k_conv5_dw_reduce(const float* __restrict__ part, float* __restrict__ dw, int n, int nsplit) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
+    dw[i] = s;
+}
+
+// K-splits of the weight gradient: only when the (row tile, channel block) grid is far from filling the chip
+static inline int conv5_dw_splits(int B, int Cin, int T, int Cout) {
+    const int wgs = (Cin / 16) * ((Cout + CT_BM - 1) / CT_BM);
+    const int c80 = ((T + 79) / 80), c96 = ((T + 95) / 96);
+    const int nkt = B * (c80 * 80 <= c96 * 96 ? c80 : c96);
+    int ns = 1;
+    while (wgs * ns * 2 <= T2V_NWG && ns * 2 <= nkt && ns < 8) ns *= 2;
+    return ns;
+}
+
+static inline int conv5_pick_bn(int T, int B, int M) {
+    const int cands[5] = {32, 48, 64, 80, 96};
+    int best = 80;
+    long best_cost = -1;
+    for (int i = 0; i < 5; ++i) {
+        const int bn = cands[i];
+        const long wgs = (long)B * ((T + bn - 1) / bn) * ((M + CT_BM - 1) / CT_BM);
+        const long cost = ((wgs + T2V_NWG - 1) / T2V_NWG) * (bn + 40);
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && bn > best)) { best = bn; best_cost = cost; }
+    }
     return best;
 }
 static inline bool conv5_tiled_ok(int Cin, int KS) { return KS == 5 && Cin % 16 == 0; }
 
 static void launch_conv5_fwd(const float* W, const float* X, const float* bias, float* Y, float* stat_part, int B,
                              int Cin, int T, int M, hipStream_t stream) {
-    const int BN = conv5_pick_bn(T);
+    const int BN = conv5_pick_bn(T, B, M);
     ConvTiledArgs a;
     a.W = W; a.X = X; a.dY = nullptr; a.bias = bias; a.Y = Y; a.stat_part = stat_part;
     a.B = B; a.Cin = Cin; a.T = T; a.M = M; a.tiles_per_item = (T + BN - 1) / BN;
     a.prof = g_t2v_prof;
     dim3 grid(B * a.tiles_per_item, (M + CT_BM - 1) / CT_BM);
-    if (BN == 64) k_conv5_fwd<4><<<grid, 256, 0, stream>>>(a);
+    if (BN == 32) k_conv5_fwd<2><<<grid, 256, 0, stream>>>(a);
+    else if (BN == 48) k_conv5_fwd<3><<<grid, 256, 0, stream>>>(a);
+    else if (BN == 64) k_conv5_fwd<4><<<grid, 256, 0, stream>>>(a);
     else if (BN == 80) k_conv5_fwd<5><<<grid, 256, 0, stream>>>(a);
     else k_conv5_fwd<6><<<grid, 256, 0, stream>>>(a);
 }
@@ -621,12 +656,14 @@ static void launch_conv5_fwd_bf16(const float* W, int flipT, unsigned short* Wp,
                                   hipStream_t stream) {
     const size_t n = (size_t)W_M * W_Cin * 5;
     k_conv5_pack_bf16<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(W, Wp, W_M, W_Cin, flipT);
-    const int BN = conv5_pick_bn(T);
+    const int BN = conv5_pick_bn(T, B, M);
     ConvBf16Args a;
     a.Wp = Wp; a.X = X; a.bias = bias; a.Y = Y; a.stat_part = stat_part;
     a.B = B; a.Cin = Cin; a.T = T; a.M = M; a.tiles_per_item = (T + BN - 1) / BN;
     dim3 grid(B * a.tiles_per_item, (M + CT_BM - 1) / CT_BM);
-    if (BN == 64) k_conv5_fwd_bf16<4><<<grid, 256, 0, stream>>>(a);
+    if (BN == 32) k_conv5_fwd_bf16<2><<<grid, 256, 0, stream>>>(a);
+    else if (BN == 48) k_conv5_fwd_bf16<3><<<grid, 256, 0, stream>>>(a);
+    else if (BN == 64) k_conv5_fwd_bf16<4><<<grid, 256, 0, stream>>>(a);
     else if (BN == 80) k_conv5_fwd_bf16<5><<<grid, 256, 0, stream>>>(a);
     else k_conv5_fwd_bf16<6><<<grid, 256, 0, stream>>>(a);
 }
@@ -657,13 +694,19 @@ extern "C" int t2v_conv1d_fwd(const float* W, const float* X, const float* bias,
     return t2v_check_launch();
 }
 
-extern "C" int t2v_conv1d_stat_blocks(int B, int T, int Cin, int KS) {
-    if (conv5_tiled_ok(Cin, KS)) { const int BN = conv5_pick_bn(T); return B * ((T + BN - 1) / BN); }
+extern "C" int t2v_conv1d_stat_blocks(int B, int T, int Cin, int Cout, int KS) {
+    if (conv5_tiled_ok(Cin, KS)) { const int BN = conv5_pick_bn(T, B, Cout); return B * ((T + BN - 1) / BN); }
     return (B * T + CG_BN - 1) / CG_BN;
 }
 
+extern "C" int t2v_conv1d_dw_scratch_floats(int B, int Cin, int T, int Cout, int KS) {
+    if (!conv5_tiled_ok(Cin, KS)) return 0;
+    const int ns = conv5_dw_splits(B, Cin, T, Cout);
+    return ns > 1 ? ns * Cout * Cin * 5 : 0;
+}
+
 extern "C" int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, float* dX, float* dW, float* Wt_scratch,
-                              int B, int Cin, int T, int Cout, int KS, void* stream_) {
+                              float* dw_scratch, int B, int Cin, int T, int Cout, int KS, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!W || !X || !dY || B < 1 || Cin < 1 || T < 1 || Cout < 1 || KS < 1 || !(KS & 1)) return T2V_ERR_ARG;
     if (dX) {
@@ -687,10 +730,17 @@ extern "C" int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, f
         a.W = nullptr; a.X = X; a.dY = dY; a.bias = nullptr; a.Y = dW; a.stat_part = nullptr;
         a.B = B; a.Cin = Cin; a.T = T; a.M = Cout; a.tiles_per_item = 0;
         a.prof = nullptr;
-        dim3 grid(Cin / 16, (Cout + CT_BM - 1) / CT_BM);
+        const int ns = conv5_dw_splits(B, Cin, T, Cout);
+        if (ns > 1 && !dw_scratch) return T2V_ERR_ARG;
+        if (ns > 1) a.Y = dw_scratch;
+        dim3 grid(Cin / 16, (Cout + CT_BM - 1) / CT_BM, ns);
         const int c80 = ((T + 79) / 80) * 80, c96 = ((T + 95) / 96) * 96;
         if (c80 <= c96) k_conv5_dw<80><<<grid, 256, 0, stream>>>(a);
         else k_conv5_dw<96><<<grid, 256, 0, stream>>>(a);
+        if (ns > 1) {
+            const int n = Cout * Cin * 5;
+            k_conv5_dw_reduce<<<(n + 255) / 256, 256, 0, stream>>>(dw_scratch, dW, n, ns);
+        }
     } else if (dW) {
         ConvGemmArgs a;
         a.W = nullptr; a.X = X; a.dY = dY; a.bias = nullptr; a.Y = dW; a.stat_part = nullptr;
@@ -716,7 +766,8 @@ extern "C" int t2v_conv1d_fwd_bf16(const float* W, const float* X, const float* 
 }
 
 extern "C" int t2v_conv1d_bwd_bf16(const float* W, const float* X, const float* dY, float* dX, float* dW,
-                                   void* Wp_scratch, int B, int Cin, int T, int Cout, int KS, void* stream_) {
+                                   void* Wp_scratch, float* dw_scratch, int B, int Cin, int T, int Cout, int KS,
+                                   void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!W || !X || !dY || B < 1 || Cin < 1 || T < 1 || Cout < 1) return T2V_ERR_ARG;
     if (!conv5_tiled_ok(Cin, KS) || !conv5_tiled_ok(Cout, KS)) return T2V_ERR_DIMS;
@@ -724,6 +775,6 @@ extern "C" int t2v_conv1d_bwd_bf16(const float* W, const float* X, const float* 
         if (!Wp_scratch) return T2V_ERR_ARG;
         launch_conv5_fwd_bf16(W, 1, (unsigned short*)Wp_scratch, dY, nullptr, dX, nullptr, B, Cout, T, Cin, Cout, Cin, stream);
     }
-    if (dW) return t2v_conv1d_bwd(W, X, dY, nullptr, dW, nullptr, B, Cin, T, Cout, KS, stream_);
+    if (dW) return t2v_conv1d_bwd(W, X, dY, nullptr, dW, nullptr, dw_scratch, B, Cin, T, Cout, KS, stream_);
     return t2v_check_launch();
 }

@@ -44,7 +44,7 @@ class _DecInferBufs(C.Structure):
 
 
 EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decoder_train_fwd',
-           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_gemm_bf16', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
+           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_conv1d_dw_scratch_floats', 't2v_gemm_bf16', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
            't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats',
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_overlap_enabled')
 
@@ -84,11 +84,12 @@ def load_library():
     lib.t2v_decoder_infer_steps.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecInferBufs), C.c_int, C.c_int, C.c_int,
                                             C.c_int, C.c_float, C.c_float, C.c_int, C.c_uint64, C.c_void_p]
     vp = C.c_void_p
-    lib.t2v_conv1d_stat_blocks.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.t2v_conv1d_stat_blocks.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.t2v_conv1d_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
-    lib.t2v_conv1d_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.t2v_conv1d_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.t2v_conv1d_dw_scratch_floats.argtypes = [C.c_int] * 5
     lib.t2v_conv1d_fwd_bf16.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
-    lib.t2v_conv1d_bwd_bf16.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.t2v_conv1d_bwd_bf16.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.t2v_bn_act_fwd.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, vp]
     lib.t2v_bn_act_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
@@ -427,7 +428,7 @@ class ConvBNAct1d(torch.autograd.Function):
         dev = x.device
         f32 = dict(device=dev, dtype=torch.float32)
         y = torch.empty(B, Cout, T, **f32)
-        nblk = lib.t2v_conv1d_stat_blocks(B, T, Cin, KS)
+        nblk = lib.t2v_conv1d_stat_blocks(B, T, Cin, Cout, KS)
         part = torch.empty(nblk, Cout, 2, **f32) if training else None
         w = weight.contiguous()
         # bf16 only for the wide layers (the three 512->512 Postnet convs, the encoder bank); the 80-channel first
@@ -470,14 +471,16 @@ class ConvBNAct1d(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty(B, Cin, T, **f32) if need_dx else None
         dw = torch.empty_like(w)
+        nscr = lib.t2v_conv1d_dw_scratch_floats(B, Cin, T, Cout, KS)
+        scr = torch.empty(nscr, **f32) if nscr else None
         if _BF16 and KS == 5 and Cin % 16 == 0 and Cout % 16 == 0 and Cin >= 128 and Cout >= 128:
             wp = torch.empty(w.numel(), device=x.device, dtype=torch.bfloat16) if need_dx else None
-            _check(lib.t2v_conv1d_bwd_bf16(_p(w), _p(x), _p(dy), _p(dx), _p(dw), _p(wp), B, Cin, T, Cout, KS,
+            _check(lib.t2v_conv1d_bwd_bf16(_p(w), _p(x), _p(dy), _p(dx), _p(dw), _p(wp), _p(scr), B, Cin, T, Cout, KS,
                                            _stream()), 't2v_conv1d_bwd_bf16')
         else:
             wt = torch.empty_like(w) if need_dx else None
-            _check(lib.t2v_conv1d_bwd(_p(w), _p(x), _p(dy), _p(dx), _p(dw), _p(wt), B, Cin, T, Cout, KS, _stream()),
-                   't2v_conv1d_bwd')
+            _check(lib.t2v_conv1d_bwd(_p(w), _p(x), _p(dy), _p(dx), _p(dw), _p(wt), _p(scr), B, Cin, T, Cout, KS,
+                                      _stream()), 't2v_conv1d_bwd')
         # d(bias) of a conv feeding a training-mode BatchNorm is identically zero (dy has zero channel mean)
         dbias = torch.zeros(Cout, **f32)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
