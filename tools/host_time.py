@@ -21,4 +21,4 @@ import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for it in range(5): eng.step(batch, 20 + it)
 pr.disable(); torch.cuda.synchronize()
-st = pstats.Stats(pr); st.sort_stats('cumulative'); st.print_stats(25)
+st = pstats.Stats(pr); st.sort_stats('tottime'); st.print_stats(22)
