@@ -30,6 +30,8 @@ struct BnFwdArgs {
     uint64_t seed; uint32_t rng_stream, rng_t;
 };
 
+#define BN_NE 12      // fast path: channels of up to 256*12 values are held in registers
+
 __global__ __launch_bounds__(256) void k_bn_act_fwd(BnFwdArgs a) {
     const int m = blockIdx.x, tid = threadIdx.x;
     float mean, rstd;
@@ -37,11 +39,23 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(BnFwdArgs a) {
     if (a.training) {
         double s = 0.0, q = 0.0;
         if (a.stat_part) {
-            // finalize the statistics: every thread sums the conv epilogue's partials in the same order
-            for (int i = 0; i < a.nblk; ++i) {
-                s += (double)a.stat_part[((size_t)i * a.M + m) * 2];
-                q += (double)a.stat_part[((size_t)i * a.M + m) * 2 + 1];
+            // finalize the statistics: the conv epilogue's partials are fetched in parallel (one per thread) and
+            // added by a fixed tree in double precision (a serial loop here cost ~0.5 us of load latency per partial)
+            __shared__ double dscr[2][256];
+            double ls = 0.0, lq = 0.0;
+            for (int i = tid; i < a.nblk; i += 256) {
+                ls += (double)a.stat_part[((size_t)i * a.M + m) * 2];
+                lq += (double)a.stat_part[((size_t)i * a.M + m) * 2 + 1];
             }
+            dscr[0][tid] = ls;
+            dscr[1][tid] = lq;
+            __syncthreads();
+            for (int st = 128; st > 0; st >>= 1) {
+                if (tid < st) { dscr[0][tid] += dscr[0][tid + st]; dscr[1][tid] += dscr[1][tid + st]; }
+                __syncthreads();
+            }
+            s = dscr[0][0];
+            q = dscr[1][0];
         } else {
             // no partials (direct-form conv2d of the reference encoder): reduce the channel here
             float ls = 0.f, lq = 0.f;
@@ -69,6 +83,31 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(BnFwdArgs a) {
         rstd = 1.0f / sqrtf(a.running_var[m] + a.eps);
     }
     const float g = a.gamma[m] * rstd, bt = a.beta[m] - mean * a.gamma[m] * rstd;
+    const int n = a.B * a.T;
+    if (n <= 256 * BN_NE) {
+        // a channel is only a few thousand values: every thread requests ALL of its elements before touching any
+        // (the per-element loop below pays one memory latency per element)
+        size_t off[BN_NE];
+        float yv[BN_NE];
+#pragma unroll
+        for (int e = 0; e < BN_NE; ++e) {
+            const int i = tid + 256 * e, ic = min(i, n - 1);
+            const int b = ic / a.T, t = ic - b * a.T;
+            off[e] = ((size_t)b * a.M + m) * a.T + t;
+            yv[e] = a.y[off[e]];
+        }
+#pragma unroll
+        for (int e = 0; e < BN_NE; ++e) {
+            if (tid + 256 * e < n) {
+                float z = fmaf(yv[e], g, bt);
+                if (a.act == ACT_TANH) z = tanhf_(z);
+                else if (a.act == ACT_RELU) z = fmaxf(z, 0.f);
+                if (a.training && a.p_drop > 0.f) z *= t2v_drop_scale(a.seed, a.rng_stream, a.rng_t, (uint32_t)off[e], a.p_drop);
+                a.out[off[e]] = z;
+            }
+        }
+        return;
+    }
     for (int b = 0; b < a.B; ++b) {
         const size_t base = ((size_t)b * a.M + m) * a.T;
         for (int t = tid; t < a.T; t += 256) {
@@ -109,6 +148,44 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd(BnBwdArgs a) {
     const float mean = a.mean[m], rstd = a.rstd[m], gam = a.gamma[m];
     const float g = gam * rstd, bt = a.beta[m] - mean * gam * rstd;
     float s1 = 0.f, s2 = 0.f;
+    const int nel = a.B * a.T;
+    if (nel <= 256 * BN_NE) {
+        // one pass over memory: y and dout of this thread's elements are requested up front, dz / xhat stay in
+        // registers across the block reduction
+        size_t off[BN_NE];
+        float yv[BN_NE], dv[BN_NE];
+#pragma unroll
+        for (int e = 0; e < BN_NE; ++e) {
+            const int i = tid + 256 * e, ic = min(i, nel - 1);
+            const int b = ic / a.T, t = ic - b * a.T;
+            off[e] = ((size_t)b * a.M + m) * a.T + t;
+            yv[e] = a.y[off[e]];
+            dv[e] = a.dout[off[e]];
+        }
+        float dzv[BN_NE], xh[BN_NE];
+#pragma unroll
+        for (int e = 0; e < BN_NE; ++e) {
+            float d = dv[e];
+            xh[e] = (yv[e] - mean) * rstd;
+            if (a.p_drop > 0.f) d *= t2v_drop_scale(a.seed, a.rng_stream, a.rng_t, (uint32_t)off[e], a.p_drop);
+            const float z = fmaf(yv[e], g, bt);
+            if (a.act == ACT_TANH) { const float th = tanhf_(z); d *= 1.0f - th * th; }
+            else if (a.act == ACT_RELU) { d = z > 0.f ? d : 0.f; }
+            if (tid + 256 * e >= nel) d = 0.f;
+            dzv[e] = d;
+            s1 += d;
+            s2 = fmaf(d, xh[e], s2);
+        }
+        const float S1 = block_sum_256(s1, scr);
+        const float S2 = block_sum_256(s2, scr);
+        if (tid == 0) { a.dbeta[m] = S1; a.dgamma[m] = S2; }
+        const float n = (float)a.B * (float)a.T;
+        const float m1 = S1 / n, m2 = S2 / n;
+#pragma unroll
+        for (int e = 0; e < BN_NE; ++e)
+            if (tid + 256 * e < nel) a.dy[off[e]] = g * (dzv[e] - m1 - xh[e] * m2);
+        return;
+    }
     for (int b = 0; b < a.B; ++b) {
         const size_t base = ((size_t)b * a.M + m) * a.T;
         for (int t = tid; t < a.T; t += 256) {
