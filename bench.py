@@ -145,6 +145,9 @@ def main():
                     help='torch CPU threads for the baseline leg (the M=6 GEMVs of this model stop scaling\n'
                          'around 8 threads on this EPYC host: 8 → 3.7 s/it, 16 → 4.2, 32 → 7.4, all cores ≈ 40)')
     ap.add_argument('--no-decode', action='store_true')
+    ap.add_argument('--koemo', action='store_true',
+                    help='secondary workload of SURVEY 8(d): the ragged koemo length profile instead of the fixed shape\n'
+                         '((T_in,T_out) = (84,400),(80,380),(71,350),(66,300),(50,260),(37,200); valid frames counted)')
     ap.add_argument('--bf16', action='store_true',
                     help='BASELINE configs[4] instead of the headline config: bf16_run=True, B=16 per GPU')
     args = ap.parse_args()
@@ -170,7 +173,11 @@ def main():
     torch.manual_seed(hp.seed)
     torch.cuda.manual_seed(hp.seed)
     engine = TR.TrainEngine(hp, world_size=world)
-    batch = synthetic_batch(B_PER_GPU, T_IN, T_OUT, 1234 + rank)
+    if args.koemo and not args.bf16:
+        koemo_in, koemo_out = [84, 80, 71, 66, 50, 37], [400, 380, 350, 300, 260, 200]
+        batch = synthetic_batch(B_PER_GPU, T_IN, T_OUT, 1234 + rank, lens_in=koemo_in, lens_out=koemo_out)
+    else:
+        batch = synthetic_batch(B_PER_GPU, T_IN, T_OUT, 1234 + rank)
     batch = tuple(t.pin_memory() for t in batch)
 
     def sync():
@@ -199,6 +206,8 @@ def main():
 
     ms_per_step = 1000.0 * elapsed / args.steps
     frames = B_PER_GPU * T_OUT * world
+    if args.koemo and not args.bf16:
+        frames = sum(koemo_out) * world          # valid (unpadded) frames, like the metric's definition
     value = frames / (elapsed / args.steps)
 
     out = {
@@ -210,7 +219,10 @@ def main():
         "config": {"workload": ("configs[4]: bf16_run train step (bf16 MFMA wide Conv1d fwd/dx + time-batched linears "
                                 "+ LSTM dW GEMMs; fp32 master/BN/recurrence), B=16/GPU fixed shape T_in=84 T_out=400, "
                                 "dropout on, random-init seed 1234") if args.bf16 else
-                               ("configs[1]: Tacotron2-VAE fp32 train step (fwd+loss+bwd+clip+Adam), "
+                               ("configs[1], koemo length profile: fp32 train step, B=6/GPU ragged (T_in,T_out) = (84,400),"
+                                "(80,380),(71,350),(66,300),(50,260),(37,200), valid frames counted, dropout on"
+                                if args.koemo else
+                                "configs[1]: Tacotron2-VAE fp32 train step (fwd+loss+bwd+clip+Adam), "
                                 "B=6/GPU fixed shape T_in=84 T_out=400, dropout on, random-init seed 1234"),
                    "global_batch": B_PER_GPU * world, "frames_per_step": frames,
                    "parallelism": "dp%d" % world},
