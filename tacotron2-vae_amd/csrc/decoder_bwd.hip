@@ -54,6 +54,50 @@ __global__ __launch_bounds__(1024) void k_lstm_bwd(LstmBwdArgs a) {
     }
 }
 
+// Four-wave version of k_lstm_bwd (same finding as for the forward stream: ~64 KB in flight per CU beats 16 waves
+// with everything in flight): wave v walks k-blocks [64v, 64v+64) of its tile in 8 rounds of 8 (W, k) float4
+// pairs, two rounds in flight, alternating direction per launch.
+__global__ __launch_bounds__(256) void k_lstm_bwd256(LstmBwdArgs a) {
+    const int w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = lane & 15, g = lane >> 4;
+    const bool dec = w < T2V_XW / 16;
+    const int wt = dec ? w : w - T2V_XW / 16;
+    const float* kv = dec ? a.dgd_t : a.dga_n;
+    if (!kv) return;   // block-uniform
+    const bool bvalid = b < a.B;
+    __shared__ f32x4 red[4][64];
+    const int ntile = dec ? T2V_XW / 16 : T2V_KATT / 16;
+    const float4* p = (dec ? a.packBD : a.packBA) + (size_t)wt * 64 + lane;   // + kb * ntile * 64
+    const float* xrow = kv + (size_t)(bvalid ? b : 0) * T2V_G + 4 * g;        // lanes b>=B read row 0 (unused D columns)
+    const int kb0 = 64 * wave, flip = a.flip;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float4 wv[2][8], xv[2][8];
+#define B256_LOAD(H)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                           \
+        const int kb = flip ? kb0 + 63 - (8 * (H) + i) : kb0 + 8 * (H) + i;                   \
+        wv[(H) & 1][i] = p[(size_t)kb * ntile * 64];                                          \
+        xv[(H) & 1][i] = *(const float4*)(xrow + 16 * kb);                                    \
+    }
+    B256_LOAD(0)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        if (h + 1 < 8) { B256_LOAD(h + 1) }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { MFMA4(acc, wv[h & 1][i], xv[h & 1][i]); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef B256_LOAD
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && bvalid) {
+        const f32x4 s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        float* y = dec ? a.YD + (size_t)b * T2V_XW : a.YA + (size_t)b * T2V_KATT;
+        *(float4*)(y + 16 * wt + 4 * g) = make_float4(s[0], s[1], s[2], s[3]);
+    }
+}
+
 // attention(t) backward, split over encoder positions: grid = (B, S), 256 threads; workgroup (b, s) owns
 // positions [s*JS, s*JS + JS), JS = 16 or 32.  The softmax backward needs dot = sum_j alpha_j dalpha_j over ALL
 // positions; since dalpha_j = dctx·memory_j + G_j and sum_j alpha_j memory_j = ctx_t (saved), every
@@ -419,7 +463,7 @@ extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_tra
             l.YA = g->YA;
             l.B = B;
             l.flip = t & 1;
-            k_lstm_bwd<<<T2V_NWG, 1024, 0, stream>>>(l);
+            k_lstm_bwd256<<<T2V_NWG, 256, 0, stream>>>(l);
 
             AttnBwdArgs f;
             f.dHC_t = g->dHC + (size_t)t * B * HC;

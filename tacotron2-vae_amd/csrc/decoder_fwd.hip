@@ -221,6 +221,119 @@ extern "C" int t2v_overlap_enabled(void) {
     return v;
 }
 
+// Training-step version of k_lstm_fwd<0> with FOUR waves per workgroup (tools/ubench_gemv_tiles.hip: for this 67 MB
+// stream about 64 KB in flight per CU is the sweet spot — 16 waves that each put 26 KB in flight queue too much).
+// Workgroup w = gate-row tile w of BOTH cells; wave v walks attention_rnn k-blocks [24v, 24v+24) then decoder_rnn
+// k-blocks [40v, 40v+40): 8 rounds of 8 (W, x) float4 pairs, two rounds in flight; odd steps walk the same
+// sequence backwards (the tail of the previous launch's stream is requested first).  Epilogue as k_lstm_fwd.
+template <bool FLIP>
+__device__ __forceinline__ void lstm256_stream(const float4* pa, const float4* pd, const float* xrow, int wave,
+                                               f32x4& accA, f32x4& accD) {
+    float4 wv[2][8], xv[2][8];
+    // round r of the walk: FLIP ? 7 - r : r;  rounds 0..2 = attention_rnn, 3..7 = decoder_rnn
+#define L256_LOAD(R)                                                                              \
+    {                                                                                             \
+        constexpr int RR = FLIP ? 7 - (R) : (R);                                                  \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                           \
+            const int ii = FLIP ? 7 - i : i;                                                      \
+            const int kb = RR < 3 ? 24 * wave + 8 * RR + ii : 40 * wave + 8 * (RR - 3) + ii;      \
+            wv[(R) & 1][i] = (RR < 3 ? pa : pd)[(size_t)kb * 64];                                 \
+            xv[(R) & 1][i] = *(const float4*)(xrow + 16 * kb);                                    \
+        }                                                                                         \
+    }
+#define L256_MATH(R)                                                                              \
+    {                                                                                             \
+        constexpr int RR = FLIP ? 7 - (R) : (R);                                                  \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                           \
+            if (RR < 3) { MFMA4(accA, wv[(R) & 1][i], xv[(R) & 1][i]); }                          \
+            else { MFMA4(accD, wv[(R) & 1][i], xv[(R) & 1][i]); }                                 \
+        }                                                                                         \
+    }
+#define L256_STEP(R, NEXT)                      \
+    NEXT                                        \
+    __builtin_amdgcn_sched_barrier(0);          \
+    L256_MATH(R)                                \
+    __builtin_amdgcn_sched_barrier(0);
+    L256_LOAD(0)
+    __builtin_amdgcn_sched_barrier(0);
+    L256_STEP(0, L256_LOAD(1))
+    L256_STEP(1, L256_LOAD(2))
+    L256_STEP(2, L256_LOAD(3))
+    L256_STEP(3, L256_LOAD(4))
+    L256_STEP(4, L256_LOAD(5))
+    L256_STEP(5, L256_LOAD(6))
+    L256_STEP(6, L256_LOAD(7))
+    L256_STEP(7, )
+#undef L256_STEP
+#undef L256_MATH
+#undef L256_LOAD
+}
+
+__global__ __launch_bounds__(256) void k_lstm_fwd256(LstmFwdArgs a) {
+    const int w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = lane & 15, g = lane >> 4;
+    const bool bvalid = b < a.B;
+    __shared__ f32x4 red[2][4][64];
+    __shared__ float hs[16][4];
+    const float4* pa = a.packA + ((size_t)w * (T2V_KATT / 16)) * 64 + lane;
+    const float4* pd = a.packD + ((size_t)w * (T2V_XW / 16)) * 64 + lane;
+    const float* xrow = a.xs_prev + (size_t)(bvalid ? b : 0) * T2V_XW + 4 * g;   // lanes b>=B read row 0 (unused D columns)
+    // tail operands first: waves 0/1 own the cell update of attention_rnn(t) / decoder_rnn(t-1) for (unit g, item b)
+    const int which = wave;
+    const bool cell_on = wave < 2 && bvalid && (which == 0 ? a.do_att : a.do_dec);
+    const int U = 4 * w + g;
+    float addv[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+    if (cell_on) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            addv[r] = which == 0 ? a.gpre_t[(size_t)b * T2V_G + r * T2V_H + U] : a.bias_dec[r * T2V_H + U];
+        cprev = (which == 0 ? a.ca_prev : a.cd_prev)[(size_t)b * T2V_H + U];
+    }
+    float wqr[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.do_att) {
+        const float* wq = a.wqT + (size_t)(4 * w) * T2V_A + (tid & (T2V_A - 1));
+        wqr[0] = wq[0]; wqr[1] = wq[T2V_A]; wqr[2] = wq[2 * T2V_A]; wqr[3] = wq[3 * T2V_A];
+    }
+    f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accD = {0.f, 0.f, 0.f, 0.f};
+    if (a.t & 1) lstm256_stream<true>(pa, pd, xrow, wave, accA, accD);
+    else lstm256_stream<false>(pa, pd, xrow, wave, accA, accD);
+    red[0][wave][lane] = accA;
+    red[1][wave][lane] = accD;
+    __syncthreads();
+    if (cell_on) {
+        const f32x4 s = (red[which][0][lane] + red[which][1][lane]) + (red[which][2][lane] + red[which][3][lane]);
+        const int tt = which == 0 ? a.t : a.t - 1;
+        const float p = which == 0 ? a.p_att : a.p_dec;
+        const uint32_t st_h = which == 0 ? T2V_RNG_ATT_H : T2V_RNG_DEC_H;
+        const uint32_t st_c = which == 0 ? T2V_RNG_ATT_C : T2V_RNG_DEC_C;
+        const float gi = sigmoidf_(s[0] + addv[0]), gf = sigmoidf_(s[1] + addv[1]);
+        const float gg = tanhf_(s[2] + addv[2]), go = sigmoidf_(s[3] + addv[3]);
+        const uint32_t idx = (uint32_t)b * T2V_H + U;
+        if (tt > 0) cprev *= t2v_drop_scale(a.seed, st_c, tt - 1, idx, p);
+        const float c = gf * cprev + gi * gg;
+        const float h = go * tanhf_(c);
+        (which == 0 ? a.ca_cur : a.cd_cur)[(size_t)b * T2V_H + U] = c;
+        float* gsave = which == 0 ? a.ga_t : a.gd_t;
+        if (gsave) {
+            gsave[(size_t)b * T2V_G + 0 * T2V_H + U] = gi;
+            gsave[(size_t)b * T2V_G + 1 * T2V_H + U] = gf;
+            gsave[(size_t)b * T2V_G + 2 * T2V_H + U] = gg;
+            gsave[(size_t)b * T2V_G + 3 * T2V_H + U] = go;
+        }
+        const float hd = h * t2v_drop_scale(a.seed, st_h, tt, idx, p);
+        a.xs_next[(size_t)b * T2V_XW + (which == 0 ? U : T2V_KATT + U)] = hd;
+        if (which == 0) hs[b][g] = hd;
+    }
+    __syncthreads();
+    if (a.do_att) {   // partial processed query of this workgroup's 4 hidden units
+        const int d = tid & (T2V_A - 1);
+        for (int bb = tid >> 7; bb < a.B; bb += 2) {
+            const float q = wqr[0] * hs[bb][0] + wqr[1] * hs[bb][1] + wqr[2] * hs[bb][2] + wqr[3] * hs[bb][3];
+            a.qp[((size_t)bb * T2V_NWG + w) * T2V_A + d] = q;
+        }
+    }
+}
+
 static void fill_lstm_args(LstmFwdArgs& a, const t2v_dec_weights* w, const t2v_dec_train_bufs* s, int B, int T_out,
                            int t, float p_att, float p_dec, uint64_t seed) {
     a.packA = (const float4*)w->packF_att;
@@ -281,7 +394,7 @@ static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
                 k_lstm_fwd<2><<<T2V_NWG, 1024, 0, sb>>>(ad);
             }
         } else {
-            if (mask & 1) k_lstm_fwd<0><<<T2V_NWG, 1024, 0, stream>>>(a);
+            if (mask & 1) k_lstm_fwd256<<<T2V_NWG, 256, 0, stream>>>(a);
             LstmFwdArgs aa = a, ad = a;
             aa.do_dec = 0;
             ad.do_att = 0;
