@@ -24,8 +24,7 @@ __global__ __launch_bounds__(1024) void k_lstm_bwd(LstmBwdArgs a) {
     if (!kv) return;   // block-uniform
     const bool bvalid = b < a.B;
     __shared__ f32x4 red[LSTM_WAVES][64];
-    const int ntile = dec ? T2V_XW / 16 : T2V_KATT / 16;
-    const float4* p = (dec ? a.packBD : a.packBA) + (size_t)wt * 64 + lane;   // + kb * ntile * 64
+    const float4* p = (dec ? a.packBD : a.packBA) + (size_t)wt * 256 * 64 + lane;   // tile-major: + kb * 64
     const float* xrow = kv + (size_t)(bvalid ? b : 0) * T2V_G + 4 * g;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int kb0 = 16 * wave;     // 256 k-blocks / 16 waves
@@ -37,7 +36,7 @@ __global__ __launch_bounds__(1024) void k_lstm_bwd(LstmBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int kb = a.flip ? kb0 + 15 - (8 * h + i) : kb0 + 8 * h + i;
-            wv[i] = p[(size_t)kb * ntile * 64];
+            wv[i] = p[(size_t)kb * 64];
             xv[i] = *(const float4*)(xrow + 16 * kb);   // lanes b>=B read row 0 (unused D columns)
         }
 #pragma unroll
@@ -66,8 +65,7 @@ __global__ __launch_bounds__(256) void k_lstm_bwd256(LstmBwdArgs a) {
     if (!kv) return;   // block-uniform
     const bool bvalid = b < a.B;
     __shared__ f32x4 red[4][64];
-    const int ntile = dec ? T2V_XW / 16 : T2V_KATT / 16;
-    const float4* p = (dec ? a.packBD : a.packBA) + (size_t)wt * 64 + lane;   // + kb * ntile * 64
+    const float4* p = (dec ? a.packBD : a.packBA) + (size_t)wt * 256 * 64 + lane;   // tile-major: + kb * 64
     const float* xrow = kv + (size_t)(bvalid ? b : 0) * T2V_G + 4 * g;        // lanes b>=B read row 0 (unused D columns)
     const int kb0 = 64 * wave, flip = a.flip;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -75,7 +73,7 @@ __global__ __launch_bounds__(256) void k_lstm_bwd256(LstmBwdArgs a) {
 #define B256_LOAD(H)                                                                          \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                           \
         const int kb = flip ? kb0 + 63 - (8 * (H) + i) : kb0 + 8 * (H) + i;                   \
-        wv[(H) & 1][i] = p[(size_t)kb * ntile * 64];                                          \
+        wv[(H) & 1][i] = p[(size_t)kb * 64];                                                  \
         xv[(H) & 1][i] = *(const float4*)(xrow + 16 * kb);                                    \
     }
     B256_LOAD(0)

@@ -26,16 +26,16 @@ __global__ void k_pack_fwd(const float* __restrict__ W, int K, float4* __restric
     P[idx] = make_float4(src[0], src[1], src[2], src[3]);
 }
 // Backward (transposed) tile n-tile w' of W^T (N = K columns of W become rows), reduction dim
-// = 4096 gate rows:  PB[kb][w'][lane][i] = W[16kb + 4(lane>>4) + i][16w' + (lane&15)]
+// = 4096 gate rows, tile-major like the forward pack (a workgroup's 256 KB are contiguous):
+//   PB[w'][kb][lane][i] = W[16kb + 4(lane>>4) + i][16w' + (lane&15)]
 __global__ void k_pack_bwd(const float* __restrict__ W, int K, int ncols, float4* __restrict__ P) {
     const int nkb = T2V_G / 16;   // 256
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)(ncols / 16) * nkb * 64;
     if (idx >= total) return;
     const int lane = idx & 63;
-    const int ntile = ncols / 16;
-    const int wt = (idx >> 6) % ntile;
-    const int kb = (idx >> 6) / ntile;
+    const int kb = (idx >> 6) % nkb;
+    const int wt = (idx >> 6) / nkb;
     const int n = 16 * wt + (lane & 15);
     const int k0 = 16 * kb + 4 * (lane >> 4);
     P[idx] = make_float4(W[(size_t)(k0 + 0) * K + n], W[(size_t)(k0 + 1) * K + n],

@@ -118,7 +118,14 @@ int main() {
             l.B = B; l.flip = i & 1;
             k_lstm_bwd<<<T2V_NWG, 1024>>>(l);
         }, reps);
-        printf("%-44s %7.2f us  %6.2f TB/s\n", "k_lstm_bwd (production, 1024 thr)", us, mb / us);
+        float us2 = timeit([&](int i) {
+            LstmBwdArgs l;
+            l.packBD = pD; l.packBA = pA; l.dgd_t = kvd; l.dga_n = kva; l.YD = out; l.YA = out + 16 * T2V_XW;
+            l.B = B; l.flip = i & 1;
+            k_lstm_bwd256<<<T2V_NWG, 256>>>(l);
+        }, reps);
+        printf("%-44s %7.2f us  %6.2f TB/s\n", "k_lstm_bwd256 (production)", us2, mb / us2);
+        printf("%-44s %7.2f us  %6.2f TB/s\n", "k_lstm_bwd (1024 thr, round-1 first half)", us, mb / us);
     }
     CK(hipDeviceSynchronize());
     return 0;
