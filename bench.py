@@ -11,7 +11,7 @@ frames (SURVEY.md §8(d) cfg-2 "train-fixed"), fp32, dropout on, synthetic data,
 weights from seed 1234.  Multi-GPU is weak scaling (6 utterances per rank).
 
 The single JSON line also carries:
-  roofline     — the dominant kernel (k_lstm_fwd: both decoder LSTM gate GEMVs, weights streamed
+  roofline     — the dominant kernel (k_lstm_fwd256: both decoder LSTM gate GEMVs, weights streamed
                  every time step).  Algorithmic bytes per launch = fp32 weights of the two cells
                  (4096×1536 + 4096×2560)×4 B = 67.1 MB; duration = events on the launch stream
                  around a replay of exactly that kernel's T+1 launches.
@@ -230,7 +230,7 @@ def main():
     }
 
     if rank == 0:
-        # ---- roofline leg: replay only k_lstm_fwd's T+1 launches of the last forward, events on
+        # ---- roofline leg: replay only k_lstm_fwd256's T+1 launches of the last forward, events on
         # the launch stream (torch's current stream is the stream the library launches on).
         reps = 3
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -247,10 +247,10 @@ def main():
         traffic = None      # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, corrected)
         try:
             with open(os.path.join(ROOT, 'profiles', 'r01_pmc_fetch_size.json')) as f:
-                traffic = json.load(f)["kernels"]["k_lstm_fwd"]["corrected_bytes_per_launch"]
+                traffic = json.load(f)["kernels"]["k_lstm_fwd256"]["corrected_bytes_per_launch"]
         except Exception:
             pass
-        out["roofline"] = {"kernel": "k_lstm_fwd", "bound": "hbm", "achieved": round(achieved, 1),
+        out["roofline"] = {"kernel": "k_lstm_fwd256", "bound": "hbm", "achieved": round(achieved, 1),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "avg_launch_us": round(us, 3),
                            "algorithmic_bytes_per_launch": LSTM_WEIGHT_BYTES, "launches_timed": n}
