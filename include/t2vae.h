@@ -89,7 +89,7 @@ int t2v_decoder_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
 int t2v_overlap_enabled(void);
 
 /* Measurement aid for bench.py: re-issues only the selected kernels of a finished forward pass on
- * its saved arena (bit0 = fused k_lstm_fwd<0>, bit1 = k_attn_fwd, bit2 = k_lstm_fwd<2> decoder_rnn-only,
+ * its saved arena (bit0 = fused k_lstm_fwd256 (both cells), bit1 = k_attn_fwd, bit2 = k_lstm_fwd<2> decoder_rnn-only,
  * bit3 = k_lstm_fwd<3> attention_rnn-only — the two kernels of the overlapped schedule),
  * so their average launch duration can be bracketed with events on `stream`.  Results are
  * bit-identical to the first pass (the kernels are pure functions of the arena). */
