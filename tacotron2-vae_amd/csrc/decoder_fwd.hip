@@ -334,6 +334,84 @@ __global__ __launch_bounds__(256) void k_lstm_fwd256(LstmFwdArgs a) {
     }
 }
 
+// Single-cell four-wave kernels for the free-running decode loop (decoder_infer.hip), same stream shape as
+// k_lstm_fwd256.  ATT = true : attention_rnn(t) with the prenet columns inside K (112 k-blocks: 28 per wave, 4
+// rounds of 7); ATT = false: decoder_rnn (160 k-blocks: 40 per wave, 5 rounds of 8).
+template <bool ATT>
+__global__ __launch_bounds__(256) void k_lstm_one256(LstmFwdArgs a) {
+    constexpr int RN = ATT ? 7 : 8, NR = ATT ? 4 : 5, KBW = RN * NR;
+    const int w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = lane & 15, g = lane >> 4;
+    const bool bvalid = b < a.B;
+    __shared__ f32x4 red[4][64];
+    __shared__ float hs[16][4];
+    const float4* pw = ATT ? a.packA + ((size_t)w * (T2V_KATT_INF / 16)) * 64 + lane
+                           : a.packD + ((size_t)w * (T2V_XW / 16)) * 64 + lane;
+    const float* xrow = a.xs_prev + (size_t)(bvalid ? b : 0) * T2V_XW + 4 * g;
+    const float* prow = ATT ? a.pre_t + (size_t)(bvalid ? b : 0) * T2V_PRE + 4 * g : nullptr;
+    const bool cell_on = wave == 0 && bvalid;
+    const int U = 4 * w + g;
+    float addv[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+    if (cell_on) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) addv[r] = (ATT ? a.bias_att : a.bias_dec)[r * T2V_H + U];
+        cprev = (ATT ? a.ca_prev : a.cd_prev)[(size_t)b * T2V_H + U];
+    }
+    float wqr[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ATT) {
+        const float* wq = a.wqT + (size_t)(4 * w) * T2V_A + (tid & (T2V_A - 1));
+        wqr[0] = wq[0]; wqr[1] = wq[T2V_A]; wqr[2] = wq[2 * T2V_A]; wqr[3] = wq[3 * T2V_A];
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int kb0 = KBW * wave;
+    const bool flip = a.t & 1;
+    float4 wv[2][RN], xv[2][RN];
+#define ONE_LOAD(H)                                                                               \
+    _Pragma("unroll") for (int i = 0; i < RN; ++i) {                                              \
+        const int kk = RN * (H) + i;                                                              \
+        const int kb = kb0 + (flip ? KBW - 1 - kk : kk);                                          \
+        wv[(H) & 1][i] = pw[(size_t)kb * 64];                                                     \
+        const float* src = (ATT && kb >= T2V_KATT / 16) ? prow + 16 * (kb - T2V_KATT / 16) : xrow + 16 * kb; \
+        xv[(H) & 1][i] = *(const float4*)src;                                                     \
+    }
+    ONE_LOAD(0)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < NR; ++h) {
+        if (h + 1 < NR) { ONE_LOAD(h + 1) }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < RN; ++i) { MFMA4(acc, wv[h & 1][i], xv[h & 1][i]); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef ONE_LOAD
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (cell_on) {
+        const f32x4 s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        const int tt = ATT ? a.t : a.t - 1;
+        const float p = ATT ? a.p_att : a.p_dec;
+        const float gi = sigmoidf_(s[0] + addv[0]), gf = sigmoidf_(s[1] + addv[1]);
+        const float gg = tanhf_(s[2] + addv[2]), go = sigmoidf_(s[3] + addv[3]);
+        const uint32_t idx = (uint32_t)b * T2V_H + U;
+        if (tt > 0) cprev *= t2v_drop_scale(a.seed, ATT ? T2V_RNG_ATT_C : T2V_RNG_DEC_C, tt - 1, idx, p);
+        const float c = gf * cprev + gi * gg;
+        const float h = go * tanhf_(c);
+        (ATT ? a.ca_cur : a.cd_cur)[(size_t)b * T2V_H + U] = c;
+        const float hd = h * t2v_drop_scale(a.seed, ATT ? T2V_RNG_ATT_H : T2V_RNG_DEC_H, tt, idx, p);
+        a.xs_next[(size_t)b * T2V_XW + (ATT ? U : T2V_KATT + U)] = hd;
+        if (ATT) hs[b][g] = hd;
+    }
+    if (ATT) {
+        __syncthreads();
+        const int d = tid & (T2V_A - 1);
+        for (int bb = tid >> 7; bb < a.B; bb += 2) {
+            const float q = wqr[0] * hs[bb][0] + wqr[1] * hs[bb][1] + wqr[2] * hs[bb][2] + wqr[3] * hs[bb][3];
+            a.qp[((size_t)bb * T2V_NWG + w) * T2V_A + d] = q;
+        }
+    }
+}
+
 static void fill_lstm_args(LstmFwdArgs& a, const t2v_dec_weights* w, const t2v_dec_train_bufs* s, int B, int T_out,
                            int t, float p_att, float p_dec, uint64_t seed) {
     a.packA = (const float4*)w->packF_att;
@@ -446,7 +524,7 @@ extern "C" int t2v_decoder_replay_fwd_kernels(const t2v_dec_weights* w, const t2
 
 void t2v_launch_lstm_fwd(int mode, const LstmFwdArgs& a, hipStream_t stream) {
     if (mode == 3) k_lstm_fwd<3><<<T2V_NWG, 1024, 0, stream>>>(a);
-    else if (mode == 1) k_lstm_fwd<1><<<T2V_NWG, 1024, 0, stream>>>(a);
-    else if (mode == 2) k_lstm_fwd<2><<<T2V_NWG, 1024, 0, stream>>>(a);
+    else if (mode == 1) k_lstm_one256<true><<<T2V_NWG, 256, 0, stream>>>(a);      // decode: attention_rnn + prenet columns
+    else if (mode == 2) k_lstm_one256<false><<<T2V_NWG, 256, 0, stream>>>(a);     // decode: decoder_rnn
     else k_lstm_fwd<0><<<T2V_NWG, 1024, 0, stream>>>(a);
 }
