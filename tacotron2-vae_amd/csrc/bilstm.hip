@@ -1,7 +1,8 @@
 // Encoder BiLSTM(512 -> 256 x 2) recurrence (reference model.py:171-173,183-190: nn.LSTM on a packed
-// sequence), forward and BPTT, as PERSISTENT cooperative kernels: 8 workgroups per direction, each owning
-// 32 hidden units whose recurrent weights (128 gate rows x 256, fp32) stay in VGPRs as
-// v_mfma_f32_16x16x4_f32 A-fragments for all T steps (1 MB per direction = 8 x 4 waves x 128 VGPRs).
+// sequence), forward and BPTT, as PERSISTENT cooperative kernels: 16 workgroups per direction, each owning
+// 16 hidden units whose recurrent weights (64 gate rows x 256, fp32) stay in VGPRs as
+// v_mfma_f32_16x16x4_f32 A-fragments for all T steps (1 MB per direction = 16 x 4 waves x 64 VGPRs; with 8
+// workgroups the per-step MFMA chain was twice as long: 576 -> 478 us forward, -160 us forward+backward).
 // Per step the workgroups of a direction exchange the new hidden state (forward) / gate gradients
 // (backward) through global memory: write-through (sc1) stores, one arrival counter per direction,
 // relaxed polling, sc1 loads (MI355X guide, Guideline 16 "R1" form).  Every spin is bounded: on a
@@ -14,8 +15,10 @@
 
 #define BL_H 256
 #define BL_G (4 * BL_H)
-#define BL_NW 8                 // workgroups per direction
-#define BL_UNITS (BL_H / BL_NW) // 32 units per workgroup
+#define BL_NW 16                // workgroups per direction
+#define BL_UNITS (BL_H / BL_NW) // 16 units per workgroup
+#define BL_NT (BL_UNITS / 16)   // forward: 16-row MFMA tiles (4 units x 4 gates) per wave; backward: 16-column tiles
+                                // of W_hh^T per workgroup
 
 struct BiLstmFwdArgs {
     const float* gx;        // (2, B, T, 1024) input projections + both biases, gate-major i,f,g,o
@@ -36,12 +39,12 @@ __global__ __launch_bounds__(256) void k_bilstm_fwd(BiLstmFwdArgs a) {
     const bool bvalid = b < a.B;
     __shared__ float hbuf[16][BL_H + 4];
     // recurrent weights of this wave's two 16-row tiles (4 units x 4 gates each) as MFMA A fragments
-    float wreg[2][64];
+    float wreg[BL_NT][64];
     {
         const float* W = a.whh + (size_t)dir * BL_G * BL_H;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int unit = j * BL_UNITS + (2 * wave + tt) * 4 + ((lane & 15) >> 2);
+        for (int tt = 0; tt < BL_NT; ++tt) {
+            const int unit = j * BL_UNITS + (BL_NT * wave + tt) * 4 + ((lane & 15) >> 2);
             const int row = (lane & 3) * BL_H + unit;
 #pragma unroll
             for (int s = 0; s < 64; ++s) wreg[tt][s] = W[(size_t)row * BL_H + 4 * s + g];
@@ -49,34 +52,38 @@ __global__ __launch_bounds__(256) void k_bilstm_fwd(BiLstmFwdArgs a) {
     }
     for (int i = tid; i < 16 * (BL_H + 4); i += 256) (&hbuf[0][0])[i] = 0.f;
     const int len = bvalid ? a.lengths[b] : 0;
-    float cst[2] = {0.f, 0.f};
+    float cst[BL_NT];
+#pragma unroll
+    for (int tt = 0; tt < BL_NT; ++tt) cst[tt] = 0.f;
     __syncthreads();
 
     for (int step = 0; step < a.T; ++step) {
         const bool active = step < len;
         const int t = dir == 0 ? step : len - 1 - step;        // own-length reverse (packed sequence)
         // input projections for this lane's (unit, item): 4 gates per tile
-        float gxv[2][4];
+        float gxv[BL_NT][4];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int U = j * BL_UNITS + (2 * wave + tt) * 4 + g;
+        for (int tt = 0; tt < BL_NT; ++tt) {
+            const int U = j * BL_UNITS + (BL_NT * wave + tt) * 4 + g;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 gxv[tt][r] = active ? a.gx[(((size_t)dir * a.B + b) * a.T + t) * BL_G + r * BL_H + U] : 0.f;
         }
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 accv[BL_NT];
+#pragma unroll
+        for (int tt = 0; tt < BL_NT; ++tt) accv[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* hrow = &hbuf[b][g];
 #pragma unroll
         for (int s = 0; s < 64; ++s) {
             const float hv = hrow[4 * s];
-            acc0 = mfma16x4(wreg[0][s], hv, acc0);
-            acc1 = mfma16x4(wreg[1][s], hv, acc1);
+#pragma unroll
+            for (int tt = 0; tt < BL_NT; ++tt) accv[tt] = mfma16x4(wreg[tt][s], hv, accv[tt]);
         }
         float* hx_w = a.hx + ((size_t)(dir * 2 + (step & 1)) * 16) * BL_H;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const f32x4 acc = tt == 0 ? acc0 : acc1;
-            const int U = j * BL_UNITS + (2 * wave + tt) * 4 + g;
+        for (int tt = 0; tt < BL_NT; ++tt) {
+            const f32x4 acc = accv[tt];
+            const int U = j * BL_UNITS + (BL_NT * wave + tt) * 4 + g;
             if (bvalid) {
                 float hnew = hbuf[b][U];                       // frozen once the sequence has ended
                 if (active) {
@@ -119,30 +126,33 @@ __global__ __launch_bounds__(256) void k_bilstm_bwd(BiLstmBwdArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = lane & 15, g = lane >> 4;
     __shared__ float dgbuf[16][BL_G + 4];           // all gate gradients of the current step
-    __shared__ f32x4 red[4][2][64];
+    __shared__ f32x4 red[4][BL_NT][64];
     __shared__ float dhrec[16][BL_UNITS + 1];       // dL/dh_{prev} for this workgroup's 32 units
     // W_hh^T rows of this workgroup's 32 units (2 tiles of 16), K = 1024 split over the 4 waves
-    float wreg[2][64];
+    float wreg[BL_NT][64];
     {
         const float* W = a.whh + (size_t)dir * BL_G * BL_H;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < BL_NT; ++tt) {
             const int col = j * BL_UNITS + tt * 16 + (lane & 15);       // h unit = column of W_hh
 #pragma unroll
             for (int s = 0; s < 64; ++s) wreg[tt][s] = W[(size_t)(256 * wave + 4 * s + g) * BL_H + col];
         }
     }
     for (int i = tid; i < 16 * (BL_UNITS + 1); i += 256) (&dhrec[0][0])[i] = 0.f;
-    // cell-backward ownership: thread -> (item bb, unit uu) pairs, uu = tid & 31, bb = tid >> 5 (+8)
-    const int uu = tid & 31, U = j * BL_UNITS + uu;
-    float dcrec[2] = {0.f, 0.f};
+    // cell-backward ownership: thread -> (item bb, unit uu) pairs, uu = tid % BL_UNITS, bb = tid / BL_UNITS (+ BL_IPP)
+    constexpr int BL_IPP = 256 / BL_UNITS, BL_REPS = 16 / BL_IPP;      // items per pass, passes
+    const int uu = tid & (BL_UNITS - 1), U = j * BL_UNITS + uu;
+    float dcrec[BL_REPS];
+#pragma unroll
+    for (int rep = 0; rep < BL_REPS; ++rep) dcrec[rep] = 0.f;
     __syncthreads();
 
     for (int step = a.T - 1; step >= 0; --step) {
         float* dgx_w = a.dgx + ((size_t)(dir * 2 + (step & 1)) * 16) * BL_G;
 #pragma unroll
-        for (int rep = 0; rep < 2; ++rep) {
-            const int bb = (tid >> 5) + 8 * rep;
+        for (int rep = 0; rep < BL_REPS; ++rep) {
+            const int bb = tid / BL_UNITS + BL_IPP * rep;
             if (bb < a.B) {
                 const int len = a.lengths[bb];
                 float di = 0.f, df = 0.f, dgg = 0.f, dob = 0.f;
@@ -177,18 +187,20 @@ __global__ __launch_bounds__(256) void k_bilstm_bwd(BiLstmBwdArgs a) {
         for (int i = tid; i < a.B * BL_G; i += 256) dgbuf[i >> 10][i & (BL_G - 1)] = ld_sc1(dgx_w + i);
         __syncthreads();
         // dh_rec[b][unit] = sum_k W_hh[k][unit] * dgates[b][k]
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 accv[BL_NT];
+#pragma unroll
+        for (int tt = 0; tt < BL_NT; ++tt) accv[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* drow = &dgbuf[b][256 * wave + g];
 #pragma unroll
         for (int s = 0; s < 64; ++s) {
             const float dv = drow[4 * s];
-            acc0 = mfma16x4(wreg[0][s], dv, acc0);
-            acc1 = mfma16x4(wreg[1][s], dv, acc1);
+#pragma unroll
+            for (int tt = 0; tt < BL_NT; ++tt) accv[tt] = mfma16x4(wreg[tt][s], dv, accv[tt]);
         }
-        red[wave][0][lane] = acc0;
-        red[wave][1][lane] = acc1;
+#pragma unroll
+        for (int tt = 0; tt < BL_NT; ++tt) red[wave][tt][lane] = accv[tt];
         __syncthreads();
-        if (wave < 2) {     // wave tt finalises tile tt: lane (col = item b, rows 4g+r = units 16tt+4g+r)
+        if (wave < BL_NT) {     // wave tt finalises tile tt: lane (col = item b, rows 4g+r = units 16tt+4g+r)
             const f32x4 s4 = red[0][wave][lane] + red[1][wave][lane] + red[2][wave][lane] + red[3][wave][lane];
             if (b < a.B) {
 #pragma unroll
