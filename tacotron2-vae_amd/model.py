@@ -72,7 +72,7 @@ def _conv_bn_act(block, x, act, training, rng_stream):
     conv, bn = block[0].conv, block[1]
     _block_calls[0] += 1
     if training:
-        bn.num_batches_tracked += 1
+        t2v_hip.note_bn_counter(bn.num_batches_tracked)     # bumped in one launch at the end of the forward
     return t2v_hip.ConvBNAct1d.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                      training, act, drop_rate, 0x5EED, rng_stream, _block_calls[0])
 
@@ -90,6 +90,7 @@ class Postnet(nn.Module):
         last = len(self.convolutions) - 1
         for i, block in enumerate(self.convolutions):
             x = _conv_bn_act(block, x, t2v_hip.ACT_TANH if i < last else t2v_hip.ACT_NONE, self.training, 32 + i)
+        t2v_hip.flush_bn_counters()
         return x
 
 
@@ -103,6 +104,7 @@ class Encoder(nn.Module):
     def _convs(self, x):
         for i, block in enumerate(self.convolutions):
             x = _conv_bn_act(block, x, t2v_hip.ACT_RELU, self.training, 16 + i)
+        t2v_hip.flush_bn_counters()
         return x.transpose(1, 2)
 
     def _bilstm(self, x, lengths):

@@ -38,9 +38,10 @@ class ReferenceEncoder(nn.Module):
         for i, (conv, bn) in enumerate(zip(self.convs, self.bns)):
             c = conv.conv if i == 0 else conv                       # layer 0: the live CoordConv inner conv (B-2)
             if self.training:
-                bn.num_batches_tracked += 1
+                t2v_hip.note_bn_counter(bn.num_batches_tracked)
             out = t2v_hip.Conv2dBNReLU.apply(out, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean,
                                              bn.running_var, self.training, i == 0)
+        t2v_hip.flush_bn_counters()
         out = out.transpose(1, 2)
         out = out.contiguous().view(n, out.size(1), -1)
         g = self.gru

@@ -119,6 +119,20 @@ def load_library():
 # per-step LSTM / attention kernels, loss and Adam stay fp32.
 _BF16 = False
 
+# BatchNorm `num_batches_tracked` counters touched by the current forward pass: bumped together by ONE
+# multi-tensor launch (flush_bn_counters) instead of one tiny kernel per layer (14 per step)
+_BN_PENDING = []
+
+
+def note_bn_counter(t):
+    _BN_PENDING.append(t)
+
+
+def flush_bn_counters():
+    if _BN_PENDING:
+        torch._foreach_add_(_BN_PENDING, 1)
+        del _BN_PENDING[:]
+
 
 def set_bf16(on):
     global _BF16
