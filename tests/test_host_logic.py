@@ -81,6 +81,26 @@ def test_c_abi_exports_every_declared_symbol():
     assert b'gfx950' in lib.t2v_version()
 
 
+def test_ctypes_bindings_match_header_arity():
+    """Every prototype in include/t2vae.h takes as many parameters as the ctypes binding passes (ABI drift guard:
+    ctypes would silently push a wrong argument list)."""
+    import t2v_hip
+    with open(os.path.join(ROOT, 'include', 't2vae.h')) as f:
+        src = re.sub(r'/\*.*?\*/', '', f.read(), flags=re.S)
+    protos = dict(re.findall(r'\b(t2v_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S))
+    lib = t2v_hip.load_library()
+    checked = 0
+    for name, params in protos.items():
+        fn = getattr(lib, name)
+        if fn.argtypes is None:
+            continue
+        params = params.strip()
+        n = 0 if params in ('', 'void') else params.count(',') + 1
+        assert n == len(fn.argtypes), (name, n, len(fn.argtypes))
+        checked += 1
+    assert checked >= 20
+
+
 def test_product_path_has_no_cpu_fallback():
     import hparams as HP
     import model as M
