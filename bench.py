@@ -155,8 +155,21 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # self-launch (replaces the reference's multiproc.py:1-23): one process per GPU under torch.distributed.run,
+        # rendezvous on 127.0.0.1 (the container hostname may not resolve)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank)
@@ -165,6 +178,7 @@ def main():
     import t2v_hip
     import train as TR
     t2v_hip.load_library()
+    t2v_hip.DecoderCore.keep_last = True       # the roofline leg replays the last forward's kernels on its arena
     global B_PER_GPU
     if args.bf16:
         B_PER_GPU = 16

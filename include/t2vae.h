@@ -31,15 +31,22 @@ void t2v_set_phase_profile(unsigned long long* dev_buf32);
 /* ------------------------------------------------------------------ weight packing
  * Re-lays the two decoder LSTM cells' weights into MFMA-fragment order for the per-step
  * weight-streaming kernels.  Replaces nothing in the reference (cuDNN/cuBLAS choose their own
- * layouts); inputs follow nn.LSTMCell (model.py:224-235).
- *   wcat_att : (4096, k_att)  = [weight_hh | weight_ih[:,256:768] (| weight_ih[:,0:256])]
+ * layouts); inputs are the nn.LSTMCell tensors themselves (model.py:224-235), read in place:
+ *   w_ih_att (4096,768) [prenet | ctx], w_hh_att (4096,1024), w_ih_dec (4096,1536) [h_att | ctx], w_hh_dec (4096,1024)
+ *   logical Wcat_att (4096,k_att) = [w_hh_att | w_ih_att[:,256:768] (| w_ih_att[:,0:256])]
  *              k_att = 1536 (training; prenet term hoisted) or 1792 (inference)
- *   wcat_dec : (4096, 2560)   = [weight_ih (h_att|ctx) | weight_hh]
- *   packF_*  : forward tiles,  same element count as the source
- *   packB_*  : transposed tiles for the backward data-gradient GEMV (may be NULL) */
-int t2v_pack_lstm_weights(const float* wcat_att, int k_att, const float* wcat_dec,
-                          float* packF_att, float* packF_dec,
+ *   logical Wcat_dec (4096,2560)  = [w_ih_dec | w_hh_dec]
+ *   packF_*  : forward tiles,  4096*k_att and 4096*2560 floats
+ *   packB_*  : transposed tiles for the backward data-gradient GEMV, 4096*1536 and 4096*2560 floats (may be NULL) */
+int t2v_pack_lstm_weights(const float* w_ih_att, const float* w_hh_att, const float* w_ih_dec,
+                          const float* w_hh_dec, int k_att, float* packF_att, float* packF_dec,
                           float* packB_att, float* packB_dec, void* stream);
+
+/* LocationLayer (model.py:12-28) is a bias-free conv followed by a bias-free linear layer, i.e. ONE linear map of the
+ * 2 x 31 alignment window.  wcomb (128,64): wcomb[d][32c + k] = sum_f loc_dense[d][f] * loc_conv[f][c][k] (k < 31;
+ * columns 31 and 63 are zero).  The attention kernels evaluate the layer (and its backward) through this fused
+ * filter bank; call once per pass after the weights changed. */
+int t2v_fuse_location_weights(const float* loc_conv, const float* loc_dense, float* wcomb, void* stream);
 
 typedef struct t2v_dec_weights {
     const float* packF_att;   /* from t2v_pack_lstm_weights */
@@ -49,8 +56,7 @@ typedef struct t2v_dec_weights {
     const float* bias_att;    /* (4096) bias_ih+bias_hh; used only when gpre == NULL */
     const float* bias_dec;    /* (4096) bias_ih+bias_hh */
     const float* wqT;         /* (1024,128) query_layer weight, transposed (model.py:35) */
-    const float* loc_conv;    /* (32,2,31)  location_conv weight (model.py:17-20) */
-    const float* loc_dense;   /* (128,32)   location_dense weight (model.py:21-22) */
+    const float* wcomb;       /* (128,64)   fused location filter bank (t2v_fuse_location_weights; model.py:17-22) */
     const float* v;           /* (128)      attention v (model.py:39) */
 } t2v_dec_weights;
 
@@ -66,31 +72,27 @@ typedef struct t2v_dec_train_bufs {
     float* CD;    /* (T+1,B,1024) pre-dropout cell of decoder_rnn;   row 0 = 0 */
     float* GA;    /* (T,B,4096) gate activations i,f,g,o of attention_rnn */
     float* GD;    /* (T,B,4096) gate activations of decoder_rnn */
-    float* QP;    /* (B*256*128 + 40960) scratch: per-workgroup partial queries, then the attention kernel's
-                     energy-exchange area and arrival counters */
+    float* QP;    /* (t2v_decoder_qp_floats(B, T_in)) scratch: per-workgroup partial queries, sync / error words, the
+                     decode loop's exchange area, then the attention kernel's energy-exchange granules */
     float* AL;    /* (T+1,B,T_in) AL[t+1] = attention weights of step t; row 0 = 0 */
     float* ACUM;  /* (T+1,B,T_in) cumulative weights; row 0 = 0 */
-    float* S;     /* (T,B,T_in,128) tanh(...) of the energies; overwritten with dpre by bwd */
-    float* CONV;  /* (T,B,32,T_in) location_conv outputs */
+    float* S;     /* (T,B,T_in,128) tanh(...) of the energies; overwritten with dpre by bwd; NULL = forward only */
 } t2v_dec_train_bufs;
+
+/* floats the QP scratch needs for (B, T_in): B*256*128 + 4160 + 2*B*8*ceil16(T_in) */
+long t2v_decoder_qp_floats(int B, int T_in);
 
 /* Decoder.forward's time loop (model.py:415-421 → Decoder.decode 346-389 → Attention.forward
  * 67-88), teacher forced, both LSTM cells + location-sensitive attention.  The 80-mel/gate
  * projection (model.py:385-388) is hoisted out of the loop: it reads [h_dec_t | ctx_t] from XS.
  * Dropout on the LSTM states (model.py:361-364,378-381) uses a counter-based RNG keyed by
- * (seed, stream, t, b, unit); p = 0 disables it. */
+ * (seed, stream, t, b, unit); p = 0 disables it.  B <= 16 per call (callers split larger batches: items are
+ * independent inside the loop); 1 <= T_in <= 4096 (the reference is unbounded; koemo reaches 555 symbols). */
 int t2v_decoder_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
                           int B, int T_in, int T_out, float p_att, float p_dec,
                           uint64_t seed, void* stream);
-/* 1 when the experimental two-stream schedule is active (env T2V_OVERLAP=1; default is the serial schedule):
- * decoder_rnn(t-1) runs on a library-owned side stream underneath attention(t) and is joined back before the
- * call returns.  Measured in round 1: critical path 21.3 vs 23.5 us per step, but event overhead and
- * contention with the attention kernel eat the gain (32.8 vs 31.5 ms/step), so it is off by default. */
-int t2v_overlap_enabled(void);
-
 /* Measurement aid for bench.py: re-issues only the selected kernels of a finished forward pass on
- * its saved arena (bit0 = fused k_lstm_fwd256 (both cells), bit1 = k_attn_fwd, bit2 = k_lstm_fwd<2> decoder_rnn-only,
- * bit3 = k_lstm_fwd<3> attention_rnn-only — the two kernels of the overlapped schedule),
+ * its saved arena (bit0 = k_lstm_fwd256 (both LSTM cells), bit1 = k_attn_fwd),
  * so their average launch duration can be bracketed with events on `stream`.  Results are
  * bit-identical to the first pass (the kernels are pure functions of the arena). */
 int t2v_decoder_replay_fwd_kernels(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
@@ -101,17 +103,21 @@ typedef struct t2v_dec_bwd_bufs {
     const float* dHC;  /* (T,B,1536) grad wrt [h_dec_t | ctx_t] coming from the projection */
     float* DGA;   /* (T,B,4096) out: grad wrt attention_rnn pre-activations (== grad of gpre) */
     float* DGD;   /* (T,B,4096) out: grad wrt decoder_rnn pre-activations */
-    float* DQ;    /* (T,B,8,128) out: per-position-slice partials of the grad wrt the processed query (sum over dim 2) */
+    float* DQ;    /* (T,B,S,128,2) out: per-position-slice partials of the grad wrt the processed query as 8-byte
+                     {value, tag} granules ([...,0] = value; sum over dim 2), S = t2v_attn_bwd_slices(T_in) */
     float* DCTX;  /* (T,B,512)  out: grad wrt attention context */
-    float* DC;    /* (T,B,32,T_in) out: grad wrt location_conv outputs */
     float* YD;    /* (B,2560) scratch, zeroed by the call */
     float* YA;    /* (B,1536) scratch, zeroed by the call */
     float* DCA;   /* (B,1024) scratch */
     float* DCD;   /* (B,1024) scratch */
-    float* GPREV; /* (2,B,8,2,64) scratch: per-slice partial location-conv gradients, parity double-buffered */
-    float* GCUM;  /* (B*8*256 + 64) scratch: per-workgroup copies of the cumulative-weights gradient, then sync words */
-    float* DV;    /* (B,8,128) out: per-item, per-slice grad of attention v (sum over dims 0,1 = dv) */
+    float* GPREV; /* (2,B,S,2,64) scratch: per-slice partial alignment-window gradients, parity double-buffered */
+    float* GCUM;  /* (B*S*ceil16(T_in) + 64) scratch: per-workgroup copies of the cumulative-weights gradient, then
+                     sync words ([1] != 0 afterwards: a bounded spin timed out) */
+    float* DV;    /* (B,S,128) out: per-item, per-slice grad of attention v (sum over dims 0,1 = dv) */
 } t2v_dec_bwd_bufs;
+
+/* position slices per item of the attention backward: ceil(T_in / 16) for T_in <= 128, else ceil(T_in / 32) */
+int t2v_attn_bwd_slices(int T_in);
 
 /* Hand-written BPTT of the loop above (what autograd does for the reference at train.py:225).
  * On return S holds dpre = grad wrt (q + loc + pm) per (t,b,j,d). */
@@ -120,14 +126,15 @@ int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
                           float p_att, float p_dec, uint64_t seed, void* stream);
 
 /* Deferred weight gradients of the location layer (model.py:24-28) reduced over the whole decoder pass in one
- * streaming kernel + a fixed-order partial sum (what autograd accumulates step by step at train.py:225):
- *   d_loc_dense (128,32)  = sum_{t,b,j} dpre[t,b,j,:] (x) conv[t,b,:,j]
- *   d_loc_conv  (32,2,31) = sum_{t,b,j} dc[t,b,:,j] (x) [al[t,b,j+k-15], acum[t,b,j+k-15]]_k
- * dpre = S after t2v_decoder_train_bwd, conv = CONV, dc = DC, al/acum = rows 0..T-1 of AL/ACUM.
+ * streaming kernel + a fixed-order partial sum (what autograd accumulates step by step at train.py:225), through
+ * the fused filter bank:  dW_comb[d][c,k] = sum_{t,b,j} dpre[t,b,j,d] * a_c[t,b,j+k-15], then
+ *   d_loc_dense (128,32)  = dW_comb · loc_conv^T,   d_loc_conv (32,2,31) = loc_dense^T · dW_comb.
+ * dpre = S after t2v_decoder_train_bwd, al/acum = rows 0..T-1 of AL/ACUM (a_0 / a_1).
  * part_scratch: t2v_attn_wgrad_scratch_floats() floats. */
 int t2v_attn_wgrad_scratch_floats(void);
-int t2v_attn_wgrad(const float* dpre, const float* conv, const float* dc, const float* al, const float* acum,
-                   float* part_scratch, float* d_loc_dense, float* d_loc_conv, int B, int T_in, int T, void* stream);
+int t2v_attn_wgrad(const float* dpre, const float* al, const float* acum, const float* loc_conv,
+                   const float* loc_dense, float* part_scratch, float* d_loc_dense, float* d_loc_conv,
+                   int B, int T_in, int T, void* stream);
 
 
 /* ------------------------------------------------------------------ free-running decode
@@ -138,7 +145,7 @@ int t2v_attn_wgrad(const float* dpre, const float* conv, const float* dc, const 
  * them.  external_prenet != 0: PRE[t] is supplied by the caller for every step (the per-step
  * `decoder.prenet(x)` + `decoder.decode(x)` call sequence) and no Prenet is evaluated here.
  * Arena rows as in t2v_dec_train_bufs (XS (Tmax+2,B,2560) rows 0,1 zeroed; CA/CD/AL/ACUM row 0 zeroed);
- * PRE[0] = Prenet(go frame) is written by the caller.  B <= 8. */
+ * PRE[0] = Prenet(go frame) is written by the caller.  B <= 8, T_in <= 4096; QP as in t2v_dec_train_bufs. */
 typedef struct t2v_dec_infer_bufs {
     const float* memory;     /* (B,T_in,512) */
     const float* pm;         /* (B,T_in,128) */

@@ -1,42 +1,70 @@
 // Location-sensitive attention, forward step (reference Attention.forward model.py:67-88 with
 // LocationLayer 12-28), split over the attention dimension: grid = (B, 8), 256 threads; workgroup (b, s) owns
-// attention dims [16s, 16s+16) and context columns [64s, 64s+64), so it pulls only ~50 KB per step through its
+// attention dims [16s, 16s+16) and context columns [64s, 64s+64), so it pulls only ~45 KB per step through its
 // CU (a CU gets ~25-40 GB/s of non-local data; the 128 KB of query partials per item was the bottleneck).
 //   1. q[16s..] = sum of the 256 per-workgroup query partials of this slice (fixed order)
-//   2. location conv for all positions as an MFMA GEMM (K = 2*31 taps padded to 64; redundant per slice)
-//   3. location_dense on MFMA + tanh + v-dot over the slice -> PARTIAL energies of all positions
-//   4. the 8 workgroups of an item exchange partial energies (write-through stores, one arrival counter per
-//      item, bounded spin, sc1 loads); each sums them in a fixed order and does the masked softmax
-//   5. context columns [64s, 64s+64) of ctx = alpha·memory
-// Saved for the backward (training): tanh outputs S, conv outputs, alpha, cumulative alpha.
+//   2. location features + energies in ONE MFMA GEMM per 16-position tile: LocationLayer is conv (no bias, no
+//      activation) followed by a linear layer, i.e. a single linear map of the 2x31 alignment window; the fused
+//      filter bank W_comb[d][c,k] = sum_f dense[d][f] conv[f][c][k] (k_loc_fuse, once per pass) makes
+//      loc[j][d] = sum_{c,k} W_comb[d][c,k] a_c[j+k-15] a K = 64 contraction, then tanh / v-dot over the slice
+//      -> PARTIAL energies of all positions
+//   3. the 8 workgroups of an item exchange partial energies as 8-byte {value, epoch tag} granules (one sc1 store
+//      each, the data is the flag: MI355X guide G16 form R2 — no counter, no fence, no drain); each sums them in a
+//      fixed order and does the masked softmax
+//   4. context columns [64s, 64s+64) of ctx = alpha·memory
+// Any T_in: NJT = 6 / 8 / 16 position tiles cover T_in <= 256 with every operand register-resident; longer
+// inputs (koemo reaches 555 symbols) take the BIG variant, which walks 256-position chunks.
+// Saved for the backward (training): tanh outputs S, alpha, cumulative alpha.
 #include "t2v_common.h"
 #include "t2v_kernels.h"
 
 #define AF_THREADS 256
-#define AF_MAXS 8
+#define AF_NS 8
 #define AF_SPIN_LIMIT 4000000
 
-__device__ __forceinline__ void af_st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float af_ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void af_put(t2v_u64* p, float v, unsigned tag) {
+    __hip_atomic_store(p, ((t2v_u64)tag << 32) | (t2v_u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ t2v_u64 af_get(const t2v_u64* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
-template <int NJT>      // 16-position tiles covering T_in (6 / 8 / 16)
+// W_comb (128, 64): column 32c + k for channel c (0 = previous weights, 1 = cumulative weights), tap k < 31;
+// columns 31 and 63 are zero padding so that K = 64 = 16 MFMA k-steps.
+__global__ void k_loc_fuse(const float* __restrict__ conv, const float* __restrict__ dense, float* __restrict__ wc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // 128 * 64
+    if (i >= T2V_A * 64) return;
+    const int d = i >> 6, n = i & 63, c = n >> 5, k = n & 31;
+    float acc = 0.f;
+    if (k < T2V_KS)
+        for (int f = 0; f < T2V_F; ++f) acc = fmaf(dense[d * T2V_F + f], conv[(f * 2 + c) * T2V_KS + k], acc);
+    wc[i] = acc;
+}
+
+extern "C" int t2v_fuse_location_weights(const float* loc_conv, const float* loc_dense, float* wcomb, void* stream_) {
+    if (!loc_conv || !loc_dense || !wcomb) return T2V_ERR_ARG;
+    k_loc_fuse<<<(T2V_A * 64 + 255) / 256, 256, 0, (hipStream_t)stream_>>>(loc_conv, loc_dense, wcomb);
+    return t2v_check_launch();
+}
+
+template <int NJT, bool BIG>      // NJT 16-position tiles per chunk; !BIG: one chunk covers T_in
 __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
     constexpr int TPAD = 16 * NJT;
+    constexpr int NI = (NJT + 3) / 4;           // tiles per wave
+    extern __shared__ __attribute__((aligned(16))) float eall[];     // Tcap energies -> attention weights
     __shared__ float q[16];
     __shared__ float ap[2][TPAD + 32];
-    __shared__ float cs[T2V_F][TPAD + 1];
-    __shared__ float wcl[T2V_F * 63];
-    __shared__ float eall[256];
     __shared__ float scr[64 * 16];          // 64 groups x 16 partial query sums; reused by the context reduction
     __shared__ int ok_flag;
     const int b = blockIdx.x, s = blockIdx.y;          // s = attention-dim slice [16s,16s+16) and context chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
     const int Tp = a.T_in;
+    const int Tcap = (Tp + 15) & ~15;
     const int len = a.lengths ? a.lengths[b] : Tp;
 
     T2V_STAMP(a, 0);
-    // ---- entry: every global read of the kernel is issued here (about 50 KB per workgroup)
+    // ---- entry: every global read that does not depend on the exchange is issued here
     // query partials of this slice: thread = (dq = tid&3 -> 4 consecutive d, wq = tid>>2 -> 4 source workgroups)
     float4 qpart[4];
     {
@@ -44,23 +72,23 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) qpart[i] = p[(size_t)i * (T2V_A / 4)];
     }
-    // location_dense rows of this slice as the MFMA A operand: A[d = 16s + c16][k = f = 4st + g]
-    float dreg[8];
+    // fused location filter rows of this slice as the MFMA A operand: A[d = 16s + c16][kk = 4st + g]
+    float areg[16];
 #pragma unroll
-    for (int st = 0; st < 8; ++st) dreg[st] = a.loc_dense[(16 * s + c16) * T2V_F + 4 * st + g];
-    // pm / v in the energy-phase output layout: lane (g, c16) <-> d = 16s + 4g + r, position 16jt + c16;
-    // wave w handles tiles jt = w, w+4, ..
-    float4 pmr[(NJT + 3) / 4];
+    for (int st = 0; st < 16; ++st) areg[st] = a.wcomb[(16 * s + c16) * 64 + 4 * st + g];
     const float4 vr = *(const float4*)(a.v + 16 * s + 4 * g);
-#pragma unroll
-    for (int i = 0; i < (NJT + 3) / 4; ++i) {
-        const int j = 16 * (wave + 4 * i) + c16;
-        pmr[i] = j < Tp ? *(const float4*)(a.pm + ((size_t)b * Tp + j) * T2V_A + 16 * s + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // context operands: column chunk s (64 columns), thread = (col = tid&63, part = tid>>6), rows part, part+4, ..
+    // pm in the energy-phase output layout: lane (g, c16) <-> d = 16s + 4g + r, position 16jt + c16;
+    // wave w handles tiles jt = w, w+4, ..
+    float4 pmr[NI];
     constexpr int MR = 4 * NJT;
-    float memr[MR];
-    {
+    float memr[BIG ? 1 : MR];
+    if constexpr (!BIG) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int j = 16 * (wave + 4 * i) + c16;
+            pmr[i] = j < Tp ? *(const float4*)(a.pm + ((size_t)b * Tp + j) * T2V_A + 16 * s + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // context operands: column chunk s (64 columns), thread = (col = tid&63, part = tid>>6), rows part, part+4, ..
         const float* mb = a.memory + (size_t)b * Tp * T2V_E + 64 * s + (tid & 63);
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
@@ -68,14 +96,10 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
             memr[i] = j < len ? mb[(size_t)j * T2V_E] : 0.f;
         }
     }
-    for (int q4 = tid; q4 < T2V_F * 62 / 4; q4 += AF_THREADS) {
-        const float4 w4 = ((const float4*)a.loc_conv)[q4];
-        const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { const int i = 4 * q4 + c; wcl[(i / 62) * 63 + (i % 62)] = wv[c]; }
-    }
+    if (tid == 0) ok_flag = 1;
+    // alignment window of chunk 0: window index x <-> position x - 15
     for (int i = tid; i < 2 * (TPAD + 32); i += AF_THREADS) {
-        const int ch = i / (TPAD + 32), x = i - ch * (TPAD + 32);      // window index x <-> position x - 15
+        const int ch = i / (TPAD + 32), x = i - ch * (TPAD + 32);
         const int j = x - 15;
         float v = 0.f;
         if (j >= 0 && j < Tp) v = (ch == 0 ? a.al_prev : a.acum_prev)[(size_t)b * Tp + j];
@@ -90,6 +114,22 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
         dst[0] = s4.x; dst[1] = s4.y; dst[2] = s4.z; dst[3] = s4.w;
     }
     __syncthreads();
+    // location features of this wave's tiles (independent of the query: issued before the reduction's barriers)
+    f32x4 lacc[NI];
+    if constexpr (!BIG) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int jt = wave + 4 * i;
+            lacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (jt < NJT && 16 * jt < Tp) {
+#pragma unroll
+                for (int st = 0; st < 16; ++st) {
+                    const int kk = 4 * st + g;
+                    lacc[i] = mfma16x4(areg[st], ap[kk >> 5][16 * jt + c16 + (kk & 31)], lacc[i]);
+                }
+            }
+        }
+    }
     {   // 64 -> 16 -> 1 in a fixed order
         const int dd = tid & 15, grp = tid >> 4;
         const float v4 = (scr[(4 * grp) * 16 + dd] + scr[(4 * grp + 1) * 16 + dd]) +
@@ -104,108 +144,85 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
             q[tid] = acc;
         }
     }
+    __syncthreads();
 
     T2V_STAMP(a, 1);
-    // ---- 2. location conv over all positions (redundant in the 8 workgroups of an item, ~2 MFMA tiles per
-    //         wave): tile = 16 filters x 16 positions, K = 64 (kk = 32*ch + k)
-    {   // wave w owns filter tile f0 = 16*(w&1) and position tiles jt = (w>>1), (w>>1)+2, ..: the weight
-        // operands are loaded once and the position tiles run as independent accumulator chains
-        const int f0 = 16 * (wave & 1);
-        float av[16];
-#pragma unroll
-        for (int st = 0; st < 16; ++st) {
-            const int kk = 4 * st + g, ch = kk >> 5, k = kk & 31;
-            av[st] = k < T2V_KS ? wcl[(f0 + c16) * 63 + ch * T2V_KS + k] : 0.f;
-        }
-        static_assert(NJT % 2 == 0, "position tiles are split evenly over wave pairs");
-        constexpr int NT = NJT / 2;
-        f32x4 acc[NT];
-#pragma unroll
-        for (int i = 0; i < NT; ++i) acc[i] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int st = 0; st < 16; ++st) {
-            const int kk = 4 * st + g, ch = kk >> 5, k = kk & 31;
-            const float* row = &ap[ch][c16 + (k < T2V_KS ? k : T2V_KS - 1)];
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int jt = (wave >> 1) + 2 * i;
-                acc[i] = mfma16x4(av[st], row[16 * jt], acc[i]);
+    // ---- 2. location features (K = 64 fused filter) + partial energies of this d-slice, tile by tile
+    t2v_u64* exb = a.ex + ((size_t)b * AF_NS + s) * Tcap;
+    const float4 q4 = make_float4(q[4 * g + 0], q[4 * g + 1], q[4 * g + 2], q[4 * g + 3]);
+    for (int c0 = 0; c0 < Tp; c0 += TPAD) {
+        if (BIG && c0 > 0) {
+            __syncthreads();            // previous chunk's window fully consumed
+            for (int i = tid; i < 2 * (TPAD + 32); i += AF_THREADS) {
+                const int ch = i / (TPAD + 32), x = i - ch * (TPAD + 32);
+                const int j = c0 + x - 15;
+                float v = 0.f;
+                if (j >= 0 && j < Tp) v = (ch == 0 ? a.al_prev : a.acum_prev)[(size_t)b * Tp + j];
+                ap[ch][x] = v;
             }
+            __syncthreads();
         }
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const int jt = (wave >> 1) + 2 * i;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cs[f0 + 4 * g + r][16 * jt + c16] = acc[i][r];
-        }
-    }
-    __syncthreads();
-    if (s == 0 && a.conv_save) {
-        for (int i = tid; i < T2V_F * Tp; i += AF_THREADS) {
-            const int f = i / Tp, j = i - f * Tp;
-            a.conv_save[((size_t)b * T2V_F + f) * Tp + j] = cs[f][j];
-        }
-    }
-
-    T2V_STAMP(a, 2);
-    // ---- 3. partial energies of this d-slice for all positions
-    {
-        float* exb = a.ex + ((size_t)b * AF_MAXS + s) * 256;
-#pragma unroll
-        for (int i = 0; i < (NJT + 3) / 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int jt = wave + 4 * i;
-            if (jt < NJT) {
-                const int j = 16 * jt + c16;
+            if (jt < NJT && c0 + 16 * jt < Tp) {
+                const int j = c0 + 16 * jt + c16;
+                float4 pm4;
+                if constexpr (BIG) pm4 = j < Tp ? *(const float4*)(a.pm + ((size_t)b * Tp + j) * T2V_A + 16 * s + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                else pm4 = pmr[i];
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (BIG) {
 #pragma unroll
-                for (int st = 0; st < 8; ++st) acc = mfma16x4(dreg[st], cs[4 * st + g][j], acc);
-                const float4 pm4 = pmr[i];
+                    for (int st = 0; st < 16; ++st) {
+                        const int kk = 4 * st + g;
+                        acc = mfma16x4(areg[st], ap[kk >> 5][16 * jt + c16 + (kk & 31)], acc);
+                    }
+                } else {
+                    acc = lacc[i];
+                }
                 float4 sv;
-                sv.x = tanhf_(q[4 * g + 0] + acc[0] + pm4.x);
-                sv.y = tanhf_(q[4 * g + 1] + acc[1] + pm4.y);
-                sv.z = tanhf_(q[4 * g + 2] + acc[2] + pm4.z);
-                sv.w = tanhf_(q[4 * g + 3] + acc[3] + pm4.w);
+                sv.x = tanhf_(q4.x + acc[0] + pm4.x);
+                sv.y = tanhf_(q4.y + acc[1] + pm4.y);
+                sv.z = tanhf_(q4.z + acc[2] + pm4.z);
+                sv.w = tanhf_(q4.w + acc[3] + pm4.w);
                 if (a.s_save && j < Tp) *(float4*)(a.s_save + ((size_t)b * Tp + j) * T2V_A + 16 * s + 4 * g) = sv;
                 float esum = vr.x * sv.x + vr.y * sv.y + vr.z * sv.z + vr.w * sv.w;
                 esum += __shfl_xor(esum, 16, 64);
                 esum += __shfl_xor(esum, 32, 64);
-                if (g == 0 && j < Tp) af_st_sc1(exb + j, esum);
+                if (g == 0 && j < Tp) af_put(exb + j, esum, a.epoch);
             }
         }
+        if (!BIG) break;
     }
 
-    T2V_STAMP(a, 3);
-    // ---- 4. the 8 workgroups of the item exchange their partial energies; masked softmax over all positions
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        unsigned* cnt = a.sync + b;
-        unsigned* err = a.sync + 31;
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned target = (unsigned)AF_MAXS * (unsigned)a.epoch;
-        int good = 1;
+    T2V_STAMP(a, 2);
+    // ---- 3. gather the 8 partial-energy granules of every position (tag == epoch <=> written this step)
+    for (int j = tid; j < Tp; j += AF_THREADS) {
+        const t2v_u64* e0 = a.ex + (size_t)b * AF_NS * Tcap + j;
+        float p[AF_NS];
         unsigned spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (++spins > AF_SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                good = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < AF_NS; ++i) {
+                const t2v_u64 x = af_get(e0 + (size_t)i * Tcap);
+                p[i] = __uint_as_float((unsigned)x);
+                ok = ok && (unsigned)(x >> 32) == a.epoch;
+            }
+            if (ok) break;
+            if (++spins > AF_SPIN_LIMIT || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok_flag = 0;
                 break;
             }
         }
-        ok_flag = good;
+        const float ev = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        eall[j] = j < len ? ev : -INFINITY;
     }
     __syncthreads();
     if (!ok_flag) return;
-    if (tid < Tp) {
-        const float* ex0 = a.ex + (size_t)b * AF_MAXS * 256 + tid;
-        float p[AF_MAXS];
-#pragma unroll
-        for (int i = 0; i < AF_MAXS; ++i) p[i] = af_ld_sc1(ex0 + i * 256);
-        const float ev = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-        eall[tid] = tid < len ? ev : -INFINITY;
-    }
-    __syncthreads();
-    {
+    T2V_STAMP(a, 3);
+    {   // masked softmax over all positions (every wave computes max / sum redundantly, same order)
         float m = -INFINITY;
         for (int j = lane; j < Tp; j += 64) m = fmaxf(m, eall[j]);
         m = wave_max(m);
@@ -214,27 +231,44 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
         sum = wave_sum(sum);
         const float inv = 1.0f / sum;
         __syncthreads();
-        if (tid < Tp) {
-            const float al = expf(eall[tid] - m) * inv;
-            eall[tid] = al;
+        for (int j = tid; j < Tp; j += AF_THREADS) {
+            const float al = expf(eall[j] - m) * inv;
+            eall[j] = al;
             if (s == 0) {
-                a.al_cur[(size_t)b * Tp + tid] = al;
-                a.acum_cur[(size_t)b * Tp + tid] = ap[1][15 + tid] + al;
+                a.al_cur[(size_t)b * Tp + j] = al;
+                const float cprev = BIG ? a.acum_prev[(size_t)b * Tp + j] : ap[1][15 + j];
+                a.acum_cur[(size_t)b * Tp + j] = cprev + al;
             }
         }
     }
     __syncthreads();
 
     T2V_STAMP(a, 4);
-    // ---- 5. context chunk s (operands already in registers)
+    // ---- 4. context chunk s
     {
         const int part = tid >> 6;
         float acc0 = 0.f, acc1 = 0.f;
+        if constexpr (BIG) {
+            const float* mb = a.memory + (size_t)b * Tp * T2V_E + 64 * s + (tid & 63);
+            int j = part;
+            for (; j + 28 < len; j += 32) {          // 8 independent loads in flight per thread
+                float mv[8];
 #pragma unroll
-        for (int i = 0; i < MR; i += 2) {
-            const int ja = part + 4 * i, jb = ja + 4;
-            acc0 = fmaf(ja < Tp ? eall[ja] : 0.f, memr[i], acc0);
-            acc1 = fmaf(jb < Tp ? eall[jb] : 0.f, memr[i + 1], acc1);
+                for (int u = 0; u < 8; ++u) mv[u] = mb[(size_t)(j + 4 * u) * T2V_E];
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) {
+                    acc0 = fmaf(eall[j + 4 * u], mv[u], acc0);
+                    acc1 = fmaf(eall[j + 4 * u + 4], mv[u + 1], acc1);
+                }
+            }
+            for (; j < len; j += 4) acc0 = fmaf(eall[j], mb[(size_t)j * T2V_E], acc0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MR; i += 2) {
+                const int ja = part + 4 * i, jb = ja + 4;
+                acc0 = fmaf(ja < Tp ? eall[ja] : 0.f, memr[i], acc0);
+                acc1 = fmaf(jb < Tp ? eall[jb] : 0.f, memr[i + 1], acc1);
+            }
         }
         __syncthreads();
         scr[tid] = acc0 + acc1;
@@ -245,12 +279,12 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
     T2V_STAMP(a, 5);
 }
 
-size_t t2v_attn_fwd_lds(int T_in) { (void)T_in; return 0; }
-
-// f.ex / f.sync / f.epoch must be set by the caller (scratch tail of the QP buffer, see t2vae.h)
+// f.ex / f.err / f.epoch are set by the caller (granule area and sync words behind the query partials, t2v_kernels.h)
 void t2v_launch_attn_fwd(const AttnFwdArgs& f, int B, int T_in, hipStream_t stream) {
-    const dim3 grid(B, AF_MAXS);
-    if (T_in <= 96) k_attn_fwd<6><<<grid, AF_THREADS, 0, stream>>>(f);
-    else if (T_in <= 128) k_attn_fwd<8><<<grid, AF_THREADS, 0, stream>>>(f);
-    else k_attn_fwd<16><<<grid, AF_THREADS, 0, stream>>>(f);
+    const dim3 grid(B, AF_NS);
+    const size_t lds = sizeof(float) * t2v_tcap(T_in);
+    if (T_in <= 96) k_attn_fwd<6, false><<<grid, AF_THREADS, lds, stream>>>(f);
+    else if (T_in <= 128) k_attn_fwd<8, false><<<grid, AF_THREADS, lds, stream>>>(f);
+    else if (T_in <= 256) k_attn_fwd<16, false><<<grid, AF_THREADS, lds, stream>>>(f);
+    else k_attn_fwd<16, true><<<grid, AF_THREADS, lds, stream>>>(f);
 }

@@ -14,45 +14,6 @@
     ACC = mfma16x4((WV).z, (XV).z, ACC);    \
     ACC = mfma16x4((WV).w, (XV).w, ACC)
 
-#define LSTM_WAVES 16
-__global__ __launch_bounds__(1024) void k_lstm_bwd(LstmBwdArgs a) {
-    const int w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int b = lane & 15, g = lane >> 4;
-    const bool dec = w < T2V_XW / 16;
-    const int wt = dec ? w : w - T2V_XW / 16;
-    const float* kv = dec ? a.dgd_t : a.dga_n;
-    if (!kv) return;   // block-uniform
-    const bool bvalid = b < a.B;
-    __shared__ f32x4 red[LSTM_WAVES][64];
-    const float4* p = (dec ? a.packBD : a.packBA) + (size_t)wt * 256 * 64 + lane;   // tile-major: + kb * 64
-    const float* xrow = kv + (size_t)(bvalid ? b : 0) * T2V_G + 4 * g;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int kb0 = 16 * wave;     // 256 k-blocks / 16 waves
-    // successive launches walk the k-blocks in opposite directions (a.flip): whatever part of the
-    // 67 MB stream the previous launch left in the XCD L2s is requested first, before it is evicted
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        float4 wv[8], xv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int kb = a.flip ? kb0 + 15 - (8 * h + i) : kb0 + 8 * h + i;
-            wv[i] = p[(size_t)kb * 64];
-            xv[i] = *(const float4*)(xrow + 16 * kb);   // lanes b>=B read row 0 (unused D columns)
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { MFMA4(acc, wv[i], xv[i]); }
-    }
-    red[wave][lane] = acc;
-    __syncthreads();
-    if (wave == 0 && bvalid) {
-        f32x4 s = red[0][lane];
-#pragma unroll
-        for (int i = 1; i < LSTM_WAVES; ++i) s += red[i][lane];
-        float* y = dec ? a.YD + (size_t)b * T2V_XW : a.YA + (size_t)b * T2V_KATT;
-        *(float4*)(y + 16 * wt + 4 * g) = make_float4(s[0], s[1], s[2], s[3]);
-    }
-}
-
 // Four-wave version of k_lstm_bwd (same finding as for the forward stream: ~64 KB in flight per CU beats 16 waves
 // with everything in flight): wave v walks k-blocks [64v, 64v+64) of its tile in 8 rounds of 8 (W, k) float4
 // pairs, two rounds in flight, alternating direction per launch.
@@ -96,34 +57,36 @@ __global__ __launch_bounds__(256) void k_lstm_bwd256(LstmBwdArgs a) {
     }
 }
 
-// attention(t) backward, split over encoder positions: grid = (B, S), 256 threads; workgroup (b, s) owns
-// positions [s*JS, s*JS + JS), JS = 16 or 32.  The softmax backward needs dot = sum_j alpha_j dalpha_j over ALL
-// positions; since dalpha_j = dctx·memory_j + G_j and sum_j alpha_j memory_j = ctx_t (saved), every
-// workgroup gets it as dot = dctx·ctx_t + sum_j alpha_j G_j without talking to the others.  Gradients that
-// flow to the previous step through the location conv (15-wide halo) are written as per-slice partial rows
-// (parity double-buffered) and re-assembled by every workgroup of step t-1; partial dq / dv rows are summed
-// by the consumers.  No atomics, fixed summation order.
+// attention(t) backward, split over encoder positions: workgroup (b, s) owns positions [s*JS, s*JS + JS), JS = 16
+// (T_in <= 128) or 32, S = ceil(T_in / JS) slices per item (any T_in).  The softmax backward needs
+// dot = sum_j alpha_j dalpha_j over ALL positions; since dalpha_j = dctx·memory_j + G_j and
+// sum_j alpha_j memory_j = ctx_t (saved), every workgroup gets it as dot = dctx·ctx_t + sum_j alpha_j G_j without
+// talking to the others.  The location layer is ONE linear map of the alignment window (fused filter bank W_comb,
+// attn_fwd.hip), so its backward is one K = 128 MFMA contraction T[(c,k)][j] = sum_d W_comb[d][c,k] dpre[j][d] and
+// a diagonal sum; the gradients that flow to the previous step (15-wide halo) are written as per-slice partial rows
+// (parity double-buffered) and re-assembled by every workgroup of step t-1; partial dq rows go to the cell
+// workgroups of the SAME launch as 8-byte {value, tag} granules (the data is the flag); partial dv rows are summed
+// by the host side.  No atomics, fixed summation order.
 #define ATB_THREADS 256
-#define ATB_MAXS 8
-static inline int attn_bwd_js(int T_in) { return 16 * ((T_in + 127) / 128); }
+#define ATB_SPIN_LIMIT 4000000u
 
 template <int JS>
 __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& a, const int b, const int s, const int S) {
     constexpr int NJT = JS / 16;           // 16-position MFMA tiles per slice
     constexpr int PW = JS + 30;            // width of a partial dcat row
-    constexpr int DW = JS + 60;            // zero-padded dc row
+    extern __shared__ __attribute__((aligned(16))) float dyn[];     // gfull[2][Tcap] | alf[Tcap]
     __shared__ __attribute__((aligned(16))) float dctx[T2V_E];
-    __shared__ float gfull[2][256];        // assembled Gprev / Gcum over all positions
-    __shared__ float alf[256];
     __shared__ float dal[JS], de[JS];
     __shared__ float dpT[T2V_A][JS + 1];
-    __shared__ float dcl[T2V_F][DW + 1];
-    __shared__ float wcl[T2V_F * 63];
-    __shared__ f32x4 red[2][2][64];
+    __shared__ float Tl[64][JS + 1];
     __shared__ float scr[ATB_THREADS * 2 + 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
     const int Tp = a.T_in, j0 = s * JS;
+    const int Tcap = (Tp + 15) & ~15;
+    float* gfull0 = dyn;
+    float* gfull1 = dyn + Tcap;
+    float* alf = dyn + 2 * Tcap;
     const int nown = min(JS, Tp - j0);     // > 0 by construction of S
 
     T2V_STAMP(a, 0);
@@ -154,47 +117,42 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& a, const int b,
         if (s == 0) a.DCTX_t[(size_t)b * T2V_E + e] = v;
     }
     const float ctx0 = a.ctx_t[(size_t)b * T2V_XW + tid], ctx1 = a.ctx_t[(size_t)b * T2V_XW + 256 + tid];
-    // assemble G over all positions from the previous reverse step's per-slice partial rows
-    if (tid < Tp) {
-        const int j = tid;
-        float gp = 0.f, gc = a.GC[((size_t)b * ATB_MAXS + s) * 256 + j];
-        float pv[ATB_MAXS][2];
+    // assemble G over all positions from the previous reverse step's per-slice partial rows: position j receives
+    // from the slices sp2 with 0 <= j - sp2*JS + 15 < PW (at most three), summed in ascending slice order
+    float dot_g = 0.f;
+    for (int j = tid; j < Tp; j += ATB_THREADS) {
+        float gp = 0.f, gc = a.GC[((size_t)b * S + s) * Tcap + j];
+        const int lo = max(0, (j + 15 - PW + JS) / JS), hi = min(S - 1, (j + 15) / JS);
+        float pv[3][2];
 #pragma unroll
-        for (int sp2 = 0; sp2 < ATB_MAXS; ++sp2) {      // all loads independent (unused slices hold zeros)
+        for (int u = 0; u < 3; ++u) {      // all loads independent
+            const int sp2 = lo + u;
             const int jj = j - sp2 * JS + 15;
-            const bool in = jj >= 0 && jj < PW;
-            const float* row = a.GP_in + (((size_t)b * ATB_MAXS + sp2) * 2) * 64 + (in ? jj : 0);
-            pv[sp2][0] = row[0];
-            pv[sp2][1] = row[64];
-            if (!in) { pv[sp2][0] = 0.f; pv[sp2][1] = 0.f; }
+            const bool in = sp2 <= hi && jj >= 0 && jj < PW;
+            const float* row = a.GP_in + (((size_t)b * S + (in ? sp2 : 0)) * 2) * 64 + (in ? jj : 0);
+            pv[u][0] = row[0];
+            pv[u][1] = row[64];
+            if (!in) { pv[u][0] = 0.f; pv[u][1] = 0.f; }
         }
 #pragma unroll
-        for (int sp2 = 0; sp2 < ATB_MAXS; ++sp2) { gp += pv[sp2][0]; gc += pv[sp2][1]; }
-        a.GC[((size_t)b * ATB_MAXS + s) * 256 + j] = gc;
-        gfull[0][j] = gp;
-        gfull[1][j] = gc;
-        alf[j] = a.al_cur[(size_t)b * Tp + j];
+        for (int u = 0; u < 3; ++u) { gp += pv[u][0]; gc += pv[u][1]; }
+        a.GC[((size_t)b * S + s) * Tcap + j] = gc;
+        gfull0[j] = gp;
+        gfull1[j] = gc;
+        const float al = a.al_cur[(size_t)b * Tp + j];
+        alf[j] = al;
+        dot_g = fmaf(al, gp + gc, dot_g);
     }
-    for (int i = tid; i < T2V_F * (DW + 1); i += ATB_THREADS) (&dcl[0][0])[i] = 0.f;
-    for (int q4 = tid; q4 < T2V_F * 62 / 4; q4 += ATB_THREADS) {
-        const float4 w4 = ((const float4*)a.loc_conv)[q4];
-        const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+    // fused location filter, transposed, as the MFMA A operand of the location backward: wave w owns the (c,k)
+    // tile [16w, 16w+16): A[m = c16][kd = 4st + g] = W_comb[4st + g][16w + c16]
+    float areg[32];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { const int i = 4 * q4 + c; wcl[(i / 62) * 63 + (i % 62)] = wv[c]; }
-    }
-    // location_dense as the MFMA A operand of phase 5: wave = (f tile = wave&1, K half = wave>>1)
-    float areg[16];
-    {
-        const int f0 = 16 * (wave & 1), kh = wave >> 1;
-#pragma unroll
-        for (int st = 0; st < 16; ++st) areg[st] = a.loc_dense[(64 * kh + 4 * st + g) * T2V_F + f0 + c16];
-    }
+    for (int st = 0; st < 32; ++st) areg[st] = a.wcomb[(4 * st + g) * 64 + 16 * wave + c16];
     __syncthreads();
 
     T2V_STAMP(a, 1);
     // ---- dot = dctx·ctx_t + sum_j alpha_j (Gprev_j + Gcum_j)
-    float dotp = dctx[tid] * ctx0 + dctx[256 + tid] * ctx1;
-    if (tid < Tp) dotp = fmaf(alf[tid], gfull[0][tid] + gfull[1][tid], dotp);
+    float dotp = dctx[tid] * ctx0 + dctx[256 + tid] * ctx1 + dot_g;
     dotp = wave_sum(dotp);
     if (lane == 0) scr[wave] = dotp;
     // ---- dalpha for the own positions: dctx·memory_j + G_j
@@ -208,7 +166,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& a, const int b,
             acc = fmaf(m1[r].x, d1.x, acc); acc = fmaf(m1[r].y, d1.y, acc);
             acc = fmaf(m1[r].z, d1.z, acc); acc = fmaf(m1[r].w, d1.w, acc);
             acc = wave_sum(acc);
-            if (lane == 0) dal[jl] = jl < nown ? acc + gfull[0][j0 + jl] + gfull[1][j0 + jl] : 0.f;
+            if (lane == 0) dal[jl] = jl < nown ? acc + gfull0[j0 + jl] + gfull1[j0 + jl] : 0.f;
         }
     }
     __syncthreads();
@@ -238,79 +196,47 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& a, const int b,
         scr[8 + ATB_THREADS + tid] = dv;
         __syncthreads();
         if (tid < T2V_A) {
-            // write-through: the cell-backward workgroups of the SAME launch consume it after the dq counter
-            __hip_atomic_store(a.DQ_t + ((size_t)b * ATB_MAXS + s) * T2V_A + tid, scr[8 + tid] + scr[8 + 128 + tid],
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a.DV[((size_t)b * ATB_MAXS + s) * T2V_A + tid] += scr[8 + ATB_THREADS + tid] + scr[8 + ATB_THREADS + 128 + tid];
+            // granule: the cell-backward workgroups of the SAME launch poll it (tag 1; the buffer is zeroed per pass)
+            const float dqs = scr[8 + tid] + scr[8 + 128 + tid];
+            __hip_atomic_store(a.DQ_t + ((size_t)b * S + s) * T2V_A + tid,
+                               ((t2v_u64)1u << 32) | (t2v_u64)__float_as_uint(dqs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.DV[((size_t)b * S + s) * T2V_A + tid] += scr[8 + ATB_THREADS + tid] + scr[8 + ATB_THREADS + 128 + tid];
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(a.dq_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     T2V_STAMP(a, 3);
-    // ---- through location_dense on MFMA: dc[f][j] = sum_d D[d][f] dpre[j][d]; K = 128 split over wave pairs
-    {
-        const int f0 = 16 * (wave & 1), kh = wave >> 1;
+    // ---- through the fused location filter on MFMA: T[(c,k)][jl] = sum_d W_comb[d][(c,k)] dpre[jl][d], K = 128
 #pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int jt = 0; jt < NJT; ++jt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int st = 0; st < 16; ++st) acc = mfma16x4(areg[st], dpT[64 * kh + 4 * st + g][16 * jt + c16], acc);
-            if (kh == 1) red[jt & 1][wave & 1][lane] = acc;
-            __syncthreads();
-            if (kh == 0) {
-                const f32x4 o = red[jt & 1][wave & 1][lane];
-                const int jl = 16 * jt + c16;
+        for (int st = 0; st < 32; ++st) acc = mfma16x4(areg[st], dpT[4 * st + g][16 * jt + c16], acc);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int f = f0 + 4 * g + r;
-                    const float v = acc[r] + o[r];
-                    dcl[f][30 + jl] = v;
-                    if (jl < nown) a.DC_t[((size_t)b * T2V_F + f) * Tp + j0 + jl] = v;
-                }
-            }
-        }
+        for (int r = 0; r < 4; ++r) Tl[16 * wave + 4 * g + r][16 * jt + c16] = acc[r];
     }
     __syncthreads();
 
     T2V_STAMP(a, 4);
-    // ---- through location_conv (transposed), scatter form over this slice's dc:
-    //      part[ch][jj] = sum_{f,k} Wc[f][ch][k] dc[f][jj - k],  jj in [0, JS+30)  <->  position j0 - 15 + jj
-    {
-        const int f = tid & 31;
-        float* gout = a.GP_out + (((size_t)b * ATB_MAXS + s) * 2) * 64;
+    // ---- gradient wrt the alignment window of this slice: position p = j0 - 15 + jj receives
+    //      part[c][jj] = sum_k T[(c,k)][jj - k]   (loc[j] reads a_c[j + k - 15])
+    if (tid < 2 * 64) {
+        const int c = tid >> 6, jj = tid & 63;
+        if (jj < PW) {
+            float acc = 0.f;
 #pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-            float wc[T2V_KS];
-#pragma unroll
-            for (int k = 0; k < T2V_KS; ++k) wc[k] = wcl[f * 63 + ch * T2V_KS + k];
-            // thread = (f, block of 6 consecutive outputs): 36-wide window in registers
-            for (int jb = 6 * (tid >> 5); jb < PW; jb += 6 * (ATB_THREADS / 32)) {
-                float win[36];
-                const float* row = &dcl[f][jb];             // dcl index of dc[f][x] is 30 + x; window covers x = jb-30 .. jb+5
-#pragma unroll
-                for (int i = 0; i < 36; ++i) win[i] = row[i];
-                float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int k = 0; k < T2V_KS; ++k)
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) acc[q] = fmaf(wc[k], win[30 + q - k], acc[q]);
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    float v = row16_sum(acc[q]);
-                    v += __shfl_xor(v, 16, 64);
-                    if (f == 0 && jb + q < PW) gout[ch * 64 + jb + q] = v;
-                }
+            for (int k = 0; k < T2V_KS; ++k) {
+                const int jl = jj - k;
+                if (jl >= 0 && jl < JS) acc += Tl[32 * c + k][jl];
             }
+            a.GP_out[(((size_t)b * S + s) * 2 + c) * 64 + jj] = acc;
         }
     }
     T2V_STAMP(a, 5);
 }
 
 // 64 workgroups x 256 threads; thread = (unit U, item b).  Inside the merged launch the decoder_rnn(t-1) part and
-// all operand fetches run while the attention workgroups are still busy; only the W_q^T·dq term waits (bounded
-// spin on the dq counter the attention workgroups bump after publishing their partial dq rows).
+// all operand fetches run while the attention workgroups are still busy; only the W_q^T·dq term waits: the partial
+// dq rows arrive as tagged granules and are polled directly (bounded).
 __device__ __forceinline__ void cell_bwd_body(const CellBwdArgs& a, const int cblk) {
     __shared__ __attribute__((aligned(16))) float wqs[16][T2V_A + 4];
     __shared__ __attribute__((aligned(16))) float dqs[16][T2V_A + 4];
@@ -320,11 +246,12 @@ __device__ __forceinline__ void cell_bwd_body(const CellBwdArgs& a, const int cb
     const bool bv = b < a.B;
     const uint32_t idx = (uint32_t)b * T2V_H + U;
     const size_t bu = (size_t)b * T2V_H + U;
+    if (tid == 0) cell_ok = 1;
     // everything this thread needs from global memory is requested up front (one latency round)
     float yd0 = 0.f, ya0 = 0.f, ga[4] = {0, 0, 0, 0}, cac = 0.f, cap = 0.f, dca = 0.f;
     float hcp = 0.f, yd1 = 0.f, gd[4] = {0, 0, 0, 0}, cdc = 0.f, cdp = 0.f, dcd = 0.f;
     if (a.do_att) {
-        // stage W_q^T rows of this block's 16 units and dq (= sum of the S per-slice partials)
+        // stage W_q^T rows of this block's 16 units
         for (int i = tid; i < 16 * T2V_A / 4; i += 256) {
             const int u = i >> 5, c4 = i & 31;
             *(float4*)&wqs[u][4 * c4] = *(const float4*)(a.wqT + (size_t)(cblk * 16 + u) * T2V_A + 4 * c4);
@@ -364,31 +291,39 @@ __device__ __forceinline__ void cell_bwd_body(const CellBwdArgs& a, const int cb
         a.DCD[bu] = dct * gf;
     }
     if (!a.do_att) return;
-    // ---- wait for the attention workgroups' partial dq rows, then sum them (fixed order)
-    if (tid == 0) {
-        int good = 1;
-        unsigned spins = 0;
-        while (__hip_atomic_load(a.dq_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.dq_target) {
-            if (++spins > 4000000u || __hip_atomic_load(a.dq_counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __hip_atomic_store(a.dq_counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                good = 0;
-                break;
-            }
-        }
-        cell_ok = good;
-    }
-    __syncthreads();
-    if (!cell_ok) return;
+    __syncthreads();       // cell_ok initialised, wqs staged
+    // ---- gather the attention workgroups' partial dq rows (granules, polled until tagged), fixed-order sum
     for (int i = tid; i < a.B * T2V_A; i += 256) {
         const int bb = i >> 7, dd = i & (T2V_A - 1);
-        float pv[8];
+        const t2v_u64* gq = a.DQ_t + (size_t)bb * a.S * T2V_A + dd;
+        float tot = 0.f;
+        for (int s0 = 0; s0 < a.S; s0 += 8) {
+            float pv[8];
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
 #pragma unroll
-        for (int sl = 0; sl < 8; ++sl)   // unused slices are zero
-            pv[sl] = __hip_atomic_load(a.DQ_t + ((size_t)bb * 8 + sl) * T2V_A + dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        dqs[bb][dd] = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
+                for (int sl = 0; sl < 8; ++sl) {
+                    pv[sl] = 0.f;
+                    if (s0 + sl < a.S) {
+                        const t2v_u64 x = __hip_atomic_load(gq + (size_t)(s0 + sl) * T2V_A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pv[sl] = __uint_as_float((unsigned)x);
+                        ok = ok && (unsigned)(x >> 32) == 1u;
+                    }
+                }
+                if (ok) break;
+                if (++spins > ATB_SPIN_LIMIT || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cell_ok = 0;
+                    break;
+                }
+            }
+            tot += ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
+        }
+        dqs[bb][dd] = tot;
     }
     __syncthreads();
-    if (!bv) return;
+    if (!cell_ok || !bv) return;
     {
         const int t = a.t;
         const float4* w4 = (const float4*)wqs[tid >> 4];
@@ -428,26 +363,28 @@ __global__ __launch_bounds__(256) void k_attn_cell_bwd(AttnBwdArgs a, CellBwdArg
     else cell_bwd_body(c, blk - nattn);
 }
 
+extern "C" int t2v_attn_bwd_slices(int T_in) { return T_in < 1 ? 0 : t2v_attn_bwd_slices_(T_in); }
+
 extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
                                      const t2v_dec_bwd_bufs* g, int B, int T_in, int T_out,
                                      float p_att, float p_dec, uint64_t seed, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!w || !s || !g || B < 1 || B > 16 || T_in < 1 || T_out < 1) return T2V_ERR_ARG;
-    if (!w->packB_att || !w->packB_dec) return T2V_ERR_ARG;
-    if (T_in > 256) return T2V_ERR_ARG;
-    const int JS = attn_bwd_js(T_in), S = (T_in + JS - 1) / JS;
+    if (!w || !s || !g || B < 1 || B > 16 || T_in < 1 || T_in > T2V_MAX_T_IN || T_out < 1) return T2V_ERR_ARG;
+    if (!w->packB_att || !w->packB_dec || !w->wcomb) return T2V_ERR_ARG;
+    const int JS = t2v_attn_bwd_js(T_in), S = t2v_attn_bwd_slices_(T_in);
+    const size_t Tcap = t2v_tcap(T_in);
     (void)hipMemsetAsync(g->YD, 0, sizeof(float) * B * T2V_XW, stream);
     (void)hipMemsetAsync(g->YA, 0, sizeof(float) * B * T2V_KATT, stream);
     (void)hipMemsetAsync(g->DCA, 0, sizeof(float) * B * T2V_H, stream);
     (void)hipMemsetAsync(g->DCD, 0, sizeof(float) * B * T2V_H, stream);
-    (void)hipMemsetAsync(g->GPREV, 0, sizeof(float) * 2 * B * ATB_MAXS * 2 * 64, stream);   // partial dcat rows x parity
-    (void)hipMemsetAsync(g->GCUM, 0, sizeof(float) * B * ATB_MAXS * 256, stream);          // per-workgroup Gcum copies
-    (void)hipMemsetAsync(g->DV, 0, sizeof(float) * B * ATB_MAXS * T2V_A, stream);
-    (void)hipMemsetAsync(g->DQ, 0, sizeof(float) * (size_t)T_out * B * ATB_MAXS * T2V_A, stream);
+    (void)hipMemsetAsync(g->GPREV, 0, sizeof(float) * 2 * B * S * 2 * 64, stream);        // partial dcat rows x parity
+    (void)hipMemsetAsync(g->GCUM, 0, sizeof(float) * ((size_t)B * S * Tcap + 64), stream);  // per-workgroup Gcum copies + sync words
+    (void)hipMemsetAsync(g->DV, 0, sizeof(float) * B * S * T2V_A, stream);
+    (void)hipMemsetAsync(g->DQ, 0, sizeof(t2v_u64) * (size_t)T_out * B * S * T2V_A, stream);  // granule tags
 
     const size_t HC = T2V_H + T2V_E;
-    unsigned* sync = (unsigned*)(g->GCUM + (size_t)B * ATB_MAXS * 256);     // [0] dq counter, [1] error word
-    (void)hipMemsetAsync(sync, 0, 2 * sizeof(unsigned), stream);
+    unsigned* sync = (unsigned*)(g->GCUM + (size_t)B * S * Tcap);     // [1] error word
+    const size_t lds = sizeof(float) * 3 * Tcap;
     for (int t = T_out; t >= 0; --t) {
         bool have_attn = false;
         AttnBwdArgs fa = {};
@@ -469,28 +406,25 @@ extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_tra
             f.YA = g->YA;
             f.al_cur = s->AL + (size_t)(t + 1) * B * T_in;
             f.memory = s->memory;
-            f.loc_conv = w->loc_conv;
-            f.loc_dense = w->loc_dense;
+            f.wcomb = w->wcomb;
             f.v = w->v;
             f.S_t = s->S + (size_t)t * B * T_in * T2V_A;
-            f.DQ_t = g->DQ + (size_t)t * B * ATB_MAXS * T2V_A;
+            f.DQ_t = (t2v_u64*)g->DQ + (size_t)t * B * S * T2V_A;
             f.ctx_t = s->XS + (size_t)(t + 1) * B * T2V_XW + T2V_H;
-            f.GP_in = g->GPREV + (size_t)((t + 1) & 1) * B * ATB_MAXS * 2 * 64;
-            f.GP_out = g->GPREV + (size_t)(t & 1) * B * ATB_MAXS * 2 * 64;
+            f.GP_in = g->GPREV + (size_t)((t + 1) & 1) * B * S * 2 * 64;
+            f.GP_out = g->GPREV + (size_t)(t & 1) * B * S * 2 * 64;
             f.GC = g->GCUM;
             f.DCTX_t = g->DCTX + (size_t)t * B * T2V_E;
-            f.DC_t = g->DC + (size_t)t * B * T2V_F * T_in;
             f.DV = g->DV;
             f.T_in = T_in;
             f.prof = g_t2v_prof ? g_t2v_prof + 16 : nullptr;
-            f.dq_counter = sync;
             have_attn = true;
             fa = f;
         }
         CellBwdArgs c;
         c.YD = g->YD;
         c.YA = g->YA;
-        c.DQ_t = t < T_out ? g->DQ + (size_t)t * B * ATB_MAXS * T2V_A : nullptr;
+        c.DQ_t = t < T_out ? (const t2v_u64*)g->DQ + (size_t)t * B * S * T2V_A : nullptr;
         c.S = S;
         c.wqT = w->wqT;
         c.dHC_prev = t >= 1 ? g->dHC + (size_t)(t - 1) * B * HC : nullptr;
@@ -511,11 +445,10 @@ extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_tra
         c.p_att = p_att;
         c.p_dec = p_dec;
         c.seed = seed;
-        c.dq_counter = sync;
-        c.dq_target = (unsigned)(B * S) * (unsigned)(T_out - t);      // every attention slice of this and all earlier reverse steps
+        c.err = sync + 1;
         const int nattn = have_attn ? B * S : 0;
-        if (JS == 16) k_attn_cell_bwd<16><<<nattn + T2V_H / 16, 256, 0, stream>>>(fa, c, nattn, S);
-        else k_attn_cell_bwd<32><<<nattn + T2V_H / 16, 256, 0, stream>>>(fa, c, nattn, S);
+        if (JS == 16) k_attn_cell_bwd<16><<<nattn + T2V_H / 16, 256, lds, stream>>>(fa, c, nattn, S);
+        else k_attn_cell_bwd<32><<<nattn + T2V_H / 16, 256, lds, stream>>>(fa, c, nattn, S);
     }
     return t2v_check_launch();
 }

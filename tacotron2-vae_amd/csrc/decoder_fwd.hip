@@ -6,13 +6,26 @@
 // Reference semantics: Decoder.decode model.py:346-389, Attention.forward model.py:67-88.
 #include "t2v_common.h"
 #include "t2v_kernels.h"
-#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------
-// Weight packing.  Forward tile w (16 rows = 4 units x 4 gates, unit-major) of a (4096,K)
-// gate-major matrix:   P[w][kb][lane][i] = W[(lane&3)*H + 4w + ((lane&15)>>2)][16kb + 4(lane>>4) + i]
+// Weight packing.  The logical (4096, K) gate-major matrices
+//   Wcat_att = [weight_hh | weight_ih[:, 256:768] (| weight_ih[:, 0:256] for the decode loop)]    K = 1536 / 1792
+//   Wcat_dec = [weight_ih (h_att | ctx) | weight_hh]                                              K = 2560
+// are never materialised: the pack kernels read the nn.LSTMCell tensors through a three-segment column map
+// (segment boundaries are multiples of 4, so every float4 of 4 consecutive k stays inside one segment).
+struct WSrc {
+    const float* p[3];
+    int ld[3], off[3], end[3];     // segment i covers logical columns [end[i-1], end[i]) -> p[i][row*ld[i] + off[i] + (c - end[i-1])]
+    __device__ __forceinline__ const float* at(int row, int c) const {
+        if (c < end[0]) return p[0] + (size_t)row * ld[0] + off[0] + c;
+        if (c < end[1]) return p[1] + (size_t)row * ld[1] + off[1] + (c - end[0]);
+        return p[2] + (size_t)row * ld[2] + off[2] + (c - end[1]);
+    }
+};
+// Forward tile w (16 rows = 4 units x 4 gates, unit-major):
+//   P[w][kb][lane][i] = W[(lane&3)*H + 4w + ((lane&15)>>2)][16kb + 4(lane>>4) + i]
 // so one float4 per lane feeds four v_mfma_f32_16x16x4_f32 A operands (k = 16kb+4g+i, i=0..3).
-__global__ void k_pack_fwd(const float* __restrict__ W, int K, float4* __restrict__ P) {
+__global__ void k_pack_fwd(WSrc W, int K, float4* __restrict__ P) {
     const int nkb = K / 16;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // float4 index
     const size_t total = (size_t)T2V_NWG * nkb * 64;
@@ -22,13 +35,12 @@ __global__ void k_pack_fwd(const float* __restrict__ W, int K, float4* __restric
     const int w = (idx >> 6) / nkb;          // 96/112/160 KiB region (tile stride is NOT a power of
     const int arow = lane & 15, g = lane >> 4;   // two, so L2/HBM channels are evenly loaded)
     const int row = (arow & 3) * T2V_H + 4 * w + (arow >> 2);
-    const float* src = W + (size_t)row * K + 16 * kb + 4 * g;
-    P[idx] = make_float4(src[0], src[1], src[2], src[3]);
+    P[idx] = *(const float4*)W.at(row, 16 * kb + 4 * g);
 }
 // Backward (transposed) tile n-tile w' of W^T (N = K columns of W become rows), reduction dim
 // = 4096 gate rows, tile-major like the forward pack (a workgroup's 256 KB are contiguous):
 //   PB[w'][kb][lane][i] = W[16kb + 4(lane>>4) + i][16w' + (lane&15)]
-__global__ void k_pack_bwd(const float* __restrict__ W, int K, int ncols, float4* __restrict__ P) {
+__global__ void k_pack_bwd(WSrc W, int ncols, float4* __restrict__ P) {
     const int nkb = T2V_G / 16;   // 256
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)(ncols / 16) * nkb * 64;
@@ -38,8 +50,7 @@ __global__ void k_pack_bwd(const float* __restrict__ W, int K, int ncols, float4
     const int wt = (idx >> 6) / nkb;
     const int n = 16 * wt + (lane & 15);
     const int k0 = 16 * kb + 4 * (lane >> 4);
-    P[idx] = make_float4(W[(size_t)(k0 + 0) * K + n], W[(size_t)(k0 + 1) * K + n],
-                         W[(size_t)(k0 + 2) * K + n], W[(size_t)(k0 + 3) * K + n]);
+    P[idx] = make_float4(*W.at(k0 + 0, n), *W.at(k0 + 1, n), *W.at(k0 + 2, n), *W.at(k0 + 3, n));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -49,179 +60,41 @@ __global__ void k_pack_bwd(const float* __restrict__ W, int K, int ncols, float4
     ACC = mfma16x4((WV).z, (XV).z, ACC);    \
     ACC = mfma16x4((WV).w, (XV).w, ACC)
 
-// 16 waves per workgroup: the K dimension of both gate GEMVs is split 16 ways so that every
-// wave issues ALL of its weight/x loads (26 x 1 KiB) before the first MFMA — the kernel is a
-// pure weight stream (262 KB per CU per launch) and needs the bytes in flight, not occupancy.
-#define LSTM_WAVES 16
-template <int MODE>   // 0: both cells (skewed); 1: attention_rnn only, prenet columns in K (inference);
-                      // 2: decoder_rnn only; 3: attention_rnn only (training, hoisted prenet term)
-__global__ __launch_bounds__(1024) void k_lstm_fwd(LstmFwdArgs a) {
-    constexpr bool INFER = MODE == 1;
-    constexpr bool DO_A = MODE != 2, DO_D = MODE == 0 || MODE == 2;
-    const int w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int b = lane & 15, g = lane >> 4;
-    const bool bvalid = b < a.B;
-    __shared__ f32x4 red[2][LSTM_WAVES][64];
-    __shared__ float hs[16][4];
-
-        const float4* pa = a.packA + ((size_t)w * (a.k_att / 16)) * 64 + lane;
-    const float4* pd = a.packD + ((size_t)w * (T2V_XW / 16)) * 64 + lane;
-    const float* xrow = a.xs_prev + (size_t)(bvalid ? b : 0) * T2V_XW + 4 * g;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    // ---- tail operands are fetched FIRST so the serial epilogue never waits on global memory:
-    // waves 0/1 own the cell update of attention_rnn(t) / decoder_rnn(t-1) for (unit g, item b)
-    const int which = wave;                               // meaningful for wave < 2 only
-    const bool cell_on = wave < 2 && bvalid && (which == 0 ? a.do_att : a.do_dec);
-    const int U = 4 * w + g;
-    float addv[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
-    if (cell_on) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (which == 0) addv[r] = a.gpre_t ? a.gpre_t[(size_t)b * T2V_G + r * T2V_H + U] : a.bias_att[r * T2V_H + U];
-            else addv[r] = a.bias_dec[r * T2V_H + U];
-        }
-        cprev = (which == 0 ? a.ca_prev : a.cd_prev)[(size_t)b * T2V_H + U];
-    }
-
-    f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accD = {0.f, 0.f, 0.f, 0.f};
-    // shared-x region: k-blocks [0,96) = [h_att | ctx] (6 per wave); decoder_rnn recurrent part:
-    // k-blocks [96,160) = h_dec (4 per wave)
-    float4 xs[6], wa[6], wd[6], xr[4], wr[4];
-    {
-        // odd steps walk this wave's k-blocks backwards: the tail of the previous launch's weight
-        // stream is still in the XCD L2 and gets requested first (measured -13 % on k_lstm_bwd)
-        const bool flip = a.t & 1;
-        const int kb0 = 6 * wave, kr0 = 96 + 4 * wave;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int kb = kb0 + (flip ? 5 - i : i);
-            xs[i] = *(const float4*)(xrow + 16 * kb);   // lanes b>=B read row 0: their D columns are never used
-            if (DO_A) wa[i] = pa[(size_t)kb * 64];   // training: both cells are always computed,
-            if (DO_D) wd[i] = pd[(size_t)kb * 64];   // do_att/do_dec only gate the cell update (t=0 / t=T)
-        }
-        if (DO_D) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int kb = kr0 + (flip ? 3 - i : i);
-                xr[i] = *(const float4*)(xrow + 16 * kb);
-                wr[i] = pd[(size_t)kb * 64];
-            }
-        }
-    }
-    float4 xp = z4, wp = z4;
-    if (INFER) {   // inference: prenet columns are part of K (k-blocks [96,112))
-        const float* prow = a.pre_t + (size_t)(bvalid ? b : 0) * T2V_PRE + 4 * g;
-        xp = *(const float4*)(prow + 16 * wave);
-        wp = pa[(size_t)(96 + wave) * 64];
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        if (DO_A) { MFMA4(accA, wa[i], xs[i]); }
-        if (DO_D) { MFMA4(accD, wd[i], xs[i]); }
-    }
-    if (INFER) { MFMA4(accA, wp, xp); }
-    if (DO_D) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { MFMA4(accD, wr[i], xr[i]); }
-    }
-    red[0][wave][lane] = accA;
-    red[1][wave][lane] = accD;
-    // query partial: thread (d = tid&127) handles items bb = tid>>7, tid>>7 + 8; its 4 query-weight values are
-    // fetched here so the latency hides under the reduction + cell update
-    float wqr[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool q_on = a.do_att && (tid >> 7) < a.B;
-    if (q_on) {
-        const float* wq = a.wqT + (size_t)(4 * w) * T2V_A + (tid & (T2V_A - 1));
-        wqr[0] = wq[0]; wqr[1] = wq[T2V_A]; wqr[2] = wq[2 * T2V_A]; wqr[3] = wq[3 * T2V_A];
-    }
-    __syncthreads();
-
-    // cell update: wave 0 -> attention_rnn(t), wave 1 -> decoder_rnn(t-1).
-    // lane = (unit u = lane>>4, item b = lane&15); acc[r] = gate r (i,f,g,o) of unit 4w+u.
-    if (cell_on) {
-        f32x4 s = red[which][0][lane];
-#pragma unroll
-        for (int i = 1; i < LSTM_WAVES; ++i) s += red[which][i][lane];
-        const int tt = which == 0 ? a.t : a.t - 1;            // time index of this cell
-        const float p = which == 0 ? a.p_att : a.p_dec;
-        const uint32_t st_h = which == 0 ? T2V_RNG_ATT_H : T2V_RNG_DEC_H;
-        const uint32_t st_c = which == 0 ? T2V_RNG_ATT_C : T2V_RNG_DEC_C;
-        const float gi = sigmoidf_(s[0] + addv[0]), gf = sigmoidf_(s[1] + addv[1]);
-        const float gg = tanhf_(s[2] + addv[2]), go = sigmoidf_(s[3] + addv[3]);
-        float* ccur_p = which == 0 ? a.ca_cur : a.cd_cur;
-        const uint32_t idx = (uint32_t)b * T2V_H + U;
-        if (tt > 0) cprev *= t2v_drop_scale(a.seed, st_c, tt - 1, idx, p);
-        const float c = gf * cprev + gi * gg;
-        const float h = go * tanhf_(c);
-        ccur_p[(size_t)b * T2V_H + U] = c;
-        float* gsave = which == 0 ? a.ga_t : a.gd_t;
-        if (gsave) {
-            gsave[(size_t)b * T2V_G + 0 * T2V_H + U] = gi;
-            gsave[(size_t)b * T2V_G + 1 * T2V_H + U] = gf;
-            gsave[(size_t)b * T2V_G + 2 * T2V_H + U] = gg;
-            gsave[(size_t)b * T2V_G + 3 * T2V_H + U] = go;
-        }
-        const float hd = h * t2v_drop_scale(a.seed, st_h, tt, idx, p);
-        a.xs_next[(size_t)b * T2V_XW + (which == 0 ? U : T2V_KATT + U)] = hd;
-        if (which == 0) hs[b][g] = hd;
-    }
-    __syncthreads();
-    if (q_on) {   // partial processed query of this workgroup's 4 hidden units
-        const int d = tid & (T2V_A - 1);
-        for (int bb = tid >> 7; bb < a.B; bb += 8) {
-            const float q = wqr[0] * hs[bb][0] + wqr[1] * hs[bb][1] + wqr[2] * hs[bb][2] + wqr[3] * hs[bb][3];
-            a.qp[((size_t)bb * T2V_NWG + w) * T2V_A + d] = q;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-extern "C" int t2v_pack_lstm_weights(const float* wcat_att, int k_att, const float* wcat_dec,
-                                     float* packF_att, float* packF_dec, float* packB_att,
-                                     float* packB_dec, void* stream_) {
+extern "C" int t2v_pack_lstm_weights(const float* w_ih_att, const float* w_hh_att, const float* w_ih_dec,
+                                     const float* w_hh_dec, int k_att, float* packF_att, float* packF_dec,
+                                     float* packB_att, float* packB_dec, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!wcat_att || !wcat_dec || !packF_att || !packF_dec) return T2V_ERR_ARG;
+    if (!w_ih_att || !w_hh_att || !w_ih_dec || !w_hh_dec || !packF_att || !packF_dec) return T2V_ERR_ARG;
     if (k_att != T2V_KATT && k_att != T2V_KATT_INF) return T2V_ERR_DIMS;
+    const int IH = T2V_PRE + T2V_E;       // 768 input columns of attention_rnn: [prenet | ctx]
+    WSrc A, D;
+    A.p[0] = w_hh_att; A.ld[0] = T2V_H; A.off[0] = 0;       A.end[0] = T2V_H;
+    A.p[1] = w_ih_att; A.ld[1] = IH;    A.off[1] = T2V_PRE; A.end[1] = T2V_KATT;
+    A.p[2] = w_ih_att; A.ld[2] = IH;    A.off[2] = 0;       A.end[2] = T2V_KATT_INF;
+    D.p[0] = w_ih_dec; D.ld[0] = T2V_KATT; D.off[0] = 0; D.end[0] = T2V_KATT;
+    D.p[1] = w_hh_dec; D.ld[1] = T2V_H;    D.off[1] = 0; D.end[1] = T2V_XW;
+    D.p[2] = w_hh_dec; D.ld[2] = T2V_H;    D.off[2] = 0; D.end[2] = T2V_XW;
     {
         const size_t n = (size_t)T2V_NWG * (k_att / 16) * 64;
-        k_pack_fwd<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(wcat_att, k_att, (float4*)packF_att);
+        k_pack_fwd<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(A, k_att, (float4*)packF_att);
     }
     {
         const size_t n = (size_t)T2V_NWG * (T2V_XW / 16) * 64;
-        k_pack_fwd<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(wcat_dec, T2V_XW, (float4*)packF_dec);
+        k_pack_fwd<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(D, T2V_XW, (float4*)packF_dec);
     }
     if (packB_att) {   // only the recurrent 1536 columns matter for the data gradient
         const size_t n = (size_t)(T2V_KATT / 16) * 256 * 64;
-        k_pack_bwd<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(wcat_att, k_att, T2V_KATT, (float4*)packB_att);
+        k_pack_bwd<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(A, T2V_KATT, (float4*)packB_att);
     }
     if (packB_dec) {
         const size_t n = (size_t)(T2V_XW / 16) * 256 * 64;
-        k_pack_bwd<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(wcat_dec, T2V_XW, T2V_XW, (float4*)packB_dec);
+        k_pack_bwd<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(D, T2V_XW, (float4*)packB_dec);
     }
     return t2v_check_launch();
 }
 
-#define ATT_THREADS_HOST 512
-// ---- side stream for the overlapped schedule (created lazily, one per host thread)
-struct T2vSide { hipStream_t stream = nullptr; hipEvent_t ev[8]; hipEvent_t join; bool ok = false; };
-static thread_local T2vSide g_side;
-static bool side_ready() {
-    if (g_side.ok) return true;
-    if (hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking) != hipSuccess) return false;
-    for (int i = 0; i < 8; ++i)
-        if (hipEventCreateWithFlags(&g_side.ev[i], hipEventDisableTiming) != hipSuccess) return false;
-    if (hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming) != hipSuccess) return false;
-    g_side.ok = true;
-    return true;
-}
-extern "C" int t2v_overlap_enabled(void) {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("T2V_OVERLAP"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v;
-}
-
-// Training-step version of k_lstm_fwd<0> with FOUR waves per workgroup (tools/ubench_gemv_tiles.hip: for this 67 MB
+// Training step: FOUR waves per workgroup (tools/ubench_gemv_tiles.hip: for this 67 MB
 // stream about 64 KB in flight per CU is the sweet spot — 16 waves that each put 26 KB in flight queue too much).
 // Workgroup w = gate-row tile w of BOTH cells; wave v walks attention_rnn k-blocks [24v, 24v+24) then decoder_rnn
 // k-blocks [40v, 40v+40): 8 rounds of 8 (W, x) float4 pairs, two rounds in flight; odd steps walk the same
@@ -440,44 +313,23 @@ static void fill_lstm_args(LstmFwdArgs& a, const t2v_dec_weights* w, const t2v_d
     a.seed = seed;
 }
 
-// mask bits: 1 = fused k_lstm_fwd<0> (serial schedule), 2 = k_attn_fwd, 4 = k_lstm_fwd<2> (decoder_rnn only),
-// 8 = k_lstm_fwd<3> (attention_rnn only); 16 = run the overlapped two-stream schedule
+// mask bits: 1 = k_lstm_fwd256 (both cells), 2 = k_attn_fwd
 static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s, int B, int T_in, int T_out,
                             float p_att, float p_dec, uint64_t seed, void* stream_, int mask) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!w || !s || B < 1 || B > 16 || T_in < 1 || T_out < 1) return T2V_ERR_ARG;
-    if (T_in > 256) return T2V_ERR_ARG;
-    // scratch tail of QP: [0,32768) partial-energy exchange, then 32 uint32 arrival counters / error word
-    float* qp_tail = s->QP + (size_t)B * T2V_NWG * T2V_A;
-    (void)hipMemsetAsync(qp_tail + 32768, 0, 32 * sizeof(uint32_t), stream);
-    const bool overlap = (mask & 16) && side_ready();
-    hipStream_t sb = overlap ? g_side.stream : stream;
+    if (!w || !s || B < 1 || B > 16 || T_in < 1 || T_in > T2V_MAX_T_IN || T_out < 1) return T2V_ERR_ARG;
+    if (!w->wcomb) return T2V_ERR_ARG;
+    // scratch behind the query partials: sync / error words, then the energy-exchange granules (t2v_kernels.h);
+    // tags and words are zeroed per pass (a memset node that replays first under graph capture)
+    unsigned* sync = (unsigned*)(s->QP + t2v_qp_sync_off(B));
+    t2v_u64* ex = (t2v_u64*)(s->QP + t2v_qp_ex_off(B));
+    (void)hipMemsetAsync(sync, 0, 64 * sizeof(uint32_t), stream);
+    (void)hipMemsetAsync(ex, 0, sizeof(t2v_u64) * (size_t)B * 8 * t2v_tcap(T_in), stream);
     for (int t = 0; t <= T_out; ++t) {
-        LstmFwdArgs a;
-        fill_lstm_args(a, w, s, B, T_out, t, p_att, p_dec, seed);
-        if (overlap) {
-            // stream A: attention_rnn(t) -> attention(t); stream B: decoder_rnn(t-1) once attention_rnn(t) is done,
-            // so its 42 MB weight stream runs underneath the latency-bound attention kernel
-            LstmFwdArgs aa = a, ad = a;
-            aa.do_dec = 0;      // each single-cell kernel must not touch the other cell's state
-            ad.do_att = 0;
-            if (t < T_out) {
-                k_lstm_fwd<3><<<T2V_NWG, 1024, 0, stream>>>(aa);
-                (void)hipEventRecord(g_side.ev[t & 7], stream);
-            } else {
-                (void)hipEventRecord(g_side.ev[t & 7], stream);     // after attention(T-1)
-            }
-            if (t >= 1) {
-                (void)hipStreamWaitEvent(sb, g_side.ev[t & 7], 0);
-                k_lstm_fwd<2><<<T2V_NWG, 1024, 0, sb>>>(ad);
-            }
-        } else {
-            if (mask & 1) k_lstm_fwd256<<<T2V_NWG, 256, 0, stream>>>(a);
-            LstmFwdArgs aa = a, ad = a;
-            aa.do_dec = 0;
-            ad.do_att = 0;
-            if ((mask & 8) && t < T_out) k_lstm_fwd<3><<<T2V_NWG, 1024, 0, stream>>>(aa);
-            if ((mask & 4) && t >= 1) k_lstm_fwd<2><<<T2V_NWG, 1024, 0, stream>>>(ad);
+        if (mask & 1) {
+            LstmFwdArgs a;
+            fill_lstm_args(a, w, s, B, T_out, t, p_att, p_dec, seed);
+            k_lstm_fwd256<<<T2V_NWG, 256, 0, stream>>>(a);
         }
         if (t < T_out && (mask & 2)) {
             AttnFwdArgs f;
@@ -489,23 +341,17 @@ static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
             f.memory = s->memory;
             f.pm = s->pm;
             f.lengths = s->lengths;
-            f.loc_conv = w->loc_conv;
-            f.loc_dense = w->loc_dense;
+            f.wcomb = w->wcomb;
             f.v = w->v;
             f.xs_next = s->XS + (size_t)(t + 1) * B * T2V_XW;
             f.s_save = s->S ? s->S + (size_t)t * B * T_in * T2V_A : nullptr;
-            f.conv_save = s->CONV ? s->CONV + (size_t)t * B * T2V_F * T_in : nullptr;
             f.T_in = T_in;
             f.prof = g_t2v_prof;
-            f.ex = qp_tail;
-            f.sync = (unsigned*)(qp_tail + 32768);
-            f.epoch = t + 1;
+            f.ex = ex;
+            f.err = sync + 31;
+            f.epoch = (unsigned)t + 1u;
             t2v_launch_attn_fwd(f, B, T_in, stream);
         }
-    }
-    if (overlap) {
-        (void)hipEventRecord(g_side.join, sb);
-        (void)hipStreamWaitEvent(stream, g_side.join, 0);
     }
     return t2v_check_launch();
 }
@@ -513,18 +359,20 @@ static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
 extern "C" int t2v_decoder_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
                                      int B, int T_in, int T_out, float p_att, float p_dec,
                                      uint64_t seed, void* stream_) {
-    return launch_train_fwd(w, s, B, T_in, T_out, p_att, p_dec, seed, stream_, t2v_overlap_enabled() ? (2 | 16) : 3);
+    return launch_train_fwd(w, s, B, T_in, T_out, p_att, p_dec, seed, stream_, 3);
 }
 
 extern "C" int t2v_decoder_replay_fwd_kernels(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
                                               int B, int T_in, int T_out, float p_att, float p_dec,
                                               uint64_t seed, int kernel_mask, void* stream_) {
-    return launch_train_fwd(w, s, B, T_in, T_out, p_att, p_dec, seed, stream_, kernel_mask & 15);
+    return launch_train_fwd(w, s, B, T_in, T_out, p_att, p_dec, seed, stream_, kernel_mask & 3);
+}
+
+extern "C" long t2v_decoder_qp_floats(int B, int T_in) {
+    return (B < 1 || T_in < 1) ? 0 : (long)t2v_qp_floats(B, T_in);
 }
 
 void t2v_launch_lstm_fwd(int mode, const LstmFwdArgs& a, hipStream_t stream) {
-    if (mode == 3) k_lstm_fwd<3><<<T2V_NWG, 1024, 0, stream>>>(a);
-    else if (mode == 1) k_lstm_one256<true><<<T2V_NWG, 256, 0, stream>>>(a);      // decode: attention_rnn + prenet columns
-    else if (mode == 2) k_lstm_one256<false><<<T2V_NWG, 256, 0, stream>>>(a);     // decode: decoder_rnn
-    else k_lstm_fwd<0><<<T2V_NWG, 1024, 0, stream>>>(a);
+    if (mode == 1) k_lstm_one256<true><<<T2V_NWG, 256, 0, stream>>>(a);      // decode: attention_rnn + prenet columns
+    else k_lstm_one256<false><<<T2V_NWG, 256, 0, stream>>>(a);               // decode: decoder_rnn
 }

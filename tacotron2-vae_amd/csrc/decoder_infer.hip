@@ -23,7 +23,7 @@ struct ProjPrenetArgs {
     float gate_logit_thr, p_prenet;
     uint64_t seed;
     float* xchg;            // [0,768) mel exchange (8 x 96), [1024,3072) layer-0 exchange (8 x 256)
-    unsigned* sync;         // [0] arrival counter (monotonic over the pass), [15] error word
+    unsigned* sync;         // [0] arrival counter (monotonic over the pass), [15] error word (QP sync words 32 / 47)
     int epoch;              // 1-based frame index within the pass
 };
 
@@ -142,10 +142,14 @@ extern "C" int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_i
                                        int t_begin, int t_end, float gate_threshold, float p_prenet,
                                        int external_prenet, uint64_t seed, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!w || !s || B < 1 || B > 8 || T_in < 1 || T_in > 256 || t_begin < 0 || t_end <= t_begin) return T2V_ERR_ARG;
-    if (!w->bias_att || !w->bias_dec) return T2V_ERR_ARG;
-    float* qp_tail = s->QP + (size_t)B * T2V_NWG * T2V_A;
-    if (t_begin == 0) (void)hipMemsetAsync(qp_tail + 32768, 0, 32 * sizeof(uint32_t), stream);
+    if (!w || !s || B < 1 || B > 8 || T_in < 1 || T_in > T2V_MAX_T_IN || t_begin < 0 || t_end <= t_begin) return T2V_ERR_ARG;
+    if (!w->bias_att || !w->bias_dec || !w->wcomb) return T2V_ERR_ARG;
+    unsigned* sync = (unsigned*)(s->QP + t2v_qp_sync_off(B));
+    t2v_u64* ex = (t2v_u64*)(s->QP + t2v_qp_ex_off(B));
+    if (t_begin == 0) {
+        (void)hipMemsetAsync(sync, 0, 64 * sizeof(uint32_t), stream);
+        (void)hipMemsetAsync(ex, 0, sizeof(t2v_u64) * (size_t)B * 8 * t2v_tcap(T_in), stream);
+    }
     const float thr = gate_threshold <= 0.f ? -INFINITY : (gate_threshold >= 1.f ? INFINITY : logf(gate_threshold / (1.f - gate_threshold)));
     for (int t = t_begin; t < t_end; ++t) {
         LstmFwdArgs a;
@@ -185,17 +189,15 @@ extern "C" int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_i
         f.memory = s->memory;
         f.pm = s->pm;
         f.lengths = s->lengths;
-        f.loc_conv = w->loc_conv;
-        f.loc_dense = w->loc_dense;
+        f.wcomb = w->wcomb;
         f.v = w->v;
         f.xs_next = s->XS + (size_t)(t + 1) * B * T2V_XW;
         f.s_save = nullptr;
-        f.conv_save = nullptr;
         f.T_in = T_in;
         f.prof = nullptr;
-        f.ex = qp_tail;
-        f.sync = (unsigned*)(qp_tail + 32768);
-        f.epoch = t + 1;
+        f.ex = ex;
+        f.err = sync + 31;
+        f.epoch = (unsigned)t + 1u;
         t2v_launch_attn_fwd(f, B, T_in, stream);
 
         // decoder_rnn(t): XS[t+1] -> XS[t+2][1536:]   (time index t+1 in the kernel's skewed convention)
@@ -225,8 +227,8 @@ extern "C" int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_i
         p.gate_logit_thr = thr;
         p.p_prenet = p_prenet;
         p.seed = seed;
-        p.xchg = qp_tail + 32768 + 64;
-        p.sync = (unsigned*)(qp_tail + 32768) + 16;
+        p.xchg = s->QP + t2v_qp_xchg_off(B);
+        p.sync = sync + 32;
         p.epoch = t + 1;
         k_proj_prenet<<<PP_NWG, 256, 0, stream>>>(p);
     }

@@ -9,9 +9,25 @@ enum { T2V_RNG_ATT_H = 1, T2V_RNG_ATT_C = 2, T2V_RNG_DEC_H = 3, T2V_RNG_DEC_C = 
 
 int t2v_check_launch();
 extern unsigned long long* g_t2v_prof;   // device buffer of 32 u64 or NULL (t2v_set_phase_profile)                 // records hipGetLastError() for t2v_last_error()
-size_t t2v_attn_fwd_lds(int T_in);
 struct LstmFwdArgs;
 struct AttnFwdArgs;
+
+// ---- layout of the QP scratch buffer (t2v_dec_train_bufs.QP / t2v_dec_infer_bufs.QP), in floats:
+//   [0, B*256*128)            per-workgroup partial queries of the current step
+//   + [0, 64)                 uint32 sync / error words (attention error word = [31]; decode loop: counter [32], error [47])
+//   + [64, 64 + 4096)         exchange area of the decode loop's projection/Prenet kernel
+//   + [4160, 4160 + 2*B*8*Tcap)  8-byte {partial energy, epoch tag} granules of the attention forward exchange,
+//                             Tcap = T_in rounded up to 16  (t2v_decoder_qp_floats() in t2vae.h returns the total)
+typedef unsigned long long t2v_u64;
+static inline size_t t2v_tcap(int T_in) { return (size_t)((T_in + 15) / 16) * 16; }
+static inline size_t t2v_qp_sync_off(int B) { return (size_t)B * 256 * 128; }
+static inline size_t t2v_qp_xchg_off(int B) { return t2v_qp_sync_off(B) + 64; }
+static inline size_t t2v_qp_ex_off(int B) { return t2v_qp_sync_off(B) + 64 + 4096; }
+#define T2V_MAX_T_IN 4096
+static inline size_t t2v_qp_floats(int B, int T_in) { return t2v_qp_ex_off(B) + 2 * (size_t)B * 8 * t2v_tcap(T_in); }
+// attention-backward slicing: positions per workgroup and slices per item
+static inline int t2v_attn_bwd_js(int T_in) { return T_in <= 128 ? 16 : 32; }
+static inline int t2v_attn_bwd_slices_(int T_in) { const int js = t2v_attn_bwd_js(T_in); return (T_in + js - 1) / js; }
 void t2v_launch_lstm_fwd(int mode, const LstmFwdArgs& a, hipStream_t stream);
 void t2v_launch_attn_fwd(const AttnFwdArgs& f, int B, int T_in, hipStream_t stream);
 
@@ -36,8 +52,6 @@ struct LstmFwdArgs {
     int B, t, do_att, do_dec;
     float p_att, p_dec;
     uint64_t seed;
-    unsigned* dq_counter;   // [0] arrivals of attention slices (monotonic over the pass), [1] error word
-    unsigned dq_target;
 };
 
 struct AttnFwdArgs {
@@ -49,17 +63,15 @@ struct AttnFwdArgs {
     const float* memory;
     const float* pm;
     const int32_t* lengths;
-    const float* loc_conv;
-    const float* loc_dense;
+    const float* wcomb;         // (128,64) fused location filter bank (t2v_fuse_location_weights)
     const float* v;
     float* xs_next;
     float* s_save;
-    float* conv_save;
     int T_in;
     unsigned long long* prof;   // optional phase stamps (s_memtime) from workgroup (0,0) thread 0
-    float* ex;                  // (B,8,256) partial-energy exchange between the workgroups of an item
-    unsigned* sync;             // [b] arrival counters (monotonic over the pass), [31] error word
-    int epoch;                  // 1-based launch index within the pass (target = S * epoch)
+    t2v_u64* ex;                // (B,8,Tcap) granules {partial energy, tag}: exchange between the 8 workgroups of an item
+    unsigned* err;              // error word (bounded-spin timeout)
+    unsigned epoch;             // 1-based launch index within the pass = the granule tag of this step
 };
 
 struct LstmBwdArgs {
@@ -79,19 +91,16 @@ struct AttnBwdArgs {
     const float* YA;
     const float* al_cur;    // AL[t+1]
     const float* memory;
-    const float* loc_conv;
-    const float* loc_dense;
+    const float* wcomb;     // (128,64) fused location filter bank
     const float* v;
     float* S_t;             // (B,T_in,128) in: tanh outputs, out: dpre
-    float* DQ_t;            // (B,128)
+    t2v_u64* DQ_t;          // (B,S,128) granules {partial dq, tag 1}
     float* DCTX_t;          // (B,512)
-    float* DC_t;            // (B,32,T_in)
     const float* ctx_t;     // XS[t+1] + 1024: attention context of step t (row stride 2560)
-    const float* GP_in;     // (B,8,2,64) per-slice partial dcat rows written by reverse step t+1
-    float* GP_out;          // (B,8,2,64) ... written by this step (other parity)
-    float* GC;              // (B,8,256) per-workgroup running copies of the cumulative-weights gradient
-    float* DV;              // (B,8,128) per-slice accumulators
-    unsigned* dq_counter;   // bumped once per attention slice after its partial dq row is published
+    const float* GP_in;     // (B,S,2,64) per-slice partial dcat rows written by reverse step t+1
+    float* GP_out;          // (B,S,2,64) ... written by this step (other parity)
+    float* GC;              // (B,S,Tcap) per-workgroup running copies of the cumulative-weights gradient
+    float* DV;              // (B,S,128) per-slice accumulators
     int T_in;
     unsigned long long* prof;
 };
@@ -99,8 +108,8 @@ struct AttnBwdArgs {
 struct CellBwdArgs {
     const float* YD;
     const float* YA;
-    const float* DQ_t;      // (B,8,128) per-slice partials of step t
-    int S;                  // slices actually written
+    const t2v_u64* DQ_t;    // (B,S,128) granules of step t
+    int S;                  // slices per item
     const float* wqT;       // (1024,128)
     const float* dHC_prev;  // dHC[t-1] (B,1536)
     const float* GA_t;      // GA[t]
@@ -116,6 +125,5 @@ struct CellBwdArgs {
     int B, t, do_att, do_dec;
     float p_att, p_dec;
     uint64_t seed;
-    unsigned* dq_counter;   // [0] arrivals of attention slices (monotonic over the pass), [1] error word
-    unsigned dq_target;
+    unsigned* err;          // error word (bounded-spin timeout)
 };

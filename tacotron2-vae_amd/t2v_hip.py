@@ -22,19 +22,17 @@ class T2VHipError(RuntimeError):
 
 class _DecWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        'packF_att', 'packF_dec', 'packB_att', 'packB_dec', 'bias_att', 'bias_dec', 'wqT',
-        'loc_conv', 'loc_dense', 'v')]
+        'packF_att', 'packF_dec', 'packB_att', 'packB_dec', 'bias_att', 'bias_dec', 'wqT', 'wcomb', 'v')]
 
 
 class _DecTrainBufs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        'gpre', 'memory', 'pm', 'lengths', 'XS', 'CA', 'CD', 'GA', 'GD', 'QP', 'AL', 'ACUM',
-        'S', 'CONV')]
+        'gpre', 'memory', 'pm', 'lengths', 'XS', 'CA', 'CD', 'GA', 'GD', 'QP', 'AL', 'ACUM', 'S')]
 
 
 class _DecBwdBufs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        'dHC', 'DGA', 'DGD', 'DQ', 'DCTX', 'DC', 'YD', 'YA', 'DCA', 'DCD', 'GPREV', 'GCUM', 'DV')]
+        'dHC', 'DGA', 'DGD', 'DQ', 'DCTX', 'YD', 'YA', 'DCA', 'DCD', 'GPREV', 'GCUM', 'DV')]
 
 
 class _DecInferBufs(C.Structure):
@@ -46,7 +44,8 @@ class _DecInferBufs(C.Structure):
 EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decoder_train_fwd',
            't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_conv1d_dw_scratch_floats', 't2v_gemm_bf16', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
            't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats',
-           't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_overlap_enabled')
+           't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_fuse_location_weights', 't2v_decoder_qp_floats',
+           't2v_attn_bwd_slices')
 
 
 def lib_path():
@@ -64,8 +63,12 @@ def load_library():
     lib = C.CDLL(_LIB_PATH)
     lib.t2v_version.restype = C.c_char_p
     lib.t2v_last_error.restype = C.c_char_p
-    lib.t2v_pack_lstm_weights.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                          C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.t2v_pack_lstm_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.t2v_fuse_location_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.t2v_decoder_qp_floats.argtypes = [C.c_int, C.c_int]
+    lib.t2v_decoder_qp_floats.restype = C.c_long
+    lib.t2v_attn_bwd_slices.argtypes = [C.c_int]
     lib.t2v_decoder_train_fwd.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecTrainBufs), C.c_int, C.c_int,
                                           C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]
     lib.t2v_decoder_train_bwd.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecTrainBufs),
@@ -99,7 +102,7 @@ def load_library():
     lib.t2v_gemm_f32.argtypes = [vp, C.c_long, C.c_long, vp, C.c_long, C.c_long, vp, vp, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, vp]
     lib.t2v_gemm_bf16.argtypes = lib.t2v_gemm_f32.argtypes
-    lib.t2v_attn_wgrad.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.t2v_attn_wgrad.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]     # 8 pointers
     lib.t2v_attn_wgrad_scratch_floats.argtypes = []
     lib.t2v_conv2d_s2_fwd.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.t2v_conv2d_s2_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
@@ -215,14 +218,43 @@ def _f32c(t):
     return t.contiguous()
 
 
+MAX_DEC_B = 16      # batch columns of one MFMA tile in the per-step kernels; larger batches run in chunks
+
+
 def replay_fwd_kernels(kernel_mask):
-    """Re-issue the k_lstm_fwd (mask 1) / k_attn_fwd (mask 2) launches of the most recent
-    DecoderCore.forward on its saved arena (bench.py roofline leg)."""
+    """Re-issue the k_lstm_fwd256 (mask 1) / k_attn_fwd (mask 2) launches of the most recent DecoderCore.forward
+    (first batch chunk) on its saved arena (bench.py roofline leg; needs DecoderCore.keep_last = True)."""
+    if DecoderCore.last_call is None:
+        raise T2VHipError("replay_fwd_kernels: set DecoderCore.keep_last = True before the forward pass")
     W, Sb, (B, T_in, T, p_att, p_dec, seed), _keep = DecoderCore.last_call
     _check(load_library().t2v_decoder_replay_fwd_kernels(C.byref(W), C.byref(Sb), B, T_in, T, p_att, p_dec,
                                                          seed, int(kernel_mask), _stream()),
            't2v_decoder_replay_fwd_kernels')
     return T + 1 if kernel_mask == 1 else T
+
+
+def pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, k_att, need_bwd):
+    """MFMA-fragment tiles of the two decoder LSTM cells, read straight from the nn.LSTMCell tensors."""
+    lib = load_library()
+    dev = w_ih_att.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    w_ih_att, w_hh_att, w_ih_dec, w_hh_dec = (_f32c(t.detach()) for t in (w_ih_att, w_hh_att, w_ih_dec, w_hh_dec))
+    packF_att = torch.empty(G4 * k_att, **f32)
+    packF_dec = torch.empty(G4 * XW, **f32)
+    packB_att = torch.empty(G4 * KATT, **f32) if need_bwd else None
+    packB_dec = torch.empty(G4 * XW, **f32) if need_bwd else None
+    _check(lib.t2v_pack_lstm_weights(_p(w_ih_att), _p(w_hh_att), _p(w_ih_dec), _p(w_hh_dec), int(k_att),
+                                     _p(packF_att), _p(packF_dec), _p(packB_att), _p(packB_dec), _stream()),
+           't2v_pack_lstm_weights')
+    return packF_att, packF_dec, packB_att, packB_dec
+
+
+def fuse_location_weights(loc_conv, loc_dense):
+    """(128,64) fused filter bank of LocationLayer (conv then dense, both bias-free: one linear map)."""
+    lib = load_library()
+    wcomb = torch.empty(A, 64, device=loc_conv.device, dtype=torch.float32)
+    _check(lib.t2v_fuse_location_weights(_p(loc_conv), _p(loc_dense), _p(wcomb), _stream()), 't2v_fuse_location_weights')
+    return wcomb
 
 
 class DecoderCore(torch.autograd.Function):
@@ -232,8 +264,35 @@ class DecoderCore(torch.autograd.Function):
              attention_rnn weight_ih/weight_hh, decoder_rnn weight_ih/weight_hh, bias_dec (4096),
              query weight (128,1024), location conv (32,2,31), location dense (128,32), v (1,128)
     outputs: HC (T,B,1536) = [h_dec_t | ctx_t],  alignments (B,T,T_in)
+    Batches larger than 16 run as independent chunks of <= 16 items (the loop has no cross-item coupling), so the
+    reference's default batch_size = 64 works; weight gradients are summed over the chunks.
     """
     last_call = None
+    keep_last = False       # bench / tests: keep the (first chunk's) arena of the last forward for replays
+
+    @staticmethod
+    def _fwd_chunk(lib, gpre, memory, pm, lengths, packs, bias_dec, wqT, wcomb, vv, need_grad, p_att, p_dec, seed):
+        T, B, _ = gpre.shape
+        T_in = memory.shape[1]
+        f32 = dict(device=gpre.device, dtype=torch.float32)
+        XS = torch.empty(T + 2, B, XW, **f32); XS[0].zero_(); XS[1, :, KATT:].zero_()
+        CA = torch.empty(T + 1, B, H, **f32); CA[0].zero_()
+        CD = torch.empty(T + 1, B, H, **f32); CD[0].zero_()
+        GA = torch.empty(T, B, G4, **f32) if need_grad else None
+        GD = torch.empty(T, B, G4, **f32) if need_grad else None
+        QP = torch.empty(lib.t2v_decoder_qp_floats(B, T_in), **f32)
+        AL = torch.empty(T + 1, B, T_in, **f32); AL[0].zero_()
+        ACUM = torch.empty(T + 1, B, T_in, **f32); ACUM[0].zero_()
+        S = torch.empty(T, B, T_in, A, **f32) if need_grad else None
+        packF_att, packF_dec, packB_att, packB_dec = packs
+        W = _DecWeights(_p(packF_att), _p(packF_dec), _p(packB_att), _p(packB_dec), None, _p(bias_dec),
+                        _p(wqT), _p(wcomb), _p(vv))
+        Sb = _DecTrainBufs(_p(gpre), _p(memory), _p(pm), _p(lengths), _p(XS), _p(CA), _p(CD), _p(GA), _p(GD),
+                           _p(QP), _p(AL), _p(ACUM), _p(S))
+        _check(lib.t2v_decoder_train_fwd(C.byref(W), C.byref(Sb), B, T_in, T, float(p_att), float(p_dec),
+                                         int(seed), _stream()), 't2v_decoder_train_fwd')
+        _err_note('decoder forward (attention exchange)', QP.view(torch.int32)[B * 256 * A + 31:][:1])
+        return W, Sb, (gpre, memory, pm, lengths, XS, CA, CD, GA, GD, QP, AL, ACUM, S)
 
     @staticmethod
     def forward(ctx, gpre, memory, pm, lengths, w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, bias_dec,
@@ -241,108 +300,114 @@ class DecoderCore(torch.autograd.Function):
         lib = _require_gpu(gpre, memory, pm, w_ih_att)
         T, B, _ = gpre.shape
         T_in = memory.shape[1]
-        dev = gpre.device
-        f32 = dict(device=dev, dtype=torch.float32)
         gpre, memory, pm = _f32c(gpre), _f32c(memory), _f32c(pm)
-        need_grad = any(ctx.needs_input_grad)
-
-        wcat_att = torch.cat((w_hh_att, w_ih_att[:, PRE:]), 1).contiguous()       # (4096,1536)
-        wcat_dec = torch.cat((w_ih_dec, w_hh_dec), 1).contiguous()                 # (4096,2560)
-        packF_att = torch.empty_like(wcat_att)
-        packF_dec = torch.empty_like(wcat_dec)
-        packB_att = torch.empty_like(wcat_att) if need_grad else None
-        packB_dec = torch.empty_like(wcat_dec) if need_grad else None
-        _check(lib.t2v_pack_lstm_weights(_p(wcat_att), KATT, _p(wcat_dec), _p(packF_att), _p(packF_dec),
-                                         _p(packB_att), _p(packB_dec), _stream()), 't2v_pack_lstm_weights')
-        wqT = wq.t().contiguous()
-        bias_dec = _f32c(bias_dec)
-        loc_conv, loc_dense, vv = _f32c(loc_conv), _f32c(loc_dense), _f32c(v).view(-1)
-
-        XS = torch.empty(T + 2, B, XW, **f32); XS[0].zero_(); XS[1, :, KATT:].zero_()
-        CA = torch.empty(T + 1, B, H, **f32); CA[0].zero_()
-        CD = torch.empty(T + 1, B, H, **f32); CD[0].zero_()
-        GA = torch.empty(T, B, G4, **f32)
-        GD = torch.empty(T, B, G4, **f32)
-        QP = torch.empty(B * 256 * A + 40960, **f32)
-        AL = torch.empty(T + 1, B, T_in, **f32); AL[0].zero_()
-        ACUM = torch.empty(T + 1, B, T_in, **f32); ACUM[0].zero_()
-        S = torch.empty(T, B, T_in, A, **f32) if need_grad else None
-        CONV = torch.empty(T, B, F_LOC, T_in, **f32) if need_grad else None
-
-        W = _DecWeights(_p(packF_att), _p(packF_dec), _p(packB_att), _p(packB_dec), None, _p(bias_dec),
-                        _p(wqT), _p(loc_conv), _p(loc_dense), _p(vv))
-        Sb = _DecTrainBufs(_p(gpre), _p(memory), _p(pm), _p(lengths), _p(XS), _p(CA), _p(CD), _p(GA), _p(GD),
-                           _p(QP), _p(AL), _p(ACUM), _p(S), _p(CONV))
-        _check(lib.t2v_decoder_train_fwd(C.byref(W), C.byref(Sb), B, T_in, T, float(p_att), float(p_dec),
-                                         int(seed), _stream()), 't2v_decoder_train_fwd')
-        _err_note('decoder forward (attention exchange)', QP.view(torch.int32)[B * 256 * A + 32768 + 31:][:1])
-        HC = torch.cat((XS[2:T + 2, :, KATT:], XS[1:T + 1, :, H:KATT]), 2)
-        align = AL[1:].permute(1, 0, 2)
+        need_grad = torch.is_grad_enabled() and any(ctx.needs_input_grad)
+        packs = pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, KATT, need_grad)
+        wqT = wq.detach().t().contiguous()
+        bias_dec = _f32c(bias_dec.detach())
+        loc_conv, loc_dense, vv = _f32c(loc_conv.detach()), _f32c(loc_dense.detach()), _f32c(v.detach()).view(-1)
+        wcomb = fuse_location_weights(loc_conv, loc_dense)
+        chunks = []
+        for b0 in range(0, B, MAX_DEC_B):
+            b1 = min(B, b0 + MAX_DEC_B)
+            if b0 == 0 and b1 == B:
+                g_c, m_c, pm_c, l_c = gpre, memory, pm, lengths
+            else:
+                g_c, m_c, pm_c = gpre[:, b0:b1].contiguous(), memory[b0:b1].contiguous(), pm[b0:b1].contiguous()
+                l_c = None if lengths is None else lengths[b0:b1].contiguous()
+            chunks.append(DecoderCore._fwd_chunk(lib, g_c, m_c, pm_c, l_c, packs, bias_dec, wqT, wcomb, vv, need_grad,
+                                                 p_att, p_dec, (int(seed) + 7919 * b0) & 0x7FFFFFFFFFFFFFFF))
+        hcs = [torch.cat((k[4][2:T + 2, :, KATT:], k[4][1:T + 1, :, H:KATT]), 2) for _, _, k in chunks]
+        als = [k[10][1:].permute(1, 0, 2) for _, _, k in chunks]
+        HC = hcs[0] if len(hcs) == 1 else torch.cat(hcs, 1)
+        align = als[0] if len(als) == 1 else torch.cat(als, 0)
         ctx.dims = (B, T_in, T, float(p_att), float(p_dec), int(seed))
-        ctx.keep = (gpre, memory, pm, lengths, packF_att, packF_dec, packB_att, packB_dec, bias_dec, wqT,
-                    loc_conv, loc_dense, vv, XS, CA, CD, GA, GD, QP, AL, ACUM, S, CONV)
+        ctx.consts = (packs, bias_dec, wqT, wcomb, vv, loc_conv, loc_dense)
+        ctx.chunks = [k for _, _, k in chunks] if need_grad else None
         ctx.mark_non_differentiable(align)
-        DecoderCore.last_call = (W, Sb, ctx.dims, ctx.keep)
+        if DecoderCore.keep_last:
+            W0, S0, k0 = chunks[0]
+            DecoderCore.last_call = (W0, S0, (k0[0].shape[1], T_in, T, float(p_att), float(p_dec), int(seed)),
+                                     k0 + (packs, bias_dec, wqT, wcomb, vv))
         return HC, align
 
     @staticmethod
     def backward(ctx, dHC, _dalign):
         lib = load_library()
-        B, T_in, T, p_att, p_dec, seed = ctx.dims
-        (gpre, memory, pm, lengths, packF_att, packF_dec, packB_att, packB_dec, bias_dec, wqT, loc_conv,
-         loc_dense, vv, XS, CA, CD, GA, GD, QP, AL, ACUM, S, CONV) = ctx.keep
-        dev = gpre.device
+        Bt, T_in, T, p_att, p_dec, seed = ctx.dims
+        packs, bias_dec, wqT, wcomb, vv, loc_conv, loc_dense = ctx.consts
+        packF_att, packF_dec, packB_att, packB_dec = packs
+        if ctx.chunks is None:
+            raise T2VHipError("DecoderCore.backward without a saved arena (forward ran under no_grad)")
+        dev = dHC.device
         f32 = dict(device=dev, dtype=torch.float32)
         dHC = _f32c(dHC)
-        DGA = torch.empty(T, B, G4, **f32)
-        DGD = torch.empty(T, B, G4, **f32)
-        DQ = torch.empty(T, B, 8, A, **f32)
-        DCTX = torch.empty(T, B, E, **f32)
-        DC = torch.empty(T, B, F_LOC, T_in, **f32)
-        YD = torch.empty(B, XW, **f32); YA = torch.empty(B, KATT, **f32)
-        DCA = torch.empty(B, H, **f32); DCD = torch.empty(B, H, **f32)
-        GPREV = torch.empty(2, B, 8, 2, 64, **f32); GCUM = torch.empty(B * 8 * 256 + 64, **f32)
-        DV = torch.empty(B, 8, A, **f32)
-        W = _DecWeights(_p(packF_att), _p(packF_dec), _p(packB_att), _p(packB_dec), None, _p(bias_dec),
-                        _p(wqT), _p(loc_conv), _p(loc_dense), _p(vv))
-        Sb = _DecTrainBufs(_p(gpre), _p(memory), _p(pm), _p(lengths), _p(XS), _p(CA), _p(CD), _p(GA), _p(GD),
-                           _p(QP), _p(AL), _p(ACUM), _p(S), _p(CONV))
-        Gb = _DecBwdBufs(_p(dHC), _p(DGA), _p(DGD), _p(DQ), _p(DCTX), _p(DC), _p(YD), _p(YA), _p(DCA),
-                         _p(DCD), _p(GPREV), _p(GCUM), _p(DV))
-        _check(lib.t2v_decoder_train_bwd(C.byref(W), C.byref(Sb), C.byref(Gb), B, T_in, T, p_att, p_dec, seed,
-                                         _stream()), 't2v_decoder_train_bwd')
-        _err_note('decoder backward (dq hand-off)', GCUM.view(torch.int32)[B * 8 * 256 + 1:][:1])
-        TB = T * B
-        dga2, dgd2 = DGA.view(TB, G4), DGD.view(TB, G4)
-        # time-batched weight-gradient GEMMs (plain library GEMMs)
-        x_prev = XS[0:T].reshape(TB, XW)          # [h_att_{t-1} | ctx_{t-1} | .]
-        x_cur = XS[1:T + 1].reshape(TB, XW)       # [h_att_t | ctx_t | h_dec_{t-1}]
-        dw_att = mm_mixed(dga2.t(), x_prev[:, :KATT])      # (4096,1536) = [dW_hh | dW_ih[:,256:]]
+        NS = lib.t2v_attn_bwd_slices(T_in)
+        tcap = (T_in + 15) // 16 * 16
+        acc = None
+        dga_l, dmem_l, dpm_l = [], [], []
+        b0 = 0
+        for keep in ctx.chunks:
+            gpre, memory, pm, lengths, XS, CA, CD, GA, GD, QP, AL, ACUM, S = keep
+            B = gpre.shape[1]
+            dhc_c = dHC if B == Bt else dHC[:, b0:b0 + B].contiguous()
+            DGA = torch.empty(T, B, G4, **f32)
+            DGD = torch.empty(T, B, G4, **f32)
+            DQ = torch.empty(T, B, NS, A, 2, **f32)
+            DCTX = torch.empty(T, B, E, **f32)
+            YD = torch.empty(B, XW, **f32); YA = torch.empty(B, KATT, **f32)
+            DCA = torch.empty(B, H, **f32); DCD = torch.empty(B, H, **f32)
+            GPREV = torch.empty(2, B, NS, 2, 64, **f32); GCUM = torch.empty(B * NS * tcap + 64, **f32)
+            DV = torch.empty(B, NS, A, **f32)
+            W = _DecWeights(_p(packF_att), _p(packF_dec), _p(packB_att), _p(packB_dec), None, _p(bias_dec),
+                            _p(wqT), _p(wcomb), _p(vv))
+            Sb = _DecTrainBufs(_p(gpre), _p(memory), _p(pm), _p(lengths), _p(XS), _p(CA), _p(CD), _p(GA), _p(GD),
+                               _p(QP), _p(AL), _p(ACUM), _p(S))
+            Gb = _DecBwdBufs(_p(dhc_c), _p(DGA), _p(DGD), _p(DQ), _p(DCTX), _p(YD), _p(YA), _p(DCA),
+                             _p(DCD), _p(GPREV), _p(GCUM), _p(DV))
+            _check(lib.t2v_decoder_train_bwd(C.byref(W), C.byref(Sb), C.byref(Gb), B, T_in, T, p_att, p_dec,
+                                             (seed + 7919 * b0) & 0x7FFFFFFFFFFFFFFF, _stream()), 't2v_decoder_train_bwd')
+            _err_note('decoder backward (dq hand-off)', GCUM.view(torch.int32)[B * NS * tcap + 1:][:1])
+            TB = T * B
+            dga2, dgd2 = DGA.view(TB, G4), DGD.view(TB, G4)
+            # time-batched weight-gradient GEMMs
+            x_prev = XS[0:T].reshape(TB, XW)          # [h_att_{t-1} | ctx_{t-1} | .]
+            x_cur = XS[1:T + 1].reshape(TB, XW)       # [h_att_t | ctx_t | h_dec_{t-1}]
+            dw_att = mm_mixed(dga2.t(), x_prev[:, :KATT])      # (4096,1536) = [dW_hh | dW_ih[:,256:]]
+            dw_dec = mm_mixed(dgd2.t(), x_cur)                 # (4096,2560) = [dW_ih | dW_hh]
+            d_bias_dec = dgd2.sum(0)
+            d_wq = DQ[..., 0].sum(2).view(TB, A).t() @ x_cur[:, :H]
+            d_memory = torch.bmm(AL[1:].permute(1, 2, 0), DCTX.permute(1, 0, 2))
+            dpre = S                                   # overwritten in place by the backward kernels
+            d_pm = dpre.sum(0)
+            d_v = DV.sum((0, 1)).view(1, A)
+            d_loc_dense, d_loc_conv = attn_wgrad(dpre, AL, ACUM, loc_conv, loc_dense, B, T_in, T)
+            parts = [dw_att, dw_dec, d_bias_dec, d_wq, d_loc_conv, d_loc_dense, d_v]
+            acc = parts if acc is None else [x + y for x, y in zip(acc, parts)]
+            dga_l.append(DGA); dmem_l.append(d_memory); dpm_l.append(d_pm)
+            b0 += B
+        ctx.chunks = None          # the arena is released as soon as the backward has consumed it
+        dw_att, dw_dec, d_bias_dec, d_wq, d_loc_conv, d_loc_dense, d_v = acc
         d_w_hh_att = dw_att[:, :H].contiguous()
         d_w_ih_att = torch.zeros(G4, PRE + E, **f32)
         d_w_ih_att[:, PRE:] = dw_att[:, H:]
-        dw_dec = mm_mixed(dgd2.t(), x_cur)                 # (4096,2560) = [dW_ih | dW_hh]
         d_w_ih_dec = dw_dec[:, :KATT].contiguous()
         d_w_hh_dec = dw_dec[:, KATT:].contiguous()
-        d_bias_dec = dgd2.sum(0)
-        d_wq = DQ.sum(2).view(TB, A).t() @ x_cur[:, :H]
-        d_memory = torch.bmm(AL[1:].permute(1, 2, 0), DCTX.permute(1, 0, 2))
-        dpre = S                                   # overwritten in place by the backward kernels
-        d_pm = dpre.sum(0)
-        d_v = DV.sum((0, 1)).view(1, A)
-        d_loc_dense, d_loc_conv = attn_wgrad(dpre, CONV, DC, AL, ACUM, B, T_in, T)
+        DGA = dga_l[0] if len(dga_l) == 1 else torch.cat(dga_l, 1)
+        d_memory = dmem_l[0] if len(dmem_l) == 1 else torch.cat(dmem_l, 0)
+        d_pm = dpm_l[0] if len(dpm_l) == 1 else torch.cat(dpm_l, 0)
         return (DGA, d_memory, d_pm, None, d_w_ih_att, d_w_hh_att, d_w_ih_dec, d_w_hh_dec, d_bias_dec,
                 d_wq, d_loc_conv, d_loc_dense, d_v, None, None, None)
 
 
-def attn_wgrad(dpre, CONV, DC, AL, ACUM, B, T_in, T):
+def attn_wgrad(dpre, AL, ACUM, loc_conv, loc_dense, B, T_in, T):
     """location_dense / location_conv weight gradients summed over the whole decoder pass (csrc/attn_wgrad.hip)."""
-    lib = _require_gpu(dpre, CONV, DC, AL, ACUM)
+    lib = _require_gpu(dpre, AL, ACUM, loc_conv, loc_dense)
     f32 = dict(device=dpre.device, dtype=torch.float32)
     part = torch.empty(lib.t2v_attn_wgrad_scratch_floats(), **f32)
     d_dense, d_conv = torch.empty(A, F_LOC, **f32), torch.empty(F_LOC, 2, KS, **f32)
-    _check(lib.t2v_attn_wgrad(_p(dpre), _p(CONV), _p(DC), _p(AL), _p(ACUM), _p(part), _p(d_dense), _p(d_conv),
-                              B, T_in, T, _stream()), 't2v_attn_wgrad')
+    _check(lib.t2v_attn_wgrad(_p(dpre), _p(AL), _p(ACUM), _p(_f32c(loc_conv)), _p(_f32c(loc_dense)), _p(part),
+                              _p(d_dense), _p(d_conv), B, T_in, T, _stream()), 't2v_attn_wgrad')
     return d_dense, d_conv
 
 
@@ -387,14 +452,11 @@ class InferenceSession(object):
         self.B, self.T_in, self.max_steps = B, T_in, int(max_steps)
         T = self.max_steps
         self.memory, self.pm, self.lengths = _f32c(memory.detach()), _f32c(pm.detach()), lengths
-        wcat_att = torch.cat((w_hh_att, w_ih_att[:, PRE:], w_ih_att[:, :PRE]), 1).detach().contiguous()   # (4096,1792)
-        wcat_dec = torch.cat((w_ih_dec, w_hh_dec), 1).detach().contiguous()
-        self.packF_att, self.packF_dec = torch.empty_like(wcat_att), torch.empty_like(wcat_dec)
-        _check(lib.t2v_pack_lstm_weights(_p(wcat_att), KATT_INF, _p(wcat_dec), _p(self.packF_att), _p(self.packF_dec),
-                                         None, None, _stream()), 't2v_pack_lstm_weights')
+        self.packF_att, self.packF_dec, _, _ = pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, KATT_INF,
+                                                                    False)
         self.b_att, self.b_dec = _f32c(b_att.detach()), _f32c(b_dec.detach())
         self.wqT = wq.detach().t().contiguous()
-        self.loc_conv, self.loc_dense = _f32c(loc_conv.detach()), _f32c(loc_dense.detach())
+        self.wcomb = fuse_location_weights(_f32c(loc_conv.detach()), _f32c(loc_dense.detach()))
         self.v = _f32c(v.detach()).view(-1)
         self.w0, self.w1 = _f32c(prenet_w0.detach()), _f32c(prenet_w1.detach())
         self.proj_w = torch.cat((proj_w, gate_w), 0).detach().contiguous()      # (81,1536)
@@ -402,7 +464,7 @@ class InferenceSession(object):
         self.XS = torch.empty(T + 2, B, XW, **f32); self.XS[0:2].zero_()
         self.CA = torch.empty(T + 1, B, H, **f32); self.CA[0].zero_()
         self.CD = torch.empty(T + 1, B, H, **f32); self.CD[0].zero_()
-        self.QP = torch.empty(B * 256 * A + 40960, **f32)
+        self.QP = torch.empty(lib.t2v_decoder_qp_floats(B, T_in), **f32)
         self.AL = torch.empty(T + 1, B, T_in, **f32); self.AL[0].zero_()
         self.ACUM = torch.empty(T + 1, B, T_in, **f32); self.ACUM[0].zero_()
         self.PRE = torch.empty(T + 1, B, PRE, **f32)
@@ -410,7 +472,7 @@ class InferenceSession(object):
         self.GATE = torch.empty(T, B, **f32)
         self.stop = torch.full((1,), self.INT_MAX, device=dev, dtype=torch.int32)
         self.W = _DecWeights(_p(self.packF_att), _p(self.packF_dec), None, None, _p(self.b_att), _p(self.b_dec),
-                             _p(self.wqT), _p(self.loc_conv), _p(self.loc_dense), _p(self.v))
+                             _p(self.wqT), _p(self.wcomb), _p(self.v))
         self.S = _DecInferBufs(_p(self.memory), _p(self.pm), _p(self.lengths), _p(self.XS), _p(self.CA), _p(self.CD),
                                _p(self.QP), _p(self.AL), _p(self.ACUM), _p(self.PRE), _p(self.MEL), _p(self.GATE),
                                _p(self.stop), _p(self.w0), _p(self.w1), _p(self.proj_w), _p(self.proj_b))
@@ -503,7 +565,8 @@ class ConvBNAct1d(torch.autograd.Function):
 class BiLSTM(torch.autograd.Function):
     """Encoder BiLSTM over per-sequence lengths (== pack_padded_sequence → nn.LSTM → pad_packed_sequence,
     reference model.py:183-190).  Input projections / weight gradients are time-batched GEMMs; the
-    recurrence (forward and BPTT) runs in the persistent cooperative kernels of csrc/bilstm.hip."""
+    recurrence (forward and BPTT) runs in the persistent cooperative kernels of csrc/bilstm.hip, 16 sequences per
+    call (larger batches run as independent chunks)."""
 
     @staticmethod
     def forward(ctx, x, lengths, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, save):
@@ -511,44 +574,60 @@ class BiLSTM(torch.autograd.Function):
         B, T, _ = x.shape
         f32 = dict(device=x.device, dtype=torch.float32)
         x = _f32c(x)
-        gx = torch.empty(2, B, T, 1024, **f32)
-        torch.addmm(b_ih + b_hh, x.view(B * T, -1), w_ih.t(), out=gx[0].view(B * T, 1024))
-        torch.addmm(b_ih_r + b_hh_r, x.view(B * T, -1), w_ih_r.t(), out=gx[1].view(B * T, 1024))
         whh = torch.stack((w_hh, w_hh_r)).contiguous()
         y = torch.zeros(B, T, 512, **f32)
-        gates = torch.empty(2, B, T, 1024, **f32) if save else None
-        cells = torch.empty(2, B, T, 256, **f32) if save else None
-        hx = torch.empty(2 * 2 * 16 * 256, **f32)
-        sync = torch.empty(3, device=x.device, dtype=torch.int32)
-        _check(lib.t2v_bilstm_fwd(_p(gx), _p(whh), _p(lengths), _p(y), _p(gates), _p(cells), _p(hx), _p(sync), B, T,
-                                  _stream()), 't2v_bilstm_fwd')
-        _err_note('BiLSTM forward', sync[2:3])
-        ctx.keep = (x, lengths, w_ih, w_ih_r, whh, y, gates, cells, sync)
+        bias, bias_r = b_ih + b_hh, b_ih_r + b_hh_r
+        chunks = []
+        for b0 in range(0, B, MAX_DEC_B):
+            b1 = min(B, b0 + MAX_DEC_B)
+            Bc = b1 - b0
+            gx = torch.empty(2, Bc, T, 1024, **f32)
+            gemm(x[b0:b1].view(Bc * T, -1), w_ih, bias, out=gx[0].view(Bc * T, 1024))
+            gemm(x[b0:b1].view(Bc * T, -1), w_ih_r, bias_r, out=gx[1].view(Bc * T, 1024))
+            gates = torch.empty(2, Bc, T, 1024, **f32) if save else None
+            cells = torch.empty(2, Bc, T, 256, **f32) if save else None
+            hx = torch.empty(2 * 2 * 16 * 256, **f32)
+            sync = torch.empty(3, device=x.device, dtype=torch.int32)
+            _check(lib.t2v_bilstm_fwd(_p(gx), _p(whh), _p(lengths[b0:b1]), _p(y[b0:b1]), _p(gates), _p(cells), _p(hx),
+                                      _p(sync), Bc, T, _stream()), 't2v_bilstm_fwd')
+            _err_note('BiLSTM forward', sync[2:3])
+            chunks.append((b0, b1, gates, cells, sync))
+        ctx.keep = (x, lengths, w_ih, w_ih_r, whh, y, chunks)
         ctx.dims = (B, T)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = load_library()
-        x, lengths, w_ih, w_ih_r, whh, y, gates, cells, sync = ctx.keep
+        x, lengths, w_ih, w_ih_r, whh, y, chunks = ctx.keep
         B, T = ctx.dims
-        if gates is None:
+        if chunks[0][2] is None:
             raise T2VHipError("BiLSTM forward ran without saving activations")
         f32 = dict(device=x.device, dtype=torch.float32)
         dy = _f32c(dy)
-        dg = torch.zeros(2, B, T, 1024, **f32)
-        dgx = torch.empty(2 * 2 * 16 * 1024, **f32)
-        _check(lib.t2v_bilstm_bwd(_p(whh), _p(lengths), _p(dy), _p(gates), _p(cells), _p(dg), _p(dgx), _p(sync), B, T,
-                                  _stream()), 't2v_bilstm_bwd')
-        _err_note('BiLSTM backward', sync[2:3])
+        dg = torch.zeros(2, B, T, 1024, **f32) if len(chunks) == 1 else None
+        dgs = []
+        for b0, b1, gates, cells, sync in chunks:
+            Bc = b1 - b0
+            dg_c = dg if dg is not None else torch.zeros(2, Bc, T, 1024, **f32)
+            dgx = torch.empty(2 * 2 * 16 * 1024, **f32)
+            _check(lib.t2v_bilstm_bwd(_p(whh), _p(lengths[b0:b1]), _p(dy[b0:b1]), _p(gates), _p(cells), _p(dg_c), _p(dgx),
+                                      _p(sync), Bc, T, _stream()), 't2v_bilstm_bwd')
+            _err_note('BiLSTM backward', sync[2:3])
+            dgs.append(dg_c)
         BT = B * T
-        d0, d1, x2 = dg[0].view(BT, 1024), dg[1].view(BT, 1024), x.view(BT, -1)
-        dx = (d0 @ w_ih + d1 @ w_ih_r).view(B, T, -1)
+        if dg is None:
+            dg = torch.cat(dgs, 1)
+        d0, d1, x2 = dg[0].reshape(BT, 1024), dg[1].reshape(BT, 1024), x.view(BT, -1)
+        dx = gemm(d0, w_ih.t())
+        gemm(d1, w_ih_r.t(), out=dx, accumulate=True)
+        dx = dx.view(B, T, -1)
         z = y.new_zeros(B, 1, 256)
         hp0 = torch.cat((z, y[:, :-1, :256]), 1).reshape(BT, 256)      # h_{t-1} of the forward direction
         hp1 = torch.cat((y[:, 1:, 256:], z), 1).reshape(BT, 256)       # h_{t+1} of the reverse direction
         db0, db1 = d0.sum(0), d1.sum(0)
-        return (dx, None, d0.t() @ x2, d0.t() @ hp0, db0, db0, d1.t() @ x2, d1.t() @ hp1, db1, db1, None)
+        return (dx, None, gemm(d0.t(), x2.t()), gemm(d0.t(), hp0.t()), db0, db0,
+                gemm(d1.t(), x2.t()), gemm(d1.t(), hp1.t()), db1, db1, None)
 
 
 def bilstm_check(sync):
@@ -666,24 +745,32 @@ class GRULast(torch.autograd.Function):
         gsave = torch.empty(B, T, 4, 256, **f32)
         whh = w_hh.contiguous()
         xchg = torch.empty(2 * 16 * 768, **f32)                       # exchange buffer (forward uses 2*16*256 of it)
-        sync = torch.empty(2, device=x.device, dtype=torch.int32)
-        _check(lib.t2v_gru_fwd(_p(gi), _p(whh), _p(b_hh), _p(hs), _p(gsave), _p(xchg), _p(sync), B, T, _stream()),
-               't2v_gru_fwd')
-        _err_note('GRU forward', sync[1:2])
-        ctx.keep = (x2, w_ih, whh, hs, gsave, xchg, sync)
+        syncs = []
+        gi3 = gi.view(B, T, 768)
+        for b0 in range(0, B, MAX_DEC_B):          # 16 sequences per cooperative launch; rows of a chunk are contiguous
+            b1 = min(B, b0 + MAX_DEC_B)
+            sync = torch.empty(2, device=x.device, dtype=torch.int32)
+            _check(lib.t2v_gru_fwd(_p(gi3[b0:b1]), _p(whh), _p(b_hh), _p(hs[b0:b1]), _p(gsave[b0:b1]), _p(xchg), _p(sync),
+                                   b1 - b0, T, _stream()), 't2v_gru_fwd')
+            _err_note('GRU forward', sync[1:2])
+            syncs.append(sync)
+        ctx.keep = (x2, w_ih, whh, hs, gsave, xchg, syncs)
         ctx.dims = (B, T, I)
         return hs[:, T].clone()
 
     @staticmethod
     def backward(ctx, dh):
         lib = load_library()
-        x2, w_ih, whh, hs, gsave, xchg, sync = ctx.keep
+        x2, w_ih, whh, hs, gsave, xchg, syncs = ctx.keep
         B, T, I = ctx.dims
         f32 = dict(device=x2.device, dtype=torch.float32)
         dgi, dgh = torch.empty(B, T, 768, **f32), torch.empty(B, T, 768, **f32)
-        _check(lib.t2v_gru_bwd(_p(whh), _p(hs), _p(gsave), _p(dh.contiguous()), _p(dgi), _p(dgh), _p(xchg), _p(sync),
-                               B, T, _stream()), 't2v_gru_bwd')
-        _err_note('GRU backward', sync[1:2])
+        dh = dh.contiguous()
+        for i, b0 in enumerate(range(0, B, MAX_DEC_B)):
+            b1 = min(B, b0 + MAX_DEC_B)
+            _check(lib.t2v_gru_bwd(_p(whh), _p(hs[b0:b1]), _p(gsave[b0:b1]), _p(dh[b0:b1]), _p(dgi[b0:b1]), _p(dgh[b0:b1]),
+                                   _p(xchg), _p(syncs[i]), b1 - b0, T, _stream()), 't2v_gru_bwd')
+            _err_note('GRU backward', syncs[i][1:2])
         dgi2, dgh2 = dgi.view(B * T, 768), dgh.view(B * T, 768)
         dx = gemm(dgi2, w_ih.t()).view(B, T, I)
         hprev = hs[:, :T].reshape(B * T, 256)

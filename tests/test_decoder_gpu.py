@@ -33,7 +33,11 @@ def _oracle(dec, memory, mels, lengths, wm, wg):
 
 @pytest.mark.parametrize("B,T_in,T_out,lens", [(3, 20, 12, [20, 17, 9]), (6, 84, 24, [84, 80, 71, 66, 50, 37]),
                                                (1, 33, 7, [33]), (2, 150, 6, [150, 97]),
-                                               (16, 40, 3, list(range(40, 24, -1))), (2, 256, 2, [256, 130]), (3, 17, 1, [17, 5, 1])])
+                                               (16, 40, 3, list(range(40, 24, -1))), (2, 256, 2, [256, 130]), (3, 17, 1, [17, 5, 1]),
+                                               # beyond the round-1 limits: koemo reaches 555 symbols (reference is
+                                               # unbounded, model.py:67-88); batches > 16 run as chunks
+                                               (2, 300, 4, [300, 211]), (2, 555, 3, [555, 290]), (1, 257, 2, [257]),
+                                               (20, 33, 3, list(range(33, 13, -1))), (2, 1000, 2, [1000, 700])])
 def test_decoder_core_matches_oracle(B, T_in, T_out, lens):
     hp, M, dec, memory, mels, lengths, wm, wg = _setup(B, T_in, T_out, lens)
     o_mel, o_gate, o_align, o_sd, o_mem = _oracle(dec, memory, mels, lengths, wm, wg)
@@ -88,6 +92,7 @@ def test_decoder_state_dropout_statistics_and_backward():
     hp, M, dec, memory, mels, lengths, wm, wg = _setup(6, 40, 30, [40] * 6)
     dev = torch.device('cuda:0')
     dec = dec.to(dev).train()
+    t2v_hip.DecoderCore.keep_last = True
     dec.p_attention_dropout = 0.5
     dec.p_decoder_dropout = 0.25
     grads = []
@@ -99,7 +104,7 @@ def test_decoder_state_dropout_statistics_and_backward():
         grads.append(mem.grad.clone())
     assert torch.isfinite(mel).all() and torch.isfinite(grads[0]).all()
     assert torch.equal(grads[0], grads[1])                  # same seed/call index ⇒ same masks in fwd and bwd
-    XS = t2v_hip.DecoderCore.last_call[3][13]               # (T+2,B,2560): [h_att | ctx | h_dec] rows
+    XS = t2v_hip.DecoderCore.last_call[3][4]                # (T+2,B,2560): [h_att | ctx | h_dec] rows
     h_att, h_dec = XS[1:31, :, :1024], XS[2:32, :, 1536:]
     assert abs((h_att == 0).float().mean().item() - 0.5) < 0.02
     assert abs((h_dec == 0).float().mean().item() - 0.25) < 0.02
@@ -111,27 +116,44 @@ def test_decoder_state_dropout_statistics_and_backward():
     dec.eval()
     with torch.no_grad():
         mel_e = dec(memory.to(dev), mels.to(dev), lengths.to(dev))[0]
-        XSe = t2v_hip.DecoderCore.last_call[3][13]
+        XSe = t2v_hip.DecoderCore.last_call[3][4]
+    t2v_hip.DecoderCore.keep_last = False
+    t2v_hip.DecoderCore.last_call = None
     assert (XSe[1:31, :, :1024] == 0).float().mean().item() < 0.01
 
 
-@pytest.mark.parametrize("B,T_in,T", [(6, 84, 40), (2, 37, 9), (3, 150, 5), (1, 256, 3)])
+@pytest.mark.parametrize("B,T_in,T", [(6, 84, 40), (2, 37, 9), (3, 150, 5), (1, 256, 3), (2, 555, 2)])
 def test_attn_wgrad_matches_torch(B, T_in, T):
-    """location_dense / location_conv weight gradients reduced over the whole pass vs the plain formula."""
+    """location_dense / location_conv weight gradients reduced over the whole pass through the fused filter bank
+    W_comb = dense·conv vs autograd through the unfused conv1d -> linear of the reference (model.py:24-28)."""
     import t2v_hip
     g = torch.Generator().manual_seed(B * 100 + T_in)
     dpre = torch.randn(T, B, T_in, 128, generator=g)
-    conv = torch.randn(T, B, 32, T_in, generator=g)
-    dc = torch.randn(T, B, 32, T_in, generator=g)
     al = torch.rand(T + 1, B, T_in, generator=g)
     acum = torch.rand(T + 1, B, T_in, generator=g) * 3
-    dd, dcv = t2v_hip.attn_wgrad(dpre.cuda(), conv.cuda(), dc.cuda(), al.cuda(), acum.cuda(), B, T_in, T)
-    ref_dense = torch.einsum('tbjd,tbfj->df', dpre.double(), conv.double())
-    apad = torch.nn.functional.pad(torch.stack((al[:T], acum[:T]), 2).double(), (15, 15))      # (T,B,2,T_in+30)
-    ref_conv = torch.einsum('tbfj,tbcjk->fck', dc.double(), apad.unfold(3, 31, 1))
+    conv_w = (torch.randn(32, 2, 31, generator=g) * 0.2)
+    dense_w = (torch.randn(128, 32, generator=g) * 0.3)
+    dd, dcv = t2v_hip.attn_wgrad(dpre.cuda(), al.cuda(), acum.cuda(), conv_w.cuda(), dense_w.cuda(), B, T_in, T)
+    cw = conv_w.double().requires_grad_(True)
+    dw = dense_w.double().requires_grad_(True)
+    cat = torch.stack((al[:T], acum[:T]), 2).double().reshape(T * B, 2, T_in)
+    loc = torch.nn.functional.conv1d(cat, cw, padding=15).transpose(1, 2) @ dw.t()        # (T*B, T_in, 128)
+    (loc * dpre.double().reshape(T * B, T_in, 128)).sum().backward()
     assert dd.shape == (128, 32) and dcv.shape == (32, 2, 31)
-    assert (dd.cpu().double() - ref_dense).abs().max().item() < 1e-4 * ref_dense.abs().max().item()
-    assert (dcv.cpu().double() - ref_conv).abs().max().item() < 1e-4 * ref_conv.abs().max().item()
+    assert (dd.cpu().double() - dw.grad).abs().max().item() < 1e-4 * dw.grad.abs().max().item()
+    assert (dcv.cpu().double() - cw.grad).abs().max().item() < 1e-4 * cw.grad.abs().max().item()
     # deterministic: fixed summation order
-    dd2, dcv2 = t2v_hip.attn_wgrad(dpre.cuda(), conv.cuda(), dc.cuda(), al.cuda(), acum.cuda(), B, T_in, T)
+    dd2, dcv2 = t2v_hip.attn_wgrad(dpre.cuda(), al.cuda(), acum.cuda(), conv_w.cuda(), dense_w.cuda(), B, T_in, T)
     assert torch.equal(dd, dd2) and torch.equal(dcv, dcv2)
+
+
+def test_fused_location_filter_matches_conv_then_dense():
+    """W_comb[d][32c+k] = sum_f dense[d][f] conv[f][c][k] (columns 31 / 63 zero)."""
+    import t2v_hip
+    g = torch.Generator().manual_seed(3)
+    conv_w, dense_w = torch.randn(32, 2, 31, generator=g), torch.randn(128, 32, generator=g)
+    wc = t2v_hip.fuse_location_weights(conv_w.cuda(), dense_w.cuda()).cpu()
+    ref = torch.einsum('df,fck->dck', dense_w.double(), conv_w.double())
+    assert wc.shape == (128, 64)
+    assert (wc.view(128, 2, 32)[:, :, :31].double() - ref).abs().max().item() < 1e-5
+    assert float(wc.view(128, 2, 32)[:, :, 31].abs().max()) == 0.0
