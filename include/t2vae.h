@@ -70,7 +70,7 @@ typedef struct t2v_dec_train_bufs {
     float* XS;    /* (T+2,B,2560) XS[t+1] = [h_att_t | ctx_t | h_dec_{t-1}]; row 0 = 0 */
     float* CA;    /* (T+1,B,1024) pre-dropout cell of attention_rnn; row 0 = 0 */
     float* CD;    /* (T+1,B,1024) pre-dropout cell of decoder_rnn;   row 0 = 0 */
-    float* GA;    /* (T,B,4096) gate activations i,f,g,o of attention_rnn */
+    float* GA;    /* (T,B,4096) gate activations i,f,g,o of attention_rnn; NULL (with GD, S) = forward only */
     float* GD;    /* (T,B,4096) gate activations of decoder_rnn */
     float* QP;    /* (t2v_decoder_qp_floats(B, T_in)) scratch: per-workgroup partial queries, sync / error words, the
                      decode loop's exchange area, then the attention kernel's energy-exchange granules */

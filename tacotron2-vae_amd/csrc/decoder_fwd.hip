@@ -300,8 +300,8 @@ static void fill_lstm_args(LstmFwdArgs& a, const t2v_dec_weights* w, const t2v_d
     a.ca_cur = s->CA + (size_t)(t + 1) * B * T2V_H;
     a.cd_prev = t >= 1 ? s->CD + (size_t)(t - 1) * B * T2V_H : nullptr;
     a.cd_cur = t >= 1 ? s->CD + (size_t)t * B * T2V_H : nullptr;
-    a.ga_t = t < T_out ? s->GA + (size_t)t * B * T2V_G : nullptr;
-    a.gd_t = t >= 1 ? s->GD + (size_t)(t - 1) * B * T2V_G : nullptr;
+    a.ga_t = (s->GA && t < T_out) ? s->GA + (size_t)t * B * T2V_G : nullptr;       // GA / GD NULL: forward only
+    a.gd_t = (s->GD && t >= 1) ? s->GD + (size_t)(t - 1) * B * T2V_G : nullptr;
     a.wqT = w->wqT;
     a.qp = s->QP;
     a.B = B;

@@ -264,7 +264,7 @@ class Decoder(nn.Module):
         self._calls += 1
         seed = (int(self.dropout_seed) * 1000003 + self._calls) & 0x7FFFFFFFFFFFFFFF
         hc, alignments = t2v_hip.DecoderCore.apply(gpre, memory, pm, lengths, *self._core_weights(),
-                                                   p_att, p_dec, seed)
+                                                   p_att, p_dec, seed, torch.is_grad_enabled())
         # linear_projection and gate_layer as ONE 81-column MFMA tile (reference model.py:385-388)
         w81 = torch.cat((self.linear_projection.weight, self.gate_layer.weight), 0)
         b81 = torch.cat((self.linear_projection.bias, self.gate_layer.bias), 0)

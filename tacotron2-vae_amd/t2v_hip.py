@@ -296,12 +296,14 @@ class DecoderCore(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, gpre, memory, pm, lengths, w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, bias_dec,
-                wq, loc_conv, loc_dense, v, p_att, p_dec, seed):
+                wq, loc_conv, loc_dense, v, p_att, p_dec, seed, grad_mode=True):
         lib = _require_gpu(gpre, memory, pm, w_ih_att)
         T, B, _ = gpre.shape
         T_in = memory.shape[1]
         gpre, memory, pm = _f32c(gpre), _f32c(memory), _f32c(pm)
-        need_grad = torch.is_grad_enabled() and any(ctx.needs_input_grad)
+        # grad_mode = torch.is_grad_enabled() of the CALLER (inside Function.forward it is always False): under
+        # no_grad (validate(), inference) nothing is saved and the backward-only buffers are not even allocated
+        need_grad = bool(grad_mode) and any(ctx.needs_input_grad)
         packs = pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, KATT, need_grad)
         wqT = wq.detach().t().contiguous()
         bias_dec = _f32c(bias_dec.detach())
@@ -397,7 +399,7 @@ class DecoderCore(torch.autograd.Function):
         d_memory = dmem_l[0] if len(dmem_l) == 1 else torch.cat(dmem_l, 0)
         d_pm = dpm_l[0] if len(dpm_l) == 1 else torch.cat(dpm_l, 0)
         return (DGA, d_memory, d_pm, None, d_w_ih_att, d_w_hh_att, d_w_ih_dec, d_w_hh_dec, d_bias_dec,
-                d_wq, d_loc_conv, d_loc_dense, d_v, None, None, None)
+                d_wq, d_loc_conv, d_loc_dense, d_v, None, None, None, None)
 
 
 def attn_wgrad(dpre, AL, ACUM, loc_conv, loc_dense, B, T_in, T):
