@@ -43,9 +43,12 @@ int t2v_pack_lstm_weights(const float* w_ih_att, const float* w_hh_att, const fl
                           float* packB_att, float* packB_dec, void* stream);
 
 /* LocationLayer (model.py:12-28) is a bias-free conv followed by a bias-free linear layer, i.e. ONE linear map of the
- * 2 x 31 alignment window.  wcomb (128,64): wcomb[d][32c + k] = sum_f loc_dense[d][f] * loc_conv[f][c][k] (k < 31;
- * columns 31 and 63 are zero).  The attention kernels evaluate the layer (and its backward) through this fused
- * filter bank; call once per pass after the weights changed. */
+ * 2 x 31 alignment window: W_comb[d][32c + k] = sum_f loc_dense[d][f] * loc_conv[f][c][k] (128 x 64; k < 31, columns
+ * 31 and 63 are zero).  The attention kernels evaluate the layer (and its backward) through this fused filter bank.
+ * wcomb: 2*128*64 floats, W_comb stored twice in the order the consuming lanes read it as float4 runs:
+ *   [0, 8192)      F[d][g][st]  = W_comb[d][4st + g]     (g < 4, st < 16)   forward
+ *   [8192, 16384)  R[kk][g][st] = W_comb[4st + g][kk]    (g < 4, st < 32)   backward
+ * Call once per pass after the weights changed. */
 int t2v_fuse_location_weights(const float* loc_conv, const float* loc_dense, float* wcomb, void* stream);
 
 typedef struct t2v_dec_weights {
@@ -56,7 +59,7 @@ typedef struct t2v_dec_weights {
     const float* bias_att;    /* (4096) bias_ih+bias_hh; used only when gpre == NULL */
     const float* bias_dec;    /* (4096) bias_ih+bias_hh */
     const float* wqT;         /* (1024,128) query_layer weight, transposed (model.py:35) */
-    const float* wcomb;       /* (128,64)   fused location filter bank (t2v_fuse_location_weights; model.py:17-22) */
+    const float* wcomb;       /* (2,128,64) fused location filter bank (t2v_fuse_location_weights; model.py:17-22) */
     const float* v;           /* (128)      attention v (model.py:39) */
 } t2v_dec_weights;
 

@@ -29,8 +29,11 @@ __device__ __forceinline__ t2v_u64 af_get(const t2v_u64* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// W_comb (128, 64): column 32c + k for channel c (0 = previous weights, 1 = cumulative weights), tap k < 31;
-// columns 31 and 63 are zero padding so that K = 64 = 16 MFMA k-steps.
+// W_comb (128, 64): column kk = 32c + k for channel c (0 = previous weights, 1 = cumulative weights), tap k < 31;
+// columns 31 and 63 are zero padding so that K = 64 = 16 MFMA k-steps.  Stored twice, each in the order the
+// consuming lanes read it as float4 runs (a lane's MFMA operands are kk = 4st + g resp. d = 4st + g):
+//   wc[0    .. 8192): forward  copy  F[d][g][st]  = W_comb[d][4st + g]        (g < 4, st < 16)
+//   wc[8192 .. 16384): backward copy R[kk][g][st] = W_comb[4st + g][kk]       (g < 4, st < 32)
 __global__ void k_loc_fuse(const float* __restrict__ conv, const float* __restrict__ dense, float* __restrict__ wc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;      // 128 * 64
     if (i >= T2V_A * 64) return;
@@ -38,7 +41,8 @@ __global__ void k_loc_fuse(const float* __restrict__ conv, const float* __restri
     float acc = 0.f;
     if (k < T2V_KS)
         for (int f = 0; f < T2V_F; ++f) acc = fmaf(dense[d * T2V_F + f], conv[(f * 2 + c) * T2V_KS + k], acc);
-    wc[i] = acc;
+    wc[d * 64 + (n & 3) * 16 + (n >> 2)] = acc;
+    wc[T2V_A * 64 + n * 128 + (d & 3) * 32 + (d >> 2)] = acc;
 }
 
 extern "C" int t2v_fuse_location_weights(const float* loc_conv, const float* loc_dense, float* wcomb, void* stream_) {
@@ -52,9 +56,8 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
     constexpr int TPAD = 16 * NJT;
     constexpr int NI = (NJT + 3) / 4;           // tiles per wave
     extern __shared__ __attribute__((aligned(16))) float eall[];     // Tcap energies -> attention weights
-    __shared__ float q[16];
     __shared__ float ap[2][TPAD + 32];
-    __shared__ float scr[64 * 16];          // 64 groups x 16 partial query sums; reused by the context reduction
+    __shared__ __attribute__((aligned(16))) float scr[AF_THREADS];   // per-wave query sums; reused by the context reduction
     __shared__ int ok_flag;
     const int b = blockIdx.x, s = blockIdx.y;          // s = attention-dim slice [16s,16s+16) and context chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -64,7 +67,19 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
     const int len = a.lengths ? a.lengths[b] : Tp;
 
     T2V_STAMP(a, 0);
-    // ---- entry: every global read that does not depend on the exchange is issued here
+    // ---- entry: every global read that does not depend on the exchange is issued here, in the order the results are
+    // needed (VMEM returns in order): alignment window and query partials first, the context operands last
+    if (tid == 0) ok_flag = 1;
+    float apv[(2 * (TPAD + 32) + AF_THREADS - 1) / AF_THREADS];
+#pragma unroll
+    for (int u = 0; u < (2 * (TPAD + 32) + AF_THREADS - 1) / AF_THREADS; ++u) {      // window index x <-> position x - 15
+        const int i = tid + AF_THREADS * u;
+        const int ch = i >= TPAD + 32 ? 1 : 0, x = i - ch * (TPAD + 32);
+        const int j = x - 15;
+        // unconditional load from a clamped address + select: a load inside a divergent branch costs a vmcnt(0)
+        const float av = (ch == 0 ? a.al_prev : a.acum_prev)[(size_t)b * Tp + min(max(j, 0), Tp - 1)];
+        apv[u] = av * ((i < 2 * (TPAD + 32) && j >= 0 && j < Tp) ? 1.f : 0.f);    // (a select would let the compiler sink the load back under the branch)
+    }
     // query partials of this slice: thread = (dq = tid&3 -> 4 consecutive d, wq = tid>>2 -> 4 source workgroups)
     float4 qpart[4];
     {
@@ -74,47 +89,58 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
     }
     // fused location filter rows of this slice as the MFMA A operand: A[d = 16s + c16][kk = 4st + g]
     float areg[16];
+    {
+        const float4* wp = (const float4*)(a.wcomb + (16 * s + c16) * 64 + 16 * g);      // forward copy: [d][g][st]
 #pragma unroll
-    for (int st = 0; st < 16; ++st) areg[st] = a.wcomb[(16 * s + c16) * 64 + 4 * st + g];
+        for (int u = 0; u < 4; ++u) {
+            const float4 w4 = wp[u];
+            areg[4 * u + 0] = w4.x; areg[4 * u + 1] = w4.y; areg[4 * u + 2] = w4.z; areg[4 * u + 3] = w4.w;
+        }
+    }
     const float4 vr = *(const float4*)(a.v + 16 * s + 4 * g);
     // pm in the energy-phase output layout: lane (g, c16) <-> d = 16s + 4g + r, position 16jt + c16;
     // wave w handles tiles jt = w, w+4, ..
     float4 pmr[NI];
-    constexpr int MR = 4 * NJT;
-    float memr[BIG ? 1 : MR];
+    float4 memr[BIG ? 1 : NJT];
     if constexpr (!BIG) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int j = 16 * (wave + 4 * i) + c16;
-            pmr[i] = j < Tp ? *(const float4*)(a.pm + ((size_t)b * Tp + j) * T2V_A + 16 * s + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pmr[i] = *(const float4*)(a.pm + ((size_t)b * Tp + min(j, Tp - 1)) * T2V_A + 16 * s + 4 * g);   // j >= T_in: unused
         }
-        // context operands: column chunk s (64 columns), thread = (col = tid&63, part = tid>>6), rows part, part+4, ..
-        const float* mb = a.memory + (size_t)b * Tp * T2V_E + 64 * s + (tid & 63);
+        // context operands: column chunk s (64 columns), thread = (column quad cq = tid&15, row group rg = tid>>4),
+        // rows rg, rg+16, ..: one float4 per row instead of four dword loads
+        const float4* mb = (const float4*)(a.memory + (size_t)b * Tp * T2V_E + 64 * s) + (tid & 15);
 #pragma unroll
-        for (int i = 0; i < MR; ++i) {
-            const int j = (tid >> 6) + 4 * i;
-            memr[i] = j < len ? mb[(size_t)j * T2V_E] : 0.f;
+        for (int i = 0; i < NJT; ++i) {
+            const int j = (tid >> 4) + 16 * i;
+            memr[i] = mb[(size_t)min(j, Tp - 1) * (T2V_E / 4)];      // rows >= len meet alpha = 0, rows >= T_in a zero factor
         }
     }
-    if (tid == 0) ok_flag = 1;
-    // alignment window of chunk 0: window index x <-> position x - 15
-    for (int i = tid; i < 2 * (TPAD + 32); i += AF_THREADS) {
-        const int ch = i / (TPAD + 32), x = i - ch * (TPAD + 32);
-        const int j = x - 15;
-        float v = 0.f;
-        if (j >= 0 && j < Tp) v = (ch == 0 ? a.al_prev : a.acum_prev)[(size_t)b * Tp + j];
-        ap[ch][x] = v;
+    __builtin_amdgcn_sched_barrier(0);      // keep the loads above in this order, ahead of everything below
+    T2V_STAMP(a, 6);
+#pragma unroll
+    for (int u = 0; u < (2 * (TPAD + 32) + AF_THREADS - 1) / AF_THREADS; ++u) {
+        const int i = tid + AF_THREADS * u;
+        if (i < 2 * (TPAD + 32)) (&ap[0][0])[i] = apv[u];
     }
-    // ---- 1. processed query slice: 64 groups of 4 partials, then 64 -> 1 through LDS (fixed order)
+    T2V_STAMP(a, 7);
+    // ---- 1. processed query slice: 4 source workgroups per thread; the four threads of a 16-lane row that share a
+    // d-quad are summed with two DPP row rotations (no LDS crossbar), the 16 row sums go through LDS (fixed order)
     {
         float4 s4 = qpart[0];
 #pragma unroll
         for (int i = 1; i < 4; ++i) { s4.x += qpart[i].x; s4.y += qpart[i].y; s4.z += qpart[i].z; s4.w += qpart[i].w; }
-        float* dst = scr + (tid >> 2) * 16 + 4 * (tid & 3);
-        dst[0] = s4.x; dst[1] = s4.y; dst[2] = s4.z; dst[3] = s4.w;
+        s4.x = T2V_DPP_ADD(s4.x, 0x124); s4.y = T2V_DPP_ADD(s4.y, 0x124);      // row_ror:4
+        s4.z = T2V_DPP_ADD(s4.z, 0x124); s4.w = T2V_DPP_ADD(s4.w, 0x124);
+        s4.x = T2V_DPP_ADD(s4.x, 0x128); s4.y = T2V_DPP_ADD(s4.y, 0x128);      // row_ror:8
+        s4.z = T2V_DPP_ADD(s4.z, 0x128); s4.w = T2V_DPP_ADD(s4.w, 0x128);
+        if ((lane & 15) < 4) *(float4*)(scr + (tid >> 4) * 16 + 4 * (lane & 3)) = s4;      // scr[row 0..15][16 d]
     }
+    T2V_STAMP(a, 8);
     __syncthreads();
-    // location features of this wave's tiles (independent of the query: issued before the reduction's barriers)
+    T2V_STAMP(a, 9);
+    // location features of this wave's tiles (independent of the query)
     f32x4 lacc[NI];
     if constexpr (!BIG) {
 #pragma unroll
@@ -130,26 +156,25 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
             }
         }
     }
-    {   // 64 -> 16 -> 1 in a fixed order
-        const int dd = tid & 15, grp = tid >> 4;
-        const float v4 = (scr[(4 * grp) * 16 + dd] + scr[(4 * grp + 1) * 16 + dd]) +
-                         (scr[(4 * grp + 2) * 16 + dd] + scr[(4 * grp + 3) * 16 + dd]);
-        __syncthreads();
-        scr[grp * 16 + dd] = v4;
-        __syncthreads();
-        if (tid < 16) {
-            float acc = 0.f;
+    T2V_STAMP(a, 10);
+    float4 q4;
+    {
+        float4 r[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc += scr[i * 16 + tid];
-            q[tid] = acc;
-        }
+        for (int u = 0; u < 16; ++u) r[u] = *(const float4*)(scr + 16 * u + 4 * g);
+#pragma unroll
+        for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+            for (int u = 0; u < w; ++u) {
+                r[u].x += r[u + w].x; r[u].y += r[u + w].y; r[u].z += r[u + w].z; r[u].w += r[u + w].w;
+            }
+        q4 = r[0];
     }
-    __syncthreads();
+    __syncthreads();        // scr is reused by the context reduction
 
     T2V_STAMP(a, 1);
     // ---- 2. location features (K = 64 fused filter) + partial energies of this d-slice, tile by tile
     t2v_u64* exb = a.ex + ((size_t)b * AF_NS + s) * Tcap;
-    const float4 q4 = make_float4(q[4 * g + 0], q[4 * g + 1], q[4 * g + 2], q[4 * g + 3]);
     for (int c0 = 0; c0 < Tp; c0 += TPAD) {
         if (BIG && c0 > 0) {
             __syncthreads();            // previous chunk's window fully consumed
@@ -210,6 +235,7 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
                 ok = ok && (unsigned)(x >> 32) == a.epoch;
             }
             if (ok) break;
+            __builtin_amdgcn_s_sleep(1);
             if (++spins > AF_SPIN_LIMIT || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                 __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok_flag = 0;
@@ -246,9 +272,9 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
     T2V_STAMP(a, 4);
     // ---- 4. context chunk s
     {
-        const int part = tid >> 6;
-        float acc0 = 0.f, acc1 = 0.f;
         if constexpr (BIG) {
+            const int part = tid >> 6;
+            float acc0 = 0.f, acc1 = 0.f;
             const float* mb = a.memory + (size_t)b * Tp * T2V_E + 64 * s + (tid & 63);
             int j = part;
             for (; j + 28 < len; j += 32) {          // 8 independent loads in flight per thread
@@ -262,19 +288,35 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
                 }
             }
             for (; j < len; j += 4) acc0 = fmaf(eall[j], mb[(size_t)j * T2V_E], acc0);
+            __syncthreads();
+            scr[tid] = acc0 + acc1;
+            __syncthreads();
+            if (tid < 64)
+                a.xs_next[(size_t)b * T2V_XW + T2V_H + 64 * s + tid] = (scr[tid] + scr[64 + tid]) + (scr[128 + tid] + scr[192 + tid]);
         } else {
+            // thread (cq, rg): partial context of columns 4cq..4cq+3 over rows rg + 16 i; 16 row groups through LDS
+            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int i = 0; i < MR; i += 2) {
-                const int ja = part + 4 * i, jb = ja + 4;
-                acc0 = fmaf(ja < Tp ? eall[ja] : 0.f, memr[i], acc0);
-                acc1 = fmaf(jb < Tp ? eall[jb] : 0.f, memr[i + 1], acc1);
+            for (int i = 0; i < NJT; ++i) {
+                const int j = (tid >> 4) + 16 * i;
+                const float al = j < Tp ? eall[j] : 0.f;
+                c4.x = fmaf(al, memr[i].x, c4.x); c4.y = fmaf(al, memr[i].y, c4.y);
+                c4.z = fmaf(al, memr[i].z, c4.z); c4.w = fmaf(al, memr[i].w, c4.w);
+            }
+            __shared__ __attribute__((aligned(16))) float cred[16][68];
+            *(float4*)&cred[tid >> 4][4 * (tid & 15)] = c4;
+            __syncthreads();
+            if (tid < 64) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = cred[u][tid];
+#pragma unroll
+                for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+                    for (int u = 0; u < w; ++u) v[u] += v[u + w];
+                a.xs_next[(size_t)b * T2V_XW + T2V_H + 64 * s + tid] = v[0];
             }
         }
-        __syncthreads();
-        scr[tid] = acc0 + acc1;
-        __syncthreads();
-        if (tid < 64)
-            a.xs_next[(size_t)b * T2V_XW + T2V_H + 64 * s + tid] = (scr[tid] + scr[64 + tid]) + (scr[128 + tid] + scr[192 + tid]);
     }
     T2V_STAMP(a, 5);
 }

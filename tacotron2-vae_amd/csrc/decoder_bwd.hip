@@ -98,7 +98,8 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& a, const int b,
 #pragma unroll
         for (int i = 0; i < JS / 2; ++i) {
             const int jl = jh + 2 * i;
-            sreg[i] = jl < nown ? sp[(size_t)jl * T2V_A] : 0.f;
+            const float sv = sp[(size_t)min(jl, nown - 1) * T2V_A];       // clamped address + select (no divergent-branch load)
+            sreg[i] = sv * (jl < nown ? 1.f : 0.f);
         }
     }
     float4 m0[JS / 4], m1[JS / 4];                         // this wave's memory rows (wave w: rows w, w+4, ..)
@@ -144,10 +145,16 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& a, const int b,
         dot_g = fmaf(al, gp + gc, dot_g);
     }
     // fused location filter, transposed, as the MFMA A operand of the location backward: wave w owns the (c,k)
-    // tile [16w, 16w+16): A[m = c16][kd = 4st + g] = W_comb[4st + g][16w + c16]
+    // tile [16w, 16w+16): A[m = c16][kd = 4st + g] = W_comb[4st + g][16w + c16] (read from the transposed copy)
     float areg[32];
+    {
+        const float4* wp = (const float4*)(a.wcomb + T2V_A * 64 + (16 * wave + c16) * 128 + 32 * g);   // backward copy [kk][g][st]
 #pragma unroll
-    for (int st = 0; st < 32; ++st) areg[st] = a.wcomb[(4 * st + g) * 64 + 16 * wave + c16];
+        for (int u = 0; u < 8; ++u) {
+            const float4 w4 = wp[u];
+            areg[4 * u + 0] = w4.x; areg[4 * u + 1] = w4.y; areg[4 * u + 2] = w4.z; areg[4 * u + 3] = w4.w;
+        }
+    }
     __syncthreads();
 
     T2V_STAMP(a, 1);
@@ -208,9 +215,12 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& a, const int b,
     // ---- through the fused location filter on MFMA: T[(c,k)][jl] = sum_d W_comb[d][(c,k)] dpre[jl][d], K = 128
 #pragma unroll
     for (int jt = 0; jt < NJT; ++jt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 ac4[4];
 #pragma unroll
-        for (int st = 0; st < 32; ++st) acc = mfma16x4(areg[st], dpT[4 * st + g][16 * jt + c16], acc);
+        for (int u = 0; u < 4; ++u) ac4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 32; ++st) ac4[st & 3] = mfma16x4(areg[st], dpT[4 * st + g][16 * jt + c16], ac4[st & 3]);
+        const f32x4 acc = (ac4[0] + ac4[1]) + (ac4[2] + ac4[3]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Tl[16 * wave + 4 * g + r][16 * jt + c16] = acc[r];
     }
@@ -222,13 +232,18 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& a, const int b,
     if (tid < 2 * 64) {
         const int c = tid >> 6, jj = tid & 63;
         if (jj < PW) {
-            float acc = 0.f;
+            float t[T2V_KS];
 #pragma unroll
-            for (int k = 0; k < T2V_KS; ++k) {
+            for (int k = 0; k < T2V_KS; ++k) {           // unconditional LDS reads (clamped address) + select
                 const int jl = jj - k;
-                if (jl >= 0 && jl < JS) acc += Tl[32 * c + k][jl];
+                const float tv = Tl[32 * c + k][min(max(jl, 0), JS - 1)];
+                t[k] = (jl >= 0 && jl < JS) ? tv : 0.f;
             }
-            a.GP_out[(((size_t)b * S + s) * 2 + c) * 64 + jj] = acc;
+            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+#pragma unroll
+            for (int k = 0; k + 3 < T2V_KS; k += 4) { acc0 += t[k]; acc1 += t[k + 1]; acc2 += t[k + 2]; acc3 += t[k + 3]; }
+            acc0 += t[28]; acc1 += t[29]; acc2 += t[30];
+            a.GP_out[(((size_t)b * S + s) * 2 + c) * 64 + jj] = (acc0 + acc1) + (acc2 + acc3);
         }
     }
     T2V_STAMP(a, 5);
@@ -237,6 +252,7 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& a, const int b,
 // 64 workgroups x 256 threads; thread = (unit U, item b).  Inside the merged launch the decoder_rnn(t-1) part and
 // all operand fetches run while the attention workgroups are still busy; only the W_q^T·dq term waits: the partial
 // dq rows arrive as tagged granules and are polled directly (bounded).
+template <int NPP>
 __device__ __forceinline__ void cell_bwd_body(const CellBwdArgs& a, const int cblk) {
     __shared__ __attribute__((aligned(16))) float wqs[16][T2V_A + 4];
     __shared__ __attribute__((aligned(16))) float dqs[16][T2V_A + 4];
@@ -247,6 +263,8 @@ __device__ __forceinline__ void cell_bwd_body(const CellBwdArgs& a, const int cb
     const uint32_t idx = (uint32_t)b * T2V_H + U;
     const size_t bu = (size_t)b * T2V_H + U;
     if (tid == 0) cell_ok = 1;
+#define CELL_STAMP(I) do { if (a.prof && tid == 0 && cblk == 0) a.prof[(I)] = __builtin_readcyclecounter(); } while (0)
+    CELL_STAMP(0);
     // everything this thread needs from global memory is requested up front (one latency round)
     float yd0 = 0.f, ya0 = 0.f, ga[4] = {0, 0, 0, 0}, cac = 0.f, cap = 0.f, dca = 0.f;
     float hcp = 0.f, yd1 = 0.f, gd[4] = {0, 0, 0, 0}, cdc = 0.f, cdp = 0.f, dcd = 0.f;
@@ -292,37 +310,77 @@ __device__ __forceinline__ void cell_bwd_body(const CellBwdArgs& a, const int cb
     }
     if (!a.do_att) return;
     __syncthreads();       // cell_ok initialised, wqs staged
+    CELL_STAMP(1);
     // ---- gather the attention workgroups' partial dq rows (granules, polled until tagged), fixed-order sum
-    for (int i = tid; i < a.B * T2V_A; i += 256) {
-        const int bb = i >> 7, dd = i & (T2V_A - 1);
-        const t2v_u64* gq = a.DQ_t + (size_t)bb * a.S * T2V_A + dd;
-        float tot = 0.f;
+    // ONE wave polls one sentinel granule per publishing wave (dims 0 and 64 of every slice row) with s_sleep between
+    // rounds; the other 255 threads of every cell workgroup stay off the memory system until the rows have landed
+    // (hundreds of pollers next to the latency-bound attention workgroups slowed the whole launch by ~2 us)
+    if (tid < 64) {
+        const int nsent = 2 * a.B * a.S;
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+            for (int i = tid; i < nsent; i += 64) {
+                const t2v_u64 x = __hip_atomic_load(a.DQ_t + (size_t)(i >> 1) * T2V_A + 64 * (i & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && (unsigned)(x >> 32) == 1u;
+            }
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > ATB_SPIN_LIMIT || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cell_ok = 0;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (!cell_ok) return;
+    CELL_STAMP(2);
+    {
+        // thread -> (item, dim) pairs i = tid + 256 p, p < NPP (NPP = pairs per thread rounded up to 1/2/4/8), eight
+        // slices per round; every load is unconditional (clamped address) so that all NPP x 8 are in flight at once —
+        // loads inside divergent branches get a vmcnt(0) each and ran one round trip at a time
+        const int npair = a.B * T2V_A;
+        float tot[NPP];
+#pragma unroll
+        for (int p = 0; p < NPP; ++p) tot[p] = 0.f;
         for (int s0 = 0; s0 < a.S; s0 += 8) {
-            float pv[8];
+            float pv[NPP][8];
             unsigned spins = 0;
             for (;;) {
                 bool ok = true;
 #pragma unroll
-                for (int sl = 0; sl < 8; ++sl) {
-                    pv[sl] = 0.f;
-                    if (s0 + sl < a.S) {
-                        const t2v_u64 x = __hip_atomic_load(gq + (size_t)(s0 + sl) * T2V_A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        pv[sl] = __uint_as_float((unsigned)x);
+                for (int p = 0; p < NPP; ++p) {
+                    const int i = min(tid + 256 * p, npair - 1);
+                    const t2v_u64* gq = a.DQ_t + (size_t)(i >> 7) * a.S * T2V_A + (i & (T2V_A - 1));
+#pragma unroll
+                    for (int sl = 0; sl < 8; ++sl) {
+                        const bool live = s0 + sl < a.S;
+                        const t2v_u64 x = __hip_atomic_load(gq + (size_t)(live ? s0 + sl : a.S - 1) * T2V_A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pv[p][sl] = live ? __uint_as_float((unsigned)x) : 0.f;
                         ok = ok && (unsigned)(x >> 32) == 1u;
                     }
                 }
                 if (ok) break;
+                __builtin_amdgcn_s_sleep(1);
                 if (++spins > ATB_SPIN_LIMIT || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     cell_ok = 0;
                     break;
                 }
             }
-            tot += ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
+#pragma unroll
+            for (int p = 0; p < NPP; ++p)
+                tot[p] += ((pv[p][0] + pv[p][1]) + (pv[p][2] + pv[p][3])) + ((pv[p][4] + pv[p][5]) + (pv[p][6] + pv[p][7]));
         }
-        dqs[bb][dd] = tot;
+#pragma unroll
+        for (int p = 0; p < NPP; ++p) {
+            const int i = tid + 256 * p;
+            if (i < npair) dqs[i >> 7][i & (T2V_A - 1)] = tot[p];
+        }
     }
     __syncthreads();
+    CELL_STAMP(3);
     if (!cell_ok || !bv) return;
     {
         const int t = a.t;
@@ -353,14 +411,23 @@ __device__ __forceinline__ void cell_bwd_body(const CellBwdArgs& a, const int cb
         o[3 * T2V_H] = dht * tc * go * (1.0f - go);
         a.DCA[bu] = dct * gf;
     }
+    CELL_STAMP(4);
 }
 
 // One launch per reverse step: workgroups [0, B*S) = attention backward slices, then 64 cell-backward workgroups.
-template <int JS>
+template <int JS, int NPP>
 __global__ __launch_bounds__(256) void k_attn_cell_bwd(AttnBwdArgs a, CellBwdArgs c, int nattn, int S) {
     const int blk = blockIdx.x;
     if (blk < nattn) attn_bwd_body<JS>(a, blk / S, blk % S, S);
-    else cell_bwd_body(c, blk - nattn);
+    else cell_bwd_body<NPP>(c, blk - nattn);
+}
+template <int JS>
+static void launch_attn_cell_bwd(const AttnBwdArgs& fa, const CellBwdArgs& c, int nattn, int S, int B, size_t lds, hipStream_t stream) {
+    const dim3 grid(nattn + T2V_H / 16);
+    if (B <= 2) k_attn_cell_bwd<JS, 1><<<grid, 256, lds, stream>>>(fa, c, nattn, S);
+    else if (B <= 4) k_attn_cell_bwd<JS, 2><<<grid, 256, lds, stream>>>(fa, c, nattn, S);
+    else if (B <= 8) k_attn_cell_bwd<JS, 4><<<grid, 256, lds, stream>>>(fa, c, nattn, S);
+    else k_attn_cell_bwd<JS, 8><<<grid, 256, lds, stream>>>(fa, c, nattn, S);
 }
 
 extern "C" int t2v_attn_bwd_slices(int T_in) { return T_in < 1 ? 0 : t2v_attn_bwd_slices_(T_in); }
@@ -446,9 +513,10 @@ extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_tra
         c.p_dec = p_dec;
         c.seed = seed;
         c.err = sync + 1;
+        c.prof = g_t2v_prof ? g_t2v_prof + 24 : nullptr;
         const int nattn = have_attn ? B * S : 0;
-        if (JS == 16) k_attn_cell_bwd<16><<<nattn + T2V_H / 16, 256, lds, stream>>>(fa, c, nattn, S);
-        else k_attn_cell_bwd<32><<<nattn + T2V_H / 16, 256, lds, stream>>>(fa, c, nattn, S);
+        if (JS == 16) launch_attn_cell_bwd<16>(fa, c, nattn, S, B, lds, stream);
+        else launch_attn_cell_bwd<32>(fa, c, nattn, S, B, lds, stream);
     }
     return t2v_check_launch();
 }

@@ -126,4 +126,5 @@ struct CellBwdArgs {
     float p_att, p_dec;
     uint64_t seed;
     unsigned* err;          // error word (bounded-spin timeout)
+    unsigned long long* prof;   // optional phase stamps of cell workgroup 0 (t2v_set_phase_profile slots 24..28)
 };

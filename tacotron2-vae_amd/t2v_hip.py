@@ -250,9 +250,11 @@ def pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, k_att, need_bwd
 
 
 def fuse_location_weights(loc_conv, loc_dense):
-    """(128,64) fused filter bank of LocationLayer (conv then dense, both bias-free: one linear map)."""
+    """Fused filter bank of LocationLayer (conv then dense, both bias-free: one linear map), W_comb (128,64) stored
+    twice in the orders the forward / backward kernels read it: [0] = F[d][g][st] = W_comb[d][4st+g],
+    [1] viewed (64,4,32) = R[kk][g][st] = W_comb[4st+g][kk]."""
     lib = load_library()
-    wcomb = torch.empty(A, 64, device=loc_conv.device, dtype=torch.float32)
+    wcomb = torch.empty(2, A, 64, device=loc_conv.device, dtype=torch.float32)
     _check(lib.t2v_fuse_location_weights(_p(loc_conv), _p(loc_dense), _p(wcomb), _stream()), 't2v_fuse_location_weights')
     return wcomb
 

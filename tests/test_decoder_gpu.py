@@ -153,7 +153,11 @@ def test_fused_location_filter_matches_conv_then_dense():
     g = torch.Generator().manual_seed(3)
     conv_w, dense_w = torch.randn(32, 2, 31, generator=g), torch.randn(128, 32, generator=g)
     wc = t2v_hip.fuse_location_weights(conv_w.cuda(), dense_w.cuda()).cpu()
-    ref = torch.einsum('df,fck->dck', dense_w.double(), conv_w.double())
-    assert wc.shape == (128, 64)
-    assert (wc.view(128, 2, 32)[:, :, :31].double() - ref).abs().max().item() < 1e-5
-    assert float(wc.view(128, 2, 32)[:, :, 31].abs().max()) == 0.0
+    ref = torch.zeros(128, 64, dtype=torch.float64)
+    ref.view(128, 2, 32)[:, :, :31] = torch.einsum('df,fck->dck', dense_w.double(), conv_w.double())
+    assert wc.shape == (2, 128, 64)
+    fwd = wc[0].view(128, 4, 16).permute(0, 2, 1).reshape(128, 64)            # F[d][g][st] -> W[d][4st+g]
+    bwd = wc[1].view(64, 4, 32).permute(2, 1, 0).reshape(128, 64)             # R[kk][g][st] -> W[4st+g][kk]
+    assert (fwd.double() - ref).abs().max().item() < 1e-5
+    assert torch.equal(fwd, bwd)
+    assert float(fwd.view(128, 2, 32)[:, :, 31].abs().max()) == 0.0

@@ -1,10 +1,12 @@
-set -x
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+# usage: bash tools/round_profile.sh <tag>   (on the GPU box) -> gpurun_out/<tag>_*.{csv,txt}
+TAG=${1:-r02}
 mkdir -p gpurun_out
-cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r01 -- python /root/repo/bench.py --steps 8 --warmup 3 > /tmp/prof_bench.log 2>&1
-tail -1 /tmp/prof_bench.log | cut -c1-200
-ST=$(find /tmp/prof -name '*kernel_stats.csv' | head -1); KT=$(find /tmp/prof -name '*kernel_trace.csv' | head -1)
-cp "$ST" /root/repo/gpurun_out/r01_bench_kernel_stats.csv
-python /root/repo/tools/steady_profile.py "$KT" 6 40 > /root/repo/gpurun_out/r01_steady_state.txt
-cd /root/repo && timeout 300 python bench.py > gpurun_out/r01_bench_line.json 2>gpurun_out/bench_err.log; tail -c 600 gpurun_out/r01_bench_line.json
+export TMPDIR=/tmp
+REPO=$(pwd)
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python $REPO/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-decode > /tmp/prof_bench_$TAG.log 2>&1
+tail -1 /tmp/prof_bench_$TAG.log | cut -c1-300
+ST=$(find /tmp/prof_$TAG -name '*kernel_stats.csv' | head -1); KT=$(find /tmp/prof_$TAG -name '*kernel_trace.csv' | head -1)
+cp "$ST" $REPO/gpurun_out/${TAG}_bench_kernel_stats.csv
+python $REPO/tools/steady_profile.py "$KT" 6 45 > $REPO/gpurun_out/${TAG}_steady_state.txt
+cd $REPO
