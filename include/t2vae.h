@@ -28,6 +28,20 @@ const char* t2v_last_error(void);
  * their phase boundaries (forward slots 0..7, backward 16..23); NULL (default) disables it. */
 void t2v_set_phase_profile(unsigned long long* dev_buf32);
 
+/* Per-step parameters in DEVICE memory (optional).  Kernel arguments are frozen when a training step is captured
+ * into a HIP graph; this 32-byte record is read by the kernels at run time instead, so every replay gets fresh
+ * dropout masks (epoch is mixed into every dropout seed: seed + epoch * 0x9E3779B97F4A7C15), the right Adam bias
+ * corrections / learning rate and KL weight.  NULL (default): the by-value arguments of each call are used. */
+typedef struct t2v_step_params {
+    uint64_t epoch;      /* training iteration */
+    float lr;            /* Adam step size (train.py:209-210 sets it every iteration) */
+    float bc1;           /* 1 - beta1^t */
+    float bc2s;          /* sqrt(1 - beta2^t) */
+    float kl_weight;     /* loss_function.py:15-24 */
+    float pad[2];
+} t2v_step_params;
+void t2v_set_step_params(const t2v_step_params* dev);
+
 /* ------------------------------------------------------------------ weight packing
  * Re-lays the two decoder LSTM cells' weights into MFMA-fragment order for the per-step
  * weight-streaming kernels.  Replaces nothing in the reference (cuDNN/cuBLAS choose their own
@@ -263,10 +277,12 @@ int t2v_loss_fwd_bwd(const float* mel, const float* post, const float* mel_t, co
  * Adam built at train.py:171-172) fused over one flat fp32 arena.  `grads` holds the SUM over
  * ranks after the all-reduce; inv_world = 1/world_size applies the averaging of
  * distributed.py:162.  partials: (1024) scratch; norm_out[0] receives the pre-clip global
- * L2 norm (the value the reference logs as grad.norm).  All four arenas 16-byte aligned. */
+ * L2 norm (the value the reference logs as grad.norm).  All four arenas 16-byte aligned.
+ * bc1 = 1 - beta1^t, bc2 = 1 - beta2^t (the caller computes them in double like torch.optim.Adam); with
+ * t2v_set_step_params installed, lr / bc1 / sqrt(bc2) come from the device record instead. */
 int t2v_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, uint64_t n,
                        float lr, float beta1, float beta2, float eps, float weight_decay,
-                       float max_norm, float inv_world, int step, float* partials,
+                       float max_norm, float inv_world, float bc1, float bc2, float* partials,
                        float* norm_out, void* stream);
 
 /* ------------------------------------------------------------------ STFT -> mel front end

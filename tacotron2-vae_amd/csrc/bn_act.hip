@@ -28,6 +28,7 @@ struct BnFwdArgs {
     int B, M, T, act, training;
     float p_drop, momentum, eps;
     uint64_t seed; uint32_t rng_stream, rng_t;
+    const t2v_step_params* step;
 };
 
 #define BN_NE 12      // fast path: channels of up to 256*12 values are held in registers
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(BnFwdArgs a) {
                 float z = fmaf(yv[e], g, bt);
                 if (a.act == ACT_TANH) z = tanhf_(z);
                 else if (a.act == ACT_RELU) z = fmaxf(z, 0.f);
-                if (a.training && a.p_drop > 0.f) z *= t2v_drop_scale(a.seed, a.rng_stream, a.rng_t, (uint32_t)off[e], a.p_drop);
+                if (a.training && a.p_drop > 0.f) z *= t2v_drop_scale(t2v_step_seed(a.seed, a.step), a.rng_stream, a.rng_t, (uint32_t)off[e], a.p_drop);
                 a.out[off[e]] = z;
             }
         }
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(BnFwdArgs a) {
             float z = fmaf(a.y[base + t], g, bt);
             if (a.act == ACT_TANH) z = tanhf_(z);
             else if (a.act == ACT_RELU) z = fmaxf(z, 0.f);
-            if (a.training && a.p_drop > 0.f) z *= t2v_drop_scale(a.seed, a.rng_stream, a.rng_t, (uint32_t)(base + t), a.p_drop);
+            if (a.training && a.p_drop > 0.f) z *= t2v_drop_scale(t2v_step_seed(a.seed, a.step), a.rng_stream, a.rng_t, (uint32_t)(base + t), a.p_drop);
             a.out[base + t] = z;
         }
     }
@@ -129,13 +130,14 @@ struct BnBwdArgs {
     int B, M, T, act;
     float p_drop;
     uint64_t seed; uint32_t rng_stream, rng_t;
+    const t2v_step_params* step;
 };
 
 __device__ __forceinline__ float bn_dz(const BnBwdArgs& a, size_t idx, float g, float bt, float& xhat, float mean, float rstd) {
     const float yv = a.y[idx];
     xhat = (yv - mean) * rstd;
     float d = a.dout[idx];
-    if (a.p_drop > 0.f) d *= t2v_drop_scale(a.seed, a.rng_stream, a.rng_t, (uint32_t)idx, a.p_drop);
+    if (a.p_drop > 0.f) d *= t2v_drop_scale(t2v_step_seed(a.seed, a.step), a.rng_stream, a.rng_t, (uint32_t)idx, a.p_drop);
     const float z = fmaf(yv, g, bt);
     if (a.act == ACT_TANH) { const float th = tanhf_(z); d *= 1.0f - th * th; }
     else if (a.act == ACT_RELU) { d = z > 0.f ? d : 0.f; }
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd(BnBwdArgs a) {
         for (int e = 0; e < BN_NE; ++e) {
             float d = dv[e];
             xh[e] = (yv[e] - mean) * rstd;
-            if (a.p_drop > 0.f) d *= t2v_drop_scale(a.seed, a.rng_stream, a.rng_t, (uint32_t)off[e], a.p_drop);
+            if (a.p_drop > 0.f) d *= t2v_drop_scale(t2v_step_seed(a.seed, a.step), a.rng_stream, a.rng_t, (uint32_t)off[e], a.p_drop);
             const float z = fmaf(yv[e], g, bt);
             if (a.act == ACT_TANH) { const float th = tanhf_(z); d *= 1.0f - th * th; }
             else if (a.act == ACT_RELU) { d = z > 0.f ? d : 0.f; }
@@ -221,7 +223,7 @@ extern "C" int t2v_bn_act_fwd(const float* y, const float* stat_part, int nblk, 
     a.y = y; a.stat_part = stat_part; a.nblk = nblk; a.gamma = gamma; a.beta = beta;
     a.running_mean = running_mean; a.running_var = running_var; a.mean_out = mean_out; a.rstd_out = rstd_out;
     a.out = out; a.B = B; a.M = M; a.T = T; a.act = act; a.training = training; a.p_drop = p_drop;
-    a.momentum = momentum; a.eps = eps; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t;
+    a.momentum = momentum; a.eps = eps; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = g_t2v_step;
     k_bn_act_fwd<<<M, 256, 0, stream>>>(a);
     return t2v_check_launch();
 }
@@ -235,7 +237,7 @@ extern "C" int t2v_bn_act_bwd(const float* y, const float* dout, const float* me
     BnBwdArgs a;
     a.y = y; a.dout = dout; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.dy = dy;
     a.dgamma = dgamma; a.dbeta = dbeta; a.B = B; a.M = M; a.T = T; a.act = act; a.p_drop = p_drop;
-    a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t;
+    a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = g_t2v_step;
     k_bn_act_bwd<<<M, 256, 0, stream>>>(a);
     return t2v_check_launch();
 }

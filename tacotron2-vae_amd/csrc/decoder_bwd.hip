@@ -262,6 +262,7 @@ __device__ __forceinline__ void cell_bwd_body(const CellBwdArgs& a, const int cb
     const bool bv = b < a.B;
     const uint32_t idx = (uint32_t)b * T2V_H + U;
     const size_t bu = (size_t)b * T2V_H + U;
+    const uint64_t seed = t2v_step_seed(a.seed, a.step);
     if (tid == 0) cell_ok = 1;
 #define CELL_STAMP(I) do { if (a.prof && tid == 0 && cblk == 0) a.prof[(I)] = __builtin_readcyclecounter(); } while (0)
     CELL_STAMP(0);
@@ -293,14 +294,14 @@ __device__ __forceinline__ void cell_bwd_body(const CellBwdArgs& a, const int cb
     if (a.do_dec && bv) {
         const int td = a.t - 1;
         const float dh = hcp + yd1;
-        const float fh = t2v_drop_scale(a.seed, T2V_RNG_DEC_H, td, idx, a.p_dec);
-        const float fc = t2v_drop_scale(a.seed, T2V_RNG_DEC_C, td, idx, a.p_dec);
+        const float fh = t2v_drop_scale(seed, T2V_RNG_DEC_H, td, idx, a.p_dec);
+        const float fc = t2v_drop_scale(seed, T2V_RNG_DEC_C, td, idx, a.p_dec);
         const float gi = gd[0], gf = gd[1], gg = gd[2], go = gd[3];
         const float tc = tanhf_(cdc);
         const float dht = dh * fh;
         const float dct = dcd * fc + dht * go * (1.0f - tc * tc);
         float cprev = cdp;
-        if (td > 0) cprev *= t2v_drop_scale(a.seed, T2V_RNG_DEC_C, td - 1, idx, a.p_dec);
+        if (td > 0) cprev *= t2v_drop_scale(seed, T2V_RNG_DEC_C, td - 1, idx, a.p_dec);
         float* o = a.DGD_p + (size_t)b * T2V_G + U;
         o[0] = dct * gg * gi * (1.0f - gi);
         o[T2V_H] = dct * cprev * gf * (1.0f - gf);
@@ -396,14 +397,14 @@ __device__ __forceinline__ void cell_bwd_body(const CellBwdArgs& a, const int cb
             dot1 = fmaf(wv.w, qv.w, dot1);
         }
         const float dh = yd0 + ya0 + (dot0 + dot1);
-        const float fh = t2v_drop_scale(a.seed, T2V_RNG_ATT_H, t, idx, a.p_att);
-        const float fc = t2v_drop_scale(a.seed, T2V_RNG_ATT_C, t, idx, a.p_att);
+        const float fh = t2v_drop_scale(seed, T2V_RNG_ATT_H, t, idx, a.p_att);
+        const float fc = t2v_drop_scale(seed, T2V_RNG_ATT_C, t, idx, a.p_att);
         const float gi = ga[0], gf = ga[1], gg = ga[2], go = ga[3];
         const float tc = tanhf_(cac);
         const float dht = dh * fh;
         const float dct = dca * fc + dht * go * (1.0f - tc * tc);
         float cprev = cap;
-        if (t > 0) cprev *= t2v_drop_scale(a.seed, T2V_RNG_ATT_C, t - 1, idx, a.p_att);
+        if (t > 0) cprev *= t2v_drop_scale(seed, T2V_RNG_ATT_C, t - 1, idx, a.p_att);
         float* o = a.DGA_t + (size_t)b * T2V_G + U;
         o[0] = dct * gg * gi * (1.0f - gi);
         o[T2V_H] = dct * cprev * gf * (1.0f - gf);
@@ -512,6 +513,7 @@ extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_tra
         c.p_att = p_att;
         c.p_dec = p_dec;
         c.seed = seed;
+        c.step = g_t2v_step;
         c.err = sync + 1;
         c.prof = g_t2v_prof ? g_t2v_prof + 24 : nullptr;
         const int nattn = have_attn ? B * S : 0;

@@ -143,6 +143,7 @@ __device__ __forceinline__ void lstm256_stream(const float4* pa, const float4* p
 }
 
 __global__ __launch_bounds__(256) void k_lstm_fwd256(LstmFwdArgs a) {
+    const uint64_t seed = t2v_step_seed(a.seed, a.step);
     const int w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = lane & 15, g = lane >> 4;
     const bool bvalid = b < a.B;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void k_lstm_fwd256(LstmFwdArgs a) {
         const float gi = sigmoidf_(s[0] + addv[0]), gf = sigmoidf_(s[1] + addv[1]);
         const float gg = tanhf_(s[2] + addv[2]), go = sigmoidf_(s[3] + addv[3]);
         const uint32_t idx = (uint32_t)b * T2V_H + U;
-        if (tt > 0) cprev *= t2v_drop_scale(a.seed, st_c, tt - 1, idx, p);
+        if (tt > 0) cprev *= t2v_drop_scale(seed, st_c, tt - 1, idx, p);
         const float c = gf * cprev + gi * gg;
         const float h = go * tanhf_(c);
         (which == 0 ? a.ca_cur : a.cd_cur)[(size_t)b * T2V_H + U] = c;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void k_lstm_fwd256(LstmFwdArgs a) {
             gsave[(size_t)b * T2V_G + 2 * T2V_H + U] = gg;
             gsave[(size_t)b * T2V_G + 3 * T2V_H + U] = go;
         }
-        const float hd = h * t2v_drop_scale(a.seed, st_h, tt, idx, p);
+        const float hd = h * t2v_drop_scale(seed, st_h, tt, idx, p);
         a.xs_next[(size_t)b * T2V_XW + (which == 0 ? U : T2V_KATT + U)] = hd;
         if (which == 0) hs[b][g] = hd;
     }
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(256) void k_lstm_fwd256(LstmFwdArgs a) {
 // rounds of 7); ATT = false: decoder_rnn (160 k-blocks: 40 per wave, 5 rounds of 8).
 template <bool ATT>
 __global__ __launch_bounds__(256) void k_lstm_one256(LstmFwdArgs a) {
+    const uint64_t seed = a.seed;       // decode loop: eval mode, state dropout off
     constexpr int RN = ATT ? 7 : 8, NR = ATT ? 4 : 5, KBW = RN * NR;
     const int w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = lane & 15, g = lane >> 4;
@@ -267,11 +269,11 @@ __global__ __launch_bounds__(256) void k_lstm_one256(LstmFwdArgs a) {
         const float gi = sigmoidf_(s[0] + addv[0]), gf = sigmoidf_(s[1] + addv[1]);
         const float gg = tanhf_(s[2] + addv[2]), go = sigmoidf_(s[3] + addv[3]);
         const uint32_t idx = (uint32_t)b * T2V_H + U;
-        if (tt > 0) cprev *= t2v_drop_scale(a.seed, ATT ? T2V_RNG_ATT_C : T2V_RNG_DEC_C, tt - 1, idx, p);
+        if (tt > 0) cprev *= t2v_drop_scale(seed, ATT ? T2V_RNG_ATT_C : T2V_RNG_DEC_C, tt - 1, idx, p);
         const float c = gf * cprev + gi * gg;
         const float h = go * tanhf_(c);
         (ATT ? a.ca_cur : a.cd_cur)[(size_t)b * T2V_H + U] = c;
-        const float hd = h * t2v_drop_scale(a.seed, ATT ? T2V_RNG_ATT_H : T2V_RNG_DEC_H, tt, idx, p);
+        const float hd = h * t2v_drop_scale(seed, ATT ? T2V_RNG_ATT_H : T2V_RNG_DEC_H, tt, idx, p);
         a.xs_next[(size_t)b * T2V_XW + (ATT ? U : T2V_KATT + U)] = hd;
         if (ATT) hs[b][g] = hd;
     }
@@ -311,6 +313,7 @@ static void fill_lstm_args(LstmFwdArgs& a, const t2v_dec_weights* w, const t2v_d
     a.p_att = p_att;
     a.p_dec = p_dec;
     a.seed = seed;
+    a.step = g_t2v_step;
 }
 
 // mask bits: 1 = k_lstm_fwd256 (both cells), 2 = k_attn_fwd

@@ -168,6 +168,7 @@ extern "C" int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_i
         a.p_att = 0.f;      // eval mode: no state dropout (F.dropout(..., self.training))
         a.p_dec = 0.f;
         a.seed = seed;
+        a.step = nullptr;
         // attention_rnn(t): XS[t] -> XS[t+1][0:1024]
         a.xs_prev = s->XS + (size_t)t * B * T2V_XW;
         a.xs_next = s->XS + (size_t)(t + 1) * B * T2V_XW;

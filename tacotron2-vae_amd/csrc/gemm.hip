@@ -20,6 +20,7 @@ struct GemmArgs {
     int M, N, K, ldc;
     int relu, accumulate;
     float p_drop; uint64_t seed; uint32_t rng_stream, rng_t;
+    const t2v_step_params* step;
 };
 
 template <bool A_KC, bool B_KC>   // operand contiguous along k?
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
                 float v = acc[r] + bv;
                 if (a.accumulate) v += a.C[idx];
                 if (a.relu) v = fmaxf(v, 0.f);
-                if (a.p_drop > 0.f) v *= t2v_drop_scale(a.seed, a.rng_stream, a.rng_t, (uint32_t)idx, a.p_drop);
+                if (a.p_drop > 0.f) v *= t2v_drop_scale(t2v_step_seed(a.seed, a.step), a.rng_stream, a.rng_t, (uint32_t)idx, a.p_drop);
                 a.C[idx] = v;
             }
         }
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
                 float v = acc[r] + bv;
                 if (a.accumulate) v += a.C[idx];
                 if (a.relu) v = fmaxf(v, 0.f);
-                if (a.p_drop > 0.f) v *= t2v_drop_scale(a.seed, a.rng_stream, a.rng_t, (uint32_t)idx, a.p_drop);
+                if (a.p_drop > 0.f) v *= t2v_drop_scale(t2v_step_seed(a.seed, a.step), a.rng_stream, a.rng_t, (uint32_t)idx, a.p_drop);
                 a.C[idx] = v;
             }
         }
@@ -181,7 +182,7 @@ extern "C" int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B,
     GemmArgs a;
     a.A = A; a.B = B; a.bias = bias; a.C = C; a.sAi = sAi; a.sAk = sAk; a.sBj = sBj; a.sBk = sBk;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
-    a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t;
+    a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = g_t2v_step;
     dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM);
     const bool akc = sAk == 1, bkc = sBk == 1;
     if (akc && bkc) k_gemm_bf16<true, true><<<grid, 256, 0, stream>>>(a);
@@ -199,7 +200,7 @@ extern "C" int t2v_gemm_f32(const float* A, long sAi, long sAk, const float* B, 
     GemmArgs a;
     a.A = A; a.B = B; a.bias = bias; a.C = C; a.sAi = sAi; a.sAk = sAk; a.sBj = sBj; a.sBk = sBk;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
-    a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t;
+    a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = g_t2v_step;
     dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM);
     const bool akc = sAk == 1, bkc = sBk == 1;
     if (akc && bkc) k_gemm_f32<true, true><<<grid, 256, 0, stream>>>(a);

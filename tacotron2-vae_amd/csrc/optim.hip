@@ -33,6 +33,7 @@ struct AdamArgs {
     const float* partials;
     float* norm_out;          // [0] = total grad norm (after the 1/world scaling)
     float lr, b1, b2, eps, wd, max_norm, inv_world, bc1, bc2s;   // bc1 = 1-b1^t, bc2s = sqrt(1-b2^t)
+    const t2v_step_params* step;     // device-side lr / bc1 / bc2s (graph replay) or NULL
 };
 
 __global__ __launch_bounds__(256) void k_clip_adam(AdamArgs a) {
@@ -54,7 +55,9 @@ __global__ __launch_bounds__(256) void k_clip_adam(AdamArgs a) {
     }
     __syncthreads();
     const float gs = s_coef;
-    const float step_size = a.lr / a.bc1;
+    const float lr = a.step ? a.step->lr : a.lr, bc1 = a.step ? a.step->bc1 : a.bc1;
+    const float bc2s = a.step ? a.step->bc2s : a.bc2s;
+    const float step_size = lr / bc1;
     const size_t n4 = a.n >> 2;
     float4* p4 = (float4*)a.p; const float4* g4 = (const float4*)a.g; float4* m4 = (float4*)a.m; float4* v4 = (float4*)a.v;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256) void k_clip_adam(AdamArgs a) {
             const float gg = fmaf(a.wd, p.c, g.c * gs);              \
             m.c = a.b1 * m.c + (1.0f - a.b1) * gg;                    \
             v.c = a.b2 * v.c + (1.0f - a.b2) * gg * gg;               \
-            p.c -= step_size * (m.c / (sqrtf(v.c) / a.bc2s + a.eps)); \
+            p.c -= step_size * (m.c / (sqrtf(v.c) / bc2s + a.eps)); \
         }
         UPD(x) UPD(y) UPD(z) UPD(w)
 #undef UPD
@@ -76,17 +79,17 @@ __global__ __launch_bounds__(256) void k_clip_adam(AdamArgs a) {
             const float m = a.b1 * a.m[i] + (1.0f - a.b1) * gg;
             const float v = a.b2 * a.v[i] + (1.0f - a.b2) * gg * gg;
             a.m[i] = m; a.v[i] = v;
-            a.p[i] -= step_size * (m / (sqrtf(v) / a.bc2s + a.eps));
+            a.p[i] -= step_size * (m / (sqrtf(v) / bc2s + a.eps));
         }
     }
 }
 
 extern "C" int t2v_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, uint64_t n,
                                   float lr, float beta1, float beta2, float eps, float weight_decay,
-                                  float max_norm, float inv_world, int step, float* partials,
+                                  float max_norm, float inv_world, float bc1, float bc2, float* partials,
                                   float* norm_out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!params || !grads || !exp_avg || !exp_avg_sq || !partials || !norm_out || step < 1) return T2V_ERR_ARG;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !partials || !norm_out || !(bc1 > 0.f) || !(bc2 > 0.f)) return T2V_ERR_ARG;
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return T2V_ERR_ARG;
     const size_t n4 = n >> 2;
     k_sumsq<<<T2V_NORM_BLOCKS, 256, 0, stream>>>((const float4*)grads, n4, grads + (n4 << 2), (int)(n & 3), inv_world, partials);
@@ -95,8 +98,9 @@ extern "C" int t2v_clip_adam_step(float* params, float* grads, float* exp_avg, f
     a.partials = partials; a.norm_out = norm_out;
     a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay; a.max_norm = max_norm;
     a.inv_world = inv_world;
-    a.bc1 = 1.0f - powf(beta1, (float)step);
-    a.bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    a.bc1 = bc1;
+    a.bc2s = sqrtf(bc2);
+    a.step = g_t2v_step;
     k_clip_adam<<<2048, 256, 0, stream>>>(a);
     return t2v_check_launch();
 }

@@ -385,6 +385,7 @@ struct LossArgs {
     float* out;      // (4)
     size_t n_mel; int n_gate, n_lat, nblk;
     float klw;
+    const t2v_step_params* step;   // device-side KL weight (graph replay) or NULL
     unsigned* ticket;
 };
 
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs a) {
     __shared__ float scr[4];
     __shared__ int last;
     const int tid = threadIdx.x;
+    const float klw = a.step ? a.step->kl_weight : a.klw;
     float s_mel = 0.f, s_gate = 0.f, s_kl = 0.f;
     const float cm = 2.0f / (float)a.n_mel;
     for (size_t i = (size_t)blockIdx.x * 256 + tid; i < a.n_mel; i += (size_t)gridDim.x * 256) {
@@ -410,8 +412,8 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs a) {
     for (int i = blockIdx.x * 256 + tid; i < a.n_lat; i += gridDim.x * 256) {
         const float m = a.mu[i], lv = a.logvar[i], e = expf(lv);
         s_kl += -0.5f * (1.f + lv - m * m - e);
-        a.dmu[i] = a.klw * m;
-        a.dlogvar[i] = a.klw * -0.5f * (1.f - e);
+        a.dmu[i] = klw * m;
+        a.dlogvar[i] = klw * -0.5f * (1.f - e);
     }
     const float v[3] = {s_mel, s_gate, s_kl};
     for (int k = 0; k < 3; ++k) {
@@ -436,8 +438,8 @@ __global__ __launch_bounds__(256) void k_loss(LossArgs a) {
         const float recon = (float)(m / (double)a.n_mel + g / (double)a.n_gate);
         a.out[1] = recon;
         a.out[2] = (float)k;
-        a.out[0] = recon + a.klw * (float)k;
-        a.out[3] = a.klw;
+        a.out[0] = recon + klw * (float)k;
+        a.out[3] = klw;
         *a.ticket = 0;
     }
 }
@@ -452,7 +454,7 @@ extern "C" int t2v_loss_fwd_bwd(const float* mel, const float* post, const float
     LossArgs a;
     a.mel = mel; a.post = post; a.mel_t = mel_t; a.gate = gate; a.gate_t = gate_t; a.mu = mu; a.logvar = logvar;
     a.dmel = dmel; a.dpost = dpost; a.dgate = dgate; a.dmu = dmu; a.dlogvar = dlogvar; a.part = part192; a.out = out4;
-    a.n_mel = n_mel; a.n_gate = n_gate; a.n_lat = n_lat; a.nblk = 64; a.klw = kl_weight; a.ticket = ticket;
+    a.n_mel = n_mel; a.n_gate = n_gate; a.n_lat = n_lat; a.nblk = 64; a.klw = kl_weight; a.ticket = ticket; a.step = g_t2v_step;
     k_loss<<<64, 256, 0, (hipStream_t)stream_>>>(a);
     return t2v_check_launch();
 }

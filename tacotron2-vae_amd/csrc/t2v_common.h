@@ -60,6 +60,12 @@ __device__ __forceinline__ uint32_t t2v_rng_u32(uint64_t seed, uint32_t stream, 
     x ^= x >> 31;
     return (uint32_t)(x >> 32);
 }
+// seed of this launch: the by-value seed, advanced by the device-side step counter when one is installed
+// (t2v_set_step_params): under graph replay the argument is frozen, the counter is not
+struct t2v_step_params;
+__device__ __forceinline__ uint64_t t2v_step_seed(uint64_t seed, const t2v_step_params* step) {
+    return step ? seed + *(const uint64_t*)step * 0x9E3779B97F4A7C15ull : seed;
+}
 // returns the multiplicative dropout factor: 0 or 1/(1-p)
 __device__ __forceinline__ float t2v_drop_scale(uint64_t seed, uint32_t stream, uint32_t t, uint32_t idx, float p) {
     if (p <= 0.0f) return 1.0f;

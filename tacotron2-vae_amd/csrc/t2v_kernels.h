@@ -9,6 +9,7 @@ enum { T2V_RNG_ATT_H = 1, T2V_RNG_ATT_C = 2, T2V_RNG_DEC_H = 3, T2V_RNG_DEC_C = 
 
 int t2v_check_launch();
 extern unsigned long long* g_t2v_prof;   // device buffer of 32 u64 or NULL (t2v_set_phase_profile)                 // records hipGetLastError() for t2v_last_error()
+extern const t2v_step_params* g_t2v_step;      // device-side per-step parameters or NULL (t2v_set_step_params)
 struct LstmFwdArgs;
 struct AttnFwdArgs;
 
@@ -52,6 +53,7 @@ struct LstmFwdArgs {
     int B, t, do_att, do_dec;
     float p_att, p_dec;
     uint64_t seed;
+    const t2v_step_params* step;
 };
 
 struct AttnFwdArgs {
@@ -125,6 +127,7 @@ struct CellBwdArgs {
     int B, t, do_att, do_dec;
     float p_att, p_dec;
     uint64_t seed;
+    const t2v_step_params* step;
     unsigned* err;          // error word (bounded-spin timeout)
     unsigned long long* prof;   // optional phase stamps of cell workgroup 0 (t2v_set_phase_profile slots 24..28)
 };

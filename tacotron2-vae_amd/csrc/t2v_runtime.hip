@@ -20,3 +20,8 @@ unsigned long long* g_t2v_prof = nullptr;
 // Tracing aid: when set, k_attn_fwd / k_attn_bwd write s_memtime stamps at their phase boundaries
 // (fwd -> slots 0..7, bwd -> slots 16..23).  NULL disables it.
 extern "C" void t2v_set_phase_profile(unsigned long long* dev_buf32) { g_t2v_prof = dev_buf32; }
+
+// Per-step parameters in device memory (optional): lets a captured HIP graph of the whole training step replay with
+// fresh dropout masks / Adam bias corrections / KL weight — kernel arguments are frozen at capture time, memory is not.
+const t2v_step_params* g_t2v_step = nullptr;
+extern "C" void t2v_set_step_params(const t2v_step_params* dev) { g_t2v_step = dev; }

@@ -48,7 +48,9 @@ _GROUPS = {
 #   bucket_batches  : length-bucketed batch sampler (low padding waste, balanced DP ranks)
 #   bf16_run        : bf16 MFMA for the Postnet/encoder convolutions and the time-batched linears, fp32
 #                     master weights / accumulation / BatchNorm / recurrent state (replaces fp16_run)
-_EXTENSIONS = dict(device_frontend=False, bucket_batches=False, bf16_run=False)
+#   graph_step      : capture the whole training iteration into a HIP graph per input shape and replay it
+#                     (train.TrainEngine); pays off with fixed / bucketed shapes, ragged batches stay eager
+_EXTENSIONS = dict(device_frontend=False, bucket_batches=False, bf16_run=False, graph_step=False)
 
 
 def _coerce(old, text):

@@ -20,6 +20,11 @@ from modules import VAE_GST
 from utils import get_mask_from_lengths, to_gpu
 
 drop_rate = 0.5   # module-level like reference model.py:11 (read at call time)
+# Dropout masks of the Prenet / conv blocks are a pure function of (seed, stream, call index, element) — and of the
+# device-side step counter (t2v_hip.StepParams.epoch = training iteration) when a training engine installed one, so
+# they differ from iteration to iteration also under graph replay and after a checkpoint resume.  The seed derives
+# from hparams.seed (set by Tacotron2.__init__).
+_drop_seed = [0x5EED]
 
 
 class LocationLayer(nn.Module):
@@ -55,7 +60,7 @@ class Prenet(nn.Module):
         # Linear + ReLU + dropout is one MFMA GEMM with a fused epilogue
         _block_calls[0] += 1
         for i, linear in enumerate(self.layers):
-            x = t2v_hip.LinearHIP.apply(x, linear.weight, None, True, drop_rate, 0x5EED, 48 + i, _block_calls[0])
+            x = t2v_hip.LinearHIP.apply(x, linear.weight, None, True, drop_rate, _drop_seed[0], 48 + i, _block_calls[0])
         return x
 
 
@@ -74,7 +79,7 @@ def _conv_bn_act(block, x, act, training, rng_stream):
     if training:
         t2v_hip.note_bn_counter(bn.num_batches_tracked)     # bumped in one launch at the end of the forward
     return t2v_hip.ConvBNAct1d.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                     training, act, drop_rate, 0x5EED, rng_stream, _block_calls[0])
+                                     training, act, drop_rate, _drop_seed[0], rng_stream, _block_calls[0])
 
 
 class Postnet(nn.Module):
@@ -279,6 +284,7 @@ class Tacotron2(nn.Module):
         super().__init__()
         self.mask_padding = hparams.mask_padding
         self.fp16_run = hparams.fp16_run
+        _drop_seed[0] = (int(hparams.seed) * 2654435761 + 0x5EED) & 0x7FFFFFFFFFFFFFFF
         self.n_mel_channels = hparams.n_mel_channels
         self.n_frames_per_step = hparams.n_frames_per_step
         self.transcript_embedding = nn.Embedding(hparams.n_symbols, hparams.symbols_embedding_dim)
@@ -331,6 +337,12 @@ class Tacotron2(nn.Module):
 
     def forward(self, inputs):
         text, input_lengths, targets, _, output_lengths, speakers, emotions = self.parse_input(inputs)
+        if t2v_hip.step_params(create=False) is not None:
+            # a training engine drives the dropout epoch through the device-side step record: the host-side call
+            # counters restart with every forward pass, so an iteration issues the same launches whether it runs
+            # eagerly or as a replayed graph (and a resumed run continues with the masks of its iteration number)
+            _block_calls[0] = 0
+            self.decoder._calls = 0
         # The text encoder and the reference encoder (VAE) are independent until the add below, and both are chains
         # of small latency-bound kernels (persistent BiLSTM on 16 workgroups, GRU, stride-2 convs): run the VAE
         # branch on a side stream so the two chains share the chip.  Autograd replays each node on its forward

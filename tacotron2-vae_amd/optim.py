@@ -62,6 +62,8 @@ class FlatAdam(object):
             self._grad_views.append(self.grads[o:o + p.numel()].view_as(p))
         self._view_of = {id(p): v for (_, _, p), v in zip(self._live, self._grad_views)}
         self._gathered = False
+        self._no_grad = []
+        self._slot_of = {id(p): (o, p.numel()) for (_, _, p), o in zip(self._live, offs)}
         self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay,
                                   amsgrad=False, maximize=False)]
         self.grad_clip_thresh = grad_clip_thresh
@@ -80,6 +82,7 @@ class FlatAdam(object):
         for _, _, p in self._live:
             p.grad = None
         self._gathered = False
+        self._no_grad = []
 
     def gather_grads(self, params=None):
         """copy `.grad` of `params` (default: all live parameters) into their arena slots; a parameter without a
@@ -90,6 +93,7 @@ class FlatAdam(object):
             v = self._view_of[id(p)]
             if p.grad is None:
                 v.zero_()
+                self._no_grad.append(p)      # torch.optim.Adam skips such a parameter entirely: see step()
             elif p.grad.data_ptr() != v.data_ptr():
                 views.append(v)
                 srcs.append(p.grad)
@@ -101,16 +105,33 @@ class FlatAdam(object):
     def mark_gathered(self):
         self._gathered = True
 
-    def rebind_grads(self):
-        """kept for callers of the earlier API: nothing to re-attach any more"""
-        return None
+    def bias_corrections(self, step_count):
+        """(1 - beta1^t, 1 - beta2^t) in double precision like torch.optim.Adam (fp32 powf loses ~1e-4 at small t)"""
+        b1, b2 = self.param_groups[0]['betas']
+        return 1.0 - float(b1) ** step_count, 1.0 - float(b2) ** step_count
+
+    def publish_step_params(self, sp, step_count=None):
+        """write lr / bias corrections of optimiser step `step_count` (default: the next one) into the device record"""
+        bc1, bc2 = self.bias_corrections(self.step_count + 1 if step_count is None else step_count)
+        sp.set(lr=self.param_groups[0]['lr'], bc1=bc1, bc2s=math.sqrt(bc2))
 
     def step(self):
         if not self._gathered:
             self.gather_grads()
         self._gathered = False
         g = self.param_groups[0]
+        # a live parameter without a gradient is skipped by torch.optim.Adam (no weight decay, no moment decay, no
+        # step); the fused kernel updates the whole arena, so such slots are put back afterwards (rare: partial freezing)
+        skipped = [(self._slot_of[id(p)],) for p in self._no_grad]
+        saved = [(o, n, self.params[o:o + n].clone(), self.exp_avg[o:o + n].clone(), self.exp_avg_sq[o:o + n].clone())
+                 for ((o, n),) in skipped]
+        self._no_grad = []
         self.step_count += 1
+        bc1, bc2 = self.bias_corrections(self.step_count)
+        sp = t2v_hip.step_params(create=False)
+        if sp is not None:       # the kernel reads lr / bias corrections from the device record once one is installed
+            self.publish_step_params(sp, self.step_count)
+            sp.upload()
         lib = t2v_hip.load_library()
         rc = lib.t2v_clip_adam_step(
             C.c_void_p(self.params.data_ptr()), C.c_void_p(self.grads.data_ptr()),
@@ -118,11 +139,15 @@ class FlatAdam(object):
             C.c_uint64(self.numel), C.c_float(g['lr']), C.c_float(g['betas'][0]), C.c_float(g['betas'][1]),
             C.c_float(g['eps']), C.c_float(g['weight_decay']),
             C.c_float(self.grad_clip_thresh if self.grad_clip_thresh else 0.0),
-            C.c_float(1.0 / self.world_size), C.c_int(self.step_count),
+            C.c_float(1.0 / self.world_size), C.c_float(bc1), C.c_float(bc2),
             C.c_void_p(self._partials.data_ptr()), C.c_void_p(self.grad_norm.data_ptr()),
             C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             raise t2v_hip.T2VHipError("t2v_clip_adam_step rc=%d" % rc)
+        for o, n, p0, m0, v0 in saved:
+            self.params[o:o + n].copy_(p0)
+            self.exp_avg[o:o + n].copy_(m0)
+            self.exp_avg_sq[o:o + n].copy_(v0)
         return self.grad_norm
 
     # -- checkpoint interchange with torch.optim.Adam (reference train.py:100-119)

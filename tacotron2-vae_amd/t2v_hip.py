@@ -45,6 +45,7 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decode
            't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_conv1d_dw_scratch_floats', 't2v_gemm_bf16', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
            't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats',
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_fuse_location_weights', 't2v_decoder_qp_floats',
+           't2v_set_step_params',
            't2v_attn_bwd_slices')
 
 
@@ -79,7 +80,9 @@ def load_library():
                                                    C.c_void_p]
     lib.t2v_clip_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float,
                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
-                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+                                       C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.t2v_set_step_params.argtypes = [C.c_void_p]
+    lib.t2v_set_step_params.restype = None
     lib.t2v_mel_frontend.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,
                                      C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -153,6 +156,66 @@ def mm_mixed(a, b):
     return a @ b
 
 
+# ---- per-step parameters in device memory (include/t2vae.h: t2v_step_params).  Kernel arguments are frozen when the
+# training step is captured into a HIP graph; the kernels read this 32-byte record at run time instead (dropout epoch,
+# Adam lr / bias corrections, KL weight).  Host values go through a ring of pinned slots: the H2D copy is asynchronous
+# and the host runs ahead of the GPU, so a slot must not be rewritten before its copy has executed.
+class StepParams(object):
+    RING = 256
+    FIELDS = {'lr': 2, 'bc1': 3, 'bc2s': 4, 'kl_weight': 5}
+
+    def __init__(self, device):
+        lib = load_library()
+        self.host = torch.zeros(self.RING, 8, dtype=torch.float32).pin_memory()
+        self.dev = torch.zeros(8, dtype=torch.float32, device=device)
+        self.cur = dict(epoch=0, lr=0.0, bc1=1.0, bc2s=1.0, kl_weight=0.0)
+        self.dirty = True
+        self._i = 0
+        lib.t2v_set_step_params(C.c_void_p(self.dev.data_ptr()))
+
+    def set(self, **kw):
+        for k, v in kw.items():
+            v = int(v) if k == 'epoch' else float(v)
+            if self.cur[k] != v:
+                self.cur[k] = v
+                self.dirty = True
+
+    def upload(self, force=False):
+        """enqueue the record on the current stream if it changed (never inside a graph capture: the training engine
+        sets every field before it captures or replays)"""
+        if not (self.dirty or force):
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise T2VHipError("step parameters changed inside a graph capture")
+        slot = self.host[self._i % self.RING]
+        self._i += 1
+        slot.view(torch.int64)[0] = self.cur['epoch']
+        for k, i in self.FIELDS.items():
+            slot[i] = self.cur[k]
+        self.dev.copy_(slot, non_blocking=True)
+        self.dirty = False
+
+
+_STEP = None
+
+
+def step_params(create=True):
+    """process-wide StepParams singleton (None until a training engine asks for it with create=True)"""
+    global _STEP
+    if _STEP is None and create:
+        _STEP = StepParams(torch.device('cuda', torch.cuda.current_device()))
+    return _STEP
+
+
+def release_step_params():
+    """uninstall the device record (the kernels fall back to their by-value arguments); engines created later install a
+    new one.  Captured graphs of an engine keep reading the old record's memory, which stays allocated with them."""
+    global _STEP
+    if _STEP is not None:
+        load_library().t2v_set_step_params(None)
+        _STEP = None
+
+
 # ---- asynchronous error ledger.  The cooperative kernels (BiLSTM, GRU, attention exchange, reverse-step hand-off)
 # use bounded spins: on a timeout they set an error word and leave instead of hanging.  Reading those words right
 # away would force a device sync per call, so the wrappers copy each word (device-to-device, 4 bytes) into a small
@@ -160,6 +223,7 @@ def mm_mixed(a, b):
 # by validate(), bench.py and the tests — reads the pool once and raises if any call reported a timeout.
 _ERR_POOL = {}
 _ERR_SLOTS = 4096
+_ERR_STICKY = [0]      # > 0: slots [0, n) belong to captured graphs (rewritten by every replay) and are never recycled
 
 
 def _err_note(label, word):
@@ -168,7 +232,9 @@ def _err_note(label, word):
     if key not in _ERR_POOL:
         _ERR_POOL[key] = [torch.zeros(_ERR_SLOTS, device=word.device, dtype=torch.int32), 0, {}]
     pool = _ERR_POOL[key]
-    slot = pool[1] % _ERR_SLOTS
+    if pool[1] >= _ERR_SLOTS:
+        pool[1] = _ERR_STICKY[0]
+    slot = pool[1]
     pool[0][slot:slot + 1].copy_(word)
     pool[2][slot] = label
     pool[1] += 1
@@ -185,11 +251,19 @@ def check_async_errors():
         for i in torch.nonzero(vals).flatten().tolist():
             bad.append(pool[2].get(i, '?'))
         pool[0].zero_()
-        pool[1] = 0
-        pool[2].clear()
+        pool[1] = _ERR_STICKY[0]
+        for i in [i for i in pool[2] if i >= _ERR_STICKY[0]]:
+            del pool[2][i]
     if bad:
         raise T2VHipError("cooperative kernel barrier timed out (results of that step are invalid): %s"
                           % ", ".join(sorted(set(bad))))
+
+
+def err_pool_pin():
+    """called right after a graph capture: the ledger slots written so far are rewritten by every replay of that graph,
+    so they stay reserved (and keep their labels) for the life of the process"""
+    for pool in _ERR_POOL.values():
+        _ERR_STICKY[0] = max(_ERR_STICKY[0], pool[1])
 
 
 def _require_gpu(*tensors):
@@ -796,6 +870,10 @@ class VAELoss(torch.autograd.Function):
         mel, post, gate, mu, logvar = (_f32c(t) for t in (mel, post, gate, mu, logvar))
         mel_t, gate_t = _f32c(mel_t), _f32c(gate_t)
         out = torch.empty(4, device=dev, dtype=torch.float32)
+        sp = step_params(create=False)
+        if sp is not None:       # the kernel reads the KL weight from the device record once one is installed
+            sp.set(kl_weight=kl_weight)
+            sp.upload()
         grads = [torch.empty_like(t) for t in (mel, post, gate, mu, logvar)]
         _check(lib.t2v_loss_fwd_bwd(_p(mel), _p(post), _p(mel_t), _p(gate), _p(gate_t), _p(mu), _p(logvar),
                                     *[_p(g) for g in grads], _p(part), _p(out), _p(ticket), mel.numel(),

@@ -72,9 +72,20 @@ def t2v_hip_check():
 
 
 class TrainEngine(object):
-    """One rank's training state: model + criterion + flat-arena optimiser (+ arena all-reduce)."""
+    """One rank's training state: model + criterion + flat-arena optimiser (+ arena all-reduce).
 
-    def __init__(self, hparams, world_size=1):
+    graph=True (hparams.graph_step): the whole iteration after the H2D copies — forward, loss, backward, gradient
+    gather, clip + Adam — is captured ONCE per input shape into a HIP graph and replayed; everything that changes from
+    step to step (dropout epoch, learning rate, Adam bias corrections, KL weight) lives in a 32-byte device record the
+    kernels read at run time (t2v_hip.StepParams).  That removes the ~21 ms of host work (1 900 launches, autograd,
+    allocator) a step otherwise needs, which is more than the GPU time of the step.  Shapes that keep changing (ragged
+    koemo batches without bucketing) simply run eagerly: a shape is captured the third time it is seen."""
+
+    GRAPH_AFTER = 2          # eager executions of a shape before it is captured (allocator / lazy-init warm-up)
+    MAX_GRAPHS = 8
+
+    def __init__(self, hparams, world_size=1, graph=None):
+        import t2v_hip
         self.hparams = hparams
         self.model = load_model(hparams)
         self.criterion = Tacotron2Loss_VAE(hparams)
@@ -88,16 +99,31 @@ class TrainEngine(object):
                 named, offs, self.optimizer.grads,
                 side_streams=lambda: [st for st in (getattr(model, '_side', None),) if st is not None],
                 gather=self.optimizer.gather_grads)
+        self.step_params = t2v_hip.step_params()
+        self.use_graph = bool(getattr(hparams, 'graph_step', False) if graph is None else graph) and world_size == 1
+        self._graphs = {}
+        self._seen = {}
+        # graph mode: EVERY step of this engine (the eager warm-up ones too) runs on one dedicated stream — autograd's
+        # AccumulateGrad nodes remember the stream of their first backward, and a capture that has to synchronise with
+        # the legacy default stream is illegal
+        self._stream = torch.cuda.Stream() if self.use_graph else None
+        if self.use_graph:
+            # one stream from the first eager step on: a branch stream used before the capture would leave its
+            # AccumulateGrad nodes behind and fork the captured graph
+            self.model.overlap_branches = False
         self.model.train()
 
-    def step(self, batch, iteration, learning_rate=None):
-        """Body of reference train.py:208-229.  Returns (loss, recon, kl, kl_weight, grad_norm) as
-        device tensors / floats without forcing a host sync."""
+    def stream_context(self):
+        """`with engine.stream_context():` around the training loop makes the engine's stream the current one, so a step
+        needs no hand-over with the caller's stream (an event round trip through the legacy default stream costs
+        ≈1.7 ms per step on this stack — measured, tools/graph_probe.py).  No-op for an eager engine."""
+        import contextlib
+        return torch.cuda.stream(self._stream) if self._stream is not None else contextlib.nullcontext()
+
+    # -- one iteration, eager
+    def _body(self, x, y, iteration):
         opt = self.optimizer
-        if learning_rate is not None:
-            opt.param_groups[0]['lr'] = learning_rate
         opt.zero_grad()
-        x, y = self.model.parse_batch(batch)
         y_pred = self.model(x)
         loss, recon, kl, w = self.criterion(y_pred, y, iteration)
         if self.allreduce is not None:
@@ -107,7 +133,74 @@ class TrainEngine(object):
             self.allreduce.finish()
             opt.mark_gathered()        # every bucket gathered its slice before it went out
         grad_norm = opt.step()
-        return loss.detach(), recon.detach(), kl.detach(), w, grad_norm
+        return loss.detach(), recon.detach(), kl.detach(), grad_norm
+
+    def _publish(self, iteration):
+        """everything the kernels of this iteration read from the device record, in one upload before the first launch"""
+        c = self.criterion
+        w = c.kl_anneal_function(c.anneal_function, c.lag, iteration, c.k, c.x0, c.upper)
+        sp = self.step_params
+        sp.set(epoch=iteration, kl_weight=w if w is not None else 0.0)
+        self.optimizer.publish_step_params(sp)
+        sp.upload()
+        return w
+
+    def step(self, batch, iteration, learning_rate=None):
+        """Body of reference train.py:208-229.  Returns (loss, recon, kl, kl_weight, grad_norm) as
+        device tensors / floats without forcing a host sync."""
+        if self._stream is not None and torch.cuda.current_stream() != self._stream:
+            cur = torch.cuda.current_stream()
+            self._stream.wait_stream(cur)
+            with torch.cuda.stream(self._stream):
+                out = self.step(batch, iteration, learning_rate)
+            cur.wait_stream(self._stream)
+            return out
+        opt = self.optimizer
+        if learning_rate is not None:
+            opt.param_groups[0]['lr'] = learning_rate
+        x, y = self.model.parse_batch(batch)
+        w = self._publish(iteration)
+        if self.use_graph and self.model.training:
+            out = self._graph_step(x, y, iteration)
+            if out is not None:
+                return out[0], out[1], out[2], w, out[3]
+        loss, recon, kl, grad_norm = self._body(x, y, iteration)
+        return loss, recon, kl, w, grad_norm
+
+    # -- graph path
+    def _graph_step(self, x, y, iteration):
+        import t2v_hip
+        tensors = [t for t in x if torch.is_tensor(t)] + list(y)
+        key = tuple((tuple(t.shape), str(t.dtype)) for t in tensors) + (int(x[3]),)
+        entry = self._graphs.get(key)
+        if entry is None:
+            n = self._seen.get(key, 0)
+            self._seen[key] = n + 1
+            if n < self.GRAPH_AFTER or len(self._graphs) >= self.MAX_GRAPHS:
+                return None
+            entry = self._capture(x, y, iteration)
+            self._graphs[key] = entry
+        graph, static_in, static_out = entry
+        for dst, src in zip(static_in, tensors):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        graph.replay()
+        self.optimizer.step_count += 1
+        return static_out
+
+    def _capture(self, x, y, iteration):
+        import t2v_hip
+        static_x = tuple(t.clone() if torch.is_tensor(t) else t for t in x)
+        static_y = tuple(t.clone() for t in y)
+        static_in = [t for t in static_x if torch.is_tensor(t)] + list(static_y)
+        torch.cuda.synchronize()
+        count0 = self.optimizer.step_count
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=self._stream):
+            out = self._body(static_x, static_y, iteration)
+        self.optimizer.step_count = count0      # capture executes nothing; the replay below is this iteration's step
+        t2v_hip.err_pool_pin()
+        return graph, static_in, tuple(out)
 
 
 def prepare_directories_and_logger(output_directory, log_directory, rank):

@@ -147,7 +147,7 @@ def test_fused_adam_matches_oracle_formula():
     dp, dg, dm, dv = (t.cuda() for t in (p, gr, m, v))
     part, norm = torch.zeros(1024, device='cuda'), torch.zeros(1, device='cuda')
     rc = lib.t2v_clip_adam_step(C.c_void_p(dp.data_ptr()), C.c_void_p(dg.data_ptr()), C.c_void_p(dm.data_ptr()),
-                                C.c_void_p(dv.data_ptr()), n, 1e-3, 0.9, 0.999, 1e-8, 1e-6, 1.0, 1.0, 3,
+                                C.c_void_p(dv.data_ptr()), n, 1e-3, 0.9, 0.999, 1e-8, 1e-6, 1.0, 1.0, 1.0 - 0.9 ** 3, 1.0 - 0.999 ** 3,
                                 C.c_void_p(part.data_ptr()), C.c_void_p(norm.data_ptr()),
                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
@@ -246,3 +246,40 @@ def test_koemo_shape_parity_against_oracle():
         assert checked >= 90
     finally:
         M.drop_rate = old
+
+
+def test_graph_replay_equals_eager_training():
+    """hparams.graph_step: the iteration captured into a HIP graph (replayed with the device-side step record) follows
+    the eager engine bit for bit — losses, gradient norms and the weights after six optimiser steps, dropout ON (the
+    masks are functions of the device-side epoch, not of frozen kernel arguments)."""
+    import sys
+    import hparams as HP
+    import train as TR
+    import t2v_hip
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from bench import synthetic_batch
+    batches = [synthetic_batch(3, 30, 48, 5, lens_in=[30, 22, 17], lens_out=[48, 40, 31]),
+               synthetic_batch(3, 30, 48, 6, lens_in=[30, 25, 11], lens_out=[48, 37, 20])]
+    runs = {}
+    for mode in ('eager', 'graph'):
+        hp = HP.create_hparams("batch_size=3,anneal_function=logistic,graph_step=%s" % (mode == 'graph'))
+        torch.manual_seed(hp.seed)
+        torch.cuda.manual_seed(hp.seed)
+        eng = TR.TrainEngine(hp)
+        eng.model.overlap_branches = False
+        eng.model.vae_gst.eps_override = torch.full((3, 32), 0.25, device='cuda')
+        vals = []
+        for it in range(6):
+            loss, recon, kl, w, gn = eng.step(batches[it % 2], 1000 * it)      # iteration drives KL weight + dropout epoch
+            vals.append((float(loss), float(kl), float(w), float(gn)))
+        torch.cuda.synchronize()
+        t2v_hip.check_async_errors()
+        assert (mode == 'graph') == (len(eng._graphs) == 1)
+        runs[mode] = (vals, eng.optimizer.params.clone(), eng.optimizer.step_count)
+    assert runs['eager'][2] == runs['graph'][2] == 6
+    assert runs['eager'][0] == runs['graph'][0], (runs['eager'][0], runs['graph'][0])
+    assert torch.equal(runs['eager'][1], runs['graph'][1])
+    ws = [v[2] for v in runs['graph'][0]]
+    assert ws[0] < ws[3] < ws[5]                 # logistic KL weight reached the replays through the device record
+    ls = [v[0] for v in runs['graph'][0]]
+    assert len(set(ls)) == 6                     # every replay saw fresh dropout masks / parameters
