@@ -115,3 +115,49 @@ def test_model_bf16_vs_fp32_build(golden_dir):
     finally:
         M.drop_rate = old
         t2v_hip.set_bf16(False)
+
+
+def test_bf16_at_config5_shape_b16_t400():
+    """BASELINE configs[4] shape on one GPU: bf16_run with B = 16, T_in = 84, T_out = 400 (bf16 and B = 16 combined):
+    same step as the fp32 build within the stated bf16 bound, two optimiser steps stay finite."""
+    import sys
+    import hparams as HP
+    import model as M
+    import t2v_hip
+    import train as TR
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic_batch
+    batch = synthetic_batch(16, 84, 400, 77)
+    old = M.drop_rate
+    M.drop_rate = 0.0
+    try:
+        outs, losses = {}, {}
+        for mode in ('fp32', 'bf16'):
+            hp = HP.create_hparams("batch_size=16,anneal_function=constant,p_attention_dropout=0.0,p_decoder_dropout=0.0,"
+                                   "bf16_run=%s" % (mode == 'bf16'))
+            torch.manual_seed(hp.seed)
+            eng = TR.TrainEngine(hp)
+            eng.model.vae_gst.eps_override = torch.full((16, 32), 0.1, device='cuda')
+            x, y = eng.model.parse_batch(batch)
+            with torch.no_grad():
+                y_pred = eng.model(x)
+            outs[mode] = [t.detach().float().cpu() for t in y_pred[:4]]
+            l0 = eng.step(batch, 0)
+            l1 = eng.step(batch, 1)
+            torch.cuda.synchronize()
+            t2v_hip.check_async_errors()
+            losses[mode] = [float(l0[0]), float(l1[0])]
+            assert all(np.isfinite(losses[mode])) and float(l1[4]) > 0
+            del eng
+        assert outs['fp32'][0].shape == (16, 80, 400)
+        d_mel = (outs['bf16'][0] - outs['fp32'][0]).abs().mean().item()
+        d_post = (outs['bf16'][1] - outs['fp32'][1]).abs().mean().item()
+        print('bf16 B=16 T=400: mel L1 %.4f, postnet-out L1 %.4f' % (d_mel, d_post))
+        assert d_mel < 2e-2                                              # SURVEY cfg-5 bound on the decoder mel
+        assert d_post < 3e-2 * max(1.0, outs['fp32'][1].abs().mean().item())
+        assert (outs['bf16'][3] - outs['fp32'][3]).abs().max().item() < 2e-2          # alignments
+        for a, b in zip(losses['bf16'], losses['fp32']):
+            assert abs(a - b) < 2e-2 * abs(b)
+    finally:
+        M.drop_rate = old
+        t2v_hip.set_bf16(False)

@@ -82,3 +82,73 @@ def test_gate_stop_and_batch(model):
         mel1, gate1, _ = dec.inference(memory[:1])
         dec.gate_layer.linear_layer.bias.copy_(old)
     assert mel1.shape[2] == 1 and gate1.shape == (1, 1, 1)
+
+
+def _cfg4_model(hh_scale=1.0, gate_bias=None, max_steps=400):
+    import hparams as HP
+    import model as M
+    hp = HP.create_hparams("max_decoder_steps=%d" % max_steps)
+    torch.manual_seed(hp.seed)
+    m = M.Tacotron2(hp).cuda().eval()
+    with torch.no_grad():
+        m.decoder.attention_rnn.weight_hh.mul_(hh_scale)
+        m.decoder.decoder_rnn.weight_hh.mul_(hh_scale)
+        if gate_bias is not None:
+            m.decoder.gate_layer.linear_layer.bias.fill_(float(gate_bias))
+    return m
+
+
+@pytest.mark.parametrize("case", ['plain', 'lively'])
+def test_gate_terminated_inference_matches_reference(golden_dir, case):
+    """BASELINE configs[3] size (200 symbols, B = 1): the reference's own stop rule (model.py:453) ends the run — the
+    HIP decode loop must stop at the same frame, with the same alignment path (fixture: oracle/gen_golden.py d2)."""
+    import model as M
+    g = np.load(os.path.join(golden_dir, 'inference_gate_stop.npz'))
+    old = M.drop_rate
+    M.drop_rate = 0.0
+    try:
+        m = _cfg4_model(float(g[case + '_hh_scale'][0]), float(g[case + '_gate_bias'][0]))
+        with torch.no_grad():
+            ids = torch.from_numpy(g['ids']).cuda()
+            enc = m.encoder.inference(m.transcript_embedding(ids).transpose(1, 2))
+            memory = enc + m.vae_gst.fc3(torch.from_numpy(g['z']).cuda()).unsqueeze(1)
+            mel, gate, al = m.decoder.inference(memory, chunk=16)
+        n = int(g[case + '_n_frames'][0])
+        assert mel.shape[2] == n and n < 400, (mel.shape, n)
+        tol = 2e-4 if case == 'plain' else 2e-2            # 'lively': x6 recurrent weights amplify fp32 round-off
+        assert (mel.cpu() - torch.from_numpy(g[case + '_mel'])).abs().max() < tol
+        assert (mel.cpu() - torch.from_numpy(g[case + '_mel'])).abs().mean() < tol / 4
+        assert torch.equal(al.cpu().argmax(-1).to(torch.int16), torch.from_numpy(g[case + '_align_argmax']))
+        assert (al.cpu().max(-1).values - torch.from_numpy(g[case + '_align_max'])).abs().max() < tol
+        assert (al.cpu()[0, :4] - torch.from_numpy(g[case + '_align_head'])).abs().max() < 2e-5
+    finally:
+        M.drop_rate = old
+
+
+def test_cfg4_decode_800_steps_matches_oracle():
+    """BASELINE configs[3] at size: B = 1, 200 symbols, exactly 800 free-running decoder steps (gate ignored), HIP loop vs
+    the CPU oracle: alignment argmax path equal, attention weights L1, mel."""
+    import model as M
+    import t2v_oracle as O
+    old = M.drop_rate
+    M.drop_rate = 0.0
+    try:
+        m = _cfg4_model(max_steps=800)
+        m.decoder.gate_threshold = 1.0                      # never stop early
+        g = torch.Generator().manual_seed(1234)
+        ids = torch.randint(2, 80, (1, 200), generator=g)
+        z = torch.randn(1, 32, generator=torch.Generator().manual_seed(7))
+        with torch.no_grad():
+            enc = m.encoder.inference(m.transcript_embedding(ids.cuda()).transpose(1, 2))
+            memory = enc + m.vae_gst.fc3(z.cuda()).unsqueeze(1)
+            import contextlib, io
+            with contextlib.redirect_stdout(io.StringIO()):
+                mel, gate, al = m.decoder.inference(memory, chunk=800)
+            sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+            o_mel, o_gate, o_al = O.decoder_inference(sd, memory.cpu(), max_steps=800, gate_threshold=1.0)
+        assert mel.shape == (1, 80, 800) and o_mel.shape == (1, 80, 800)
+        assert torch.equal(al.cpu().argmax(-1), o_al.argmax(-1))                    # alignment path over all 800 frames
+        assert (al.cpu() - o_al).abs().sum(-1).max() < 1e-3                         # per-frame L1 of the attention weights
+        assert (mel.cpu() - o_mel).abs().max() < 5e-4 and (mel.cpu() - o_mel).abs().mean() < 1e-4
+    finally:
+        M.drop_rate = old

@@ -283,3 +283,59 @@ def test_graph_replay_equals_eager_training():
     assert ws[0] < ws[3] < ws[5]                 # logistic KL weight reached the replays through the device record
     ls = [v[0] for v in runs['graph'][0]]
     assert len(set(ls)) == 6                     # every replay saw fresh dropout masks / parameters
+
+
+def _grad_sample_check(g, grads, tol_rel):
+    names, strides = [str(x) for x in g['grad_sample_names']], [int(x) for x in g['grad_sample_strides']]
+    for i, (k, st) in enumerate(zip(names, strides)):
+        ref = torch.from_numpy(g['grad_sample_%d' % i]).double()
+        got = grads[k].reshape(-1)[::st].double()
+        assert got.shape == ref.shape, k
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) < tol_rel * scale + 1e-9, (k, float((got - ref).abs().max()), scale)
+        assert float((got * ref).sum()) > 0.999 * float((ref * ref).sum()), k
+
+
+def test_full_gradient_pins_match_reference(run):
+    """six key parameters over the WHOLE tensor (stride samples of the flattened gradient) against the reference:
+    location_conv, query_layer, attention_rnn.weight_hh, postnet conv-0 (B-5 quirk), reverse encoder LSTM, ref-enc conv-0"""
+    _grad_sample_check(run['g'], run['grads'], 3e-3)
+
+
+def test_long_text_step_matches_reference(golden_dir):
+    """T_in = 300 > 256 through the whole model against the reference's own outputs and gradients
+    (fixture written by oracle/gen_golden.py; koemo has 76 training utterances beyond 256 symbols)."""
+    import hparams as HP
+    import model as M
+    import train as TR
+    g = np.load(os.path.join(golden_dir, 'train_step_long.npz'))
+    hp = HP.create_hparams("anneal_function=constant,p_attention_dropout=0.0,p_decoder_dropout=0.0")
+    old = M.drop_rate
+    M.drop_rate = 0.0
+    try:
+        torch.manual_seed(hp.seed)
+        eng = TR.TrainEngine(hp)
+        eng.model.vae_gst.eps_override = torch.from_numpy(g['eps']).cuda()
+        batch = (torch.from_numpy(g['text']), torch.from_numpy(g['input_lengths']), torch.from_numpy(g['mel']),
+                 torch.from_numpy(g['gate']), torch.from_numpy(g['output_lengths']),
+                 torch.zeros(2, 1, dtype=torch.long), torch.from_numpy(g['emotions']))
+        eng.optimizer.zero_grad()
+        x, y = eng.model.parse_batch(batch)
+        y_pred = eng.model(x)
+        loss = eng.criterion(y_pred, y, 0)[0]
+        loss.backward()
+        torch.cuda.synchronize()
+        import t2v_hip
+        t2v_hip.check_async_errors()
+        tol = dict(out_mel=1e-4, out_post=3e-4, out_gate=1e-4, out_align=2e-5)
+        for i, name in enumerate(['out_mel', 'out_post', 'out_gate', 'out_align']):
+            d = (y_pred[i].detach().cpu() - torch.from_numpy(g[name])).abs().max().item()
+            assert d < tol[name], (name, d)
+        assert abs(float(loss) - g['scalars'][0]) < 1e-4 * abs(g['scalars'][0])
+        grads = {n: p.grad.detach().cpu() for n, p in eng.model.named_parameters() if p.grad is not None}
+        gmax = float(g['grad_norms'].max())
+        for k, ref in zip([str(s) for s in g['grad_names']], g['grad_norms']):
+            assert abs(float(grads[k].norm()) - float(ref)) < 3e-3 * max(float(ref), 1e-4 * gmax) + 1e-7, k
+        _grad_sample_check(g, grads, 3e-3)
+    finally:
+        M.drop_rate = old

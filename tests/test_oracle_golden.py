@@ -161,3 +161,104 @@ def test_oracle_two_adam_steps(model_sd, golden_dir, digests):
             # noise into ±lr steps whose sign is implementation-defined → bound by 2 steps · lr · numel
             tol += 2 * 1e-3 * sd[k].numel()
         assert abs(got[1] - ref[1]) <= tol, k
+
+
+def _grad_sample_check(g, grad_of, tol_rel, who):
+    """whole-tensor pins: flattened gradient sampled with the stored stride (stride 1 = the full tensor)"""
+    names, strides = [str(x) for x in g['grad_sample_names']], [int(x) for x in g['grad_sample_strides']]
+    assert len(names) >= 6
+    for i, (k, st) in enumerate(zip(names, strides)):
+        ref = torch.from_numpy(g['grad_sample_%d' % i]).double()
+        got = grad_of(k).detach().cpu().reshape(-1)[::st].double()
+        assert got.shape == ref.shape, (who, k)
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) < tol_rel * scale + 1e-9, (who, k, float((got - ref).abs().max()), scale)
+        # a sign flip or a permutation of the tensor cannot hide behind a norm: correlation with the reference
+        assert float((got * ref).sum()) > 0.999 * float((ref * ref).sum()), (who, k)
+
+
+def test_oracle_full_gradient_pins(oracle_step):
+    """six key parameters, sampled over the WHOLE tensor, against the reference's gradients"""
+    g, sd, _, _ = oracle_step
+    _grad_sample_check(g, lambda k: sd[k].grad, 2e-3, 'oracle')
+
+
+@pytest.fixture(scope='module')
+def oracle_long_step(model_sd, golden_dir):
+    import t2v_oracle as O
+    _, _, sd0 = model_sd
+    g = np.load(os.path.join(golden_dir, 'train_step_long.npz'))
+    sd = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and 'running_' not in k else v.clone())
+          for k, v in sd0.items()}
+    text, lin = torch.from_numpy(g['text']), torch.from_numpy(g['input_lengths'])
+    mel, gate, lout = torch.from_numpy(g['mel']), torch.from_numpy(g['gate']), torch.from_numpy(g['output_lengths'])
+    out = O.tacotron2_forward(sd, text, lin, mel, lout, True, torch.from_numpy(g['eps']))
+    loss, recon, kl, w = O.loss_forward(out, mel, gate, 0, 'constant')
+    loss.backward()
+    return g, sd, out, loss
+
+
+def test_oracle_long_text_step_matches_reference(oracle_long_step):
+    """T_in = 300 (> 256: koemo reaches 555 symbols; the reference's attention is unbounded, model.py:67-88)"""
+    g, sd, out, loss = oracle_long_step
+    assert g['text'].shape == (2, 300)
+    for i, name in enumerate(['out_mel', 'out_post', 'out_gate', 'out_align']):
+        assert (out[i].detach() - torch.from_numpy(g[name])).abs().max().item() < 5e-5, name
+    assert abs(float(loss) - g['scalars'][0]) < 1e-4 * abs(g['scalars'][0])
+    names = [str(x) for x in g['grad_names']]
+    gmax = float(g['grad_norms'].max())
+    for k, ref in zip(names, g['grad_norms']):
+        assert abs(float(sd[k].grad.norm()) - float(ref)) < 2e-3 * max(float(ref), 1e-4 * gmax) + 1e-7, k
+    _grad_sample_check(g, lambda k: sd[k].grad, 2e-3, 'oracle-long')
+
+
+@pytest.mark.parametrize("case", ['plain', 'lively'])
+def test_oracle_gate_terminated_inference(model_sd, golden_dir, case):
+    """BASELINE configs[3] size (200 symbols): the run ends because the reference's own stop rule fired
+    (model.py:453), not because max_decoder_steps was reached."""
+    import t2v_oracle as O
+    _, _, sd0 = model_sd
+    g = np.load(os.path.join(golden_dir, 'inference_gate_stop.npz'))
+    sd = {k: v.clone() for k, v in sd0.items()}
+    fac = float(g[case + '_hh_scale'][0])
+    sd['decoder.attention_rnn.weight_hh'] *= fac
+    sd['decoder.decoder_rnn.weight_hh'] *= fac
+    sd['decoder.gate_layer.linear_layer.bias'] = torch.from_numpy(g[case + '_gate_bias']).clone()
+    ids = torch.from_numpy(g['ids'])
+    with torch.no_grad():
+        memory = O.encoder_forward(sd, ids, torch.tensor([ids.shape[1]]), training=False)
+        memory = memory + (torch.from_numpy(g['z']) @ sd['vae_gst.fc3.weight'].t() + sd['vae_gst.fc3.bias'])[:, None]
+        mel, gate, al = O.decoder_inference(sd, memory, max_steps=400)
+    n = int(g[case + '_n_frames'][0])
+    assert mel.shape[2] == n and n < 400                                  # stopped on the gate, at the same frame
+    tol = 1e-4 if case == 'plain' else 5e-3                               # 'lively': x6 recurrent weights amplify round-off
+    assert (mel - torch.from_numpy(g[case + '_mel'])).abs().max() < tol
+    assert torch.equal(al.argmax(-1).to(torch.int16), torch.from_numpy(g[case + '_align_argmax']))
+    assert (al.max(-1).values - torch.from_numpy(g[case + '_align_max'])).abs().max() < tol
+
+
+def test_koemo_text_front_end_hash(golden_dir):
+    """every unique sentence of the koemo filelists through OUR text front end, one SHA-256 against the reference's
+    (needs the read-only reference's filelists: data, present in the build container only)"""
+    import hashlib
+    from text import text_to_sequence
+    ref_dir = os.environ.get('T2V_REFERENCE', '/root/reference')
+    names = ['koemo_spk_emo_all_%s.txt' % s for s in ('train', 'valid', 'test')]
+    if not all(os.path.isfile(os.path.join(ref_dir, 'filelists', n)) for n in names):
+        pytest.skip("reference filelists not available here")
+    with open(os.path.join(golden_dir, 'koemo_ids_sha256.json')) as f:
+        gold = json.load(f)
+    sents = []
+    for n in names:
+        with open(os.path.join(ref_dir, 'filelists', n), encoding='utf-8') as f:
+            sents += [ln.strip().split('|')[1] for ln in f if ln.strip()]
+    uniq = sorted(set(sents))
+    assert len(uniq) == gold['unique_sentences'] and gold['skipped_need_nltk'] == 0
+    h = hashlib.sha256()
+    longest = 0
+    for t in uniq:
+        ids = text_to_sequence(t, ['korean_cleaners'])
+        longest = max(longest, len(ids))
+        h.update((t + '\t' + ','.join(str(i) for i in ids) + '\n').encode('utf-8'))
+    assert longest == gold['max_symbols'] == 555
+    assert h.hexdigest() == gold['sha256']
