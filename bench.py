@@ -30,7 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tacotron2-vae_amd'))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-B_PER_GPU, T_IN, T_OUT = 6, 84, 400
+T_IN, T_OUT = 84, 400
 LSTM_WEIGHT_BYTES = (4096 * 1536 + 4096 * 2560) * 4
 HBM_PEAK_GBS = 8000.0
 
@@ -55,8 +55,20 @@ def synthetic_batch(B, T_in, T_out, seed, lens_in=None, lens_out=None):
             emotions)
 
 
-def cpu_baseline(steps=2, warmup=1, threads=None):
-    """Oracle train step (fwd+loss+bwd+clip+Adam) on host cores, same workload, bounded sample."""
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for ln in f:
+                if ln.lower().startswith('model name'):
+                    return ln.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(steps=5, warmup=2, threads=None):
+    """Oracle train step (fwd+loss+bwd+clip+Adam) on host cores, same workload, bounded sample (SURVEY 8(d):
+    median of `steps` timed iterations after `warmup` warm-ups)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     if threads:
         torch.set_num_threads(threads)
@@ -70,19 +82,19 @@ def cpu_baseline(steps=2, warmup=1, threads=None):
     for k in names:
         sd[k].requires_grad_(True)
     mstate = {k: (torch.zeros_like(sd[k]), torch.zeros_like(sd[k])) for k in names}
-    text, lin, mel, gate, lout, _, _ = synthetic_batch(B_PER_GPU, T_IN, T_OUT, 1234)
+    text, lin, mel, gate, lout, _, _ = synthetic_batch(6, T_IN, T_OUT, 1234)
     g = torch.Generator().manual_seed(7)
     times = []
     for it in range(warmup + steps):
         t0 = time.perf_counter()
         drop = {}
         for i in range(3):
-            drop['enc%d' % i] = torch.rand(B_PER_GPU, 512, T_IN, generator=g) >= 0.5
+            drop['enc%d' % i] = torch.rand(6, 512, T_IN, generator=g) >= 0.5
         for i in range(5):
-            drop['post%d' % i] = torch.rand(B_PER_GPU, 512 if i < 4 else 80, T_OUT, generator=g) >= 0.5
-        drop['prenet0'] = torch.rand(T_OUT + 1, B_PER_GPU, 256, generator=g) >= 0.5
-        drop['prenet1'] = torch.rand(T_OUT + 1, B_PER_GPU, 256, generator=g) >= 0.5
-        drop['lstm'] = [{k: torch.rand(B_PER_GPU, 1024, generator=g) >= 0.1 for k in ('att_h', 'att_c', 'dec_h', 'dec_c')}
+            drop['post%d' % i] = torch.rand(6, 512 if i < 4 else 80, T_OUT, generator=g) >= 0.5
+        drop['prenet0'] = torch.rand(T_OUT + 1, 6, 256, generator=g) >= 0.5
+        drop['prenet1'] = torch.rand(T_OUT + 1, 6, 256, generator=g) >= 0.5
+        drop['lstm'] = [{k: torch.rand(6, 1024, generator=g) >= 0.1 for k in ('att_h', 'att_c', 'dec_h', 'dec_c')}
                         for _ in range(T_OUT)]
         out = O.tacotron2_forward(sd, text, lin, mel, lout, True, None, 0.1, 0.1, drop, 0.5, 0.5)
         loss = O.loss_forward(out, mel, gate, it, 'constant')[0]
@@ -96,10 +108,11 @@ def cpu_baseline(steps=2, warmup=1, threads=None):
                 mstate[k] = (m, v)
         times.append(time.perf_counter() - t0)
     t = sorted(times[warmup:])[len(times[warmup:]) // 2]
-    return {"value": round(B_PER_GPU * T_OUT / t, 2), "unit": "mel-frames/s", "cores": torch.get_num_threads(),
-            "kind": "port", "s_per_it": round(t, 3),
-            "sample": "%d timed train steps (after %d warm-up) of the same B=6,T_in=84,T_out=400 workload, "
-                      "oracle/t2v_oracle.py with stock torch CPU fp32 ops, dropout on" % (steps, warmup)}
+    return {"value": round(6 * T_OUT / t, 2), "unit": "mel-frames/s", "cores": torch.get_num_threads(),
+            "kind": "port", "s_per_it": round(t, 3), "host_cpu": _cpu_model(), "host_nproc": os.cpu_count(),
+            "sample": "median of %d timed train steps after %d warm-up(s) of the same B=6,T_in=84,T_out=400 workload, "
+                      "oracle/t2v_oracle.py with stock torch CPU fp32 ops, dropout on, %d torch threads"
+                      % (steps, warmup, torch.get_num_threads())}
 
 
 def decode_bench(model, T_in=200, steps=800):
@@ -134,27 +147,158 @@ def decode_bench(model, T_in=200, steps=800):
             "steps": steps, "note": "decoder loop only (incl. weight packing + memory_layer); encoder/postnet excluded"}
 
 
+def frontend_bench(B=6, n_samples=102144, reps=20):
+    """STFT->mel front end (k_mel_frontend): B utterances of 102 144 int16 samples (-> 400 frames
+    each), events on the launch stream.  Algorithmic bytes per frame = 256 new samples x 2 B + 80 mels x 4 B = 832 B
+    (SURVEY 8(d) counts 1 344 B/frame with fp32 samples)."""
+    import layers
+    import t2v_hip
+    stft = layers.TacotronSTFT(1024, 256, 1024, 80, 16000, 0.0, 8000.0)
+    g = torch.Generator().manual_seed(0)
+    wav = (torch.clamp(0.1 * torch.randn(B, n_samples, generator=g), -1, 1) * 32767).to(torch.int16).cuda()
+    n = torch.full((B,), n_samples, dtype=torch.int64)
+    tables = stft._tables(wav.device)
+    t2v_hip.mel_frontend(wav, n, tables, scale=1.0 / 32768.0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        mel = t2v_hip.mel_frontend(wav, n, tables, scale=1.0 / 32768.0, t_stride=n_samples // 256 + 1)
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1000.0 * e0.elapsed_time(e1) / reps
+    frames = B * (n_samples // 256 + 1)
+    return {"kernel": "k_mel_frontend", "frames_per_s": round(frames / (us * 1e-6), 1), "us_per_launch": round(us, 2),
+            "frames_per_launch": frames, "bytes_per_frame": 832, "achieved_GBps": round(frames * 832 / (us * 1e-6) / 1e9, 2),
+            "note": "int16 PCM in HBM -> (B,80,T) log-mel in HBM, one launch per batch; not part of the timed train step "
+                    "(the synthetic batch carries mels, like the reference's collate output)"}
+
+
+def roofline_table(B, T_in, T, reps=3):
+    """Event-timed replays of the four per-time-step kernels of the decoder recurrence on the arena of the last step
+    (events on the launch stream = torch's current stream).  Algorithmic bytes: what one launch must move at least."""
+    import t2v_hip
+    f4 = 4
+    lstm_bytes = LSTM_WEIGHT_BYTES
+    attn_fwd_bytes = f4 * (B * 256 * 128 + B * T_in * 128 + B * T_in * 512 + 2 * B * T_in + 8192        # qp, pm, memory, al/acum, W_comb
+                           + B * T_in * 128 + 2 * B * T_in + B * 512)                                    # S, al/acum out, ctx
+    attn_bwd_bytes = f4 * (2 * B * T_in * 128 + B * T_in * 512 + B * (1536 + 2560 + 1536)                # S r/w, memory, dHC/YD/YA
+                           + 2 * B * 4096 + 4 * B * 1024 + 2 * B * 4096 + 1024 * 128 + 8192)             # GA/GD, cells, DGA/DGD, W_q^T, W_comb
+    rows = []
+    for name, fn, mask, nbytes in (("k_lstm_fwd256", t2v_hip.replay_fwd_kernels, 1, lstm_bytes),
+                                   ("k_lstm_bwd256", t2v_hip.replay_bwd_kernels, 1, lstm_bytes),
+                                   ("k_attn_cell_bwd", t2v_hip.replay_bwd_kernels, 2, attn_bwd_bytes),
+                                   ("k_attn_fwd", t2v_hip.replay_fwd_kernels, 2, attn_fwd_bytes)):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn(mask)
+        torch.cuda.synchronize()
+        ev0.record()
+        n = 0
+        for _ in range(reps):
+            n += fn(mask)
+        ev1.record()
+        torch.cuda.synchronize()
+        us = 1000.0 * ev0.elapsed_time(ev1) / n
+        gbs = nbytes / (us * 1e-6) / 1e9
+        rows.append({"kernel": name, "bound": "hbm", "algorithmic_bytes_per_launch": int(nbytes),
+                     "avg_launch_us": round(us, 3), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(gbs / HBM_PEAK_GBS, 4), "launches_per_step": T + (1 if name in ("k_lstm_fwd256", "k_attn_cell_bwd") else 0),
+                     "launches_timed": n})
+    return rows
+
+
+def run_workload(args, world, rank, bf16, koemo, steps, warmup, graph):
+    """one timed configuration; returns (engine, result dict)"""
+    import hparams as HP
+    import t2v_hip
+    import train as TR
+    bpg = 16 if bf16 else 6
+    hp = HP.create_hparams("batch_size=%d,anneal_function=constant%s%s" % (
+        bpg, ",distributed_run=True" if world > 1 else "", ",bf16_run=True" if bf16 else ""))
+    torch.manual_seed(hp.seed)
+    torch.cuda.manual_seed(hp.seed)
+    engine = TR.TrainEngine(hp, world_size=world, graph=graph)
+    koemo_in, koemo_out = [84, 80, 71, 66, 50, 37], [400, 380, 350, 300, 260, 200]
+    if koemo:
+        batch = synthetic_batch(bpg, T_IN, T_OUT, 1234 + rank, lens_in=koemo_in, lens_out=koemo_out)
+    else:
+        batch = synthetic_batch(bpg, T_IN, T_OUT, 1234 + rank)
+    batch = tuple(t.pin_memory() for t in batch)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    it = 0
+    startup = 0
+    with engine.stream_context():
+        if engine.use_graph:
+            # graph priming is start-up cost like building the model: the shape is captured the third time it is seen,
+            # so these extra untimed steps make sure neither the warm-up nor the timed region contains the capture
+            startup = engine.GRAPH_AFTER + 1 + args.settle
+            for _ in range(startup):
+                engine.step(batch, it)
+                it += 1
+        for _ in range(warmup):
+            engine.step(batch, it)
+            it += 1
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = engine.step(batch, it)[0]
+            it += 1
+        sync()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final_loss = float(loss.item())
+    t2v_hip.check_async_errors()     # any bounded-spin timeout inside the timed steps invalidates the run
+    frames = (sum(koemo_out) if koemo else bpg * T_OUT) * world      # koemo: valid (unpadded) frames, like the metric
+    ms = 1000.0 * elapsed / steps
+    res = {"value": round(frames / (elapsed / steps), 1), "ms_per_step": round(ms, 3), "frames_per_step": frames,
+           "final_loss": round(final_loss, 5), "step_mode": "hip-graph replay" if engine.use_graph else "eager launches",
+           "startup_steps": startup, "batch_per_gpu": bpg}
+    if world > 1 and engine.allreduce is not None:
+        res["allreduce_exposed_ms"] = round(engine.allreduce.exposed_ms(), 3)
+    return engine, res
+
+
+WORKLOADS = {
+    "headline": "configs[1]: Tacotron2-VAE fp32 train step (fwd+loss+bwd+clip+Adam), B=6/GPU fixed shape T_in=84 T_out=400, "
+                "dropout on, random-init seed 1234",
+    "koemo": "configs[1], koemo length profile: fp32 train step, B=6/GPU ragged (T_in,T_out) = (84,400),(80,380),(71,350),"
+             "(66,300),(50,260),(37,200), valid frames counted, dropout on",
+    "bf16": "configs[4]: bf16_run train step (bf16 MFMA wide Conv1d fwd/dx + time-batched linears + LSTM dW GEMMs; fp32 "
+            "master/BN/recurrence), B=16/GPU fixed shape T_in=84 T_out=400, dropout on, random-init seed 1234",
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-steps', type=int, default=5)
+    ap.add_argument('--cpu-warmup', type=int, default=2)
     ap.add_argument('--cpu-threads', type=int, default=8,
                     help='torch CPU threads for the baseline leg (the M=6 GEMVs of this model stop scaling\n'
                          'around 8 threads on this EPYC host: 8 → 3.7 s/it, 16 → 4.2, 32 → 7.4, all cores ≈ 40)')
+    ap.add_argument('--cpu-all-cores', action='store_true',
+                    help='additionally time ONE oracle step with every host core (≈40 s on the 128-core host)')
     ap.add_argument('--no-decode', action='store_true')
-    ap.add_argument('--koemo', action='store_true',
-                    help='secondary workload of SURVEY 8(d): the ragged koemo length profile instead of the fixed shape\n'
-                         '((T_in,T_out) = (84,400),(80,380),(71,350),(66,300),(50,260),(37,200); valid frames counted)')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip the secondary workloads (koemo length profile, bf16 B=16) and the front-end leg')
     ap.add_argument('--settle', type=int, default=40,
-                    help='extra untimed start-up steps after the graph capture (the first ~40 replays after process start\n'
-                         'run ~4 %% slower than the steady state on this box; reported as config.startup_steps)')
+                    help='extra untimed start-up steps after the graph capture (reported as config.startup_steps)')
     ap.add_argument('--no-graph', action='store_true',
                     help='run the step eagerly (one host launch per kernel) instead of replaying the captured HIP graph')
-    ap.add_argument('--bf16', action='store_true',
-                    help='BASELINE configs[4] instead of the headline config: bf16_run=True, B=16 per GPU')
+    ap.add_argument('--koemo', action='store_true', help='make the koemo length profile the headline workload')
+    ap.add_argument('--bf16', action='store_true', help='make BASELINE configs[4] (bf16_run, B=16 per GPU) the headline workload')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -179,116 +323,82 @@ def main():
     if world > 1:
         dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank)
 
-    import hparams as HP
     import t2v_hip
-    import train as TR
     t2v_hip.load_library()
-    t2v_hip.DecoderCore.keep_last = True       # the roofline leg replays the last forward's kernels on its arena
-    global B_PER_GPU
-    if args.bf16:
-        B_PER_GPU = 16
-    hp = HP.create_hparams("batch_size=%d,anneal_function=constant%s%s" % (
-        B_PER_GPU, ",distributed_run=True" if world > 1 else "", ",bf16_run=True" if args.bf16 else ""))
-    torch.manual_seed(hp.seed)
-    torch.cuda.manual_seed(hp.seed)
-    engine = TR.TrainEngine(hp, world_size=world, graph=not args.no_graph)
-    if args.koemo and not args.bf16:
-        koemo_in, koemo_out = [84, 80, 71, 66, 50, 37], [400, 380, 350, 300, 260, 200]
-        batch = synthetic_batch(B_PER_GPU, T_IN, T_OUT, 1234 + rank, lens_in=koemo_in, lens_out=koemo_out)
-    else:
-        batch = synthetic_batch(B_PER_GPU, T_IN, T_OUT, 1234 + rank)
-    batch = tuple(t.pin_memory() for t in batch)
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    it = 0
-    with engine.stream_context():
-        if engine.use_graph:
-            # graph priming is start-up cost like building the model: the shape is captured the third time it is seen,
-            # so three extra untimed steps make sure neither the warm-up nor the timed region contains the capture
-            for _ in range(engine.GRAPH_AFTER + 1 + args.settle):
-                engine.step(batch, it)
-                it += 1
-        for _ in range(args.warmup):
-            engine.step(batch, it)
-            it += 1
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = engine.step(batch, it)[0]
-            it += 1
-        sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    final_loss = float(loss.item())
-    t2v_hip.check_async_errors()     # any bounded-spin timeout inside the timed steps invalidates the run
-
-    ms_per_step = 1000.0 * elapsed / args.steps
-    frames = B_PER_GPU * T_OUT * world
-    if args.koemo and not args.bf16:
-        frames = sum(koemo_out) * world          # valid (unpadded) frames, like the metric's definition
-    value = frames / (elapsed / args.steps)
-
+    t2v_hip.DecoderCore.keep_last = True       # the roofline leg replays the last step's kernels on its arena
+    kind = 'bf16' if args.bf16 else ('koemo' if args.koemo else 'headline')
+    engine, res = run_workload(args, world, rank, args.bf16, args.koemo and not args.bf16, args.steps, args.warmup,
+                               not args.no_graph)
+    bpg = res["batch_per_gpu"]
     out = {
-        "metric": "mel-frames/s (train step, batch=%d, 80-mel)" % B_PER_GPU, "value": round(value, 1),
+        "metric": "mel-frames/s (train step, batch=%d, 80-mel)" % bpg, "value": res["value"],
         "unit": "mel-frames/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.bf16 else "f32",
         "data": "synthetic",
-        "config": {"workload": ("configs[4]: bf16_run train step (bf16 MFMA wide Conv1d fwd/dx + time-batched linears "
-                                "+ LSTM dW GEMMs; fp32 master/BN/recurrence), B=16/GPU fixed shape T_in=84 T_out=400, "
-                                "dropout on, random-init seed 1234") if args.bf16 else
-                               ("configs[1], koemo length profile: fp32 train step, B=6/GPU ragged (T_in,T_out) = (84,400),"
-                                "(80,380),(71,350),(66,300),(50,260),(37,200), valid frames counted, dropout on"
-                                if args.koemo else
-                                "configs[1]: Tacotron2-VAE fp32 train step (fwd+loss+bwd+clip+Adam), "
-                                "B=6/GPU fixed shape T_in=84 T_out=400, dropout on, random-init seed 1234"),
-                   "step_mode": "hip-graph replay" if engine.use_graph else "eager launches",
-                   "startup_steps": (engine.GRAPH_AFTER + 1 + args.settle) if engine.use_graph else 0,
-                   "global_batch": B_PER_GPU * world, "frames_per_step": frames,
+        "config": {"workload": WORKLOADS[kind], "step_mode": res["step_mode"], "startup_steps": res["startup_steps"],
+                   "global_batch": bpg * world, "frames_per_step": res["frames_per_step"],
                    "parallelism": "dp%d" % world},
-        "final_loss": round(final_loss, 5),
+        "final_loss": res["final_loss"],
     }
+    if world > 1:
+        out["rccl_ranks"] = dist.get_world_size()
+        if "allreduce_exposed_ms" in res:
+            out["allreduce_exposed_ms"] = res["allreduce_exposed_ms"]
 
     if rank == 0:
-        # ---- roofline leg: replay only k_lstm_fwd256's T+1 launches of the last forward, events on
-        # the launch stream (torch's current stream is the stream the library launches on).
-        reps = 3
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t2v_hip.replay_fwd_kernels(1)
-        torch.cuda.synchronize()
-        ev0.record()
-        n = 0
-        for _ in range(reps):
-            n += t2v_hip.replay_fwd_kernels(1)
-        ev1.record()
-        torch.cuda.synchronize()
-        us = 1000.0 * ev0.elapsed_time(ev1) / n
-        achieved = LSTM_WEIGHT_BYTES / (us * 1e-6) / 1e9
-        traffic = None      # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, corrected)
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_pmc_fetch_size.json')) as f:
-                traffic = json.load(f)["kernels"]["k_lstm_fwd256"]["corrected_bytes_per_launch"]
-        except Exception:
-            pass
-        out["roofline"] = {"kernel": "k_lstm_fwd256", "bound": "hbm", "achieved": round(achieved, 1),
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                           "traffic": traffic, "avg_launch_us": round(us, 3),
-                           "algorithmic_bytes_per_launch": LSTM_WEIGHT_BYTES, "launches_timed": n}
+        # ---- roofline leg: the four per-time-step kernels of the decoder recurrence (87 % of the GPU time of a step)
+        rows = roofline_table(bpg, T_IN, T_OUT)
+        top = rows[0]
+        traffic, tsrc = None, None      # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, corrected)
+        for fn in ('r02_pmc_fetch_size.json', 'r01_pmc_fetch_size.json'):
+            try:
+                with open(os.path.join(ROOT, 'profiles', fn)) as f:
+                    traffic = json.load(f)["kernels"]["k_lstm_fwd256"]["corrected_bytes_per_launch"]
+                tsrc = "profiles/%s (separate rocprofv3 --pmc pass, tools/pmc_fetch_size.sh; not measured in this run)" % fn
+                break
+            except Exception:
+                pass
         e2e_bytes = 58.9e9   # compulsory bytes of one cfg-2 iteration
-        out["roofline"]["end_to_end_frac"] = round(e2e_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        rec_us = sum(r["avg_launch_us"] for r in rows)
+        out["roofline"] = {"kernel": top["kernel"], "bound": "hbm", "achieved": top["achieved"], "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": top["frac"], "traffic": traffic, "traffic_source": tsrc,
+                           "avg_launch_us": top["avg_launch_us"],
+                           "algorithmic_bytes_per_launch": top["algorithmic_bytes_per_launch"],
+                           "launches_timed": top["launches_timed"],
+                           "note": "the 67 MB weight stream of a launch is re-read every time step and is served by the "
+                                   "256 MiB Infinity Cache, not by HBM proper; 8 TB/s is the HBM3E peak the guide prices against",
+                           "kernels": rows,
+                           "recurrence_us_per_time_step": round(rec_us, 2),
+                           "recurrence_hbm_floor_us_per_time_step": round(4 * 0 + 2 * LSTM_WEIGHT_BYTES / (HBM_PEAK_GBS * 1e3), 2),
+                           "end_to_end_frac": round(e2e_bytes / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                           if kind == 'headline' else None}
         if not args.no_decode:
             out["decode"] = decode_bench(engine.model)
+        if world == 1 and not args.no_secondary:
+            out["frontend"] = frontend_bench()
+            sec = {}
+            del engine
+            t2v_hip.DecoderCore.keep_last = False
+            t2v_hip.DecoderCore.last_call = t2v_hip.DecoderCore.last_bwd = None
+            torch.cuda.empty_cache()
+            for name, (b16, ko) in (("koemo", (False, True)), ("bf16", (True, False))):
+                if name == kind:
+                    continue
+                t2v_hip.release_step_params()
+                _, r2 = run_workload(args, world, rank, b16, ko, max(10, args.steps // 2), 3, not args.no_graph)
+                r2["workload"] = WORKLOADS[name]
+                r2["unit"] = "mel-frames/s"
+                sec[name] = r2
+                t2v_hip.set_bf16(False)
+            out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(steps=args.cpu_steps, threads=args.cpu_threads)
-            out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+            out["cpu_baseline"] = cpu_baseline(steps=args.cpu_steps, warmup=args.cpu_warmup, threads=args.cpu_threads)
+            out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            if args.cpu_all_cores:
+                allc = cpu_baseline(steps=1, warmup=0, threads=os.cpu_count())
+                out["cpu_baseline"]["all_cores"] = {"value": allc["value"], "cores": allc["cores"], "s_per_it": allc["s_per_it"],
+                                                    "sample": "ONE timed step, no warm-up, every host core"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

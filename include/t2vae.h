@@ -142,6 +142,13 @@ int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
                           const t2v_dec_bwd_bufs* g, int B, int T_in, int T_out,
                           float p_att, float p_dec, uint64_t seed, void* stream);
 
+/* Measurement aid like t2v_decoder_replay_fwd_kernels for the reverse pass (bit0 = k_lstm_bwd256, bit1 = k_attn_cell_bwd) on the
+ * buffers of a finished backward.  Timing only: S already holds dpre, so the replayed attention backward is not a
+ * second valid gradient (the launch shapes, operand sizes and hand-offs are those of the real pass). */
+int t2v_decoder_replay_bwd_kernels(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
+                                   const t2v_dec_bwd_bufs* g, int B, int T_in, int T_out,
+                                   float p_att, float p_dec, uint64_t seed, int kernel_mask, void* stream);
+
 /* Deferred weight gradients of the location layer (model.py:24-28) reduced over the whole decoder pass in one
  * streaming kernel + a fixed-order partial sum (what autograd accumulates step by step at train.py:225), through
  * the fused filter bank:  dW_comb[d][c,k] = sum_{t,b,j} dpre[t,b,j,d] * a_c[t,b,j+k-15], then

@@ -433,9 +433,10 @@ static void launch_attn_cell_bwd(const AttnBwdArgs& fa, const CellBwdArgs& c, in
 
 extern "C" int t2v_attn_bwd_slices(int T_in) { return T_in < 1 ? 0 : t2v_attn_bwd_slices_(T_in); }
 
-extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
-                                     const t2v_dec_bwd_bufs* g, int B, int T_in, int T_out,
-                                     float p_att, float p_dec, uint64_t seed, void* stream_) {
+// mask bits: 1 = k_lstm_bwd256, 2 = k_attn_cell_bwd (3 = the reverse pass; single bits = measurement replays)
+static int launch_train_bwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
+                            const t2v_dec_bwd_bufs* g, int B, int T_in, int T_out,
+                            float p_att, float p_dec, uint64_t seed, void* stream_, int mask) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!w || !s || !g || B < 1 || B > 16 || T_in < 1 || T_in > T2V_MAX_T_IN || T_out < 1) return T2V_ERR_ARG;
     if (!w->packB_att || !w->packB_dec || !w->wcomb) return T2V_ERR_ARG;
@@ -466,7 +467,7 @@ extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_tra
             l.YA = g->YA;
             l.B = B;
             l.flip = t & 1;
-            k_lstm_bwd256<<<T2V_NWG, 256, 0, stream>>>(l);
+            if (mask & 1) k_lstm_bwd256<<<T2V_NWG, 256, 0, stream>>>(l);
 
             AttnBwdArgs f;
             f.dHC_t = g->dHC + (size_t)t * B * HC;
@@ -517,8 +518,21 @@ extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_tra
         c.err = sync + 1;
         c.prof = g_t2v_prof ? g_t2v_prof + 24 : nullptr;
         const int nattn = have_attn ? B * S : 0;
+        if (!(mask & 2)) continue;
         if (JS == 16) launch_attn_cell_bwd<16>(fa, c, nattn, S, B, lds, stream);
         else launch_attn_cell_bwd<32>(fa, c, nattn, S, B, lds, stream);
     }
     return t2v_check_launch();
+}
+
+extern "C" int t2v_decoder_train_bwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
+                                     const t2v_dec_bwd_bufs* g, int B, int T_in, int T_out,
+                                     float p_att, float p_dec, uint64_t seed, void* stream_) {
+    return launch_train_bwd(w, s, g, B, T_in, T_out, p_att, p_dec, seed, stream_, 3);
+}
+
+extern "C" int t2v_decoder_replay_bwd_kernels(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
+                                              const t2v_dec_bwd_bufs* g, int B, int T_in, int T_out,
+                                              float p_att, float p_dec, uint64_t seed, int kernel_mask, void* stream_) {
+    return launch_train_bwd(w, s, g, B, T_in, T_out, p_att, p_dec, seed, stream_, kernel_mask & 3);
 }

@@ -126,6 +126,7 @@ class OverlappedArenaAllReduce(object):
         self._works = [None] * len(buckets)
         self._active = False
         self.launch_log = []          # (bucket index, launched from a hook i.e. while backward was running)
+        self._exposed = []
         for bi, b in enumerate(buckets):
             for p in b[3]:
                 p.register_post_accumulate_grad_hook(self._make_hook(bi))
@@ -165,9 +166,25 @@ class OverlappedArenaAllReduce(object):
             return
         for bi in range(len(self.buckets)):
             self._launch(bi, False)
+        timed = self.flat.is_cuda
+        if timed:       # the compute stream stalls exactly between these two events: the EXPOSED part of the exchange
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self._works:
             w.wait()
+        if timed:
+            e1.record()
+            self._exposed.append((e0, e1))
+            del self._exposed[:-64]
         self._active = False
+
+    def exposed_ms(self):
+        """mean time per step the compute stream waited for collectives that had not finished when backward ended
+        (events on the compute stream around the waits of the last <= 64 steps; synchronises)"""
+        if not self._exposed:
+            return 0.0
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._exposed) / len(self._exposed)
 
 
 def reduce_tensor(tensor, n_gpus):

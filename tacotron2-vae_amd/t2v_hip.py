@@ -45,7 +45,7 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decode
            't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_conv1d_dw_scratch_floats', 't2v_gemm_bf16', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
            't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats',
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_fuse_location_weights', 't2v_decoder_qp_floats',
-           't2v_set_step_params',
+           't2v_set_step_params', 't2v_decoder_replay_bwd_kernels',
            't2v_attn_bwd_slices')
 
 
@@ -78,6 +78,9 @@ def load_library():
     lib.t2v_decoder_replay_fwd_kernels.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecTrainBufs), C.c_int,
                                                    C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_int,
                                                    C.c_void_p]
+    lib.t2v_decoder_replay_bwd_kernels.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecTrainBufs),
+                                                   C.POINTER(_DecBwdBufs), C.c_int, C.c_int, C.c_int, C.c_float,
+                                                   C.c_float, C.c_uint64, C.c_int, C.c_void_p]
     lib.t2v_clip_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float,
                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -307,6 +310,18 @@ def replay_fwd_kernels(kernel_mask):
     return T + 1 if kernel_mask == 1 else T
 
 
+def replay_bwd_kernels(kernel_mask):
+    """Re-issue the k_lstm_bwd256 (mask 1) / k_attn_cell_bwd (mask 2) launches of the most recent DecoderCore.backward
+    (first batch chunk) on its buffers — timing only (bench.py roofline leg; needs DecoderCore.keep_last = True)."""
+    if DecoderCore.last_bwd is None:
+        raise T2VHipError("replay_bwd_kernels: no backward pass was kept (DecoderCore.keep_last = True before the step)")
+    W, Sb, Gb, (B, T_in, T, p_att, p_dec, seed), _keep = DecoderCore.last_bwd
+    _check(load_library().t2v_decoder_replay_bwd_kernels(C.byref(W), C.byref(Sb), C.byref(Gb), B, T_in, T, p_att, p_dec,
+                                                         seed, int(kernel_mask), _stream()),
+           't2v_decoder_replay_bwd_kernels')
+    return T if kernel_mask == 1 else T + 1
+
+
 def pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, k_att, need_bwd):
     """MFMA-fragment tiles of the two decoder LSTM cells, read straight from the nn.LSTMCell tensors."""
     lib = load_library()
@@ -344,6 +359,7 @@ class DecoderCore(torch.autograd.Function):
     reference's default batch_size = 64 works; weight gradients are summed over the chunks.
     """
     last_call = None
+    last_bwd = None
     keep_last = False       # bench / tests: keep the (first chunk's) arena of the last forward for replays
 
     @staticmethod
@@ -446,6 +462,10 @@ class DecoderCore(torch.autograd.Function):
             _check(lib.t2v_decoder_train_bwd(C.byref(W), C.byref(Sb), C.byref(Gb), B, T_in, T, p_att, p_dec,
                                              (seed + 7919 * b0) & 0x7FFFFFFFFFFFFFFF, _stream()), 't2v_decoder_train_bwd')
             _err_note('decoder backward (dq hand-off)', GCUM.view(torch.int32)[B * NS * tcap + 1:][:1])
+            if DecoderCore.keep_last and b0 == 0:
+                DecoderCore.last_bwd = (W, Sb, Gb, (B, T_in, T, p_att, p_dec, seed),
+                                        keep + (dhc_c, DGA, DGD, DQ, DCTX, YD, YA, DCA, DCD, GPREV, GCUM, DV, packs, bias_dec,
+                                                wqT, wcomb, vv))
             TB = T * B
             dga2, dgd2 = DGA.view(TB, G4), DGD.view(TB, G4)
             # time-batched weight-gradient GEMMs
