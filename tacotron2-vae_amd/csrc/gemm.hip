@@ -93,6 +93,167 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
     }
 }
 
+// ---- large-tile variant for the big time-batched GEMMs (the deferred LSTM weight gradients DGA^T·X / DGD^T·X with
+// K = T·B, the hoisted attention_rnn input term, the data gradients of the Prenet): 128x128x16 block tile, 256 threads =
+// 2x2 waves, each wave a 64x64 patch = 2x2 accumulators of v_mfma_f32_32x32x2_f32 (one LDS read per operand per MFMA:
+// 4 ds_read_b32 feed 4 MFMAs = 256 matrix-core cycles), 16-byte global loads from clamped addresses (no divergent
+// branch around a load), register-staged double buffering with ONE barrier per k-tile.  LDS rows are 160 floats so
+// that the two k-rows an MFMA reads sit in disjoint bank halves.
+#define GB_BM 128
+#define GB_BK 32
+#define GB_LD 160
+template <bool A_KC, bool B_KC, int BN>     // BN = 128 or 64 columns per block (the narrower tile evens out the last wave of tiles)
+__global__ __launch_bounds__(256) void k_gemm_f32_big(GemmArgs a) {
+    constexpr int NY = BN / 64;                      // 32-column accumulators per wave
+    constexpr int NA = GB_BM * GB_BK / 4 / 256;      // float4 of the A tile per thread (4)
+    constexpr int NB = BN * GB_BK / 4 / 256;         // float4 of the B tile per thread (2 or 4)
+    constexpr int KQ = GB_BK / 4;                    // float4 per row of a k-contiguous operand (8)
+    __shared__ __attribute__((aligned(16))) float As[2][GB_BK][GB_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GB_BK][BN + 32];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i0 = blockIdx.y * GB_BM, j0 = blockIdx.x * BN;
+    float4 ra[NA], rb[NB];
+    // thread -> element of the operand tile: k-contiguous operand: (row = tid/KQ + (256/KQ) e, k4 = tid%KQ);
+    //                                        row-contiguous operand: (k = tid/(rows/4) + .. e, row4 = tid%(rows/4))
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < NA; ++e) {
+            if (A_KC) {
+                const int i = min(i0 + tid / KQ + (256 / KQ) * e, a.M - 1), k = min(k0 + 4 * (tid % KQ), a.K - 4);
+                ra[e] = *(const float4*)(a.A + (long)i * a.sAi + k);
+            } else {
+                const int k = min(k0 + (tid >> 5) + 8 * e, a.K - 1), i = min(i0 + 4 * (tid & 31), a.M - 4);
+                ra[e] = *(const float4*)(a.A + (long)k * a.sAk + i);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            if (B_KC) {
+                const int j = min(j0 + tid / KQ + (256 / KQ) * e, a.N - 1), k = min(k0 + 4 * (tid % KQ), a.K - 4);
+                rb[e] = *(const float4*)(a.B + (long)j * a.sBj + k);
+            } else {
+                constexpr int RQ = BN / 4;       // float4 per k-row
+                const int k = min(k0 + tid / RQ + (256 / RQ) * e, a.K - 1), j = min(j0 + 4 * (tid % RQ), a.N - 4);
+                rb[e] = *(const float4*)(a.B + (long)k * a.sBk + j);
+            }
+        }
+    };
+    // rows beyond K contribute zero: the clamped loads above fetched valid (finite) memory, the k mask zeroes it
+    auto store_tiles = [&](int buf, int k0) {
+#pragma unroll
+        for (int e = 0; e < NA; ++e) {
+            if (A_KC) {
+                const int m = tid / KQ + (256 / KQ) * e, kk = 4 * (tid % KQ);
+                const float z = k0 + kk < a.K ? 1.f : 0.f;        // K % 4 == 0: a float4 is all in or all out
+                As[buf][kk + 0][m] = ra[e].x * z; As[buf][kk + 1][m] = ra[e].y * z;
+                As[buf][kk + 2][m] = ra[e].z * z; As[buf][kk + 3][m] = ra[e].w * z;
+            } else {
+                const int kk = (tid >> 5) + 8 * e;
+                const float z = k0 + kk < a.K ? 1.f : 0.f;
+                *(float4*)&As[buf][kk][4 * (tid & 31)] = make_float4(ra[e].x * z, ra[e].y * z, ra[e].z * z, ra[e].w * z);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            if (B_KC) {
+                const int n = tid / KQ + (256 / KQ) * e, kk = 4 * (tid % KQ);
+                const float z = k0 + kk < a.K ? 1.f : 0.f;
+                Bs[buf][kk + 0][n] = rb[e].x * z; Bs[buf][kk + 1][n] = rb[e].y * z;
+                Bs[buf][kk + 2][n] = rb[e].z * z; Bs[buf][kk + 3][n] = rb[e].w * z;
+            } else {
+                constexpr int RQ = BN / 4;
+                const int kk = tid / RQ + (256 / RQ) * e;
+                const float z = k0 + kk < a.K ? 1.f : 0.f;
+                *(float4*)&Bs[buf][kk][4 * (tid % RQ)] = make_float4(rb[e].x * z, rb[e].y * z, rb[e].z * z, rb[e].w * z);
+            }
+        }
+    };
+    f32x16 acc[2][NY];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < NY; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+    const int nkt = (a.K + GB_BK - 1) / GB_BK;
+    load_tiles(0);
+    store_tiles(0, 0);
+    __syncthreads();
+    const int am = 64 * wm + (lane & 31), bn = (BN / 2) * wn + (lane & 31), kh = lane >> 5;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tiles((kt + 1) * GB_BK);
+        // LDS operands are requested half a k-tile ahead of their MFMAs (the compiler otherwise waits for each step's
+        // reads right before its MFMAs: one LDS latency per 2-4 MFMAs); the MFMAs then drain the queue in order
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float av[GB_BK / 4][2], bw[GB_BK / 4][NY];
+#pragma unroll
+            for (int s = 0; s < GB_BK / 4; ++s) {
+                const int kr = GB_BK / 2 * h + 2 * s + kh;
+                av[s][0] = As[buf][kr][am];
+                av[s][1] = As[buf][kr][am + 32];
+#pragma unroll
+                for (int y = 0; y < NY; ++y) bw[s][y] = Bs[buf][kr][bn + 32 * y];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < GB_BK / 4; ++s) {
+#pragma unroll
+                for (int y = 0; y < NY; ++y) {
+                    acc[0][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][0], bw[s][y], acc[0][y], 0, 0, 0);
+                    acc[1][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][1], bw[s][y], acc[1][y], 0, 0, 0);
+                }
+            }
+        }
+        if (kt + 1 < nkt) store_tiles(buf ^ 1, (kt + 1) * GB_BK);
+        __syncthreads();
+    }
+    const uint64_t seed = t2v_step_seed(a.seed, a.step);
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < NY; ++y) {
+            const int j = j0 + (BN / 2) * wn + 32 * y + (lane & 31);
+            if (j < a.N) {
+                const float bvs = a.bias ? a.bias[j] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = i0 + 64 * wm + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (i < a.M) {
+                        const size_t idx = (size_t)i * a.ldc + j;
+                        float v = acc[x][y][r] + bvs;
+                        if (a.accumulate) v += a.C[idx];
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        if (a.p_drop > 0.f) v *= t2v_drop_scale(seed, a.rng_stream, a.rng_t, (uint32_t)idx, a.p_drop);
+                        a.C[idx] = v;
+                    }
+                }
+            }
+        }
+}
+
+// rounds of resident tiles the chip needs (256 CUs, 2 blocks per CU) relative to the ideal: picks the column width
+static double gemm_big_waste(int M, int N, int BN) {
+    const double tiles = (double)((M + GB_BM - 1) / GB_BM) * ((N + BN - 1) / BN) * (BN / 64.0);   // in 128x64 units of work
+    const double per_cu = tiles / 256.0;
+    const double unit = BN / 64.0;
+    return (double)((long)((per_cu + unit - 1e-9) / unit) + 0) * unit / per_cu;      // ceil to whole tiles per CU
+}
+
+// the large-tile kernel needs 16-byte-aligned float4 runs along each operand's contiguous index
+static bool gemm_big_ok(const GemmArgs& a) {
+    if (a.M < GB_BM || a.N < 128 || a.K < 4) return false;
+    // the tiles must still fill the chip: mid-size GEMMs (Prenet, BiLSTM projections: < 256 tiles of 128x64) keep the 64x64 kernel
+    if ((long)((a.M + GB_BM - 1) / GB_BM) * ((a.N + 63) / 64) < 256) return false;
+    if (((uintptr_t)a.A | (uintptr_t)a.B) & 15) return false;
+    const bool akc = a.sAk == 1, bkc = a.sBk == 1;
+    if (akc ? ((a.K & 3) || (a.sAi & 3)) : (a.sAi != 1 || (a.M & 3) || (a.sAk & 3))) return false;
+    if (bkc ? ((a.K & 3) || (a.sBj & 3)) : (a.sBj != 1 || (a.N & 3) || (a.sBk & 3))) return false;
+    return true;
+}
+
 // ---- bf16 variant (hparams bf16_run): operands rounded to bf16 (RNE) while staged, fp32 accumulate on
 // v_mfma_f32_32x32x8_bf16, fp32 in / fp32 out.  LDS tiles are k-contiguous [row][32 (+4 pad)] so each MFMA operand
 // is one ds_read_b64 (row stride 72 B: conflict-free).
@@ -201,8 +362,22 @@ extern "C" int t2v_gemm_f32(const float* A, long sAi, long sAk, const float* B, 
     a.A = A; a.B = B; a.bias = bias; a.C = C; a.sAi = sAi; a.sAk = sAk; a.sBj = sBj; a.sBk = sBk;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
     a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = g_t2v_step;
-    dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM);
     const bool akc = sAk == 1, bkc = sBk == 1;
+    if (gemm_big_ok(a)) {
+        const bool wide = gemm_big_waste(M, N, 128) <= gemm_big_waste(M, N, 64) + 1e-6;
+        const int BN = wide ? 128 : 64;
+        dim3 gb((N + BN - 1) / BN, (M + GB_BM - 1) / GB_BM);
+#define T2V_BIG(AK, BK)                                                             \
+        if (wide) k_gemm_f32_big<AK, BK, 128><<<gb, 256, 0, stream>>>(a);           \
+        else k_gemm_f32_big<AK, BK, 64><<<gb, 256, 0, stream>>>(a)
+        if (akc && bkc) { T2V_BIG(true, true); }
+        else if (akc) { T2V_BIG(true, false); }
+        else if (bkc) { T2V_BIG(false, true); }
+        else { T2V_BIG(false, false); }
+#undef T2V_BIG
+        return t2v_check_launch();
+    }
+    dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM);
     if (akc && bkc) k_gemm_f32<true, true><<<grid, 256, 0, stream>>>(a);
     else if (akc) k_gemm_f32<true, false><<<grid, 256, 0, stream>>>(a);
     else if (bkc) k_gemm_f32<false, true><<<grid, 256, 0, stream>>>(a);

@@ -471,11 +471,18 @@ class DecoderCore(torch.autograd.Function):
             # time-batched weight-gradient GEMMs
             x_prev = XS[0:T].reshape(TB, XW)          # [h_att_{t-1} | ctx_{t-1} | .]
             x_cur = XS[1:T + 1].reshape(TB, XW)       # [h_att_t | ctx_t | h_dec_{t-1}]
-            dw_att = mm_mixed(dga2.t(), x_prev[:, :KATT])      # (4096,1536) = [dW_hh | dW_ih[:,256:]]
-            dw_dec = mm_mixed(dgd2.t(), x_cur)                 # (4096,2560) = [dW_ih | dW_hh]
+            # ... on the own large-tile MFMA GEMM (fp32) / the library bf16 GEMM under bf16_run
+            if _BF16:
+                dw_att = mm_mixed(dga2.t(), x_prev[:, :KATT])      # (4096,1536) = [dW_hh | dW_ih[:,256:]]
+                dw_dec = mm_mixed(dgd2.t(), x_cur)                 # (4096,2560) = [dW_ih | dW_hh]
+            else:
+                dw_att = gemm(dga2.t(), x_prev[:, :KATT].t())
+                dw_dec = gemm(dgd2.t(), x_cur.t())
             d_bias_dec = dgd2.sum(0)
-            d_wq = DQ[..., 0].sum(2).view(TB, A).t() @ x_cur[:, :H]
-            d_memory = torch.bmm(AL[1:].permute(1, 2, 0), DCTX.permute(1, 0, 2))
+            d_wq = gemm(DQ[..., 0].sum(2).view(TB, A).t(), x_cur[:, :H].t())            # (128,1024)
+            d_memory = torch.empty(B, T_in, E, **f32)
+            for bi in range(B):                                # per item: alpha_b^T (T_in x T) · dctx_b (T x 512)
+                gemm(AL[1:, bi].t(), DCTX[:, bi].t(), out=d_memory[bi])
             dpre = S                                   # overwritten in place by the backward kernels
             d_pm = dpre.sum(0)
             d_v = DV.sum((0, 1)).view(1, A)

@@ -5,7 +5,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("M,N,K", [(2406, 81, 1536), (2406, 256, 80), (504, 128, 512), (7, 5, 3), (65, 129, 33)])
+@pytest.mark.parametrize("M,N,K", [(2406, 81, 1536), (2406, 256, 80), (504, 128, 512), (7, 5, 3), (65, 129, 33),
+                                   # large-tile kernel (M, N >= 128, 16-byte runs): ragged edges, K not a multiple of 16
+                                   (2400, 4096, 256), (1340, 1536, 2404), (2000, 1028, 52), (4096, 640, 20)])
 def test_gemm_forms(M, N, K):
     import t2v_hip
     g = torch.Generator().manual_seed(M + N + K)
@@ -49,3 +51,31 @@ def test_linear_autograd_with_relu_dropout():
     y2 = t2v_hip.LinearHIP.apply(gx, gw, None, True, 0.5, 123, 48, 7)
     y3 = t2v_hip.LinearHIP.apply(gx, gw, None, True, 0.5, 123, 48, 8)
     assert torch.equal(y, y2) and not torch.equal(y, y3)
+
+
+def test_gemm_big_tile_throughput_shape():
+    """the deferred decoder-LSTM weight gradient DGD^T·X at the bench shape: (4096 x 2400)·(2400 x 2560), TN form"""
+    import t2v_hip
+    g = torch.Generator().manual_seed(5)
+    dg = (torch.randn(2400, 4096, generator=g) * 0.1).cuda()
+    x = torch.randn(2400, 2560, generator=g).cuda()
+    out = t2v_hip.gemm(dg.t(), x.t())
+    ref = (dg.double().t() @ x.double()).float()
+    assert out.shape == (4096, 2560)
+    assert (out - ref).abs().max() < 1e-4 * ref.abs().max()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(10):
+        t2v_hip.gemm(dg.t(), x.t(), out=out)
+    ev1.record()
+    torch.cuda.synchronize()
+    tf = 10 * 2 * 4096 * 2400 * 2560 / (ev0.elapsed_time(ev1) * 1e-3) / 1e12
+    print('k_gemm_f32_big TN 4096x2560x2400: %.1f TFLOP/s (fp32 MFMA peak 157)' % tf)
+    lib0, lib1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    lib0.record()
+    for _ in range(10):
+        ref2 = dg.t() @ x
+    lib1.record()
+    torch.cuda.synchronize()
+    print('library GEMM same shape: %.1f TFLOP/s' % (10 * 2 * 4096 * 2400 * 2560 / (lib0.elapsed_time(lib1) * 1e-3) / 1e12))
+    assert tf > 40.0
