@@ -80,13 +80,6 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
         const float av = (ch == 0 ? a.al_prev : a.acum_prev)[(size_t)b * Tp + min(max(j, 0), Tp - 1)];
         apv[u] = av * ((i < 2 * (TPAD + 32) && j >= 0 && j < Tp) ? 1.f : 0.f);    // (a select would let the compiler sink the load back under the branch)
     }
-    // query partials of this slice: thread = (dq = tid&3 -> 4 consecutive d, wq = tid>>2 -> 4 source workgroups)
-    float4 qpart[4];
-    {
-        const float4* p = (const float4*)(a.qp + ((size_t)b * T2V_NWG + 4 * (tid >> 2)) * T2V_A + 16 * s) + (tid & 3);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) qpart[i] = p[(size_t)i * (T2V_A / 4)];
-    }
     // fused location filter rows of this slice as the MFMA A operand: A[d = 16s + c16][kk = 4st + g]
     float areg[16];
     {
@@ -98,6 +91,13 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
         }
     }
     const float4 vr = *(const float4*)(a.v + 16 * s + 4 * g);
+    // query partials of this slice: thread = (dq = tid&3 -> 4 consecutive d, wq = tid>>2 -> 4 source workgroups)
+    float4 qpart[4];
+    {
+        const float4* p = (const float4*)(a.qp + ((size_t)b * T2V_NWG + 4 * (tid >> 2)) * T2V_A + 16 * s) + (tid & 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qpart[i] = p[(size_t)i * (T2V_A / 4)];
+    }
     // pm in the energy-phase output layout: lane (g, c16) <-> d = 16s + 4g + r, position 16jt + c16;
     // wave w handles tiles jt = w, w+4, ..
     float4 pmr[NI];
@@ -124,7 +124,36 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
         const int i = tid + AF_THREADS * u;
         if (i < 2 * (TPAD + 32)) (&ap[0][0])[i] = apv[u];
     }
+    __syncthreads();                      // alignment window visible
     T2V_STAMP(a, 7);
+    // location features of this wave's tiles (independent of the query)
+    f32x4 lacc[NI];
+    if constexpr (!BIG) {
+        // every LDS operand is requested before the first MFMA (left to itself the compiler waits for each read right
+        // before its MFMA: one LDS latency per MFMA)
+        float bop[NI][16];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int jt = min(wave + 4 * i, NJT - 1);
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                const int kk = 4 * st + g;
+                bop[i][st] = ap[kk >> 5][16 * jt + c16 + (kk & 31)];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            f32x4 l0 = {0.f, 0.f, 0.f, 0.f}, l1 = {0.f, 0.f, 0.f, 0.f};          // two independent accumulator chains per tile
+#pragma unroll
+            for (int st = 0; st < 16; st += 2) {
+                l0 = mfma16x4(areg[st], bop[i][st], l0);
+                l1 = mfma16x4(areg[st + 1], bop[i][st + 1], l1);
+            }
+            lacc[i] = l0 + l1;
+        }
+    }
+    T2V_STAMP(a, 8);
     // ---- 1. processed query slice: 4 source workgroups per thread; the four threads of a 16-lane row that share a
     // d-quad are summed with two DPP row rotations (no LDS crossbar), the 16 row sums go through LDS (fixed order)
     {
@@ -137,25 +166,8 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
         s4.z = T2V_DPP_ADD(s4.z, 0x128); s4.w = T2V_DPP_ADD(s4.w, 0x128);
         if ((lane & 15) < 4) *(float4*)(scr + (tid >> 4) * 16 + 4 * (lane & 3)) = s4;      // scr[row 0..15][16 d]
     }
-    T2V_STAMP(a, 8);
     __syncthreads();
     T2V_STAMP(a, 9);
-    // location features of this wave's tiles (independent of the query)
-    f32x4 lacc[NI];
-    if constexpr (!BIG) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int jt = wave + 4 * i;
-            lacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (jt < NJT && 16 * jt < Tp) {
-#pragma unroll
-                for (int st = 0; st < 16; ++st) {
-                    const int kk = 4 * st + g;
-                    lacc[i] = mfma16x4(areg[st], ap[kk >> 5][16 * jt + c16 + (kk & 31)], lacc[i]);
-                }
-            }
-        }
-    }
     T2V_STAMP(a, 10);
     float4 q4;
     {
@@ -221,7 +233,10 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
     }
 
     T2V_STAMP(a, 2);
-    // ---- 3. gather the 8 partial-energy granules of every position (tag == epoch <=> written this step)
+    // ---- 3. gather the 8 partial-energy granules of every position (tag == epoch <=> written this step), masked
+    // softmax: 16-lane row max / sum with DPP, the 16 row partials through LDS (no LDS-crossbar shuffles)
+    __shared__ float rmax[16], rsum[16];
+    float ev0 = -INFINITY, mloc = -INFINITY;          // !BIG: this thread's single energy stays in a register
     for (int j = tid; j < Tp; j += AF_THREADS) {
         const t2v_u64* e0 = a.ex + (size_t)b * AF_NS * Tcap + j;
         float p[AF_NS];
@@ -243,22 +258,45 @@ __global__ __launch_bounds__(AF_THREADS) void k_attn_fwd(AttnFwdArgs a) {
             }
         }
         const float ev = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-        eall[j] = j < len ? ev : -INFINITY;
+        ev0 = j < len ? ev : -INFINITY;
+        if (BIG) eall[j] = ev0;
+        mloc = fmaxf(mloc, ev0);
     }
+    mloc = T2V_DPP_MAX(mloc, 0xB1); mloc = T2V_DPP_MAX(mloc, 0x4E);
+    mloc = T2V_DPP_MAX(mloc, 0x141); mloc = T2V_DPP_MAX(mloc, 0x140);
+    if (c16 == 0) rmax[tid >> 4] = mloc;
     __syncthreads();
     if (!ok_flag) return;
     T2V_STAMP(a, 3);
-    {   // masked softmax over all positions (every wave computes max / sum redundantly, same order)
-        float m = -INFINITY;
-        for (int j = lane; j < Tp; j += 64) m = fmaxf(m, eall[j]);
-        m = wave_max(m);
-        float sum = 0.f;
-        for (int j = lane; j < Tp; j += 64) sum += expf(eall[j] - m);
-        sum = wave_sum(sum);
-        const float inv = 1.0f / sum;
+    {
+        float mr[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) mr[u] = rmax[u];
+#pragma unroll
+        for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+            for (int u = 0; u < w; ++u) mr[u] = fmaxf(mr[u], mr[u + w]);
+        const float m = mr[0];
+        float e0v = 0.f, sloc = 0.f;
+        if constexpr (BIG) {
+            for (int j = tid; j < Tp; j += AF_THREADS) { const float e = expf(eall[j] - m); eall[j] = e; sloc += e; }
+        } else {
+            e0v = tid < Tp ? expf(ev0 - m) : 0.f;
+            sloc = e0v;
+        }
+        sloc = row16_sum(sloc);
+        if (c16 == 0) rsum[tid >> 4] = sloc;
         __syncthreads();
+        float sr[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sr[u] = rsum[u];
+#pragma unroll
+        for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+            for (int u = 0; u < w; ++u) sr[u] += sr[u + w];
+        const float inv = 1.0f / sr[0];
         for (int j = tid; j < Tp; j += AF_THREADS) {
-            const float al = expf(eall[j] - m) * inv;
+            const float al = (BIG ? eall[j] : e0v) * inv;
             eall[j] = al;
             if (s == 0) {
                 a.al_cur[(size_t)b * Tp + j] = al;

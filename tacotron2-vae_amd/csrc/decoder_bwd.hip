@@ -76,10 +76,11 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& a, const int b,
     constexpr int PW = JS + 30;            // width of a partial dcat row
     extern __shared__ __attribute__((aligned(16))) float dyn[];     // gfull[2][Tcap] | alf[Tcap]
     __shared__ __attribute__((aligned(16))) float dctx[T2V_E];
-    __shared__ float dal[JS], de[JS];
+    __shared__ float de[JS];
+    __shared__ float red[1 + JS / 4][16];                       // per (wave, 16-lane row) partial sums: dot, then one row per dalpha
     __shared__ float dpT[T2V_A][JS + 1];
     __shared__ float Tl[64][JS + 1];
-    __shared__ float scr[ATB_THREADS * 2 + 8];
+    __shared__ __attribute__((aligned(16))) float rq[8][T2V_A], rv[8][T2V_A];     // per row-group partial dq / dv
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
     const int Tp = a.T_in, j0 = s * JS;
@@ -90,16 +91,16 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& a, const int b,
     const int nown = min(JS, Tp - j0);     // > 0 by construction of S
 
     T2V_STAMP(a, 0);
-    // ---- entry loads
-    const int d = tid & (T2V_A - 1), jh = tid >> 7;       // (column, row parity) for the tanh phase
-    float sreg[JS / 2];
+    // ---- entry loads (wide, unconditional, in the order they are needed)
+    // tanh phase mapping: thread = (dim quad d4 = tid & 31, row group rg = tid >> 5), rows rg, rg + 8, ..
+    const int d4 = tid & 31, rg = tid >> 5;
+    float4 sreg[JS / 8];
     {
-        const float* sp = a.S_t + ((size_t)b * Tp + j0) * T2V_A + d;
+        const float* sp = a.S_t + ((size_t)b * Tp + j0) * T2V_A + 4 * d4;
 #pragma unroll
-        for (int i = 0; i < JS / 2; ++i) {
-            const int jl = jh + 2 * i;
-            const float sv = sp[(size_t)min(jl, nown - 1) * T2V_A];       // clamped address + select (no divergent-branch load)
-            sreg[i] = sv * (jl < nown ? 1.f : 0.f);
+        for (int i = 0; i < JS / 8; ++i) {
+            const int jl = rg + 8 * i;
+            sreg[i] = *(const float4*)(sp + (size_t)min(jl, nown - 1) * T2V_A);       // rows >= nown: masked below
         }
     }
     float4 m0[JS / 4], m1[JS / 4];                         // this wave's memory rows (wave w: rows w, w+4, ..)
@@ -110,14 +111,16 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& a, const int b,
         m0[r] = *(const float4*)mrow;
         m1[r] = *(const float4*)(mrow + 256);
     }
-    const float vd = a.v[d];
-    for (int e = tid; e < T2V_E; e += ATB_THREADS) {
-        const float v = a.dHC_t[(size_t)b * (T2V_H + T2V_E) + T2V_H + e] + a.YD[(size_t)b * T2V_XW + T2V_H + e] +
-                        a.YA[(size_t)b * T2V_KATT + T2V_H + e];
-        dctx[e] = v;
-        if (s == 0) a.DCTX_t[(size_t)b * T2V_E + e] = v;
+    const float4 vd4 = *(const float4*)(a.v + 4 * d4);
+    {
+        const float2 h2 = *(const float2*)(a.dHC_t + (size_t)b * (T2V_H + T2V_E) + T2V_H + 2 * tid);
+        const float2 y2 = *(const float2*)(a.YD + (size_t)b * T2V_XW + T2V_H + 2 * tid);
+        const float2 z2 = *(const float2*)(a.YA + (size_t)b * T2V_KATT + T2V_H + 2 * tid);
+        const float2 v2 = make_float2(h2.x + y2.x + z2.x, h2.y + y2.y + z2.y);
+        *(float2*)(dctx + 2 * tid) = v2;
+        if (s == 0) *(float2*)(a.DCTX_t + (size_t)b * T2V_E + 2 * tid) = v2;
     }
-    const float ctx0 = a.ctx_t[(size_t)b * T2V_XW + tid], ctx1 = a.ctx_t[(size_t)b * T2V_XW + 256 + tid];
+    const float2 ctx2 = *(const float2*)(a.ctx_t + (size_t)b * T2V_XW + 2 * tid);
     // assemble G over all positions from the previous reverse step's per-slice partial rows: position j receives
     // from the slices sp2 with 0 <= j - sp2*JS + 15 < PW (at most three), summed in ascending slice order
     float dot_g = 0.f;
@@ -131,9 +134,9 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& a, const int b,
             const int jj = j - sp2 * JS + 15;
             const bool in = sp2 <= hi && jj >= 0 && jj < PW;
             const float* row = a.GP_in + (((size_t)b * S + (in ? sp2 : 0)) * 2) * 64 + (in ? jj : 0);
-            pv[u][0] = row[0];
-            pv[u][1] = row[64];
-            if (!in) { pv[u][0] = 0.f; pv[u][1] = 0.f; }
+            const float z = in ? 1.f : 0.f;
+            pv[u][0] = row[0] * z;
+            pv[u][1] = row[64] * z;
         }
 #pragma unroll
         for (int u = 0; u < 3; ++u) { gp += pv[u][0]; gc += pv[u][1]; }
@@ -158,56 +161,67 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& a, const int b,
     __syncthreads();
 
     T2V_STAMP(a, 1);
-    // ---- dot = dctx·ctx_t + sum_j alpha_j (Gprev_j + Gcum_j)
-    float dotp = dctx[tid] * ctx0 + dctx[256 + tid] * ctx1 + dot_g;
-    dotp = wave_sum(dotp);
-    if (lane == 0) scr[wave] = dotp;
-    // ---- dalpha for the own positions: dctx·memory_j + G_j
+    // ---- dot = dctx·ctx_t + sum_j alpha_j (Gprev_j + Gcum_j); dalpha of the own positions = dctx·memory_j + G_j.
+    // Sums over a 16-lane row with DPP, the 16 row partials of each quantity through LDS (no LDS-crossbar shuffles)
     {
+        float dotp = dctx[2 * tid] * ctx2.x + dctx[2 * tid + 1] * ctx2.y + dot_g;
+        dotp = row16_sum(dotp);
+        if (c16 == 0) red[0][4 * wave + g] = dotp;
         const float4 d0 = *(const float4*)(dctx + lane * 4), d1 = *(const float4*)(dctx + 256 + lane * 4);
 #pragma unroll
         for (int r = 0; r < JS / 4; ++r) {
-            const int jl = wave + 4 * r;
             float acc = m0[r].x * d0.x;
             acc = fmaf(m0[r].y, d0.y, acc); acc = fmaf(m0[r].z, d0.z, acc); acc = fmaf(m0[r].w, d0.w, acc);
             acc = fmaf(m1[r].x, d1.x, acc); acc = fmaf(m1[r].y, d1.y, acc);
             acc = fmaf(m1[r].z, d1.z, acc); acc = fmaf(m1[r].w, d1.w, acc);
-            acc = wave_sum(acc);
-            if (lane == 0) dal[jl] = jl < nown ? acc + gfull0[j0 + jl] + gfull1[j0 + jl] : 0.f;
+            acc = row16_sum(acc);
+            if (c16 == 0) red[1 + r][4 * wave + g] = acc;
         }
     }
     __syncthreads();
-    const float dot = (scr[0] + scr[1]) + (scr[2] + scr[3]);
-    if (tid < JS) de[tid] = tid < nown ? alf[j0 + tid] * (dal[tid] - dot) : 0.f;
+    if (tid < JS) {
+        float dsum[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) dsum[u] = red[0][u];
+#pragma unroll
+        for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+            for (int u = 0; u < w; ++u) dsum[u] += dsum[u + w];
+        const int wv = tid & 3, r = tid >> 2;            // row jl = tid was summed by wave wv as its r-th row
+        const float dalv = ((red[1 + r][4 * wv] + red[1 + r][4 * wv + 1]) + (red[1 + r][4 * wv + 2] + red[1 + r][4 * wv + 3])) +
+                           gfull0[j0 + min(tid, nown - 1)] + gfull1[j0 + min(tid, nown - 1)];
+        de[tid] = tid < nown ? alf[j0 + tid] * (dalv - dsum[0]) : 0.f;
+    }
     __syncthreads();
 
     T2V_STAMP(a, 2);
     // ---- through v·tanh(.): dpre, partial dq / dv
     {
-        float* sp = a.S_t + ((size_t)b * Tp + j0) * T2V_A + d;
-        float dq = 0.f, dv = 0.f;
+        float* sp = a.S_t + ((size_t)b * Tp + j0) * T2V_A + 4 * d4;
+        float4 dq = make_float4(0.f, 0.f, 0.f, 0.f), dv = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int i = 0; i < JS / 2; ++i) {
-            const int jl = jh + 2 * i;
-            float dp = 0.f;
-            if (jl < nown) {
-                const float sv = sreg[i], dej = de[jl];
-                dp = dej * vd * (1.0f - sv * sv);
-                sp[(size_t)jl * T2V_A] = dp;
-                dq += dp;
-                dv = fmaf(dej, sv, dv);
-            }
-            dpT[d][jl] = dp;
+        for (int i = 0; i < JS / 8; ++i) {
+            const int jl = rg + 8 * i;
+            const float dej = de[jl];                    // 0 for rows >= nown
+            const float4 sv = sreg[i];
+            float4 dp;
+            dp.x = dej * vd4.x * (1.0f - sv.x * sv.x); dp.y = dej * vd4.y * (1.0f - sv.y * sv.y);
+            dp.z = dej * vd4.z * (1.0f - sv.z * sv.z); dp.w = dej * vd4.w * (1.0f - sv.w * sv.w);
+            if (jl < nown) *(float4*)(sp + (size_t)jl * T2V_A) = dp;
+            dq.x += dp.x; dq.y += dp.y; dq.z += dp.z; dq.w += dp.w;
+            dv.x = fmaf(dej, sv.x, dv.x); dv.y = fmaf(dej, sv.y, dv.y); dv.z = fmaf(dej, sv.z, dv.z); dv.w = fmaf(dej, sv.w, dv.w);
+            dpT[4 * d4 + 0][jl] = dp.x; dpT[4 * d4 + 1][jl] = dp.y; dpT[4 * d4 + 2][jl] = dp.z; dpT[4 * d4 + 3][jl] = dp.w;
         }
-        scr[8 + tid] = dq;
-        scr[8 + ATB_THREADS + tid] = dv;
+        *(float4*)&rq[rg][4 * d4] = dq;
+        *(float4*)&rv[rg][4 * d4] = dv;
         __syncthreads();
         if (tid < T2V_A) {
             // granule: the cell-backward workgroups of the SAME launch poll it (tag 1; the buffer is zeroed per pass)
-            const float dqs = scr[8 + tid] + scr[8 + 128 + tid];
+            const float dqs = ((rq[0][tid] + rq[1][tid]) + (rq[2][tid] + rq[3][tid])) + ((rq[4][tid] + rq[5][tid]) + (rq[6][tid] + rq[7][tid]));
             __hip_atomic_store(a.DQ_t + ((size_t)b * S + s) * T2V_A + tid,
                                ((t2v_u64)1u << 32) | (t2v_u64)__float_as_uint(dqs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a.DV[((size_t)b * S + s) * T2V_A + tid] += scr[8 + ATB_THREADS + tid] + scr[8 + ATB_THREADS + 128 + tid];
+            a.DV[((size_t)b * S + s) * T2V_A + tid] += ((rv[0][tid] + rv[1][tid]) + (rv[2][tid] + rv[3][tid])) +
+                                                        ((rv[4][tid] + rv[5][tid]) + (rv[6][tid] + rv[7][tid]));
         }
     }
 
@@ -316,26 +330,11 @@ __device__ __forceinline__ void cell_bwd_body(const CellBwdArgs& a, const int cb
     // ONE wave polls one sentinel granule per publishing wave (dims 0 and 64 of every slice row) with s_sleep between
     // rounds; the other 255 threads of every cell workgroup stay off the memory system until the rows have landed
     // (hundreds of pollers next to the latency-bound attention workgroups slowed the whole launch by ~2 us)
-    if (tid < 64) {
-        const int nsent = 2 * a.B * a.S;
-        unsigned spins = 0;
-        for (;;) {
-            bool ok = true;
-            for (int i = tid; i < nsent; i += 64) {
-                const t2v_u64 x = __hip_atomic_load(a.DQ_t + (size_t)(i >> 1) * T2V_A + 64 * (i & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = ok && (unsigned)(x >> 32) == 1u;
-            }
-            if (__all(ok)) break;
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > ATB_SPIN_LIMIT || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                cell_ok = 0;
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    if (!cell_ok) return;
+    // the partial dq rows cannot be there before the attention workgroups have done their entry loads, softmax backward
+    // and tanh backward (>= 3.5 us after the launch): nap first, then poll the rows themselves (the data is the flag) with
+    // short naps in between — a separate sentinel poll ahead of the gather cost one more memory round trip (+0.35 us),
+    // polling without the naps slows the attention workgroups' own loads
+    __builtin_amdgcn_s_sleep(40);
     CELL_STAMP(2);
     {
         // thread -> (item, dim) pairs i = tid + 256 p, p < NPP (NPP = pairs per thread rounded up to 1/2/4/8), eight
@@ -363,7 +362,7 @@ __device__ __forceinline__ void cell_bwd_body(const CellBwdArgs& a, const int cb
                     }
                 }
                 if (ok) break;
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(6);
                 if (++spins > ATB_SPIN_LIMIT || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     cell_ok = 0;
@@ -382,21 +381,29 @@ __device__ __forceinline__ void cell_bwd_body(const CellBwdArgs& a, const int cb
     }
     __syncthreads();
     CELL_STAMP(3);
-    if (!cell_ok || !bv) return;
+    if (!cell_ok) return;
+    // W_q^T·dq for this block's 16 units x 16 items on MFMA: D[m = unit][n = item] = sum_d wqs[m][d] dqs[n][d]; the four
+    // waves split K = 128 (8 k-steps each), partial tiles through LDS (fixed order).  Rows of dqs for items >= B hold
+    // stale LDS words: they only reach D columns nobody reads.
+    float wq_dq;
+    {
+        __shared__ f32x4 dred[4][64];
+        const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const int k = 4 * (8 * wave + st) + g;
+            acc = mfma16x4(wqs[c16][k], dqs[c16][k], acc);
+        }
+        dred[wave][lane] = acc;
+        __syncthreads();
+        const int m = tid >> 4, n = tid & 15, src = n + 16 * (m >> 2), r = m & 3;
+        wq_dq = (dred[0][src][r] + dred[1][src][r]) + (dred[2][src][r] + dred[3][src][r]);
+    }
+    if (!bv) return;
     {
         const int t = a.t;
-        const float4* w4 = (const float4*)wqs[tid >> 4];
-        const float4* q4 = (const float4*)dqs[b];
-        float dot0 = 0.f, dot1 = 0.f;
-#pragma unroll 8
-        for (int i = 0; i < T2V_A / 4; ++i) {
-            const float4 wv = w4[i], qv = q4[i];
-            dot0 = fmaf(wv.x, qv.x, dot0);
-            dot1 = fmaf(wv.y, qv.y, dot1);
-            dot0 = fmaf(wv.z, qv.z, dot0);
-            dot1 = fmaf(wv.w, qv.w, dot1);
-        }
-        const float dh = yd0 + ya0 + (dot0 + dot1);
+        const float dh = yd0 + ya0 + wq_dq;
         const float fh = t2v_drop_scale(seed, T2V_RNG_ATT_H, t, idx, a.p_att);
         const float fc = t2v_drop_scale(seed, T2V_RNG_ATT_C, t, idx, a.p_att);
         const float gi = ga[0], gf = ga[1], gg = ga[2], go = ga[3];

@@ -42,6 +42,8 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * fast_rcp
 // 16-lane row sum with DPP (no LDS crossbar): every lane of a row ends with the row's sum.
 #define T2V_DPP_ADD(v, CTRL) \
     ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (CTRL), 0xF, 0xF, true)))
+#define T2V_DPP_MAX(v, CTRL) \
+    fmaxf((v), __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (CTRL), 0xF, 0xF, true)))
 __device__ __forceinline__ float row16_sum(float v) {
     v = T2V_DPP_ADD(v, 0xB1);    // quad_perm [1,0,3,2]
     v = T2V_DPP_ADD(v, 0x4E);    // quad_perm [2,3,0,1]

@@ -19,6 +19,6 @@ for _ in range(2):
 torch.cuda.synchronize()
 v = buf.cpu().tolist()
 print('attn_fwd phase cycles:', [v[i + 1] - v[i] for i in range(0, 5)], 'total', v[5] - v[0])
-print('attn_fwd entry detail (loads issued, window landed, partials reduced, barrier, location MFMAs):', [v[i] - v[0] for i in range(6, 11)])
+print('attn_fwd entry detail (loads issued, window barrier, location MFMAs, partials reduced, barrier):', [v[i] - v[0] for i in range(6, 11)])
 print('attn_bwd phase cycles:', [v[16 + i + 1] - v[16 + i] for i in range(0, 5)], 'total', v[21] - v[16])
 print('cell_bwd stamps relative to the attention workgroup start:', [v[24 + i] - v[16] for i in range(5)])

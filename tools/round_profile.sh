@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 REPO=$(pwd)
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python $REPO/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-decode > /tmp/prof_bench_$TAG.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python $REPO/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-decode --no-secondary > /tmp/prof_bench_$TAG.log 2>&1
 tail -1 /tmp/prof_bench_$TAG.log | cut -c1-300
 ST=$(find /tmp/prof_$TAG -name '*kernel_stats.csv' | head -1); KT=$(find /tmp/prof_$TAG -name '*kernel_trace.csv' | head -1)
 cp "$ST" $REPO/gpurun_out/${TAG}_bench_kernel_stats.csv
