@@ -217,7 +217,7 @@ def run_workload(args, world, rank, bf16, koemo, steps, warmup, graph):
         bpg, ",distributed_run=True" if world > 1 else "", ",bf16_run=True" if bf16 else ""))
     torch.manual_seed(hp.seed)
     torch.cuda.manual_seed(hp.seed)
-    engine = TR.TrainEngine(hp, world_size=world, graph=graph)
+    engine = TR.TrainEngine(hp, world_size=world, graph=graph, force_dist=bool(getattr(args, 'force_dist', False)))
     koemo_in, koemo_out = [84, 80, 71, 66, 50, 37], [400, 380, 350, 300, 260, 200]
     if koemo:
         batch = synthetic_batch(bpg, T_IN, T_OUT, 1234 + rank, lens_in=koemo_in, lens_out=koemo_out)
@@ -262,8 +262,9 @@ def run_workload(args, world, rank, bf16, koemo, steps, warmup, graph):
     res = {"value": round(frames / (elapsed / steps), 1), "ms_per_step": round(ms, 3), "frames_per_step": frames,
            "final_loss": round(final_loss, 5), "step_mode": "hip-graph replay" if engine.use_graph else "eager launches",
            "startup_steps": startup, "batch_per_gpu": bpg}
-    if world > 1 and engine.allreduce is not None:
+    if engine.allreduce is not None:
         res["allreduce_exposed_ms"] = round(engine.allreduce.exposed_ms(), 3)
+        res["allreduce_buckets"] = [(b[0], 4 * (b[2] - b[1])) for b in engine.allreduce.buckets]
     return engine, res
 
 
@@ -297,6 +298,10 @@ def main():
                     help='extra untimed start-up steps after the graph capture (reported as config.startup_steps)')
     ap.add_argument('--no-graph', action='store_true',
                     help='run the step eagerly (one host launch per kernel) instead of replaying the captured HIP graph')
+    ap.add_argument('--launch', action='store_true',
+                    help='self-launch under torch.distributed.run even for --gpus 1 (exercises the multi-GPU entry on one GPU)')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='initialise RCCL and run the bucketed gradient all-reduce even in a 1-rank world (tests)')
     ap.add_argument('--koemo', action='store_true', help='make the koemo length profile the headline workload')
     ap.add_argument('--bf16', action='store_true', help='make BASELINE configs[4] (bf16_run, B=16 per GPU) the headline workload')
     args = ap.parse_args()
@@ -304,7 +309,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    if (args.gpus > 1 or args.launch) and 'WORLD_SIZE' not in os.environ:
         # self-launch (replaces the reference's multiproc.py:1-23): one process per GPU under torch.distributed.run,
         # rendezvous on 127.0.0.1 (the container hostname may not resolve)
         import socket
@@ -320,7 +325,9 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or args.force_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank)
 
     import t2v_hip
@@ -341,10 +348,11 @@ def main():
                    "parallelism": "dp%d" % world},
         "final_loss": res["final_loss"],
     }
-    if world > 1:
+    if dist.is_initialized():
         out["rccl_ranks"] = dist.get_world_size()
         if "allreduce_exposed_ms" in res:
             out["allreduce_exposed_ms"] = res["allreduce_exposed_ms"]
+            out["allreduce_buckets_bytes"] = res["allreduce_buckets"]
 
     if rank == 0:
         # ---- roofline leg: the four per-time-step kernels of the decoder recurrence (87 % of the GPU time of a step)
@@ -375,7 +383,7 @@ def main():
                            if kind == 'headline' else None}
         if not args.no_decode:
             out["decode"] = decode_bench(engine.model)
-        if world == 1 and not args.no_secondary:
+        if world == 1 and not args.no_secondary and not args.force_dist:
             out["frontend"] = frontend_bench()
             sec = {}
             del engine
@@ -400,7 +408,7 @@ def main():
                 out["cpu_baseline"]["all_cores"] = {"value": allc["value"], "cores": allc["cores"], "s_per_it": allc["s_per_it"],
                                                     "sample": "ONE timed step, no warm-up, every host core"}
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -225,6 +225,14 @@ int t2v_bn_act_bwd(const float* y, const float* dout, const float* mean, const f
                    int B, int M, int T, int act, float p_drop, uint64_t seed, uint32_t rng_stream,
                    uint32_t rng_t, void* stream);
 
+/* ------------------------------------------------------------------ symbol embedding
+ * nn.Embedding(n_symbols, C) of the text encoder (model.py:474-482) as used at model.py:528
+ * (`transcript_embedding(text).transpose(1, 2)`): ids (B,T) int64 -> out (B,C,T) channel-major, the layout the first
+ * encoder Conv1d reads.  Backward: dW (n_symbols,C) = per-symbol sum of dy (B,C,T) over the positions holding that
+ * symbol, ascending position order (deterministic). */
+int t2v_embedding_fwd(const long long* ids, const float* W, float* out_bct, int B, int T, int C, int n_symbols, void* stream);
+int t2v_embedding_bwd(const long long* ids, const float* dy_bct, float* dW, int B, int T, int C, int n_symbols, void* stream);
+
 /* ------------------------------------------------------------------ encoder BiLSTM recurrence
  * nn.LSTM(512, 256, bidirectional) on a packed sequence (model.py:171-173, 183-190), recurrent part only:
  * gx (2,B,T,1024) = X·W_ih^T + b_ih + b_hh per direction (time-batched GEMM done by the caller), whh

@@ -279,6 +279,14 @@ class Decoder(nn.Module):
         return mel, gate, alignments
 
 
+class SymbolEmbedding(nn.Embedding):
+    """nn.Embedding with the same parameter (`weight`), init and call surface; on the GPU the lookup and its backward
+    run on the HIP gather / per-symbol accumulation kernels (csrc/embed.hip)."""
+
+    def forward(self, ids):
+        return t2v_hip.SymbolEmbedding.apply(ids, self.weight)       # raises T2VHipError for CPU tensors: no CPU fallback
+
+
 class Tacotron2(nn.Module):
     def __init__(self, hparams):
         super().__init__()
@@ -287,7 +295,7 @@ class Tacotron2(nn.Module):
         _drop_seed[0] = (int(hparams.seed) * 2654435761 + 0x5EED) & 0x7FFFFFFFFFFFFFFF
         self.n_mel_channels = hparams.n_mel_channels
         self.n_frames_per_step = hparams.n_frames_per_step
-        self.transcript_embedding = nn.Embedding(hparams.n_symbols, hparams.symbols_embedding_dim)
+        self.transcript_embedding = SymbolEmbedding(hparams.n_symbols, hparams.symbols_embedding_dim)
         self.speaker_embedding = LinearNorm(hparams.n_speakers, hparams.speaker_embedding_dim, bias=True,
                                             w_init_gain='tanh')     # constructed, never used (B-7)
         self.emotion_embedding = LinearNorm(hparams.n_emotions, hparams.emotion_embedding_dim, bias=True,

@@ -45,7 +45,7 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decode
            't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_conv1d_dw_scratch_floats', 't2v_gemm_bf16', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
            't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats',
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_fuse_location_weights', 't2v_decoder_qp_floats',
-           't2v_set_step_params', 't2v_decoder_replay_bwd_kernels',
+           't2v_set_step_params', 't2v_decoder_replay_bwd_kernels', 't2v_embedding_fwd', 't2v_embedding_bwd',
            't2v_attn_bwd_slices')
 
 
@@ -84,6 +84,8 @@ def load_library():
     lib.t2v_clip_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float,
                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.t2v_embedding_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.t2v_embedding_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.t2v_set_step_params.argtypes = [C.c_void_p]
     lib.t2v_set_step_params.restype = None
     lib.t2v_mel_frontend.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,
@@ -665,6 +667,35 @@ class ConvBNAct1d(torch.autograd.Function):
         # d(bias) of a conv feeding a training-mode BatchNorm is identically zero (dy has zero channel mean)
         dbias = torch.zeros(Cout, **f32)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+class SymbolEmbedding(torch.autograd.Function):
+    """nn.Embedding lookup of the text encoder (reference model.py:474-482,528).  Returns the (B,T,C) tensor of
+    nn.Embedding as a transposed VIEW of a (B,C,T) buffer, so the reference's `.transpose(1, 2)` that follows hands the
+    first encoder convolution a contiguous channel-major tensor without a copy."""
+
+    @staticmethod
+    def forward(ctx, ids, weight):
+        lib = _require_gpu(ids, weight)
+        ids = ids.contiguous().long()
+        B, T = ids.shape
+        n, Cc = weight.shape
+        out = torch.empty(B, Cc, T, device=weight.device, dtype=torch.float32)
+        _check(lib.t2v_embedding_fwd(_p(ids), _p(_f32c(weight)), _p(out), B, T, Cc, n, _stream()), 't2v_embedding_fwd')
+        ctx.save_for_backward(ids)
+        ctx.dims = (B, T, Cc, n)
+        return out.transpose(1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load_library()
+        ids, = ctx.saved_tensors
+        B, T, Cc, n = ctx.dims
+        dy_bct = dy.transpose(1, 2)
+        dy_bct = dy_bct if dy_bct.is_contiguous() else dy_bct.contiguous()
+        dW = torch.empty(n, Cc, device=dy.device, dtype=torch.float32)
+        _check(lib.t2v_embedding_bwd(_p(ids), _p(_f32c(dy_bct)), _p(dW), B, T, Cc, n, _stream()), 't2v_embedding_bwd')
+        return None, dW
 
 
 class BiLSTM(torch.autograd.Function):

@@ -84,7 +84,7 @@ class TrainEngine(object):
     GRAPH_AFTER = 2          # eager executions of a shape before it is captured (allocator / lazy-init warm-up)
     MAX_GRAPHS = 8
 
-    def __init__(self, hparams, world_size=1, graph=None):
+    def __init__(self, hparams, world_size=1, graph=None, force_dist=False):
         import t2v_hip
         self.hparams = hparams
         self.model = load_model(hparams)
@@ -92,15 +92,16 @@ class TrainEngine(object):
         self.optimizer = FlatAdam(self.model, lr=hparams.learning_rate, weight_decay=hparams.weight_decay,
                                   grad_clip_thresh=hparams.grad_clip_thresh, world_size=world_size)
         self.allreduce = None
-        if world_size > 1:
+        if world_size > 1 or force_dist:      # force_dist: 1-rank RCCL group (tests of the launch path on one GPU)
             named, offs = self.optimizer.arena_layout()
             model = self.model
             self.allreduce = t2v_dist.OverlappedArenaAllReduce(
-                named, offs, self.optimizer.grads,
+                named, offs, self.optimizer.grads, force=bool(force_dist),
                 side_streams=lambda: [st for st in (getattr(model, '_side', None),) if st is not None],
                 gather=self.optimizer.gather_grads)
         self.step_params = t2v_hip.step_params()
-        self.use_graph = bool(getattr(hparams, 'graph_step', False) if graph is None else graph) and world_size == 1
+        self.use_graph = (bool(getattr(hparams, 'graph_step', False) if graph is None else graph) and world_size == 1
+                          and self.allreduce is None)
         self._graphs = {}
         self._seen = {}
         # graph mode: EVERY step of this engine (the eager warm-up ones too) runs on one dedicated stream — autograd's

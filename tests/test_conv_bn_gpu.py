@@ -71,3 +71,26 @@ def test_dropout_statistics_and_backward_mask():
     assert torch.allclose(a[kept], 2.0 * b[kept], atol=1e-5)        # kept values scaled by 1/(1-p)
     a.sum().backward()
     assert torch.isfinite(x.grad).all()
+
+
+def test_symbol_embedding_matches_nn_embedding():
+    """own gather (channel-major output) + deterministic per-symbol backward vs nn.Embedding / autograd on CPU"""
+    import model as M
+    g = torch.Generator().manual_seed(2)
+    emb = M.SymbolEmbedding(80, 512)
+    ids = torch.randint(0, 80, (6, 84), generator=g)
+    w_out = torch.randn(6, 512, 84, generator=g)
+    ref = torch.nn.functional.embedding(ids, emb.weight).transpose(1, 2)
+    (ref * w_out).sum().backward()
+    ref_grad = emb.weight.grad.clone()
+    emb.weight.grad = None
+    emb = emb.cuda()
+    y = emb(ids.cuda())
+    assert y.shape == (6, 84, 512) and y.transpose(1, 2).is_contiguous()          # no transpose copy for the first conv
+    assert torch.equal(y.transpose(1, 2).cpu(), ref.detach())
+    (y.transpose(1, 2) * w_out.cuda()).sum().backward()
+    assert (emb.weight.grad.cpu() - ref_grad).abs().max() < 1e-5 * ref_grad.abs().max()
+    g1 = emb.weight.grad.clone()
+    emb.weight.grad = None
+    (emb(ids.cuda()).transpose(1, 2) * w_out.cuda()).sum().backward()
+    assert torch.equal(g1, emb.weight.grad)                                        # fixed summation order

@@ -107,3 +107,28 @@ def test_async_error_ledger_reports_and_clears():
     with pytest.raises(t2v_hip.T2VHipError, match='synthetic timeout'):
         t2v_hip.check_async_errors()
     t2v_hip.check_async_errors()
+
+
+def test_bench_multi_gpu_entry_on_one_gpu():
+    """`bench.py --gpus N` self-launches one process per GPU under torch.distributed.run (replaces the reference's
+    multiproc.py).  Here: the same entry with one rank — RCCL initialisation, the bucketed gradient all-reduce issued
+    from the backward hooks, clip + Adam after it, and the extra keys of the JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--launch', '--force-dist', '--steps', '3',
+                          '--warmup', '1', '--no-cpu-baseline', '--no-decode', '--no-secondary'],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 1 and d['rccl_ranks'] == 1 and d['value'] > 0
+    assert d['config']['step_mode'] == 'eager launches'               # the all-reduce path runs eagerly
+    assert d['allreduce_exposed_ms'] >= 0.0
+    names = [b[0] for b in d['allreduce_buckets_bytes']]
+    assert len(names) == 4 and sum(b[1] for b in d['allreduce_buckets_bytes']) > 100e6        # 115.5 MB arena in 4 buckets
