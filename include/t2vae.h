@@ -179,10 +179,10 @@ typedef struct t2v_dec_infer_bufs {
     float* MEL;              /* (Tmax,B,80) out */
     float* GATE;             /* (Tmax,B)    out */
     int32_t* stop_flag;      /* (1) */
-    const float* prenet_w0;  /* (256,80)  */
-    const float* prenet_w1;  /* (256,256) */
-    const float* proj_w;     /* (81,1536) rows 0..79 = linear_projection, row 80 = gate_layer */
-    const float* proj_b;     /* (81) */
+    const float* prenet_w1;  /* (256,256) Prenet layer 1 */
+    const float* proj_w;     /* (337,1536) rows 0..79 = linear_projection, row 80 = gate_layer, rows 81..336 = W0·linear_projection
+                                (Prenet layer 0 is bias-free and linear in the mel frame: folded so it need not wait for it) */
+    const float* proj_b;     /* (337) linear_projection / gate_layer biases, then W0·b_projection */
 } t2v_dec_infer_bufs;
 
 int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_infer_bufs* s, int B, int T_in,

@@ -3,17 +3,19 @@
 //   k_lstm_fwd<1>  attention_rnn(t), prenet columns inside K
 //   k_attn_fwd     location-sensitive attention (mask = None)
 //   k_lstm_fwd<2>  decoder_rnn(t)
-//   k_proj_prenet  80-mel + gate projection of [h_dec_t | ctx_t], stop flag, Prenet of the new frame
+//   k_proj_prenet  80-mel + gate projection of [h_dec_t | ctx_t], stop flag, Prenet of the new frame (layer 0 folded
+//                  into the projection, one granule hop to layer 1)
 #include "t2v_common.h"
 #include "t2v_kernels.h"
 #include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 struct ProjPrenetArgs {
     const float* xs_cur;     // XS[t+1]: ctx_t at [1024,1536)
     const float* xs_next;    // XS[t+2]: h_dec_t at [1536,2560)
-    const float* proj_w;     // (81,1536): rows 0..79 linear_projection, row 80 gate_layer
-    const float* proj_b;     // (81)
-    const float* w0;         // (256,80)  prenet layer 0
+    const float* proj_w;     // (337,1536): rows 0..79 linear_projection, row 80 gate_layer, rows 81..336 = W0·linear_projection
+    const float* proj_b;     // (337): projection / gate biases, then W0·b_projection
     const float* w1;         // (256,256) prenet layer 1
     float* mel_t;            // MEL[t]  (B,80)
     float* gate_t;           // GATE[t] (B)
@@ -22,46 +24,35 @@ struct ProjPrenetArgs {
     int B, t;
     float gate_logit_thr, p_prenet;
     uint64_t seed;
-    float* xchg;            // [0,768) mel exchange (8 x 96), [1024,3072) layer-0 exchange (8 x 256)
-    unsigned* sync;         // [0] arrival counter (monotonic over the pass), [15] error word (QP sync words 32 / 47)
-    int epoch;              // 1-based frame index within the pass
+    t2v_u64* xchg;          // (8,256) granules {prenet layer-0 output, tag = frame epoch}
+    unsigned* err;          // error word (bounded-spin timeout)
+    unsigned epoch;         // 1-based frame index within the pass
 };
 
-// 16 cooperating workgroups x 256 threads (B <= 8): the 0.83 MB of projection + Prenet weights touched per frame
-// are spread over 16 CUs (a single CU pulls only ~40 GB/s of non-local data), with two bounded-spin group
-// barriers between the three dependent stages: [80-mel + gate projection] -> [Prenet layer 0] -> [Prenet layer 1].
-#define PP_NWG 16
-__device__ __forceinline__ bool pp_barrier(unsigned* cnt, unsigned* err, unsigned target, int* ok_flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int good = 1;
-        unsigned spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (++spins > 4000000u || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                good = 0;
-                break;
-            }
-        }
-        *ok_flag = good;
-    }
-    __syncthreads();
-    return *ok_flag != 0;
-}
-
+// Projection + Prenet of one decoded frame: 64 workgroups x 4 waves, one output row per wave.
+//   stage 1: 337 rows of length 1536 over [h_dec_t | ctx_t]: the 80 mel rows, the gate row, and — because the Prenet's
+//            first layer is bias-free and LINEAR in the mel frame — its 256 pre-activations directly through the folded
+//            matrix W0·P (+ W0·b), so the layer does not have to wait for the mel frame; ReLU + dropout (always on,
+//            model.py:101) and an 8-byte {value, epoch} granule per output (the data is the flag)
+//   stage 2: Prenet layer 1, one of its 256 rows per wave: polls the 256 granules of every item, ReLU + dropout, PRE[t+1]
+// One in-kernel hop instead of two counter barriers; 2.6 MB of weights per frame spread over 64 CUs.
+#define PP_NWG 64
 __global__ __launch_bounds__(256) void k_proj_prenet(ProjPrenetArgs a) {
-    __shared__ __attribute__((aligned(16))) float xin[8][T2V_PRE];     // stage input: mel (80) or layer-0 output (256)
-    __shared__ int ok_flag;
-    const int gidx = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int gw = blockIdx.x * 4 + wave;                 // global wave index 0..255
     const int HC = T2V_H + T2V_E;
-    // ---- stage 1: outputs o = gidx, gidx+16, ... of the 81-row projection; one wave per output row
-    for (int o = gidx + PP_NWG * wave; o < T2V_NMEL + 1; o += PP_NWG * 4) {
+    const int nrows = a.pre_next ? T2V_NMEL + 1 + T2V_PRE : T2V_NMEL + 1;
+    // stage-2 operands requested up front: this wave's row of W1 (4 floats per lane)
+    float4 w1r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.pre_next) w1r = *(const float4*)(a.w1 + (size_t)gw * T2V_PRE + 4 * lane);
+    // ---- stage 1: rows gw, gw + 256 (the second pass only for the first 81 waves)
+    for (int o = gw; o < nrows; o += 4 * PP_NWG) {
         const float4* wr = (const float4*)(a.proj_w + (size_t)o * HC);
         float4 wv[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) wv[i] = wr[lane + 64 * i];
+        const float bias = a.proj_b[o];
+        bool all_fired = true;
         for (int b = 0; b < a.B; ++b) {
             float acc = 0.f;
 #pragma unroll
@@ -72,68 +63,50 @@ __global__ __launch_bounds__(256) void k_proj_prenet(ProjPrenetArgs a) {
                 acc = fmaf(wv[i].x, xv.x, acc); acc = fmaf(wv[i].y, xv.y, acc);
                 acc = fmaf(wv[i].z, xv.z, acc); acc = fmaf(wv[i].w, xv.w, acc);
             }
-            acc = wave_sum(acc) + a.proj_b[o];
-            if (lane == 0) {
-                if (o < T2V_NMEL) {
-                    a.mel_t[(size_t)b * T2V_NMEL + o] = acc;
-                    if (a.pre_next) __hip_atomic_store(a.xchg + b * 96 + o, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    a.gate_t[b] = acc;
-                    // stop rule sigmoid(gate) > threshold (model.py:453; B == 1 in the reference): all items must fire.
-                    // This wave sees every item's gate in turn, so it can decide alone.
-                    xin[0][b] = acc;
-                }
+            acc = wave_sum(acc) + bias;
+            if (o < T2V_NMEL) {
+                if (lane == 0) a.mel_t[(size_t)b * T2V_NMEL + o] = acc;
+            } else if (o == T2V_NMEL) {
+                if (lane == 0) a.gate_t[b] = acc;
+                // stop rule sigmoid(gate) > threshold (model.py:453; B == 1 in the reference): all items must fire.
+                // This wave sees every item's gate in turn, so it can decide alone.
+                all_fired = all_fired && acc > a.gate_logit_thr;
+            } else if (lane == 0) {
+                const int r = o - (T2V_NMEL + 1);
+                float v = fmaxf(acc, 0.f) * t2v_drop_scale(a.seed, T2V_RNG_PRENET0, a.t + 1, (uint32_t)(b * T2V_PRE + r), a.p_prenet);
+                __hip_atomic_store(a.xchg + (size_t)b * T2V_PRE + r, ((t2v_u64)a.epoch << 32) | (t2v_u64)__float_as_uint(v),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        if (o == T2V_NMEL && lane == 0) {
-            bool all = true;
-            for (int b = 0; b < a.B; ++b) all = all && (xin[0][b] > a.gate_logit_thr);
-            if (all) atomicMin(a.stop_flag, a.t);
-        }
+        if (o == T2V_NMEL && lane == 0 && all_fired) atomicMin(a.stop_flag, a.t);
     }
     if (!a.pre_next) return;
-    if (!pp_barrier(a.sync, a.sync + 15, (unsigned)PP_NWG * (2u * (unsigned)a.epoch - 1u), &ok_flag)) return;
-    // ---- stage 2: Prenet layer 0, outputs [16g, 16g+16) (dropout always on, model.py:101)
-    for (int i = tid; i < a.B * T2V_NMEL; i += 256) {
-        const int b = i / T2V_NMEL, k = i - b * T2V_NMEL;
-        xin[b][k] = __hip_atomic_load(a.xchg + b * 96 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    {
-        const int o = 16 * gidx + (tid & 15), b = tid >> 4;
-        if (b < a.B) {
-            const float4* w = (const float4*)(a.w0 + (size_t)o * T2V_NMEL);
-            const float4* x = (const float4*)xin[b];
-            float acc = 0.f;
+    // ---- stage 2: Prenet layer 1, row gw (dropout always on)
+    for (int b = 0; b < a.B; ++b) {
+        const t2v_u64* gq = a.xchg + (size_t)b * T2V_PRE + 4 * lane;
+        float xv[4];
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
 #pragma unroll
-            for (int k = 0; k < T2V_NMEL / 4; ++k) {
-                const float4 wv = w[k], xv = x[k];
-                acc = fmaf(wv.x, xv.x, acc); acc = fmaf(wv.y, xv.y, acc);
-                acc = fmaf(wv.z, xv.z, acc); acc = fmaf(wv.w, xv.w, acc);
+            for (int i = 0; i < 4; ++i) {
+                const t2v_u64 x = __hip_atomic_load(gq + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                xv[i] = __uint_as_float((unsigned)x);
+                ok = ok && (unsigned)(x >> 32) == a.epoch;
             }
-            acc = fmaxf(acc, 0.f) * t2v_drop_scale(a.seed, T2V_RNG_PRENET0, a.t + 1, (uint32_t)(b * T2V_PRE + o), a.p_prenet);
-            __hip_atomic_store(a.xchg + 1024 + b * T2V_PRE + o, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > 4000000u || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
         }
-    }
-    if (!pp_barrier(a.sync, a.sync + 15, (unsigned)PP_NWG * 2u * (unsigned)a.epoch, &ok_flag)) return;
-    // ---- stage 3: Prenet layer 1, outputs [16g, 16g+16)
-    for (int i = tid; i < a.B * T2V_PRE; i += 256)
-        xin[i >> 8][i & 255] = __hip_atomic_load(a.xchg + 1024 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    {
-        const int o = 16 * gidx + (tid & 15), b = tid >> 4;
-        if (b < a.B) {
-            const float4* w = (const float4*)(a.w1 + (size_t)o * T2V_PRE);
-            const float4* x = (const float4*)xin[b];
-            float acc = 0.f;
-#pragma unroll 16
-            for (int k = 0; k < T2V_PRE / 4; ++k) {
-                const float4 wv = w[k], xv = x[k];
-                acc = fmaf(wv.x, xv.x, acc); acc = fmaf(wv.y, xv.y, acc);
-                acc = fmaf(wv.z, xv.z, acc); acc = fmaf(wv.w, xv.w, acc);
-            }
-            acc = fmaxf(acc, 0.f) * t2v_drop_scale(a.seed, T2V_RNG_PRENET1, a.t + 1, (uint32_t)(b * T2V_PRE + o), a.p_prenet);
-            a.pre_next[(size_t)b * T2V_PRE + o] = acc;
+        float acc = w1r.x * xv[0];
+        acc = fmaf(w1r.y, xv[1], acc); acc = fmaf(w1r.z, xv[2], acc); acc = fmaf(w1r.w, xv[3], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            acc = fmaxf(acc, 0.f) * t2v_drop_scale(a.seed, T2V_RNG_PRENET1, a.t + 1, (uint32_t)(b * T2V_PRE + gw), a.p_prenet);
+            a.pre_next[(size_t)b * T2V_PRE + gw] = acc;
         }
     }
 }
@@ -147,10 +120,12 @@ extern "C" int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_i
     unsigned* sync = (unsigned*)(s->QP + t2v_qp_sync_off(B));
     t2v_u64* ex = (t2v_u64*)(s->QP + t2v_qp_ex_off(B));
     if (t_begin == 0) {
-        (void)hipMemsetAsync(sync, 0, 64 * sizeof(uint32_t), stream);
+        (void)hipMemsetAsync(sync, 0, (64 + 4096) * sizeof(uint32_t), stream);        // sync words + Prenet granule tags
         (void)hipMemsetAsync(ex, 0, sizeof(t2v_u64) * (size_t)B * 8 * t2v_tcap(T_in), stream);
     }
     const float thr = gate_threshold <= 0.f ? -INFINITY : (gate_threshold >= 1.f ? INFINITY : logf(gate_threshold / (1.f - gate_threshold)));
+    const int dbgm = getenv("T2V_DEBUG_SYNC") ? atoi(getenv("T2V_DEBUG_SYNC")) : 0;
+#define DBG(bit, tag) do { if (dbgm & (bit)) { hipError_t e_ = hipStreamSynchronize(stream); fprintf(stderr, "[t2v decode] t=%d %s: %s\n", t, tag, hipGetErrorString(e_)); } } while (0)
     for (int t = t_begin; t < t_end; ++t) {
         LstmFwdArgs a;
         a.packA = (const float4*)w->packF_att;
@@ -180,6 +155,7 @@ extern "C" int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_i
         a.do_att = 1;
         a.do_dec = 0;
         t2v_launch_lstm_fwd(1, a, stream);
+        DBG(1, "attention_rnn");
 
         AttnFwdArgs f;
         f.qp = s->QP;
@@ -200,6 +176,7 @@ extern "C" int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_i
         f.err = sync + 31;
         f.epoch = (unsigned)t + 1u;
         t2v_launch_attn_fwd(f, B, T_in, stream);
+        DBG(2, "attention");
 
         // decoder_rnn(t): XS[t+1] -> XS[t+2][1536:]   (time index t+1 in the kernel's skewed convention)
         a.xs_prev = s->XS + (size_t)(t + 1) * B * T2V_XW;
@@ -211,13 +188,13 @@ extern "C" int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_i
         a.do_att = 0;
         a.do_dec = 1;
         t2v_launch_lstm_fwd(2, a, stream);
+        DBG(4, "decoder_rnn");
 
         ProjPrenetArgs p;
         p.xs_cur = s->XS + (size_t)(t + 1) * B * T2V_XW;
         p.xs_next = s->XS + (size_t)(t + 2) * B * T2V_XW;
         p.proj_w = s->proj_w;
         p.proj_b = s->proj_b;
-        p.w0 = s->prenet_w0;
         p.w1 = s->prenet_w1;
         p.mel_t = s->MEL + (size_t)t * B * T2V_NMEL;
         p.gate_t = s->GATE + (size_t)t * B;
@@ -228,10 +205,11 @@ extern "C" int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_i
         p.gate_logit_thr = thr;
         p.p_prenet = p_prenet;
         p.seed = seed;
-        p.xchg = s->QP + t2v_qp_xchg_off(B);
-        p.sync = sync + 32;
-        p.epoch = t + 1;
+        p.xchg = (t2v_u64*)(s->QP + t2v_qp_xchg_off(B));
+        p.err = sync + 47;
+        p.epoch = (unsigned)t + 1u;
         k_proj_prenet<<<PP_NWG, 256, 0, stream>>>(p);
+        DBG(8, "proj_prenet");
     }
     return t2v_check_launch();
 }

@@ -38,7 +38,7 @@ class _DecBwdBufs(C.Structure):
 class _DecInferBufs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         'memory', 'pm', 'lengths', 'XS', 'CA', 'CD', 'QP', 'AL', 'ACUM', 'PRE', 'MEL', 'GATE', 'stop_flag',
-        'prenet_w0', 'prenet_w1', 'proj_w', 'proj_b')]
+        'prenet_w1', 'proj_w', 'proj_b')]
 
 
 EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decoder_train_fwd',
@@ -565,9 +565,14 @@ class InferenceSession(object):
         self.wqT = wq.detach().t().contiguous()
         self.wcomb = fuse_location_weights(_f32c(loc_conv.detach()), _f32c(loc_dense.detach()))
         self.v = _f32c(v.detach()).view(-1)
-        self.w0, self.w1 = _f32c(prenet_w0.detach()), _f32c(prenet_w1.detach())
-        self.proj_w = torch.cat((proj_w, gate_w), 0).detach().contiguous()      # (81,1536)
-        self.proj_b = torch.cat((proj_b, gate_b), 0).detach().contiguous()
+        self.w1 = _f32c(prenet_w1.detach())
+        # Prenet layer 0 (bias-free, linear in the mel frame) folded into the projection: rows 81.. = W0·P, W0·b
+        w0 = _f32c(prenet_w0.detach())
+        pw, pb = _f32c(proj_w.detach()), _f32c(proj_b.detach())
+        w0p = gemm(w0, pw.t())                                                   # (256,1536) = W0 (256,80) · P (80,1536)
+        b0p = gemm(w0, pb.view(1, -1)).view(-1)                                  # (256) = W0 · b
+        self.proj_w = torch.cat((pw, gate_w.detach(), w0p), 0).contiguous()      # (337,1536)
+        self.proj_b = torch.cat((pb, gate_b.detach(), b0p), 0).contiguous()
         self.XS = torch.empty(T + 2, B, XW, **f32); self.XS[0:2].zero_()
         self.CA = torch.empty(T + 1, B, H, **f32); self.CA[0].zero_()
         self.CD = torch.empty(T + 1, B, H, **f32); self.CD[0].zero_()
@@ -582,7 +587,7 @@ class InferenceSession(object):
                              _p(self.wqT), _p(self.wcomb), _p(self.v))
         self.S = _DecInferBufs(_p(self.memory), _p(self.pm), _p(self.lengths), _p(self.XS), _p(self.CA), _p(self.CD),
                                _p(self.QP), _p(self.AL), _p(self.ACUM), _p(self.PRE), _p(self.MEL), _p(self.GATE),
-                               _p(self.stop), _p(self.w0), _p(self.w1), _p(self.proj_w), _p(self.proj_b))
+                               _p(self.stop), _p(self.w1), _p(self.proj_w), _p(self.proj_b))
         self.t = 0
 
     def run(self, t0, t1, gate_threshold, p_prenet, external_prenet, seed):
