@@ -238,8 +238,9 @@ int t2v_embedding_bwd(const long long* ids, const float* dy_bct, float* dW, int 
  * gx (2,B,T,1024) = X·W_ih^T + b_ih + b_hh per direction (time-batched GEMM done by the caller), whh
  * (2,1024,256).  Persistent cooperative kernels (16 workgroups, W_hh register-resident for all T steps).
  * y (B,T,512) and dg (2,B,T,1024) must be zeroed by the caller (padded positions stay zero);
- * hx_scratch (2*2*16*256 floats) / dgx_scratch (2*2*16*1024 floats) are exchange buffers; sync3 = 3 uint32
- * (zeroed by the call; sync3[2] != 0 afterwards means a bounded spin timed out).  gates/cells (saved
+ * hx_scratch (2*2*16*256 8-byte granules = 2*2*2*16*256 floats) / dgx_scratch (2*2*2*16*1024 floats) are exchange
+ * buffers of {value, step tag} granules (zeroed by the call); sync3 = 3 uint32 (zeroed by the call; sync3[2] != 0
+ * afterwards means a bounded spin timed out).  gates/cells (saved
  * activations) may be NULL for inference.  B <= 16. */
 int t2v_bilstm_fwd(const float* gx, const float* whh, const int32_t* lengths, float* y, float* gates,
                    float* cells, float* hx_scratch, uint32_t* sync3, int B, int T, void* stream);

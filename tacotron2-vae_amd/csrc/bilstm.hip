@@ -4,9 +4,10 @@
 // v_mfma_f32_16x16x4_f32 A-fragments for all T steps (1 MB per direction = 16 x 4 waves x 64 VGPRs; with 8
 // workgroups the per-step MFMA chain was twice as long: 576 -> 478 us forward, -160 us forward+backward).
 // Per step the workgroups of a direction exchange the new hidden state (forward) / gate gradients
-// (backward) through global memory: write-through (sc1) stores, one arrival counter per direction,
-// relaxed polling, sc1 loads (MI355X guide, Guideline 16 "R1" form).  Every spin is bounded: on a
-// timeout the kernel sets an error word and every workgroup leaves (no hang).
+// (backward) through global memory as 8-byte {value, step tag} granules (one sc1 store each, the data is the
+// flag: MI355X guide, Guideline 16 form R2): the consumers poll the granules themselves — no arrival counter,
+// no drain, no barrier (the counter barrier cost ~3 us of the 5 / 9.5 us a step took).  Every spin is bounded:
+// on a timeout the kernel sets an error word and every workgroup leaves (no hang).
 // The input projection X·W_ih^T + b (time-batched GEMM) is done outside; packing semantics = each
 // sequence runs over its OWN length (reverse direction starts at len_b-1), padded outputs are zero.
 #include "t2v_common.h"
@@ -27,17 +28,25 @@ struct BiLstmFwdArgs {
     float* y;               // (B, T, 512) outputs [fwd | rev], zero at padded positions (pre-zeroed by caller)
     float* gates;           // (2, B, T, 1024) saved gate activations (training) or NULL
     float* cells;           // (2, B, T, 256)  saved cell states (training) or NULL
-    float* hx;              // (2, 2, 16, 256) exchange buffer (double buffered by step parity)
-    unsigned* sync;         // [0..1] arrival counters per direction, [2] error word; zeroed by the launcher
+    t2v_u64* hx;            // (2, 2, 16, 256) granule exchange buffer (double buffered by step parity), zeroed by the launcher
+    unsigned* sync;         // [2] error word; zeroed by the launcher
     int B, T;
 };
 
+#define BL_SPIN 4000000u
+__device__ __forceinline__ void bl_put(t2v_u64* p, float v, unsigned tag) {
+    __hip_atomic_store(p, ((t2v_u64)tag << 32) | (t2v_u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int BQ>       // batch rounded up to a multiple of 4: items polled per thread
 __global__ __launch_bounds__(256) void k_bilstm_fwd(BiLstmFwdArgs a) {
     const int dir = blockIdx.x / BL_NW, j = blockIdx.x % BL_NW;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = lane & 15, g = lane >> 4;
     const bool bvalid = b < a.B;
     __shared__ float hbuf[16][BL_H + 4];
+    __shared__ int ok_flag;
+    if (tid == 0) ok_flag = 1;
     // recurrent weights of this wave's two 16-row tiles (4 units x 4 gates each) as MFMA A fragments
     float wreg[BL_NT][64];
     {
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(256) void k_bilstm_fwd(BiLstmFwdArgs a) {
 #pragma unroll
             for (int tt = 0; tt < BL_NT; ++tt) accv[tt] = mfma16x4(wreg[tt][s], hv, accv[tt]);
         }
-        float* hx_w = a.hx + ((size_t)(dir * 2 + (step & 1)) * 16) * BL_H;
+        t2v_u64* hx_w = a.hx + ((size_t)(dir * 2 + (step & 1)) * 16) * BL_H;
 #pragma unroll
         for (int tt = 0; tt < BL_NT; ++tt) {
             const f32x4 acc = accv[tt];
@@ -99,13 +108,36 @@ __global__ __launch_bounds__(256) void k_bilstm_fwd(BiLstmFwdArgs a) {
                         a.cells[(((size_t)dir * a.B + b) * a.T + t) * BL_H + U] = c;
                     }
                 }
-                st_sc1(hx_w + (size_t)b * BL_H + U, hnew);
+                bl_put(hx_w + (size_t)b * BL_H + U, hnew, (unsigned)step + 1u);
             }
         }
         if (step + 1 == a.T) break;
-        if (!group_barrier(a.sync + dir, (unsigned)(BL_NW * (step + 1)), a.sync + 2)) return;
-        for (int i = tid; i < a.B * BL_H; i += 256) hbuf[i >> 8][i & (BL_H - 1)] = ld_sc1(hx_w + i);
+        {   // gather the new hidden state of every item (thread = unit tid, items 0..BQ-1): poll until every tag matches
+            float hv[BQ];
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int u = 0; u < BQ; ++u) {
+                    const t2v_u64 x = __hip_atomic_load(hx_w + (size_t)min(u, a.B - 1) * BL_H + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hv[u] = __uint_as_float((unsigned)x);
+                    ok = ok && (unsigned)(x >> 32) == (unsigned)step + 1u;
+                }
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > BL_SPIN || __hip_atomic_load(a.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(a.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok_flag = 0;
+                    break;
+                }
+            }
+            __syncthreads();           // every wave is done reading hbuf of this step
+#pragma unroll
+            for (int u = 0; u < BQ; ++u)
+                if (u < a.B) hbuf[u][tid] = hv[u];
+        }
         __syncthreads();
+        if (!ok_flag) return;
     }
 }
 
@@ -116,11 +148,12 @@ struct BiLstmBwdArgs {
     const float* gates;     // (2, B, T, 1024)
     const float* cells;     // (2, B, T, 256)
     float* dg;              // (2, B, T, 1024) out: grad wrt gate pre-activations (pre-zeroed by caller)
-    float* dgx;             // (2, 2, 16, 1024) exchange buffer
+    t2v_u64* dgx;           // (2, 2, 16, 1024) granule exchange buffer, zeroed by the launcher
     unsigned* sync;
     int B, T;
 };
 
+template <int BQ>
 __global__ __launch_bounds__(256) void k_bilstm_bwd(BiLstmBwdArgs a) {
     const int dir = blockIdx.x / BL_NW, j = blockIdx.x % BL_NW;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -128,6 +161,8 @@ __global__ __launch_bounds__(256) void k_bilstm_bwd(BiLstmBwdArgs a) {
     __shared__ float dgbuf[16][BL_G + 4];           // all gate gradients of the current step
     __shared__ f32x4 red[4][BL_NT][64];
     __shared__ float dhrec[16][BL_UNITS + 1];       // dL/dh_{prev} for this workgroup's 32 units
+    __shared__ int ok_flag;
+    if (tid == 0) ok_flag = 1;
     // W_hh^T rows of this workgroup's 32 units (2 tiles of 16), K = 1024 split over the 4 waves
     float wreg[BL_NT][64];
     {
@@ -149,7 +184,8 @@ __global__ __launch_bounds__(256) void k_bilstm_bwd(BiLstmBwdArgs a) {
     __syncthreads();
 
     for (int step = a.T - 1; step >= 0; --step) {
-        float* dgx_w = a.dgx + ((size_t)(dir * 2 + (step & 1)) * 16) * BL_G;
+        t2v_u64* dgx_w = a.dgx + ((size_t)(dir * 2 + (step & 1)) * 16) * BL_G;
+        const unsigned tag = (unsigned)(a.T - step);
 #pragma unroll
         for (int rep = 0; rep < BL_REPS; ++rep) {
             const int bb = tid / BL_UNITS + BL_IPP * rep;
@@ -178,14 +214,61 @@ __global__ __launch_bounds__(256) void k_bilstm_bwd(BiLstmBwdArgs a) {
                     float* o = a.dg + idx * BL_G + U;
                     o[0] = di; o[BL_H] = df; o[2 * BL_H] = dgg; o[3 * BL_H] = dob;
                 }
-                float* x = dgx_w + (size_t)bb * BL_G + U;
-                st_sc1(x, di); st_sc1(x + BL_H, df); st_sc1(x + 2 * BL_H, dgg); st_sc1(x + 3 * BL_H, dob);
+                t2v_u64* x = dgx_w + (size_t)bb * BL_G + U;
+                bl_put(x, di, tag); bl_put(x + BL_H, df, tag); bl_put(x + 2 * BL_H, dgg, tag); bl_put(x + 3 * BL_H, dob, tag);
             }
         }
         if (step == 0) break;
-        if (!group_barrier(a.sync + dir, (unsigned)(BL_NW * (a.T - step)), a.sync + 2)) return;
-        for (int i = tid; i < a.B * BL_G; i += 256) dgbuf[i >> 10][i & (BL_G - 1)] = ld_sc1(dgx_w + i);
+        // one wave polls a sentinel granule per (producer workgroup, item) — the last one each producing thread writes —
+        // with naps in between; the other waves stay off the memory system until the rows have landed (256 threads x 32
+        // polling loads per workgroup slowed every producer down)
+        if (wave == 0) {
+            const int nsent = BL_NW * a.B;
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+                for (int i = lane; i < nsent; i += 64) {
+                    const int pj = i % BL_NW, pb = i / BL_NW;
+                    const t2v_u64 x = __hip_atomic_load(dgx_w + (size_t)pb * BL_G + 3 * BL_H + pj * BL_UNITS + (BL_UNITS - 1), __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && (unsigned)(x >> 32) == tag;
+                }
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > BL_SPIN || __hip_atomic_load(a.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(a.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok_flag = 0;
+                    break;
+                }
+            }
+        }
         __syncthreads();
+        if (!ok_flag) return;
+        {   // gather all gate gradients of this step (thread = gate rows tid, tid+256, .. of items 0..BQ-1)
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int u = 0; u < BQ; ++u) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const t2v_u64 x = __hip_atomic_load(dgx_w + (size_t)min(u, a.B - 1) * BL_G + 256 * q + tid, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
+                        ok = ok && (unsigned)(x >> 32) == tag;
+                        if (u < a.B) dgbuf[u][256 * q + tid] = __uint_as_float((unsigned)x);
+                    }
+                }
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > BL_SPIN || __hip_atomic_load(a.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(a.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok_flag = 0;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (!ok_flag) return;
         // dh_rec[b][unit] = sum_k W_hh[k][unit] * dgates[b][k]
         f32x4 accv[BL_NT];
 #pragma unroll
@@ -217,10 +300,14 @@ extern "C" int t2v_bilstm_fwd(const float* gx, const float* whh, const int32_t* 
     if (!gx || !whh || !lengths || !y || !hx_scratch || !sync3 || B < 1 || B > 16 || T < 1) return T2V_ERR_ARG;
     if ((gates == nullptr) != (cells == nullptr)) return T2V_ERR_ARG;
     (void)hipMemsetAsync(sync3, 0, 3 * sizeof(uint32_t), stream);
+    (void)hipMemsetAsync(hx_scratch, 0, sizeof(t2v_u64) * 2 * 2 * 16 * BL_H, stream);       // granule tags
     BiLstmFwdArgs a;
-    a.gx = gx; a.whh = whh; a.lengths = lengths; a.y = y; a.gates = gates; a.cells = cells; a.hx = hx_scratch;
+    a.gx = gx; a.whh = whh; a.lengths = lengths; a.y = y; a.gates = gates; a.cells = cells; a.hx = (t2v_u64*)hx_scratch;
     a.sync = sync3; a.B = B; a.T = T;
-    k_bilstm_fwd<<<2 * BL_NW, 256, 0, stream>>>(a);
+    if (B <= 4) k_bilstm_fwd<4><<<2 * BL_NW, 256, 0, stream>>>(a);
+    else if (B <= 8) k_bilstm_fwd<8><<<2 * BL_NW, 256, 0, stream>>>(a);
+    else if (B <= 12) k_bilstm_fwd<12><<<2 * BL_NW, 256, 0, stream>>>(a);
+    else k_bilstm_fwd<16><<<2 * BL_NW, 256, 0, stream>>>(a);
     return t2v_check_launch();
 }
 
@@ -231,9 +318,13 @@ extern "C" int t2v_bilstm_bwd(const float* whh, const int32_t* lengths, const fl
     if (!whh || !lengths || !dy || !gates || !cells || !dg || !dgx_scratch || !sync3 || B < 1 || B > 16 || T < 1)
         return T2V_ERR_ARG;
     (void)hipMemsetAsync(sync3, 0, 3 * sizeof(uint32_t), stream);
+    (void)hipMemsetAsync(dgx_scratch, 0, sizeof(t2v_u64) * 2 * 2 * 16 * BL_G, stream);      // granule tags
     BiLstmBwdArgs a;
-    a.whh = whh; a.lengths = lengths; a.dy = dy; a.gates = gates; a.cells = cells; a.dg = dg; a.dgx = dgx_scratch;
+    a.whh = whh; a.lengths = lengths; a.dy = dy; a.gates = gates; a.cells = cells; a.dg = dg; a.dgx = (t2v_u64*)dgx_scratch;
     a.sync = sync3; a.B = B; a.T = T;
-    k_bilstm_bwd<<<2 * BL_NW, 256, 0, stream>>>(a);
+    if (B <= 4) k_bilstm_bwd<4><<<2 * BL_NW, 256, 0, stream>>>(a);
+    else if (B <= 8) k_bilstm_bwd<8><<<2 * BL_NW, 256, 0, stream>>>(a);
+    else if (B <= 12) k_bilstm_bwd<12><<<2 * BL_NW, 256, 0, stream>>>(a);
+    else k_bilstm_bwd<16><<<2 * BL_NW, 256, 0, stream>>>(a);
     return t2v_check_launch();
 }

@@ -727,7 +727,7 @@ class BiLSTM(torch.autograd.Function):
             gemm(x[b0:b1].view(Bc * T, -1), w_ih_r, bias_r, out=gx[1].view(Bc * T, 1024))
             gates = torch.empty(2, Bc, T, 1024, **f32) if save else None
             cells = torch.empty(2, Bc, T, 256, **f32) if save else None
-            hx = torch.empty(2 * 2 * 16 * 256, **f32)
+            hx = torch.empty(2 * 2 * 2 * 16 * 256, **f32)              # 8-byte granules
             sync = torch.empty(3, device=x.device, dtype=torch.int32)
             _check(lib.t2v_bilstm_fwd(_p(gx), _p(whh), _p(lengths[b0:b1]), _p(y[b0:b1]), _p(gates), _p(cells), _p(hx),
                                       _p(sync), Bc, T, _stream()), 't2v_bilstm_fwd')
@@ -751,7 +751,7 @@ class BiLSTM(torch.autograd.Function):
         for b0, b1, gates, cells, sync in chunks:
             Bc = b1 - b0
             dg_c = dg if dg is not None else torch.zeros(2, Bc, T, 1024, **f32)
-            dgx = torch.empty(2 * 2 * 16 * 1024, **f32)
+            dgx = torch.empty(2 * 2 * 2 * 16 * 1024, **f32)            # 8-byte granules
             _check(lib.t2v_bilstm_bwd(_p(whh), _p(lengths[b0:b1]), _p(dy[b0:b1]), _p(gates), _p(cells), _p(dg_c), _p(dgx),
                                       _p(sync), Bc, T, _stream()), 't2v_bilstm_bwd')
             _err_note('BiLSTM backward', sync[2:3])

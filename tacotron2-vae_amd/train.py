@@ -108,7 +108,7 @@ class TrainEngine(object):
         # AccumulateGrad nodes remember the stream of their first backward, and a capture that has to synchronise with
         # the legacy default stream is illegal
         self._stream = torch.cuda.Stream() if self.use_graph else None
-        if self.use_graph:
+        if self.use_graph and not os.environ.get('T2V_GRAPH_BRANCHES'):
             # one stream from the first eager step on: a branch stream used before the capture would leave its
             # AccumulateGrad nodes behind and fork the captured graph
             self.model.overlap_branches = False
