@@ -1,22 +1,24 @@
 # Separate PMC-only pass (no --stats / sys-trace): HBM bytes fetched per launch of the dominant kernels.
 # FETCH_SIZE is reported in KB and, on gfx950, counts 64 B per 128-B request for wide coalesced streams:
 # bytes = 2 * 1024 * FETCH_SIZE (MI355X_MICROARCH.md, HBM section).
+TAG=${1:-r02}
+REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmcf -o p -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode > /tmp/pmcf.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmcf -o p -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode --no-secondary --no-graph > /tmp/pmcf.log 2>&1
 F=$(find /tmp/pmcf -name '*counter_collection.csv' | head -1)
-mkdir -p /root/repo/gpurun_out
-python - "$F" > /root/repo/gpurun_out/r01_pmc_fetch_size.json <<'PY'
+mkdir -p $REPO/gpurun_out
+python - "$F" > $REPO/gpurun_out/${TAG}_pmc_fetch_size.json <<'PY'
 import csv, sys, json, collections
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     if r['Counter_Name'] != 'FETCH_SIZE':
         continue
     n = r['Kernel_Name']
-    for key in ('k_lstm_fwd256', 'k_lstm_bwd256', 'k_attn_fwd', 'k_attn_cell_bwd', 'k_clip_adam', 'k_attn_wgrad_part', 'k_conv5_fwd<5>'):
+    for key in ('k_lstm_fwd256', 'k_lstm_bwd256', 'k_attn_fwd', 'k_attn_cell_bwd', 'k_clip_adam', 'k_attn_wgrad_part', 'k_conv5_fwd<5>', 'k_gemm_f32_big'):
         if key in n:
             agg[key].append(float(r['Counter_Value']))
 alg = {'k_lstm_fwd256': 67108864, 'k_lstm_bwd256': 67108864, 'k_clip_adam': 462000000}
-out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode  (round 1, MI355X, separate PMC-only pass, tools/pmc_fetch_size.sh)",
+out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode --no-secondary --no-graph  (round 2, MI355X, separate PMC-only pass, tools/pmc_fetch_size.sh)",
        "unit_note": "FETCH_SIZE is reported in KB and, on gfx950, counts 64 B per 128-B request for wide coalesced streams: bytes = 2 * 1024 * FETCH_SIZE (MI355X_MICROARCH.md, HBM section)",
        "kernels": {}}
 for k, v in agg.items():
@@ -26,4 +28,4 @@ for k, v in agg.items():
     out["kernels"][k] = e
 print(json.dumps(out, indent=1))
 PY
-cat /root/repo/gpurun_out/r01_pmc_fetch_size.json | head -30
+cat $REPO/gpurun_out/${TAG}_pmc_fetch_size.json | head -50
