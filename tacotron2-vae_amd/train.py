@@ -228,6 +228,9 @@ def prepare_dataloaders(hparams):
     from torch.utils.data.distributed import DistributedSampler
     from data_utils import BucketBatchSampler, DeviceFrontendCollate, TextMelCollate, TextMelLoader
     device_fe = bool(getattr(hparams, 'device_frontend', False))
+    if device_fe and getattr(hparams, 'load_mel_from_disk', False):
+        raise ValueError("device_frontend=True needs raw audio: it cannot be combined with load_mel_from_disk=True "
+                         "(the collate would run the STFT over stored mels)")
     trainset = TextMelLoader(hparams.training_files, hparams, return_audio=device_fe)
     valset = TextMelLoader(hparams.validation_files, hparams, return_audio=device_fe)
     collate_fn = (DeviceFrontendCollate(hparams, stft=trainset.stft) if device_fe
