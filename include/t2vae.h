@@ -256,6 +256,14 @@ int t2v_bilstm_bwd(const float* whh, const int32_t* lengths, const float* dy, co
 int t2v_gemm_f32(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
                  float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
                  uint64_t seed, uint32_t rng_stream, uint32_t rng_t, void* stream);
+/* Same product with split-K for skinny deep-K shapes (weight gradients of small layers with K = T*B): when
+ * t2v_gemm_splitk_scratch_floats(M,N,K) > 0 and `splitk_scratch` holds that many floats, the k range is cut over
+ * gridDim.z and the partial tiles are summed in a fixed order together with the epilogue (deterministic); otherwise
+ * identical to t2v_gemm_f32. */
+long t2v_gemm_splitk_scratch_floats(int M, int N, int K);
+int t2v_gemm_f32_splitk(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
+                        float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
+                        uint64_t seed, uint32_t rng_stream, uint32_t rng_t, float* splitk_scratch, void* stream);
 /* same contract, bf16 operands / fp32 accumulate (bf16_run) */
 int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
                   float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,

@@ -21,6 +21,8 @@ struct GemmArgs {
     int relu, accumulate;
     float p_drop; uint64_t seed; uint32_t rng_stream, rng_t;
     const t2v_step_params* step;
+    int kz_chunk;          // split-K: k range per blockIdx.z (multiple of GM_BK), 0 = whole K in one block
+    float* part;           // split-K partial tiles (gridDim.z, M, N) or NULL
 };
 
 template <bool A_KC, bool B_KC>   // operand contiguous along k?
@@ -30,6 +32,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int i0 = blockIdx.y * GM_BM, j0 = blockIdx.x * GM_BN;
+    const int kbeg = a.kz_chunk ? blockIdx.z * a.kz_chunk : 0, kend = a.kz_chunk ? min(a.K, kbeg + a.kz_chunk) : a.K;
     constexpr int NE = GM_BM * GM_BK / 256;   // 8
     float ra[NE], rb[NE];
     auto load_tiles = [&](int k0) {
@@ -40,13 +43,13 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
                 const int kk = A_KC ? (e & (GM_BK - 1)) : (e >> 6);
                 const int ii = A_KC ? (e >> 5) : (e & (GM_BM - 1));
                 const int i = i0 + ii, k = k0 + kk;
-                ra[e8] = (i < a.M && k < a.K) ? a.A[(long)i * a.sAi + (long)k * a.sAk] : 0.f;
+                ra[e8] = (i < a.M && k < kend) ? a.A[(long)i * a.sAi + (long)k * a.sAk] : 0.f;
             }
             {
                 const int kk = B_KC ? (e & (GM_BK - 1)) : (e >> 6);
                 const int jj = B_KC ? (e >> 5) : (e & (GM_BN - 1));
                 const int j = j0 + jj, k = k0 + kk;
-                rb[e8] = (j < a.N && k < a.K) ? a.B[(long)j * a.sBj + (long)k * a.sBk] : 0.f;
+                rb[e8] = (j < a.N && k < kend) ? a.B[(long)j * a.sBj + (long)k * a.sBk] : 0.f;
             }
         }
     };
@@ -61,14 +64,14 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int nkt = (a.K + GM_BK - 1) / GM_BK;
-    load_tiles(0);
+    const int nkt = (kend - kbeg + GM_BK - 1) / GM_BK;
+    load_tiles(kbeg);
     store_tiles(0);
     __syncthreads();
     const int ai = 32 * wm + (lane & 31), bj = 32 * wn + (lane & 31), kh = lane >> 5;
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tiles((kt + 1) * GM_BK);
+        if (kt + 1 < nkt) load_tiles(kbeg + (kt + 1) * GM_BK);
 #pragma unroll
         for (int s = 0; s < GM_BK / 2; ++s)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][2 * s + kh][ai], Bs[buf][2 * s + kh][bj], acc, 0, 0, 0);
@@ -76,6 +79,16 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
         __syncthreads();
     }
     const int j = j0 + 32 * wn + (lane & 31);
+    if (a.part) {      // split-K: raw partial tile, epilogue in k_gemm_splitk_reduce
+        if (j < a.N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (i < a.M) a.part[((size_t)blockIdx.z * a.M + i) * a.N + j] = acc[r];
+            }
+        }
+        return;
+    }
     if (j < a.N) {
         const float bv = a.bias ? a.bias[j] : 0.f;
 #pragma unroll
@@ -91,6 +104,37 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
             }
         }
     }
+}
+
+// ---- split-K for the skinny deep-K products (weight gradients of the Prenet / projection / GRU / VAE head: a handful of
+// 64x64 tiles with K = T*B = 2400): the k range is cut over gridDim.z, partial tiles are summed in a fixed order
+// (deterministic) together with the bias / ReLU / dropout / accumulate epilogue.
+__global__ void k_gemm_splitk_reduce(GemmArgs a, int nsplit) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)a.M * a.N) return;
+    const int i = (int)(e / a.N), j = (int)(e - (size_t)i * a.N);
+    float v = 0.f;
+    for (int z = 0; z < nsplit; ++z) v += a.part[(size_t)z * a.M * a.N + e];
+    const size_t idx = (size_t)i * a.ldc + j;
+    if (a.bias) v += a.bias[j];
+    if (a.accumulate) v += a.C[idx];
+    if (a.relu) v = fmaxf(v, 0.f);
+    if (a.p_drop > 0.f) v *= t2v_drop_scale(t2v_step_seed(a.seed, a.step), a.rng_stream, a.rng_t, (uint32_t)idx, a.p_drop);
+    a.C[idx] = v;
+}
+// number of k-splits for the 64x64 kernel: fill ~256 workgroups, keep >= 8 k-tiles per split
+static int gemm_splits(int M, int N, int K) {
+    const long tiles = (long)((M + GM_BM - 1) / GM_BM) * ((N + GM_BN - 1) / GM_BN);
+    if (tiles >= 64 || K < 16 * GM_BK) return 1;
+    long ns = 256 / tiles;
+    const long maxk = K / (8 * GM_BK);
+    if (ns > maxk) ns = maxk;
+    if (ns > 32) ns = 32;
+    return ns < 2 ? 1 : (int)ns;
+}
+extern "C" long t2v_gemm_splitk_scratch_floats(int M, int N, int K) {
+    const int ns = (M < 1 || N < 1 || K < 1) ? 1 : gemm_splits(M, N, K);
+    return ns > 1 ? (long)ns * M * N : 0;
 }
 
 // ---- large-tile variant for the big time-batched GEMMs (the deferred LSTM weight gradients DGA^T·X / DGD^T·X with
@@ -344,6 +388,7 @@ extern "C" int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B,
     a.A = A; a.B = B; a.bias = bias; a.C = C; a.sAi = sAi; a.sAk = sAk; a.sBj = sBj; a.sBk = sBk;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
     a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = g_t2v_step;
+    a.kz_chunk = 0; a.part = nullptr;
     dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM);
     const bool akc = sAk == 1, bkc = sBk == 1;
     if (akc && bkc) k_gemm_bf16<true, true><<<grid, 256, 0, stream>>>(a);
@@ -353,15 +398,31 @@ extern "C" int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B,
     return t2v_check_launch();
 }
 
+static int gemm_f32_impl(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
+                         float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
+                         uint64_t seed, uint32_t rng_stream, uint32_t rng_t, float* splitk_scratch, void* stream_);
 extern "C" int t2v_gemm_f32(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
                             float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
                             uint64_t seed, uint32_t rng_stream, uint32_t rng_t, void* stream_) {
+    return gemm_f32_impl(A, sAi, sAk, B, sBj, sBk, bias, C, ldc, M, N, K, relu, accumulate, p_drop, seed, rng_stream, rng_t,
+                         nullptr, stream_);
+}
+extern "C" int t2v_gemm_f32_splitk(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
+                                   float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
+                                   uint64_t seed, uint32_t rng_stream, uint32_t rng_t, float* splitk_scratch, void* stream_) {
+    return gemm_f32_impl(A, sAi, sAk, B, sBj, sBk, bias, C, ldc, M, N, K, relu, accumulate, p_drop, seed, rng_stream, rng_t,
+                         splitk_scratch, stream_);
+}
+static int gemm_f32_impl(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
+                         float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
+                         uint64_t seed, uint32_t rng_stream, uint32_t rng_t, float* splitk_scratch, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!A || !B || !C || M < 1 || N < 1 || K < 1 || ldc < N) return T2V_ERR_ARG;
     GemmArgs a;
     a.A = A; a.B = B; a.bias = bias; a.C = C; a.sAi = sAi; a.sAk = sAk; a.sBj = sBj; a.sBk = sBk;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
     a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = g_t2v_step;
+    a.kz_chunk = 0; a.part = nullptr;
     const bool akc = sAk == 1, bkc = sBk == 1;
     if (gemm_big_ok(a)) {
         const bool wide = gemm_big_waste(M, N, 128) <= gemm_big_waste(M, N, 64) + 1e-6;
@@ -377,10 +438,17 @@ extern "C" int t2v_gemm_f32(const float* A, long sAi, long sAk, const float* B, 
 #undef T2V_BIG
         return t2v_check_launch();
     }
-    dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM);
+    const int ns = splitk_scratch ? gemm_splits(M, N, K) : 1;
+    if (ns > 1) {
+        const int tiles_k = (K + GM_BK - 1) / GM_BK;
+        a.kz_chunk = ((tiles_k + ns - 1) / ns) * GM_BK;
+        a.part = splitk_scratch;
+    }
+    dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, ns);
     if (akc && bkc) k_gemm_f32<true, true><<<grid, 256, 0, stream>>>(a);
     else if (akc) k_gemm_f32<true, false><<<grid, 256, 0, stream>>>(a);
     else if (bkc) k_gemm_f32<false, true><<<grid, 256, 0, stream>>>(a);
     else k_gemm_f32<false, false><<<grid, 256, 0, stream>>>(a);
+    if (ns > 1) k_gemm_splitk_reduce<<<(unsigned)(((size_t)M * N + 255) / 256), 256, 0, stream>>>(a, ns);
     return t2v_check_launch();
 }

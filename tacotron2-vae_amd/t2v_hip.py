@@ -45,7 +45,7 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decode
            't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_conv1d_dw_scratch_floats', 't2v_gemm_bf16', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
            't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats',
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_fuse_location_weights', 't2v_decoder_qp_floats',
-           't2v_set_step_params', 't2v_decoder_replay_bwd_kernels', 't2v_embedding_fwd', 't2v_embedding_bwd',
+           't2v_set_step_params', 't2v_decoder_replay_bwd_kernels', 't2v_embedding_fwd', 't2v_embedding_bwd', 't2v_gemm_f32_splitk', 't2v_gemm_splitk_scratch_floats',
            't2v_attn_bwd_slices')
 
 
@@ -110,6 +110,9 @@ def load_library():
     lib.t2v_gemm_f32.argtypes = [vp, C.c_long, C.c_long, vp, C.c_long, C.c_long, vp, vp, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, vp]
     lib.t2v_gemm_bf16.argtypes = lib.t2v_gemm_f32.argtypes
+    lib.t2v_gemm_f32_splitk.argtypes = lib.t2v_gemm_f32.argtypes[:-1] + [vp, vp]
+    lib.t2v_gemm_splitk_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.t2v_gemm_splitk_scratch_floats.restype = C.c_long
     lib.t2v_attn_wgrad.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]     # 8 pointers
     lib.t2v_attn_wgrad_scratch_floats.argtypes = []
     lib.t2v_conv2d_s2_fwd.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
@@ -787,6 +790,14 @@ def gemm(A, B, bias=None, out=None, relu=False, accumulate=False, p_drop=0.0, se
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32)
     assert out.is_contiguous() and out.shape == (M, N)
+    if not _BF16:
+        nscr = lib.t2v_gemm_splitk_scratch_floats(M, N, K)
+        if nscr:        # skinny deep-K product: split K over workgroups, fixed-order partial sum
+            scr = torch.empty(nscr, device=A.device, dtype=torch.float32)
+            _check(lib.t2v_gemm_f32_splitk(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(bias), _p(out),
+                                           N, M, N, K, int(relu), int(accumulate), float(p_drop), int(seed), int(rng_stream),
+                                           int(rng_t), _p(scr), _stream()), 't2v_gemm_f32_splitk')
+            return out
     fn = lib.t2v_gemm_bf16 if _BF16 else lib.t2v_gemm_f32
     _check(fn(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(bias), _p(out), N,
               M, N, K, int(relu), int(accumulate), float(p_drop), int(seed), int(rng_stream),

@@ -7,7 +7,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("M,N,K", [(2406, 81, 1536), (2406, 256, 80), (504, 128, 512), (7, 5, 3), (65, 129, 33),
                                    # large-tile kernel (M, N >= 128, 16-byte runs): ragged edges, K not a multiple of 16
-                                   (2400, 4096, 256), (1340, 1536, 2404), (2000, 1028, 52), (4096, 640, 20)])
+                                   (2400, 4096, 256), (1340, 1536, 2404), (2000, 1028, 52), (4096, 640, 20),
+                                   # split-K (few tiles, deep K): Prenet / projection / d_wq weight-gradient shapes
+                                   (256, 80, 2406), (81, 1536, 2400), (128, 1024, 2400), (42, 256, 768), (256, 256, 2406)])
 def test_gemm_forms(M, N, K):
     import t2v_hip
     g = torch.Generator().manual_seed(M + N + K)
