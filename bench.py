@@ -132,19 +132,25 @@ def decode_bench(model, T_in=200, steps=800):
             enc = model.encoder.inference(model.transcript_embedding(ids).transpose(1, 2))
             memory = enc + model.vae_gst.fc3(z).unsqueeze(1)
             import contextlib, io
+            res = {}
             with contextlib.redirect_stdout(io.StringIO()):
-                dec.inference(memory, chunk=steps)                  # warm-up
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                mel, _, _ = dec.inference(memory, chunk=steps)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t0
+                for name, flag in (("persistent", True), ("launch_per_stage", False)):
+                    dec.inference(memory, chunk=steps, persistent=flag)                  # warm-up
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    mel, _, _ = dec.inference(memory, chunk=steps, persistent=flag)
+                    torch.cuda.synchronize()
+                    res[name] = time.perf_counter() - t0
+            dt = res["persistent"]
     finally:
         dec.max_decoder_steps, dec.gate_threshold = old_steps, old_thr
         if was_training:
             model.train()
     return {"frames_per_s": round(steps / dt, 1), "us_per_frame": round(1e6 * dt / steps, 2), "B": 1, "T_in": T_in,
-            "steps": steps, "note": "decoder loop only (incl. weight packing + memory_layer); encoder/postnet excluded"}
+            "steps": steps, "mode": "one persistent launch, weights resident on chip (csrc/decoder_persist.hip)",
+            "launch_per_stage_us_per_frame": round(1e6 * res["launch_per_stage"] / steps, 2),
+            "note": "decoder loop only (incl. session set-up: weight packing, memory_layer, one-time weight load); "
+                    "encoder/postnet excluded"}
 
 
 def frontend_bench(B=6, n_samples=102144, reps=20):

@@ -189,6 +189,40 @@ int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_infer_bufs* 
                             int t_begin, int t_end, float gate_threshold, float p_prenet,
                             int external_prenet, uint64_t seed, void* stream);
 
+/* The same loop as ONE persistent launch (csrc/decoder_persist.hip): 256 workgroups stay resident for the whole
+ * utterance, all weights in registers / LDS, the per-frame state vectors travel between CUs as tagged 8-byte granules,
+ * the loop ends on the frame the gate fires (nothing is computed after it).  Runs frames 0..t_end-1 from the zero state;
+ * pre_first = Prenet(go frame).  Supported when t2v_decoder_persist_supported(B, T_in) != 0 (B <= 4 and the attention
+ * operands of T_in positions fit the 160 KB LDS: T_in <= 224 at B = 1); everything else takes t2v_decoder_infer_steps.
+ * Weights are the nn.LSTMCell / LinearNorm tensors themselves (no packing). */
+typedef struct t2v_dec_persist_weights {
+    const float* w_ih_att; const float* w_hh_att;   /* (4096,768) [prenet | ctx], (4096,1024) */
+    const float* w_ih_dec; const float* w_hh_dec;   /* (4096,1536) [h_att | ctx], (4096,1024) */
+    const float* bias_att; const float* bias_dec;   /* (4096) b_ih + b_hh */
+    const float* wq;        /* (128,1024) query_layer weight */
+    const float* wcomb;     /* t2v_fuse_location_weights output */
+    const float* v;         /* (128) */
+    const float* proj_w;    /* (337,1536) as in t2v_dec_infer_bufs */
+    const float* proj_b;    /* (337) */
+    const float* prenet_w1; /* (256,256) */
+} t2v_dec_persist_weights;
+typedef struct t2v_dec_persist_bufs {
+    const float* memory;     /* (B,T_in,512) */
+    const float* pm;         /* (B,T_in,128) */
+    const int32_t* lengths;  /* NULL at inference */
+    const float* pre_first;  /* (B,256) */
+    float* MEL;              /* (t_end,B,80) out */
+    float* GATE;             /* (t_end,B) out */
+    float* AL;               /* (t_end+1,B,T_in) out: row t+1 = attention weights of frame t */
+    int32_t* stop_flag;      /* (1): first frame on which every item's gate fired (caller presets INT_MAX) */
+    void* granules;          /* t2v_decoder_persist_granules(B) x 8 bytes of exchange scratch (zeroed by the call) */
+    uint32_t* err_word;      /* (1): != 0 afterwards: a bounded spin timed out */
+} t2v_dec_persist_bufs;
+long t2v_decoder_persist_granules(int B);
+int t2v_decoder_persist_supported(int B, int T_in);
+int t2v_decoder_infer_persistent(const t2v_dec_persist_weights* w, const t2v_dec_persist_bufs* s, int B, int T_in,
+                                 int t_end, float gate_threshold, float p_prenet, uint64_t seed, void* stream);
+
 /* ------------------------------------------------------------------ Conv1d + BatchNorm1d + activation
  * The encoder conv bank (model.py:159-177) and the Postnet (model.py:110-148): stride-1 "same" Conv1d as
  * an implicit GEMM on fp32 MFMA, BatchNorm1d (train: biased batch statistics over B*T incl. padded frames;

@@ -1,0 +1,558 @@
+// Free-running decode as ONE persistent launch (reference Decoder.inference model.py:428-464 / the loop at
+// synthesizer.py:139-154): 256 workgroups x 512 threads stay resident for the whole utterance, every weight of the
+// loop lives in registers / LDS, and the five dependent stages of a frame
+//     attention_rnn -> attention -> decoder_rnn -> projection (+ folded Prenet layer 0) -> Prenet layer 1
+// hand their small result vectors (1024 / 512 / 256 values per item) from CU to CU as 8-byte {value, frame tag}
+// granules (MI355X guide G16 form R2: one sc1 store per value, consumers poll the values themselves — no counters, no
+// fences, no grid barrier).  Nothing is streamed from HBM per frame: the 71 MB of LSTM weights that the launch-per-stage
+// loop (decoder_infer.hip) re-reads every frame are read once.
+//
+// Roles (every workgroup runs the frame loop, phases in the same order, so the waits cannot form a cycle):
+//   all 256 workgroups : 4 hidden units of both LSTM cells (16 gate rows each): rows x K/8 per wave in VGPRs
+//                        (136 per lane), VALU dot products against the LDS copy of the state vectors
+//   wg 0 .. 8B-1       : attention slice (item b = wg/8, 16 attention dims + 64 context columns): W_q slice, memory /
+//                        processed-memory slices and the alignment window stay in LDS for all frames
+//   wg 64 .. 106       : 8 of the 337 projection rows each (80 mel + gate + 256 folded Prenet-0 rows), rows in LDS
+//   wg 128 .. 159      : 8 Prenet layer-1 rows each
+// The gate row decides the stop (model.py:453) and publishes it as a granule every workgroup reads at the top of the
+// next frame: nothing is computed after the stop frame.
+// Limits of this path: B <= 4, T_in <= 224 (LDS residency of the attention operands); the launch-per-stage loop serves
+// everything else (and the stepwise decode() API).
+#include "t2v_common.h"
+#include "t2v_kernels.h"
+#include <limits.h>
+
+#define PD_THREADS 512
+#define PD_MAXB 4
+#define PD_MAXT 224
+#define PD_SPIN 3000000u
+#define PD_XW 2816                 // LDS state row: [h_att 1024 | ctx 512 | pre1 256 | h_dec 1024]
+#define PD_X_HA 0
+#define PD_X_CX 1024
+#define PD_X_P1 1536
+#define PD_X_HD 1792
+#define PD_KATT 1792               // attention_rnn K: [h_att | ctx | pre1]   (contiguous in the LDS row)
+#define PD_KDEC 2560               // decoder_rnn   K: [h_att | ctx | h_dec]  (h_dec sits 256 further)
+#define PD_NROW 337
+#define PD_WG_PROJ 64
+#define PD_WG_PRE1 128
+
+struct PersistArgs {
+    const float* w_ih_att; const float* w_hh_att; const float* w_ih_dec; const float* w_hh_dec;   // nn.LSTMCell tensors
+    const float* bias_att; const float* bias_dec;     // (4096) b_ih + b_hh
+    const float* wq;          // (128,1024) query_layer weight
+    const float* wcomb;       // fused location filter, forward copy F[d][g][st]
+    const float* v;           // (128)
+    const float* proj_w;      // (337,1536) [linear_projection; gate_layer; W0·linear_projection]
+    const float* proj_b;      // (337)
+    const float* w1;          // (256,256) Prenet layer 1
+    const float* memory;      // (B,T_in,512)
+    const float* pm;          // (B,T_in,128)
+    const int32_t* lengths;   // (B) or NULL
+    const float* pre_first;   // (B,256) Prenet(go frame)
+    float* MEL; float* GATE; float* AL;      // (Tmax,B,80) (Tmax,B) (Tmax+1,B,T_in): AL[t+1] = weights of frame t
+    int* stop_flag;
+    t2v_u64* xg;              // granule exchange, 2 parities x pd_par(B)
+    unsigned* err;
+    int B, T_in, t_end;
+    float gate_logit_thr, p_prenet;
+    uint64_t seed;
+    unsigned long long* prof;   // optional: stamps of frame 100 (workgroup 0 slots 0..9, workgroup 64 slots 10..13, workgroup 128 slots 14..16)
+};
+#define PD_STAMP(WG, I) do { if (a.prof && t == 100 && wg == (WG) && tid == 0) a.prof[(I)] = __builtin_readcyclecounter(); } while (0)
+
+// granule offsets inside one parity block
+__host__ __device__ static inline size_t pd_hatt(int B) { (void)B; return 0; }
+__host__ __device__ static inline size_t pd_hdec(int B) { return (size_t)B * 1024; }
+__host__ __device__ static inline size_t pd_ctx(int B) { return (size_t)B * 2048; }
+__host__ __device__ static inline size_t pd_pre0(int B) { return (size_t)B * 2560; }
+__host__ __device__ static inline size_t pd_pre1(int B) { return (size_t)B * 2816; }
+__host__ __device__ static inline size_t pd_ex(int B) { return (size_t)B * 3072; }          // [b][8][256]
+__host__ __device__ static inline size_t pd_stop(int B) { return (size_t)B * 5120; }
+__host__ __device__ static inline size_t pd_par(int B) { return (size_t)B * 5120 + 8; }
+
+__device__ __forceinline__ void pd_put(t2v_u64* p, float v, unsigned tag) {
+    __hip_atomic_store(p, ((t2v_u64)tag << 32) | (t2v_u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ t2v_u64 pd_get(const t2v_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Poll `n` granules (n <= PER * 512) until every tag matches, then copy the values to LDS.  Returns false on a timeout
+// (error word set); block-uniform through `flag` (an LDS int, 1 on entry) — the caller syncs before reading dst.
+template <int PER>
+__device__ __forceinline__ void pd_gather(float* dst, const t2v_u64* src, int n, unsigned tag, unsigned* err, int* flag) {
+    const int tid = threadIdx.x;
+    float v[PER];
+    unsigned spins = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = min(tid + PD_THREADS * u, n - 1);
+            const t2v_u64 x = pd_get(src + i);
+            v[u] = __uint_as_float((unsigned)x);
+            ok = ok && (unsigned)(x >> 32) == tag;
+        }
+        if (ok) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > PD_SPIN || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = 0;
+            break;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int i = tid + PD_THREADS * u;
+        if (i < n) dst[i] = v[u];
+    }
+}
+
+// LSTM gate rows of this workgroup for one cell: lane = (row r = lane>>2 (unit r>>2, gate r&3), kq = lane&3), wave = K
+// eighth; weights wreg[j] <-> logical k = wave*KW + 4j + kq.  Partial dot products -> red[wave][r][b].
+template <int NJ, int KSPLIT>   // NJ = K/32 weights per lane; KSPLIT: logical k >= KSPLIT sits 256 further in the LDS row
+__device__ __forceinline__ void pd_gemv(const float (&wreg)[NJ], const float* X, int B, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kq = lane & 3, r = lane >> 2;
+    for (int b = 0; b < B; ++b) {
+        const float* xb = X + (size_t)b * PD_XW;
+        float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; j += 2) {
+            const int k0 = wave * (4 * NJ) + 4 * j + kq, k1 = k0 + 4;
+            acc0 = fmaf(wreg[j], xb[k0 + (k0 >= KSPLIT ? 256 : 0)], acc0);
+            acc1 = fmaf(wreg[j + 1], xb[k1 + (k1 >= KSPLIT ? 256 : 0)], acc1);
+        }
+        float acc = acc0 + acc1;
+        acc = T2V_DPP_ADD(acc, 0xB1);        // quad: lanes kq = 0..3 of a row
+        acc = T2V_DPP_ADD(acc, 0x4E);
+        if (kq == 0) red[(wave * 16 + r) * PD_MAXB + b] = acc;
+    }
+}
+
+__global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wg = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int B = a.B, Tp = a.T_in;
+    // ---- LDS carve (floats; sizes follow the runtime B and T_in: pd_lds_floats())
+    const int Tcap = (Tp + 15) & ~15, TW = Tcap + 32;
+    float* X = lds;                                      // [B][2816]
+    float* red = X + B * PD_XW;                          // [8][16][MAXB]
+    float* gst = red + 8 * 16 * PD_MAXB;                 // [MAXB][16] gate pre-activations
+    float* cst = gst + PD_MAXB * 16;                     // [2][MAXB][4] cell states (attention_rnn, decoder_rnn)
+    int* flag = (int*)(cst + 2 * PD_MAXB * 4);           // [4]
+    float* role = (float*)(flag + 4);                    // role area
+    // attention role
+    float* wq_s = role;                                  // [16][1028]
+    float* mem_s = wq_s + 16 * 1028;                     // [Tcap][64]
+    float* pm_s = mem_s + Tcap * 64;                     // [Tcap][16]
+    float* win = pm_s + Tcap * 16;                       // [2][TW]: alignment window, index x <-> position x - 15
+    float* eall = win + 2 * TW;                          // [Tcap]
+    float* qv = eall + Tcap;                             // [16]
+    float* qred = qv + 16;                               // [32][16]
+    float* cred = qred + 32 * 16;                        // [8][64]
+    float* rsm = cred + 8 * 64;                          // [32] row maxima
+    float* rss = rsm + 32;                               // [32] row sums
+    // projection / Prenet-1 roles (their own workgroups: alias the same area)
+    float* prow_s = role;                                // [8][1536]
+    float* w1_s = role;                                  // [8][256]
+
+    const bool is_attn = wg < 8 * B;
+    const int ab = wg >> 3, as = wg & 7;                 // attention item / slice
+    const int gw = wg * 8 + wave;                        // global wave index
+    const int prow = (wg >= PD_WG_PROJ && wg < PD_WG_PROJ + 43) ? (wg - PD_WG_PROJ) * 8 + wave : -1;      // projection row of this wave
+    const bool is_proj = prow >= 0 && prow < PD_NROW;
+    const bool wg_proj = prow >= 0;                       // whole workgroup (the last one has idle waves)
+    const int p1row = (wg >= PD_WG_PRE1 && wg < PD_WG_PRE1 + 32) ? (wg - PD_WG_PRE1) * 8 + wave : -1;    // Prenet-1 row of this wave
+    (void)gw;
+
+    // ---- one-time loads: LSTM weights of this workgroup's 16 gate rows per cell into registers
+    const int kq = lane & 3, r16 = lane >> 2;
+    const int grow = (r16 & 3) * T2V_H + 4 * wg + (r16 >> 2);           // gate-major row of (unit 4wg + r16>>2, gate r16&3)
+    float wa[PD_KATT / 32], wd[PD_KDEC / 32];
+#pragma unroll
+    for (int j = 0; j < PD_KATT / 32; ++j) {
+        const int k = wave * (PD_KATT / 8) + 4 * j + kq;                // [h_att | ctx | pre1]
+        wa[j] = k < T2V_H ? a.w_hh_att[(size_t)grow * T2V_H + k]
+                          : (k < T2V_KATT ? a.w_ih_att[(size_t)grow * 768 + T2V_PRE + (k - T2V_H)] : a.w_ih_att[(size_t)grow * 768 + (k - T2V_KATT)]);
+    }
+#pragma unroll
+    for (int j = 0; j < PD_KDEC / 32; ++j) {
+        const int k = wave * (PD_KDEC / 8) + 4 * j + kq;                // [h_att | ctx | h_dec]
+        wd[j] = k < T2V_KATT ? a.w_ih_dec[(size_t)grow * T2V_KATT + k] : a.w_hh_dec[(size_t)grow * T2V_H + (k - T2V_KATT)];
+    }
+    float bias_a = 0.f, bias_d = 0.f;                                   // threads 0..15: gate row biases
+    if (tid < 16) {
+        const int row = (tid & 3) * T2V_H + 4 * wg + (tid >> 2);
+        bias_a = a.bias_att[row];
+        bias_d = a.bias_dec[row];
+    }
+    for (int i = tid; i < B * PD_XW; i += PD_THREADS) X[i] = 0.f;
+    if (tid < 2 * PD_MAXB * 4) cst[tid] = 0.f;
+    if (tid == 0) flag[0] = 1;
+    // role operands
+    float areg[16];
+#pragma unroll
+    for (int st = 0; st < 16; ++st) areg[st] = 0.f;
+    float4 vr = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (is_attn) {
+        for (int i = tid; i < 16 * 1024; i += PD_THREADS) wq_s[(i >> 10) * 1028 + (i & 1023)] = a.wq[(size_t)(16 * as) * 1024 + i];
+        for (int i = tid; i < Tp * 64; i += PD_THREADS) mem_s[i] = a.memory[((size_t)ab * Tp + (i >> 6)) * T2V_E + 64 * as + (i & 63)];
+        for (int i = tid; i < Tp * 16; i += PD_THREADS) pm_s[i] = a.pm[((size_t)ab * Tp + (i >> 4)) * T2V_A + 16 * as + (i & 15)];
+        for (int i = tid; i < 2 * TW; i += PD_THREADS) win[i] = 0.f;
+        const int g = lane >> 4, c16 = lane & 15;
+        const float4* wp = (const float4*)(a.wcomb + (16 * as + c16) * 64 + 16 * g);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 w4 = wp[u];
+            areg[4 * u] = w4.x; areg[4 * u + 1] = w4.y; areg[4 * u + 2] = w4.z; areg[4 * u + 3] = w4.w;
+        }
+        vr = *(const float4*)(a.v + 16 * as + 4 * g);
+    } else if (prow >= 0) {
+        if (is_proj)
+            for (int i = lane; i < 1536; i += 64) prow_s[wave * 1536 + i] = a.proj_w[(size_t)prow * 1536 + i];
+    } else if (p1row >= 0) {
+        for (int i = lane; i < 256; i += 64) w1_s[wave * 256 + i] = a.w1[(size_t)p1row * 256 + i];
+    }
+    const float pbias = is_proj ? a.proj_b[prow] : 0.f;
+    // Prenet of the go frame (frame 0 input)
+    for (int i = tid; i < B * T2V_PRE; i += PD_THREADS) X[(i >> 8) * PD_XW + PD_X_P1 + (i & 255)] = a.pre_first[i];
+    __syncthreads();
+
+    for (int t = 0; t < a.t_end; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+        t2v_u64* xcur = a.xg + (size_t)(t & 1) * pd_par(B);
+        const t2v_u64* xprev = a.xg + (size_t)((t + 1) & 1) * pd_par(B);
+        // ---- frame entry (t > 0): stop decision of the previous frame, Prenet output of the new frame's input
+        if (t > 0) {
+            // one polling loop for both: every thread its share of the Prenet granules, thread 0 also the stop granule
+            // (two separate polls were two serial memory round trips at the top of every frame)
+            {
+                const int n = B * 256;                          // <= 1024: two granules per thread
+                float pv[2];
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int i = min(tid + PD_THREADS * u, n - 1);
+                        const t2v_u64 x = pd_get(xprev + pd_pre1(B) + i);           // [b][256] is contiguous
+                        pv[u] = __uint_as_float((unsigned)x);
+                        ok = ok && (unsigned)(x >> 32) == (unsigned)t;
+                    }
+                    const t2v_u64 sx = pd_get(xprev + pd_stop(B));
+                    const bool stop_known = (unsigned)(sx >> 32) == (unsigned)t;
+                    if (stop_known && (unsigned)sx != 0u) {         // the gate fired on the previous frame: its Prenet rows
+                        if (tid == 0) flag[0] = 2;                  // belong to a frame that will not run
+                        break;
+                    }
+                    if (ok && stop_known) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > PD_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        flag[0] = 0;
+                        break;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = tid + PD_THREADS * u;
+                    if (i < n) X[(size_t)(i >> 8) * PD_XW + PD_X_P1 + (i & 255)] = pv[u];
+                }
+            }
+            __syncthreads();
+            if (flag[0] != 1) return;                          // stopped on the gate (2) or timed out (0)
+        }
+        PD_STAMP(0, 0); PD_STAMP(64, 10); PD_STAMP(128, 14);
+        // ---- 1. attention_rnn(t): gates of this workgroup's 4 units, cell update, publish h_att
+        pd_gemv<PD_KATT / 32, PD_KATT>(wa, X, B, red);        // K contiguous in the LDS row: no split offset
+        __syncthreads();
+        if (tid < 16 * B) {                                    // thread = (row r = tid & 15, item b = tid >> 4)
+            const int r = tid & 15, b = tid >> 4;
+            float s = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) s += red[(w8 * 16 + r) * PD_MAXB + b];
+            gst[b * 16 + r] = s + __shfl(bias_a, r, 64);       // pre-activation where the unit's thread finds its four gates
+        }
+        __syncthreads();
+        if (tid < 4 * B) {                                     // thread = (unit u = tid & 3, item b = tid >> 2)
+            const int u = tid & 3, b = tid >> 2;
+            const float* gp = gst + b * 16 + 4 * u;
+            const float gi = sigmoidf_(gp[0]), gf = sigmoidf_(gp[1]), gg = tanhf_(gp[2]), go = sigmoidf_(gp[3]);
+            const float c = gf * cst[b * 4 + u] + gi * gg;
+            cst[b * 4 + u] = c;
+            pd_put(xcur + pd_hatt(B) + (size_t)b * 1024 + 4 * wg + u, go * tanhf_(c), tag);
+        }
+        PD_STAMP(0, 1);
+        // ---- 2. h_att(t) for everyone (attention slices need it now, the others for decoder_rnn)
+        for (int b = 0; b < B; ++b)
+            pd_gather<2>(X + (size_t)b * PD_XW + PD_X_HA, xcur + pd_hatt(B) + (size_t)b * 1024, 1024, tag, a.err, flag);
+        __syncthreads();
+        if (flag[0] != 1) return;
+        PD_STAMP(0, 2);
+        if (is_attn) {
+            const int g = lane >> 4, c16 = lane & 15;
+            const int len = a.lengths ? a.lengths[ab] : Tp;
+            // query slice: thread = (dim d = tid & 15, k part kp = tid >> 4 of 32 k's)
+            {
+                const int d = tid & 15, kp = tid >> 4;
+                const float* wrow = wq_s + d * 1028 + 32 * kp;
+                const float* hx = X + (size_t)ab * PD_XW + PD_X_HA + 32 * kp;
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) acc = fmaf(wrow[i], hx[i], acc);
+                qred[kp * 16 + d] = acc;
+            }
+            __syncthreads();
+            if (tid < 16) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) acc += qred[i * 16 + tid];
+                qv[tid] = acc;
+            }
+            __syncthreads();
+            const float4 q4 = make_float4(qv[4 * g], qv[4 * g + 1], qv[4 * g + 2], qv[4 * g + 3]);
+            // partial energies of this slice: wave -> position tiles wave, wave + 8
+            t2v_u64* exw = xcur + pd_ex(B) + ((size_t)ab * 8 + as) * 256;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int jt = wave + 8 * i;
+                if (16 * jt < Tp) {
+                    float bop[16];
+#pragma unroll
+                    for (int st = 0; st < 16; ++st) {
+                        const int kk = 4 * st + g;
+                        bop[st] = win[(kk >> 5) * TW + 16 * jt + c16 + (kk & 31)];
+                    }
+                    f32x4 l0 = {0.f, 0.f, 0.f, 0.f}, l1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int st = 0; st < 16; st += 2) {
+                        l0 = mfma16x4(areg[st], bop[st], l0);
+                        l1 = mfma16x4(areg[st + 1], bop[st + 1], l1);
+                    }
+                    const f32x4 acc = l0 + l1;
+                    const int j = 16 * jt + c16;
+                    const float4 pm4 = *(const float4*)(pm_s + min(j, Tp - 1) * 16 + 4 * g);
+                    const float s0 = tanhf_(q4.x + acc[0] + pm4.x), s1 = tanhf_(q4.y + acc[1] + pm4.y);
+                    const float s2 = tanhf_(q4.z + acc[2] + pm4.z), s3 = tanhf_(q4.w + acc[3] + pm4.w);
+                    float esum = vr.x * s0 + vr.y * s1 + vr.z * s2 + vr.w * s3;
+                    esum += __shfl_xor(esum, 16, 64);
+                    esum += __shfl_xor(esum, 32, 64);
+                    if (g == 0 && j < Tp) pd_put(exw + j, esum, tag);
+                }
+            }
+            PD_STAMP(0, 3);
+            // gather the 8 partials of every position, masked softmax
+            float ev0 = -INFINITY;
+            if (tid < Tp) {
+                const t2v_u64* e0 = xcur + pd_ex(B) + (size_t)ab * 8 * 256 + tid;
+                float p[8];
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const t2v_u64 x = pd_get(e0 + i * 256);
+                        p[i] = __uint_as_float((unsigned)x);
+                        ok = ok && (unsigned)(x >> 32) == tag;
+                    }
+                    if (ok) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > PD_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        flag[0] = 0;
+                        break;
+                    }
+                }
+                const float ev = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+                ev0 = tid < len ? ev : -INFINITY;
+            }
+            float mloc = ev0;
+            mloc = T2V_DPP_MAX(mloc, 0xB1); mloc = T2V_DPP_MAX(mloc, 0x4E);
+            mloc = T2V_DPP_MAX(mloc, 0x141); mloc = T2V_DPP_MAX(mloc, 0x140);
+            if ((lane & 15) == 0) rsm[tid >> 4] = mloc;
+            __syncthreads();
+            if (flag[0] != 1) return;
+            float m = rsm[0];
+#pragma unroll
+            for (int u = 1; u < 32; ++u) m = fmaxf(m, rsm[u]);
+            const float e0v = tid < Tp ? expf(ev0 - m) : 0.f;
+            float sloc = row16_sum(e0v);
+            if ((lane & 15) == 0) rss[tid >> 4] = sloc;
+            __syncthreads();
+            float ssum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) ssum += rss[u];
+            const float al = e0v * (1.0f / ssum);
+            if (tid < Tp) {
+                eall[tid] = al;
+                win[15 + tid] = al;                                         // previous weights of the next frame
+                win[TW + 15 + tid] += al;                                   // cumulative weights
+                if (as == 0) a.AL[((size_t)(t + 1) * B + ab) * Tp + tid] = al;
+            }
+            __syncthreads();
+            PD_STAMP(0, 4);
+            // context columns 64 as .. 64 as + 63: thread = (column c = tid & 63, part = tid >> 6)
+            {
+                const int c = tid & 63, part = tid >> 6;
+                float acc = 0.f;
+                for (int j = part; j < Tp; j += 8) acc = fmaf(eall[j], mem_s[j * 64 + c], acc);
+                cred[part * 64 + c] = acc;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                float acc = 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += cred[u * 64 + tid];
+                pd_put(xcur + pd_ctx(B) + (size_t)ab * 512 + 64 * as + tid, acc, tag);
+            }
+        }
+        PD_STAMP(0, 5); PD_STAMP(64, 11);
+        // ---- 3. ctx(t) and h_dec(t-1) for everyone, decoder_rnn(t)
+        for (int b = 0; b < B; ++b) {
+            pd_gather<1>(X + (size_t)b * PD_XW + PD_X_CX, xcur + pd_ctx(B) + (size_t)b * 512, 512, tag, a.err, flag);
+            if (t > 0 && !wg_proj)     // projection workgroups already hold h_dec(t-1) (they gathered it in stage 4)
+                pd_gather<2>(X + (size_t)b * PD_XW + PD_X_HD, xprev + pd_hdec(B) + (size_t)b * 1024, 1024, (unsigned)t, a.err, flag);
+        }
+        __syncthreads();
+        if (flag[0] != 1) return;
+        PD_STAMP(0, 6);
+        pd_gemv<PD_KDEC / 32, T2V_KATT>(wd, X, B, red);       // logical k >= 1536 (h_dec) sits 256 further in the LDS row
+        __syncthreads();
+        if (tid < 16 * B) {
+            const int r = tid & 15, b = tid >> 4;
+            float s = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) s += red[(w8 * 16 + r) * PD_MAXB + b];
+            gst[b * 16 + r] = s + __shfl(bias_d, r, 64);
+        }
+        __syncthreads();
+        if (tid < 4 * B) {
+            const int u = tid & 3, b = tid >> 2;
+            const float* gp = gst + b * 16 + 4 * u;
+            const float gi = sigmoidf_(gp[0]), gf = sigmoidf_(gp[1]), gg = tanhf_(gp[2]), go = sigmoidf_(gp[3]);
+            const float c = gf * cst[PD_MAXB * 4 + b * 4 + u] + gi * gg;
+            cst[PD_MAXB * 4 + b * 4 + u] = c;
+            pd_put(xcur + pd_hdec(B) + (size_t)b * 1024 + 4 * wg + u, go * tanhf_(c), tag);
+        }
+        PD_STAMP(0, 7); PD_STAMP(64, 12);
+        // ---- 4. projection rows (mel, gate, folded Prenet layer 0)
+        if (prow >= 0) {            // whole workgroup takes the branch: barriers inside are uniform
+            for (int b = 0; b < B; ++b)
+                pd_gather<2>(X + (size_t)b * PD_XW + PD_X_HD, xcur + pd_hdec(B) + (size_t)b * 1024, 1024, tag, a.err, flag);
+            __syncthreads();
+            if (flag[0] != 1) return;
+            if (is_proj) {
+                const float* wr = prow_s + wave * 1536;
+                bool all_fired = true;
+                for (int b = 0; b < B; ++b) {
+                    const float* xb = X + (size_t)b * PD_XW;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 24; ++i) {
+                        const int k = lane + 64 * i;                         // [h_dec (1024) | ctx (512)]
+                        acc = fmaf(wr[k], k < T2V_H ? xb[PD_X_HD + k] : xb[PD_X_CX + (k - T2V_H)], acc);
+                    }
+                    acc = wave_sum(acc) + pbias;
+                    if (lane == 0) {
+                        if (prow < T2V_NMEL) a.MEL[((size_t)t * B + b) * T2V_NMEL + prow] = acc;
+                        else if (prow == T2V_NMEL) a.GATE[(size_t)t * B + b] = acc;
+                        else {
+                            const int rr = prow - (T2V_NMEL + 1);
+                            const float pv = fmaxf(acc, 0.f) * t2v_drop_scale(a.seed, T2V_RNG_PRENET0, t + 1, (uint32_t)(b * T2V_PRE + rr), a.p_prenet);
+                            pd_put(xcur + pd_pre0(B) + (size_t)b * 256 + rr, pv, tag);
+                        }
+                    }
+                    all_fired = all_fired && acc > a.gate_logit_thr;
+                }
+                if (prow == T2V_NMEL && lane == 0) {
+                    // stop rule sigmoid(gate) > threshold for every item (model.py:453; B == 1 in the reference)
+                    if (all_fired) atomicMin(a.stop_flag, t);
+                    pd_put(xcur + pd_stop(B), __uint_as_float(all_fired ? 1u : 0u), tag);
+                }
+            }
+            __syncthreads();        // X[HD] now holds h_dec(t): the next frame's decoder_rnn input for this workgroup
+        }
+        PD_STAMP(64, 13); PD_STAMP(128, 15);
+        // ---- 5. Prenet layer 1 rows
+        if (p1row >= 0) {
+            const float4 w4 = *(const float4*)(w1_s + wave * 256 + 4 * lane);
+            for (int b = 0; b < B; ++b) {
+                const t2v_u64* gq = xcur + pd_pre0(B) + (size_t)b * 256 + 4 * lane;
+                float xv[4];
+                unsigned spins = 0;
+                bool dead = false;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const t2v_u64 x = pd_get(gq + i);
+                        xv[i] = __uint_as_float((unsigned)x);
+                        ok = ok && (unsigned)(x >> 32) == tag;
+                    }
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > PD_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dead = true;
+                        break;
+                    }
+                }
+                if (dead) break;
+                float acc = w4.x * xv[0];
+                acc = fmaf(w4.y, xv[1], acc); acc = fmaf(w4.z, xv[2], acc); acc = fmaf(w4.w, xv[3], acc);
+                acc = wave_sum(acc);
+                if (lane == 0) {
+                    acc = fmaxf(acc, 0.f) * t2v_drop_scale(a.seed, T2V_RNG_PRENET1, t + 1, (uint32_t)(b * T2V_PRE + p1row), a.p_prenet);
+                    pd_put(xcur + pd_pre1(B) + (size_t)b * 256 + p1row, acc, tag);
+                }
+            }
+        }
+        PD_STAMP(128, 16); PD_STAMP(0, 8);
+    }
+}
+
+static size_t pd_lds_bytes(int B, int T_in) {
+    const size_t Tcap = (size_t)((T_in + 15) / 16) * 16;
+    size_t f = (size_t)B * PD_XW + 8 * 16 * PD_MAXB + PD_MAXB * 16 + 2 * PD_MAXB * 4 + 4;
+    const size_t attn = 16 * 1028 + Tcap * 64 + Tcap * 16 + 2 * (Tcap + 32) + Tcap + 16 + 32 * 16 + 8 * 64 + 64;
+    const size_t proj = 8 * 1536;
+    f += attn > proj ? attn : proj;
+    return f * sizeof(float);
+}
+#define PD_LDS_MAX (160 * 1024)
+
+extern "C" long t2v_decoder_persist_granules(int B) { return (B < 1 || B > PD_MAXB) ? 0 : (long)(2 * pd_par(B)); }
+extern "C" int t2v_decoder_persist_supported(int B, int T_in) {
+    return B >= 1 && B <= PD_MAXB && T_in >= 1 && T_in <= PD_MAXT && pd_lds_bytes(B, T_in) <= PD_LDS_MAX;
+}
+
+extern "C" int t2v_decoder_infer_persistent(const t2v_dec_persist_weights* w, const t2v_dec_persist_bufs* s, int B, int T_in,
+                                            int t_end, float gate_threshold, float p_prenet, uint64_t seed, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!w || !s || !t2v_decoder_persist_supported(B, T_in) || t_end < 1) return T2V_ERR_ARG;
+    if (!w->w_ih_att || !w->w_hh_att || !w->w_ih_dec || !w->w_hh_dec || !w->bias_att || !w->bias_dec || !w->wq || !w->wcomb ||
+        !w->v || !w->proj_w || !w->proj_b || !w->prenet_w1 || !s->memory || !s->pm || !s->pre_first || !s->MEL || !s->GATE ||
+        !s->AL || !s->stop_flag || !s->granules || !s->err_word)
+        return T2V_ERR_ARG;
+    static bool attr_set = false;
+    const size_t lds = pd_lds_bytes(B, T_in);
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_decode_persist, hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX) != hipSuccess)
+            return t2v_check_launch();
+        attr_set = true;
+    }
+    (void)hipMemsetAsync(s->granules, 0, sizeof(t2v_u64) * 2 * pd_par(B), stream);
+    (void)hipMemsetAsync(s->err_word, 0, sizeof(unsigned), stream);
+    PersistArgs a;
+    a.w_ih_att = w->w_ih_att; a.w_hh_att = w->w_hh_att; a.w_ih_dec = w->w_ih_dec; a.w_hh_dec = w->w_hh_dec;
+    a.bias_att = w->bias_att; a.bias_dec = w->bias_dec; a.wq = w->wq; a.wcomb = w->wcomb; a.v = w->v;
+    a.proj_w = w->proj_w; a.proj_b = w->proj_b; a.w1 = w->prenet_w1;
+    a.memory = s->memory; a.pm = s->pm; a.lengths = s->lengths; a.pre_first = s->pre_first;
+    a.MEL = s->MEL; a.GATE = s->GATE; a.AL = s->AL; a.stop_flag = s->stop_flag;
+    a.xg = (t2v_u64*)s->granules; a.err = s->err_word;
+    a.B = B; a.T_in = T_in; a.t_end = t_end;
+    a.gate_logit_thr = gate_threshold <= 0.f ? -INFINITY : (gate_threshold >= 1.f ? INFINITY : logf(gate_threshold / (1.f - gate_threshold)));
+    a.p_prenet = p_prenet; a.seed = seed;
+    a.prof = g_t2v_prof;
+    k_decode_persist<<<T2V_NWG, PD_THREADS, lds, stream>>>(a);
+    return t2v_check_launch();
+}

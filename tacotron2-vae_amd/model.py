@@ -10,6 +10,8 @@ runs in libt2vae_hip (t2v_hip.DecoderCore); there is no CPU fallback.
 """
 from math import sqrt
 
+import os
+
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -225,7 +227,7 @@ class Decoder(nn.Module):
         self.attention_weights, self.attention_weights_cum = s.AL[t + 1], s.ACUM[t + 1]
         return s.MEL[t], s.GATE[t].unsqueeze(1), s.AL[t + 1]
 
-    def inference(self, memory, chunk=32):
+    def inference(self, memory, chunk=32, persistent=None):
         """reference model.py:428-464: decode until sigmoid(gate) > gate_threshold or max_decoder_steps.
         The loop runs on the GPU in chunks of `chunk` frames between stop-flag reads."""
         self.initialize_decoder_states(memory, mask=None)
@@ -234,6 +236,17 @@ class Decoder(nn.Module):
         self._calls += 1
         seed = (int(self.dropout_seed) * 1000003 + self._calls) & 0x7FFFFFFFFFFFFFFF
         n, t = None, 0
+        if persistent is None:
+            persistent = os.environ.get('T2V_DECODE_PERSISTENT', '1') != '0'
+        if persistent and s.persistent_supported():
+            # one persistent launch for the whole utterance: weights resident on chip, state handed between CUs as
+            # tagged granules, the loop ends on the frame the gate fires
+            s.run_persistent(self.gate_threshold, drop_rate, seed)
+            stop = int(s.stop.item())
+            t2v_hip.check_async_errors()
+            if stop < s.max_steps:
+                n = stop + 1
+            t = s.max_steps
         while t < s.max_steps:
             t1 = min(s.max_steps, t + chunk)
             s.run(t, t1, self.gate_threshold, drop_rate, False, seed)

@@ -35,6 +35,17 @@ class _DecBwdBufs(C.Structure):
         'dHC', 'DGA', 'DGD', 'DQ', 'DCTX', 'YD', 'YA', 'DCA', 'DCD', 'GPREV', 'GCUM', 'DV')]
 
 
+class _DecPersistWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        'w_ih_att', 'w_hh_att', 'w_ih_dec', 'w_hh_dec', 'bias_att', 'bias_dec', 'wq', 'wcomb', 'v', 'proj_w', 'proj_b',
+        'prenet_w1')]
+
+
+class _DecPersistBufs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        'memory', 'pm', 'lengths', 'pre_first', 'MEL', 'GATE', 'AL', 'stop_flag', 'granules', 'err_word')]
+
+
 class _DecInferBufs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         'memory', 'pm', 'lengths', 'XS', 'CA', 'CD', 'QP', 'AL', 'ACUM', 'PRE', 'MEL', 'GATE', 'stop_flag',
@@ -46,6 +57,7 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decode
            't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats',
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_fuse_location_weights', 't2v_decoder_qp_floats',
            't2v_set_step_params', 't2v_decoder_replay_bwd_kernels', 't2v_embedding_fwd', 't2v_embedding_bwd', 't2v_gemm_f32_splitk', 't2v_gemm_splitk_scratch_floats',
+           't2v_decoder_infer_persistent', 't2v_decoder_persist_supported', 't2v_decoder_persist_granules',
            't2v_attn_bwd_slices')
 
 
@@ -92,6 +104,11 @@ def load_library():
                                      C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.t2v_set_phase_profile.argtypes = [C.c_void_p]
+    lib.t2v_decoder_infer_persistent.argtypes = [C.POINTER(_DecPersistWeights), C.POINTER(_DecPersistBufs), C.c_int, C.c_int,
+                                                 C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]
+    lib.t2v_decoder_persist_supported.argtypes = [C.c_int, C.c_int]
+    lib.t2v_decoder_persist_granules.argtypes = [C.c_int]
+    lib.t2v_decoder_persist_granules.restype = C.c_long
     lib.t2v_decoder_infer_steps.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecInferBufs), C.c_int, C.c_int, C.c_int,
                                             C.c_int, C.c_float, C.c_float, C.c_int, C.c_uint64, C.c_void_p]
     vp = C.c_void_p
@@ -564,6 +581,9 @@ class InferenceSession(object):
         self.memory, self.pm, self.lengths = _f32c(memory.detach()), _f32c(pm.detach()), lengths
         self.packF_att, self.packF_dec, _, _ = pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, KATT_INF,
                                                                     False)
+        # the persistent one-launch loop reads the nn.LSTMCell tensors themselves (weights stay in registers)
+        self.raw = tuple(_f32c(t.detach()) for t in (w_ih_att, w_hh_att, w_ih_dec, w_hh_dec))
+        self.wq = _f32c(wq.detach())
         self.b_att, self.b_dec = _f32c(b_att.detach()), _f32c(b_dec.detach())
         self.wqT = wq.detach().t().contiguous()
         self.wcomb = fuse_location_weights(_f32c(loc_conv.detach()), _f32c(loc_dense.detach()))
@@ -592,6 +612,26 @@ class InferenceSession(object):
                                _p(self.QP), _p(self.AL), _p(self.ACUM), _p(self.PRE), _p(self.MEL), _p(self.GATE),
                                _p(self.stop), _p(self.w1), _p(self.proj_w), _p(self.proj_b))
         self.t = 0
+
+    def persistent_supported(self):
+        return bool(load_library().t2v_decoder_persist_supported(self.B, self.T_in))
+
+    def run_persistent(self, gate_threshold, p_prenet, seed):
+        """frames 0..max_steps-1 (or up to the frame the gate fires) as ONE persistent launch (csrc/decoder_persist.hip);
+        PRE[0] must hold Prenet(go frame).  Outputs: MEL, GATE, AL, stop."""
+        lib = load_library()
+        dev = self.memory.device
+        if not hasattr(self, '_gran'):
+            self._gran = torch.empty(lib.t2v_decoder_persist_granules(self.B), device=dev, dtype=torch.int64)
+            self._perr = torch.zeros(1, device=dev, dtype=torch.int32)
+        W = _DecPersistWeights(_p(self.raw[0]), _p(self.raw[1]), _p(self.raw[2]), _p(self.raw[3]), _p(self.b_att), _p(self.b_dec),
+                               _p(self.wq), _p(self.wcomb), _p(self.v), _p(self.proj_w), _p(self.proj_b), _p(self.w1))
+        Bf = _DecPersistBufs(_p(self.memory), _p(self.pm), _p(self.lengths), _p(self.PRE[0]), _p(self.MEL), _p(self.GATE),
+                             _p(self.AL), _p(self.stop), _p(self._gran), _p(self._perr))
+        _check(lib.t2v_decoder_infer_persistent(C.byref(W), C.byref(Bf), self.B, self.T_in, self.max_steps,
+                                                float(gate_threshold), float(p_prenet), int(seed), _stream()),
+               't2v_decoder_infer_persistent')
+        _err_note('persistent decode (granule hand-off)', self._perr)
 
     def run(self, t0, t1, gate_threshold, p_prenet, external_prenet, seed):
         _check(load_library().t2v_decoder_infer_steps(C.byref(self.W), C.byref(self.S), self.B, self.T_in, int(t0),
