@@ -77,14 +77,14 @@ typedef struct t2v_dec_weights {
     const float* v;           /* (128)      attention v (model.py:39) */
 } t2v_dec_weights;
 
-/* Saved-activation arena of one teacher-forced decoder pass (caller allocates; rows marked
- * "row 0 = 0" must be zeroed by the caller before t2v_decoder_train_fwd). */
+/* Saved-activation arena of one teacher-forced decoder pass (caller allocates; t2v_decoder_train_fwd clears the rows
+ * marked "row 0 = 0" — the zero initial states of model.py:280-296 — together with its sync words in one launch). */
 typedef struct t2v_dec_train_bufs {
     const float* gpre;      /* (T,B,4096)  prenet(x_t)·W_ih[:, :256]^T + b_ih + b_hh */
     const float* memory;    /* (B,T_in,512) encoder outputs + style */
     const float* pm;        /* (B,T_in,128) memory_layer(memory) (model.py:290) */
     const int32_t* lengths; /* (B) valid encoder positions; NULL = no mask */
-    float* XS;    /* (T+2,B,2560) XS[t+1] = [h_att_t | ctx_t | h_dec_{t-1}]; row 0 = 0 */
+    float* XS;    /* (T+2,B,2560) XS[t+1] = [h_att_t | ctx_t | h_dec_{t-1}]; row 0 = 0 (rows 0..1 are cleared) */
     float* CA;    /* (T+1,B,1024) pre-dropout cell of attention_rnn; row 0 = 0 */
     float* CD;    /* (T+1,B,1024) pre-dropout cell of decoder_rnn;   row 0 = 0 */
     float* GA;    /* (T,B,4096) gate activations i,f,g,o of attention_rnn; NULL (with GD, S) = forward only */
@@ -232,7 +232,9 @@ int t2v_decoder_infer_persistent(const t2v_dec_persist_weights* w, const t2v_dec
  *   t2v_bn_act_fwd : out = dropout(act(BN(y)));  act 0 none / 1 tanh / 2 relu.  training != 0 finalises
  *                    the statistics from stat_part, writes mean/rstd for the backward and updates the
  *                    running buffers (momentum, unbiased variance).
- *   t2v_bn_act_bwd : dy (grad wrt the conv output), dgamma, dbeta from dout.
+ *   t2v_bn_act_bwd : dy (grad wrt the conv output), dgamma, dbeta from dout.  dconv_bias ((M) or NULL) receives the
+ *                    gradient of the bias of the convolution that feeds this training-mode BatchNorm, which is
+ *                    identically zero (dy has zero mean per channel): written here so the caller launches no fill.
  *   t2v_conv1d_bwd : dX (may be NULL; needs Wt_scratch of W's size) and dW (may be NULL). */
 int t2v_conv1d_stat_blocks(int B, int T, int Cin, int Cout, int KS);
 int t2v_conv1d_fwd(const float* W, const float* X, const float* bias, float* Y, float* stat_part,
@@ -256,8 +258,8 @@ int t2v_bn_act_fwd(const float* y, const float* stat_part, int nblk, const float
                    uint64_t seed, uint32_t rng_stream, uint32_t rng_t, void* stream);
 int t2v_bn_act_bwd(const float* y, const float* dout, const float* mean, const float* rstd,
                    const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta,
-                   int B, int M, int T, int act, float p_drop, uint64_t seed, uint32_t rng_stream,
-                   uint32_t rng_t, void* stream);
+                   float* dconv_bias, int B, int M, int T, int act, float p_drop, uint64_t seed,
+                   uint32_t rng_stream, uint32_t rng_t, void* stream);
 
 /* ------------------------------------------------------------------ symbol embedding
  * nn.Embedding(n_symbols, C) of the text encoder (model.py:474-482) as used at model.py:528
@@ -267,11 +269,23 @@ int t2v_bn_act_bwd(const float* y, const float* dout, const float* mean, const f
 int t2v_embedding_fwd(const long long* ids, const float* W, float* out_bct, int B, int T, int C, int n_symbols, void* stream);
 int t2v_embedding_bwd(const long long* ids, const float* dy_bct, float* dW, int B, int T, int C, int n_symbols, void* stream);
 
+/* backward of the GEMM's relu / dropout epilogue (Prenet, model.py:96-99): out = dy * [y != 0] * scale, where y is the
+ * forward output (already relu'd and scaled by 1/(1-p)) and scale = 1/(1-p); n contiguous floats, 16-byte aligned. */
+int t2v_gemm_epilogue_bwd(const float* dy, const float* y, float* out, size_t n, float scale, void* stream);
+
+/* ------------------------------------------------------------------ column sums (bias gradients)
+ * out[j] = sum_i A[i*lda + j] for a row-major (M,N) matrix: what autograd computes as `grad.sum(0)` for the bias of
+ * every nn.Linear / LSTM cell on the path (model.py:171-190, 200-236) and for the sum over decoder steps of the
+ * processed-memory gradient (model.py:60-64).  Fixed slice boundaries and summation order (bit-reproducible).
+ * scratch: t2v_colsum_scratch_floats(M,N) floats (may be 0 -> NULL). */
+long t2v_colsum_scratch_floats(long M, long N);
+int t2v_colsum(const float* A, long lda, long M, long N, float* scratch, float* out, void* stream);
+
 /* ------------------------------------------------------------------ encoder BiLSTM recurrence
  * nn.LSTM(512, 256, bidirectional) on a packed sequence (model.py:171-173, 183-190), recurrent part only:
  * gx (2,B,T,1024) = X·W_ih^T + b_ih + b_hh per direction (time-batched GEMM done by the caller), whh
  * (2,1024,256).  Persistent cooperative kernels (16 workgroups, W_hh register-resident for all T steps).
- * y (B,T,512) and dg (2,B,T,1024) must be zeroed by the caller (padded positions stay zero);
+ * y (B,T,512) and dg (2,B,T,1024) are cleared by the calls themselves (padded positions stay zero);
  * hx_scratch (2*2*16*256 8-byte granules = 2*2*2*16*256 floats) / dgx_scratch (2*2*2*16*1024 floats) are exchange
  * buffers of {value, step tag} granules (zeroed by the call); sync3 = 3 uint32 (zeroed by the call; sync3[2] != 0
  * afterwards means a bounded spin timed out).  gates/cells (saved

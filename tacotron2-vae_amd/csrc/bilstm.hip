@@ -299,8 +299,11 @@ extern "C" int t2v_bilstm_fwd(const float* gx, const float* whh, const int32_t* 
     hipStream_t stream = (hipStream_t)stream_;
     if (!gx || !whh || !lengths || !y || !hx_scratch || !sync3 || B < 1 || B > 16 || T < 1) return T2V_ERR_ARG;
     if ((gates == nullptr) != (cells == nullptr)) return T2V_ERR_ARG;
-    (void)hipMemsetAsync(sync3, 0, 3 * sizeof(uint32_t), stream);
-    (void)hipMemsetAsync(hx_scratch, 0, sizeof(t2v_u64) * 2 * 2 * 16 * BL_H, stream);       // granule tags
+    T2VZeroRegions z;
+    z.add(sync3, 3 * sizeof(uint32_t));
+    z.add(hx_scratch, sizeof(t2v_u64) * 2 * 2 * 16 * BL_H);       // granule tags
+    z.add(y, sizeof(float) * (size_t)B * T * 2 * BL_H);           // padded positions stay zero (pad_packed_sequence)
+    t2v_zero_regions(z, stream);
     BiLstmFwdArgs a;
     a.gx = gx; a.whh = whh; a.lengths = lengths; a.y = y; a.gates = gates; a.cells = cells; a.hx = (t2v_u64*)hx_scratch;
     a.sync = sync3; a.B = B; a.T = T;
@@ -317,8 +320,11 @@ extern "C" int t2v_bilstm_bwd(const float* whh, const int32_t* lengths, const fl
     hipStream_t stream = (hipStream_t)stream_;
     if (!whh || !lengths || !dy || !gates || !cells || !dg || !dgx_scratch || !sync3 || B < 1 || B > 16 || T < 1)
         return T2V_ERR_ARG;
-    (void)hipMemsetAsync(sync3, 0, 3 * sizeof(uint32_t), stream);
-    (void)hipMemsetAsync(dgx_scratch, 0, sizeof(t2v_u64) * 2 * 2 * 16 * BL_G, stream);      // granule tags
+    T2VZeroRegions z;
+    z.add(sync3, 3 * sizeof(uint32_t));
+    z.add(dgx_scratch, sizeof(t2v_u64) * 2 * 2 * 16 * BL_G);      // granule tags
+    z.add(dg, sizeof(float) * (size_t)2 * B * T * BL_G);          // padded positions carry no gradient
+    t2v_zero_regions(z, stream);
     BiLstmBwdArgs a;
     a.whh = whh; a.lengths = lengths; a.dy = dy; a.gates = gates; a.cells = cells; a.dg = dg; a.dgx = (t2v_u64*)dgx_scratch;
     a.sync = sync3; a.B = B; a.T = T;

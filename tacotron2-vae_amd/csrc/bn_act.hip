@@ -127,6 +127,7 @@ struct BnBwdArgs {
     const float* mean; const float* rstd; const float* gamma; const float* beta;
     float* dy;               // grad wrt the conv output (B,M,T)
     float* dgamma; float* dbeta;   // (M)
+    float* dconv_bias;             // (M) or NULL: receives zeros (see t2v_bn_act_bwd)
     int B, M, T, act;
     float p_drop;
     uint64_t seed; uint32_t rng_stream, rng_t;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd(BnBwdArgs a) {
         }
         const float S1 = block_sum_256(s1, scr);
         const float S2 = block_sum_256(s2, scr);
-        if (tid == 0) { a.dbeta[m] = S1; a.dgamma[m] = S2; }
+        if (tid == 0) { a.dbeta[m] = S1; a.dgamma[m] = S2; if (a.dconv_bias) a.dconv_bias[m] = 0.f; }
         const float n = (float)a.B * (float)a.T;
         const float m1 = S1 / n, m2 = S2 / n;
 #pragma unroll
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd(BnBwdArgs a) {
     }
     const float S1 = block_sum_256(s1, scr);
     const float S2 = block_sum_256(s2, scr);
-    if (tid == 0) { a.dbeta[m] = S1; a.dgamma[m] = S2; }
+    if (tid == 0) { a.dbeta[m] = S1; a.dgamma[m] = S2; if (a.dconv_bias) a.dconv_bias[m] = 0.f; }
     const float n = (float)a.B * (float)a.T;
     const float m1 = S1 / n, m2 = S2 / n;
     for (int b = 0; b < a.B; ++b) {
@@ -230,13 +231,13 @@ extern "C" int t2v_bn_act_fwd(const float* y, const float* stat_part, int nblk, 
 
 extern "C" int t2v_bn_act_bwd(const float* y, const float* dout, const float* mean, const float* rstd,
                               const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta,
-                              int B, int M, int T, int act, float p_drop, uint64_t seed, uint32_t rng_stream,
-                              uint32_t rng_t, void* stream_) {
+                              float* dconv_bias, int B, int M, int T, int act, float p_drop, uint64_t seed,
+                              uint32_t rng_stream, uint32_t rng_t, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!y || !dout || !mean || !rstd || !gamma || !beta || !dy || !dgamma || !dbeta) return T2V_ERR_ARG;
     BnBwdArgs a;
     a.y = y; a.dout = dout; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.dy = dy;
-    a.dgamma = dgamma; a.dbeta = dbeta; a.B = B; a.M = M; a.T = T; a.act = act; a.p_drop = p_drop;
+    a.dgamma = dgamma; a.dbeta = dbeta; a.dconv_bias = dconv_bias; a.B = B; a.M = M; a.T = T; a.act = act; a.p_drop = p_drop;
     a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = g_t2v_step;
     k_bn_act_bwd<<<M, 256, 0, stream>>>(a);
     return t2v_check_launch();

@@ -449,14 +449,16 @@ static int launch_train_bwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
     if (!w->packB_att || !w->packB_dec || !w->wcomb) return T2V_ERR_ARG;
     const int JS = t2v_attn_bwd_js(T_in), S = t2v_attn_bwd_slices_(T_in);
     const size_t Tcap = t2v_tcap(T_in);
-    (void)hipMemsetAsync(g->YD, 0, sizeof(float) * B * T2V_XW, stream);
-    (void)hipMemsetAsync(g->YA, 0, sizeof(float) * B * T2V_KATT, stream);
-    (void)hipMemsetAsync(g->DCA, 0, sizeof(float) * B * T2V_H, stream);
-    (void)hipMemsetAsync(g->DCD, 0, sizeof(float) * B * T2V_H, stream);
-    (void)hipMemsetAsync(g->GPREV, 0, sizeof(float) * 2 * B * S * 2 * 64, stream);        // partial dcat rows x parity
-    (void)hipMemsetAsync(g->GCUM, 0, sizeof(float) * ((size_t)B * S * Tcap + 64), stream);  // per-workgroup Gcum copies + sync words
-    (void)hipMemsetAsync(g->DV, 0, sizeof(float) * B * S * T2V_A, stream);
-    (void)hipMemsetAsync(g->DQ, 0, sizeof(t2v_u64) * (size_t)T_out * B * S * T2V_A, stream);  // granule tags
+    T2VZeroRegions z;
+    z.add(g->YD, sizeof(float) * B * T2V_XW);
+    z.add(g->YA, sizeof(float) * B * T2V_KATT);
+    z.add(g->DCA, sizeof(float) * B * T2V_H);
+    z.add(g->DCD, sizeof(float) * B * T2V_H);
+    z.add(g->GPREV, sizeof(float) * 2 * B * S * 2 * 64);                    // partial dcat rows x parity
+    z.add(g->GCUM, sizeof(float) * ((size_t)B * S * Tcap + 64));            // per-workgroup Gcum copies + sync words
+    z.add(g->DV, sizeof(float) * B * S * T2V_A);
+    z.add(g->DQ, sizeof(t2v_u64) * (size_t)T_out * B * S * T2V_A);          // granule tags
+    t2v_zero_regions(z, stream);
 
     const size_t HC = T2V_H + T2V_E;
     unsigned* sync = (unsigned*)(g->GCUM + (size_t)B * S * Tcap);     // [1] error word

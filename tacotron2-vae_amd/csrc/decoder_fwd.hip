@@ -326,8 +326,18 @@ static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
     // tags and words are zeroed per pass (a memset node that replays first under graph capture)
     unsigned* sync = (unsigned*)(s->QP + t2v_qp_sync_off(B));
     t2v_u64* ex = (t2v_u64*)(s->QP + t2v_qp_ex_off(B));
-    (void)hipMemsetAsync(sync, 0, 64 * sizeof(uint32_t), stream);
-    (void)hipMemsetAsync(ex, 0, sizeof(t2v_u64) * (size_t)B * 8 * t2v_tcap(T_in), stream);
+    T2VZeroRegions z;
+    z.add(sync, 64 * sizeof(uint32_t));
+    z.add(ex, sizeof(t2v_u64) * (size_t)B * 8 * t2v_tcap(T_in));
+    if (mask == 3) {    // the initial states of the pass (reference model.py:280-296 initialize_decoder_states): rows 0 of
+                        // the state arenas; row 1 of XS holds h_dec_{-1} = 0 beside fields that step 0 overwrites
+        z.add(s->XS, sizeof(float) * 2 * B * T2V_XW);
+        z.add(s->CA, sizeof(float) * B * T2V_H);
+        z.add(s->CD, sizeof(float) * B * T2V_H);
+        z.add(s->AL, sizeof(float) * B * T_in);
+        z.add(s->ACUM, sizeof(float) * B * T_in);
+    }
+    t2v_zero_regions(z, stream);
     for (int t = 0; t <= T_out; ++t) {
         if (mask & 1) {
             LstmFwdArgs a;

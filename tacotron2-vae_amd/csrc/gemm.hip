@@ -379,6 +379,34 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
     }
 }
 
+// Backward of the relu / dropout epilogue: the stored output y already carries relu and the 1/(1-p) scaling, so
+// d(pre-activation) = dy * [y != 0] * scale (reference Prenet, model.py:96-99: F.dropout(F.relu(linear(x)), p=0.5)).
+__global__ __launch_bounds__(256) void k_epilogue_bwd(const float4* __restrict__ dy, const float4* __restrict__ y,
+                                                      float4* __restrict__ out, size_t n4, float scale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 g = dy[i], v = y[i];
+    float4 o;
+    o.x = v.x != 0.f ? g.x * scale : 0.f; o.y = v.y != 0.f ? g.y * scale : 0.f;
+    o.z = v.z != 0.f ? g.z * scale : 0.f; o.w = v.w != 0.f ? g.w * scale : 0.f;
+    out[i] = o;
+}
+__global__ __launch_bounds__(256) void k_epilogue_bwd_tail(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           float* __restrict__ out, size_t lo, size_t n, float scale) {
+    const size_t i = lo + threadIdx.x;
+    if (i < n) out[i] = y[i] != 0.f ? dy[i] * scale : 0.f;
+}
+
+extern "C" int t2v_gemm_epilogue_bwd(const float* dy, const float* y, float* out, size_t n, float scale, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!dy || !y || !out || n < 1) return T2V_ERR_ARG;
+    if (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out) & 15) return T2V_ERR_ARG;
+    const size_t n4 = n / 4;
+    if (n4) k_epilogue_bwd<<<(unsigned)((n4 + 255) / 256), 256, 0, stream>>>((const float4*)dy, (const float4*)y, (float4*)out, n4, scale);
+    if (n & 3) k_epilogue_bwd_tail<<<1, 256, 0, stream>>>(dy, y, out, 4 * n4, n, scale);
+    return t2v_check_launch();
+}
+
 extern "C" int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
                              float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
                              uint64_t seed, uint32_t rng_stream, uint32_t rng_t, void* stream_) {

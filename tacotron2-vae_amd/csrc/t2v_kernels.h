@@ -10,6 +10,15 @@ enum { T2V_RNG_ATT_H = 1, T2V_RNG_ATT_C = 2, T2V_RNG_DEC_H = 3, T2V_RNG_DEC_C = 
 int t2v_check_launch();
 extern unsigned long long* g_t2v_prof;   // device buffer of 32 u64 or NULL (t2v_set_phase_profile)                 // records hipGetLastError() for t2v_last_error()
 extern const t2v_step_params* g_t2v_step;      // device-side per-step parameters or NULL (t2v_set_step_params)
+
+// several device regions (byte counts: multiples of 4) zeroed by ONE launch (t2v_runtime.hip)
+struct T2VZeroRegions {
+    void* p[10];
+    size_t bytes[10];
+    int n = 0;
+    void add(void* ptr, size_t nbytes) { p[n] = ptr; bytes[n] = nbytes; ++n; }
+};
+void t2v_zero_regions(T2VZeroRegions& z, hipStream_t stream);
 struct LstmFwdArgs;
 struct AttnFwdArgs;
 

@@ -25,3 +25,33 @@ extern "C" void t2v_set_phase_profile(unsigned long long* dev_buf32) { g_t2v_pro
 // fresh dropout masks / Adam bias corrections / KL weight — kernel arguments are frozen at capture time, memory is not.
 const t2v_step_params* g_t2v_step = nullptr;
 extern "C" void t2v_set_step_params(const t2v_step_params* dev) { g_t2v_step = dev; }
+
+// One launch that zeroes several device regions (grid.y = region): the per-pass resets of a decoder pass (initial
+// states, sync words, granule tags) cost one kernel instead of one memset node each.
+__global__ __launch_bounds__(256) void k_zero_regions(T2VZeroRegions z) {
+    const int r = blockIdx.y;
+    char* p = (char*)z.p[r];
+    const size_t nb = z.bytes[r];
+    const size_t gt = (size_t)blockIdx.x * 256 + threadIdx.x, gs = (size_t)gridDim.x * 256;
+    size_t w0 = 0;
+    if (!((uintptr_t)p & 15)) {
+        const size_t n16 = nb >> 4;
+        uint4* q = (uint4*)p;
+        const uint4 zero = {0u, 0u, 0u, 0u};
+        for (size_t i = gt; i < n16; i += gs) q[i] = zero;
+        w0 = n16 << 2;
+    }
+    uint32_t* qw = (uint32_t*)p;
+    for (size_t i = w0 + gt; i < (nb >> 2); i += gs) qw[i] = 0u;
+}
+
+void t2v_zero_regions(T2VZeroRegions& z, hipStream_t stream) {
+    size_t mx = 0;
+    int n = 0;
+    for (int i = 0; i < z.n; ++i)
+        if (z.p[i] && z.bytes[i]) { z.p[n] = z.p[i]; z.bytes[n] = z.bytes[i]; mx = z.bytes[i] > mx ? z.bytes[i] : mx; ++n; }
+    if (!n) return;
+    size_t bx = (mx + 4095) / 4096;
+    if (bx > 1024) bx = 1024;
+    k_zero_regions<<<dim3((unsigned)bx, (unsigned)n), 256, 0, stream>>>(z);
+}

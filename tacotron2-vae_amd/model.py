@@ -270,10 +270,9 @@ class Decoder(nn.Module):
         frames = self.parse_decoder_inputs(decoder_inputs)                       # (T,B,80)
         T = frames.size(0)
         x = torch.cat((self.get_go_frame(memory).unsqueeze(0), frames), 0)       # go frame first
-        pre = self.prenet(x)[:T]                                                  # (T,B,256)
+        pre = self.prenet(x[:T])        # (T,B,256); the dropout mask is indexed per element, so dropping the unused last row first changes nothing
         att = self.attention_rnn
         lin = t2v_hip.LinearHIP.apply
-        gpre = lin(pre, att.weight_ih[:, :self.prenet_dim], att.bias_ih + att.bias_hh, False, 0.0, 0, 0, 0)
         pm = lin(memory, self.attention_layer.memory_layer.weight, None, False, 0.0, 0, 0, 0)
         lengths = memory_lengths.to(device=memory.device, dtype=torch.int32)
         training = self.training
@@ -281,8 +280,11 @@ class Decoder(nn.Module):
         p_dec = self.p_decoder_dropout if training else 0.0
         self._calls += 1
         seed = (int(self.dropout_seed) * 1000003 + self._calls) & 0x7FFFFFFFFFFFFFFF
-        hc, alignments = t2v_hip.DecoderCore.apply(gpre, memory, pm, lengths, *self._core_weights(),
-                                                   p_att, p_dec, seed, torch.is_grad_enabled())
+        # the prenet term of attention_rnn's gates (pre · weight_ih[:, :256]^T + b_ih + b_hh for all steps) is computed
+        # inside the node, so weight_ih has a single gradient producer
+        hc, alignments = t2v_hip.DecoderCore.apply(None, memory, pm, lengths, *self._core_weights(),
+                                                   p_att, p_dec, seed, torch.is_grad_enabled(),
+                                                   pre, att.bias_ih, att.bias_hh)
         # linear_projection and gate_layer as ONE 81-column MFMA tile (reference model.py:385-388)
         w81 = torch.cat((self.linear_projection.weight, self.gate_layer.weight), 0)
         b81 = torch.cat((self.linear_projection.bias, self.gate_layer.bias), 0)
@@ -357,6 +359,10 @@ class Tacotron2(nn.Module):
         return outputs
 
     def forward(self, inputs):
+        with t2v_hip.defer_bn_counters():
+            return self._forward(inputs)
+
+    def _forward(self, inputs):
         text, input_lengths, targets, _, output_lengths, speakers, emotions = self.parse_input(inputs)
         if t2v_hip.step_params(create=False) is not None:
             # a training engine drives the dropout epoch through the device-side step record: the host-side call

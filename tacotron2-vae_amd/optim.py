@@ -61,6 +61,9 @@ class FlatAdam(object):
             p.grad = None
             self._grad_views.append(self.grads[o:o + p.numel()].view_as(p))
         self._view_of = {id(p): v for (_, _, p), v in zip(self._live, self._grad_views)}
+        # backward passes that know these slots write weight gradients straight into the arena (t2v_hip.grad_slot)
+        t2v_hip.register_grad_slots({p.data_ptr(): (self.grads, o, tuple(p.shape))
+                                     for (_, _, p), o in zip(self._live, offs)})
         self._gathered = False
         self._no_grad = []
         self._slot_of = {id(p): (o, p.numel()) for (_, _, p), o in zip(self._live, offs)}

@@ -58,7 +58,7 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decode
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_fuse_location_weights', 't2v_decoder_qp_floats',
            't2v_set_step_params', 't2v_decoder_replay_bwd_kernels', 't2v_embedding_fwd', 't2v_embedding_bwd', 't2v_gemm_f32_splitk', 't2v_gemm_splitk_scratch_floats',
            't2v_decoder_infer_persistent', 't2v_decoder_persist_supported', 't2v_decoder_persist_granules',
-           't2v_attn_bwd_slices')
+           't2v_attn_bwd_slices', 't2v_colsum', 't2v_colsum_scratch_floats', 't2v_gemm_epilogue_bwd')
 
 
 def lib_path():
@@ -98,6 +98,10 @@ def load_library():
                                        C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.t2v_embedding_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.t2v_embedding_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.t2v_gemm_epilogue_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]
+    lib.t2v_colsum.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.t2v_colsum_scratch_floats.argtypes = [C.c_long, C.c_long]
+    lib.t2v_colsum_scratch_floats.restype = C.c_long
     lib.t2v_set_step_params.argtypes = [C.c_void_p]
     lib.t2v_set_step_params.restype = None
     lib.t2v_mel_frontend.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,
@@ -120,7 +124,7 @@ def load_library():
     lib.t2v_conv1d_bwd_bf16.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.t2v_bn_act_fwd.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, vp]
-    lib.t2v_bn_act_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+    lib.t2v_bn_act_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                    C.c_uint64, C.c_uint32, C.c_uint32, vp]
     lib.t2v_bilstm_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.t2v_bilstm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
@@ -159,10 +163,29 @@ def note_bn_counter(t):
     _BN_PENDING.append(t)
 
 
+_BN_DEFER = [0]
+
+
 def flush_bn_counters():
-    if _BN_PENDING:
+    if _BN_PENDING and not _BN_DEFER[0]:
         torch._foreach_add_(_BN_PENDING, 1)
         del _BN_PENDING[:]
+
+
+class defer_bn_counters(object):
+    """inside this context the per-module flushes are postponed: the whole model's counters (14 BatchNorm layers) are
+    bumped by one launch when the outermost context exits"""
+
+    def __enter__(self):
+        _BN_DEFER[0] += 1
+
+    def __exit__(self, *exc):
+        _BN_DEFER[0] -= 1
+        if exc[0] is None:
+            flush_bn_counters()
+        elif not _BN_DEFER[0]:
+            del _BN_PENDING[:]
+        return False
 
 
 def set_bf16(on):
@@ -389,14 +412,15 @@ class DecoderCore(torch.autograd.Function):
         T, B, _ = gpre.shape
         T_in = memory.shape[1]
         f32 = dict(device=gpre.device, dtype=torch.float32)
-        XS = torch.empty(T + 2, B, XW, **f32); XS[0].zero_(); XS[1, :, KATT:].zero_()
-        CA = torch.empty(T + 1, B, H, **f32); CA[0].zero_()
-        CD = torch.empty(T + 1, B, H, **f32); CD[0].zero_()
+        # row 0 of the state arenas (zero initial states) is cleared by the library's one reset launch
+        XS = torch.empty(T + 2, B, XW, **f32)
+        CA = torch.empty(T + 1, B, H, **f32)
+        CD = torch.empty(T + 1, B, H, **f32)
         GA = torch.empty(T, B, G4, **f32) if need_grad else None
         GD = torch.empty(T, B, G4, **f32) if need_grad else None
         QP = torch.empty(lib.t2v_decoder_qp_floats(B, T_in), **f32)
-        AL = torch.empty(T + 1, B, T_in, **f32); AL[0].zero_()
-        ACUM = torch.empty(T + 1, B, T_in, **f32); ACUM[0].zero_()
+        AL = torch.empty(T + 1, B, T_in, **f32)
+        ACUM = torch.empty(T + 1, B, T_in, **f32)
         S = torch.empty(T, B, T_in, A, **f32) if need_grad else None
         packF_att, packF_dec, packB_att, packB_dec = packs
         W = _DecWeights(_p(packF_att), _p(packF_dec), _p(packB_att), _p(packB_dec), None, _p(bias_dec),
@@ -410,8 +434,15 @@ class DecoderCore(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, gpre, memory, pm, lengths, w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, bias_dec,
-                wq, loc_conv, loc_dense, v, p_att, p_dec, seed, grad_mode=True):
-        lib = _require_gpu(gpre, memory, pm, w_ih_att)
+                wq, loc_conv, loc_dense, v, p_att, p_dec, seed, grad_mode=True, pre=None, b_ih_att=None, b_hh_att=None):
+        lib = _require_gpu(memory, pm, w_ih_att)
+        pre2 = None
+        if pre is not None:
+            # gpre = pre · weight_ih[:, :256]^T + b_ih + b_hh computed here (gpre argument None), so attention_rnn.weight_ih
+            # has ONE gradient producer and its prenet columns are written in place by the backward
+            assert gpre is None
+            pre2 = _f32c(pre).view(-1, PRE)
+            gpre = gemm(pre2, w_ih_att.detach()[:, :PRE], (b_ih_att + b_hh_att).detach()).view(pre.shape[0], pre.shape[1], G4)
         T, B, _ = gpre.shape
         T_in = memory.shape[1]
         gpre, memory, pm = _f32c(gpre), _f32c(memory), _f32c(pm)
@@ -439,6 +470,8 @@ class DecoderCore(torch.autograd.Function):
         align = als[0] if len(als) == 1 else torch.cat(als, 0)
         ctx.dims = (B, T_in, T, float(p_att), float(p_dec), int(seed))
         ctx.consts = (packs, bias_dec, wqT, wcomb, vv, loc_conv, loc_dense)
+        ctx.wrefs = (w_ih_att, w_hh_att, w_ih_dec, w_hh_dec)
+        ctx.pre2 = pre2
         ctx.chunks = [k for _, _, k in chunks] if need_grad else None
         ctx.mark_non_differentiable(align)
         if DecoderCore.keep_last:
@@ -461,6 +494,7 @@ class DecoderCore(torch.autograd.Function):
         NS = lib.t2v_attn_bwd_slices(T_in)
         tcap = (T_in + 15) // 16 * 16
         acc = None
+        wg = None
         dga_l, dmem_l, dpm_l = [], [], []
         b0 = 0
         for keep in ctx.chunks:
@@ -494,37 +528,56 @@ class DecoderCore(torch.autograd.Function):
             x_prev = XS[0:T].reshape(TB, XW)          # [h_att_{t-1} | ctx_{t-1} | .]
             x_cur = XS[1:T + 1].reshape(TB, XW)       # [h_att_t | ctx_t | h_dec_{t-1}]
             # ... on the own large-tile MFMA GEMM (fp32) / the library bf16 GEMM under bf16_run
+            first = wg is None
+            if first:       # gradient tensors of the four nn.LSTMCell weights (arena slots when FlatAdam registered them)
+                wg = [grad_slot(w) for w in ctx.wrefs]
+                wg = [torch.empty(w.shape, **f32) if g is None else g for g, w in zip(wg, ctx.wrefs)]
+                if ctx.pre2 is None:        # the prenet columns of attention_rnn.weight_ih get their gradient via gpre
+                    wg[0][:, :PRE].zero_()
+            d_w_ih_att, d_w_hh_att, d_w_ih_dec, d_w_hh_dec = wg
             if _BF16:
                 dw_att = mm_mixed(dga2.t(), x_prev[:, :KATT])      # (4096,1536) = [dW_hh | dW_ih[:,256:]]
                 dw_dec = mm_mixed(dgd2.t(), x_cur)                 # (4096,2560) = [dW_ih | dW_hh]
-            else:
-                dw_att = gemm(dga2.t(), x_prev[:, :KATT].t())
-                dw_dec = gemm(dgd2.t(), x_cur.t())
-            d_bias_dec = dgd2.sum(0)
+                for dst, src in ((d_w_hh_att, dw_att[:, :H]), (d_w_ih_att[:, PRE:], dw_att[:, H:]),
+                                 (d_w_ih_dec, dw_dec[:, :KATT]), (d_w_hh_dec, dw_dec[:, KATT:])):
+                    if first:
+                        dst.copy_(src)
+                    else:
+                        dst.add_(src)
+            else:           # each product lands in its own tensor: no split / copy afterwards
+                gemm(dga2.t(), x_prev[:, :H].t(), out=d_w_hh_att, accumulate=not first)
+                gemm(dga2.t(), x_prev[:, H:KATT].t(), out=d_w_ih_att[:, PRE:], accumulate=not first)
+                gemm(dgd2.t(), x_cur[:, :KATT].t(), out=d_w_ih_dec, accumulate=not first)
+                gemm(dgd2.t(), x_cur[:, KATT:].t(), out=d_w_hh_dec, accumulate=not first)
+            d_bias_dec = colsum(dgd2)
             d_wq = gemm(DQ[..., 0].sum(2).view(TB, A).t(), x_cur[:, :H].t())            # (128,1024)
             d_memory = torch.empty(B, T_in, E, **f32)
             for bi in range(B):                                # per item: alpha_b^T (T_in x T) · dctx_b (T x 512)
                 gemm(AL[1:, bi].t(), DCTX[:, bi].t(), out=d_memory[bi])
             dpre = S                                   # overwritten in place by the backward kernels
-            d_pm = dpre.sum(0)
+            d_pm = colsum(dpre.view(T, B * T_in * A)).view(B, T_in, A)
             d_v = DV.sum((0, 1)).view(1, A)
             d_loc_dense, d_loc_conv = attn_wgrad(dpre, AL, ACUM, loc_conv, loc_dense, B, T_in, T)
-            parts = [dw_att, dw_dec, d_bias_dec, d_wq, d_loc_conv, d_loc_dense, d_v]
+            parts = [d_bias_dec, d_wq, d_loc_conv, d_loc_dense, d_v]
             acc = parts if acc is None else [x + y for x, y in zip(acc, parts)]
             dga_l.append(DGA); dmem_l.append(d_memory); dpm_l.append(d_pm)
             b0 += B
         ctx.chunks = None          # the arena is released as soon as the backward has consumed it
-        dw_att, dw_dec, d_bias_dec, d_wq, d_loc_conv, d_loc_dense, d_v = acc
-        d_w_hh_att = dw_att[:, :H].contiguous()
-        d_w_ih_att = torch.zeros(G4, PRE + E, **f32)
-        d_w_ih_att[:, PRE:] = dw_att[:, H:]
-        d_w_ih_dec = dw_dec[:, :KATT].contiguous()
-        d_w_hh_dec = dw_dec[:, KATT:].contiguous()
+        d_bias_dec, d_wq, d_loc_conv, d_loc_dense, d_v = acc
+        d_w_ih_att, d_w_hh_att, d_w_ih_dec, d_w_hh_dec = wg
         DGA = dga_l[0] if len(dga_l) == 1 else torch.cat(dga_l, 1)
         d_memory = dmem_l[0] if len(dmem_l) == 1 else torch.cat(dmem_l, 0)
         d_pm = dpm_l[0] if len(dpm_l) == 1 else torch.cat(dpm_l, 0)
+        d_pre = d_b_att = None
+        if ctx.pre2 is not None:    # the input projection of the prenet output, folded into this node
+            dga_all = DGA.view(T * Bt, G4)
+            if ctx.needs_input_grad[17]:
+                d_pre = gemm(dga_all, ctx.wrefs[0].detach()[:, :PRE].t()).view(T, Bt, PRE)
+            gemm(dga_all.t(), ctx.pre2.t(), out=d_w_ih_att[:, :PRE])
+            d_b_att = colsum(dga_all)
+            DGA = None
         return (DGA, d_memory, d_pm, None, d_w_ih_att, d_w_hh_att, d_w_ih_dec, d_w_hh_dec, d_bias_dec,
-                d_wq, d_loc_conv, d_loc_dense, d_v, None, None, None, None)
+                d_wq, d_loc_conv, d_loc_dense, d_v, None, None, None, None, d_pre, d_b_att, d_b_att)
 
 
 def attn_wgrad(dpre, AL, ACUM, loc_conv, loc_dense, B, T_in, T):
@@ -682,6 +735,7 @@ class ConvBNAct1d(torch.autograd.Function):
         ctx.cfg = (B, Cin, T, Cout, KS, int(act), float(p_drop if training else 0.0), int(seed), int(rng_stream),
                    int(rng_t), bool(training))
         ctx.keep = (x, w, y, mean, rstd, gamma, beta, running_mean, running_var)
+        ctx.small = (gamma, beta, bias)
         return out
 
     @staticmethod
@@ -696,12 +750,15 @@ class ConvBNAct1d(torch.autograd.Function):
             raise T2VHipError("ConvBNAct1d backward is implemented for training-mode BatchNorm only")
         dout = dout.contiguous()
         dy = torch.empty(B, Cout, T, **f32)
-        dgamma, dbeta = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
+        # d(bias) of a conv feeding a training-mode BatchNorm is identically zero (dy has zero channel mean): the BN
+        # kernel writes those zeros along with dgamma / dbeta
+        dgamma, dbeta, dbias = _small_grads(ctx.small, Cout, f32)
         _check(lib.t2v_bn_act_bwd(_p(y), _p(dout), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dy), _p(dgamma),
-                                  _p(dbeta), B, Cout, T, act, p, seed, rs, rt, _stream()), 't2v_bn_act_bwd')
+                                  _p(dbeta), _p(dbias), B, Cout, T, act, p, seed, rs, rt, _stream()), 't2v_bn_act_bwd')
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty(B, Cin, T, **f32) if need_dx else None
-        dw = torch.empty_like(w)
+        dw = grad_slot(w)
+        dw = torch.empty_like(w) if dw is None else dw
         nscr = lib.t2v_conv1d_dw_scratch_floats(B, Cin, T, Cout, KS)
         scr = torch.empty(nscr, **f32) if nscr else None
         if _BF16 and KS == 5 and Cin % 16 == 0 and Cout % 16 == 0 and Cin >= 128 and Cout >= 128:
@@ -712,8 +769,6 @@ class ConvBNAct1d(torch.autograd.Function):
             wt = torch.empty_like(w) if need_dx else None
             _check(lib.t2v_conv1d_bwd(_p(w), _p(x), _p(dy), _p(dx), _p(dw), _p(wt), _p(scr), B, Cin, T, Cout, KS,
                                       _stream()), 't2v_conv1d_bwd')
-        # d(bias) of a conv feeding a training-mode BatchNorm is identically zero (dy has zero channel mean)
-        dbias = torch.zeros(Cout, **f32)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
@@ -759,7 +814,7 @@ class BiLSTM(torch.autograd.Function):
         f32 = dict(device=x.device, dtype=torch.float32)
         x = _f32c(x)
         whh = torch.stack((w_hh, w_hh_r)).contiguous()
-        y = torch.zeros(B, T, 512, **f32)
+        y = torch.empty(B, T, 512, **f32)       # cleared by t2v_bilstm_fwd's reset launch
         bias, bias_r = b_ih + b_hh, b_ih_r + b_hh_r
         chunks = []
         for b0 in range(0, B, MAX_DEC_B):
@@ -789,11 +844,11 @@ class BiLSTM(torch.autograd.Function):
             raise T2VHipError("BiLSTM forward ran without saving activations")
         f32 = dict(device=x.device, dtype=torch.float32)
         dy = _f32c(dy)
-        dg = torch.zeros(2, B, T, 1024, **f32) if len(chunks) == 1 else None
+        dg = torch.empty(2, B, T, 1024, **f32) if len(chunks) == 1 else None     # cleared by t2v_bilstm_bwd
         dgs = []
         for b0, b1, gates, cells, sync in chunks:
             Bc = b1 - b0
-            dg_c = dg if dg is not None else torch.zeros(2, Bc, T, 1024, **f32)
+            dg_c = dg if dg is not None else torch.empty(2, Bc, T, 1024, **f32)
             dgx = torch.empty(2 * 2 * 2 * 16 * 1024, **f32)            # 8-byte granules
             _check(lib.t2v_bilstm_bwd(_p(whh), _p(lengths[b0:b1]), _p(dy[b0:b1]), _p(gates), _p(cells), _p(dg_c), _p(dgx),
                                       _p(sync), Bc, T, _stream()), 't2v_bilstm_bwd')
@@ -809,15 +864,64 @@ class BiLSTM(torch.autograd.Function):
         z = y.new_zeros(B, 1, 256)
         hp0 = torch.cat((z, y[:, :-1, :256]), 1).reshape(BT, 256)      # h_{t-1} of the forward direction
         hp1 = torch.cat((y[:, 1:, 256:], z), 1).reshape(BT, 256)       # h_{t+1} of the reverse direction
-        db0, db1 = d0.sum(0), d1.sum(0)
-        return (dx, None, gemm(d0.t(), x2.t()), gemm(d0.t(), hp0.t()), db0, db0,
-                gemm(d1.t(), x2.t()), gemm(d1.t(), hp1.t()), db1, db1, None)
+        db0, db1 = colsum(d0), colsum(d1)
+        return (dx, None, gemm(d0.t(), x2.t(), out=grad_slot(w_ih)), gemm(d0.t(), hp0.t()), db0, db0,
+                gemm(d1.t(), x2.t(), out=grad_slot(w_ih_r)), gemm(d1.t(), hp1.t()), db1, db1, None)
 
 
 def bilstm_check(sync):
     """Raises if a cooperative kernel reported a barrier timeout (forces a device sync; tests only)."""
     if int(sync[2].item()) != 0:
         raise T2VHipError("BiLSTM cooperative kernel timed out on its inter-workgroup barrier")
+
+
+def colsum(x):
+    """sum over the rows of a 2-D fp32 matrix (unit column stride): the `grad.sum(0)` of a bias, on t2v_colsum"""
+    lib = _require_gpu(x)
+    assert x.dim() == 2 and x.dtype == torch.float32
+    if x.stride(1) != 1 and x.shape[1] > 1:
+        x = x.contiguous()
+    M, N = x.shape
+    out = torch.empty(N, device=x.device, dtype=torch.float32)
+    nscr = lib.t2v_colsum_scratch_floats(M, N)
+    scr = torch.empty(nscr, device=x.device, dtype=torch.float32) if nscr else None
+    _check(lib.t2v_colsum(_p(x), x.stride(0) if M > 1 else N, M, N, _p(scr), _p(out), _stream()), 't2v_colsum')
+    return out
+
+
+# ---- gradient slots: FlatAdam keeps every parameter's gradient in one flat arena; a backward that knows the slot of
+# its weight writes the gradient GEMM straight into it (autograd then adopts the returned view as `.grad` and
+# FlatAdam.gather_grads() finds it already in place) instead of a fresh tensor that is copied into the arena later.
+_GRAD_SLOTS = {}
+
+
+def register_grad_slots(slots):
+    """slots: {param.data_ptr(): (flat grads tensor, offset, shape)}; replaces the previous registration"""
+    _GRAD_SLOTS.clear()
+    _GRAD_SLOTS.update(slots)
+
+
+def grad_slot(weight):
+    """a fresh view of the arena slot that holds d(weight), or None (= let the GEMM allocate) when no slot is
+    registered or the parameter already carries a gradient (a second backward before zero_grad must ADD to it)"""
+    if not weight.is_leaf or weight.grad is not None:
+        return None
+    ent = _GRAD_SLOTS.get(weight.data_ptr())
+    if ent is None:
+        return None
+    flat, off, shape = ent
+    if tuple(shape) != tuple(weight.shape) or flat.device != weight.device:
+        return None
+    return flat[off:off + weight.numel()].view(shape)
+
+
+def _small_grads(params, n, f32):
+    """gradient tensors for (gamma, beta, conv bias): their arena slots when registered, else one fresh tensor each"""
+    out = []
+    for p in params:
+        g = grad_slot(p) if p is not None else None
+        out.append(torch.empty(n, **f32) if g is None else g)
+    return out
 
 
 def gemm(A, B, bias=None, out=None, relu=False, accumulate=False, p_drop=0.0, seed=0, rng_stream=0, rng_t=0):
@@ -829,17 +933,21 @@ def gemm(A, B, bias=None, out=None, relu=False, accumulate=False, p_drop=0.0, se
     assert K == K2 and A.dtype == torch.float32 and B.dtype == torch.float32
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32)
-    assert out.is_contiguous() and out.shape == (M, N)
+    # `out` may be a column block of a wider row-major matrix (row stride ldc >= N): the weight-gradient GEMMs write
+    # the [weight_ih | weight_hh] halves of one product straight into their own tensors
+    assert out.shape == (M, N) and out.dtype == torch.float32 and (N == 1 or out.stride(1) == 1)
+    ldc = out.stride(0) if M > 1 else max(N, out.stride(0))
+    assert ldc >= N and (ldc == N or p_drop == 0.0)
     if not _BF16:
         nscr = lib.t2v_gemm_splitk_scratch_floats(M, N, K)
         if nscr:        # skinny deep-K product: split K over workgroups, fixed-order partial sum
             scr = torch.empty(nscr, device=A.device, dtype=torch.float32)
             _check(lib.t2v_gemm_f32_splitk(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(bias), _p(out),
-                                           N, M, N, K, int(relu), int(accumulate), float(p_drop), int(seed), int(rng_stream),
+                                           ldc, M, N, K, int(relu), int(accumulate), float(p_drop), int(seed), int(rng_stream),
                                            int(rng_t), _p(scr), _stream()), 't2v_gemm_f32_splitk')
             return out
     fn = lib.t2v_gemm_bf16 if _BF16 else lib.t2v_gemm_f32
-    _check(fn(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(bias), _p(out), N,
+    _check(fn(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(bias), _p(out), ldc,
               M, N, K, int(relu), int(accumulate), float(p_drop), int(seed), int(rng_stream),
               int(rng_t), _stream()), 't2v_gemm_bf16' if _BF16 else 't2v_gemm_f32')
     return out
@@ -863,15 +971,17 @@ class LinearHIP(torch.autograd.Function):
     def backward(ctx, dy):
         x2, weight, y = ctx.saved_tensors
         xshape, relu, p, has_bias = ctx.cfg
-        dy2 = dy.reshape(-1, weight.shape[0])
+        dy2 = _f32c(dy.reshape(-1, weight.shape[0]))
         if relu or p > 0:
             # y already carries relu and the 1/(1-p) scaling: d/dpre = dy * [y != 0] * scale
             scale = 1.0 / (1.0 - p) if p > 0 else 1.0
-            dy2 = dy2 * (y != 0).to(dy2.dtype) * scale
-        dy2 = dy2.contiguous()
+            masked = torch.empty_like(dy2)
+            _check(load_library().t2v_gemm_epilogue_bwd(_p(dy2), _p(y), _p(masked), dy2.numel(), scale, _stream()),
+                   't2v_gemm_epilogue_bwd')
+            dy2 = masked
         dx = gemm(dy2, weight.t()) if ctx.needs_input_grad[0] else None          # (N,K) = dy · W
-        dw = gemm(dy2.t(), x2.t())                                                # (M,K) = dy^T · x
-        db = dy2.sum(0) if has_bias else None
+        dw = gemm(dy2.t(), x2.t(), out=grad_slot(weight))                          # (M,K) = dy^T · x
+        db = colsum(dy2) if has_bias else None
         return (dx.view(xshape) if dx is not None else None), dw, db, None, None, None, None, None
 
 
@@ -898,6 +1008,7 @@ class Conv2dBNReLU(torch.autograd.Function):
                                   _p(rstd), _p(out), B, Cout, Ho * Wo, ACT_RELU, int(bool(training)), 0.0, 0.1, 1e-5,
                                   0, 0, 0, _stream()), 't2v_bn_act_fwd')
         ctx.keep = (x, w, y, mean, rstd, gamma, beta)
+        ctx.small = (gamma, beta, bias)
         ctx.cfg = (B, Cx, Hh, Ww, Cout, Ho, Wo, int(coord), bool(training))
         return out
 
@@ -911,16 +1022,16 @@ class Conv2dBNReLU(torch.autograd.Function):
         f32 = dict(device=x.device, dtype=torch.float32)
         dout = dout.contiguous()
         dy = torch.empty_like(y)
-        dgamma, dbeta = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
+        dgamma, dbeta, dbias = _small_grads(ctx.small, Cout, f32)
         _check(lib.t2v_bn_act_bwd(_p(y), _p(dout), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dy), _p(dgamma),
-                                  _p(dbeta), B, Cout, Ho * Wo, ACT_RELU, 0.0, 0, 0, 0, _stream()), 't2v_bn_act_bwd')
+                                  _p(dbeta), _p(dbias), B, Cout, Ho * Wo, ACT_RELU, 0.0, 0, 0, 0, _stream()), 't2v_bn_act_bwd')
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = torch.empty_like(w)
         nscr = lib.t2v_conv2d_s2_dw_scratch_floats(B, Cx, Hh, Ww, Cout, coord)
         scr = torch.empty(nscr, **f32) if nscr else None
         _check(lib.t2v_conv2d_s2_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(scr), B, Cx, Hh, Ww, Cout, coord,
                                      _stream()), 't2v_conv2d_s2_bwd')
-        return dx, dw, torch.zeros(Cout, **f32), dgamma, dbeta, None, None, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None
 
 
 class GRULast(torch.autograd.Function):
@@ -966,7 +1077,7 @@ class GRULast(torch.autograd.Function):
         dgi2, dgh2 = dgi.view(B * T, 768), dgh.view(B * T, 768)
         dx = gemm(dgi2, w_ih.t()).view(B, T, I)
         hprev = hs[:, :T].reshape(B * T, 256)
-        return dx, gemm(dgi2.t(), x2.t()), gemm(dgh2.t(), hprev.t()), dgi2.sum(0), dgh2.sum(0)
+        return dx, gemm(dgi2.t(), x2.t()), gemm(dgh2.t(), hprev.t()), colsum(dgi2), colsum(dgh2)
 
 
 class VAELoss(torch.autograd.Function):

@@ -81,3 +81,36 @@ def test_gemm_big_tile_throughput_shape():
     torch.cuda.synchronize()
     print('library GEMM same shape: %.1f TFLOP/s' % (10 * 2 * 4096 * 2400 * 2560 / (lib0.elapsed_time(lib1) * 1e-3) / 1e12))
     assert tf > 40.0
+
+
+@pytest.mark.parametrize("M,N", [(504, 1024), (2400, 4096), (400, 64512), (7, 5), (1, 300), (333, 1), (4099, 130)])
+def test_colsum_matches_torch(M, N):
+    """t2v_colsum (bias gradients, sum over decoder steps) vs a float64 column sum; strided rows too"""
+    import t2v_hip
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, N, generator=g)
+    ref = x.double().sum(0)
+    out = t2v_hip.colsum(x.cuda())
+    assert out.shape == (N,)
+    assert (out.cpu().double() - ref).abs().max() < 2e-6 * M ** 0.5 * 10 + 1e-6
+    assert torch.equal(out, t2v_hip.colsum(x.cuda()))              # fixed summation order: bit-reproducible
+    wide = torch.randn(M, N + 12, generator=g).cuda()
+    view = wide[:, 4:4 + N]                                          # row stride N + 12, base offset 16 bytes
+    assert (t2v_hip.colsum(view).cpu().double() - view.cpu().double().sum(0)).abs().max() < 2e-6 * M ** 0.5 * 10 + 1e-6
+
+
+def test_gemm_writes_column_block_of_wider_matrix():
+    """out may be a column block (row stride ldc > N): the decoder's weight-gradient GEMMs write the halves of
+    [weight_ih | weight_hh] products into their own tensors"""
+    import t2v_hip
+    g = torch.Generator().manual_seed(3)
+    A, B = torch.randn(4096, 600, generator=g), torch.randn(512, 600, generator=g)
+    big = torch.full((4096, 768), 7.0).cuda()
+    t2v_hip.gemm(A.cuda(), B.cuda(), out=big[:, 256:])
+    ref = A @ B.t()
+    assert torch.equal(big[:, :256].cpu(), torch.full((4096, 256), 7.0))
+    assert (big[:, 256:].cpu() - ref).abs().max() < 2e-4 * ref.abs().max()
+    small = torch.zeros(40, 100).cuda()
+    t2v_hip.gemm(A[:40, :64].cuda(), B[:30, :64].cuda(), out=small[:, 10:40])
+    assert (small[:, 10:40].cpu() - A[:40, :64] @ B[:30, :64].t()).abs().max() < 1e-4
+    assert float(small[:, :10].abs().max()) == 0.0 and float(small[:, 40:].abs().max()) == 0.0

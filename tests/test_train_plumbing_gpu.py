@@ -132,3 +132,42 @@ def test_bench_multi_gpu_entry_on_one_gpu():
     assert d['allreduce_exposed_ms'] >= 0.0
     names = [b[0] for b in d['allreduce_buckets_bytes']]
     assert len(names) == 4 and sum(b[1] for b in d['allreduce_buckets_bytes']) > 100e6        # 115.5 MB arena in 4 buckets
+
+
+def test_weight_gradients_land_in_the_optimizer_arena():
+    """The backward passes write the large weight gradients straight into FlatAdam's flat gradient arena
+    (t2v_hip.grad_slot), so gather_grads() has nothing to copy for them; the step is bit-identical to the one with the
+    slots unregistered (fresh gradient tensors copied into the arena afterwards)."""
+    import sys
+    import hparams as HP
+    import train as TR
+    import t2v_hip
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic_batch
+    batch = synthetic_batch(3, 20, 30, 11)
+
+    def run(with_slots):
+        hp = HP.create_hparams("batch_size=3,anneal_function=constant")
+        torch.manual_seed(hp.seed)
+        eng = TR.TrainEngine(hp, graph=False)
+        if not with_slots:
+            t2v_hip.register_grad_slots({})
+        out = [eng.step(batch, it) for it in range(2)]
+        torch.cuda.synchronize()
+        return eng, [float(o[0]) for o in out], [float(o[4]) for o in out]
+
+    eng, loss_a, gn_a = run(True)
+    opt = eng.optimizer
+    named = dict(eng.model.named_parameters())
+    in_place = 0
+    for name in ('decoder.attention_rnn.weight_hh', 'decoder.decoder_rnn.weight_ih', 'decoder.decoder_rnn.weight_hh',
+                 'decoder.attention_rnn.weight_ih', 'postnet.convolutions.1.0.conv.weight',
+                 'encoder.lstm.weight_ih_l0', 'decoder.prenet.layers.1.linear_layer.weight'):
+        p = named[name]
+        assert p.grad is not None
+        in_place += int(p.grad.data_ptr() == opt._view_of[id(p)].data_ptr())
+    assert in_place == 7, "only %d of 7 large weight gradients were written into the arena" % in_place
+    snap = opt.params.clone()
+    eng_b, loss_b, gn_b = run(False)
+    assert loss_a == loss_b and gn_a == gn_b
+    assert torch.equal(snap, eng_b.optimizer.params)
