@@ -302,6 +302,54 @@ class SymbolEmbedding(nn.Embedding):
         return t2v_hip.SymbolEmbedding.apply(ids, self.weight)       # raises T2VHipError for CPU tensors: no CPU fallback
 
 
+class BatchLayout(object):
+    """Byte layout of one collated batch (reference data_utils.py:84-128 TextMelCollate output) inside a single staging
+    buffer: (text int64, input_lengths int64, mel f32, gate f32, output_lengths int64, speakers f32, emotions f32),
+    every field 16-byte aligned.  `key` identifies the shapes (the training engine keys its captured graphs on it)."""
+    _DT = (torch.int64, torch.int64, torch.float32, torch.float32, torch.int64, torch.float32, torch.float32)
+    _ring = {}          # nbytes -> [pinned host buffers], [events], next slot
+    RING = 4
+
+    def __init__(self, batch):
+        self.max_len = int(torch.max(batch[1]).item())
+        self.fields = []
+        off = 0
+        for t, dt in zip(batch, self._DT):
+            nb = t.numel() * (8 if dt == torch.int64 else 4)
+            self.fields.append((off, nb, dt, tuple(t.shape)))
+            off += (nb + 15) & ~15
+        self.nbytes = max(off, 16)
+        self.key = tuple(f[3] for f in self.fields) + (self.max_len,)
+
+    def upload(self, batch, into=None):
+        ring = self._ring.get(self.nbytes)
+        if ring is None:
+            ring = self._ring[self.nbytes] = [[torch.empty(self.nbytes, dtype=torch.uint8).pin_memory()
+                                               for _ in range(self.RING)], [None] * self.RING, 0]
+        slot = ring[2]
+        ring[2] = (slot + 1) % self.RING
+        if ring[1][slot] is not None:
+            ring[1][slot].synchronize()        # the copy that last read this pinned slot has finished
+        host = ring[0][slot]
+        for t, (off, nb, dt, shape) in zip(batch, self.fields):
+            if nb:
+                host[off:off + nb].view(dt).view(shape).copy_(t)      # dtype conversion happens here, on the host
+        dev = into if into is not None else torch.empty(self.nbytes, dtype=torch.uint8, device='cuda')
+        assert dev.numel() == self.nbytes and dev.dtype == torch.uint8
+        dev.copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring[1][slot] = ev
+        return dev
+
+    def views(self, dev):
+        """((text, input_lengths, mel, max_len, output_lengths, speakers, emotions), (mel, gate)) over `dev`"""
+        v = [dev[off:off + nb].view(dt).view(shape) if nb else torch.empty(shape, dtype=dt, device=dev.device)
+             for off, nb, dt, shape in self.fields]
+        text, input_lengths, mel, gate, output_lengths, speakers, emotions = v
+        return ((text, input_lengths, mel, self.max_len, output_lengths, speakers, emotions), (mel, gate))
+
+
 class Tacotron2(nn.Module):
     def __init__(self, hparams):
         super().__init__()
@@ -322,13 +370,21 @@ class Tacotron2(nn.Module):
         self.postnet = Postnet(hparams)
         self.vae_gst = VAE_GST(hparams)
 
-    def parse_batch(self, batch):
+    def parse_batch(self, batch, into=None):
+        """reference model.py:486-503.  With a GPU and a host batch the seven tensors travel as ONE pinned staging
+        buffer and ONE async H2D copy (dtype conversions done on the host while packing); the returned tensors are
+        views of that device buffer.  `into` (a device uint8 buffer of BatchLayout(batch).nbytes) receives the upload
+        instead of a fresh allocation — the training engine passes the static input buffer of a captured graph."""
         text, input_lengths, mel, gate, output_lengths, speakers, emotions = batch
-        text = to_gpu(text).long()
-        speakers, emotions = to_gpu(speakers).float(), to_gpu(emotions).float()
         # max_len is read from the HOST copy: `.item()` on the device tensor (reference model.py:496) would make the
         # host wait for everything queued so far — i.e. for the previous iteration's backward — every step
+        if torch.cuda.is_available() and not any(t.is_cuda for t in batch):
+            lay = BatchLayout(batch)
+            dev = lay.upload(batch, into)
+            return lay.views(dev)
         max_len = int(torch.max(input_lengths).item())
+        text = to_gpu(text).long()
+        speakers, emotions = to_gpu(speakers).float(), to_gpu(emotions).float()
         input_lengths = to_gpu(input_lengths).long()
         mel, gate = to_gpu(mel).float(), to_gpu(gate).float()
         output_lengths = to_gpu(output_lengths).long()

@@ -19,7 +19,7 @@ import torch.distributed as dist
 import distributed as t2v_dist
 from hparams import create_hparams
 from loss_function import Tacotron2Loss_VAE
-from model import Tacotron2
+from model import BatchLayout, Tacotron2
 from optim import FlatAdam
 
 
@@ -159,16 +159,46 @@ class TrainEngine(object):
         opt = self.optimizer
         if learning_rate is not None:
             opt.param_groups[0]['lr'] = learning_rate
-        x, y = self.model.parse_batch(batch)
         w = self._publish(iteration)
-        if self.use_graph and self.model.training:
-            out = self._graph_step(x, y, iteration)
-            if out is not None:
-                return out[0], out[1], out[2], w, out[3]
+        graphable = self.use_graph and self.model.training
+        if not any(t.is_cuda for t in batch):
+            # host batch: one pinned staging buffer, one H2D copy — straight into the static input buffer of the
+            # captured graph when this shape has one
+            lay = BatchLayout(batch)
+            if graphable:
+                out = self._graph_step_staged(lay, batch, iteration)
+                if out is not None:
+                    return out[0], out[1], out[2], w, out[3]
+            x, y = lay.views(lay.upload(batch))
+        else:           # the device front end already produced device tensors
+            x, y = self.model.parse_batch(batch)
+            if graphable:
+                out = self._graph_step(x, y, iteration)
+                if out is not None:
+                    return out[0], out[1], out[2], w, out[3]
         loss, recon, kl, grad_norm = self._body(x, y, iteration)
         return loss, recon, kl, w, grad_norm
 
     # -- graph path
+    def _graph_step_staged(self, lay, batch, iteration):
+        key = ('staged',) + lay.key
+        entry = self._graphs.get(key)
+        if entry is None:
+            n = self._seen.get(key, 0)
+            self._seen[key] = n + 1
+            if n < self.GRAPH_AFTER or len(self._graphs) >= self.MAX_GRAPHS:
+                return None
+            static_buf = torch.empty(lay.nbytes, dtype=torch.uint8, device='cuda')
+            lay.upload(batch, into=static_buf)
+            x, y = lay.views(static_buf)
+            graph, out = self._capture_static(x, y, iteration)
+            entry = self._graphs[key] = (graph, static_buf, out)
+        else:
+            lay.upload(batch, into=entry[1])
+        entry[0].replay()
+        self.optimizer.step_count += 1
+        return entry[2]
+
     def _graph_step(self, x, y, iteration):
         import t2v_hip
         tensors = [t for t in x if torch.is_tensor(t)] + list(y)
@@ -194,6 +224,11 @@ class TrainEngine(object):
         static_x = tuple(t.clone() if torch.is_tensor(t) else t for t in x)
         static_y = tuple(t.clone() for t in y)
         static_in = [t for t in static_x if torch.is_tensor(t)] + list(static_y)
+        graph, out = self._capture_static(static_x, static_y, iteration)
+        return graph, static_in, out
+
+    def _capture_static(self, static_x, static_y, iteration):
+        import t2v_hip
         torch.cuda.synchronize()
         count0 = self.optimizer.step_count
         graph = torch.cuda.CUDAGraph()
@@ -201,7 +236,7 @@ class TrainEngine(object):
             out = self._body(static_x, static_y, iteration)
         self.optimizer.step_count = count0      # capture executes nothing; the replay below is this iteration's step
         t2v_hip.err_pool_pin()
-        return graph, static_in, tuple(out)
+        return graph, tuple(out)
 
 
 def prepare_directories_and_logger(output_directory, log_directory, rank):
