@@ -286,7 +286,8 @@ int t2v_colsum(const float* A, long lda, long M, long N, float* scratch, float* 
  * gx (2,B,T,1024) = X·W_ih^T + b_ih + b_hh per direction (time-batched GEMM done by the caller), whh
  * (2,1024,256).  Persistent cooperative kernels (16 workgroups, W_hh register-resident for all T steps).
  * y (B,T,512) and dg (2,B,T,1024) are cleared by the calls themselves (padded positions stay zero);
- * hx_scratch (2*2*16*256 8-byte granules = 2*2*2*16*256 floats) / dgx_scratch (2*2*2*16*1024 floats) are exchange
+ * hx_scratch (2*2*16*256 8-byte granules = 2*2*2*16*256 floats) / dgx_scratch (2*2*16*16*256 granules = 2*2*2*16*16*256
+ * floats: per direction and step parity, the 256 partial recurrent gradients x 16 items of each of 16 producers) are exchange
  * buffers of {value, step tag} granules (zeroed by the call); sync3 = 3 uint32 (zeroed by the call; sync3[2] != 0
  * afterwards means a bounded spin timed out).  gates/cells (saved
  * activations) may be NULL for inference.  B <= 16. */

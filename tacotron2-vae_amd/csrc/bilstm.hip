@@ -147,118 +147,84 @@ struct BiLstmBwdArgs {
     const float* dy;        // (B, T, 512)
     const float* gates;     // (2, B, T, 1024)
     const float* cells;     // (2, B, T, 256)
-    float* dg;              // (2, B, T, 1024) out: grad wrt gate pre-activations (pre-zeroed by caller)
-    t2v_u64* dgx;           // (2, 2, 16, 1024) granule exchange buffer, zeroed by the launcher
+    float* dg;              // (2, B, T, 1024) out: grad wrt gate pre-activations (zeroed by the launcher)
+    t2v_u64* dgx;           // (2 dirs, 2 parities, 16 producers, 16 items, 256 units) granules, zeroed by the launcher
     unsigned* sync;
     int B, T;
 };
 
-template <int BQ>
+// BPTT as a reduce-scatter: workgroup j keeps the SAME 64 gate rows of W_hh as in the forward (its 16 units x 4 gates) and
+// turns its own gate gradients of step t into the partial recurrent gradient of ALL 256 units,
+//     P_j[b][u] = sum_{r in rows of j} W_hh[r][u] * dgate[b][r]          (K = 64, on the MFMA, operands in registers)
+// and publishes the 256 x B partials as {value, step tag} granules; the consumer thread (item b, unit u) sums the 16
+// partials of its unit (fixed order) — 16 granule loads — instead of the whole workgroup pulling all 1024 x B gate
+// gradients (an all-gather) before it could start its matrix product.  Per workgroup and step: 256 B stores + 256 B
+// loads, the loads being the only round trip on the critical path.
+#define BLB_GR ((size_t)16 * 16 * BL_H)     // granules per (direction, parity)
 __global__ __launch_bounds__(256) void k_bilstm_bwd(BiLstmBwdArgs a) {
     const int dir = blockIdx.x / BL_NW, j = blockIdx.x % BL_NW;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = lane & 15, g = lane >> 4;
-    __shared__ float dgbuf[16][BL_G + 4];           // all gate gradients of the current step
-    __shared__ f32x4 red[4][BL_NT][64];
-    __shared__ float dhrec[16][BL_UNITS + 1];       // dL/dh_{prev} for this workgroup's 32 units
+    __shared__ __attribute__((aligned(16))) float dgl[16][64 + 4];      // own gate gradients [item][k = gate*16 + unit]
     __shared__ int ok_flag;
     if (tid == 0) ok_flag = 1;
-    // W_hh^T rows of this workgroup's 32 units (2 tiles of 16), K = 1024 split over the 4 waves
-    float wreg[BL_NT][64];
+    // A fragments of W_hh^T: tile tt of this wave = units 64 wave + 16 tt .. +16, k-step s covers own rows k = 4s + g
+    float wreg[4][16];
     {
         const float* W = a.whh + (size_t)dir * BL_G * BL_H;
 #pragma unroll
-        for (int tt = 0; tt < BL_NT; ++tt) {
-            const int col = j * BL_UNITS + tt * 16 + (lane & 15);       // h unit = column of W_hh
+        for (int s = 0; s < 16; ++s) {
+            const int k = 4 * s + g;
+            const int row = (k >> 4) * BL_H + j * BL_UNITS + (k & 15);
 #pragma unroll
-            for (int s = 0; s < 64; ++s) wreg[tt][s] = W[(size_t)(256 * wave + 4 * s + g) * BL_H + col];
+            for (int tt = 0; tt < 4; ++tt) wreg[tt][s] = W[(size_t)row * BL_H + 64 * wave + 16 * tt + (lane & 15)];
         }
     }
-    for (int i = tid; i < 16 * (BL_UNITS + 1); i += 256) (&dhrec[0][0])[i] = 0.f;
-    // cell-backward ownership: thread -> (item bb, unit uu) pairs, uu = tid % BL_UNITS, bb = tid / BL_UNITS (+ BL_IPP)
-    constexpr int BL_IPP = 256 / BL_UNITS, BL_REPS = 16 / BL_IPP;      // items per pass, passes
-    const int uu = tid & (BL_UNITS - 1), U = j * BL_UNITS + uu;
-    float dcrec[BL_REPS];
-#pragma unroll
-    for (int rep = 0; rep < BL_REPS; ++rep) dcrec[rep] = 0.f;
+    for (int i = tid; i < 16 * 68; i += 256) (&dgl[0][0])[i] = 0.f;
+    // cell-backward ownership: thread -> (item bb = tid / 16, unit uu = tid % 16)
+    const int uu = tid & 15, bb = tid >> 4, U = j * BL_UNITS + uu;
+    const bool live = bb < a.B;
+    const int len = live ? a.lengths[bb] : 0;
+    float dcrec = 0.f;
     __syncthreads();
 
     for (int step = a.T - 1; step >= 0; --step) {
-        t2v_u64* dgx_w = a.dgx + ((size_t)(dir * 2 + (step & 1)) * 16) * BL_G;
-        const unsigned tag = (unsigned)(a.T - step);
-#pragma unroll
-        for (int rep = 0; rep < BL_REPS; ++rep) {
-            const int bb = tid / BL_UNITS + BL_IPP * rep;
-            if (bb < a.B) {
-                const int len = a.lengths[bb];
-                float di = 0.f, df = 0.f, dgg = 0.f, dob = 0.f;
-                if (step < len) {
-                    const int t = dir == 0 ? step : len - 1 - step;
-                    const size_t idx = ((size_t)dir * a.B + bb) * a.T + t;
-                    const float* gs = a.gates + idx * BL_G + U;
-                    const float gi = gs[0], gf = gs[BL_H], gg = gs[2 * BL_H], go = gs[3 * BL_H];
-                    const float c = a.cells[idx * BL_H + U];
-                    float cprev = 0.f;
-                    if (step > 0) {
-                        const int tp = dir == 0 ? t - 1 : t + 1;
-                        cprev = a.cells[(((size_t)dir * a.B + bb) * a.T + tp) * BL_H + U];
-                    }
-                    const float dh = a.dy[((size_t)bb * a.T + t) * (2 * BL_H) + dir * BL_H + U] + dhrec[bb][uu];
-                    const float tc = tanhf_(c);
-                    const float dct = dcrec[rep] + dh * go * (1.f - tc * tc);
-                    dob = dh * tc * go * (1.f - go);
-                    di = dct * gg * gi * (1.f - gi);
-                    df = dct * cprev * gf * (1.f - gf);
-                    dgg = dct * gi * (1.f - gg * gg);
-                    dcrec[rep] = dct * gf;
-                    float* o = a.dg + idx * BL_G + U;
-                    o[0] = di; o[BL_H] = df; o[2 * BL_H] = dgg; o[3 * BL_H] = dob;
-                }
-                t2v_u64* x = dgx_w + (size_t)bb * BL_G + U;
-                bl_put(x, di, tag); bl_put(x + BL_H, df, tag); bl_put(x + 2 * BL_H, dgg, tag); bl_put(x + 3 * BL_H, dob, tag);
-            }
+        const unsigned tag = (unsigned)(a.T - step);           // tag of the partials THIS iteration publishes
+        // operands of this step's cell backward: independent of the recurrence, requested before the wait below
+        const bool on = live && step < len;
+        const int t = dir == 0 ? step : len - 1 - step;
+        const size_t idx = ((size_t)dir * a.B + (live ? bb : 0)) * a.T + (on ? t : 0);
+        float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, c = 0.f, cprev = 0.f, dyv = 0.f;
+        if (on) {
+            const float* gs = a.gates + idx * BL_G + U;
+            gi = gs[0]; gf = gs[BL_H]; gg = gs[2 * BL_H]; go = gs[3 * BL_H];
+            c = a.cells[idx * BL_H + U];
+            if (step > 0) cprev = a.cells[(((size_t)dir * a.B + bb) * a.T + (dir == 0 ? t - 1 : t + 1)) * BL_H + U];
+            dyv = a.dy[((size_t)bb * a.T + t) * (2 * BL_H) + dir * BL_H + U];
         }
-        if (step == 0) break;
-        // one wave polls a sentinel granule per (producer workgroup, item) — the last one each producing thread writes —
-        // with naps in between; the other waves stay off the memory system until the rows have landed (256 threads x 32
-        // polling loads per workgroup slowed every producer down)
-        if (wave == 0) {
-            const int nsent = BL_NW * a.B;
+        // recurrent gradient of (bb, U): the 16 partials published by iteration step + 1 (tag - 1)
+        float dhr = 0.f;
+        if (step < a.T - 1 && live) {
+            const t2v_u64* src = a.dgx + (size_t)(dir * 2 + ((step + 1) & 1)) * BLB_GR + (size_t)bb * BL_H + U;
             unsigned spins = 0;
             for (;;) {
+                t2v_u64 x[16];
+#pragma unroll
+                for (int p = 0; p < 16; ++p) x[p] = __hip_atomic_load(src + (size_t)p * 16 * BL_H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 bool ok = true;
-                for (int i = lane; i < nsent; i += 64) {
-                    const int pj = i % BL_NW, pb = i / BL_NW;
-                    const t2v_u64 x = __hip_atomic_load(dgx_w + (size_t)pb * BL_G + 3 * BL_H + pj * BL_UNITS + (BL_UNITS - 1), __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT);
-                    ok = ok && (unsigned)(x >> 32) == tag;
-                }
-                if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > BL_SPIN || __hip_atomic_load(a.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    __hip_atomic_store(a.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok_flag = 0;
+#pragma unroll
+                for (int p = 0; p < 16; ++p) ok = ok && (unsigned)(x[p] >> 32) == tag - 1u;
+                if (ok) {
+                    float v[16];
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) v[p] = __uint_as_float((unsigned)x[p]);
+#pragma unroll
+                    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+                        for (int p = 0; p < w; ++p) v[p] += v[p + w];
+                    dhr = v[0];
                     break;
                 }
-            }
-        }
-        __syncthreads();
-        if (!ok_flag) return;
-        {   // gather all gate gradients of this step (thread = gate rows tid, tid+256, .. of items 0..BQ-1)
-            unsigned spins = 0;
-            for (;;) {
-                bool ok = true;
-#pragma unroll
-                for (int u = 0; u < BQ; ++u) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const t2v_u64 x = __hip_atomic_load(dgx_w + (size_t)min(u, a.B - 1) * BL_G + 256 * q + tid, __ATOMIC_RELAXED,
-                                                            __HIP_MEMORY_SCOPE_AGENT);
-                        ok = ok && (unsigned)(x >> 32) == tag;
-                        if (u < a.B) dgbuf[u][256 * q + tid] = __uint_as_float((unsigned)x);
-                    }
-                }
-                if (ok) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > BL_SPIN || __hip_atomic_load(a.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     __hip_atomic_store(a.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -267,30 +233,45 @@ __global__ __launch_bounds__(256) void k_bilstm_bwd(BiLstmBwdArgs a) {
                 }
             }
         }
+        float di = 0.f, df = 0.f, dgg = 0.f, dob = 0.f;
+        if (on) {
+            const float dh = dyv + dhr;
+            const float tc = tanhf_(c);
+            const float dct = dcrec + dh * go * (1.f - tc * tc);
+            dob = dh * tc * go * (1.f - go);
+            di = dct * gg * gi * (1.f - gi);
+            df = dct * cprev * gf * (1.f - gf);
+            dgg = dct * gi * (1.f - gg * gg);
+            dcrec = dct * gf;
+            float* o = a.dg + idx * BL_G + U;
+            o[0] = di; o[BL_H] = df; o[2 * BL_H] = dgg; o[3 * BL_H] = dob;
+        }
+        if (live) { dgl[bb][uu] = di; dgl[bb][16 + uu] = df; dgl[bb][32 + uu] = dgg; dgl[bb][48 + uu] = dob; }
         __syncthreads();
         if (!ok_flag) return;
-        // dh_rec[b][unit] = sum_k W_hh[k][unit] * dgates[b][k]
-        f32x4 accv[BL_NT];
+        if (step == 0) break;
+        // partial recurrent gradient of all 256 units from the own 64 gate rows
+        {
+            float bop[16];
 #pragma unroll
-        for (int tt = 0; tt < BL_NT; ++tt) accv[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* drow = &dgbuf[b][256 * wave + g];
+            for (int s = 0; s < 16; ++s) bop[s] = dgl[b][4 * s + g];
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc[4];
 #pragma unroll
-        for (int s = 0; s < 64; ++s) {
-            const float dv = drow[4 * s];
+            for (int tt = 0; tt < 4; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int tt = 0; tt < BL_NT; ++tt) accv[tt] = mfma16x4(wreg[tt][s], dv, accv[tt]);
-        }
+            for (int s = 0; s < 16; ++s)
 #pragma unroll
-        for (int tt = 0; tt < BL_NT; ++tt) red[wave][tt][lane] = accv[tt];
-        __syncthreads();
-        if (wave < BL_NT) {     // wave tt finalises tile tt: lane (col = item b, rows 4g+r = units 16tt+4g+r)
-            const f32x4 s4 = red[0][wave][lane] + red[1][wave][lane] + red[2][wave][lane] + red[3][wave][lane];
+                for (int tt = 0; tt < 4; ++tt) acc[tt] = mfma16x4(wreg[tt][s], bop[s], acc[tt]);
             if (b < a.B) {
+                t2v_u64* dst = a.dgx + (size_t)(dir * 2 + (step & 1)) * BLB_GR + ((size_t)j * 16 + b) * BL_H + 64 * wave + 4 * g;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dhrec[b][16 * wave + 4 * g + r] = s4[r];
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bl_put(dst + 16 * tt + r, acc[tt][r], tag);
             }
         }
-        __syncthreads();
+        __syncthreads();        // dgl is rewritten by the next iteration
     }
 }
 
@@ -322,15 +303,12 @@ extern "C" int t2v_bilstm_bwd(const float* whh, const int32_t* lengths, const fl
         return T2V_ERR_ARG;
     T2VZeroRegions z;
     z.add(sync3, 3 * sizeof(uint32_t));
-    z.add(dgx_scratch, sizeof(t2v_u64) * 2 * 2 * 16 * BL_G);      // granule tags
+    z.add(dgx_scratch, sizeof(t2v_u64) * 2 * 2 * BLB_GR);         // granule tags
     z.add(dg, sizeof(float) * (size_t)2 * B * T * BL_G);          // padded positions carry no gradient
     t2v_zero_regions(z, stream);
     BiLstmBwdArgs a;
     a.whh = whh; a.lengths = lengths; a.dy = dy; a.gates = gates; a.cells = cells; a.dg = dg; a.dgx = (t2v_u64*)dgx_scratch;
     a.sync = sync3; a.B = B; a.T = T;
-    if (B <= 4) k_bilstm_bwd<4><<<2 * BL_NW, 256, 0, stream>>>(a);
-    else if (B <= 8) k_bilstm_bwd<8><<<2 * BL_NW, 256, 0, stream>>>(a);
-    else if (B <= 12) k_bilstm_bwd<12><<<2 * BL_NW, 256, 0, stream>>>(a);
-    else k_bilstm_bwd<16><<<2 * BL_NW, 256, 0, stream>>>(a);
+    k_bilstm_bwd<<<2 * BL_NW, 256, 0, stream>>>(a);
     return t2v_check_launch();
 }

@@ -849,7 +849,7 @@ class BiLSTM(torch.autograd.Function):
         for b0, b1, gates, cells, sync in chunks:
             Bc = b1 - b0
             dg_c = dg if dg is not None else torch.empty(2, Bc, T, 1024, **f32)
-            dgx = torch.empty(2 * 2 * 2 * 16 * 1024, **f32)            # 8-byte granules
+            dgx = torch.empty(2 * 2 * 2 * 16 * 16 * 256, **f32)        # 8-byte granules: (dir, parity, producer, item, unit)
             _check(lib.t2v_bilstm_bwd(_p(whh), _p(lengths[b0:b1]), _p(dy[b0:b1]), _p(gates), _p(cells), _p(dg_c), _p(dgx),
                                       _p(sync), Bc, T, _stream()), 't2v_bilstm_bwd')
             _err_note('BiLSTM backward', sync[2:3])
