@@ -16,32 +16,36 @@ __global__ __launch_bounds__(256) void k_embed_fwd(const long long* __restrict__
     for (int c = threadIdx.x >> 6; c < C; c += 4) out[((size_t)b * C + c) * T + t] = w[c];      // coalesced along t
 }
 
-// grid = nsym, block = 256 (thread = channels tid, tid + 256, ..): dW[v][c] = sum over positions with id v of dy[b][c][t]
+// grid = nsym, block = 256 (thread = channels tid, tid + 256, ..): dW[v][c] = sum over positions with id v of dy[b][c][t].
+// The positions holding symbol v are compacted 256 at a time in ascending order (wave ballot + prefix over the four
+// waves), so the summation order is fixed.
 __global__ __launch_bounds__(256) void k_embed_bwd(const long long* __restrict__ ids, const float* __restrict__ dy,
                                                    float* __restrict__ dW, int B, int T, int C) {
-    const int v = blockIdx.x;
-    __shared__ int hits[1024];
-    __shared__ int nhit;
+    const int v = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    __shared__ int hits[256];
+    __shared__ int wcount[4];
+    const int n = B * T;
     for (int c0 = 0; c0 < C; c0 += 512) {
         float acc0 = 0.f, acc1 = 0.f;
-        for (int p0 = 0; p0 < B * T; p0 += 1024) {       // compact the matching positions of this chunk (ascending order)
+        const int c = c0 + tid;
+        for (int p0 = 0; p0 < n; p0 += 256) {
+            __syncthreads();                                  // hits / wcount of the previous chunk fully consumed
+            const int p = p0 + tid;
+            const bool hit = p < n && ids[p] == v;
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) wcount[wave] = __popcll(m);
             __syncthreads();
-            if (threadIdx.x == 0) {
-                int n = 0;
-                const int hi = min(B * T, p0 + 1024);
-                for (int p = p0; p < hi; ++p)
-                    if (ids[p] == v) hits[n++] = p;
-                nhit = n;
-            }
+            int base = 0;
+            for (int w = 0; w < wave; ++w) base += wcount[w];
+            if (hit) hits[base + __popcll(m & ((1ull << lane) - 1ull))] = p;
+            const int nhit = wcount[0] + wcount[1] + wcount[2] + wcount[3];
             __syncthreads();
             for (int i = 0; i < nhit; ++i) {
-                const int p = hits[i], b = p / T, t = p - b * T;
-                const int c = c0 + threadIdx.x;
+                const int q = hits[i], b = q / T, t = q - b * T;
                 if (c < C) acc0 += dy[((size_t)b * C + c) * T + t];
                 if (c + 256 < C) acc1 += dy[((size_t)b * C + c + 256) * T + t];
             }
         }
-        const int c = c0 + threadIdx.x;
         if (c < C) dW[(size_t)v * C + c] = acc0;
         if (c + 256 < C) dW[(size_t)v * C + c + 256] = acc1;
     }
