@@ -10,3 +10,10 @@ ST=$(find /tmp/prof_$TAG -name '*kernel_stats.csv' | head -1); KT=$(find /tmp/pr
 cp "$ST" $REPO/gpurun_out/${TAG}_bench_kernel_stats.csv
 python $REPO/tools/steady_profile.py "$KT" 6 45 > $REPO/gpurun_out/${TAG}_steady_state.txt
 cd $REPO
+# the same trace with eager launches (rocprofv3's per-kernel tracing stalls graph replays for ~1 ms every few dozen nodes,
+# so the graph-mode trace overstates the idle time; GPU-busy time per kernel is unaffected)
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_eager -o ${TAG}e -- python $REPO/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-decode --no-secondary --no-graph > /tmp/prof_bench_${TAG}_eager.log 2>&1
+KT=$(find /tmp/prof_${TAG}_eager -name '*kernel_trace.csv' | head -1)
+python $REPO/tools/steady_profile.py "$KT" 6 45 > $REPO/gpurun_out/${TAG}_steady_state_eager.txt
+cd $REPO
