@@ -5,7 +5,7 @@
 #include "t2v_common.h"
 #include "t2v_kernels.h"
 
-// grid = (ceil(T/64), B), block = 256: thread = (position t = 64 bx + (tid & 63), channel group cg = tid >> 6)
+// grid = (ceil(T/64), B, channel slices), block = 256: thread = (position t = 64 bx + (tid & 63), channel group cg = tid >> 6)
 __global__ __launch_bounds__(256) void k_embed_fwd(const long long* __restrict__ ids, const float* __restrict__ W,
                                                    float* __restrict__ out, int T, int C, int nsym) {
     const int b = blockIdx.y, t = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -13,7 +13,9 @@ __global__ __launch_bounds__(256) void k_embed_fwd(const long long* __restrict__
     long long id = ids[(size_t)b * T + t];
     id = id < 0 ? 0 : (id >= nsym ? nsym - 1 : id);
     const float* w = W + (size_t)id * C;
-    for (int c = threadIdx.x >> 6; c < C; c += 4) out[((size_t)b * C + c) * T + t] = w[c];      // coalesced along t
+    // grid.z slices the channels (12 workgroups for the whole table took 21 us: one long serial loop per thread)
+    const int cper = (C + gridDim.z - 1) / gridDim.z, c_lo = blockIdx.z * cper, c_hi = min(C, c_lo + cper);
+    for (int c = c_lo + (threadIdx.x >> 6); c < c_hi; c += 4) out[((size_t)b * C + c) * T + t] = w[c];      // coalesced along t
 }
 
 // grid = nsym, block = 256 (thread = channels tid, tid + 256, ..): dW[v][c] = sum over positions with id v of dy[b][c][t].
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const long long* __restrict__
 extern "C" int t2v_embedding_fwd(const long long* ids, const float* W, float* out_bct, int B, int T, int C, int n_symbols,
                                  void* stream_) {
     if (!ids || !W || !out_bct || B < 1 || T < 1 || C < 1 || n_symbols < 1) return T2V_ERR_ARG;
-    k_embed_fwd<<<dim3((T + 63) / 64, B), 256, 0, (hipStream_t)stream_>>>(ids, W, out_bct, T, C, n_symbols);
+    k_embed_fwd<<<dim3((T + 63) / 64, B, C >= 64 ? 16 : 1), 256, 0, (hipStream_t)stream_>>>(ids, W, out_bct, T, C, n_symbols);
     return t2v_check_launch();
 }
 
