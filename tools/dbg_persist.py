@@ -41,3 +41,6 @@ if steps > 101:
           % (v[1]-v[0], v[2]-v[1], v[3]-v[2], v[4]-v[3], v[5]-v[4], v[6]-v[5], v[7]-v[6], v[8]-v[7], v[8]-v[0]))
     print('wg64 (projection) frame 100: to stage 3 %d | stage 3 (ctx hop + dec_rnn) %d | h_dec hop + projection %d' % (v[11]-v[10], v[12]-v[11], v[13]-v[12]))
     print('wg128 (Prenet 1) frame 100: to stage 5 %d | pre0 hop + layer 1 %d' % (v[15]-v[14], v[16]-v[15]))
+    if steps > 601 and v[23] > v[21]:
+        print('500 frames = %d shader cycles = %.1f us on the 100 MHz wall clock  =>  %.2f GHz, %.2f us per frame' % (
+            v[22] - v[20], (v[23] - v[21]) / 100.0, (v[22] - v[20]) / ((v[23] - v[21]) * 10.0), (v[23] - v[21]) / 100.0 / 500))
