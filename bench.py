@@ -266,7 +266,8 @@ def run_workload(args, world, rank, bf16, koemo, steps, warmup, graph):
     frames = (sum(koemo_out) if koemo else bpg * T_OUT) * world      # koemo: valid (unpadded) frames, like the metric
     ms = 1000.0 * elapsed / steps
     res = {"value": round(frames / (elapsed / steps), 1), "ms_per_step": round(ms, 3), "frames_per_step": frames,
-           "final_loss": round(final_loss, 5), "step_mode": "hip-graph replay" if engine.use_graph else "eager launches",
+           "final_loss": round(final_loss, 5), "step_mode": ("hip-graph replay of forward + backward, then one eager all-reduce and the fused clip + Adam"
+                         if getattr(engine, 'graph_ddp', False) else "hip-graph replay") if engine.use_graph else "eager launches",
            "startup_steps": startup, "batch_per_gpu": bpg}
     if engine.allreduce is not None:
         res["allreduce_exposed_ms"] = round(engine.allreduce.exposed_ms(), 3)

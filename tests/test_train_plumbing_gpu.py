@@ -121,17 +121,23 @@ def test_bench_multi_gpu_entry_on_one_gpu():
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--launch', '--force-dist', '--steps', '3',
-                          '--warmup', '1', '--no-cpu-baseline', '--no-decode', '--no-secondary'],
-                         capture_output=True, text=True, timeout=600, env=env)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
-    d = json.loads(line)
-    assert d['n_gpus'] == 1 and d['rccl_ranks'] == 1 and d['value'] > 0
-    assert d['config']['step_mode'] == 'eager launches'               # the all-reduce path runs eagerly
-    assert d['allreduce_exposed_ms'] >= 0.0
-    names = [b[0] for b in d['allreduce_buckets_bytes']]
-    assert len(names) == 4 and sum(b[1] for b in d['allreduce_buckets_bytes']) > 100e6        # 115.5 MB arena in 4 buckets
+    res = {}
+    for mode, extra in (('graph', []), ('eager', ['--no-graph'])):
+        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--launch', '--force-dist', '--steps', '3',
+                              '--warmup', '1', '--settle', '2', '--no-cpu-baseline', '--no-decode', '--no-secondary'] + extra,
+                             capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
+        d = res[mode] = json.loads(line)
+        assert d['n_gpus'] == 1 and d['rccl_ranks'] == 1 and d['value'] > 0
+        assert d['allreduce_exposed_ms'] >= 0.0
+        names = [b[0] for b in d['allreduce_buckets_bytes']]
+        assert len(names) == 4 and sum(b[1] for b in d['allreduce_buckets_bytes']) > 100e6    # 115.5 MB arena in 4 buckets
+    # multi-rank default: forward + backward replay as one graph, one eager all-reduce of the arena, eager clip + Adam
+    assert res['graph']['config']['step_mode'].startswith('hip-graph replay of forward + backward')
+    # --no-graph: bucketed all-reduce issued from the backward hooks
+    assert res['eager']['config']['step_mode'] == 'eager launches'
+    assert res['graph']['config']['startup_steps'] != res['eager']['config']['startup_steps']
 
 
 def test_weight_gradients_land_in_the_optimizer_arena():
