@@ -416,8 +416,20 @@ def main():
                                                     "sample": "ONE timed step, no warm-up, every host core"}
         print(json.dumps(out))
     if dist.is_initialized():
+        # orderly teardown of a rank: captured graphs and their arenas go first, then the communicator; the process then
+        # leaves without running the remaining library destructors (HIP graph / RCCL teardown order at interpreter exit
+        # aborted one run in a few with exit code -6 AFTER the result line had been printed)
+        import gc
+        torch.cuda.synchronize()
         dist.barrier()
+        t2v_hip.DecoderCore.last_call = t2v_hip.DecoderCore.last_bwd = None
+        del engine
+        gc.collect()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == '__main__':

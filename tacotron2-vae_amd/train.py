@@ -263,7 +263,12 @@ class TrainEngine(object):
         torch.cuda.synchronize()
         count0 = self.optimizer.step_count
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=self._stream):
+        # with a process group alive its watchdog thread polls events while this thread captures: under the default
+        # 'global' error mode such a query from ANOTHER thread aborts the process now and then (seen as exit code -6 in
+        # one of five runs); 'thread_local' restricts the check to this thread — the launches of the autograd worker
+        # thread are still captured (capture follows the stream, not the thread)
+        mode = 'thread_local' if self.allreduce is not None else 'global'
+        with torch.cuda.graph(graph, stream=self._stream, capture_error_mode=mode):
             out = (self._body_fb if self.graph_ddp else self._body)(static_x, static_y, iteration)
         self.optimizer.step_count = count0      # capture executes nothing; the replay below is this iteration's step
         t2v_hip.err_pool_pin()
