@@ -109,28 +109,15 @@ __device__ __forceinline__ void pd_gather(float* dst, const t2v_u64* src, int n,
 
 // LSTM gate rows of this workgroup for one cell: lane = (row r = lane>>2 (unit r>>2, gate r&3), kq = lane&3), wave = K
 // eighth; weights wreg[j] <-> logical k = wave*KW + 4j + kq.  Partial dot products -> red[wave][r][b].
-// Plain map (decoder_rnn): weights wreg[j] <-> logical k = wave*KW + 4j + kq.
-// Split map (attention_rnn, PSPLIT = 1536): every wave owns an eighth of the [h_att | ctx] columns AND an eighth of the
-// Prenet columns — wreg[j], j < JS <-> k = wave*(PSPLIT/8) + 4j + kq; j >= JS <-> k = PSPLIT + wave*((K-PSPLIT)/8) + 4(j-JS) + kq —
-// so that either part alone is spread over all eight waves.  PART 0: whole row, 1: k < PSPLIT only, 2: k >= PSPLIT only.
-template <int NJ, int PSPLIT>
-__device__ __forceinline__ int pd_kmap(int wave, int j, int kq) {
-    if (PSPLIT == 0) return wave * (4 * NJ) + 4 * j + kq;
-    constexpr int JS = PSPLIT / 32;
-    return j < JS ? wave * (PSPLIT / 8) + 4 * j + kq : PSPLIT + wave * ((32 * NJ - PSPLIT) / 8) + 4 * (j - JS) + kq;
-}
-template <int NJ, int KSPLIT, int PART = 0, int PSPLIT = 0>   // NJ = K/32 weights per lane; KSPLIT: logical k >= KSPLIT sits 256 further in the LDS row
+template <int NJ, int KSPLIT>   // NJ = K/32 weights per lane; KSPLIT: logical k >= KSPLIT sits 256 further in the LDS row
 __device__ __forceinline__ void pd_gemv(const float (&wreg)[NJ], const float* X, int B, float* red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kq = lane & 3, r = lane >> 2;
-    constexpr int JS = PSPLIT / 32;
-    static_assert(PSPLIT % 64 == 0 && (PART == 0 || PSPLIT > 0), "the split must fall on a weight-pair boundary");
-    constexpr int J0 = PART == 2 ? JS : 0, J1 = PART == 1 ? JS : NJ;
     for (int b = 0; b < B; ++b) {
         const float* xb = X + (size_t)b * PD_XW;
         float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
-        for (int j = J0; j < J1; j += 2) {
-            const int k0 = pd_kmap<NJ, PSPLIT>(wave, j, kq), k1 = pd_kmap<NJ, PSPLIT>(wave, j + 1, kq);
+        for (int j = 0; j < NJ; j += 2) {
+            const int k0 = wave * (4 * NJ) + 4 * j + kq, k1 = k0 + 4;
             acc0 = fmaf(wreg[j], xb[k0 + (k0 >= KSPLIT ? 256 : 0)], acc0);
             acc1 = fmaf(wreg[j + 1], xb[k1 + (k1 >= KSPLIT ? 256 : 0)], acc1);
         }
@@ -149,8 +136,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
     const int Tcap = (Tp + 15) & ~15, TW = Tcap + 32;
     float* X = lds;                                      // [B][2816]
     float* red = X + B * PD_XW;                          // [8][16][MAXB]
-    float* reda = red + 8 * 16 * PD_MAXB;                // [8][16][MAXB] early partial sums of attention_rnn(t+1)
-    float* gst = reda + 8 * 16 * PD_MAXB;                // [MAXB][16] gate pre-activations
+    float* gst = red + 8 * 16 * PD_MAXB;                 // [MAXB][16] gate pre-activations
     float* cst = gst + PD_MAXB * 16;                     // [2][MAXB][4] cell states (attention_rnn, decoder_rnn)
     int* flag = (int*)(cst + 2 * PD_MAXB * 4);           // [4]
     float* role = (float*)(flag + 4);                    // role area
@@ -184,7 +170,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
     float wa[PD_KATT / 32], wd[PD_KDEC / 32];
 #pragma unroll
     for (int j = 0; j < PD_KATT / 32; ++j) {
-        const int k = pd_kmap<PD_KATT / 32, T2V_KATT>(wave, j, kq);      // [h_att | ctx | pre1], split map
+        const int k = wave * (PD_KATT / 8) + 4 * j + kq;                // [h_att | ctx | pre1]
         wa[j] = k < T2V_H ? a.w_hh_att[(size_t)grow * T2V_H + k]
                           : (k < T2V_KATT ? a.w_ih_att[(size_t)grow * 768 + T2V_PRE + (k - T2V_H)] : a.w_ih_att[(size_t)grow * 768 + (k - T2V_KATT)]);
     }
@@ -276,25 +262,14 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             if (flag[0] != 1) return;                          // stopped on the gate (2) or timed out (0)
         }
         PD_STAMP(0, 0); PD_STAMP(64, 10); PD_STAMP(128, 14);
-        if (a.prof && wg == 0 && tid == 0 && (t == 100 || t == 600)) {      // clock calibration: shader cycles vs the 100 MHz wall clock
-            a.prof[t == 100 ? 20 : 22] = __builtin_readcyclecounter();
-            a.prof[t == 100 ? 21 : 23] = wall_clock64();
-        }
         // ---- 1. attention_rnn(t): gates of this workgroup's 4 units, cell update, publish h_att
-        // (frames > 0: the [h_att | ctx] columns were summed at the end of the previous frame, while the projection /
-        // Prenet chain was running: only the 256 Prenet columns are left on the critical path)
-        if (t == 0) pd_gemv<PD_KATT / 32, PD_KATT, 0, T2V_KATT>(wa, X, B, red);      // K contiguous in the LDS row: no split offset
-        else pd_gemv<PD_KATT / 32, PD_KATT, 2, T2V_KATT>(wa, X, B, red);
+        pd_gemv<PD_KATT / 32, PD_KATT>(wa, X, B, red);        // K contiguous in the LDS row: no split offset
         __syncthreads();
         if (tid < 16 * B) {                                    // thread = (row r = tid & 15, item b = tid >> 4)
             const int r = tid & 15, b = tid >> 4;
             float s = 0.f;
 #pragma unroll
             for (int w8 = 0; w8 < 8; ++w8) s += red[(w8 * 16 + r) * PD_MAXB + b];
-            if (t > 0) {
-#pragma unroll
-                for (int w8 = 0; w8 < 8; ++w8) s += reda[(w8 * 16 + r) * PD_MAXB + b];
-            }
             gst[b * 16 + r] = s + __shfl(bias_a, r, 64);       // pre-activation where the unit's thread finds its four gates
         }
         __syncthreads();
@@ -307,31 +282,6 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             pd_put(xcur + pd_hatt(B) + (size_t)b * 1024 + 4 * wg + u, go * tanhf_(c), tag);
         }
         PD_STAMP(0, 1);
-        // location features of this slice's position tiles: they depend on the previous frame's alignment only, so they
-        // are evaluated while h_att(t) of the other workgroups is still in flight
-        f32x4 lacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        if (is_attn) {
-            const int g = lane >> 4, c16 = lane & 15;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int jt = wave + 8 * i;
-                if (16 * jt < Tp) {
-                    float bop[16];
-#pragma unroll
-                    for (int st = 0; st < 16; ++st) {
-                        const int kk = 4 * st + g;
-                        bop[st] = win[(kk >> 5) * TW + 16 * jt + c16 + (kk & 31)];
-                    }
-                    f32x4 l0 = {0.f, 0.f, 0.f, 0.f}, l1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int st = 0; st < 16; st += 2) {
-                        l0 = mfma16x4(areg[st], bop[st], l0);
-                        l1 = mfma16x4(areg[st + 1], bop[st + 1], l1);
-                    }
-                    lacc[i] = l0 + l1;
-                }
-            }
-        }
         // ---- 2. h_att(t) for everyone (attention slices need it now, the others for decoder_rnn)
         for (int b = 0; b < B; ++b)
             pd_gather<2>(X + (size_t)b * PD_XW + PD_X_HA, xcur + pd_hatt(B) + (size_t)b * 1024, 1024, tag, a.err, flag);
@@ -366,7 +316,19 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             for (int i = 0; i < 2; ++i) {
                 const int jt = wave + 8 * i;
                 if (16 * jt < Tp) {
-                    const f32x4 acc = lacc[i];
+                    float bop[16];
+#pragma unroll
+                    for (int st = 0; st < 16; ++st) {
+                        const int kk = 4 * st + g;
+                        bop[st] = win[(kk >> 5) * TW + 16 * jt + c16 + (kk & 31)];
+                    }
+                    f32x4 l0 = {0.f, 0.f, 0.f, 0.f}, l1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int st = 0; st < 16; st += 2) {
+                        l0 = mfma16x4(areg[st], bop[st], l0);
+                        l1 = mfma16x4(areg[st + 1], bop[st + 1], l1);
+                    }
+                    const f32x4 acc = l0 + l1;
                     const int j = 16 * jt + c16;
                     const float4 pm4 = *(const float4*)(pm_s + min(j, Tp - 1) * 16 + 4 * g);
                     const float s0 = tanhf_(q4.x + acc[0] + pm4.x), s1 = tanhf_(q4.y + acc[1] + pm4.y);
@@ -472,9 +434,6 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             pd_put(xcur + pd_hdec(B) + (size_t)b * 1024 + 4 * wg + u, go * tanhf_(c), tag);
         }
         PD_STAMP(0, 7); PD_STAMP(64, 12);
-        // attention_rnn(t+1), recurrent columns [h_att_t | ctx_t]: everything it needs is in X already, and this workgroup
-        // would otherwise idle until the projection -> Prenet chain delivers the next frame's Prenet output
-        if (!wg_proj) pd_gemv<PD_KATT / 32, PD_KATT, 1, T2V_KATT>(wa, X, B, reda);
         // ---- 4. projection rows (mel, gate, folded Prenet layer 0)
         if (prow >= 0) {            // whole workgroup takes the branch: barriers inside are uniform
             for (int b = 0; b < B; ++b)
@@ -511,7 +470,6 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                 }
             }
             __syncthreads();        // X[HD] now holds h_dec(t): the next frame's decoder_rnn input for this workgroup
-            pd_gemv<PD_KATT / 32, PD_KATT, 1, T2V_KATT>(wa, X, B, reda);      // (the chain goes first in these workgroups)
         }
         PD_STAMP(64, 13); PD_STAMP(128, 15);
         // ---- 5. Prenet layer 1 rows
@@ -554,7 +512,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
 
 static size_t pd_lds_bytes(int B, int T_in) {
     const size_t Tcap = (size_t)((T_in + 15) / 16) * 16;
-    size_t f = (size_t)B * PD_XW + 2 * 8 * 16 * PD_MAXB + PD_MAXB * 16 + 2 * PD_MAXB * 4 + 4;
+    size_t f = (size_t)B * PD_XW + 8 * 16 * PD_MAXB + PD_MAXB * 16 + 2 * PD_MAXB * 4 + 4;
     const size_t attn = 16 * 1028 + Tcap * 64 + Tcap * 16 + 2 * (Tcap + 32) + Tcap + 16 + 32 * 16 + 8 * 64 + 64;
     const size_t proj = 8 * 1536;
     f += attn > proj ? attn : proj;
