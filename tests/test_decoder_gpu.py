@@ -37,7 +37,9 @@ def _oracle(dec, memory, mels, lengths, wm, wg):
                                                # beyond the round-1 limits: koemo reaches 555 symbols (reference is
                                                # unbounded, model.py:67-88); batches > 16 run as chunks
                                                (2, 300, 4, [300, 211]), (2, 555, 3, [555, 290]), (1, 257, 2, [257]),
-                                               (20, 33, 3, list(range(33, 13, -1))), (2, 1000, 2, [1000, 700])])
+                                               (20, 33, 3, list(range(33, 13, -1))), (2, 1000, 2, [1000, 700]),
+                                               # very short texts: fewer positions than one 16-position tile / one position
+                                               (2, 5, 3, [5, 1]), (1, 1, 2, [1]), (2, 16, 2, [16, 15])])
 def test_decoder_core_matches_oracle(B, T_in, T_out, lens):
     hp, M, dec, memory, mels, lengths, wm, wg = _setup(B, T_in, T_out, lens)
     o_mel, o_gate, o_align, o_sd, o_mem = _oracle(dec, memory, mels, lengths, wm, wg)
@@ -63,7 +65,9 @@ def test_decoder_core_matches_oracle(B, T_in, T_out, lens):
         assert p.grad is not None, name
         d = (p.grad.cpu() - og).abs().max().item()
         s = og.abs().max().item()
-        rel = d / (s + 1e-6)
+        # a tensor whose reference gradient is identically zero (T_in = 1: the softmax over one position is constant, so
+        # nothing flows into the query / memory / location weights) is compared absolutely (< 2e-6): fp32 round-off of ~1e-7
+        rel = d / (s + 1e-6) if s > 0 else d / 1e-3
         worst = max(worst, rel)
         assert rel < 2e-3, (name, d, s)
     dm = (mem.grad.cpu() - o_mem.grad).abs().max().item() / (o_mem.grad.abs().max().item() + 1e-6)
