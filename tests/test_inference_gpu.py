@@ -152,3 +152,30 @@ def test_cfg4_decode_800_steps_matches_oracle():
         assert (mel.cpu() - o_mel).abs().max() < 5e-4 and (mel.cpu() - o_mel).abs().mean() < 1e-4
     finally:
         M.drop_rate = old
+
+
+@pytest.mark.parametrize("T_in,B", [(1, 1), (3, 1), (16, 2), (224, 1), (225, 1)])
+def test_short_and_limit_texts_both_decode_paths_agree(model, T_in, B):
+    """Free-running decode at the edges of the persistent kernel's range (one symbol; one 16-position tile; T_in = 224 is
+    its LDS limit, 225 falls back to the launch-per-stage path): persistent == launch-per-stage == oracle."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+    import t2v_oracle as O
+    g = torch.Generator().manual_seed(100 + T_in)
+    memory = (torch.randn(B, T_in, 512, generator=g) * 0.5).cuda()
+    dec = model.decoder
+    old_thr = dec.gate_threshold
+    dec.gate_threshold = 1.0                                        # never stop: all 24 frames
+    try:
+        with torch.no_grad():
+            mel_a, gate_a, al_a = dec.inference(memory, persistent=False)
+            mel_b, gate_b, al_b = dec.inference(memory)             # persistent when supported
+    finally:
+        dec.gate_threshold = old_thr
+    assert mel_a.shape == mel_b.shape == (B, 80, 24)
+    assert (mel_a - mel_b).abs().max() < 2e-5 and (gate_a - gate_b).abs().max() < 2e-5
+    assert (al_a - al_b).abs().max() < 2e-6
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    o_mel, o_gate, o_al = O.decoder_inference(sd, memory.cpu(), max_steps=24, stop_on_gate=False)
+    assert (mel_b.cpu() - o_mel).abs().max() < 2e-4
+    assert (al_b.cpu() - o_al).abs().max() < 2e-5
