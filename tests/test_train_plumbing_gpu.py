@@ -177,3 +177,23 @@ def test_weight_gradients_land_in_the_optimizer_arena():
     eng_b, loss_b, gn_b = run(False)
     assert loss_a == loss_b and gn_a == gn_b
     assert torch.equal(snap, eng_b.optimizer.params)
+
+
+@pytest.mark.parametrize("B,T_in,T_out", [(1, 7, 9), (2, 1, 3), (3, 130, 5)])
+def test_engine_step_tiny_and_odd_shapes(B, T_in, T_out):
+    """whole optimiser steps on shapes far from the benchmark's: one utterance, one symbol, odd lengths"""
+    import sys
+    import hparams as HP
+    import train as TR
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic_batch
+    hp = HP.create_hparams("batch_size=%d,anneal_function=constant" % B)
+    torch.manual_seed(hp.seed)
+    eng = TR.TrainEngine(hp, graph=False)
+    batch = synthetic_batch(B, T_in, T_out, 3)
+    out = [eng.step(batch, it) for it in range(2)]
+    torch.cuda.synchronize()
+    import t2v_hip
+    t2v_hip.check_async_errors()
+    for o in out:
+        assert torch.isfinite(o[0]).item() and torch.isfinite(o[4]).all().item()
