@@ -55,6 +55,12 @@ void t2v_set_step_params(const t2v_step_params* dev);
 int t2v_pack_lstm_weights(const float* w_ih_att, const float* w_hh_att, const float* w_ih_dec,
                           const float* w_hh_dec, int k_att, float* packF_att, float* packF_dec,
                           float* packB_att, float* packB_dec, void* stream);
+/* bf16_run: the same tiles with every weight rounded to bf16 (RNE), 8 bytes per lane and k-block instead of 16: the two
+ * per-step LSTM kernels then stream 33.5 MB instead of 67 MB and multiply bf16-rounded states on
+ * v_mfma_f32_16x16x16_bf16 (fp32 accumulation, fp32 cell state, fp32 saved activations).  Same buffer sizes or half. */
+int t2v_pack_lstm_weights_bf16(const float* w_ih_att, const float* w_hh_att, const float* w_ih_dec,
+                               const float* w_hh_dec, int k_att, void* packF_att, void* packF_dec,
+                               void* packB_att, void* packB_dec, void* stream);
 
 /* LocationLayer (model.py:12-28) is a bias-free conv followed by a bias-free linear layer, i.e. ONE linear map of the
  * 2 x 31 alignment window: W_comb[d][32c + k] = sum_f loc_dense[d][f] * loc_conv[f][c][k] (128 x 64; k < 31, columns
@@ -75,6 +81,7 @@ typedef struct t2v_dec_weights {
     const float* wqT;         /* (1024,128) query_layer weight, transposed (model.py:35) */
     const float* wcomb;       /* (2,128,64) fused location filter bank (t2v_fuse_location_weights; model.py:17-22) */
     const float* v;           /* (128)      attention v (model.py:39) */
+    int32_t packs_bf16;       /* != 0: the four packs came from t2v_pack_lstm_weights_bf16 (hparams bf16_run) */
 } t2v_dec_weights;
 
 /* Saved-activation arena of one teacher-forced decoder pass (caller allocates; t2v_decoder_train_fwd clears the rows

@@ -5,6 +5,7 @@
 //   k_cell_bwd : LSTM cell backward for attention_rnn(t) and decoder_rnn(t-1)
 // Weight gradients are NOT accumulated here: the saved per-step pre-activation gradients
 // (DGA, DGD, DQ, dpre, DC, DCTX) feed time-batched GEMMs after the loop.
+#include <type_traits>
 #include "t2v_common.h"
 #include "t2v_kernels.h"
 
@@ -17,7 +18,9 @@
 // Four-wave version of k_lstm_bwd (same finding as for the forward stream: ~64 KB in flight per CU beats 16 waves
 // with everything in flight): wave v walks k-blocks [64v, 64v+64) of its tile in 8 rounds of 8 (W, k) float4
 // pairs, two rounds in flight, alternating direction per launch.
+template <bool WBF>       // WBF: bf16 packs (uint2 per lane and k-block), one 16x16x16 bf16 MFMA per block
 __global__ __launch_bounds__(256) void k_lstm_bwd256(LstmBwdArgs a) {
+    typedef typename std::conditional<WBF, uint2, float4>::type wt_t;
     const int w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = lane & 15, g = lane >> 4;
     const bool dec = w < T2V_XW / 16;
@@ -26,11 +29,12 @@ __global__ __launch_bounds__(256) void k_lstm_bwd256(LstmBwdArgs a) {
     if (!kv) return;   // block-uniform
     const bool bvalid = b < a.B;
     __shared__ f32x4 red[4][64];
-    const float4* p = (dec ? a.packBD : a.packBA) + (size_t)wt * 256 * 64 + lane;   // tile-major: + kb * 64
+    const wt_t* p = (const wt_t*)(dec ? a.packBD : a.packBA) + (size_t)wt * 256 * 64 + lane;   // tile-major: + kb * 64
     const float* xrow = kv + (size_t)(bvalid ? b : 0) * T2V_G + 4 * g;        // lanes b>=B read row 0 (unused D columns)
     const int kb0 = 64 * wave, flip = a.flip;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    float4 wv[2][8], xv[2][8];
+    wt_t wv[2][8];
+    float4 xv[2][8];
 #define B256_LOAD(H)                                                                          \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                           \
         const int kb = flip ? kb0 + 63 - (8 * (H) + i) : kb0 + 8 * (H) + i;                   \
@@ -44,7 +48,7 @@ __global__ __launch_bounds__(256) void k_lstm_bwd256(LstmBwdArgs a) {
         if (h + 1 < 8) { B256_LOAD(h + 1) }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { MFMA4(acc, wv[h & 1][i], xv[h & 1][i]); }
+        for (int i = 0; i < 8; ++i) mfma_block(acc, wv[h & 1][i], xv[h & 1][i]);
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef B256_LOAD
@@ -476,7 +480,10 @@ static int launch_train_bwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
             l.YA = g->YA;
             l.B = B;
             l.flip = t & 1;
-            if (mask & 1) k_lstm_bwd256<<<T2V_NWG, 256, 0, stream>>>(l);
+            if (mask & 1) {
+                if (w->packs_bf16) k_lstm_bwd256<true><<<T2V_NWG, 256, 0, stream>>>(l);
+                else k_lstm_bwd256<false><<<T2V_NWG, 256, 0, stream>>>(l);
+            }
 
             AttnBwdArgs f;
             f.dHC_t = g->dHC + (size_t)t * B * HC;

@@ -4,6 +4,7 @@
 //   k_attn_fwd : location-sensitive attention of step t (query sum, location conv + dense,
 //                tanh/v energies, masked softmax, context).
 // Reference semantics: Decoder.decode model.py:346-389, Attention.forward model.py:67-88.
+#include <type_traits>
 #include "t2v_common.h"
 #include "t2v_kernels.h"
 
@@ -25,7 +26,8 @@ struct WSrc {
 // Forward tile w (16 rows = 4 units x 4 gates, unit-major):
 //   P[w][kb][lane][i] = W[(lane&3)*H + 4w + ((lane&15)>>2)][16kb + 4(lane>>4) + i]
 // so one float4 per lane feeds four v_mfma_f32_16x16x4_f32 A operands (k = 16kb+4g+i, i=0..3).
-__global__ void k_pack_fwd(WSrc W, int K, float4* __restrict__ P) {
+template <bool BF16>
+__global__ void k_pack_fwd(WSrc W, int K, void* __restrict__ Pv) {
     const int nkb = K / 16;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // float4 index
     const size_t total = (size_t)T2V_NWG * nkb * 64;
@@ -35,12 +37,15 @@ __global__ void k_pack_fwd(WSrc W, int K, float4* __restrict__ P) {
     const int w = (idx >> 6) / nkb;          // 96/112/160 KiB region (tile stride is NOT a power of
     const int arow = lane & 15, g = lane >> 4;   // two, so L2/HBM channels are evenly loaded)
     const int row = (arow & 3) * T2V_H + 4 * w + (arow >> 2);
-    P[idx] = *(const float4*)W.at(row, 16 * kb + 4 * g);
+    const float4 v = *(const float4*)W.at(row, 16 * kb + 4 * g);
+    if (BF16) ((uint2*)Pv)[idx] = t2v_pack_bf16x4(v);
+    else ((float4*)Pv)[idx] = v;
 }
 // Backward (transposed) tile n-tile w' of W^T (N = K columns of W become rows), reduction dim
 // = 4096 gate rows, tile-major like the forward pack (a workgroup's 256 KB are contiguous):
 //   PB[w'][kb][lane][i] = W[16kb + 4(lane>>4) + i][16w' + (lane&15)]
-__global__ void k_pack_bwd(WSrc W, int ncols, float4* __restrict__ P) {
+template <bool BF16>
+__global__ void k_pack_bwd(WSrc W, int ncols, void* __restrict__ Pv) {
     const int nkb = T2V_G / 16;   // 256
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)(ncols / 16) * nkb * 64;
@@ -50,7 +55,9 @@ __global__ void k_pack_bwd(WSrc W, int ncols, float4* __restrict__ P) {
     const int wt = (idx >> 6) / nkb;
     const int n = 16 * wt + (lane & 15);
     const int k0 = 16 * kb + 4 * (lane >> 4);
-    P[idx] = make_float4(*W.at(k0 + 0, n), *W.at(k0 + 1, n), *W.at(k0 + 2, n), *W.at(k0 + 3, n));
+    const float4 v = make_float4(*W.at(k0 + 0, n), *W.at(k0 + 1, n), *W.at(k0 + 2, n), *W.at(k0 + 3, n));
+    if (BF16) ((uint2*)Pv)[idx] = t2v_pack_bf16x4(v);
+    else ((float4*)Pv)[idx] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -59,11 +66,13 @@ __global__ void k_pack_bwd(WSrc W, int ncols, float4* __restrict__ P) {
     ACC = mfma16x4((WV).y, (XV).y, ACC);    \
     ACC = mfma16x4((WV).z, (XV).z, ACC);    \
     ACC = mfma16x4((WV).w, (XV).w, ACC)
+#define MFMAW(ACC, WV, XV) mfma_block(ACC, WV, XV)
 
 // ------------------------------------------------------------------------------------------
-extern "C" int t2v_pack_lstm_weights(const float* w_ih_att, const float* w_hh_att, const float* w_ih_dec,
-                                     const float* w_hh_dec, int k_att, float* packF_att, float* packF_dec,
-                                     float* packB_att, float* packB_dec, void* stream_) {
+template <bool BF16>
+static int pack_lstm_weights_impl(const float* w_ih_att, const float* w_hh_att, const float* w_ih_dec,
+                                  const float* w_hh_dec, int k_att, float* packF_att, float* packF_dec,
+                                  float* packB_att, float* packB_dec, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!w_ih_att || !w_hh_att || !w_ih_dec || !w_hh_dec || !packF_att || !packF_dec) return T2V_ERR_ARG;
     if (k_att != T2V_KATT && k_att != T2V_KATT_INF) return T2V_ERR_DIMS;
@@ -77,21 +86,33 @@ extern "C" int t2v_pack_lstm_weights(const float* w_ih_att, const float* w_hh_at
     D.p[2] = w_hh_dec; D.ld[2] = T2V_H;    D.off[2] = 0; D.end[2] = T2V_XW;
     {
         const size_t n = (size_t)T2V_NWG * (k_att / 16) * 64;
-        k_pack_fwd<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(A, k_att, (float4*)packF_att);
+        k_pack_fwd<BF16><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(A, k_att, packF_att);
     }
     {
         const size_t n = (size_t)T2V_NWG * (T2V_XW / 16) * 64;
-        k_pack_fwd<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(D, T2V_XW, (float4*)packF_dec);
+        k_pack_fwd<BF16><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(D, T2V_XW, packF_dec);
     }
     if (packB_att) {   // only the recurrent 1536 columns matter for the data gradient
         const size_t n = (size_t)(T2V_KATT / 16) * 256 * 64;
-        k_pack_bwd<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(A, T2V_KATT, (float4*)packB_att);
+        k_pack_bwd<BF16><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(A, T2V_KATT, packB_att);
     }
     if (packB_dec) {
         const size_t n = (size_t)(T2V_XW / 16) * 256 * 64;
-        k_pack_bwd<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(D, T2V_XW, (float4*)packB_dec);
+        k_pack_bwd<BF16><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(D, T2V_XW, packB_dec);
     }
     return t2v_check_launch();
+}
+
+extern "C" int t2v_pack_lstm_weights(const float* w_ih_att, const float* w_hh_att, const float* w_ih_dec,
+                                     const float* w_hh_dec, int k_att, float* packF_att, float* packF_dec,
+                                     float* packB_att, float* packB_dec, void* stream_) {
+    return pack_lstm_weights_impl<false>(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, k_att, packF_att, packF_dec, packB_att, packB_dec, stream_);
+}
+extern "C" int t2v_pack_lstm_weights_bf16(const float* w_ih_att, const float* w_hh_att, const float* w_ih_dec,
+                                          const float* w_hh_dec, int k_att, void* packF_att, void* packF_dec,
+                                          void* packB_att, void* packB_dec, void* stream_) {
+    return pack_lstm_weights_impl<true>(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, k_att, (float*)packF_att, (float*)packF_dec,
+                                        (float*)packB_att, (float*)packB_dec, stream_);
 }
 
 // Training step: FOUR waves per workgroup (tools/ubench_gemv_tiles.hip: for this 67 MB
@@ -99,10 +120,14 @@ extern "C" int t2v_pack_lstm_weights(const float* w_ih_att, const float* w_hh_at
 // Workgroup w = gate-row tile w of BOTH cells; wave v walks attention_rnn k-blocks [24v, 24v+24) then decoder_rnn
 // k-blocks [40v, 40v+40): 8 rounds of 8 (W, x) float4 pairs, two rounds in flight; odd steps walk the same
 // sequence backwards (the tail of the previous launch's stream is requested first).  Epilogue as k_lstm_fwd.
-template <bool FLIP>
-__device__ __forceinline__ void lstm256_stream(const float4* pa, const float4* pd, const float* xrow, int wave,
+template <bool FLIP, bool WBF>       // WBF: the packs hold bf16 (uint2 per lane and k-block), one 16x16x16 bf16 MFMA per block
+__device__ __forceinline__ void lstm256_stream(const float4* pa4, const float4* pd4, const float* xrow, int wave,
                                                f32x4& accA, f32x4& accD) {
-    float4 wv[2][8], xv[2][8];
+    typedef typename std::conditional<WBF, uint2, float4>::type wt_t;
+    const wt_t* pa = (const wt_t*)pa4;
+    const wt_t* pd = (const wt_t*)pd4;
+    wt_t wv[2][8];
+    float4 xv[2][8];
     // round r of the walk: FLIP ? 7 - r : r;  rounds 0..2 = attention_rnn, 3..7 = decoder_rnn
 #define L256_LOAD(R)                                                                              \
     {                                                                                             \
@@ -118,8 +143,8 @@ __device__ __forceinline__ void lstm256_stream(const float4* pa, const float4* p
     {                                                                                             \
         constexpr int RR = FLIP ? 7 - (R) : (R);                                                  \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                           \
-            if (RR < 3) { MFMA4(accA, wv[(R) & 1][i], xv[(R) & 1][i]); }                          \
-            else { MFMA4(accD, wv[(R) & 1][i], xv[(R) & 1][i]); }                                 \
+            if (RR < 3) { MFMAW(accA, wv[(R) & 1][i], xv[(R) & 1][i]); }                          \
+            else { MFMAW(accD, wv[(R) & 1][i], xv[(R) & 1][i]); }                                 \
         }                                                                                         \
     }
 #define L256_STEP(R, NEXT)                      \
@@ -142,6 +167,7 @@ __device__ __forceinline__ void lstm256_stream(const float4* pa, const float4* p
 #undef L256_LOAD
 }
 
+template <bool WBF>
 __global__ __launch_bounds__(256) void k_lstm_fwd256(LstmFwdArgs a) {
     const uint64_t seed = t2v_step_seed(a.seed, a.step);
     const int w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -149,8 +175,11 @@ __global__ __launch_bounds__(256) void k_lstm_fwd256(LstmFwdArgs a) {
     const bool bvalid = b < a.B;
     __shared__ f32x4 red[2][4][64];
     __shared__ float hs[16][4];
-    const float4* pa = a.packA + ((size_t)w * (T2V_KATT / 16)) * 64 + lane;
-    const float4* pd = a.packD + ((size_t)w * (T2V_XW / 16)) * 64 + lane;
+    // element = one lane's share of one k-block: float4 (fp32 packs) or uint2 (bf16 packs); same element indexing
+    const float4* pa = WBF ? (const float4*)((const uint2*)a.packA + ((size_t)w * (T2V_KATT / 16)) * 64 + lane)
+                           : a.packA + ((size_t)w * (T2V_KATT / 16)) * 64 + lane;
+    const float4* pd = WBF ? (const float4*)((const uint2*)a.packD + ((size_t)w * (T2V_XW / 16)) * 64 + lane)
+                           : a.packD + ((size_t)w * (T2V_XW / 16)) * 64 + lane;
     const float* xrow = a.xs_prev + (size_t)(bvalid ? b : 0) * T2V_XW + 4 * g;   // lanes b>=B read row 0 (unused D columns)
     // tail operands first: waves 0/1 own the cell update of attention_rnn(t) / decoder_rnn(t-1) for (unit g, item b)
     const int which = wave;
@@ -169,8 +198,8 @@ __global__ __launch_bounds__(256) void k_lstm_fwd256(LstmFwdArgs a) {
         wqr[0] = wq[0]; wqr[1] = wq[T2V_A]; wqr[2] = wq[2 * T2V_A]; wqr[3] = wq[3 * T2V_A];
     }
     f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accD = {0.f, 0.f, 0.f, 0.f};
-    if (a.t & 1) lstm256_stream<true>(pa, pd, xrow, wave, accA, accD);
-    else lstm256_stream<false>(pa, pd, xrow, wave, accA, accD);
+    if (a.t & 1) lstm256_stream<true, WBF>(pa, pd, xrow, wave, accA, accD);
+    else lstm256_stream<false, WBF>(pa, pd, xrow, wave, accA, accD);
     red[0][wave][lane] = accA;
     red[1][wave][lane] = accD;
     __syncthreads();
@@ -342,7 +371,8 @@ static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
         if (mask & 1) {
             LstmFwdArgs a;
             fill_lstm_args(a, w, s, B, T_out, t, p_att, p_dec, seed);
-            k_lstm_fwd256<<<T2V_NWG, 256, 0, stream>>>(a);
+            if (w->packs_bf16) k_lstm_fwd256<true><<<T2V_NWG, 256, 0, stream>>>(a);
+            else k_lstm_fwd256<false><<<T2V_NWG, 256, 0, stream>>>(a);
         }
         if (t < T_out && (mask & 2)) {
             AttnFwdArgs f;

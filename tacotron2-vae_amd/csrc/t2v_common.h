@@ -26,6 +26,29 @@ __device__ __forceinline__ f32x4 mfma16x4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// bf16 weight streams of the decoder LSTM kernels (hparams bf16_run): a lane's four consecutive k of a 16x16x16 tile.
+// v_mfma_f32_16x16x16_bf16: lane l holds A[l&15][4(l>>4)+i], B[4(l>>4)+i][l&15], i = 0..3 — the same (row, k) ownership as
+// four steps of the fp32 16x16x4 tile, so the bf16 packs are the fp32 packs rounded element by element (RNE).
+typedef short t2v_s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 t2v_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned t2v_pack_bf16x2(float lo, float hi) {
+    t2v_bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return *(unsigned*)&v;
+}
+__device__ __forceinline__ uint2 t2v_pack_bf16x4(float4 v) { return make_uint2(t2v_pack_bf16x2(v.x, v.y), t2v_pack_bf16x2(v.z, v.w)); }
+__device__ __forceinline__ f32x4 mfma16x16_bf16(uint2 a, uint2 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*(const t2v_s16x4*)&a, *(const t2v_s16x4*)&b, c, 0, 0, 0);
+}
+
+// one k-block of 16 of a 16x16 tile: four fp32 MFMA steps, or one bf16 MFMA on the rounded operands
+__device__ __forceinline__ void mfma_block(f32x4& acc, const float4& wv, const float4& xv) {
+    acc = mfma16x4(wv.x, xv.x, acc); acc = mfma16x4(wv.y, xv.y, acc);
+    acc = mfma16x4(wv.z, xv.z, acc); acc = mfma16x4(wv.w, xv.w, acc);
+}
+__device__ __forceinline__ void mfma_block(f32x4& acc, const uint2& wv, const float4& xv) {
+    acc = mfma16x16_bf16(wv, t2v_pack_bf16x4(xv), acc);
+}
+
 // exp via v_exp_f32 (2^x, ~1 ulp) and v_rcp_f32: absolute error of sigmoid/tanh ~1e-7, which is
 // what the fp32 parity budget (mel-L1 < 1e-4 through 400 recurrent steps) needs; far cheaper
 // than the libm tanhf/expf call sequences.

@@ -86,7 +86,7 @@ struct AttnFwdArgs {
 };
 
 struct LstmBwdArgs {
-    const float4* packBD;   // 160 tiles
+    const float4* packBD;   // 160 tiles (uint2 per lane and k-block when the packs are bf16)
     const float4* packBA;   // 96 tiles
     const float* dgd_t;     // DGD[t]   (B,4096)
     const float* dga_n;     // DGA[t+1] (B,4096) or NULL

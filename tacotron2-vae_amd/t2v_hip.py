@@ -22,7 +22,8 @@ class T2VHipError(RuntimeError):
 
 class _DecWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        'packF_att', 'packF_dec', 'packB_att', 'packB_dec', 'bias_att', 'bias_dec', 'wqT', 'wcomb', 'v')]
+        'packF_att', 'packF_dec', 'packB_att', 'packB_dec', 'bias_att', 'bias_dec', 'wqT', 'wcomb', 'v')] + [
+        ('packs_bf16', C.c_int32)]
 
 
 class _DecTrainBufs(C.Structure):
@@ -52,7 +53,7 @@ class _DecInferBufs(C.Structure):
         'prenet_w1', 'proj_w', 'proj_b')]
 
 
-EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_decoder_train_fwd',
+EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_pack_lstm_weights_bf16', 't2v_decoder_train_fwd',
            't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_conv1d_dw_scratch_floats', 't2v_gemm_bf16', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
            't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats',
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_fuse_location_weights', 't2v_decoder_qp_floats',
@@ -77,6 +78,8 @@ def load_library():
     lib.t2v_version.restype = C.c_char_p
     lib.t2v_last_error.restype = C.c_char_p
     lib.t2v_pack_lstm_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.t2v_pack_lstm_weights_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.t2v_fuse_location_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.t2v_decoder_qp_floats.argtypes = [C.c_int, C.c_int]
@@ -367,8 +370,9 @@ def replay_bwd_kernels(kernel_mask):
     return T if kernel_mask == 1 else T + 1
 
 
-def pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, k_att, need_bwd):
-    """MFMA-fragment tiles of the two decoder LSTM cells, read straight from the nn.LSTMCell tensors."""
+def pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, k_att, need_bwd, bf16=False):
+    """MFMA-fragment tiles of the two decoder LSTM cells, read straight from the nn.LSTMCell tensors.  bf16=True
+    (bf16_run, training pass): the same tiles rounded to bf16 — the per-step kernels stream half the bytes."""
     lib = load_library()
     dev = w_ih_att.device
     f32 = dict(device=dev, dtype=torch.float32)
@@ -377,9 +381,9 @@ def pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, k_att, need_bwd
     packF_dec = torch.empty(G4 * XW, **f32)
     packB_att = torch.empty(G4 * KATT, **f32) if need_bwd else None
     packB_dec = torch.empty(G4 * XW, **f32) if need_bwd else None
-    _check(lib.t2v_pack_lstm_weights(_p(w_ih_att), _p(w_hh_att), _p(w_ih_dec), _p(w_hh_dec), int(k_att),
-                                     _p(packF_att), _p(packF_dec), _p(packB_att), _p(packB_dec), _stream()),
-           't2v_pack_lstm_weights')
+    fn = lib.t2v_pack_lstm_weights_bf16 if bf16 else lib.t2v_pack_lstm_weights
+    _check(fn(_p(w_ih_att), _p(w_hh_att), _p(w_ih_dec), _p(w_hh_dec), int(k_att),
+              _p(packF_att), _p(packF_dec), _p(packB_att), _p(packB_dec), _stream()), 't2v_pack_lstm_weights')
     return packF_att, packF_dec, packB_att, packB_dec
 
 
@@ -408,7 +412,7 @@ class DecoderCore(torch.autograd.Function):
     keep_last = False       # bench / tests: keep the (first chunk's) arena of the last forward for replays
 
     @staticmethod
-    def _fwd_chunk(lib, gpre, memory, pm, lengths, packs, bias_dec, wqT, wcomb, vv, need_grad, p_att, p_dec, seed):
+    def _fwd_chunk(lib, gpre, memory, pm, lengths, packs, bias_dec, wqT, wcomb, vv, need_grad, p_att, p_dec, seed, wbf=False):
         T, B, _ = gpre.shape
         T_in = memory.shape[1]
         f32 = dict(device=gpre.device, dtype=torch.float32)
@@ -424,7 +428,7 @@ class DecoderCore(torch.autograd.Function):
         S = torch.empty(T, B, T_in, A, **f32) if need_grad else None
         packF_att, packF_dec, packB_att, packB_dec = packs
         W = _DecWeights(_p(packF_att), _p(packF_dec), _p(packB_att), _p(packB_dec), None, _p(bias_dec),
-                        _p(wqT), _p(wcomb), _p(vv))
+                        _p(wqT), _p(wcomb), _p(vv), int(bool(wbf)))
         Sb = _DecTrainBufs(_p(gpre), _p(memory), _p(pm), _p(lengths), _p(XS), _p(CA), _p(CD), _p(GA), _p(GD),
                            _p(QP), _p(AL), _p(ACUM), _p(S))
         _check(lib.t2v_decoder_train_fwd(C.byref(W), C.byref(Sb), B, T_in, T, float(p_att), float(p_dec),
@@ -449,7 +453,8 @@ class DecoderCore(torch.autograd.Function):
         # grad_mode = torch.is_grad_enabled() of the CALLER (inside Function.forward it is always False): under
         # no_grad (validate(), inference) nothing is saved and the backward-only buffers are not even allocated
         need_grad = bool(grad_mode) and any(ctx.needs_input_grad)
-        packs = pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, KATT, need_grad)
+        wbf = bool(_BF16)
+        packs = pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, KATT, need_grad, bf16=wbf)
         wqT = wq.detach().t().contiguous()
         bias_dec = _f32c(bias_dec.detach())
         loc_conv, loc_dense, vv = _f32c(loc_conv.detach()), _f32c(loc_dense.detach()), _f32c(v.detach()).view(-1)
@@ -463,13 +468,14 @@ class DecoderCore(torch.autograd.Function):
                 g_c, m_c, pm_c = gpre[:, b0:b1].contiguous(), memory[b0:b1].contiguous(), pm[b0:b1].contiguous()
                 l_c = None if lengths is None else lengths[b0:b1].contiguous()
             chunks.append(DecoderCore._fwd_chunk(lib, g_c, m_c, pm_c, l_c, packs, bias_dec, wqT, wcomb, vv, need_grad,
-                                                 p_att, p_dec, (int(seed) + 7919 * b0) & 0x7FFFFFFFFFFFFFFF))
+                                                 p_att, p_dec, (int(seed) + 7919 * b0) & 0x7FFFFFFFFFFFFFFF, wbf))
         hcs = [torch.cat((k[4][2:T + 2, :, KATT:], k[4][1:T + 1, :, H:KATT]), 2) for _, _, k in chunks]
         als = [k[10][1:].permute(1, 0, 2) for _, _, k in chunks]
         HC = hcs[0] if len(hcs) == 1 else torch.cat(hcs, 1)
         align = als[0] if len(als) == 1 else torch.cat(als, 0)
         ctx.dims = (B, T_in, T, float(p_att), float(p_dec), int(seed))
         ctx.consts = (packs, bias_dec, wqT, wcomb, vv, loc_conv, loc_dense)
+        ctx.wbf = wbf
         ctx.wrefs = (w_ih_att, w_hh_att, w_ih_dec, w_hh_dec)
         ctx.pre2 = pre2
         ctx.chunks = [k for _, _, k in chunks] if need_grad else None
@@ -510,7 +516,7 @@ class DecoderCore(torch.autograd.Function):
             GPREV = torch.empty(2, B, NS, 2, 64, **f32); GCUM = torch.empty(B * NS * tcap + 64, **f32)
             DV = torch.empty(B, NS, A, **f32)
             W = _DecWeights(_p(packF_att), _p(packF_dec), _p(packB_att), _p(packB_dec), None, _p(bias_dec),
-                            _p(wqT), _p(wcomb), _p(vv))
+                            _p(wqT), _p(wcomb), _p(vv), int(bool(ctx.wbf)))
             Sb = _DecTrainBufs(_p(gpre), _p(memory), _p(pm), _p(lengths), _p(XS), _p(CA), _p(CD), _p(GA), _p(GD),
                                _p(QP), _p(AL), _p(ACUM), _p(S))
             Gb = _DecBwdBufs(_p(dhc_c), _p(DGA), _p(DGD), _p(DQ), _p(DCTX), _p(YD), _p(YA), _p(DCA),

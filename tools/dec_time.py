@@ -7,6 +7,8 @@ import ctypes as C
 import torch, t2v_hip as H, hparams as HP, model as M
 B, T_in, T = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (6, 84, 400)))
 lib = H.load_library()
+if os.environ.get('T2V_BF16'):
+    H.set_bf16(True)      # bf16_run: bf16 weight streams in the two per-step LSTM kernels
 hp = HP.create_hparams(); torch.manual_seed(0)
 dec = M.Decoder(hp).cuda().train()
 mem = (torch.randn(B, T_in, 512, device='cuda') * 0.5).requires_grad_(True)
