@@ -55,9 +55,10 @@ void t2v_set_step_params(const t2v_step_params* dev);
 int t2v_pack_lstm_weights(const float* w_ih_att, const float* w_hh_att, const float* w_ih_dec,
                           const float* w_hh_dec, int k_att, float* packF_att, float* packF_dec,
                           float* packB_att, float* packB_dec, void* stream);
-/* bf16_run: the same tiles with every weight rounded to bf16 (RNE), 8 bytes per lane and k-block instead of 16: the two
- * per-step LSTM kernels then stream 33.5 MB instead of 67 MB and multiply bf16-rounded states on
- * v_mfma_f32_16x16x16_bf16 (fp32 accumulation, fp32 cell state, fp32 saved activations).  Same buffer sizes or half. */
+/* bf16_run: the same tiles with every weight rounded to bf16 (RNE), laid out in 32-column blocks (16 bytes = 8 values per
+ * lane and block: lane l of a 16-row tile holds columns 32 kb + 8 (l >> 4) .. + 8): the two per-step LSTM kernels then
+ * stream 33.5 MB instead of 67 MB with HALF the weight-load instructions and multiply bf16-rounded states on
+ * v_mfma_f32_16x16x32_bf16 (fp32 accumulation, fp32 cell state, fp32 saved activations).  Same buffer sizes or half. */
 int t2v_pack_lstm_weights_bf16(const float* w_ih_att, const float* w_hh_att, const float* w_ih_dec,
                                const float* w_hh_dec, int k_att, void* packF_att, void* packF_dec,
                                void* packB_att, void* packB_dec, void* stream);

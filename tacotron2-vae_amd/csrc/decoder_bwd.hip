@@ -41,6 +41,31 @@ __global__ __launch_bounds__(256) void k_lstm_bwd256(LstmBwdArgs a) {
         wv[(H) & 1][i] = p[(size_t)kb * 64];                                                  \
         xv[(H) & 1][i] = *(const float4*)(xrow + 16 * kb);                                    \
     }
+    if constexpr (WBF) {
+        // bf16 packs: 128 blocks of 32 rows per tile, wave v walks [32v, 32v+32) in 8 rounds of 4, two rounds in flight
+        const uint4* p8 = (const uint4*)(dec ? a.packBD : a.packBA) + (size_t)wt * 128 * 64 + lane;
+        const float* xrow8 = kv + (size_t)(bvalid ? b : 0) * T2V_G + 8 * g;
+        uint4 w8[2][4];
+        float4 x8[2][8];
+#define B8_LOAD(H)                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+        const int jb = flip ? 32 * wave + 31 - (4 * (H) + i) : 32 * wave + 4 * (H) + i;       \
+        w8[(H) & 1][i] = p8[(size_t)jb * 64];                                                 \
+        x8[(H) & 1][2 * i] = *(const float4*)(xrow8 + 32 * jb);                               \
+        x8[(H) & 1][2 * i + 1] = *(const float4*)(xrow8 + 32 * jb + 4);                       \
+    }
+        B8_LOAD(0)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            if (h + 1 < 8) { B8_LOAD(h + 1) }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = mfma16x32_bf16(w8[h & 1][i], x8[h & 1][2 * i], x8[h & 1][2 * i + 1], acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef B8_LOAD
+    } else {
     B256_LOAD(0)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -50,6 +75,7 @@ __global__ __launch_bounds__(256) void k_lstm_bwd256(LstmBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) mfma_block(acc, wv[h & 1][i], xv[h & 1][i]);
         __builtin_amdgcn_sched_barrier(0);
+    }
     }
 #undef B256_LOAD
     red[wave][lane] = acc;

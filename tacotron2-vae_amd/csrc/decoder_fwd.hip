@@ -28,8 +28,8 @@ struct WSrc {
 // so one float4 per lane feeds four v_mfma_f32_16x16x4_f32 A operands (k = 16kb+4g+i, i=0..3).
 template <bool BF16>
 __global__ void k_pack_fwd(WSrc W, int K, void* __restrict__ Pv) {
-    const int nkb = K / 16;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // float4 index
+    const int nkb = BF16 ? K / 32 : K / 16;     // bf16 packs: 32-column blocks, 8 values (one uint4) per lane
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // element index
     const size_t total = (size_t)T2V_NWG * nkb * 64;
     if (idx >= total) return;
     const int lane = idx & 63;
@@ -37,16 +37,18 @@ __global__ void k_pack_fwd(WSrc W, int K, void* __restrict__ Pv) {
     const int w = (idx >> 6) / nkb;          // 96/112/160 KiB region (tile stride is NOT a power of
     const int arow = lane & 15, g = lane >> 4;   // two, so L2/HBM channels are evenly loaded)
     const int row = (arow & 3) * T2V_H + 4 * w + (arow >> 2);
-    const float4 v = *(const float4*)W.at(row, 16 * kb + 4 * g);
-    if (BF16) ((uint2*)Pv)[idx] = t2v_pack_bf16x4(v);
-    else ((float4*)Pv)[idx] = v;
+    if (BF16) {
+        ((uint4*)Pv)[idx] = t2v_pack_bf16x8(*(const float4*)W.at(row, 32 * kb + 8 * g), *(const float4*)W.at(row, 32 * kb + 8 * g + 4));
+    } else {
+        ((float4*)Pv)[idx] = *(const float4*)W.at(row, 16 * kb + 4 * g);
+    }
 }
 // Backward (transposed) tile n-tile w' of W^T (N = K columns of W become rows), reduction dim
 // = 4096 gate rows, tile-major like the forward pack (a workgroup's 256 KB are contiguous):
 //   PB[w'][kb][lane][i] = W[16kb + 4(lane>>4) + i][16w' + (lane&15)]
 template <bool BF16>
 __global__ void k_pack_bwd(WSrc W, int ncols, void* __restrict__ Pv) {
-    const int nkb = T2V_G / 16;   // 256
+    const int nkb = BF16 ? T2V_G / 32 : T2V_G / 16;   // 128 / 256
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)(ncols / 16) * nkb * 64;
     if (idx >= total) return;
@@ -54,10 +56,14 @@ __global__ void k_pack_bwd(WSrc W, int ncols, void* __restrict__ Pv) {
     const int kb = (idx >> 6) % nkb;
     const int wt = (idx >> 6) / nkb;
     const int n = 16 * wt + (lane & 15);
-    const int k0 = 16 * kb + 4 * (lane >> 4);
-    const float4 v = make_float4(*W.at(k0 + 0, n), *W.at(k0 + 1, n), *W.at(k0 + 2, n), *W.at(k0 + 3, n));
-    if (BF16) ((uint2*)Pv)[idx] = t2v_pack_bf16x4(v);
-    else ((float4*)Pv)[idx] = v;
+    if (BF16) {
+        const int k0 = 32 * kb + 8 * (lane >> 4);
+        ((uint4*)Pv)[idx] = t2v_pack_bf16x8(make_float4(*W.at(k0 + 0, n), *W.at(k0 + 1, n), *W.at(k0 + 2, n), *W.at(k0 + 3, n)),
+                                            make_float4(*W.at(k0 + 4, n), *W.at(k0 + 5, n), *W.at(k0 + 6, n), *W.at(k0 + 7, n)));
+    } else {
+        const int k0 = 16 * kb + 4 * (lane >> 4);
+        ((float4*)Pv)[idx] = make_float4(*W.at(k0 + 0, n), *W.at(k0 + 1, n), *W.at(k0 + 2, n), *W.at(k0 + 3, n));
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -85,19 +91,19 @@ static int pack_lstm_weights_impl(const float* w_ih_att, const float* w_hh_att, 
     D.p[1] = w_hh_dec; D.ld[1] = T2V_H;    D.off[1] = 0; D.end[1] = T2V_XW;
     D.p[2] = w_hh_dec; D.ld[2] = T2V_H;    D.off[2] = 0; D.end[2] = T2V_XW;
     {
-        const size_t n = (size_t)T2V_NWG * (k_att / 16) * 64;
+        const size_t n = (size_t)T2V_NWG * (k_att / (BF16 ? 32 : 16)) * 64;
         k_pack_fwd<BF16><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(A, k_att, packF_att);
     }
     {
-        const size_t n = (size_t)T2V_NWG * (T2V_XW / 16) * 64;
+        const size_t n = (size_t)T2V_NWG * (T2V_XW / (BF16 ? 32 : 16)) * 64;
         k_pack_fwd<BF16><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(D, T2V_XW, packF_dec);
     }
     if (packB_att) {   // only the recurrent 1536 columns matter for the data gradient
-        const size_t n = (size_t)(T2V_KATT / 16) * 256 * 64;
+        const size_t n = (size_t)(T2V_KATT / 16) * (BF16 ? 128 : 256) * 64;
         k_pack_bwd<BF16><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(A, T2V_KATT, packB_att);
     }
     if (packB_dec) {
-        const size_t n = (size_t)(T2V_XW / 16) * 256 * 64;
+        const size_t n = (size_t)(T2V_XW / 16) * (BF16 ? 128 : 256) * 64;
         k_pack_bwd<BF16><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(D, T2V_XW, packB_dec);
     }
     return t2v_check_launch();
@@ -167,6 +173,51 @@ __device__ __forceinline__ void lstm256_stream(const float4* pa4, const float4* 
 #undef L256_LOAD
 }
 
+// bf16 packs: 32-column blocks, one uint4 weight load and two float4 state loads per block, v_mfma_f32_16x16x32_bf16.
+// Wave v walks attention_rnn blocks [12v, 12v+12) then decoder_rnn blocks [20v, 20v+20): 8 rounds of 4 blocks, two in flight.
+template <bool FLIP>
+__device__ __forceinline__ void lstm256_stream_bf(const uint4* pa, const uint4* pd, const float* xrow8, int wave, f32x4& accA, f32x4& accD) {
+    uint4 wv[2][4];
+    float4 xv[2][8];
+#define LB_LOAD(R)                                                                                \
+    {                                                                                             \
+        constexpr int RR = FLIP ? 7 - (R) : (R);                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+            const int ii = FLIP ? 3 - i : i;                                                      \
+            const int jb = RR < 3 ? 12 * wave + 4 * RR + ii : 20 * wave + 4 * (RR - 3) + ii;      \
+            wv[(R) & 1][i] = (RR < 3 ? pa : pd)[(size_t)jb * 64];                                 \
+            xv[(R) & 1][2 * i] = *(const float4*)(xrow8 + 32 * jb);                               \
+            xv[(R) & 1][2 * i + 1] = *(const float4*)(xrow8 + 32 * jb + 4);                       \
+        }                                                                                         \
+    }
+#define LB_MATH(R)                                                                                \
+    {                                                                                             \
+        constexpr int RR = FLIP ? 7 - (R) : (R);                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+            if (RR < 3) accA = mfma16x32_bf16(wv[(R) & 1][i], xv[(R) & 1][2 * i], xv[(R) & 1][2 * i + 1], accA); \
+            else accD = mfma16x32_bf16(wv[(R) & 1][i], xv[(R) & 1][2 * i], xv[(R) & 1][2 * i + 1], accD);        \
+        }                                                                                         \
+    }
+#define LB_STEP(R, NEXT)                        \
+    NEXT                                        \
+    __builtin_amdgcn_sched_barrier(0);          \
+    LB_MATH(R)                                  \
+    __builtin_amdgcn_sched_barrier(0);
+    LB_LOAD(0)
+    __builtin_amdgcn_sched_barrier(0);
+    LB_STEP(0, LB_LOAD(1))
+    LB_STEP(1, LB_LOAD(2))
+    LB_STEP(2, LB_LOAD(3))
+    LB_STEP(3, LB_LOAD(4))
+    LB_STEP(4, LB_LOAD(5))
+    LB_STEP(5, LB_LOAD(6))
+    LB_STEP(6, LB_LOAD(7))
+    LB_STEP(7, )
+#undef LB_STEP
+#undef LB_MATH
+#undef LB_LOAD
+}
+
 template <bool WBF>
 __global__ __launch_bounds__(256) void k_lstm_fwd256(LstmFwdArgs a) {
     const uint64_t seed = t2v_step_seed(a.seed, a.step);
@@ -198,8 +249,16 @@ __global__ __launch_bounds__(256) void k_lstm_fwd256(LstmFwdArgs a) {
         wqr[0] = wq[0]; wqr[1] = wq[T2V_A]; wqr[2] = wq[2 * T2V_A]; wqr[3] = wq[3 * T2V_A];
     }
     f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accD = {0.f, 0.f, 0.f, 0.f};
-    if (a.t & 1) lstm256_stream<true, WBF>(pa, pd, xrow, wave, accA, accD);
-    else lstm256_stream<false, WBF>(pa, pd, xrow, wave, accA, accD);
+    if constexpr (WBF) {
+        const uint4* pa8 = (const uint4*)a.packA + ((size_t)w * (T2V_KATT / 32)) * 64 + lane;
+        const uint4* pd8 = (const uint4*)a.packD + ((size_t)w * (T2V_XW / 32)) * 64 + lane;
+        const float* xrow8 = a.xs_prev + (size_t)(bvalid ? b : 0) * T2V_XW + 8 * g;
+        if (a.t & 1) lstm256_stream_bf<true>(pa8, pd8, xrow8, wave, accA, accD);
+        else lstm256_stream_bf<false>(pa8, pd8, xrow8, wave, accA, accD);
+    } else {
+        if (a.t & 1) lstm256_stream<true, false>(pa, pd, xrow, wave, accA, accD);
+        else lstm256_stream<false, false>(pa, pd, xrow, wave, accA, accD);
+    }
     red[0][wave][lane] = accA;
     red[1][wave][lane] = accD;
     __syncthreads();

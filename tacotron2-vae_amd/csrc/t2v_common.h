@@ -45,6 +45,15 @@ __device__ __forceinline__ void mfma_block(f32x4& acc, const float4& wv, const f
     acc = mfma16x4(wv.x, xv.x, acc); acc = mfma16x4(wv.y, xv.y, acc);
     acc = mfma16x4(wv.z, xv.z, acc); acc = mfma16x4(wv.w, xv.w, acc);
 }
+// 16x16x32 bf16 tile step: lane l holds A[l&15][8(l>>4)+i], B[8(l>>4)+i][l&15], i = 0..7 (one uint4 each)
+typedef __bf16 t2v_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma16x32_bf16(uint4 a, float4 x0, float4 x1, f32x4 c) {
+    const uint4 b = make_uint4(t2v_pack_bf16x2(x0.x, x0.y), t2v_pack_bf16x2(x0.z, x0.w), t2v_pack_bf16x2(x1.x, x1.y), t2v_pack_bf16x2(x1.z, x1.w));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const t2v_bf16x8*)&a, *(const t2v_bf16x8*)&b, c, 0, 0, 0);
+}
+__device__ __forceinline__ uint4 t2v_pack_bf16x8(float4 a, float4 b) {
+    return make_uint4(t2v_pack_bf16x2(a.x, a.y), t2v_pack_bf16x2(a.z, a.w), t2v_pack_bf16x2(b.x, b.y), t2v_pack_bf16x2(b.z, b.w));
+}
 __device__ __forceinline__ void mfma_block(f32x4& acc, const uint2& wv, const float4& xv) {
     acc = mfma16x16_bf16(wv, t2v_pack_bf16x4(xv), acc);
 }
