@@ -4,6 +4,7 @@
 //   k_attn_fwd : location-sensitive attention of step t (query sum, location conv + dense,
 //                tanh/v energies, masked softmax, context).
 // Reference semantics: Decoder.decode model.py:346-389, Attention.forward model.py:67-88.
+#include <stdlib.h>
 #include <type_traits>
 #include "t2v_common.h"
 #include "t2v_kernels.h"
@@ -173,6 +174,67 @@ __device__ __forceinline__ void lstm256_stream(const float4* pa4, const float4* 
 #undef L256_LOAD
 }
 
+// fp32, state loads shared between the two cells.  attention_rnn and decoder_rnn multiply the SAME columns [h_att | ctx]
+// (k-blocks 0..95 of both packs), so a wave that owns the same k-range of both tiles loads those state values once:
+// wave v walks shared blocks [24v, 24v+24) (6 rounds of 4: 4 W_att + 4 W_dec + 4 x loads) and then decoder_rnn's h_dec
+// blocks [96+16v, 96+16v+16) (2 rounds of 8 pairs): 64 weight + 40 state loads per wave instead of 64 + 64 — the kernel
+// is bound by the vector-memory instructions it issues.  Two rounds in flight = 16 weight loads, as before.
+template <bool FLIP>
+__device__ __forceinline__ void lstm256_stream_shared(const float4* pa, const float4* pd, const float* xrow, int wave,
+                                                      f32x4& accA, f32x4& accD) {
+    float4 wv[2][8], xv[2][8];
+#define LS_LOAD(R)                                                                                \
+    {                                                                                             \
+        constexpr int RR = FLIP ? 7 - (R) : (R);                                                  \
+        if (RR < 6) {                                                                             \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+                const int ii = FLIP ? 3 - i : i;                                                  \
+                const int kb = 24 * wave + 4 * RR + ii;                                           \
+                wv[(R) & 1][i] = pa[(size_t)kb * 64];                                             \
+                wv[(R) & 1][4 + i] = pd[(size_t)kb * 64];                                         \
+                xv[(R) & 1][i] = *(const float4*)(xrow + 16 * kb);                                \
+            }                                                                                     \
+        } else {                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                       \
+                const int ii = FLIP ? 7 - i : i;                                                  \
+                const int kb = 96 + 16 * wave + 8 * (RR - 6) + ii;                                \
+                wv[(R) & 1][i] = pd[(size_t)kb * 64];                                             \
+                xv[(R) & 1][i] = *(const float4*)(xrow + 16 * kb);                                \
+            }                                                                                     \
+        }                                                                                         \
+    }
+#define LS_MATH(R)                                                                                \
+    {                                                                                             \
+        constexpr int RR = FLIP ? 7 - (R) : (R);                                                  \
+        if (RR < 6) {                                                                             \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+                MFMA4(accA, wv[(R) & 1][i], xv[(R) & 1][i]);                                      \
+                MFMA4(accD, wv[(R) & 1][4 + i], xv[(R) & 1][i]);                                  \
+            }                                                                                     \
+        } else {                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) { MFMA4(accD, wv[(R) & 1][i], xv[(R) & 1][i]); } \
+        }                                                                                         \
+    }
+#define LS_STEP(R, NEXT)                        \
+    NEXT                                        \
+    __builtin_amdgcn_sched_barrier(0);          \
+    LS_MATH(R)                                  \
+    __builtin_amdgcn_sched_barrier(0);
+    LS_LOAD(0)
+    __builtin_amdgcn_sched_barrier(0);
+    LS_STEP(0, LS_LOAD(1))
+    LS_STEP(1, LS_LOAD(2))
+    LS_STEP(2, LS_LOAD(3))
+    LS_STEP(3, LS_LOAD(4))
+    LS_STEP(4, LS_LOAD(5))
+    LS_STEP(5, LS_LOAD(6))
+    LS_STEP(6, LS_LOAD(7))
+    LS_STEP(7, )
+#undef LS_STEP
+#undef LS_MATH
+#undef LS_LOAD
+}
+
 // bf16 packs: 32-column blocks, one uint4 weight load and two float4 state loads per block, v_mfma_f32_16x16x32_bf16.
 // Wave v walks attention_rnn blocks [12v, 12v+12) then decoder_rnn blocks [20v, 20v+20): 8 rounds of 4 blocks, two in flight.
 template <bool FLIP>
@@ -256,8 +318,13 @@ __global__ __launch_bounds__(256) void k_lstm_fwd256(LstmFwdArgs a) {
         if (a.t & 1) lstm256_stream_bf<true>(pa8, pd8, xrow8, wave, accA, accD);
         else lstm256_stream_bf<false>(pa8, pd8, xrow8, wave, accA, accD);
     } else {
-        if (a.t & 1) lstm256_stream<true, false>(pa, pd, xrow, wave, accA, accD);
-        else lstm256_stream<false, false>(pa, pd, xrow, wave, accA, accD);
+        if (a.shared_x) {
+            if (a.t & 1) lstm256_stream_shared<true>(pa, pd, xrow, wave, accA, accD);
+            else lstm256_stream_shared<false>(pa, pd, xrow, wave, accA, accD);
+        } else {
+            if (a.t & 1) lstm256_stream<true, false>(pa, pd, xrow, wave, accA, accD);
+            else lstm256_stream<false, false>(pa, pd, xrow, wave, accA, accD);
+        }
     }
     red[0][wave][lane] = accA;
     red[1][wave][lane] = accD;
@@ -394,6 +461,10 @@ static void fill_lstm_args(LstmFwdArgs& a, const t2v_dec_weights* w, const t2v_d
     a.gd_t = (s->GD && t >= 1) ? s->GD + (size_t)(t - 1) * B * T2V_G : nullptr;
     a.wqT = w->wqT;
     a.qp = s->QP;
+    {
+        static const int sx = getenv("T2V_NO_SHARED_X") ? 0 : 1;
+        a.shared_x = sx;
+    }
     a.B = B;
     a.t = t;
     a.do_att = t < T_out;

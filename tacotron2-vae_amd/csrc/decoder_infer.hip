@@ -139,6 +139,7 @@ extern "C" int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_i
         a.gd_t = nullptr;
         a.wqT = w->wqT;
         a.qp = s->QP;
+        a.shared_x = 0;
         a.B = B;
         a.p_att = 0.f;      // eval mode: no state dropout (F.dropout(..., self.training))
         a.p_dec = 0.f;

@@ -59,6 +59,7 @@ struct LstmFwdArgs {
     float* gd_t;            // GD[t-1] or NULL
     const float* wqT;
     float* qp;
+    int shared_x;           // fp32 packs: one load of the [h_att | ctx] state columns serves both cells (lstm256_stream_shared)
     int B, t, do_att, do_dec;
     float p_att, p_dec;
     uint64_t seed;
