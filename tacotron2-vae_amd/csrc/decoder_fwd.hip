@@ -236,28 +236,31 @@ __device__ __forceinline__ void lstm256_stream_shared(const float4* pa, const fl
 }
 
 // bf16 packs: 32-column blocks, one uint4 weight load and two float4 state loads per block, v_mfma_f32_16x16x32_bf16.
-// Wave v walks attention_rnn blocks [12v, 12v+12) then decoder_rnn blocks [20v, 20v+20): 8 rounds of 4 blocks, two in flight.
+// Like lstm256_stream_shared a wave owns the same column range of both cells: shared blocks [12v, 12v+12) (3 rounds of
+// 4: 4 W_att + 4 W_dec + 8 state loads), then decoder_rnn's h_dec blocks [48+8v, 48+8v+8) (2 rounds of 4): 32 weight +
+// 40 state loads per wave.  Two rounds in flight.
 template <bool FLIP>
 __device__ __forceinline__ void lstm256_stream_bf(const uint4* pa, const uint4* pd, const float* xrow8, int wave, f32x4& accA, f32x4& accD) {
-    uint4 wv[2][4];
+    uint4 wv[2][8];
     float4 xv[2][8];
 #define LB_LOAD(R)                                                                                \
     {                                                                                             \
-        constexpr int RR = FLIP ? 7 - (R) : (R);                                                  \
+        constexpr int RR = FLIP ? 4 - (R) : (R);                                                  \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
             const int ii = FLIP ? 3 - i : i;                                                      \
-            const int jb = RR < 3 ? 12 * wave + 4 * RR + ii : 20 * wave + 4 * (RR - 3) + ii;      \
-            wv[(R) & 1][i] = (RR < 3 ? pa : pd)[(size_t)jb * 64];                                 \
+            const int jb = RR < 3 ? 12 * wave + 4 * RR + ii : 48 + 8 * wave + 4 * (RR - 3) + ii;  \
+            if (RR < 3) wv[(R) & 1][i] = pa[(size_t)jb * 64];                                     \
+            wv[(R) & 1][4 + i] = pd[(size_t)jb * 64];                                             \
             xv[(R) & 1][2 * i] = *(const float4*)(xrow8 + 32 * jb);                               \
             xv[(R) & 1][2 * i + 1] = *(const float4*)(xrow8 + 32 * jb + 4);                       \
         }                                                                                         \
     }
 #define LB_MATH(R)                                                                                \
     {                                                                                             \
-        constexpr int RR = FLIP ? 7 - (R) : (R);                                                  \
+        constexpr int RR = FLIP ? 4 - (R) : (R);                                                  \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
             if (RR < 3) accA = mfma16x32_bf16(wv[(R) & 1][i], xv[(R) & 1][2 * i], xv[(R) & 1][2 * i + 1], accA); \
-            else accD = mfma16x32_bf16(wv[(R) & 1][i], xv[(R) & 1][2 * i], xv[(R) & 1][2 * i + 1], accD);        \
+            accD = mfma16x32_bf16(wv[(R) & 1][4 + i], xv[(R) & 1][2 * i], xv[(R) & 1][2 * i + 1], accD);         \
         }                                                                                         \
     }
 #define LB_STEP(R, NEXT)                        \
@@ -271,10 +274,7 @@ __device__ __forceinline__ void lstm256_stream_bf(const uint4* pa, const uint4* 
     LB_STEP(1, LB_LOAD(2))
     LB_STEP(2, LB_LOAD(3))
     LB_STEP(3, LB_LOAD(4))
-    LB_STEP(4, LB_LOAD(5))
-    LB_STEP(5, LB_LOAD(6))
-    LB_STEP(6, LB_LOAD(7))
-    LB_STEP(7, )
+    LB_STEP(4, )
 #undef LB_STEP
 #undef LB_MATH
 #undef LB_LOAD
