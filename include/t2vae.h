@@ -41,6 +41,10 @@ typedef struct t2v_step_params {
     float pad[2];
 } t2v_step_params;
 void t2v_set_step_params(const t2v_step_params* dev);
+/* Per-stream binding (one training engine = one rank = one stream, SURVEY.md 8(b) "thread-safe per ctx"): launches on
+ * `stream` read THIS record; launches on a stream without a binding read the process default above.  dev = NULL removes
+ * the binding.  Two engines in one process therefore never share a step record as long as each runs on its own stream. */
+int t2v_set_step_params_stream(void* stream, const t2v_step_params* dev);
 
 /* ------------------------------------------------------------------ weight packing
  * Re-lays the two decoder LSTM cells' weights into MFMA-fragment order for the per-step

@@ -41,4 +41,8 @@ class CoordConv2d(nn.Conv2d):
                               padding, dilation, groups, bias)
 
     def forward(self, x):
-        return self.conv(self.addcoords(x))
+        """the live layer runs inside ReferenceEncoder.forward (fused CoordConv + Conv2d s2 + BatchNorm + ReLU HIP
+        kernel, coordinates generated in-kernel); a direct call would be a stock-library convolution"""
+        import t2v_hip
+        raise t2v_hip.T2VHipError("CoordConv2d.forward is not a product path: ReferenceEncoder.forward runs the fused "
+                                  "HIP kernel on conv.weight")

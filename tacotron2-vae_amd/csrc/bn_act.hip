@@ -224,7 +224,7 @@ extern "C" int t2v_bn_act_fwd(const float* y, const float* stat_part, int nblk, 
     a.y = y; a.stat_part = stat_part; a.nblk = nblk; a.gamma = gamma; a.beta = beta;
     a.running_mean = running_mean; a.running_var = running_var; a.mean_out = mean_out; a.rstd_out = rstd_out;
     a.out = out; a.B = B; a.M = M; a.T = T; a.act = act; a.training = training; a.p_drop = p_drop;
-    a.momentum = momentum; a.eps = eps; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = g_t2v_step;
+    a.momentum = momentum; a.eps = eps; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
     k_bn_act_fwd<<<M, 256, 0, stream>>>(a);
     return t2v_check_launch();
 }
@@ -238,7 +238,7 @@ extern "C" int t2v_bn_act_bwd(const float* y, const float* dout, const float* me
     BnBwdArgs a;
     a.y = y; a.dout = dout; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.dy = dy;
     a.dgamma = dgamma; a.dbeta = dbeta; a.dconv_bias = dconv_bias; a.B = B; a.M = M; a.T = T; a.act = act; a.p_drop = p_drop;
-    a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = g_t2v_step;
+    a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
     k_bn_act_bwd<<<M, 256, 0, stream>>>(a);
     return t2v_check_launch();
 }

@@ -493,6 +493,7 @@ static int launch_train_bwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
     const size_t HC = T2V_H + T2V_E;
     unsigned* sync = (unsigned*)(g->GCUM + (size_t)B * S * Tcap);     // [1] error word
     const size_t lds = sizeof(float) * 3 * Tcap;
+    const t2v_step_params* step_rec = t2v_step_for(stream);
     for (int t = T_out; t >= 0; --t) {
         bool have_attn = false;
         AttnBwdArgs fa = {};
@@ -556,7 +557,7 @@ static int launch_train_bwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
         c.p_att = p_att;
         c.p_dec = p_dec;
         c.seed = seed;
-        c.step = g_t2v_step;
+        c.step = step_rec;
         c.err = sync + 1;
         c.prof = g_t2v_prof ? g_t2v_prof + 24 : nullptr;
         const int nattn = have_attn ? B * S : 0;

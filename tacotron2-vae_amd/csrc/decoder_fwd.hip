@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void k_lstm_one256(LstmFwdArgs a) {
 }
 
 static void fill_lstm_args(LstmFwdArgs& a, const t2v_dec_weights* w, const t2v_dec_train_bufs* s, int B, int T_out,
-                           int t, float p_att, float p_dec, uint64_t seed) {
+                           int t, float p_att, float p_dec, uint64_t seed, const t2v_step_params* step) {
     a.packA = (const float4*)w->packF_att;
     a.packD = (const float4*)w->packF_dec;
     a.k_att = T2V_KATT;
@@ -472,7 +472,7 @@ static void fill_lstm_args(LstmFwdArgs& a, const t2v_dec_weights* w, const t2v_d
     a.p_att = p_att;
     a.p_dec = p_dec;
     a.seed = seed;
-    a.step = g_t2v_step;
+    a.step = step;
 }
 
 // mask bits: 1 = k_lstm_fwd256 (both cells), 2 = k_attn_fwd
@@ -497,10 +497,11 @@ static int launch_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* 
         z.add(s->ACUM, sizeof(float) * B * T_in);
     }
     t2v_zero_regions(z, stream);
+    const t2v_step_params* step = t2v_step_for(stream);
     for (int t = 0; t <= T_out; ++t) {
         if (mask & 1) {
             LstmFwdArgs a;
-            fill_lstm_args(a, w, s, B, T_out, t, p_att, p_dec, seed);
+            fill_lstm_args(a, w, s, B, T_out, t, p_att, p_dec, seed, step);
             if (w->packs_bf16) k_lstm_fwd256<true><<<T2V_NWG, 256, 0, stream>>>(a);
             else k_lstm_fwd256<false><<<T2V_NWG, 256, 0, stream>>>(a);
         }

@@ -521,8 +521,39 @@ static size_t pd_lds_bytes(int B, int T_in) {
 #define PD_LDS_MAX (160 * 1024)
 
 extern "C" long t2v_decoder_persist_granules(int B) { return (B < 1 || B > PD_MAXB) ? 0 : (long)(2 * pd_par(B)); }
+// The workgroups of this kernel spin on each other's granules, so ALL 256 must be resident at once: one per CU on a
+// device with >= 256 CUs whose occupancy query admits this launch configuration (512 threads, the run-time LDS carve).
+// Answered once per device and (B, T_in) class; a device that is shared with other work can still fail to co-schedule
+// them — the bounded spins then set the error word and Decoder.inference re-runs the utterance on the launch-per-stage
+// loop.
+static int pd_device_ok(size_t lds) {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        cus = prop.multiProcessorCount;
+    }
+    if (cus < T2V_NWG) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_decode_persist, hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        attr_set = true;
+    }
+    int nblk = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)k_decode_persist, PD_THREADS, lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return nblk >= 1;
+}
+
 extern "C" int t2v_decoder_persist_supported(int B, int T_in) {
-    return B >= 1 && B <= PD_MAXB && T_in >= 1 && T_in <= PD_MAXT && pd_lds_bytes(B, T_in) <= PD_LDS_MAX;
+    if (!(B >= 1 && B <= PD_MAXB && T_in >= 1 && T_in <= PD_MAXT && pd_lds_bytes(B, T_in) <= PD_LDS_MAX)) return 0;
+    return pd_device_ok(pd_lds_bytes(B, T_in));
 }
 
 extern "C" int t2v_decoder_infer_persistent(const t2v_dec_persist_weights* w, const t2v_dec_persist_bufs* s, int B, int T_in,
@@ -533,13 +564,7 @@ extern "C" int t2v_decoder_infer_persistent(const t2v_dec_persist_weights* w, co
         !w->v || !w->proj_w || !w->proj_b || !w->prenet_w1 || !s->memory || !s->pm || !s->pre_first || !s->MEL || !s->GATE ||
         !s->AL || !s->stop_flag || !s->granules || !s->err_word)
         return T2V_ERR_ARG;
-    static bool attr_set = false;
-    const size_t lds = pd_lds_bytes(B, T_in);
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_decode_persist, hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_MAX) != hipSuccess)
-            return t2v_check_launch();
-        attr_set = true;
-    }
+    const size_t lds = pd_lds_bytes(B, T_in);     // (t2v_decoder_persist_supported raised the dynamic-LDS limit)
     (void)hipMemsetAsync(s->granules, 0, sizeof(t2v_u64) * 2 * pd_par(B), stream);
     (void)hipMemsetAsync(s->err_word, 0, sizeof(unsigned), stream);
     PersistArgs a;

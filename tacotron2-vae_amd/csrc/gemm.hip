@@ -415,7 +415,7 @@ extern "C" int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B,
     GemmArgs a;
     a.A = A; a.B = B; a.bias = bias; a.C = C; a.sAi = sAi; a.sAk = sAk; a.sBj = sBj; a.sBk = sBk;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
-    a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = g_t2v_step;
+    a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
     a.kz_chunk = 0; a.part = nullptr;
     dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM);
     const bool akc = sAk == 1, bkc = sBk == 1;
@@ -449,7 +449,7 @@ static int gemm_f32_impl(const float* A, long sAi, long sAk, const float* B, lon
     GemmArgs a;
     a.A = A; a.B = B; a.bias = bias; a.C = C; a.sAi = sAi; a.sAk = sAk; a.sBj = sBj; a.sBk = sBk;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
-    a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = g_t2v_step;
+    a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
     a.kz_chunk = 0; a.part = nullptr;
     const bool akc = sAk == 1, bkc = sBk == 1;
     if (gemm_big_ok(a)) {

@@ -100,7 +100,7 @@ extern "C" int t2v_clip_adam_step(float* params, float* grads, float* exp_avg, f
     a.inv_world = inv_world;
     a.bc1 = bc1;
     a.bc2s = sqrtf(bc2);
-    a.step = g_t2v_step;
+    a.step = t2v_step_for(stream);
     k_clip_adam<<<2048, 256, 0, stream>>>(a);
     return t2v_check_launch();
 }

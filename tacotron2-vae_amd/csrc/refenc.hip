@@ -454,7 +454,7 @@ extern "C" int t2v_loss_fwd_bwd(const float* mel, const float* post, const float
     LossArgs a;
     a.mel = mel; a.post = post; a.mel_t = mel_t; a.gate = gate; a.gate_t = gate_t; a.mu = mu; a.logvar = logvar;
     a.dmel = dmel; a.dpost = dpost; a.dgate = dgate; a.dmu = dmu; a.dlogvar = dlogvar; a.part = part192; a.out = out4;
-    a.n_mel = n_mel; a.n_gate = n_gate; a.n_lat = n_lat; a.nblk = 64; a.klw = kl_weight; a.ticket = ticket; a.step = g_t2v_step;
+    a.n_mel = n_mel; a.n_gate = n_gate; a.n_lat = n_lat; a.nblk = 64; a.klw = kl_weight; a.ticket = ticket; a.step = t2v_step_for((hipStream_t)stream_);
     k_loss<<<64, 256, 0, (hipStream_t)stream_>>>(a);
     return t2v_check_launch();
 }

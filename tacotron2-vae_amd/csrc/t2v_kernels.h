@@ -9,7 +9,7 @@ enum { T2V_RNG_ATT_H = 1, T2V_RNG_ATT_C = 2, T2V_RNG_DEC_H = 3, T2V_RNG_DEC_C = 
 
 int t2v_check_launch();
 extern unsigned long long* g_t2v_prof;   // device buffer of 32 u64 or NULL (t2v_set_phase_profile)                 // records hipGetLastError() for t2v_last_error()
-extern const t2v_step_params* g_t2v_step;      // device-side per-step parameters or NULL (t2v_set_step_params)
+const t2v_step_params* t2v_step_for(hipStream_t stream);   // device-side per-step parameters bound to this stream, else the process default, else NULL
 
 // several device regions (byte counts: multiples of 4) zeroed by ONE launch (t2v_runtime.hip)
 struct T2VZeroRegions {

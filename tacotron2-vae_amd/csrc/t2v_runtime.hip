@@ -23,8 +23,40 @@ extern "C" void t2v_set_phase_profile(unsigned long long* dev_buf32) { g_t2v_pro
 
 // Per-step parameters in device memory (optional): lets a captured HIP graph of the whole training step replay with
 // fresh dropout masks / Adam bias corrections / KL weight — kernel arguments are frozen at capture time, memory is not.
-const t2v_step_params* g_t2v_step = nullptr;
-extern "C" void t2v_set_step_params(const t2v_step_params* dev) { g_t2v_step = dev; }
+// The record is looked up per STREAM (one training engine = one rank = one stream): an engine binds its
+// record to its own stream with t2v_set_step_params_stream(); launches on a stream without a binding use the process
+// default installed by t2v_set_step_params() (NULL: the by-value arguments of each call).
+#include <mutex>
+static const t2v_step_params* g_t2v_step = nullptr;
+static std::mutex g_step_mu;
+static struct { hipStream_t s; const t2v_step_params* p; } g_step_tab[32];
+static int g_step_n = 0;
+extern "C" void t2v_set_step_params(const t2v_step_params* dev) {
+    std::lock_guard<std::mutex> lk(g_step_mu);
+    g_t2v_step = dev;
+}
+extern "C" int t2v_set_step_params_stream(void* stream, const t2v_step_params* dev) {
+    std::lock_guard<std::mutex> lk(g_step_mu);
+    const hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < g_step_n; ++i)
+        if (g_step_tab[i].s == s) {
+            if (dev) g_step_tab[i].p = dev;
+            else g_step_tab[i] = g_step_tab[--g_step_n];
+            return T2V_OK;
+        }
+    if (!dev) return T2V_OK;
+    if (g_step_n >= 32) return T2V_ERR_ARG;
+    g_step_tab[g_step_n].s = s;
+    g_step_tab[g_step_n].p = dev;
+    ++g_step_n;
+    return T2V_OK;
+}
+const t2v_step_params* t2v_step_for(hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_step_mu);
+    for (int i = 0; i < g_step_n; ++i)
+        if (g_step_tab[i].s == stream) return g_step_tab[i].p;
+    return g_t2v_step;
+}
 
 // One launch that zeroes several device regions (grid.y = region): the per-pass resets of a decoder pass (initial
 // states, sync words, granule tags) cost one kernel instead of one memset node each.

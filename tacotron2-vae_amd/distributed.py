@@ -37,6 +37,36 @@ def init_distributed(hparams=None, n_gpus=None, rank=None, group_name=None, back
         dist.init_process_group(init_method=hparams.dist_url, world_size=n_gpus, rank=rank, **kw)
 
 
+class _Done(object):
+    def wait(self):
+        return True
+
+
+def _stage_through_host(t, group):
+    """gloo worlds (CPU tests; two ranks sharing ONE GPU in the -m gpu suite, where RCCL refuses duplicate devices)
+    reduce / broadcast device tensors through host memory in fp32 — the semantics of the collective, not its speed."""
+    return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+def all_reduce_sum(t, group=None, async_op=False):
+    """all-reduce(SUM) of `t` in place; returns a work handle with .wait() when async_op"""
+    if _stage_through_host(t, group):
+        c = t.detach().float().cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(c)
+        return _Done() if async_op else None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def broadcast(t, src=0, group=None):
+    if _stage_through_host(t, group):
+        c = t.detach().cpu()
+        dist.broadcast(c, src, group=group)
+        t.copy_(c)
+        return
+    dist.broadcast(t, src, group=group)
+
+
 def broadcast_state(module, src=0):
     """rank-0 weights and buffers to everybody (reference distributed.py:132-135), coalesced per
     dtype instead of 142 separate broadcasts."""
@@ -48,7 +78,7 @@ def broadcast_state(module, src=0):
             by_dtype.setdefault(t.dtype, []).append(t)
     for dtype, tensors in by_dtype.items():
         flat = torch.cat([t.reshape(-1) for t in tensors])
-        dist.broadcast(flat, src)
+        broadcast(flat, src)
         o = 0
         for t in tensors:
             t.copy_(flat[o:o + t.numel()].view_as(t))
@@ -68,8 +98,7 @@ class ArenaAllReduce(object):
     def __call__(self):
         if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return
-        works = [dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                 for a, b in self.bounds]
+        works = [all_reduce_sum(self.flat[a:b], group=self.group, async_op=True) for a, b in self.bounds]
         for w in works:
             w.wait()
 
@@ -86,9 +115,14 @@ class OverlappedArenaAllReduce(object):
     One collective per bucket on a point-to-point fabric: few, large messages (xGMI rings are per-link bound)."""
 
     def __init__(self, named_params, offsets, flat, group=None, min_bucket=1 << 16, force=False, side_streams=None,
-                 gather=None):
-        """named_params: [(name, param)] in arena order; offsets: start of each param inside `flat`."""
+                 gather=None, wire_dtype=None):
+        """named_params: [(name, param)] in arena order; offsets: start of each param inside `flat`.
+        wire_dtype=torch.bfloat16 (bf16_run, SURVEY 8(e): 57.7 MB instead of 115.5 MB per step): every slice is rounded
+        into a bf16 wire buffer, summed over the ranks in bf16, and widened back into the fp32 arena."""
         self.flat, self.group = flat, group
+        self.wire = None
+        if wire_dtype is not None and wire_dtype != flat.dtype:
+            self.wire = torch.empty(flat.numel(), dtype=wire_dtype, device=flat.device)
         self.force = force      # run the hooks and collectives even in a 1-rank group (tests)
         # callable -> streams other than the current one on which gradients of the model may be produced (the model
         # runs its reference-encoder branch on a side stream): a bucket waits for them before it goes out
@@ -150,8 +184,35 @@ class OverlappedArenaAllReduce(object):
                 cur.wait_stream(st)
         if self.gather is not None:
             self.gather(self._bucket_params[bi])
-        self._works[bi] = dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works[bi] = self._issue(lo, hi)
         self.launch_log.append((bi, from_hook))
+
+    def _issue(self, lo, hi):
+        if self.wire is None:
+            return all_reduce_sum(self.flat[lo:hi], group=self.group, async_op=True)
+        w = self.wire[lo:hi]
+        w.copy_(self.flat[lo:hi])
+        return all_reduce_sum(w, group=self.group, async_op=True)
+
+    def wire_bytes(self):
+        t = self.flat if self.wire is None else self.wire
+        return t.numel() * t.element_size()
+
+    def reduce_all(self):
+        """ONE collective over the whole arena (the graph engine's exchange, and its eager warm-up / fallback steps: the
+        collective pattern of a rank must not depend on whether that rank replays a graph or runs eagerly this
+        iteration — ranks see different batch shapes).  Timed like finish()."""
+        timed = self.flat.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self._issue(0, self.flat.numel()).wait()
+        if self.wire is not None:
+            self.flat.copy_(self.wire)
+        if timed:
+            e1.record()
+            self._exposed.append((e0, e1))
+            del self._exposed[:-64]
 
     def begin(self):
         """call before backward()"""
@@ -172,6 +233,8 @@ class OverlappedArenaAllReduce(object):
             e0.record()
         for w in self._works:
             w.wait()
+        if self.wire is not None:           # the waits above ordered the compute stream behind the collectives
+            self.flat.copy_(self.wire)
         if timed:
             e1.record()
             self._exposed.append((e0, e1))
@@ -190,7 +253,7 @@ class OverlappedArenaAllReduce(object):
 def reduce_tensor(tensor, n_gpus):
     """reference train.py:31-35 (mean of a scalar over ranks, for logging)."""
     rt = tensor.clone()
-    dist.all_reduce(rt, op=dist.ReduceOp.SUM)
+    all_reduce_sum(rt)
     rt /= n_gpus
     return rt
 

@@ -49,8 +49,11 @@ _GROUPS = {
 #   bf16_run        : bf16 MFMA for the Postnet/encoder convolutions and the time-batched linears, fp32
 #                     master weights / accumulation / BatchNorm / recurrent state (replaces fp16_run)
 #   graph_step      : capture the whole training iteration into a HIP graph per input shape and replay it
-#                     (train.TrainEngine); pays off with fixed / bucketed shapes, ragged batches stay eager
-_EXTENSIONS = dict(device_frontend=False, bucket_batches=False, bf16_run=False, graph_step=False)
+#                     (train.TrainEngine).  ON by default: a shape is captured the third time it is seen (at most 8
+#                     shapes), so fixed / bucketed shapes replay and ragged batches whose shapes never repeat simply
+#                     stay eager; `python train.py` then runs what bench.py measures
+#   fp32_allreduce  : under bf16_run the gradient exchange is bf16 (57.7 MB per step); True keeps it fp32 (115.5 MB)
+_EXTENSIONS = dict(device_frontend=False, bucket_batches=False, bf16_run=False, graph_step=True, fp32_allreduce=False)
 
 
 def _coerce(old, text):

@@ -9,6 +9,24 @@ def _xavier(weight, gain_name):
     nn.init.xavier_uniform_(weight, gain=nn.init.calculate_gain(gain_name))
 
 
+def hip_linear(x, weight, bias):
+    """x (..., in) @ weight^T + bias on the own fp32 MFMA GEMM (t2v_hip.LinearHIP, differentiable); CPU tensors are
+    refused — there is no stock-library fallback on this path."""
+    import t2v_hip
+    if not x.is_cuda:
+        raise t2v_hip.T2VHipError("linear layer called with a CPU tensor; this path has no CPU fallback")
+    lead = x.shape[:-1]
+    y = t2v_hip.LinearHIP.apply(x.reshape(-1, x.shape[-1]).float(), weight, bias, False, 0.0, 0, 0, 0)
+    return y.view(*lead, weight.shape[0])
+
+
+class HipLinear(nn.Linear):
+    """nn.Linear parameters / state_dict keys, forward on the HIP GEMM (the VAE head: fc1 / fc2 / fc3)."""
+
+    def forward(self, x):
+        return hip_linear(x, self.weight, self.bias)
+
+
 class LinearNorm(nn.Module):
     """state_dict keys `linear_layer.{weight,bias}` as in the reference."""
 
@@ -26,7 +44,7 @@ class LinearNorm(nn.Module):
         return self.linear_layer.bias
 
     def forward(self, x):
-        return F.linear(x, self.linear_layer.weight, self.linear_layer.bias)
+        return hip_linear(x, self.linear_layer.weight, self.linear_layer.bias)
 
 
 class ConvNorm(nn.Module):
@@ -44,7 +62,12 @@ class ConvNorm(nn.Module):
         _xavier(self.conv.weight, w_init_gain)
 
     def forward(self, signal):
-        return self.conv(signal)
+        """ConvNorm is a parameter holder on this path: Encoder / Postnet feed `conv.weight` to the fused HIP
+        Conv1d + BatchNorm + activation kernels, LocationLayer's filters are folded into the attention kernels.  A
+        direct call would be a stock-library convolution standing in for the HIP path, so it is refused loudly."""
+        import t2v_hip
+        raise t2v_hip.T2VHipError("ConvNorm.forward is not a product path: call the owning module (Encoder / Postnet / "
+                                  "Attention), which runs the fused HIP kernels on conv.weight")
 
 
 def slaney_mel_filterbank(sr, n_fft, n_mels, fmin, fmax):

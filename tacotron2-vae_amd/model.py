@@ -243,10 +243,16 @@ class Decoder(nn.Module):
             # tagged granules, the loop ends on the frame the gate fires
             s.run_persistent(self.gate_threshold, drop_rate, seed)
             stop = int(s.stop.item())
-            t2v_hip.check_async_errors()
-            if stop < s.max_steps:
-                n = stop + 1
-            t = s.max_steps
+            if s.persistent_timed_out():
+                # the 256 workgroups were not co-scheduled (a GPU shared with other work): the bounded spins gave up.
+                # The launch-per-stage loop below restarts from the zero state — nothing of the failed run is kept
+                print("Warning! persistent decode kernel could not be co-scheduled; using the launch-per-stage loop")
+                s.reset_for_rerun()
+            else:
+                t2v_hip.check_async_errors()
+                if stop < s.max_steps:
+                    n = stop + 1
+                t = s.max_steps
         while t < s.max_steps:
             t1 = min(s.max_steps, t + chunk)
             s.run(t, t1, self.gate_threshold, drop_rate, False, seed)
@@ -309,8 +315,19 @@ class BatchLayout(object):
     _DT = (torch.int64, torch.int64, torch.float32, torch.float32, torch.int64, torch.float32, torch.float32)
     _ring = {}          # nbytes -> [pinned host buffers], [events], next slot
     RING = 4
+    n_symbols = None    # set by Tacotron2.__init__: symbol ids are validated here, on the host, like nn.Embedding would
+
+    @classmethod
+    def check_ids(cls, text):
+        """nn.Embedding (reference model.py:528) raises on an id outside [0, n_symbols); the HIP gather clamps instead, so
+        the check happens where the ids are still host memory (a bad text front end must not train silently)"""
+        if cls.n_symbols is not None and text.numel() and not text.is_cuda:
+            lo, hi = int(text.min()), int(text.max())
+            if lo < 0 or hi >= cls.n_symbols:
+                raise IndexError("symbol id out of range: got [%d, %d], embedding has %d rows" % (lo, hi, cls.n_symbols))
 
     def __init__(self, batch):
+        self.check_ids(batch[0])
         self.max_len = int(torch.max(batch[1]).item())
         self.fields = []
         off = 0
@@ -359,6 +376,7 @@ class Tacotron2(nn.Module):
         self.n_mel_channels = hparams.n_mel_channels
         self.n_frames_per_step = hparams.n_frames_per_step
         self.transcript_embedding = SymbolEmbedding(hparams.n_symbols, hparams.symbols_embedding_dim)
+        BatchLayout.n_symbols = int(hparams.n_symbols)
         self.speaker_embedding = LinearNorm(hparams.n_speakers, hparams.speaker_embedding_dim, bias=True,
                                             w_init_gain='tanh')     # constructed, never used (B-7)
         self.emotion_embedding = LinearNorm(hparams.n_emotions, hparams.emotion_embedding_dim, bias=True,
@@ -383,6 +401,7 @@ class Tacotron2(nn.Module):
             dev = lay.upload(batch, into)
             return lay.views(dev)
         max_len = int(torch.max(input_lengths).item())
+        BatchLayout.check_ids(text)
         text = to_gpu(text).long()
         speakers, emotions = to_gpu(speakers).float(), to_gpu(emotions).float()
         input_lengths = to_gpu(input_lengths).long()

@@ -4,6 +4,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from CoordConv import CoordConv2d
+from layers import HipLinear
 
 
 class ReferenceEncoder(nn.Module):
@@ -52,9 +53,11 @@ class VAE_GST(nn.Module):
     def __init__(self, hparams):
         super().__init__()
         self.ref_encoder = ReferenceEncoder(hparams)
-        self.fc1 = nn.Linear(hparams.ref_enc_gru_size, hparams.z_latent_dim)
-        self.fc2 = nn.Linear(hparams.ref_enc_gru_size, hparams.z_latent_dim)
-        self.fc3 = nn.Linear(hparams.z_latent_dim, hparams.E)
+        # HipLinear: nn.Linear's parameters / init / state_dict keys; a direct `model.vae_gst.fc3(z)` (reference
+        # synthesizer.py:131, README inference snippet) runs the own GEMM like the fused forward below
+        self.fc1 = HipLinear(hparams.ref_enc_gru_size, hparams.z_latent_dim)
+        self.fc2 = HipLinear(hparams.ref_enc_gru_size, hparams.z_latent_dim)
+        self.fc3 = HipLinear(hparams.z_latent_dim, hparams.E)
         self.eps_override = None   # test hook: inject the reparameterisation noise
 
     def reparameterize(self, mu, logvar):

@@ -72,6 +72,7 @@ class FlatAdam(object):
         self.grad_clip_thresh = grad_clip_thresh
         self.world_size = world_size
         self.step_count = 0
+        self.step_params = None     # the owning engine's device-side record (train.TrainEngine), else the active one
 
     def arena_layout(self):
         """([(name, param)], [offset]) of the live parameters in arena order (for the bucketed all-reduce)"""
@@ -131,7 +132,7 @@ class FlatAdam(object):
         self._no_grad = []
         self.step_count += 1
         bc1, bc2 = self.bias_corrections(self.step_count)
-        sp = t2v_hip.step_params(create=False)
+        sp = self.step_params if self.step_params is not None else t2v_hip.step_params(create=False)
         if sp is not None:       # the kernel reads lr / bias corrections from the device record once one is installed
             self.publish_step_params(sp, self.step_count)
             sp.upload()

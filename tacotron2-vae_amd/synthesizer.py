@@ -23,7 +23,11 @@ EMOTIONS = ('neu', 'sad', 'ang', 'hap')      # label ids 0..3 of the koemo filel
 
 class Synthesizer(object):
     def __init__(self, hparams=None):
-        self.hparams = hparams if hparams is not None else create_hparams()
+        if hparams is None:             # the reference's constructor (synthesizer.py:47-51): defaults + two overrides
+            hparams = create_hparams()
+            hparams.sampling_rate = 16000
+            hparams.max_decoder_steps = 600
+        self.hparams = hparams
         hp = self.hparams
         self.stft = TacotronSTFT(hp.filter_length, hp.hop_length, hp.win_length, hp.n_mel_channels,
                                  hp.sampling_rate, hp.mel_fmin, hp.mel_fmax)
@@ -46,12 +50,28 @@ class Synthesizer(object):
         suffix = filelist_path.rsplit('_', 1)[1].split('.')[0] if '_' in filelist_path else 'refs'
         return os.path.join(os.path.dirname(checkpoint_path), os.path.basename(checkpoint_path) + '_' + suffix + '.npz')
 
-    def load(self, checkpoint_path, vocoder=None, filelist_path='./web/static/uploads/koemo_spk_emo_all_test.txt'):
-        """vocoder: optional callable mel -> audio (the reference loads a WaveGlow checkpoint here)."""
+    def load(self, checkpoint_path, waveglow_path=None, vocoder=None,
+             filelist_path='./web/static/uploads/koemo_spk_emo_all_test.txt'):
+        """Positional order of the reference (synthesizer.py:74: `load(checkpoint_path, waveglow_path)`, called from
+        app.py:161).  waveglow_path: a WaveGlow checkpoint `{'model': module}` exactly as the reference loads it
+        (needs the `waveglow` package importable: it is an un-vendored submodule of the reference); `vocoder`: any
+        callable mel (1,80,T) -> audio instead.  A callable passed in the second position is taken as the vocoder."""
         from train import load_model
         self.model = load_model(self.hparams)
         self.model.load_state_dict(torch.load(checkpoint_path, map_location='cpu')['state_dict'])
         self.model.eval()
+        if callable(waveglow_path) and vocoder is None:
+            vocoder, waveglow_path = waveglow_path, None
+        self.waveglow = None
+        if waveglow_path is not None:
+            try:
+                self.waveglow = torch.load(waveglow_path, map_location='cpu', weights_only=False)['model'].cuda()
+            except Exception as e:
+                raise RuntimeError("cannot load the WaveGlow checkpoint %r (the reference's vocoder is an un-vendored "
+                                   "submodule; its package must be importable): %s" % (waveglow_path, e))
+            if vocoder is None:
+                waveglow = self.waveglow
+                vocoder = lambda mel: waveglow.infer(mel, sigma=0.666)      # reference synthesizer.py:163
         self.vocoder = vocoder
         npz_path = self.centroid_cache_path(checkpoint_path, filelist_path)
         if os.path.exists(npz_path):

@@ -57,7 +57,7 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_pack_l
            't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_conv1d_dw_scratch_floats', 't2v_gemm_bf16', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
            't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats',
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_fuse_location_weights', 't2v_decoder_qp_floats',
-           't2v_set_step_params', 't2v_decoder_replay_bwd_kernels', 't2v_embedding_fwd', 't2v_embedding_bwd', 't2v_gemm_f32_splitk', 't2v_gemm_splitk_scratch_floats',
+           't2v_set_step_params', 't2v_set_step_params_stream', 't2v_decoder_replay_bwd_kernels', 't2v_embedding_fwd', 't2v_embedding_bwd', 't2v_gemm_f32_splitk', 't2v_gemm_splitk_scratch_floats',
            't2v_decoder_infer_persistent', 't2v_decoder_persist_supported', 't2v_decoder_persist_granules',
            't2v_attn_bwd_slices', 't2v_colsum', 't2v_colsum_scratch_floats', 't2v_gemm_epilogue_bwd')
 
@@ -107,6 +107,7 @@ def load_library():
     lib.t2v_colsum_scratch_floats.restype = C.c_long
     lib.t2v_set_step_params.argtypes = [C.c_void_p]
     lib.t2v_set_step_params.restype = None
+    lib.t2v_set_step_params_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.t2v_mel_frontend.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,
                                      C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -212,17 +213,25 @@ def mm_mixed(a, b):
 # Adam lr / bias corrections, KL weight).  Host values go through a ring of pinned slots: the H2D copy is asynchronous
 # and the host runs ahead of the GPU, so a slot must not be rewritten before its copy has executed.
 class StepParams(object):
+    """One engine's record.  stream=None: installed as the process default (read by launches on any stream that has no
+    binding of its own); stream=<torch.cuda.Stream>: bound to that stream only (t2v_set_step_params_stream), so two engines
+    in one process never share a record."""
     RING = 256
     FIELDS = {'lr': 2, 'bc1': 3, 'bc2s': 4, 'kl_weight': 5}
 
-    def __init__(self, device):
+    def __init__(self, device, stream=None):
         lib = load_library()
         self.host = torch.zeros(self.RING, 8, dtype=torch.float32).pin_memory()
         self.dev = torch.zeros(8, dtype=torch.float32, device=device)
         self.cur = dict(epoch=0, lr=0.0, bc1=1.0, bc2s=1.0, kl_weight=0.0)
         self.dirty = True
         self._i = 0
-        lib.t2v_set_step_params(C.c_void_p(self.dev.data_ptr()))
+        self.stream = stream
+        if stream is None:
+            lib.t2v_set_step_params(C.c_void_p(self.dev.data_ptr()))
+        else:
+            _check(lib.t2v_set_step_params_stream(C.c_void_p(stream.cuda_stream), C.c_void_p(self.dev.data_ptr())),
+                   't2v_set_step_params_stream')
 
     def set(self, **kw):
         for k, v in kw.items():
@@ -246,22 +255,46 @@ class StepParams(object):
         self.dev.copy_(slot, non_blocking=True)
         self.dirty = False
 
+    def release(self):
+        lib = load_library()
+        if self.stream is None:
+            lib.t2v_set_step_params(None)
+        else:
+            lib.t2v_set_step_params_stream(C.c_void_p(self.stream.cuda_stream), None)
 
-_STEP = None
+
+_STEP = None          # the ACTIVE record: the one of the engine whose step is being issued (or the process default)
+_STEP_ALL = []
 
 
-def step_params(create=True):
-    """process-wide StepParams singleton (None until a training engine asks for it with create=True)"""
+def step_params(create=True, stream=None, fresh=False):
+    """the active StepParams (None until a training engine asks for one with create=True).  fresh=True: a new record for
+    a new engine (bound to `stream` when given); it becomes the active one."""
     global _STEP
-    if _STEP is None and create:
-        _STEP = StepParams(torch.device('cuda', torch.cuda.current_device()))
+    if (_STEP is None and create) or fresh:
+        _STEP = StepParams(torch.device('cuda', torch.cuda.current_device()), stream=stream)
+        _STEP_ALL.append(_STEP)
     return _STEP
 
 
-def release_step_params():
-    """uninstall the device record (the kernels fall back to their by-value arguments); engines created later install a
-    new one.  Captured graphs of an engine keep reading the old record's memory, which stays allocated with them."""
+def activate_step_params(sp):
+    """an engine calls this at the top of every step: the Python-side helpers (FlatAdam.step, VAELoss, the model's
+    per-forward dropout counters) then talk to THIS engine's record.  A record that is not bound to a stream is also
+    (re)installed as the process default."""
     global _STEP
+    if _STEP is not sp:
+        _STEP = sp
+        if sp is not None and sp.stream is None:
+            load_library().t2v_set_step_params(C.c_void_p(sp.dev.data_ptr()))
+
+
+def release_step_params():
+    """uninstall every device record (the kernels fall back to their by-value arguments); engines created later install
+    new ones.  Captured graphs of an engine keep reading the old record's memory, which stays allocated with them."""
+    global _STEP
+    for sp in _STEP_ALL:
+        sp.release()
+    del _STEP_ALL[:]
     if _STEP is not None:
         load_library().t2v_set_step_params(None)
         _STEP = None
@@ -690,7 +723,17 @@ class InferenceSession(object):
         _check(lib.t2v_decoder_infer_persistent(C.byref(W), C.byref(Bf), self.B, self.T_in, self.max_steps,
                                                 float(gate_threshold), float(p_prenet), int(seed), _stream()),
                't2v_decoder_infer_persistent')
-        _err_note('persistent decode (granule hand-off)', self._perr)
+
+    def persistent_timed_out(self):
+        """True when a bounded spin of the last run_persistent() gave up (the 256 workgroups were not co-resident);
+        synchronises — Decoder.inference reads the stop frame at the same point anyway"""
+        return bool(self._perr.item())
+
+    def reset_for_rerun(self):
+        """after a failed persistent run: the launch-per-stage loop starts again from the zero state (rows 0 of the state
+        arenas are still zero — the persistent kernel keeps its state on chip — and PRE[0] still holds Prenet(go frame))"""
+        self.stop.fill_(self.INT_MAX)
+        self._perr.zero_()
 
     def run(self, t0, t1, gate_threshold, p_prenet, external_prenet, seed):
         _check(load_library().t2v_decoder_infer_steps(C.byref(self.W), C.byref(self.S), self.B, self.T_in, int(t0),

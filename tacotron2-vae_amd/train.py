@@ -95,11 +95,13 @@ class TrainEngine(object):
         if world_size > 1 or force_dist:      # force_dist: 1-rank RCCL group (tests of the launch path on one GPU)
             named, offs = self.optimizer.arena_layout()
             model = self.model
+            # bf16_run exchanges bf16 gradients (57.7 MB per step instead of 115.5 MB) unless fp32_allreduce
+            wire = (torch.bfloat16 if getattr(hparams, 'bf16_run', False) and not getattr(hparams, 'fp32_allreduce', False)
+                    else None)
             self.allreduce = t2v_dist.OverlappedArenaAllReduce(
                 named, offs, self.optimizer.grads, force=bool(force_dist),
                 side_streams=lambda: [st for st in (getattr(model, '_side', None),) if st is not None],
-                gather=self.optimizer.gather_grads)
-        self.step_params = t2v_hip.step_params()
+                gather=self.optimizer.gather_grads, wire_dtype=wire)
         self.use_graph = bool(getattr(hparams, 'graph_step', False) if graph is None else graph)
         # multi-rank graph mode: forward + backward + gradient gather replay as ONE graph, then the whole gradient arena
         # crosses xGMI in one eager all-reduce and the fused clip + Adam runs eagerly (2 launches).  The hook-issued
@@ -112,6 +114,10 @@ class TrainEngine(object):
         # AccumulateGrad nodes remember the stream of their first backward, and a capture that has to synchronise with
         # the legacy default stream is illegal
         self._stream = torch.cuda.Stream() if self.use_graph else None
+        # this engine's device-side step record (dropout epoch, lr, Adam bias corrections, KL weight): bound to the
+        # engine's own stream when it has one, so that two engines in one process never share a record
+        self.step_params = t2v_hip.step_params(fresh=True, stream=self._stream)
+        self.optimizer.step_params = self.step_params
         if self.use_graph and not os.environ.get('T2V_GRAPH_BRANCHES'):
             # one stream from the first eager step on: a branch stream used before the capture would leave its
             # AccumulateGrad nodes behind and fork the captured graph
@@ -135,21 +141,25 @@ class TrainEngine(object):
         opt.gather_grads()
         return loss.detach(), recon.detach(), kl.detach()
 
-    def _reduce_and_step(self, out):
-        """multi-rank graph mode, after the replay: one all-reduce of the arena, then clip + Adam (1/world folded in)"""
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        dist.all_reduce(self.optimizer.grads, op=dist.ReduceOp.SUM, group=self.allreduce.group)
-        e1.record()
-        ex = self.allreduce._exposed
-        ex.append((e0, e1))
-        del ex[:-64]
+    def _reduce_and_step(self, out, no_grad=None):
+        """multi-rank graph mode, after the replay: one all-reduce of the arena, then clip + Adam (1/world folded in).
+        no_grad: the live parameters that had no gradient when this graph was captured (FlatAdam skips them like
+        torch.optim.Adam does; gather_grads() only runs at capture time, so the set travels with the graph)."""
+        self.allreduce.reduce_all()
+        if no_grad is not None:
+            self.optimizer._no_grad = list(no_grad)
         self.optimizer.mark_gathered()
         grad_norm = self.optimizer.step()
         return out[0], out[1], out[2], grad_norm
 
     # -- one iteration, eager
     def _body(self, x, y, iteration):
+        if self.graph_ddp:
+            # eager warm-up / fallback step of the multi-rank graph engine: the SAME single whole-arena all-reduce as a
+            # replayed step.  Ranks choose replay-or-eager from their own batch-shape history (ragged batches: every
+            # rank sees different shapes), so the collective pattern must not depend on that choice — the bucketed
+            # hook-issued exchange below belongs to the eager engine only (ADVICE r2)
+            return self._reduce_and_step(self._body_fb(x, y, iteration))
         opt = self.optimizer
         opt.zero_grad()
         y_pred = self.model(x)
@@ -168,6 +178,8 @@ class TrainEngine(object):
         c = self.criterion
         w = c.kl_anneal_function(c.anneal_function, c.lag, iteration, c.k, c.x0, c.upper)
         sp = self.step_params
+        import t2v_hip
+        t2v_hip.activate_step_params(sp)
         sp.set(epoch=iteration, kl_weight=w if w is not None else 0.0)
         self.optimizer.publish_step_params(sp)
         sp.upload()
@@ -218,15 +230,12 @@ class TrainEngine(object):
             static_buf = torch.empty(lay.nbytes, dtype=torch.uint8, device='cuda')
             lay.upload(batch, into=static_buf)
             x, y = lay.views(static_buf)
-            graph, out = self._capture_static(x, y, iteration)
-            entry = self._graphs[key] = (graph, static_buf, out)
+            graph, out, no_grad = self._capture_static(x, y, iteration)
+            entry = self._graphs[key] = (graph, static_buf, out, no_grad)
         else:
             lay.upload(batch, into=entry[1])
         entry[0].replay()
-        if self.graph_ddp:
-            return self._reduce_and_step(entry[2])
-        self.optimizer.step_count += 1
-        return entry[2]
+        return self._after_replay(entry[2], entry[3])
 
     def _graph_step(self, x, y, iteration):
         import t2v_hip
@@ -240,23 +249,29 @@ class TrainEngine(object):
                 return None
             entry = self._capture(x, y, iteration)
             self._graphs[key] = entry
-        graph, static_in, static_out = entry
+        graph, static_in, static_out, no_grad = entry
         for dst, src in zip(static_in, tensors):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         graph.replay()
+        return self._after_replay(static_out, no_grad)
+
+    def _after_replay(self, static_out, no_grad):
+        """the captured graph writes its scalars (loss, recon, kl[, grad_norm]) into static tensors that the NEXT replay
+        overwrites: hand the caller fresh copies (one small launch), like the eager path does"""
+        vals = torch.cat([t.reshape(1) for t in static_out])
         if self.graph_ddp:
-            return self._reduce_and_step(static_out)
+            return self._reduce_and_step((vals[0], vals[1], vals[2]), no_grad)
         self.optimizer.step_count += 1
-        return static_out
+        return vals[0], vals[1], vals[2], vals[3:4]
 
     def _capture(self, x, y, iteration):
         import t2v_hip
         static_x = tuple(t.clone() if torch.is_tensor(t) else t for t in x)
         static_y = tuple(t.clone() for t in y)
         static_in = [t for t in static_x if torch.is_tensor(t)] + list(static_y)
-        graph, out = self._capture_static(static_x, static_y, iteration)
-        return graph, static_in, out
+        graph, out, no_grad = self._capture_static(static_x, static_y, iteration)
+        return graph, static_in, out, no_grad
 
     def _capture_static(self, static_x, static_y, iteration):
         import t2v_hip
@@ -271,8 +286,9 @@ class TrainEngine(object):
         with torch.cuda.graph(graph, stream=self._stream, capture_error_mode=mode):
             out = (self._body_fb if self.graph_ddp else self._body)(static_x, static_y, iteration)
         self.optimizer.step_count = count0      # capture executes nothing; the replay below is this iteration's step
+        no_grad = list(self.optimizer._no_grad) if self.graph_ddp else None
         t2v_hip.err_pool_pin()
-        return graph, tuple(out)
+        return graph, tuple(out), no_grad
 
 
 def prepare_directories_and_logger(output_directory, log_directory, rank):
@@ -367,29 +383,32 @@ def train(output_directory, log_directory, checkpoint_path, warm_start, n_gpus, 
             iteration += 1
             epoch_offset = max(0, int(iteration / len(train_loader)))
 
-    for epoch in range(epoch_offset, hparams.epochs):
-        print("Epoch: {}".format(epoch))
-        if hasattr(getattr(train_loader, 'batch_sampler', None), 'set_epoch'):
-            train_loader.batch_sampler.set_epoch(epoch)
-        for batch in train_loader:
-            start = time.perf_counter()
-            loss, recon, kl, kl_w, grad_norm = engine.step(batch, iteration, learning_rate)
-            reduced = (t2v_dist.reduce_tensor(loss, n_gpus) if hparams.distributed_run else loss).item()
-            t2v_hip_check()      # the .item() above synced: a cooperative-kernel timeout of this step raises here
-            if not math.isnan(reduced) and rank == 0:
-                duration = time.perf_counter() - start
-                print("Train loss {} {:.6f} Grad Norm {:.6f} {:.2f}s/it".format(
-                    iteration, reduced, grad_norm.item(), duration))
-                if logger is not None:
-                    logger.log_training(reduced, grad_norm.item(), learning_rate, duration, recon.item(), kl.item(),
-                                        kl_w, iteration)
-            if iteration % hparams.iters_per_checkpoint == 0:
-                validate(model, criterion, valset, iteration, hparams.batch_size, n_gpus, collate_fn, logger,
-                         hparams.distributed_run, rank)
-                if rank == 0:
-                    save_checkpoint(model, optimizer, learning_rate, iteration,
-                                    os.path.join(output_directory, "checkpoint_{}".format(iteration)))
-            iteration += 1
+    # the whole loop runs on the engine's stream (graph_step, the default): a step then needs no hand-over with the
+    # caller's stream (≈1.7 ms per step otherwise) and `python train.py` delivers what bench.py measures
+    with engine.stream_context():
+        for epoch in range(epoch_offset, hparams.epochs):
+            print("Epoch: {}".format(epoch))
+            if hasattr(getattr(train_loader, 'batch_sampler', None), 'set_epoch'):
+                train_loader.batch_sampler.set_epoch(epoch)
+            for batch in train_loader:
+                start = time.perf_counter()
+                loss, recon, kl, kl_w, grad_norm = engine.step(batch, iteration, learning_rate)
+                reduced = (t2v_dist.reduce_tensor(loss, n_gpus) if hparams.distributed_run else loss).item()
+                t2v_hip_check()      # the .item() above synced: a cooperative-kernel timeout of this step raises here
+                if not math.isnan(reduced) and rank == 0:
+                    duration = time.perf_counter() - start
+                    print("Train loss {} {:.6f} Grad Norm {:.6f} {:.2f}s/it".format(
+                        iteration, reduced, grad_norm.item(), duration))
+                    if logger is not None:
+                        logger.log_training(reduced, grad_norm.item(), learning_rate, duration, recon.item(), kl.item(),
+                                            kl_w, iteration)
+                if iteration % hparams.iters_per_checkpoint == 0:
+                    validate(model, criterion, valset, iteration, hparams.batch_size, n_gpus, collate_fn, logger,
+                             hparams.distributed_run, rank)
+                    if rank == 0:
+                        save_checkpoint(model, optimizer, learning_rate, iteration,
+                                        os.path.join(output_directory, "checkpoint_{}".format(iteration)))
+                iteration += 1
     if logger is not None:
         logger.close()
 

@@ -42,5 +42,5 @@ def _no_step_record_leak():
     call kernels directly afterwards must see the by-value arguments again"""
     yield
     mod = sys.modules.get('t2v_hip')
-    if mod is not None and getattr(mod, '_STEP', None) is not None:
+    if mod is not None and (getattr(mod, '_STEP', None) is not None or getattr(mod, '_STEP_ALL', None)):
         mod.release_step_params()

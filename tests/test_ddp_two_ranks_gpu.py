@@ -1,0 +1,208 @@
+"""The REAL training engine with two data-parallel ranks (reference distributed.py:126-174, train.py:31-50,59-60).
+
+Two processes share the one GPU of the test box; the process group is gloo (RCCL refuses two ranks on one device), whose
+collectives on device tensors are staged through host memory by `distributed.all_reduce_sum / broadcast` — the SEMANTICS
+of the exchange are what is pinned here, the transport is RCCL in production (`bench.py --gpus N`, 1-rank RCCL run in
+test_train_plumbing_gpu.py).  Each rank runs `TrainEngine(world_size=2)` on its own 3-utterance shard, in both engines:
+
+  eager  : bucketed all-reduce issued from the backward hooks (OverlappedArenaAllReduce), then fused clip + Adam
+  graph  : forward + backward replay as one HIP graph, ONE all-reduce of the arena, fused clip + Adam
+
+and checks what data parallelism promises:
+  * `load_model` broadcast: all 142 state tensors equal rank 0's although the ranks were seeded differently;
+  * the gradient arena after the exchange == g_rank0 + g_rank1 of two single-process backward passes (per-rank
+    BatchNorm statistics and a per-rank KL *sum*), to fp32 round-off;
+  * the update is Adam on the MEAN gradient (1/world folded into the fused clip + Adam kernel);
+  * weights stay bit-identical on the two ranks over several steps, dead parameters are never touched;
+  * ranks that see DIFFERENT batch shapes (one replays its captured graph, the other runs eagerly) issue the same
+    collectives and stay in lock-step (mismatched collective patterns);
+  * bf16_run exchanges bf16 gradients (half the bytes) and stays in lock-step.
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+T_IN, T_OUT = 20, 36
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, out_dir):
+    for p in (os.path.join(ROOT, 'tacotron2-vae_amd'), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import torch.distributed as dist
+    import distributed as D
+    import hparams as HP
+    import model as M
+    import t2v_hip
+    import train as TR
+    from bench import synthetic_batch
+    torch.cuda.set_device(0)
+    D.init_distributed(backend='gloo', timeout_s=300)
+    graph = mode in ('graph', 'ragged')
+    bf16 = mode == 'bf16'
+    extra = ',bf16_run=True' if bf16 else ''
+    hp_ref = HP.create_hparams("batch_size=3,anneal_function=constant" + extra)
+    hp = HP.create_hparams("batch_size=3,anneal_function=constant,distributed_run=True" + extra)
+
+    # a single-process engine of the same weights gives this rank's own gradient (no exchange)
+    torch.manual_seed(hp.seed)
+    ref = TR.TrainEngine(hp_ref, world_size=1, graph=False)
+    init_state = {k: v.detach().clone() for k, v in ref.model.state_dict().items()}
+
+    torch.manual_seed(hp.seed + 17 * rank)          # ranks start from DIFFERENT weights: the broadcast must fix that
+    eng = TR.TrainEngine(hp, world_size=world, graph=graph)
+    res = {'rank': rank}
+    sd = eng.model.state_dict()
+    res['n_state'] = len(sd)
+    res['bcast_equal_rank0_seed'] = all(torch.equal(sd[k].cpu(), init_state[k].cpu()) for k in sd) if rank == 0 else None
+    flat_state = torch.cat([v.detach().reshape(-1).double() for v in sd.values()])
+    g0 = flat_state.cpu().clone()
+    D.broadcast(g0, 0)
+    res['bcast_same_as_rank0'] = bool(torch.equal(g0, flat_state.cpu()))
+    ref.model.load_state_dict({k: v.clone() for k, v in sd.items()})
+    # the reparameterisation noise is the one torch-RNG draw of a step: fixed, so that the single-process engine and the
+    # DP engine of this rank compute the same local gradient (dropout masks are counter-based: equal by construction)
+    eps = torch.randn(3, 32, generator=torch.Generator().manual_seed(5 + rank)).cuda()
+    ref.model.vae_gst.eps_override = eps
+    eng.model.vae_gst.eps_override = eps
+
+    def batch_for(step):
+        t_out = T_OUT
+        if mode == 'ragged' and rank == 1:
+            t_out = T_OUT - 4 * (step % 3)          # rank 1 never sees a shape three times in a row: it stays eager
+        lens_in = [T_IN, T_IN - 3, T_IN - 7]
+        lens_out = [t_out, t_out - 5, t_out - 9]
+        return synthetic_batch(3, T_IN, t_out, 100 + 10 * rank + step, lens_in=lens_in, lens_out=lens_out)
+
+    dead = {n: p.detach().clone() for n, p in eng.model.named_parameters()
+            if n.startswith(('speaker_embedding.', 'emotion_embedding.')) or n.startswith('vae_gst.ref_encoder.convs.0.weight')
+            or n.startswith('vae_gst.ref_encoder.convs.0.bias')}
+
+    # ---- step 0: own gradient (single-process engine), then the exchanged arena of the DP engine
+    b0 = batch_for(0)
+    x, y = ref.model.parse_batch(b0)
+    ref._publish(0)
+    ref._body_fb(x, y, 0)
+    g_local = ref.optimizer.grads.detach().clone()
+    p_before = eng.optimizer.params.detach().clone()
+    eng.step(b0, 0)
+    torch.cuda.synchronize()
+    g_sum = eng.optimizer.grads.detach().clone()
+    parts = []
+    for r in range(world):
+        t = g_local.cpu().clone()
+        D.broadcast(t, r)
+        parts.append(t)
+    want = parts[0] + parts[1]
+    scale = want.abs().max().item()
+    tol = 2e-2 if bf16 else 2e-5
+    res['grad_sum_err'] = float((g_sum.cpu() - want).abs().max().item() / scale)
+    res['grad_sum_ok'] = res['grad_sum_err'] < tol
+    # the optimiser stepped on the MEAN gradient: replay clip + Adam on a single-process optimiser fed with want / world
+    ref.optimizer.params.copy_(p_before)
+    ref.optimizer.exp_avg.zero_(); ref.optimizer.exp_avg_sq.zero_()
+    ref.optimizer.step_count = 0
+    ref.optimizer.grads.copy_((g_sum / world))
+    ref.optimizer._no_grad = []
+    ref.optimizer.mark_gathered()
+    t2v_hip.activate_step_params(ref.step_params)
+    ref.optimizer.step()
+    torch.cuda.synchronize()
+    res['adam_mean_err'] = float((ref.optimizer.params - eng.optimizer.params).abs().max().item())
+    res['grad_norm_world'] = float(eng.optimizer.grad_norm.item())
+    res['grad_norm_mean'] = float(ref.optimizer.grad_norm.item())
+
+    # ---- more steps (graph mode captures on the third identical shape): ranks stay in lock-step
+    n_steps = 6 if graph else 3
+    losses = []
+    for it in range(1, n_steps):
+        out = eng.step(batch_for(it), it)
+        losses.append(float(out[0].item()))
+    torch.cuda.synchronize()
+    t2v_hip.check_async_errors()
+    res['losses'] = losses
+    res['n_graphs'] = len(eng._graphs)
+    mine = eng.optimizer.params.detach().cpu()
+    other = mine.clone()
+    D.broadcast(other, 0)
+    res['weights_equal_across_ranks'] = bool(torch.equal(mine, other))
+    res['moved'] = float((mine - p_before.cpu()).abs().max().item())
+    cur = dict(eng.model.named_parameters())
+    res['dead_untouched'] = all(torch.equal(cur[n].detach(), v) for n, v in dead.items()) and len(dead) >= 4
+    res['wire_bytes'] = eng.allreduce.wire_bytes()
+    res['arena_bytes'] = eng.optimizer.grads.numel() * 4
+    res['bucket_log'] = list(eng.allreduce.launch_log)
+    res['params_digest'] = float(mine.double().sum().item())
+    torch.save(res, os.path.join(out_dir, 'r%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(mode, tmp_path):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, mode, str(tmp_path)), nprocs=world, join=True)
+    return [torch.load(os.path.join(str(tmp_path), 'r%d.pt' % r), weights_only=False) for r in range(world)]
+
+
+def _common_checks(rs, bf16=False):
+    for r in rs:
+        assert r['n_state'] == 142
+        assert r['bcast_same_as_rank0'], "load_model() must broadcast rank 0's state (distributed.py:132-135)"
+        assert r['grad_sum_ok'], r['grad_sum_err']
+        assert r['adam_mean_err'] < (1e-4 if bf16 else 2e-6), r['adam_mean_err']
+        assert r['weights_equal_across_ranks']
+        assert r['dead_untouched']
+        assert r['moved'] > 1e-4
+        assert all(l == l and abs(l) < 1e4 for l in r['losses'])
+    assert rs[0]['bcast_equal_rank0_seed']
+    assert rs[0]['params_digest'] == rs[1]['params_digest']
+
+
+@pytest.mark.gpu
+def test_two_ranks_eager_bucketed_allreduce(tmp_path):
+    rs = _run('eager', tmp_path)
+    _common_checks(rs)
+    for r in rs:
+        assert r['n_graphs'] == 0
+        assert len(r['bucket_log']) == 4 and any(h for _, h in r['bucket_log'])      # buckets issued from backward hooks
+        assert r['wire_bytes'] == r['arena_bytes'] > 100e6
+
+
+@pytest.mark.gpu
+def test_two_ranks_graph_engine_single_allreduce(tmp_path):
+    rs = _run('graph', tmp_path)
+    _common_checks(rs)
+    for r in rs:
+        assert r['n_graphs'] == 1            # the shape was captured (third time it was seen) and replayed
+        assert r['bucket_log'] == []         # the graph engine never uses the hook-issued buckets, warm-up steps included
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_different_shapes_do_not_mismatch_collectives(tmp_path):
+    rs = _run('ragged', tmp_path)
+    _common_checks(rs)
+    assert rs[0]['n_graphs'] == 1 and rs[1]['n_graphs'] == 0      # rank 0 replays while rank 1 runs eagerly
+
+
+@pytest.mark.gpu
+def test_two_ranks_bf16_run_exchanges_bf16_gradients(tmp_path):
+    rs = _run('bf16', tmp_path)
+    _common_checks(rs, bf16=True)
+    for r in rs:
+        assert r['wire_bytes'] * 2 == r['arena_bytes']

@@ -124,3 +124,54 @@ def test_product_never_imports_oracle():
                 with open(os.path.join(dirpath, fn), encoding='utf-8') as f:
                     src = f.read()
                 assert 't2v_oracle' not in src and 'ref_shims' not in src and '_refimport' not in src, fn
+
+
+def _header_structs():
+    """{struct name: [(field name, is_pointer)]} parsed from include/t2vae.h"""
+    import re
+    text = open(os.path.join(ROOT, 'include', 't2vae.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    out = {}
+    for m in re.finditer(r'typedef struct (\w+) \{(.*?)\} \1;', text, flags=re.S):
+        fields = []
+        for decl in m.group(2).split(';'):
+            decl = decl.strip()
+            if not decl:
+                continue
+            name = re.search(r'(\w+)\s*(\[\d+\])?$', decl).group(1)
+            fields.append((name, '*' in decl))
+        out[m.group(1)] = fields
+    return out
+
+
+def test_ctypes_structs_match_header_in_package_and_integration_stub():
+    """A ctypes.Structure that is one field short passes garbage for the missing member (the INTEGRATION stub
+    lacked t2v_dec_weights.packs_bf16).  Every Structure of t2v_hip.py and every `class X(C.Structure):  # t2v_...` of
+    INTEGRATION.md must list the header's fields, in order, pointers as c_void_p."""
+    import ctypes as C
+    import re
+    import t2v_hip
+    hdr = _header_structs()
+    pairs = {'_DecWeights': 't2v_dec_weights', '_DecTrainBufs': 't2v_dec_train_bufs', '_DecBwdBufs': 't2v_dec_bwd_bufs',
+             '_DecPersistWeights': 't2v_dec_persist_weights', '_DecPersistBufs': 't2v_dec_persist_bufs',
+             '_DecInferBufs': 't2v_dec_infer_bufs'}
+    for cls_name in [n for n in dir(t2v_hip) if isinstance(getattr(t2v_hip, n), type) and issubclass(getattr(t2v_hip, n), C.Structure)
+                     and n != 'Structure']:
+        assert cls_name in pairs or cls_name.lstrip('_') in [k.lstrip('_') for k in pairs] or cls_name.startswith('_Dec'), cls_name
+    for cls_name, sname in list(pairs.items()) + [(n, None) for n in dir(t2v_hip) if n.startswith('_Dec') and n not in pairs]:
+        cls = getattr(t2v_hip, cls_name)
+        if sname is None:
+            sname = getattr(cls, 'C_NAME')
+        want = hdr[sname]
+        got = [(n, t is C.c_void_p) for n, t in cls._fields_]
+        assert got == want, (cls_name, got, want)
+    # the stub a maintainer copies out of INTEGRATION.md
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    stubs = re.findall(r'class (\w+)\(C\.Structure\):\s*#\s*(t2v_\w+)\n(.*?)(?=\nclass |\n\n)', doc, flags=re.S)
+    assert len(stubs) >= 2
+    for cls_name, sname, body in stubs:
+        ns = {'C': C}
+        exec('class %s(C.Structure):\n%s' % (cls_name, body), ns)
+        got = [(n, t is C.c_void_p) for n, t in ns[cls_name]._fields_]
+        assert got == hdr[sname], (cls_name, got, hdr[sname])
+        assert C.sizeof(ns[cls_name]) == C.sizeof(getattr(t2v_hip, {v: k for k, v in pairs.items()}[sname]))

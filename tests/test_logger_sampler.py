@@ -87,4 +87,4 @@ def test_hparams_extensions_do_not_leak_into_reference_values():
     hp = HP.create_hparams("device_frontend=True,bucket_batches=1,batch_size=4")
     assert hp.device_frontend is True and hp.bucket_batches is True and hp.bf16_run is False
     assert 'device_frontend' not in hp.values() and hp.values()['batch_size'] == 4
-    assert set(hp.extensions()) == {'device_frontend', 'bucket_batches', 'bf16_run', 'graph_step'}
+    assert set(hp.extensions()) == {'device_frontend', 'bucket_batches', 'bf16_run', 'graph_step', 'fp32_allreduce'}
