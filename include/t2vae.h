@@ -55,7 +55,8 @@ int t2v_set_step_params_stream(void* stream, const t2v_step_params* dev);
  *              k_att = 1536 (training; prenet term hoisted) or 1792 (inference)
  *   logical Wcat_dec (4096,2560)  = [w_ih_dec | w_hh_dec]
  *   packF_*  : forward tiles,  4096*k_att and 4096*2560 floats
- *   packB_*  : transposed tiles for the backward data-gradient GEMV, 4096*1536 and 4096*2560 floats (may be NULL) */
+ *   packB_*  : transposed tiles for the backward data-gradient GEMV, 4096*1536 and 4096*2560 floats (may be NULL)
+ *   packF_att and packF_dec may BOTH be NULL when only the transposed tiles are wanted (forward on the persistent kernel) */
 int t2v_pack_lstm_weights(const float* w_ih_att, const float* w_hh_att, const float* w_ih_dec,
                           const float* w_hh_dec, int k_att, float* packF_att, float* packF_dec,
                           float* packB_att, float* packB_dec, void* stream);
@@ -120,6 +121,29 @@ long t2v_decoder_qp_floats(int B, int T_in);
 int t2v_decoder_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
                           int B, int T_in, int T_out, float p_att, float p_dec,
                           uint64_t seed, void* stream);
+/* The same forward loop as ONE persistent launch (csrc/decoder_train_persist.hip): 256 workgroups stay resident for all
+ * T_out steps, the LSTM weights of both cells live in registers (read once per pass from the nn.LSTMCell tensors — no
+ * packs), attention_rnn -> attention -> attention_rnn is the only per-step dependency chain (teacher forcing: decoder_rnn
+ * trails one step behind on the same workgroups), and the recurrent state travels between CUs THROUGH a sentinel-filled
+ * copy of the saved activations (`scratch`): a word that is no longer 0xFFFFFFFF has been produced — no tags, no flags,
+ * no grid barrier.  Writes the same arena as t2v_decoder_train_fwd (XS, CA, CD, GA, GD, AL, ACUM, S; QP only supplies
+ * the error word), so t2v_decoder_train_bwd runs on it unchanged; dropout masks are the same counter-based ones, i.e.
+ * the two paths agree to fp32 summation order.  Supported when t2v_decoder_train_persist_supported(B, T_in) != 0:
+ * B <= 6, T_in <= 224, a device with >= 256 CUs that can hold one 512-thread workgroup with this LDS carve per CU.
+ * scratch: t2v_decoder_train_persist_scratch_floats(B, T_in, T_out) floats, 16-byte aligned (filled by the call). */
+typedef struct t2v_dec_train_persist_weights {
+    const float* w_ih_att; const float* w_hh_att;   /* attention_rnn (4096,768) [prenet | ctx], (4096,1024) */
+    const float* w_ih_dec; const float* w_hh_dec;   /* decoder_rnn   (4096,1536) [h_att | ctx], (4096,1024) */
+    const float* bias_dec;  /* (4096) bias_ih + bias_hh of decoder_rnn (attention_rnn's biases are inside gpre) */
+    const float* wq;        /* (128,1024) query_layer weight (model.py:35), NOT transposed */
+    const float* wcomb;     /* t2v_fuse_location_weights output */
+    const float* v;         /* (128) */
+} t2v_dec_train_persist_weights;
+int t2v_decoder_train_persist_supported(int B, int T_in);
+long t2v_decoder_train_persist_scratch_floats(int B, int T_in, int T_out);
+int t2v_decoder_train_fwd_persistent(const t2v_dec_train_persist_weights* w, const t2v_dec_train_bufs* s, float* scratch,
+                                     int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed, void* stream);
+
 /* Measurement aid for bench.py: re-issues only the selected kernels of a finished forward pass on
  * its saved arena (bit0 = k_lstm_fwd256 (both LSTM cells), bit1 = k_attn_fwd),
  * so their average launch duration can be bracketed with events on `stream`.  Results are

@@ -81,7 +81,8 @@ static int pack_lstm_weights_impl(const float* w_ih_att, const float* w_hh_att, 
                                   const float* w_hh_dec, int k_att, float* packF_att, float* packF_dec,
                                   float* packB_att, float* packB_dec, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!w_ih_att || !w_hh_att || !w_ih_dec || !w_hh_dec || !packF_att || !packF_dec) return T2V_ERR_ARG;
+    if (!w_ih_att || !w_hh_att || !w_ih_dec || !w_hh_dec) return T2V_ERR_ARG;
+    if (!packF_att != !packF_dec || (!packF_att && !packB_att && !packB_dec)) return T2V_ERR_ARG;
     if (k_att != T2V_KATT && k_att != T2V_KATT_INF) return T2V_ERR_DIMS;
     const int IH = T2V_PRE + T2V_E;       // 768 input columns of attention_rnn: [prenet | ctx]
     WSrc A, D;
@@ -91,11 +92,11 @@ static int pack_lstm_weights_impl(const float* w_ih_att, const float* w_hh_att, 
     D.p[0] = w_ih_dec; D.ld[0] = T2V_KATT; D.off[0] = 0; D.end[0] = T2V_KATT;
     D.p[1] = w_hh_dec; D.ld[1] = T2V_H;    D.off[1] = 0; D.end[1] = T2V_XW;
     D.p[2] = w_hh_dec; D.ld[2] = T2V_H;    D.off[2] = 0; D.end[2] = T2V_XW;
-    {
+    if (packF_att) {       // NULL (both): the caller runs the forward pass on the persistent kernel, which reads the tensors themselves
         const size_t n = (size_t)T2V_NWG * (k_att / (BF16 ? 32 : 16)) * 64;
         k_pack_fwd<BF16><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(A, k_att, packF_att);
     }
-    {
+    if (packF_dec) {
         const size_t n = (size_t)T2V_NWG * (T2V_XW / (BF16 ? 32 : 16)) * 64;
         k_pack_fwd<BF16><<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(D, T2V_XW, packF_dec);
     }

@@ -74,6 +74,9 @@ class FlatAdam(object):
         self.step_count = 0
         self.step_params = None     # the owning engine's device-side record (train.TrainEngine), else the active one
 
+    def live_params(self):
+        return [p for _, _, p in self._live]
+
     def arena_layout(self):
         """([(name, param)], [offset]) of the live parameters in arena order (for the bucketed all-reduce)"""
         return [(n, p) for _, n, p in self._live], list(self._offsets)

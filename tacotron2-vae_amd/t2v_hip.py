@@ -47,6 +47,12 @@ class _DecPersistBufs(C.Structure):
         'memory', 'pm', 'lengths', 'pre_first', 'MEL', 'GATE', 'AL', 'stop_flag', 'granules', 'err_word')]
 
 
+class _DecTrainPersistWeights(C.Structure):
+    C_NAME = 't2v_dec_train_persist_weights'
+    _fields_ = [(n, C.c_void_p) for n in (
+        'w_ih_att', 'w_hh_att', 'w_ih_dec', 'w_hh_dec', 'bias_dec', 'wq', 'wcomb', 'v')]
+
+
 class _DecInferBufs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         'memory', 'pm', 'lengths', 'XS', 'CA', 'CD', 'QP', 'AL', 'ACUM', 'PRE', 'MEL', 'GATE', 'stop_flag',
@@ -59,7 +65,9 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_pack_l
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_fuse_location_weights', 't2v_decoder_qp_floats',
            't2v_set_step_params', 't2v_set_step_params_stream', 't2v_decoder_replay_bwd_kernels', 't2v_embedding_fwd', 't2v_embedding_bwd', 't2v_gemm_f32_splitk', 't2v_gemm_splitk_scratch_floats',
            't2v_decoder_infer_persistent', 't2v_decoder_persist_supported', 't2v_decoder_persist_granules',
-           't2v_attn_bwd_slices', 't2v_colsum', 't2v_colsum_scratch_floats', 't2v_gemm_epilogue_bwd')
+           't2v_attn_bwd_slices', 't2v_colsum', 't2v_colsum_scratch_floats', 't2v_gemm_epilogue_bwd',
+           't2v_decoder_train_fwd_persistent', 't2v_decoder_train_persist_supported',
+           't2v_decoder_train_persist_scratch_floats')
 
 
 def lib_path():
@@ -90,6 +98,11 @@ def load_library():
     lib.t2v_decoder_train_bwd.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecTrainBufs),
                                           C.POINTER(_DecBwdBufs), C.c_int, C.c_int, C.c_int, C.c_float,
                                           C.c_float, C.c_uint64, C.c_void_p]
+    lib.t2v_decoder_train_fwd_persistent.argtypes = [C.POINTER(_DecTrainPersistWeights), C.POINTER(_DecTrainBufs), C.c_void_p,
+                                                     C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]
+    lib.t2v_decoder_train_persist_supported.argtypes = [C.c_int, C.c_int]
+    lib.t2v_decoder_train_persist_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.t2v_decoder_train_persist_scratch_floats.restype = C.c_long
     lib.t2v_decoder_replay_fwd_kernels.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecTrainBufs), C.c_int,
                                                    C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_int,
                                                    C.c_void_p]
@@ -403,15 +416,16 @@ def replay_bwd_kernels(kernel_mask):
     return T if kernel_mask == 1 else T + 1
 
 
-def pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, k_att, need_bwd, bf16=False):
+def pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, k_att, need_bwd, bf16=False, need_fwd=True):
     """MFMA-fragment tiles of the two decoder LSTM cells, read straight from the nn.LSTMCell tensors.  bf16=True
     (bf16_run, training pass): the same tiles rounded to bf16 — the per-step kernels stream half the bytes."""
     lib = load_library()
     dev = w_ih_att.device
     f32 = dict(device=dev, dtype=torch.float32)
     w_ih_att, w_hh_att, w_ih_dec, w_hh_dec = (_f32c(t.detach()) for t in (w_ih_att, w_hh_att, w_ih_dec, w_hh_dec))
-    packF_att = torch.empty(G4 * k_att, **f32)
-    packF_dec = torch.empty(G4 * XW, **f32)
+    need_fwd = need_fwd or not need_bwd
+    packF_att = torch.empty(G4 * k_att, **f32) if need_fwd else None
+    packF_dec = torch.empty(G4 * XW, **f32) if need_fwd else None
     packB_att = torch.empty(G4 * KATT, **f32) if need_bwd else None
     packB_dec = torch.empty(G4 * XW, **f32) if need_bwd else None
     fn = lib.t2v_pack_lstm_weights_bf16 if bf16 else lib.t2v_pack_lstm_weights
@@ -444,8 +458,21 @@ class DecoderCore(torch.autograd.Function):
     last_bwd = None
     keep_last = False       # bench / tests: keep the (first chunk's) arena of the last forward for replays
 
+    # T2V_TRAIN_PERSISTENT=0 forces the launch-per-step forward; the default takes the one-launch persistent kernel
+    # (csrc/decoder_train_persist.hip) whenever t2v_decoder_train_persist_supported(B, T_in): B <= 6, T_in <= 224
+    persistent = None
+    last_mode = None        # 'persistent' | 'launch-per-step' of the most recent forward chunk (bench / tests)
+
     @staticmethod
-    def _fwd_chunk(lib, gpre, memory, pm, lengths, packs, bias_dec, wqT, wcomb, vv, need_grad, p_att, p_dec, seed, wbf=False):
+    def use_persistent(lib, B, T_in):
+        flag = DecoderCore.persistent
+        if flag is None:
+            flag = os.environ.get('T2V_TRAIN_PERSISTENT', '1') != '0'
+        return bool(flag) and bool(lib.t2v_decoder_train_persist_supported(int(B), int(T_in)))
+
+    @staticmethod
+    def _fwd_chunk(lib, gpre, memory, pm, lengths, packs, bias_dec, wqT, wcomb, vv, need_grad, p_att, p_dec, seed, wbf=False,
+                   raw=None):
         T, B, _ = gpre.shape
         T_in = memory.shape[1]
         f32 = dict(device=gpre.device, dtype=torch.float32)
@@ -464,9 +491,20 @@ class DecoderCore(torch.autograd.Function):
                         _p(wqT), _p(wcomb), _p(vv), int(bool(wbf)))
         Sb = _DecTrainBufs(_p(gpre), _p(memory), _p(pm), _p(lengths), _p(XS), _p(CA), _p(CD), _p(GA), _p(GD),
                            _p(QP), _p(AL), _p(ACUM), _p(S))
+        if raw is not None and DecoderCore.use_persistent(lib, B, T_in):
+            w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, wq = raw
+            scratch = torch.empty(lib.t2v_decoder_train_persist_scratch_floats(B, T_in, T), **f32)
+            PW = _DecTrainPersistWeights(_p(w_ih_att), _p(w_hh_att), _p(w_ih_dec), _p(w_hh_dec), _p(bias_dec), _p(wq),
+                                         _p(wcomb), _p(vv))
+            _check(lib.t2v_decoder_train_fwd_persistent(C.byref(PW), C.byref(Sb), _p(scratch), B, T_in, T, float(p_att),
+                                                        float(p_dec), int(seed), _stream()), 't2v_decoder_train_fwd_persistent')
+            _err_note('decoder forward (persistent kernel hand-off)', QP.view(torch.int32)[B * 256 * A + 31:][:1])
+            DecoderCore.last_mode = 'persistent'
+            return W, Sb, (gpre, memory, pm, lengths, XS, CA, CD, GA, GD, QP, AL, ACUM, S)
         _check(lib.t2v_decoder_train_fwd(C.byref(W), C.byref(Sb), B, T_in, T, float(p_att), float(p_dec),
                                          int(seed), _stream()), 't2v_decoder_train_fwd')
         _err_note('decoder forward (attention exchange)', QP.view(torch.int32)[B * 256 * A + 31:][:1])
+        DecoderCore.last_mode = 'launch-per-step'
         return W, Sb, (gpre, memory, pm, lengths, XS, CA, CD, GA, GD, QP, AL, ACUM, S)
 
     @staticmethod
@@ -487,7 +525,12 @@ class DecoderCore(torch.autograd.Function):
         # no_grad (validate(), inference) nothing is saved and the backward-only buffers are not even allocated
         need_grad = bool(grad_mode) and any(ctx.needs_input_grad)
         wbf = bool(_BF16)
-        packs = pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, KATT, need_grad, bf16=wbf)
+        # the persistent forward reads the nn.LSTMCell tensors themselves; the forward packs are only built when some
+        # chunk takes the launch-per-step path (the transposed packs of the backward are always needed)
+        fwd_persist = all(DecoderCore.use_persistent(lib, min(B, b0 + MAX_DEC_B) - b0, T_in) for b0 in range(0, B, MAX_DEC_B))
+        packs = pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, KATT, need_grad, bf16=wbf,
+                                     need_fwd=not fwd_persist)
+        raw = tuple(_f32c(t.detach()) for t in (w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, wq))
         wqT = wq.detach().t().contiguous()
         bias_dec = _f32c(bias_dec.detach())
         loc_conv, loc_dense, vv = _f32c(loc_conv.detach()), _f32c(loc_dense.detach()), _f32c(v.detach()).view(-1)
@@ -501,7 +544,7 @@ class DecoderCore(torch.autograd.Function):
                 g_c, m_c, pm_c = gpre[:, b0:b1].contiguous(), memory[b0:b1].contiguous(), pm[b0:b1].contiguous()
                 l_c = None if lengths is None else lengths[b0:b1].contiguous()
             chunks.append(DecoderCore._fwd_chunk(lib, g_c, m_c, pm_c, l_c, packs, bias_dec, wqT, wcomb, vv, need_grad,
-                                                 p_att, p_dec, (int(seed) + 7919 * b0) & 0x7FFFFFFFFFFFFFFF, wbf))
+                                                 p_att, p_dec, (int(seed) + 7919 * b0) & 0x7FFFFFFFFFFFFFFF, wbf, raw))
         hcs = [torch.cat((k[4][2:T + 2, :, KATT:], k[4][1:T + 1, :, H:KATT]), 2) for _, _, k in chunks]
         als = [k[10][1:].permute(1, 0, 2) for _, _, k in chunks]
         HC = hcs[0] if len(hcs) == 1 else torch.cat(hcs, 1)

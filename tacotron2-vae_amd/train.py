@@ -137,9 +137,24 @@ class TrainEngine(object):
         opt.zero_grad()
         y_pred = self.model(x)
         loss, recon, kl, w = self.criterion(y_pred, y, iteration)
-        loss.backward()
+        self._backward(loss)
         opt.gather_grads()
         return loss.detach(), recon.detach(), kl.detach()
+
+    def _backward(self, loss):
+        """graph engine: gradients through torch.autograd.grad, NOT loss.backward().  backward() ends in the parameters'
+        AccumulateGrad nodes, and such a node keeps the stream of the forward pass that created it: a forward pass the
+        caller once ran on another stream (model(x) outside step(), with its outputs still alive) would pull the legacy
+        default stream into the capture — which kills the process on this stack.  autograd.grad captures the same
+        gradient tensors at the edges instead (the big weight gradients are still written straight into the arena by the
+        backward kernels) and never runs those nodes; `.grad` is set by hand so gather_grads() finds them."""
+        if not self.use_graph:
+            loss.backward()
+            return
+        params = self.optimizer.live_params()
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        for p, g in zip(params, grads):
+            p.grad = g
 
     def _reduce_and_step(self, out, no_grad=None):
         """multi-rank graph mode, after the replay: one all-reduce of the arena, then clip + Adam (1/world folded in).
@@ -166,7 +181,9 @@ class TrainEngine(object):
         loss, recon, kl, w = self.criterion(y_pred, y, iteration)
         if self.allreduce is not None:
             self.allreduce.begin()
-        loss.backward()
+            loss.backward()         # (a multi-rank engine that reaches this line is the eager one: hook-issued buckets)
+        else:
+            self._backward(loss)
         if self.allreduce is not None:
             self.allreduce.finish()
             opt.mark_gathered()        # every bucket gathered its slice before it went out
