@@ -48,21 +48,30 @@ struct PTArgs {
     const t2v_step_params* step;
     unsigned long long* prof;   // optional: stamps of step T_out/2 (L workgroup 8B: slots 0..7, T workgroup 0: slots 8..15)
 };
+// wall clock (100 MHz, the same counter on every CU): hop latencies between workgroups
+#define PT_WALL(COND, I) do { if (a.prof && (COND) && tid == 0) a.prof[(I)] = wall_clock64(); } while (0)
 #define PT_STAMP(COND, I) do { if (a.prof && (COND) && tid == 0) a.prof[(I)] = __builtin_readcyclecounter(); } while (0)
 
-// 16-byte / 4-byte accesses at agent scope (bypass the CU's vector L1; stores are write-through)
-__device__ __forceinline__ void pt_ld16_issue(f32x4& v, const float* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+// 16-byte / 4-byte accesses at agent scope (sc1: bypass the CU's vector L1, stores are write-through) as raw buffer
+// operations: the compiler tracks their vmcnt itself (an inline-asm load is invisible to its scoreboard — the result
+// registers can be read or copied before the data has landed).  Offsets are BYTES from the buffer base (< 2 GiB).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define PT_SC1 16
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pt_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
-__device__ __forceinline__ void pt_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void pt_st16(float* p, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+__device__ __forceinline__ f32x4 pt_ld16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, PT_SC1);
+    return __builtin_bit_cast(f32x4, v);
 }
-__device__ __forceinline__ void pt_st4(float* p, float v) {
-    __hip_atomic_store((unsigned*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void pt_st16(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)off, 0, PT_SC1);
 }
-__device__ __forceinline__ unsigned pt_ld4(const float* p) {
-    return __hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void pt_st4(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)off, 0, PT_SC1);
+}
+__device__ __forceinline__ unsigned pt_ld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, PT_SC1);
 }
 __device__ __forceinline__ bool pt_valid(f32x4 v, int nw) {      // the first nw words are not the sentinel
     bool ok = __float_as_uint(v[0]) != PT_SENT;
@@ -72,36 +81,42 @@ __device__ __forceinline__ bool pt_valid(f32x4 v, int nw) {      // the first nw
     return ok;
 }
 
-// Gather nk columns [k0, k0 + nk) of all planes of one G row into the LDS state planes.  PER chunks per thread
-// (NP * nk <= PER * 512).  A chunk is valid when the words of the items it carries are all written.  Returns through
-// *flag (LDS, stays 1 unless a spin timed out); the caller syncs before reading X.
+// Gather nk columns [k0, k0 + nk) of all planes of one G row (byte offset row_off) into the LDS state planes.  PER
+// chunks per thread (NP * nk <= PER * 512).  A chunk is valid when the words of the items it carries are all written.
+// Returns through *flag (LDS, stays 1 unless a spin timed out); the caller syncs before reading X.
 template <int PER, int NP>
-__device__ __forceinline__ void pt_gather(f32x4* X, const float* grow, int k0, int nk, int B, unsigned* err, int* flag) {
+__device__ __forceinline__ int pt_gather(f32x4* X, __amdgpu_buffer_rsrc_t rG, unsigned row_off, int k0, int nk, int B, int nap,
+                                         unsigned* err, int* flag, int gap_at = 1 << 30, int gap = 0) {
     const int tid = threadIdx.x;
-    const float* src[PER];
+    unsigned src[PER];
     int dsti[PER], nw[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         int c = tid + PT_THREADS * u;
         const bool on = c < NP * nk;
         c = on ? c : 0;
-        const int pl = c / nk, kk = k0 + (c - pl * nk);
-        src[u] = grow + ((size_t)pl * T2V_XW + kk) * 4;
+        const int pl = c / nk;
+        int kk = k0 + (c - pl * nk);
+        kk += kk >= gap_at ? gap : 0;            // two column segments in one pass: [k0, gap_at) and [gap_at + gap, ..)
+        src[u] = row_off + (unsigned)(pl * T2V_XW + kk) * 16u;
         dsti[u] = on ? pl * T2V_XW + kk : -1;
         nw[u] = min(4, B - 4 * pl);
     }
+    // nap first (s_sleep units of 64 clocks): the caller passes what the previous steps' waits suggested, so that a
+    // known-long wait issues no load at all; then the payload itself is polled — the first round that finds every
+    // word written IS the gather (no separate flag round trip).  Rounds are counted per wave (wave-uniform loop).
+    for (int i = 0; i < nap; i += 8) __builtin_amdgcn_s_sleep(8);
     f32x4 v[PER];
-    unsigned spins = 0;
+    int rounds = 0;
     for (;;) {
 #pragma unroll
-        for (int u = 0; u < PER; ++u) pt_ld16_issue(v[u], src[u]);
-        pt_wait_loads();
+        for (int u = 0; u < PER; ++u) v[u] = pt_ld16(rG, src[u]);
         bool ok = true;
 #pragma unroll
         for (int u = 0; u < PER; ++u) ok = ok && pt_valid(v[u], nw[u]);
-        if (ok) break;
+        if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > PT_SPIN || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        if (++rounds > (int)(PT_SPIN / 4) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
             __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *flag = 0;
             break;
@@ -110,52 +125,195 @@ __device__ __forceinline__ void pt_gather(f32x4* X, const float* grow, int k0, i
 #pragma unroll
     for (int u = 0; u < PER; ++u)
         if (dsti[u] >= 0) X[dsti[u]] = v[u];
+    return rounds;
 }
 
-// one cell's gate pre-activations for the NI items of one plane: acc[u][i] = sum_j w[u][j] * x[kp + 128 j][i], then the
-// 16-lane row sums; lane (lane & 15) == (idx & 15) of every row writes value idx = u * NB + B0 + i, so the 8 row partials
-// of a gate (2 waves x 4 rows) land in red[gate][partial][idx].  One plane at a time keeps 20 (not 30) accumulators live
-// next to the 160 weight registers.
-template <int NJ, int NI, int NB, int B0>
-__device__ __forceinline__ void pt_gemv_plane(const float (&w)[PT_MAXU][NJ], const f32x4* Xp, int kp, float* red) {
-    float acc[PT_MAXU][NI];
-#pragma unroll
-    for (int u = 0; u < PT_MAXU; ++u)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) acc[u][i] = 0.f;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int k = kp + 128 * j;
-        float x[4];
-        if (NI == 4) {
-            const f32x4 x4 = Xp[k];
-            x[0] = x4[0]; x[1] = x4[1]; x[2] = x4[2]; x[3] = x4[3];
-        } else {
-            const float2 x2 = *(const float2*)&Xp[k];
-            x[0] = x2.x; x[1] = x2.y; x[2] = 0.f; x[3] = 0.f;
+// Sparse wait ahead of a bulk gather: threads [0, npoll) each watch ONE word (one per producing workgroup); everybody
+// else parks at the block barrier.  Hundreds of threads per CU polling the payload itself cost the producers' stores and
+// the other consumers' loads (MI355X guide: polling-cost row) — this way a CU issues npoll 4-byte loads per round.
+// nap: s_sleep units (64 clocks each) to spend before the first look — the caller passes what the previous step's wait
+// suggested, so that most of a known-long wait issues no load at all.  Returns the rounds it took.
+__device__ __forceinline__ int pt_wait_words(__amdgpu_buffer_rsrc_t r, unsigned off, int npoll, int nap, unsigned* err, int* flag) {
+    const int tid = threadIdx.x;
+    if (tid < 64)
+        for (int i = 0; i < nap; i += 16) __builtin_amdgcn_s_sleep(16);
+    int rounds = 0;
+    unsigned spins = 0;
+    for (;;) {
+        bool ok = true;
+        if (tid < npoll) ok = pt_ld4(r, off) != PT_SENT;
+        if (__syncthreads_and(ok)) break;
+        ++rounds;
+        if (tid == 0 && (++spins > PT_SPIN / 8 || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = 0;
         }
+        __syncthreads();
+        if (*flag != 1) break;
+    }
+    return rounds;
+}
+
+// acc[u][pair] += w[u] * x[pair] for the 5 unit rows of a thread and the item PAIRS (0,1), (2,3)[, (4,5)] as ONE volatile
+// asm block of packed FMAs.  (a) v_pk_fma_f32 does two fp32 FMAs per lane in the 4 cycles a plain v_fma_f32 needs for one
+// — measured here: the scalar-FMA version of this loop ran at 4.8 cycles per FMA and SIMD — with the weight broadcast to
+// both halves through op_sel (weights of two consecutive k share a register pair: even k = low word, odd k = high word);
+// (b) volatile asm, because left to itself the compiler sinks the (pure) FMAs of the fully unrolled k loop to the end of
+// the function, first loads all operand vectors (80 registers) and then walks one accumulator at a time as a dependent
+// chain — with 160 weight registers live that spills, and the chains stall.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int NB>
+struct PTAcc {
+    static constexpr int NPAIR = NB > 4 ? 3 : 2;
+    f32x2 p[PT_MAXU][NPAIR];
+    __device__ __forceinline__ void clear() {
 #pragma unroll
         for (int u = 0; u < PT_MAXU; ++u)
 #pragma unroll
-            for (int i = 0; i < NI; ++i) acc[u][i] = fmaf(w[u][j], x[i], acc[u][i]);
-        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // keep the operand loads close to their use
+            for (int i = 0; i < NPAIR; ++i) p[u][i] = f32x2{0.f, 0.f};
     }
+};
+template <bool ODD>
+__device__ __forceinline__ void pt_pkfma(PTAcc<6>& acc, f32x2 w0, f32x2 w1, f32x2 w2, f32x2 w3, f32x2 w4, f32x2 x01, f32x2 x23, f32x2 x45) {
+    if (ODD)
+        asm volatile("v_pk_fma_f32 %0, %15, %20, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %1, %15, %21, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %2, %15, %22, %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %3, %16, %20, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %4, %16, %21, %4 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %5, %16, %22, %5 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %6, %17, %20, %6 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %7, %17, %21, %7 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %8, %17, %22, %8 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %9, %18, %20, %9 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %10, %18, %21, %10 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %11, %18, %22, %11 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %12, %19, %20, %12 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %13, %19, %21, %13 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %14, %19, %22, %14 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 : "+v"(acc.p[0][0]), "+v"(acc.p[0][1]), "+v"(acc.p[0][2]), "+v"(acc.p[1][0]), "+v"(acc.p[1][1]), "+v"(acc.p[1][2]), "+v"(acc.p[2][0]), "+v"(acc.p[2][1]), "+v"(acc.p[2][2]), "+v"(acc.p[3][0]), "+v"(acc.p[3][1]), "+v"(acc.p[3][2]), "+v"(acc.p[4][0]), "+v"(acc.p[4][1]), "+v"(acc.p[4][2])
+                 : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(x01), "v"(x23), "v"(x45));
+    else
+        asm volatile("v_pk_fma_f32 %0, %15, %20, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %1, %15, %21, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %2, %15, %22, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %3, %16, %20, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %4, %16, %21, %4 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %5, %16, %22, %5 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %6, %17, %20, %6 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %7, %17, %21, %7 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %8, %17, %22, %8 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %9, %18, %20, %9 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %10, %18, %21, %10 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %11, %18, %22, %11 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %12, %19, %20, %12 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %13, %19, %21, %13 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %14, %19, %22, %14 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 : "+v"(acc.p[0][0]), "+v"(acc.p[0][1]), "+v"(acc.p[0][2]), "+v"(acc.p[1][0]), "+v"(acc.p[1][1]), "+v"(acc.p[1][2]), "+v"(acc.p[2][0]), "+v"(acc.p[2][1]), "+v"(acc.p[2][2]), "+v"(acc.p[3][0]), "+v"(acc.p[3][1]), "+v"(acc.p[3][2]), "+v"(acc.p[4][0]), "+v"(acc.p[4][1]), "+v"(acc.p[4][2])
+                 : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(x01), "v"(x23), "v"(x45));
+}
+template <bool ODD>
+__device__ __forceinline__ void pt_pkfma(PTAcc<4>& acc, f32x2 w0, f32x2 w1, f32x2 w2, f32x2 w3, f32x2 w4, f32x2 x01, f32x2 x23, f32x2) {
+    if (ODD)
+        asm volatile("v_pk_fma_f32 %0, %10, %15, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %1, %10, %16, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %2, %11, %15, %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %3, %11, %16, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %4, %12, %15, %4 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %5, %12, %16, %5 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %6, %13, %15, %6 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %7, %13, %16, %7 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %8, %14, %15, %8 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %9, %14, %16, %9 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 : "+v"(acc.p[0][0]), "+v"(acc.p[0][1]), "+v"(acc.p[1][0]), "+v"(acc.p[1][1]), "+v"(acc.p[2][0]), "+v"(acc.p[2][1]), "+v"(acc.p[3][0]), "+v"(acc.p[3][1]), "+v"(acc.p[4][0]), "+v"(acc.p[4][1])
+                 : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(x01), "v"(x23));
+    else
+        asm volatile("v_pk_fma_f32 %0, %10, %15, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %1, %10, %16, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %2, %11, %15, %2 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %3, %11, %16, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %4, %12, %15, %4 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %5, %12, %16, %5 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %6, %13, %15, %6 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %7, %13, %16, %7 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %8, %14, %15, %8 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %9, %14, %16, %9 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                 : "+v"(acc.p[0][0]), "+v"(acc.p[0][1]), "+v"(acc.p[1][0]), "+v"(acc.p[1][1]), "+v"(acc.p[2][0]), "+v"(acc.p[2][1]), "+v"(acc.p[3][0]), "+v"(acc.p[3][1]), "+v"(acc.p[4][0]), "+v"(acc.p[4][1])
+                 : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(x01), "v"(x23));
+}
+
+// acc += sum_{j in [J0, J1)} w[.][j] * x[kp + 128 j][.]: per k one 16-byte (+ one 8-byte) LDS operand, PT_PF of them in
+// flight; w2[u][j / 2] holds the weights of k-blocks j (even, low word) and j + 1 (high word)
+#define PT_PF 3
+template <int NJ2, int J0, int J1, int NB>
+__device__ __forceinline__ void pt_fma_range(const f32x2 (&w2)[PT_MAXU][NJ2], const f32x4* X, int kp, PTAcc<NB>& acc) {
+    f32x4 xq[PT_PF];
+    f32x2 yq[PT_PF];
+#pragma unroll
+    for (int d = 0; d < PT_PF; ++d) {
+        yq[d] = f32x2{0.f, 0.f};
+        if (J0 + d < J1) {
+            xq[d] = X[kp + 128 * (J0 + d)];
+            if constexpr (NB > 4) yq[d] = *(const f32x2*)&X[T2V_XW + kp + 128 * (J0 + d)];
+        }
+    }
+#pragma unroll
+    for (int j = J0; j < J1; ++j) {
+        const f32x4 xc = xq[(j - J0) % PT_PF];
+        const f32x2 yc = yq[(j - J0) % PT_PF];
+        const f32x2 x01 = {xc[0], xc[1]}, x23 = {xc[2], xc[3]};
+        if (j & 1) pt_pkfma<true>(acc, w2[0][j / 2], w2[1][j / 2], w2[2][j / 2], w2[3][j / 2], w2[4][j / 2], x01, x23, yc);
+        else pt_pkfma<false>(acc, w2[0][j / 2], w2[1][j / 2], w2[2][j / 2], w2[3][j / 2], w2[4][j / 2], x01, x23, yc);
+        if (j + PT_PF < J1) {
+            xq[(j - J0) % PT_PF] = X[kp + 128 * (j + PT_PF)];
+            if constexpr (NB > 4) yq[(j - J0) % PT_PF] = *(const f32x2*)&X[T2V_XW + kp + 128 * (j + PT_PF)];
+        }
+    }
+}
+
+// 16-lane row sums of the 5 x NB accumulators as a TRANSPOSING butterfly: 32 values (index u * NB + b, zero padded) are
+// halved four times — at every stage a lane keeps the half selected by one bit of its lane id and adds its partner's
+// copy of that half (row_mirror, row_half_mirror, quad xor 2, quad xor 1: the partner always differs in the selector
+// bit) — 30 DPP adds + 60 selects instead of 120 dependent DPP adds + 30 masked stores.  Lane c of a row ends with the
+// row sums of values 2c and 2c + 1 and stores them as one float2: red[gate][partial = 2 waves x 4 rows][32].
+#define PT_DPP_F(v, CTRL) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (CTRL), 0xF, 0xF, true))
+template <int NB>
+__device__ __forceinline__ void pt_reduce_store(const PTAcc<NB>& acc, float* red) {
     const int tid = threadIdx.x, lane = tid & 63, g = tid >> 7;
-    const int part = ((tid >> 6) & 1) * 4 + (lane >> 4);
-    float* dst = red + (g * 8 + part) * 32;
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = 0.f;
 #pragma unroll
     for (int u = 0; u < PT_MAXU; ++u)
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int idx = u * NB + B0 + i;
-            const float sm = row16_sum(acc[u][i]);
-            if ((lane & 15) == (idx & 15)) dst[idx] = sm;
+        for (int i = 0; i < PTAcc<NB>::NPAIR; ++i) {
+            v[u * NB + 2 * i] = acc.p[u][i][0];
+            v[u * NB + 2 * i + 1] = acc.p[u][i][1];
         }
-}
-template <int NJ, int NB>
-__device__ __forceinline__ void pt_gemv_all(const float (&w)[PT_MAXU][NJ], const f32x4* X, int kp, float* red) {
-    pt_gemv_plane<NJ, 4, NB, 0>(w, X, kp, red);
-    if constexpr (NB > 4) pt_gemv_plane<NJ, 2, NB, 4>(w, X + T2V_XW, kp, red);
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+    float w16[16], w8[8], w4[4], w2[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float keep = b3 ? v[16 + i] : v[i], send = b3 ? v[i] : v[16 + i];
+        w16[i] = keep + PT_DPP_F(send, 0x140);            // row_mirror
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float keep = b2 ? w16[8 + i] : w16[i], send = b2 ? w16[i] : w16[8 + i];
+        w8[i] = keep + PT_DPP_F(send, 0x141);             // row_half_mirror
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = b1 ? w8[4 + i] : w8[i], send = b1 ? w8[i] : w8[4 + i];
+        w4[i] = keep + PT_DPP_F(send, 0x4E);              // quad_perm [2,3,0,1]
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = b0 ? w4[2 + i] : w4[i], send = b0 ? w4[i] : w4[2 + i];
+        w2[i] = keep + PT_DPP_F(send, 0xB1);              // quad_perm [1,0,3,2]
+    }
+    const int part = ((tid >> 6) & 1) * 4 + (lane >> 4);
+    *(float2*)(red + (g * 8 + part) * 32 + 2 * (lane & 15)) = make_float2(w2[0], w2[1]);
 }
 
 template <int NB>      // 4: B <= 4 (one item plane), 6: B = 5, 6 (two planes)
@@ -166,7 +324,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
     const int wg = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int B = a.B, Tp = a.T_in, T = a.T_out;
     const int NT = 8 * B, NL = T2V_NWG - NT;
-    const size_t grow_f = (size_t)NP * T2V_XW * 4;            // floats per G row
+    const unsigned grow_b = (unsigned)NP * T2V_XW * 16u;      // bytes per G row
+    const __amdgpu_buffer_rsrc_t rG = pt_rsrc(a.G), rE = pt_rsrc(a.EX);
     const int Tcap = (Tp + 15) & ~15;
 
     if (wg >= NT) {
@@ -178,7 +337,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
         const int j = wg - NT;
         const int u0 = (j * T2V_H) / NL, nu = ((j + 1) * T2V_H) / NL - u0;      // 4 or 5 units
         const int g = tid >> 7, kp = tid & 127;
-        float wa[PT_MAXU][PT_JA], wd[PT_MAXU][PT_JD];
+        f32x2 wa[PT_MAXU][PT_JA / 2], wd[PT_MAXU][PT_JD / 2];     // [u][j / 2][j & 1]: weight of k = kp + 128 j
 #pragma unroll
         for (int u = 0; u < PT_MAXU; ++u) {
             const bool on = u < nu;
@@ -187,13 +346,13 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
             for (int jj = 0; jj < PT_JA; ++jj) {          // [h_att | ctx]: weight_hh, then weight_ih columns 256..767
                 const int k = kp + 128 * jj;
                 const float w = jj < 8 ? a.w_hh_att[row * T2V_H + k] : a.w_ih_att[row * (T2V_PRE + T2V_E) + T2V_PRE + (k - T2V_H)];
-                wa[u][jj] = on ? w : 0.f;
+                wa[u][jj / 2][jj & 1] = on ? w : 0.f;
             }
 #pragma unroll
             for (int jj = 0; jj < PT_JD; ++jj) {          // [h_att | ctx | h_dec]: weight_ih, then weight_hh
                 const int k = kp + 128 * jj;
                 const float w = jj < 12 ? a.w_ih_dec[row * T2V_KATT + k] : a.w_hh_dec[row * T2V_H + (k - T2V_KATT)];
-                wd[u][jj] = on ? w : 0.f;
+                wd[u][jj / 2][jj & 1] = on ? w : 0.f;
             }
         }
         for (int i = tid; i < NP * T2V_XW; i += PT_THREADS) X[i] = f32x4{0.f, 0.f, 0.f, 0.f};      // row 0: zero initial states
@@ -208,20 +367,27 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
             for (int r = 0; r < 4; ++r) cst[64 + 32 * r + tid] = a.bias_dec[r * T2V_H + U];
         }
         __syncthreads();
+        int ctx_nap = 0;
+        PTAcc<NB> accA;
+        accA.clear();                  // row 0 is zero: the h_att half of attention_rnn(0) is zero
 
         for (int t = 0; t <= T; ++t) {
             const bool do_att = t < T, do_dec = t >= 1;
-            float* grow = a.G + (size_t)(t + 1) * grow_f;          // row t+1 = [h_att(t) | ctx(t) | h_dec(t-1)]
+            const unsigned grow = (unsigned)(t + 1) * grow_b;      // row t+1 = [h_att(t) | ctx(t) | h_dec(t-1)] (byte offset)
             PT_STAMP(wg == NT && t == T / 2, 0);
-            // ---- attention_rnn(t): X holds row t = [h_att(t-1) | ctx(t-1) | h_dec(t-2)]
+            // ---- attention_rnn(t): X holds row t = [h_att(t-1) | ctx(t-1) | h_dec(t-2)]; the h_att half of the sum was
+            // accumulated into accA before ctx(t-1) arrived (end of the previous iteration), the ctx half is left
             if (do_att) {
                 float gp[4] = {0.f, 0.f, 0.f, 0.f};
                 if (cell_on) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) gp[r] = a.gpre[((size_t)t * B + cb) * T2V_G + r * T2V_H + U];
                 }
-                pt_gemv_all<PT_JA, NB>(wa, X, kp, red);
+                pt_fma_range<PT_JA / 2, 8, PT_JA, NB>(wa, X, kp, accA);
+                pt_reduce_store<NB>(accA, red);
+                PT_STAMP(wg == NT && t == T / 2, 16);
                 __syncthreads();
+                PT_STAMP(wg == NT && t == T / 2, 17);
                 if (wave == 0) {
                     float hd = 0.f;
                     if (cell_on) {
@@ -245,7 +411,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
                         hd = go * tanhf_(c) * t2v_drop_scale(seed, T2V_RNG_ATT_H, t, idx, a.p_att);
                         a.XS[((size_t)(t + 1) * B + cb) * T2V_XW + U] = hd;
                     }
-                    // publish: lane (u, plane) sends the 4 items of its plane as one 16-byte write-through store
+                    // publish FIRST (the write-through store is what attention(t) waits for): lane (u, plane) sends the 4
+                    // items of its plane as one 16-byte store; the saved activations follow
                     const int pu = lane / NP, pp = lane - pu * NP;
                     f32x4 v4;
 #pragma unroll
@@ -254,14 +421,18 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
                         const float x = __shfl(hd, min(pu, PT_MAXU - 1) * NB + min(bb, NB - 1), 64);
                         v4[i] = bb < B ? x : 0.f;
                     }
-                    if (lane < PT_MAXU * NP && pu < nu) pt_st16(grow + ((size_t)pp * T2V_XW + u0 + pu) * 4, v4);
+                    if (lane < PT_MAXU * NP && pu < nu) pt_st16(rG, grow + (unsigned)(pp * T2V_XW + u0 + pu) * 16u, v4);
+                    PT_WALL(wg == NT && t == T / 2, 20);
                 }
             }
             PT_STAMP(wg == NT && t == T / 2, 1);
             // ---- decoder_rnn(t-1): same row (its h_dec(t-2) columns included)
             if (do_dec) {
+                PTAcc<NB> accD;
+                accD.clear();
+                pt_fma_range<PT_JD / 2, 0, PT_JD, NB>(wd, X, kp, accD);
                 __syncthreads();               // attention_rnn's cell threads are done with red
-                pt_gemv_all<PT_JD, NB>(wd, X, kp, red);
+                pt_reduce_store<NB>(accD, red);
                 __syncthreads();
                 if (wave == 0) {
                     float hd = 0.f;
@@ -295,23 +466,39 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
                         const float x = __shfl(hd, min(pu, PT_MAXU - 1) * NB + min(bb, NB - 1), 64);
                         v4[i] = bb < B ? x : 0.f;
                     }
-                    if (t < T && lane < PT_MAXU * NP && pu < nu) pt_st16(grow + ((size_t)pp * T2V_XW + T2V_KATT + u0 + pu) * 4, v4);
+                    if (t < T && lane < PT_MAXU * NP && pu < nu) pt_st16(rG, grow + (unsigned)(pp * T2V_XW + T2V_KATT + u0 + pu) * 16u, v4);
                 }
             } else if (wave == 0) {
                 // t = 0: h_dec(-1) = 0 (XS row 1 was cleared by the reset launch)
                 const int pu = lane / NP, pp = lane - pu * NP;
                 if (lane < PT_MAXU * NP && pu < nu)
-                    pt_st16(grow + ((size_t)pp * T2V_XW + T2V_KATT + u0 + pu) * 4, f32x4{0.f, 0.f, 0.f, 0.f});
+                    pt_st16(rG, grow + (unsigned)(pp * T2V_XW + T2V_KATT + u0 + pu) * 16u, f32x4{0.f, 0.f, 0.f, 0.f});
             }
             if (t == T) break;
             PT_STAMP(wg == NT && t == T / 2, 2);
             __syncthreads();                   // every wave is done reading X (row t)
-            // ---- row t+1 into X: h_att(t) is there (or about to be), h_dec(t-1) follows, ctx(t) comes last
-            pt_gather<(NP * T2V_H + PT_THREADS - 1) / PT_THREADS, NP>(X, grow, 0, T2V_H, B, a.err, flag);
-            PT_STAMP(wg == NT && t == T / 2, 3);
-            pt_gather<(NP * T2V_H + PT_THREADS - 1) / PT_THREADS, NP>(X, grow, T2V_KATT, T2V_H, B, a.err, flag);
-            PT_STAMP(wg == NT && t == T / 2, 4);
-            pt_gather<(NP * T2V_E + PT_THREADS - 1) / PT_THREADS, NP>(X, grow, T2V_H, T2V_E, B, a.err, flag);
+            // ---- row t+1 into X: h_att(t) is there (or about to be), h_dec(t-1) follows, ctx(t) comes last.  Each bulk
+            // gather is preceded by a sparse wait on one word per producer (first unit of every L workgroup / last context
+            // column of every T workgroup); the bulk loads then find their data on the first try almost always
+            {
+                // (both segments in ONE pass — 8 loads of 16 bytes in flight per thread — measured slower: the 32 extra
+                // registers spill next to the 160 weight registers and the cell phases pay for it: 9.2 vs 8.7 us per step)
+                pt_gather<(NP * T2V_H + PT_THREADS - 1) / PT_THREADS, NP>(X, rG, grow, 0, T2V_H, B, 0, a.err, flag);
+                PT_STAMP(wg == NT && t == T / 2, 3);
+                pt_gather<(NP * T2V_H + PT_THREADS - 1) / PT_THREADS, NP>(X, rG, grow, T2V_KATT, T2V_H, B, 0, a.err, flag);
+                PT_STAMP(wg == NT && t == T / 2, 4);
+                __syncthreads();
+                if (flag[0] != 1) return;
+                // the h_att(t) half of attention_rnn(t+1), in the shadow of attention(t)
+                accA.clear();
+                if (t + 1 < T) pt_fma_range<PT_JA / 2, 0, 8, NB>(wa, X, kp, accA);
+                PT_STAMP(wg == NT && t == T / 2, 6);
+                const int rounds = pt_gather<(NP * T2V_E + PT_THREADS - 1) / PT_THREADS, NP>(X, rG, grow, T2V_H, T2V_E, B, ctx_nap, a.err, flag);
+                // adaptive nap: wake up just before the context lands (a poll round is about 16 nap units long)
+                ctx_nap = rounds > 1 ? ctx_nap + 12 * (rounds - 1) : (rounds == 0 ? max(0, ctx_nap - 6) : ctx_nap);
+                PT_WALL(wg == NT && t == T / 2, 23);
+                if (a.prof && wg == NT && t == T / 2 && tid == 0) { a.prof[24] = (unsigned long long)rounds; a.prof[25] = (unsigned long long)ctx_nap; }
+            }
             __syncthreads();
             if (flag[0] != 1) return;
             PT_STAMP(wg == NT && t == T / 2, 5);
@@ -353,57 +540,18 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
     const int len = a.lengths ? a.lengths[ab] : Tp;
     const int mypl = ab >> 2, myw = ab & 3;
     __syncthreads();
+    int h_nap = 0;
 
     for (int t = 0; t < T; ++t) {
-        float* grow = a.G + (size_t)(t + 1) * grow_f;
+        const unsigned grow = (unsigned)(t + 1) * grow_b;
         PT_STAMP(wg == 0 && t == T / 2, 8);
-        // ---- h_att(t) of this item: word myw of 1024 chunks of plane mypl (two per thread)
-        {
-            const float* s0 = grow + ((size_t)mypl * T2V_XW + tid) * 4;
-            f32x4 v0, v1;
-            unsigned spins = 0;
-            for (;;) {
-                pt_ld16_issue(v0, s0);
-                pt_ld16_issue(v1, s0 + PT_THREADS * 4);
-                pt_wait_loads();
-                if (__float_as_uint(v0[myw]) != PT_SENT && __float_as_uint(v1[myw]) != PT_SENT) break;
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > PT_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    flag[0] = 0;
-                    break;
-                }
-            }
-            hx[tid] = v0[myw];
-            hx[tid + PT_THREADS] = v1[myw];
-        }
-        __syncthreads();
-        if (flag[0] != 1) return;
-        PT_STAMP(wg == 0 && t == T / 2, 9);
-        // ---- query slice: thread = (dim d = tid & 15, k part kp = tid >> 4 of 32 k's)
-        {
-            const int d = tid & 15, kq = tid >> 4;
-            const float* wrow = wq_s + d * 1028 + 32 * kq;
-            const float* hp = hx + 32 * kq;
-            float acc = 0.f;
-#pragma unroll
-            for (int i = 0; i < 32; ++i) acc = fmaf(wrow[i], hp[i], acc);
-            qred[kq * 16 + d] = acc;
-        }
-        __syncthreads();
-        if (tid < 16) {
-            float acc = 0.f;
-#pragma unroll
-            for (int i = 0; i < 32; ++i) acc += qred[i * 16 + tid];
-            qv[tid] = acc;
-        }
-        __syncthreads();
-        const float4 q4 = make_float4(qv[4 * g], qv[4 * g + 1], qv[4 * g + 2], qv[4 * g + 3]);
-        // ---- location features (fused filter, K = 64) + partial energies of this slice: wave -> tiles wave, wave + 8
-        float* exw = a.EX + (((size_t)t * B + ab) * 8 + as) * Tcap;
+        // ---- location features of this step's tiles (fused filter, K = 64): they depend on alpha(t-1) only, so they
+        // are evaluated BEFORE h_att(t) arrives (wave -> tiles wave, wave + 8)
+        f32x4 lacc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int jt = wave + 8 * i;
+            lacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (16 * jt < Tp) {
                 float bop[16];
 #pragma unroll
@@ -417,31 +565,87 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
                     l0 = mfma16x4(areg[st], bop[st], l0);
                     l1 = mfma16x4(areg[st + 1], bop[st + 1], l1);
                 }
-                const f32x4 acc = l0 + l1;
+                lacc[i] = l0 + l1;
+            }
+        }
+        // ---- h_att(t) of this item: word myw of the 1024 chunks of plane mypl (two per thread); nap, then poll the payload
+        {
+            const unsigned s0 = grow + (unsigned)(mypl * T2V_XW + tid) * 16u + 4u * (unsigned)myw;
+            float v0, v1;
+            for (int i = 0; i < h_nap; i += 8) __builtin_amdgcn_s_sleep(8);
+            int rounds = 0;
+            for (;;) {
+                v0 = __uint_as_float(pt_ld4(rG, s0));
+                v1 = __uint_as_float(pt_ld4(rG, s0 + PT_THREADS * 16u));
+                if (__all(__float_as_uint(v0) != PT_SENT && __float_as_uint(v1) != PT_SENT)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++rounds > (int)(PT_SPIN / 4) || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    flag[0] = 0;
+                    break;
+                }
+            }
+            h_nap = rounds > 1 ? h_nap + 12 * (rounds - 1) : (rounds == 0 ? max(0, h_nap - 6) : h_nap);
+            PT_WALL(wg == 0 && t == T / 2, 21);
+            if (a.prof && wg == 0 && t == T / 2 && tid == 0) { a.prof[26] = (unsigned long long)rounds; a.prof[27] = (unsigned long long)h_nap; }
+            hx[tid] = v0;
+            hx[tid + PT_THREADS] = v1;
+        }
+        __syncthreads();
+        if (flag[0] != 1) return;
+        PT_STAMP(wg == 0 && t == T / 2, 9);
+        // ---- query slice: thread = (dim d = tid >> 5, k part kq = tid & 31): k = 4 kq + 128 i, 16-byte LDS operands;
+        // 32-lane sum = 16-lane DPP row sum + one cross-row exchange
+        {
+            const int d = tid >> 5, kq = tid & 31;
+            const float* wrow = wq_s + d * 1028 + 4 * kq;
+            const float* hp = hx + 4 * kq;
+            float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 w4 = *(const float4*)(wrow + 128 * i);
+                const float4 h4 = *(const float4*)(hp + 128 * i);
+                acc0 = fmaf(w4.x, h4.x, acc0); acc1 = fmaf(w4.y, h4.y, acc1);
+                acc0 = fmaf(w4.z, h4.z, acc0); acc1 = fmaf(w4.w, h4.w, acc1);
+            }
+            float q = row16_sum(acc0 + acc1);
+            q += __shfl_xor(q, 16, 64);
+            if (kq == 0) qv[d] = q;
+        }
+        __syncthreads();
+        const float4 q4 = *(const float4*)(qv + 4 * g);
+        PT_STAMP(wg == 0 && t == T / 2, 13);
+        // ---- partial energies of this slice
+        const unsigned exw = (unsigned)(((t * B + ab) * 8 + as) * Tcap) * 4u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int jt = wave + 8 * i;
+            if (16 * jt < Tp) {
+                const f32x4 acc = lacc[i];
                 const int jp = 16 * jt + c16;
                 const float4 pm4 = *(const float4*)(pm_s + min(jp, Tp - 1) * 16 + 4 * g);
                 float4 sv;
                 sv.x = tanhf_(q4.x + acc[0] + pm4.x); sv.y = tanhf_(q4.y + acc[1] + pm4.y);
                 sv.z = tanhf_(q4.z + acc[2] + pm4.z); sv.w = tanhf_(q4.w + acc[3] + pm4.w);
-                if (a.S && jp < Tp) *(float4*)(a.S + (((size_t)t * B + ab) * Tp + jp) * T2V_A + 16 * as + 4 * g) = sv;
                 float esum = vr.x * sv.x + vr.y * sv.y + vr.z * sv.z + vr.w * sv.w;
                 esum += __shfl_xor(esum, 16, 64);
                 esum += __shfl_xor(esum, 32, 64);
-                if (g == 0 && jp < Tp) pt_st4(exw + jp, esum);
+                if (g == 0 && jp < Tp) pt_st4(rE, exw + 4u * (unsigned)jp, esum);
+                if (a.S && jp < Tp) *(float4*)(a.S + (((size_t)t * B + ab) * Tp + jp) * T2V_A + 16 * as + 4 * g) = sv;
             }
         }
         PT_STAMP(wg == 0 && t == T / 2, 10);
         // ---- the 8 partials of every position (fixed order), masked softmax
         float ev0 = -INFINITY;
         if (tid < Tp) {
-            const float* e0 = a.EX + ((size_t)t * B + ab) * 8 * Tcap + tid;
+            const unsigned e0 = (unsigned)((t * B + ab) * 8 * Tcap + tid) * 4u;
             unsigned p[8];
             unsigned spins = 0;
             for (;;) {
                 bool ok = true;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    p[i] = pt_ld4(e0 + (size_t)i * Tcap);
+                    p[i] = pt_ld4(rE, e0 + (unsigned)(i * Tcap) * 4u);
                     ok = ok && p[i] != PT_SENT;
                 }
                 if (ok) break;
@@ -456,29 +660,34 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
                              ((__uint_as_float(p[4]) + __uint_as_float(p[5])) + (__uint_as_float(p[6]) + __uint_as_float(p[7])));
             ev0 = tid < len ? ev : -INFINITY;
         }
-        float mloc = ev0;
-        mloc = T2V_DPP_MAX(mloc, 0xB1); mloc = T2V_DPP_MAX(mloc, 0x4E);
-        mloc = T2V_DPP_MAX(mloc, 0x141); mloc = T2V_DPP_MAX(mloc, 0x140);
-        if ((lane & 15) == 0) rsm[tid >> 4] = mloc;
+        PT_STAMP(wg == 0 && t == T / 2, 14);
+        {
+            float mloc = ev0;
+            mloc = T2V_DPP_MAX(mloc, 0xB1); mloc = T2V_DPP_MAX(mloc, 0x4E);
+            mloc = T2V_DPP_MAX(mloc, 0x141); mloc = T2V_DPP_MAX(mloc, 0x140);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            if (lane == 0) rsm[wave] = mloc;
+        }
         __syncthreads();
         if (flag[0] != 1) return;
-        float m = rsm[0];
-#pragma unroll
-        for (int u = 1; u < 32; ++u) m = fmaxf(m, rsm[u]);
-        const float e0v = tid < Tp ? expf(ev0 - m) : 0.f;
-        const float sloc = row16_sum(e0v);
-        if ((lane & 15) == 0) rss[tid >> 4] = sloc;
-        __syncthreads();
-        float ssum = 0.f;
+        float m;
         {
-            float sr[32];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) sr[u] = rss[u];
-#pragma unroll
-            for (int w = 16; w >= 1; w >>= 1)
-#pragma unroll
-                for (int u = 0; u < w; ++u) sr[u] += sr[u + w];
-            ssum = sr[0];
+            const float4 a0 = *(const float4*)rsm, a1 = *(const float4*)(rsm + 4);
+            m = fmaxf(fmaxf(fmaxf(a0.x, a0.y), fmaxf(a0.z, a0.w)), fmaxf(fmaxf(a1.x, a1.y), fmaxf(a1.z, a1.w)));
+        }
+        const float e0v = tid < Tp ? expf(ev0 - m) : 0.f;
+        {
+            float sloc = row16_sum(e0v);
+            sloc += __shfl_xor(sloc, 16, 64);
+            sloc += __shfl_xor(sloc, 32, 64);
+            if (lane == 0) rss[wave] = sloc;
+        }
+        __syncthreads();
+        float ssum;
+        {
+            const float4 a0 = *(const float4*)rss, a1 = *(const float4*)(rss + 4);
+            ssum = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
         }
         const float al = e0v * (1.0f / ssum);
         if (tid < Tp) {
@@ -505,9 +714,10 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
             float acc = 0.f;
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc += cred[u * 64 + tid];
-            pt_st4(grow + ((size_t)mypl * T2V_XW + T2V_H + 64 * as + tid) * 4 + myw, acc);
-            a.XS[((size_t)(t + 1) * B + ab) * T2V_XW + T2V_H + 64 * as + tid] = acc;
+            pt_st4(rG, grow + (unsigned)(mypl * T2V_XW + T2V_H + 64 * as + tid) * 16u + 4u * (unsigned)myw, acc);
+            a.XS[((size_t)(t + 1) * B + ab) * T2V_XW + T2V_H + 64 * as + tid] = acc;       // (after the publish)
         }
+        PT_WALL(wg == 0 && t == T / 2, 22);
         PT_STAMP(wg == 0 && t == T / 2, 12);
     }
 }
@@ -570,6 +780,7 @@ extern "C" int t2v_decoder_train_fwd_persistent(const t2v_dec_train_persist_weig
         !s->memory || !s->pm || !s->XS || !s->CA || !s->CD || !s->QP || !s->AL || !s->ACUM)
         return T2V_ERR_ARG;
     if ((uintptr_t)scratch & 15) return T2V_ERR_ARG;
+    if (pt_g_floats(B, T_out) * 4 >= 0x7fffffffull || pt_ex_floats(B, T_in, T_out) * 4 >= 0x7fffffffull) return T2V_ERR_ARG;   // 31-bit buffer offsets
     // per-pass resets: the sync / error words, the zero initial states of the arena (as t2v_decoder_train_fwd)
     unsigned* sync = (unsigned*)(s->QP + t2v_qp_sync_off(B));
     T2VZeroRegions z;

@@ -464,11 +464,13 @@ class DecoderCore(torch.autograd.Function):
     last_mode = None        # 'persistent' | 'launch-per-step' of the most recent forward chunk (bench / tests)
 
     @staticmethod
-    def use_persistent(lib, B, T_in):
+    def use_persistent(lib, B, T_in, T):
         flag = DecoderCore.persistent
         if flag is None:
             flag = os.environ.get('T2V_TRAIN_PERSISTENT', '1') != '0'
-        return bool(flag) and bool(lib.t2v_decoder_train_persist_supported(int(B), int(T_in)))
+        if not (bool(flag) and bool(lib.t2v_decoder_train_persist_supported(int(B), int(T_in)))):
+            return False
+        return 4 * lib.t2v_decoder_train_persist_scratch_floats(int(B), int(T_in), int(T)) < 2 ** 31 - 1     # 31-bit buffer offsets
 
     @staticmethod
     def _fwd_chunk(lib, gpre, memory, pm, lengths, packs, bias_dec, wqT, wcomb, vv, need_grad, p_att, p_dec, seed, wbf=False,
@@ -491,7 +493,7 @@ class DecoderCore(torch.autograd.Function):
                         _p(wqT), _p(wcomb), _p(vv), int(bool(wbf)))
         Sb = _DecTrainBufs(_p(gpre), _p(memory), _p(pm), _p(lengths), _p(XS), _p(CA), _p(CD), _p(GA), _p(GD),
                            _p(QP), _p(AL), _p(ACUM), _p(S))
-        if raw is not None and DecoderCore.use_persistent(lib, B, T_in):
+        if raw is not None and DecoderCore.use_persistent(lib, B, T_in, T):
             w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, wq = raw
             scratch = torch.empty(lib.t2v_decoder_train_persist_scratch_floats(B, T_in, T), **f32)
             PW = _DecTrainPersistWeights(_p(w_ih_att), _p(w_hh_att), _p(w_ih_dec), _p(w_hh_dec), _p(bias_dec), _p(wq),
@@ -527,7 +529,7 @@ class DecoderCore(torch.autograd.Function):
         wbf = bool(_BF16)
         # the persistent forward reads the nn.LSTMCell tensors themselves; the forward packs are only built when some
         # chunk takes the launch-per-step path (the transposed packs of the backward are always needed)
-        fwd_persist = all(DecoderCore.use_persistent(lib, min(B, b0 + MAX_DEC_B) - b0, T_in) for b0 in range(0, B, MAX_DEC_B))
+        fwd_persist = all(DecoderCore.use_persistent(lib, min(B, b0 + MAX_DEC_B) - b0, T_in, T) for b0 in range(0, B, MAX_DEC_B))
         packs = pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, KATT, need_grad, bf16=wbf,
                                      need_fwd=not fwd_persist)
         raw = tuple(_f32c(t.detach()) for t in (w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, wq))
@@ -923,7 +925,9 @@ class BiLSTM(torch.autograd.Function):
                                       _p(sync), Bc, T, _stream()), 't2v_bilstm_fwd')
             _err_note('BiLSTM forward', sync[2:3])
             chunks.append((b0, b1, gates, cells, sync))
-        ctx.keep = (x, lengths, w_ih, w_ih_r, whh, y, chunks)
+        # (an alias of y, not y itself: the returned tensor gets this node as its grad_fn — keeping it here would tie the
+        # node and its arenas into a reference cycle that only the cyclic GC frees, AccumulateGrad nodes included)
+        ctx.keep = (x, lengths, w_ih, w_ih_r, whh, y.detach(), chunks)
         ctx.dims = (B, T)
         return y
 

@@ -118,6 +118,17 @@ class TrainEngine(object):
         # engine's own stream when it has one, so that two engines in one process never share a record
         self.step_params = t2v_hip.step_params(fresh=True, stream=self._stream)
         self.optimizer.step_params = self.step_params
+        # graph engine: the forward pass of a step runs on SHADOW leaves (p.detach().requires_grad_(): same storage, own
+        # autograd identity) that only this engine ever touches.  An autograd leaf's gradient sink (AccumulateGrad node)
+        # keeps the stream that was current when it was created, and the engine routes gradients to it on that stream
+        # even when torch.autograd.grad only captures them there.  A forward pass the caller once ran on another stream
+        # with its outputs still alive (evaluate, then train) would therefore pull the legacy default stream into the
+        # capture — which kills the process on this stack (found with tests/test_bf16_gpu.py under graph_step=True).
+        self._shadow = self._shadow_live = None
+        if self.use_graph:
+            with torch.cuda.stream(self._stream):
+                self._shadow = {n: p.detach().requires_grad_(True) for n, p in self.model.named_parameters()}
+            self._shadow_live = [self._shadow[n] for n, _ in self.optimizer.arena_layout()[0]]
         if self.use_graph and not os.environ.get('T2V_GRAPH_BRANCHES'):
             # one stream from the first eager step on: a branch stream used before the capture would leave its
             # AccumulateGrad nodes behind and fork the captured graph
@@ -135,25 +146,26 @@ class TrainEngine(object):
     def _body_fb(self, x, y, iteration):
         opt = self.optimizer
         opt.zero_grad()
-        y_pred = self.model(x)
+        y_pred = self._forward(x)
         loss, recon, kl, w = self.criterion(y_pred, y, iteration)
         self._backward(loss)
         opt.gather_grads()
         return loss.detach(), recon.detach(), kl.detach()
 
+    def _forward(self, x):
+        if self._shadow is None:
+            return self.model(x)
+        return torch.func.functional_call(self.model, self._shadow, (x,))
+
     def _backward(self, loss):
-        """graph engine: gradients through torch.autograd.grad, NOT loss.backward().  backward() ends in the parameters'
-        AccumulateGrad nodes, and such a node keeps the stream of the forward pass that created it: a forward pass the
-        caller once ran on another stream (model(x) outside step(), with its outputs still alive) would pull the legacy
-        default stream into the capture — which kills the process on this stack.  autograd.grad captures the same
-        gradient tensors at the edges instead (the big weight gradients are still written straight into the arena by the
-        backward kernels) and never runs those nodes; `.grad` is set by hand so gather_grads() finds them."""
-        if not self.use_graph:
+        """graph engine: gradients of the shadow leaves through torch.autograd.grad (the big weight gradients are still
+        written straight into the arena by the backward kernels: a shadow shares its parameter's storage, so
+        t2v_hip.grad_slot finds the slot); `.grad` of the real parameters is set by hand so gather_grads() finds them."""
+        if self._shadow is None:
             loss.backward()
             return
-        params = self.optimizer.live_params()
-        grads = torch.autograd.grad(loss, params, allow_unused=True)
-        for p, g in zip(params, grads):
+        grads = torch.autograd.grad(loss, self._shadow_live, allow_unused=True)
+        for p, g in zip(self.optimizer.live_params(), grads):
             p.grad = g
 
     def _reduce_and_step(self, out, no_grad=None):
@@ -177,7 +189,7 @@ class TrainEngine(object):
             return self._reduce_and_step(self._body_fb(x, y, iteration))
         opt = self.optimizer
         opt.zero_grad()
-        y_pred = self.model(x)
+        y_pred = self.model(x) if self.allreduce is not None else self._forward(x)
         loss, recon, kl, w = self.criterion(y_pred, y, iteration)
         if self.allreduce is not None:
             self.allreduce.begin()

@@ -12,6 +12,12 @@ print('supported:', lib.t2v_decoder_train_persist_supported(B, T_in), flush=True
 hp = HP.create_hparams(); torch.manual_seed(0)
 dec = M.Decoder(hp).cuda().train()
 dec.p_attention_dropout = dec.p_decoder_dropout = p
+M.drop_rate = 0.0          # Prenet dropout off: its masks are keyed by a per-call counter that differs between the two runs
+zero = os.environ.get('ZERO', '')
+with torch.no_grad():
+    if 'hh' in zero: dec.attention_rnn.weight_hh.zero_()
+    if 'ih' in zero: dec.attention_rnn.weight_ih[:, 256:].zero_()
+    if 'pre' in zero: dec.attention_rnn.weight_ih[:, :256].zero_()
 g = torch.Generator().manual_seed(1)
 mem0 = (torch.randn(B, T_in, 512, generator=g) * 0.5).cuda()
 mels = torch.randn(B, 80, T, generator=g).cuda()
@@ -57,6 +63,20 @@ for n in ('XS', 'CA', 'CD', 'GA', 'GD', 'AL', 'ACUM', 'S'):
         x, y = x[:T + 2], y[:T + 2]
     bad = torch.isnan(y).sum().item()
     print(' arena', n, cmp(x, y), 'nan in persistent:', bad)
+xa, xb = a[3]['XS'], b[3]['XS']
+for t in range(min(T + 2, 6)):
+    print('  XS row', t, 'h_att %.3e ctx %.3e h_dec %.3e' % ((xa[t, :, :1024] - xb[t, :, :1024]).abs().max().item(),
+          (xa[t, :, 1024:1536] - xb[t, :, 1024:1536]).abs().max().item(), (xa[t, :, 1536:] - xb[t, :, 1536:]).abs().max().item()),
+          ' AL %.3e' % ((a[3]['AL'][t] - b[3]['AL'][t]).abs().max().item() if t <= T else -1),
+          ' S %.3e' % ((a[3]['S'][t] - b[3]['S'][t]).abs().max().item() if t < T else -1),
+          ' CA %.3e' % ((a[3]['CA'][t] - b[3]['CA'][t]).abs().max().item() if t <= T else -1),
+          ' GA %.3e' % ((a[3]['GA'][t] - b[3]['GA'][t]).abs().max().item() if t < T else -1))
+ga, gb = a[3]['GA'][1], b[3]['GA'][1]          # (B, 4096)
+d = (ga - gb).abs()
+print('GA[1] err by gate:', [float(d[:, r * 1024:(r + 1) * 1024].max()) for r in range(4)], 'by item:', [float(d[i].max()) for i in range(B)])
+du = d.view(B, 4, 1024).amax((0, 1))
+bad = torch.nonzero(du > 1e-4).flatten().tolist()
+print('bad units: %d of 1024; first %s last %s' % (len(bad), bad[:24], bad[-8:]))
 worst = 0.0
 for n in a[4]:
     d = (a[4][n] - b[4][n]).abs().max().item() / (a[4][n].abs().max().item() + 1e-30)

@@ -21,9 +21,12 @@ with torch.no_grad():
     lib.t2v_set_phase_profile(None)
 pv = prof.cpu().tolist()
 L = pv[0:6]; Tt = pv[8:13]
-print('L role (cycles from step start): A-gemv+publish %d, D-gemv+publish %d, gather h_att %d, gather h_dec %d, gather ctx %d  | step %d'
-      % (L[1] - L[0], L[2] - L[1], L[3] - L[2], L[4] - L[3], L[5] - L[4], L[5] - L[0]))
-print('T role: wait h_att %d, query+energies %d, exchange+softmax %d, context+publish %d | step %d'
-      % (Tt[1] - Tt[0], Tt[2] - Tt[1], Tt[3] - Tt[2], Tt[4] - Tt[3], Tt[4] - Tt[0]))
+print('L role (cycles): A(ctx half)+cell+publish %d, D-gemv+publish %d, gather h_att %d, gather h_dec %d, A(h_att half) %d, gather ctx %d  | step %d'
+      % (L[1] - L[0], L[2] - L[1], L[3] - L[2], L[4] - L[3], pv[6] - L[4], L[5] - pv[6], L[5] - L[0]))
+print('T role: loc + wait h_att %d, query %d, energies+store %d, EX gather %d, softmax %d, context+publish %d | step %d'
+      % (Tt[1] - Tt[0], pv[13] - Tt[1], Tt[2] - pv[13], pv[14] - Tt[2], Tt[3] - pv[14], Tt[4] - Tt[3], Tt[4] - Tt[0]))
+print('  inside A (cycles from step start): own gemv+row sums done %d, barrier passed %d, cell+publish done %d' % (pv[16] - L[0], pv[17] - L[0], L[1] - L[0]))
 print('T start relative to L start (cycles, different CUs: indicative only): %d' % (Tt[0] - L[0]))
+print('wall clock (10 ns units): L publishes h_att -> T sees it: %d ; T sees h_att -> T publishes ctx: %d ; T publishes ctx -> L has ctx: %d' % (pv[21] - pv[20], pv[22] - pv[21], pv[23] - pv[22]))
+print('  L ctx poll rounds %d nap %d ; T h_att poll rounds %d nap %d' % (pv[24], pv[25], pv[26], pv[27]))
 H.check_async_errors()
