@@ -180,9 +180,24 @@ def frontend_bench(B=6, n_samples=102144, reps=20):
                     "(the synthetic batch carries mels, like the reference's collate output)"}
 
 
+def _in_situ_durations():
+    """per-kernel average durations of a traced steady-state step (rocprofv3 --kernel-trace over graph replays of the same
+    command, committed under profiles/ by tools/round_profile.sh): the in-situ counterpart of the replay timings below"""
+    for fn in ('r03_kernel_durations.json', 'r02_kernel_durations.json'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', fn)) as f:
+                return json.load(f), 'profiles/' + fn
+        except Exception:
+            pass
+    return {}, None
+
+
 def roofline_table(B, T_in, T, reps=3):
-    """Event-timed replays of the four per-time-step kernels of the decoder recurrence on the arena of the last step
-    (events on the launch stream = torch's current stream).  Algorithmic bytes: what one launch must move at least."""
+    """Event-timed replays of the per-time-step kernels of the decoder recurrence on the arena of the last step (events
+    on the launch stream = torch's current stream).  Algorithmic bytes: what one launch must move at least.
+    `avg_launch_us` is the duration of back-to-back replays of exactly that kernel (warm caches, no neighbours);
+    `in_situ_us` / `frac_in_situ` come from the committed rocprofv3 trace of the whole step (profiles/), where the kernel
+    runs between its real neighbours — the number to recompute `frac` from."""
     import t2v_hip
     f4 = 4
     lstm_bytes = LSTM_WEIGHT_BYTES
@@ -190,11 +205,23 @@ def roofline_table(B, T_in, T, reps=3):
                            + B * T_in * 128 + 2 * B * T_in + B * 512)                                    # S, al/acum out, ctx
     attn_bwd_bytes = f4 * (2 * B * T_in * 128 + B * T_in * 512 + B * (1536 + 2560 + 1536)                # S r/w, memory, dHC/YD/YA
                            + 2 * B * 4096 + 4 * B * 1024 + 2 * B * 4096 + 1024 * 128 + 8192)             # GA/GD, cells, DGA/DGD, W_q^T, W_comb
+    # the persistent forward: every weight once per PASS, the Prenet term in, every saved activation out
+    persist_bytes = (LSTM_WEIGHT_BYTES + f4 * (128 * 1024 + 16384 + B * T_in * 640)                       # weights, W_q, W_comb, memory + pm
+                     + f4 * T * B * 4096                                                                 # gpre
+                     + f4 * ((T + 2) * B * 2560 + 2 * (T + 1) * B * 1024 + 2 * T * B * 4096              # XS, CA/CD, GA/GD
+                             + 2 * (T + 1) * B * T_in + T * B * T_in * 128))                              # AL/ACUM, S
+    persistent = t2v_hip.DecoderCore.last_mode == 'persistent'
+    legs = []
+    if persistent:
+        legs.append(("k_dec_train_persist", lambda _m: t2v_hip.replay_persistent_forward(), 0, persist_bytes, 1))
+    else:
+        legs.append(("k_lstm_fwd256", t2v_hip.replay_fwd_kernels, 1, lstm_bytes, T + 1))
+        legs.append(("k_attn_fwd", t2v_hip.replay_fwd_kernels, 2, attn_fwd_bytes, T))
+    legs.append(("k_lstm_bwd256", t2v_hip.replay_bwd_kernels, 1, lstm_bytes, T))
+    legs.append(("k_attn_cell_bwd", t2v_hip.replay_bwd_kernels, 2, attn_bwd_bytes, T + 1))
+    situ, situ_src = _in_situ_durations()
     rows = []
-    for name, fn, mask, nbytes in (("k_lstm_fwd256", t2v_hip.replay_fwd_kernels, 1, lstm_bytes),
-                                   ("k_lstm_bwd256", t2v_hip.replay_bwd_kernels, 1, lstm_bytes),
-                                   ("k_attn_cell_bwd", t2v_hip.replay_bwd_kernels, 2, attn_bwd_bytes),
-                                   ("k_attn_fwd", t2v_hip.replay_fwd_kernels, 2, attn_fwd_bytes)):
+    for name, fn, mask, nbytes, per_step in legs:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         fn(mask)
         torch.cuda.synchronize()
@@ -206,10 +233,21 @@ def roofline_table(B, T_in, T, reps=3):
         torch.cuda.synchronize()
         us = 1000.0 * ev0.elapsed_time(ev1) / n
         gbs = nbytes / (us * 1e-6) / 1e9
-        rows.append({"kernel": name, "bound": "hbm", "algorithmic_bytes_per_launch": int(nbytes),
-                     "avg_launch_us": round(us, 3), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(gbs / HBM_PEAK_GBS, 4), "launches_per_step": T + (1 if name in ("k_lstm_fwd256", "k_attn_cell_bwd") else 0),
-                     "launches_timed": n})
+        row = {"kernel": name, "bound": "hbm", "algorithmic_bytes_per_launch": int(nbytes),
+               "avg_launch_us": round(us, 3), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(gbs / HBM_PEAK_GBS, 4), "launches_per_step": per_step, "launches_timed": n,
+               "timing": "HIP events around back-to-back replays of this kernel alone"}
+        if name in situ:
+            row["in_situ_us"] = situ[name]
+            row["frac_in_situ"] = round(nbytes / (situ[name] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            row["in_situ_source"] = situ_src
+        if name == "k_dec_train_persist":
+            row["us_per_time_step"] = round(us / T, 3)
+            row["note"] = ("ONE launch for all %d time steps: a chain of dependent hand-offs between CUs (attention_rnn -> "
+                           "attention -> attention_rnn), latency-bound by construction; its 67 MB of LSTM weights are read "
+                           "once per pass into registers instead of once per step" % T)
+        rows.append(row)
+    rows.sort(key=lambda r: -r["avg_launch_us"] * r["launches_per_step"])
     return rows
 
 
@@ -268,7 +306,8 @@ def run_workload(args, world, rank, bf16, koemo, steps, warmup, graph):
     res = {"value": round(frames / (elapsed / steps), 1), "ms_per_step": round(ms, 3), "frames_per_step": frames,
            "final_loss": round(final_loss, 5), "step_mode": ("hip-graph replay of forward + backward, then one eager all-reduce and the fused clip + Adam"
                          if getattr(engine, 'graph_ddp', False) else "hip-graph replay") if engine.use_graph else "eager launches",
-           "startup_steps": startup, "batch_per_gpu": bpg}
+           "startup_steps": startup, "batch_per_gpu": bpg,
+           "decoder_forward": t2v_hip.DecoderCore.last_mode}
     if engine.allreduce is not None:
         res["allreduce_exposed_ms"] = round(engine.allreduce.exposed_ms(), 3)
         res["allreduce_buckets"] = [(b[0], 4 * (b[2] - b[1])) for b in engine.allreduce.buckets]
@@ -350,7 +389,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.bf16 else "f32",
         "data": "synthetic",
-        "config": {"workload": WORKLOADS[kind], "step_mode": res["step_mode"], "startup_steps": res["startup_steps"],
+        "config": {"workload": WORKLOADS[kind], "step_mode": res["step_mode"], "decoder_forward": res["decoder_forward"],
+                   "startup_steps": res["startup_steps"],
                    "global_batch": bpg * world, "frames_per_step": res["frames_per_step"],
                    "parallelism": "dp%d" % world},
         "final_loss": res["final_loss"],
@@ -364,28 +404,32 @@ def main():
     if rank == 0:
         # ---- roofline leg: the four per-time-step kernels of the decoder recurrence (87 % of the GPU time of a step)
         rows = roofline_table(bpg, T_IN, T_OUT)
-        top = rows[0]
+        top = rows[0]                   # the kernel with the most time per step
         traffic, tsrc = None, None      # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, corrected)
-        for fn in ('r02_pmc_fetch_size.json', 'r01_pmc_fetch_size.json'):
+        for fn in ('r03_pmc_fetch_size.json', 'r02_pmc_fetch_size.json', 'r01_pmc_fetch_size.json'):
             try:
                 with open(os.path.join(ROOT, 'profiles', fn)) as f:
-                    traffic = json.load(f)["kernels"]["k_lstm_fwd256"]["corrected_bytes_per_launch"]
+                    traffic = json.load(f)["kernels"][top["kernel"]]["corrected_bytes_per_launch"]
                 tsrc = "profiles/%s (separate rocprofv3 --pmc pass, tools/pmc_fetch_size.sh; not measured in this run)" % fn
                 break
             except Exception:
                 pass
         e2e_bytes = 58.9e9   # compulsory bytes of one cfg-2 iteration
-        rec_us = sum(r["avg_launch_us"] for r in rows)
+        rec_us = sum(r["avg_launch_us"] * r["launches_per_step"] for r in rows) / T_OUT
+        stream_rows = [r for r in rows if r["kernel"].startswith("k_lstm_")]
         out["roofline"] = {"kernel": top["kernel"], "bound": "hbm", "achieved": top["achieved"], "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": top["frac"], "traffic": traffic, "traffic_source": tsrc,
                            "avg_launch_us": top["avg_launch_us"],
                            "algorithmic_bytes_per_launch": top["algorithmic_bytes_per_launch"],
                            "launches_timed": top["launches_timed"],
+                           "frac_in_situ": top.get("frac_in_situ"), "in_situ_us": top.get("in_situ_us"),
+                           "in_situ_source": top.get("in_situ_source"),
                            "note": "the 67 MB weight stream of a launch is re-read every time step and is served by the "
                                    "256 MiB Infinity Cache, not by HBM proper; 8 TB/s is the HBM3E peak the guide prices against",
                            "kernels": rows,
+                           "forward_mode": t2v_hip.DecoderCore.last_mode,
                            "recurrence_us_per_time_step": round(rec_us, 2),
-                           "recurrence_hbm_floor_us_per_time_step": round(4 * 0 + 2 * LSTM_WEIGHT_BYTES / (HBM_PEAK_GBS * 1e3), 2),
+                           "recurrence_hbm_floor_us_per_time_step": round(len(stream_rows) * LSTM_WEIGHT_BYTES / (HBM_PEAK_GBS * 1e3), 2),
                            "end_to_end_frac": round(e2e_bytes / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                            if kind == 'headline' else None}
         if not args.no_decode:
@@ -395,7 +439,7 @@ def main():
             sec = {}
             del engine
             t2v_hip.DecoderCore.keep_last = False
-            t2v_hip.DecoderCore.last_call = t2v_hip.DecoderCore.last_bwd = None
+            t2v_hip.DecoderCore.last_call = t2v_hip.DecoderCore.last_bwd = t2v_hip.DecoderCore.last_persist = None
             torch.cuda.empty_cache()
             for name, (b16, ko) in (("koemo", (False, True)), ("bf16", (True, False))):
                 if name == kind:
@@ -422,7 +466,7 @@ def main():
         import gc
         torch.cuda.synchronize()
         dist.barrier()
-        t2v_hip.DecoderCore.last_call = t2v_hip.DecoderCore.last_bwd = None
+        t2v_hip.DecoderCore.last_call = t2v_hip.DecoderCore.last_bwd = t2v_hip.DecoderCore.last_persist = None
         del engine
         gc.collect()
         torch.cuda.synchronize()

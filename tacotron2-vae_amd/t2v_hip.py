@@ -404,6 +404,18 @@ def replay_fwd_kernels(kernel_mask):
     return T + 1 if kernel_mask == 1 else T
 
 
+def replay_persistent_forward():
+    """Re-issue the persistent forward launch (csrc/decoder_train_persist.hip) of the most recent DecoderCore.forward on
+    its arena — timing only (bench.py roofline leg; needs DecoderCore.keep_last = True).  Returns the launches issued (1)."""
+    if DecoderCore.last_persist is None:
+        raise T2VHipError("replay_persistent_forward: the last forward pass did not run on the persistent kernel (or "
+                          "DecoderCore.keep_last was off)")
+    PW, Sb, scratch, (B, T_in, T, p_att, p_dec, seed), _keep = DecoderCore.last_persist
+    _check(load_library().t2v_decoder_train_fwd_persistent(C.byref(PW), C.byref(Sb), _p(scratch), B, T_in, T, p_att, p_dec,
+                                                           seed, _stream()), 't2v_decoder_train_fwd_persistent')
+    return 1
+
+
 def replay_bwd_kernels(kernel_mask):
     """Re-issue the k_lstm_bwd256 (mask 1) / k_attn_cell_bwd (mask 2) launches of the most recent DecoderCore.backward
     (first batch chunk) on its buffers — timing only (bench.py roofline leg; needs DecoderCore.keep_last = True)."""
@@ -462,6 +474,7 @@ class DecoderCore(torch.autograd.Function):
     # (csrc/decoder_train_persist.hip) whenever t2v_decoder_train_persist_supported(B, T_in): B <= 6, T_in <= 224
     persistent = None
     last_mode = None        # 'persistent' | 'launch-per-step' of the most recent forward chunk (bench / tests)
+    last_persist = None     # keep_last: (weights, bufs, scratch, dims, tensors) of the last persistent forward, for replays
 
     @staticmethod
     def use_persistent(lib, B, T_in, T):
@@ -502,6 +515,8 @@ class DecoderCore(torch.autograd.Function):
                                                         float(p_dec), int(seed), _stream()), 't2v_decoder_train_fwd_persistent')
             _err_note('decoder forward (persistent kernel hand-off)', QP.view(torch.int32)[B * 256 * A + 31:][:1])
             DecoderCore.last_mode = 'persistent'
+            if DecoderCore.keep_last:
+                DecoderCore.last_persist = (PW, Sb, scratch, (B, T_in, T, float(p_att), float(p_dec), int(seed)), raw)
             return W, Sb, (gpre, memory, pm, lengths, XS, CA, CD, GA, GD, QP, AL, ACUM, S)
         _check(lib.t2v_decoder_train_fwd(C.byref(W), C.byref(Sb), B, T_in, T, float(p_att), float(p_dec),
                                          int(seed), _stream()), 't2v_decoder_train_fwd')

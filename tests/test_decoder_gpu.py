@@ -40,7 +40,15 @@ def _oracle(dec, memory, mels, lengths, wm, wg):
                                                (20, 33, 3, list(range(33, 13, -1))), (2, 1000, 2, [1000, 700]),
                                                # very short texts: fewer positions than one 16-position tile / one position
                                                (2, 5, 3, [5, 1]), (1, 1, 2, [1]), (2, 16, 2, [16, 15])])
-def test_decoder_core_matches_oracle(B, T_in, T_out, lens):
+@pytest.mark.parametrize("engine", ["persistent", "launch-per-step"])
+def test_decoder_core_matches_oracle(B, T_in, T_out, lens, engine, monkeypatch):
+    """both forward engines against the oracle: the one-launch persistent kernel (csrc/decoder_train_persist.hip: B <= 6,
+    T_in <= 224) and the launch-per-step loop (any shape); the hand-written BPTT runs on the arena either of them saved"""
+    import t2v_hip
+    persistent_ok = B <= 6 and T_in <= 224
+    if engine == "persistent" and not persistent_ok:
+        pytest.skip("outside the persistent kernel's range: the launch-per-step loop serves this shape")
+    monkeypatch.setattr(t2v_hip.DecoderCore, 'persistent', engine == "persistent")
     hp, M, dec, memory, mels, lengths, wm, wg = _setup(B, T_in, T_out, lens)
     o_mel, o_gate, o_align, o_sd, o_mem = _oracle(dec, memory, mels, lengths, wm, wg)
 
@@ -50,9 +58,11 @@ def test_decoder_core_matches_oracle(B, T_in, T_out, lens):
     dec.p_decoder_dropout = 0.0
     mem = memory.to(dev).requires_grad_(True)
     mel, gate, align = dec(mem, mels.to(dev), lengths.to(dev))
+    assert t2v_hip.DecoderCore.last_mode == engine
     loss = (mel * wm.to(dev)).sum() + (gate * wg.to(dev)).sum()
     loss.backward()
     torch.cuda.synchronize()
+    t2v_hip.check_async_errors()
 
     # forward tolerance: fp32, different summation order through T_out recurrent steps
     assert (mel.cpu() - o_mel).abs().max().item() < 2e-4

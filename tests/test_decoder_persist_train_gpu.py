@@ -1,0 +1,92 @@
+"""The one-launch persistent teacher-forced decoder forward (csrc/decoder_train_persist.hip) against the launch-per-step
+loop (decoder_fwd.hip + attn_fwd.hip) on the same inputs, state dropout ON: both draw the same counter-based masks, so
+every saved array of the arena (XS, CA, CD, GA, GD, AL, ACUM, S) and every gradient of the shared backward pass must
+agree to fp32 summation order — the persistent path is a re-scheduling of the same arithmetic (reference loop
+model.py:415-421), not an approximation."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ('gpre', 'memory', 'pm', 'lengths', 'XS', 'CA', 'CD', 'GA', 'GD', 'QP', 'AL', 'ACUM', 'S')
+
+
+def _run(dec, mode, mem0, mels, lens, T):
+    import t2v_hip as H
+    H.DecoderCore.persistent = mode
+    dec._calls = 0
+    for q in dec.parameters():
+        q.grad = None
+    mem = mem0.clone().requires_grad_(True)
+    mel, gate, al = dec(mem, mels, lens)
+    used = H.DecoderCore.last_mode
+    keep = H.DecoderCore.last_call[3]
+    arena = {n: keep[i].clone() for i, n in enumerate(NAMES) if torch.is_tensor(keep[i]) and n in ('XS', 'CA', 'CD', 'GA', 'GD', 'AL', 'ACUM', 'S')}
+    (mel.sum() + 0.3 * gate.sum() + 0.01 * (mel * mel).sum()).backward()
+    torch.cuda.synchronize()
+    H.check_async_errors()
+    grads = {n: q.grad.clone() for n, q in dec.named_parameters() if q.grad is not None}
+    grads['memory'] = mem.grad.clone()
+    return used, mel.detach(), gate.detach(), al.detach(), arena, grads
+
+
+@pytest.mark.parametrize("B,T_in,T,ragged", [(6, 84, 40, False), (6, 84, 25, True), (1, 5, 7, False), (2, 16, 9, True),
+                                             (4, 84, 12, True), (5, 130, 8, True), (6, 224, 5, True), (3, 200, 6, True),
+                                             (6, 1, 4, False)])
+def test_persistent_forward_equals_launch_per_step(B, T_in, T, ragged):
+    import hparams as HP
+    import model as M
+    import t2v_hip as H
+    assert H.load_library().t2v_decoder_train_persist_supported(B, T_in) == 1
+    old_drop, old_keep, old_mode = M.drop_rate, H.DecoderCore.keep_last, H.DecoderCore.persistent
+    M.drop_rate = 0.0           # Prenet dropout is keyed by a per-call counter; the LSTM state dropout below stays ON
+    H.DecoderCore.keep_last = True
+    try:
+        torch.manual_seed(0)
+        dec = M.Decoder(HP.create_hparams()).cuda().train()
+        dec.p_attention_dropout = dec.p_decoder_dropout = 0.1
+        g = torch.Generator().manual_seed(1)
+        mem0 = (torch.randn(B, T_in, 512, generator=g) * 0.5).cuda()
+        mels = torch.randn(B, 80, T, generator=g).cuda()
+        lens = torch.tensor([max(1, T_in - 7 * i) for i in range(B)] if ragged else [T_in] * B).cuda()
+        a = _run(dec, False, mem0, mels, lens, T)
+        b = _run(dec, True, mem0, mels, lens, T)
+        assert a[0] == 'launch-per-step' and b[0] == 'persistent'
+        for i, name in ((1, 'mel'), (2, 'gate'), (3, 'alignments')):
+            assert (a[i] - b[i]).abs().max().item() < 2e-6, name
+        for n in a[4]:
+            x, y = a[4][n], b[4][n]
+            if n == 'XS':               # row T+1 carries h_dec(T-1) only; its other columns are never written
+                x, y = torch.cat((x[:T + 1].flatten(), x[T + 1][:, 1536:].flatten())), torch.cat((y[:T + 1].flatten(), y[T + 1][:, 1536:].flatten()))
+            assert not torch.isnan(y).any(), n
+            assert (x - y).abs().max().item() < 5e-6 * max(1.0, x.abs().max().item()), n
+        gmax = max(v.abs().max().item() for v in a[5].values())
+        for n in a[5]:
+            scale = a[5][n].abs().max().item()
+            # (T_in = 1: alpha == 1, so the query / location / memory_layer gradients are rounding noise around zero)
+            assert (a[5][n] - b[5][n]).abs().max().item() < 2e-5 * scale + 1e-6 * gmax + 1e-7, (n, scale, gmax)
+    finally:
+        M.drop_rate, H.DecoderCore.keep_last, H.DecoderCore.persistent = old_drop, old_keep, old_mode
+        H.DecoderCore.last_call = H.DecoderCore.last_bwd = None
+
+
+def test_persistent_range_and_fallback():
+    """outside B <= 6 / T_in <= 224 the library says so and the wrapper takes the launch-per-step loop"""
+    import hparams as HP
+    import model as M
+    import t2v_hip as H
+    lib = H.load_library()
+    assert lib.t2v_decoder_train_persist_supported(6, 224) == 1
+    assert lib.t2v_decoder_train_persist_supported(7, 84) == 0
+    assert lib.t2v_decoder_train_persist_supported(6, 225) == 0
+    assert lib.t2v_decoder_train_persist_scratch_floats(6, 84, 400) == 402 * 2 * 2560 * 4 + 400 * 6 * 8 * 96
+    torch.manual_seed(0)
+    dec = M.Decoder(HP.create_hparams()).cuda().train()
+    with torch.no_grad():
+        dec(torch.randn(7, 30, 512, device='cuda'), torch.randn(7, 80, 3, device='cuda'), torch.full((7,), 30, device='cuda'))
+    assert H.DecoderCore.last_mode == 'launch-per-step'
+    with torch.no_grad():
+        dec(torch.randn(2, 30, 512, device='cuda'), torch.randn(2, 80, 3, device='cuda'), torch.full((2,), 30, device='cuda'))
+    assert H.DecoderCore.last_mode == 'persistent'
+    torch.cuda.synchronize()
+    H.check_async_errors()
