@@ -1,7 +1,7 @@
 # Separate PMC-only pass (no --stats / sys-trace): HBM bytes fetched per launch of the dominant kernels.
 # FETCH_SIZE is reported in KB and, on gfx950, counts 64 B per 128-B request for wide coalesced streams:
 # bytes = 2 * 1024 * FETCH_SIZE (MI355X_MICROARCH.md, HBM section).
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmcf -o p -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode --no-secondary --no-graph > /tmp/pmcf.log 2>&1
@@ -14,11 +14,11 @@ for r in csv.DictReader(open(sys.argv[1])):
     if r['Counter_Name'] != 'FETCH_SIZE':
         continue
     n = r['Kernel_Name']
-    for key in ('k_lstm_fwd256', 'k_lstm_bwd256', 'k_attn_fwd', 'k_attn_cell_bwd', 'k_clip_adam', 'k_attn_wgrad_part', 'k_conv5_fwd<5>', 'k_gemm_f32_big'):
+    for key in ('k_dec_train_persist', 'k_lstm_fwd256', 'k_lstm_bwd256', 'k_attn_fwd', 'k_attn_cell_bwd', 'k_clip_adam', 'k_attn_wgrad_part', 'k_conv5_fwd<5>', 'k_gemm_f32_big'):
         if key in n:
             agg[key].append(float(r['Counter_Value']))
 alg = {'k_lstm_fwd256': 67108864, 'k_lstm_bwd256': 67108864, 'k_clip_adam': 462000000}
-out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode --no-secondary --no-graph  (round 2, MI355X, separate PMC-only pass, tools/pmc_fetch_size.sh)",
+out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode --no-secondary --no-graph  (round 3, MI355X, separate PMC-only pass, tools/pmc_fetch_size.sh)",
        "unit_note": "FETCH_SIZE is reported in KB and, on gfx950, counts 64 B per 128-B request for wide coalesced streams: bytes = 2 * 1024 * FETCH_SIZE (MI355X_MICROARCH.md, HBM section)",
        "kernels": {}}
 for k, v in agg.items():

@@ -56,3 +56,16 @@ for t_, d_ in ev:
     depth += d_
     last = t_
 print("time with >= 2 kernels in flight: %.3f ms/step" % (over / nsteps / 1e6))
+
+# ---- machine-readable per-kernel in-situ durations (bench.py's roofline rows read this from profiles/)
+if len(sys.argv) > 4:
+    import json, re
+    def short(n):
+        m = re.match(r'(?:void )?([A-Za-z_0-9]+)', n)
+        return m.group(1) if m else n
+    dur = collections.defaultdict(lambda: [0, 0])
+    for n, (t, c) in agg.items():
+        k = short(n)
+        dur[k][0] += t
+        dur[k][1] += c
+    json.dump({k: round(t / c / 1e3, 3) for k, (t, c) in sorted(dur.items())}, open(sys.argv[4], 'w'), indent=1)
