@@ -197,6 +197,20 @@ int t2v_attn_wgrad(const float* dpre, const float* al, const float* acum, const 
                    int B, int T_in, int T, void* stream);
 
 
+/* ------------------------------------------------------------------ persistent BPTT (csrc/decoder_train_bwd_persist.hip)
+ * The reverse recurrence of the decoder loop as persistent launches for the shapes of the persistent forward
+ * (t2v_decoder_bwd_persist_supported: B <= 6, T_in <= 224, >= 256 CUs).  decoder_rnn's chain does not depend on the
+ * attention path, so it runs first for all steps:
+ *   t2v_decoder_bwd_dchain : dHC[:, :, :1024] (grad wrt h_dec from the projection), GD, CD (saved by the forward pass)
+ *                            -> DGD (T,B,4096), grad wrt decoder_rnn's pre-activations.  256 workgroups x 4 hidden units,
+ *                            W_hh_dec^T in registers; the gate-gradient rows travel between CUs through `scratch`
+ *                            (t2v_decoder_bwd_dchain_scratch_floats(B, T_out) floats, 16-byte aligned, filled by the call).
+ * err_word (1 x uint32, zeroed by the call): != 0 afterwards = a bounded spin timed out. */
+int t2v_decoder_bwd_persist_supported(int B, int T_in);
+long t2v_decoder_bwd_dchain_scratch_floats(int B, int T_out);
+int t2v_decoder_bwd_dchain(const float* w_hh_dec, const float* dHC, const float* GD, const float* CD, float* DGD,
+                           float* scratch, uint32_t* err_word, int B, int T_out, float p_dec, uint64_t seed, void* stream);
+
 /* ------------------------------------------------------------------ free-running decode
  * Decoder.inference (model.py:428-464) == the synthesizer loop (synthesizer.py:139-154): steps
  * t_begin..t_end-1, each = attention_rnn → attention → decoder_rnn → 80-mel/gate projection → Prenet of

@@ -67,7 +67,8 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_pack_l
            't2v_decoder_infer_persistent', 't2v_decoder_persist_supported', 't2v_decoder_persist_granules',
            't2v_attn_bwd_slices', 't2v_colsum', 't2v_colsum_scratch_floats', 't2v_gemm_epilogue_bwd',
            't2v_decoder_train_fwd_persistent', 't2v_decoder_train_persist_supported',
-           't2v_decoder_train_persist_scratch_floats')
+           't2v_decoder_train_persist_scratch_floats', 't2v_decoder_bwd_persist_supported',
+           't2v_decoder_bwd_dchain_scratch_floats', 't2v_decoder_bwd_dchain')
 
 
 def lib_path():
@@ -103,6 +104,10 @@ def load_library():
     lib.t2v_decoder_train_persist_supported.argtypes = [C.c_int, C.c_int]
     lib.t2v_decoder_train_persist_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.t2v_decoder_train_persist_scratch_floats.restype = C.c_long
+    lib.t2v_decoder_bwd_persist_supported.argtypes = [C.c_int, C.c_int]
+    lib.t2v_decoder_bwd_dchain_scratch_floats.argtypes = [C.c_int, C.c_int]
+    lib.t2v_decoder_bwd_dchain_scratch_floats.restype = C.c_long
+    lib.t2v_decoder_bwd_dchain.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_void_p]
     lib.t2v_decoder_replay_fwd_kernels.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecTrainBufs), C.c_int,
                                                    C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_int,
                                                    C.c_void_p]
