@@ -210,6 +210,20 @@ int t2v_decoder_bwd_persist_supported(int B, int T_in);
 long t2v_decoder_bwd_dchain_scratch_floats(int B, int T_out);
 int t2v_decoder_bwd_dchain(const float* w_hh_dec, const float* dHC, const float* GD, const float* CD, float* DGD,
                            float* scratch, uint32_t* err_word, int B, int T_out, float p_dec, uint64_t seed, void* stream);
+/* The WHOLE reverse pass as ONE persistent launch (k_achain_bwd): attention_rnn + attention form the per-step dependency
+ * chain (all-gather dga(t+1) -> Wcat_att^T columns -> d ctx(t) -> attention(t) backward on position-split workgroups ->
+ * dq(t) -> W_q^T, cell backward -> dga(t)); decoder_rnn's chain (cell backward, all-gather of dgd, Wcat_dec^T columns)
+ * runs one step ahead on the same workgroups in the shadow of the attention workgroups.  All transposed LSTM weight
+ * columns live in registers (read once per pass from the nn.LSTMCell tensors).  Same outputs as t2v_decoder_train_bwd:
+ *   DGA, DGD (T,B,4096), DCTX (T,B,512), S overwritten with dpre, DV (B,S,128) per-slice partial dv (sum dims 0,1),
+ *   DQP (T,B,S,128) per-slice partial dq rows (sum over dim 2 = dq of a step), S = t2v_attn_bwd_slices(T_in).
+ * w: the struct of the persistent forward (bias_dec unused); s: the forward pass's arena (gpre, QP unused);
+ * scratch: t2v_decoder_bwd_achain_scratch_floats(B, T_in, T_out) floats, 16-byte aligned; DQP 16-byte aligned. */
+long t2v_decoder_bwd_achain_scratch_floats(int B, int T_in, int T_out);
+int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, const float* reserved, const t2v_dec_train_bufs* s,
+                           const float* dHC, float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
+                           uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
+                           void* stream);
 
 /* ------------------------------------------------------------------ free-running decode
  * Decoder.inference (model.py:428-464) == the synthesizer loop (synthesizer.py:139-154): steps

@@ -333,3 +333,594 @@ extern "C" int t2v_decoder_bwd_dchain(const float* w_hh_dec, const float* dHC, c
     else k_dchain_bwd<4><<<T2V_NWG, PB_THREADS, pbd_lds_bytes(B), stream>>>(a);
     return t2v_check_launch();
 }
+
+// ======================================================================= chain A: attention_rnn + attention, one launch
+// Roles (one workgroup per CU):
+//   T : workgroups [0, B*S) — attention(t) backward of item b, encoder positions [s*JS, s*JS + JS) (the position-split
+//       body of decoder_bwd.hip: softmax / tanh / fused-location-filter backward), operands that do not change over the
+//       pass (memory rows, W_comb^T tile, v) resident in registers, the cumulative-weights gradient resident in LDS.
+//       Runs on the first 256 threads; waves 4..7 only keep the barriers company.
+//   L : the other workgroups — workgroup j owns hidden units [j*1024/NL, ..) (4 or 5) and context columns
+//       [j*512/NL, ..) (2 or 3): their columns of Wcat_att^T (attention_rnn) AND of Wcat_dec^T (decoder_rnn) live in
+//       registers (thread = 8 of the 4096 gate rows, <= 21 columns).  decoder_rnn's chain runs ONE STEP AHEAD in the
+//       shadow of attention(t): cell D(t-1), all-gather of dgd(t-1), D-GEMV(t-1) happen while the T workgroups work.
+// Per reverse step the dependency chain is
+//   all-gather dga(t+1) -> A-GEMV -> [d ctx(t)] -> hop -> attention(t) backward -> [dq(t)] -> hop -> W_q^T dq + cell A(t)
+//   -> [dga(t)] -> all-gather ...
+struct PBAArgs {
+    // weights
+    const float* w_ih_att; const float* w_hh_att; const float* w_ih_dec; const float* w_hh_dec;
+    const float* wq;            // (128,1024)
+    const float* wcomb;         // fused location filter (both copies)
+    const float* v;             // (128)
+    // saved by the forward pass
+    const float* memory; const float* XS; const float* CA; const float* CD; const float* GA; const float* GD; const float* AL;
+    float* S;                   // (T,B,T_in,128) in: tanh outputs, out: dpre
+    const float* dHC;           // (T,B,1536)
+    // outputs
+    float* DGA; float* DGD; float* DCTX; float* DV;       // DV (B,S,128)
+    // exchange (sentinel-filled): gate-gradient rows of both cells, context gradients, dq partials, window partials
+    float* GXA; float* GXD; float* CX; float* DQX; float* GPX;
+    unsigned* err;
+    int B, T_in, T, S_sl;
+    float p_att, p_dec;
+    uint64_t seed;
+    const t2v_step_params* step;
+    unsigned long long* prof;
+};
+#define PBA_STAMP(COND, I) do { if (a.prof && (COND) && threadIdx.x == 0) a.prof[(I)] = __builtin_readcyclecounter(); } while (0)
+
+// context-gradient row of a step in CX: [plane][512 columns][4 items] (16 bytes per column and plane)
+#define PB_CX_ROW_BYTES(NB) ((NB) > 4 ? 16384u : 8192u)
+
+template <int JS>
+__device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds, const int b, const int s, const int NB) {
+    constexpr int NJT = JS / 16;
+    constexpr int PW = JS + 30;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool act = tid < 256;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int B = a.B, Tp = a.T_in, T = a.T, S = a.S_sl, j0 = s * JS;
+    const int Tcap = (Tp + 15) & ~15;
+    const int nown = min(JS, Tp - j0);
+    // ---- LDS carve
+    float* gfull0 = lds;                      // [Tcap]
+    float* gfull1 = gfull0 + Tcap;            // [Tcap]
+    float* alf = gfull1 + Tcap;               // [Tcap]
+    float* gcum = alf + Tcap;                 // [Tcap] running cumulative-weights gradient (this workgroup's copy)
+    float* dctx = gcum + Tcap;                // [512]
+    float* de = dctx + T2V_E;                 // [JS]
+    float* red = de + JS;                     // [1 + JS/4][16]
+    float* dpT = red + (1 + JS / 4) * 16;     // [128][JS+1]
+    float* Tl = dpT + T2V_A * (JS + 1);       // [64][JS+1]
+    float* rq = Tl + 64 * (JS + 1);           // [8][128]
+    float* rv = rq + 8 * T2V_A;               // [8][128]
+    int* flag = (int*)(rv + 8 * T2V_A);
+    const __amdgpu_buffer_rsrc_t rC = pb_rsrc(a.CX), rQ = pb_rsrc(a.DQX), rP = pb_rsrc(a.GPX);
+    const int mypl = b >> 2, myw = b & 3;
+    // ---- operands resident for the whole pass
+    const int d4 = tid & 31, rg = (tid >> 5) & 7;
+    float4 m0[JS / 4], m1[JS / 4];
+    float areg[32];
+    float4 vd4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < JS / 4; ++r) {
+            const int jl = wave + 4 * r;
+            const float* mrow = a.memory + ((size_t)b * Tp + j0 + (jl < nown ? jl : 0)) * T2V_E + lane * 4;
+            m0[r] = *(const float4*)mrow;
+            m1[r] = *(const float4*)(mrow + 256);
+        }
+        const float4* wp = (const float4*)(a.wcomb + T2V_A * 64 + (16 * wave + c16) * 128 + 32 * g);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 w4 = wp[u];
+            areg[4 * u + 0] = w4.x; areg[4 * u + 1] = w4.y; areg[4 * u + 2] = w4.z; areg[4 * u + 3] = w4.w;
+        }
+        vd4 = *(const float4*)(a.v + 4 * d4);
+    }
+    for (int j = tid; j < Tcap; j += PB_THREADS) gcum[j] = 0.f;
+    if (tid == 0) flag[0] = 1;
+    float dvacc = 0.f;                          // tid < 128: running dv[tid] of this slice
+    int nap = 0;
+    __syncthreads();
+
+    for (int t = T - 1; t >= 0; --t) {
+        PBA_STAMP(blockIdx.x == 0 && t == T / 2, 8);
+        // ---- operands that do not wait for the context gradient: tanh outputs, alpha(t), ctx(t), window partials of step t+1
+        float4 sreg[JS / 8];
+        float2 ctx2 = make_float2(0.f, 0.f);
+        if (act) {
+            const float* sp = a.S + (((size_t)t * B + b) * Tp + j0) * T2V_A + 4 * d4;
+#pragma unroll
+            for (int i = 0; i < JS / 8; ++i) {
+                const int jl = rg + 8 * i;
+                sreg[i] = *(const float4*)(sp + (size_t)min(jl, nown - 1) * T2V_A);
+            }
+            ctx2 = *(const float2*)(a.XS + ((size_t)(t + 1) * B + b) * T2V_XW + T2V_H + 2 * tid);
+        }
+        float dot_g = 0.f;
+        for (int j = tid; j < Tp; j += PB_THREADS) {
+            float gp = 0.f, gc = gcum[j];
+            if (t < T - 1) {
+                const int lo = max(0, (j + 15 - PW + JS) / JS), hi = min(S - 1, (j + 15) / JS);
+                for (int sp2 = lo; sp2 <= hi; ++sp2) {
+                    const int jj = j - sp2 * JS + 15;
+                    if (jj < 0 || jj >= PW) continue;
+                    const unsigned off = (unsigned)((((t + 1) * B + b) * S + sp2) * 128 + jj) * 4u;
+                    unsigned x0, x1;
+                    int spins = 0;
+                    for (;;) {          // published at the end of the previous reverse step: almost always there
+                        x0 = pb_ld4(rP, off);
+                        x1 = pb_ld4(rP, off + 256u);
+                        if (x0 != PB_SENT && x1 != PB_SENT) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > PB_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            flag[0] = 0;
+                            break;
+                        }
+                    }
+                    gp += __uint_as_float(x0);
+                    gc += __uint_as_float(x1);
+                }
+            }
+            gcum[j] = gc;
+            gfull0[j] = gp;
+            gfull1[j] = gc;
+            const float al = a.AL[((size_t)(t + 1) * B + b) * Tp + j];
+            alf[j] = al;
+            dot_g = fmaf(al, gp + gc, dot_g);
+        }
+        // ---- the context gradient of this item (one 4-byte word per thread), nap first
+        {
+            const unsigned off = (unsigned)t * PB_CX_ROW_BYTES(NB) + (unsigned)(mypl * T2V_E + tid) * 16u + 4u * (unsigned)myw;
+            for (int i = 0; i < nap; i += 8) __builtin_amdgcn_s_sleep(8);
+            unsigned x;
+            int rounds = 0;
+            for (;;) {
+                x = pb_ld4(rC, off);
+                if (__all(x != PB_SENT)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++rounds > PB_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    flag[0] = 0;
+                    break;
+                }
+            }
+            nap = rounds > 1 ? nap + 12 * (rounds - 1) : (rounds == 0 ? max(0, nap - 6) : nap);
+            dctx[tid] = __uint_as_float(x);
+        }
+        __syncthreads();
+        if (flag[0] != 1) return;
+        PBA_STAMP(blockIdx.x == 0 && t == T / 2, 9);
+        // ---- dot = dctx·ctx_t + sum_j alpha_j (Gprev_j + Gcum_j); dalpha of the own positions = dctx·memory_j + G_j
+        {
+            float dotp = dot_g;
+            if (act) dotp += dctx[2 * tid] * ctx2.x + dctx[2 * tid + 1] * ctx2.y;
+            dotp = row16_sum(dotp);
+            // 32 row partials (8 waves x 4 rows): waves 4..7 carry only their share of dot_g
+            if (c16 == 0) rq[4 * wave + g] = dotp;
+            if (act) {
+                const float4 d0 = *(const float4*)(dctx + lane * 4), d1 = *(const float4*)(dctx + 256 + lane * 4);
+#pragma unroll
+                for (int r = 0; r < JS / 4; ++r) {
+                    float acc = m0[r].x * d0.x;
+                    acc = fmaf(m0[r].y, d0.y, acc); acc = fmaf(m0[r].z, d0.z, acc); acc = fmaf(m0[r].w, d0.w, acc);
+                    acc = fmaf(m1[r].x, d1.x, acc); acc = fmaf(m1[r].y, d1.y, acc);
+                    acc = fmaf(m1[r].z, d1.z, acc); acc = fmaf(m1[r].w, d1.w, acc);
+                    acc = row16_sum(acc);
+                    if (c16 == 0) red[(1 + r) * 16 + 4 * wave + g] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < JS) {
+            float dsum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) dsum += rq[u];
+            const int wv = tid & 3, r = tid >> 2;
+            const float* rr = red + (1 + r) * 16 + 4 * wv;
+            const float dalv = ((rr[0] + rr[1]) + (rr[2] + rr[3])) + gfull0[j0 + min(tid, nown - 1)] + gfull1[j0 + min(tid, nown - 1)];
+            de[tid] = tid < nown ? alf[j0 + tid] * (dalv - dsum) : 0.f;
+        }
+        __syncthreads();
+        // ---- through v·tanh(.): dpre, partial dq / dv
+        if (act) {
+            float* sp = a.S + (((size_t)t * B + b) * Tp + j0) * T2V_A + 4 * d4;
+            float4 dq = make_float4(0.f, 0.f, 0.f, 0.f), dv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < JS / 8; ++i) {
+                const int jl = rg + 8 * i;
+                const float dej = de[jl];
+                const float4 sv = sreg[i];
+                float4 dp;
+                dp.x = dej * vd4.x * (1.0f - sv.x * sv.x); dp.y = dej * vd4.y * (1.0f - sv.y * sv.y);
+                dp.z = dej * vd4.z * (1.0f - sv.z * sv.z); dp.w = dej * vd4.w * (1.0f - sv.w * sv.w);
+                if (jl < nown) *(float4*)(sp + (size_t)jl * T2V_A) = dp;
+                dq.x += dp.x; dq.y += dp.y; dq.z += dp.z; dq.w += dp.w;
+                dv.x = fmaf(dej, sv.x, dv.x); dv.y = fmaf(dej, sv.y, dv.y); dv.z = fmaf(dej, sv.z, dv.z); dv.w = fmaf(dej, sv.w, dv.w);
+                dpT[(4 * d4 + 0) * (JS + 1) + jl] = dp.x; dpT[(4 * d4 + 1) * (JS + 1) + jl] = dp.y;
+                dpT[(4 * d4 + 2) * (JS + 1) + jl] = dp.z; dpT[(4 * d4 + 3) * (JS + 1) + jl] = dp.w;
+            }
+            *(float4*)&rq[rg * T2V_A + 4 * d4] = dq;
+            *(float4*)&rv[rg * T2V_A + 4 * d4] = dv;
+        }
+        __syncthreads();
+        if (tid < T2V_A) {
+            float q = 0.f, vv = 0.f;
+            {
+                const float* p = rq + tid;
+                q = ((p[0] + p[T2V_A]) + (p[2 * T2V_A] + p[3 * T2V_A])) + ((p[4 * T2V_A] + p[5 * T2V_A]) + (p[6 * T2V_A] + p[7 * T2V_A]));
+                const float* p2 = rv + tid;
+                vv = ((p2[0] + p2[T2V_A]) + (p2[2 * T2V_A] + p2[3 * T2V_A])) + ((p2[4 * T2V_A] + p2[5 * T2V_A]) + (p2[6 * T2V_A] + p2[7 * T2V_A]));
+            }
+            pb_st4(rQ, (unsigned)(((t * B + b) * S + s) * T2V_A + tid) * 4u, q);       // the cell workgroups wait for this
+            dvacc += vv;
+        }
+        PBA_STAMP(blockIdx.x == 0 && t == T / 2, 10);
+        // ---- through the fused location filter on MFMA: T[(c,k)][jl] = sum_d W_comb[d][(c,k)] dpre[jl][d], K = 128
+        if (act) {
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                f32x4 ac4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ac4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < 32; ++st) ac4[st & 3] = mfma16x4(areg[st], dpT[(4 * st + g) * (JS + 1) + 16 * jt + c16], ac4[st & 3]);
+                const f32x4 acc = (ac4[0] + ac4[1]) + (ac4[2] + ac4[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Tl[(16 * wave + 4 * g + r) * (JS + 1) + 16 * jt + c16] = acc[r];
+            }
+        }
+        __syncthreads();
+        // ---- gradient wrt the alignment window of this slice -> the slices of step t-1 (their window partials)
+        if (tid < 2 * 64 && t > 0) {
+            const int c = tid >> 6, jj = tid & 63;
+            if (jj < PW) {
+                float tt[T2V_KS];
+#pragma unroll
+                for (int k = 0; k < T2V_KS; ++k) {
+                    const int jl = jj - k;
+                    const float tv = Tl[(32 * c + k) * (JS + 1) + min(max(jl, 0), JS - 1)];
+                    tt[k] = (jl >= 0 && jl < JS) ? tv : 0.f;
+                }
+                float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+#pragma unroll
+                for (int k = 0; k + 3 < T2V_KS; k += 4) { acc0 += tt[k]; acc1 += tt[k + 1]; acc2 += tt[k + 2]; acc3 += tt[k + 3]; }
+                acc0 += tt[28]; acc1 += tt[29]; acc2 += tt[30];
+                pb_st4(rP, (unsigned)(((t * B + b) * S + s) * 128 + c * 64 + jj) * 4u, (acc0 + acc1) + (acc2 + acc3));
+            }
+        }
+        __syncthreads();
+        PBA_STAMP(blockIdx.x == 0 && t == T / 2, 11);
+    }
+    if (tid < T2V_A) a.DV[((size_t)b * S + s) * T2V_A + tid] = dvacc;
+}
+
+// y[C0 + c][pair] = sum_j w[C0 + c][j] * x[k_j][pair] for NC of the thread's columns; one LDS operand per gate row with two
+// more in flight (the 168 weight registers leave no room for all eight)
+template <int NCT, int C0, int NC, int NB>
+__device__ __forceinline__ void pb_gemv_cols(const pb_f32x2 (&w)[NCT][PB_KJ / 2], const f32x4* X0, const pb_f32x2* X1, float (&v)[32]) {
+    const int tid = threadIdx.x;
+    pb_f32x2 acc[NC][3];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c][0] = acc[c][1] = acc[c][2] = pb_f32x2{0.f, 0.f};
+    constexpr int PF = 3;
+    f32x4 xa[PF];
+    pb_f32x2 xb[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        xa[d] = X0[tid + PB_THREADS * d];
+        xb[d] = pb_f32x2{0.f, 0.f};
+        if (NB > 4) xb[d] = X1[tid + PB_THREADS * d];
+    }
+#pragma unroll
+    for (int j = 0; j < PB_KJ; ++j) {
+        const f32x4 xc = xa[j % PF];
+        const pb_f32x2 yc = xb[j % PF];
+        const pb_f32x2 x01 = {xc[0], xc[1]}, x23 = {xc[2], xc[3]};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (j & 1) pb_pk3<true>(acc[c][0], acc[c][1], acc[c][2], w[C0 + c][j / 2], x01, x23, yc);
+            else pb_pk3<false>(acc[c][0], acc[c][1], acc[c][2], w[C0 + c][j / 2], x01, x23, yc);
+        }
+        if (j + PF < PB_KJ) {
+            xa[j % PF] = X0[tid + PB_THREADS * (j + PF)];
+            if (NB > 4) xb[j % PF] = X1[tid + PB_THREADS * (j + PF)];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { v[c * 8 + 2 * i] = acc[c][i][0]; v[c * 8 + 2 * i + 1] = acc[c][i][1]; }
+}
+
+// publish / gather helpers of the L role
+template <int NB>
+__device__ __forceinline__ void pba_publish_rows(__amdgpu_buffer_rsrc_t r, unsigned row_off, const float* stage, int u0, int nu) {
+    // stage[u][gate r][8 items]; thread (u, r): one 16-byte (+ one 8-byte) write-through store per gate row k = r*1024 + U
+    const int tid = threadIdx.x;
+    if (tid < 20) {
+        const int u = tid >> 2, rr = tid & 3;
+        if (u < nu) {
+            const int k = rr * T2V_H + u0 + u;
+            const float* sp = stage + (u * 4 + rr) * 8;
+            pb_st16(r, row_off + 16u * (unsigned)k, f32x4{sp[0], sp[1], sp[2], sp[3]});
+            if (NB > 4) pb_st8(r, row_off + 65536u + 8u * (unsigned)k, pb_f32x2{sp[4], sp[5]});
+        }
+    }
+}
+
+template <int NB>      // 4: B <= 4, 6: B = 5, 6
+__global__ __launch_bounds__(PB_THREADS) void k_achain_bwd(PBAArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int B = a.B, T = a.T, S = a.S_sl;
+    const int NT = B * S, NL = T2V_NWG - NT;
+    if (wg < NT) {
+        if (a.T_in <= 128) pba_attention_role<16>(a, lds, wg / S, wg % S, NB);
+        else pba_attention_role<32>(a, lds, wg / S, wg % S, NB);
+        return;
+    }
+    // =================================================================================== L role
+    const uint64_t seed = t2v_step_seed(a.seed, a.step);
+    f32x4* X0 = (f32x4*)lds;                               // [4096] items 0..3 of the gathered gate-gradient row
+    pb_f32x2* X1 = (pb_f32x2*)(lds + 4 * T2V_G);           // [4096] items 4, 5
+    float* part = lds + (NB > 4 ? 6 : 4) * T2V_G;          // [4 groups][32 partials][32]
+    float* ysumA = part + 4 * 1024;                        // [8 cols][8]
+    float* ysumD = ysumA + 64;                             // [13 cols -> 16][8]
+    float* dhA = ysumD + 128;                              // [5][8]  yd_h(t) + ya_h(t+1)
+    float* stage = dhA + 64;                               // [5][4][8]
+    float* wqs = stage + 256;                              // [5][128] W_q^T rows of the own units
+    float* dqs = wqs + 5 * T2V_A;                          // [8][128] dq(t) per item
+    int* flag = (int*)(dqs + 8 * T2V_A);
+    const int j = wg - NT;
+    const int u0 = (j * T2V_H) / NL, nu = ((j + 1) * T2V_H) / NL - u0;      // 4 or 5 units
+    const int c0 = (j * T2V_E) / NL, nc = ((j + 1) * T2V_E) / NL - c0;      // 2 or 3 context columns
+    const __amdgpu_buffer_rsrc_t rA = pb_rsrc(a.GXA), rD = pb_rsrc(a.GXD), rC = pb_rsrc(a.CX), rQ = pb_rsrc(a.DQX);
+    // ---- transposed weight columns of this workgroup, gate rows k = tid + 512 jj
+    pb_f32x2 wA[8][PB_KJ / 2], wD[13][PB_KJ / 2];
+#pragma unroll
+    for (int jj = 0; jj < PB_KJ; ++jj) {
+        const size_t k = (size_t)(tid + PB_THREADS * jj);
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const bool on = u < nu;
+            const int U = u0 + (on ? u : 0);
+            wA[u][jj / 2][jj & 1] = on ? a.w_hh_att[k * T2V_H + U] : 0.f;
+            wD[u][jj / 2][jj & 1] = on ? a.w_ih_dec[k * T2V_KATT + U] : 0.f;
+            wD[8 + u][jj / 2][jj & 1] = on ? a.w_hh_dec[k * T2V_H + U] : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const bool on = c < nc;
+            const int Cc = c0 + (on ? c : 0);
+            wA[5 + c][jj / 2][jj & 1] = on ? a.w_ih_att[k * (T2V_PRE + T2V_E) + T2V_PRE + Cc] : 0.f;
+            wD[5 + c][jj / 2][jj & 1] = on ? a.w_ih_dec[k * T2V_KATT + T2V_H + Cc] : 0.f;
+        }
+    }
+    for (int i = tid; i < 5 * T2V_A; i += PB_THREADS) {
+        const int u = i >> 7, d = i & 127;
+        wqs[i] = u < nu ? a.wq[(size_t)d * T2V_H + u0 + u] : 0.f;
+    }
+    for (int i = tid; i < 64 + 128 + 64; i += PB_THREADS) ysumA[i] = 0.f;       // ysumA, ysumD, dhA
+    if (tid == 0) flag[0] = 1;
+    // cell threads: row = tid >> 4 = u * NB + b, the thread with (tid & 15) == 0 owns (unit u, item b) for the whole pass
+    const int rowi = tid >> 4, cu = rowi / NB, cb = rowi - cu * NB;
+    const bool cell_thr = (tid & 15) == 0 && cu < nu && cb < B;
+    const int U = u0 + (cu < nu ? cu : 0);
+    const uint32_t idx = (uint32_t)cb * T2V_H + U;
+    float dca = 0.f, dcd = 0.f;
+    int napA = 0, napQ = 0;
+    __syncthreads();
+
+    for (int t = T; t >= 0; --t) {
+        const bool do_att = t < T, do_dec = t >= 1;
+        PBA_STAMP(wg == NT && t == T / 2, 0);
+        if (do_att) {
+            // ---- P1: ya = Wcat_att^T dga(t+1) for the own columns
+            if (t < T - 1) {
+                const int rounds = pb_gather_row<NB>(X0, X1, rA, (unsigned)(t + 1) * PB_ROW_BYTES(NB), B, napA, a.err, flag);
+                napA = rounds > 1 ? napA + 12 * (rounds - 1) : (rounds == 0 ? max(0, napA - 6) : napA);
+                __syncthreads();
+                if (flag[0] != 1) return;
+                PBA_STAMP(wg == NT && t == T / 2, 1);
+                float v[32];
+                pb_gemv_cols<8, 0, 4, NB>(wA, X0, X1, v);
+                pb_reduce32(v, part);
+                pb_gemv_cols<8, 4, 4, NB>(wA, X0, X1, v);
+                pb_reduce32(v, part + 1024);
+                __syncthreads();
+                if (tid < 64) ysumA[tid] = pb_sum32(part + (tid >> 5) * 1024, tid & 31);      // [col][8]: group col>>2, idx (col&3)*8 + b
+                __syncthreads();
+            }
+            PBA_STAMP(wg == NT && t == T / 2, 2);
+            // ---- P2: the context gradient of the own columns -> attention workgroups; d h_att partial for the cell
+            if (tid < 24) {
+                const int c = tid >> 3, b = tid & 7;
+                if (c < nc && b < B) {
+                    const float val = a.dHC[((size_t)t * B + b) * (T2V_H + T2V_E) + T2V_H + c0 + c] + ysumD[(5 + c) * 8 + b] +
+                                      (t < T - 1 ? ysumA[(5 + c) * 8 + b] : 0.f);
+                    pb_st4(rC, (unsigned)t * PB_CX_ROW_BYTES(NB) + (unsigned)((b >> 2) * T2V_E + c0 + c) * 16u + 4u * (unsigned)(b & 3), val);
+                    a.DCTX[((size_t)t * B + b) * T2V_E + c0 + c] = val;
+                }
+            } else if (tid >= 64 && tid < 64 + 40) {
+                const int i = tid - 64;
+                dhA[i] = ysumD[i] + (t < T - 1 ? ysumA[i] : 0.f);
+            }
+        }
+        PBA_STAMP(wg == NT && t == T / 2, 3);
+        if (do_dec) {
+            // ---- P3 (in the shadow of attention(t)): cell D(t-1), all-gather dgd(t-1), yd = Wcat_dec^T dgd(t-1)
+            __syncthreads();
+            const int td = t - 1;
+            if (cell_thr) {
+                const float dh = a.dHC[((size_t)td * B + cb) * (T2V_H + T2V_E) + U] + (t < T ? ysumD[(8 + cu) * 8 + cb] : 0.f);
+                const float* gp = a.GD + ((size_t)td * B + cb) * T2V_G + U;
+                const float gi = gp[0], gf = gp[T2V_H], gg = gp[2 * T2V_H], go = gp[3 * T2V_H];
+                const float cdc = a.CD[((size_t)(td + 1) * B + cb) * T2V_H + U];
+                float cprev = a.CD[((size_t)td * B + cb) * T2V_H + U];
+                const float fh = t2v_drop_scale(seed, T2V_RNG_DEC_H, td, idx, a.p_dec);
+                const float fc = t2v_drop_scale(seed, T2V_RNG_DEC_C, td, idx, a.p_dec);
+                if (td > 0) cprev *= t2v_drop_scale(seed, T2V_RNG_DEC_C, td - 1, idx, a.p_dec);
+                const float tc = tanhf_(cdc);
+                const float dht = dh * fh;
+                const float dct = dcd * fc + dht * go * (1.0f - tc * tc);
+                const float d0 = dct * gg * gi * (1.0f - gi), d1 = dct * cprev * gf * (1.0f - gf);
+                const float d2 = dct * gi * (1.0f - gg * gg), d3 = dht * tc * go * (1.0f - go);
+                dcd = dct * gf;
+                float* o = a.DGD + ((size_t)td * B + cb) * T2V_G + U;
+                o[0] = d0; o[T2V_H] = d1; o[2 * T2V_H] = d2; o[3 * T2V_H] = d3;
+                float* sp = stage + (cu * 4) * 8 + cb;
+                sp[0] = d0; sp[8] = d1; sp[16] = d2; sp[24] = d3;
+            }
+            __syncthreads();
+            pba_publish_rows<NB>(rD, (unsigned)td * PB_ROW_BYTES(NB), stage, u0, nu);
+            if (td > 0 || true) {
+                pb_gather_row<NB>(X0, X1, rD, (unsigned)td * PB_ROW_BYTES(NB), B, 0, a.err, flag);
+                __syncthreads();
+                if (flag[0] != 1) return;
+                float v[32];
+                pb_gemv_cols<13, 0, 4, NB>(wD, X0, X1, v);
+                pb_reduce32(v, part);
+                pb_gemv_cols<13, 4, 4, NB>(wD, X0, X1, v);
+                pb_reduce32(v, part + 1024);
+                pb_gemv_cols<13, 8, 4, NB>(wD, X0, X1, v);
+                pb_reduce32(v, part + 2048);
+                pb_gemv_cols<13, 12, 1, NB>(wD, X0, X1, v);
+                pb_reduce32(v, part + 3072);
+            }
+        }
+        PBA_STAMP(wg == NT && t == T / 2, 4);
+        float wq_dq = 0.f;
+        if (do_att) {
+            // ---- P4: dq(t) of every item (sum of the position slices' partial rows), W_q^T dq for the own units
+            if (tid < B * 32) {
+                const int b = tid >> 5, q = tid & 31;
+                const unsigned off = (unsigned)(((t * B + b) * S) * T2V_A + 4 * q) * 4u;
+                for (int i = 0; i < napQ; i += 8) __builtin_amdgcn_s_sleep(8);
+                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                int rounds = 0;
+                for (;;) {
+                    bool ok = true;
+                    sum = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int s = 0; s < S; ++s) {
+                        const f32x4 x = pb_ld16(rQ, off + (unsigned)(s * T2V_A) * 4u);
+                        ok = ok && pb_ok(x[0]) && pb_ok(x[1]) && pb_ok(x[2]) && pb_ok(x[3]);
+                        sum += x;
+                    }
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++rounds > PB_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        flag[0] = 0;
+                        break;
+                    }
+                }
+                napQ = rounds > 1 ? napQ + 12 * (rounds - 1) : (rounds == 0 ? max(0, napQ - 6) : napQ);
+                *(f32x4*)(dqs + b * T2V_A + 4 * q) = sum;
+            }
+        }
+        __syncthreads();            // dqs ready; the D-GEMV partials of P3 are complete
+        if (flag[0] != 1) return;
+        if (do_dec && tid < 104) ysumD[tid] = pb_sum32(part + (tid >> 5) * 1024, tid & 31);     // yd of step t-1, for the next iteration
+        PBA_STAMP(wg == NT && t == T / 2, 5);
+        if (do_att) {
+            // thread (row = (u, b), lane l of 16): 8 of the 128 attention dims
+            float acc = 0.f;
+            if (rowi < 5 * NB) {
+                const float* wr = wqs + cu * T2V_A + 8 * (tid & 15);
+                const float* dr = dqs + cb * T2V_A + 8 * (tid & 15);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc = fmaf(wr[i], dr[i], acc);
+            }
+            wq_dq = row16_sum(acc);
+            // ---- P5: cell A(t)
+            if (cell_thr) {
+                const float dh = dhA[cu * 8 + cb] + wq_dq;
+                const float* gp = a.GA + ((size_t)t * B + cb) * T2V_G + U;
+                const float gi = gp[0], gf = gp[T2V_H], gg = gp[2 * T2V_H], go = gp[3 * T2V_H];
+                const float cac = a.CA[((size_t)(t + 1) * B + cb) * T2V_H + U];
+                float cprev = a.CA[((size_t)t * B + cb) * T2V_H + U];
+                const float fh = t2v_drop_scale(seed, T2V_RNG_ATT_H, t, idx, a.p_att);
+                const float fc = t2v_drop_scale(seed, T2V_RNG_ATT_C, t, idx, a.p_att);
+                if (t > 0) cprev *= t2v_drop_scale(seed, T2V_RNG_ATT_C, t - 1, idx, a.p_att);
+                const float tc = tanhf_(cac);
+                const float dht = dh * fh;
+                const float dct = dca * fc + dht * go * (1.0f - tc * tc);
+                const float d0 = dct * gg * gi * (1.0f - gi), d1 = dct * cprev * gf * (1.0f - gf);
+                const float d2 = dct * gi * (1.0f - gg * gg), d3 = dht * tc * go * (1.0f - go);
+                dca = dct * gf;
+                float* o = a.DGA + ((size_t)t * B + cb) * T2V_G + U;
+                o[0] = d0; o[T2V_H] = d1; o[2 * T2V_H] = d2; o[3 * T2V_H] = d3;
+                float* sp = stage + (cu * 4) * 8 + cb;
+                sp[0] = d0; sp[8] = d1; sp[16] = d2; sp[24] = d3;
+            }
+            __syncthreads();
+            if (t > 0) pba_publish_rows<NB>(rA, (unsigned)t * PB_ROW_BYTES(NB), stage, u0, nu);
+        }
+        __syncthreads();
+        PBA_STAMP(wg == NT && t == T / 2, 6);
+    }
+}
+
+static size_t pba_lds_bytes(int B, int T_in) {
+    const size_t lrole = (B > 4 ? 6 : 4) * T2V_G + 4 * 1024 + 64 + 128 + 64 + 256 + 5 * T2V_A + 8 * T2V_A + 4;
+    const size_t Tcap = (size_t)((T_in + 15) / 16) * 16, JS = T_in <= 128 ? 16 : 32;
+    const size_t trole = 4 * Tcap + T2V_E + JS + (1 + JS / 4) * 16 + T2V_A * (JS + 1) + 64 * (JS + 1) + 2 * 8 * T2V_A + 4;
+    return sizeof(float) * (lrole > trole ? lrole : trole);
+}
+
+// exchange scratch of the attention chain (floats): gate-gradient rows of both cells, context gradients, window partials.
+// The dq partials (T,B,S,128) are an OUTPUT (the caller reduces them into d W_q) and are passed separately.
+extern "C" long t2v_decoder_bwd_achain_scratch_floats(int B, int T_in, int T_out) {
+    if (B < 1 || B > PB_MAXB || T_in < 1 || T_in > PB_MAXT || T_out < 1) return 0;
+    const size_t S = (size_t)t2v_attn_bwd_slices_(T_in);
+    const size_t cx = (size_t)T_out * (B > 4 ? 16384 : 8192) / 4;
+    return (long)(2 * (size_t)T_out * pb_row_bytes(B) / 4 + cx + (size_t)T_out * B * S * 128);
+}
+
+extern "C" int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, const float* w_unused, const t2v_dec_train_bufs* s,
+                                      const float* dHC, float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
+                                      uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
+                                      void* stream_) {
+    (void)w_unused;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!w || !s || !dHC || !DGA || !DGD || !DCTX || !DV || !DQP || !scratch || !err_word) return T2V_ERR_ARG;
+    if (!t2v_decoder_bwd_persist_supported(B, T_in) || T_out < 1) return T2V_ERR_ARG;
+    if (!w->w_ih_att || !w->w_hh_att || !w->w_ih_dec || !w->w_hh_dec || !w->wq || !w->wcomb || !w->v || !s->memory || !s->XS || !s->CA ||
+        !s->CD || !s->GA || !s->GD || !s->AL || !s->S)
+        return T2V_ERR_ARG;
+    const int S = t2v_attn_bwd_slices_(T_in);
+    const size_t rowf = pb_row_bytes(B) / 4, cxf = (size_t)(B > 4 ? 16384 : 8192) / 4;
+    const size_t n_gx = (size_t)T_out * rowf, n_cx = (size_t)T_out * cxf, n_dq = (size_t)T_out * B * S * 128, n_gp = n_dq;
+    if (((uintptr_t)scratch & 15) || ((uintptr_t)DQP & 15) || n_gx * 4 >= 0x7fffffffull || n_dq * 4 >= 0x7fffffffull) return T2V_ERR_ARG;
+    if (pba_lds_bytes(B, T_in) > PB_LDS_MAX) return T2V_ERR_ARG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_achain_bwd<4>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_MAX) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_achain_bwd<6>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_MAX) != hipSuccess)
+            return t2v_check_launch();
+        attr_set = true;
+    }
+    (void)hipMemsetAsync(err_word, 0, sizeof(uint32_t), stream);
+    k_pb_fill<<<1024, 256, 0, stream>>>((uint4*)scratch, (2 * n_gx + n_cx + n_gp) / 4);
+    k_pb_fill<<<256, 256, 0, stream>>>((uint4*)DQP, n_dq / 4);
+    PBAArgs a;
+    a.w_ih_att = w->w_ih_att; a.w_hh_att = w->w_hh_att; a.w_ih_dec = w->w_ih_dec; a.w_hh_dec = w->w_hh_dec;
+    a.wq = w->wq; a.wcomb = w->wcomb; a.v = w->v;
+    a.memory = s->memory; a.XS = s->XS; a.CA = s->CA; a.CD = s->CD; a.GA = s->GA; a.GD = s->GD; a.AL = s->AL; a.S = s->S;
+    a.dHC = dHC; a.DGA = DGA; a.DGD = DGD; a.DCTX = DCTX; a.DV = DV;
+    a.GXA = scratch; a.GXD = scratch + n_gx; a.CX = scratch + 2 * n_gx; a.GPX = scratch + 2 * n_gx + n_cx; a.DQX = DQP;
+    a.err = err_word;
+    a.B = B; a.T_in = T_in; a.T = T_out; a.S_sl = S; a.p_att = p_att; a.p_dec = p_dec; a.seed = seed;
+    a.step = t2v_step_for(stream);
+    a.prof = g_t2v_prof;
+    const size_t lds = pba_lds_bytes(B, T_in);
+    if (B > 4) k_achain_bwd<6><<<T2V_NWG, PB_THREADS, lds, stream>>>(a);
+    else k_achain_bwd<4><<<T2V_NWG, PB_THREADS, lds, stream>>>(a);
+    return t2v_check_launch();
+}

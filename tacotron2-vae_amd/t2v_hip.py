@@ -68,7 +68,8 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_pack_l
            't2v_attn_bwd_slices', 't2v_colsum', 't2v_colsum_scratch_floats', 't2v_gemm_epilogue_bwd',
            't2v_decoder_train_fwd_persistent', 't2v_decoder_train_persist_supported',
            't2v_decoder_train_persist_scratch_floats', 't2v_decoder_bwd_persist_supported',
-           't2v_decoder_bwd_dchain_scratch_floats', 't2v_decoder_bwd_dchain')
+           't2v_decoder_bwd_dchain_scratch_floats', 't2v_decoder_bwd_dchain', 't2v_decoder_bwd_achain_scratch_floats',
+           't2v_decoder_bwd_achain')
 
 
 def lib_path():
@@ -108,6 +109,10 @@ def load_library():
     lib.t2v_decoder_bwd_dchain_scratch_floats.argtypes = [C.c_int, C.c_int]
     lib.t2v_decoder_bwd_dchain_scratch_floats.restype = C.c_long
     lib.t2v_decoder_bwd_dchain.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_void_p]
+    lib.t2v_decoder_bwd_achain_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.t2v_decoder_bwd_achain_scratch_floats.restype = C.c_long
+    lib.t2v_decoder_bwd_achain.argtypes = [C.POINTER(_DecTrainPersistWeights), C.c_void_p, C.POINTER(_DecTrainBufs)] + [C.c_void_p] * 8 + [
+        C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]
     lib.t2v_decoder_replay_fwd_kernels.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecTrainBufs), C.c_int,
                                                    C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_int,
                                                    C.c_void_p]
@@ -478,7 +483,10 @@ class DecoderCore(torch.autograd.Function):
     # T2V_TRAIN_PERSISTENT=0 forces the launch-per-step forward; the default takes the one-launch persistent kernel
     # (csrc/decoder_train_persist.hip) whenever t2v_decoder_train_persist_supported(B, T_in): B <= 6, T_in <= 224
     persistent = None
+    persistent_bwd = None   # same switch for the reverse pass (env T2V_BWD_PERSISTENT, default on)
+    last_bwd_mode = None
     last_mode = None        # 'persistent' | 'launch-per-step' of the most recent forward chunk (bench / tests)
+    last_bwd_persist = None
     last_persist = None     # keep_last: (weights, bufs, scratch, dims, tensors) of the last persistent forward, for replays
 
     @staticmethod
@@ -489,6 +497,15 @@ class DecoderCore(torch.autograd.Function):
         if not (bool(flag) and bool(lib.t2v_decoder_train_persist_supported(int(B), int(T_in)))):
             return False
         return 4 * lib.t2v_decoder_train_persist_scratch_floats(int(B), int(T_in), int(T)) < 2 ** 31 - 1     # 31-bit buffer offsets
+
+    @staticmethod
+    def use_persistent_bwd(lib, B, T_in, T):
+        flag = DecoderCore.persistent_bwd
+        if flag is None:
+            flag = os.environ.get('T2V_BWD_PERSISTENT', '1') != '0'
+        if not (bool(flag) and bool(lib.t2v_decoder_bwd_persist_supported(int(B), int(T_in)))):
+            return False
+        return 4 * lib.t2v_decoder_bwd_achain_scratch_floats(int(B), int(T_in), int(T)) < 2 ** 31 - 1
 
     @staticmethod
     def _fwd_chunk(lib, gpre, memory, pm, lengths, packs, bias_dec, wqT, wcomb, vv, need_grad, p_att, p_dec, seed, wbf=False,
@@ -550,8 +567,13 @@ class DecoderCore(torch.autograd.Function):
         # the persistent forward reads the nn.LSTMCell tensors themselves; the forward packs are only built when some
         # chunk takes the launch-per-step path (the transposed packs of the backward are always needed)
         fwd_persist = all(DecoderCore.use_persistent(lib, min(B, b0 + MAX_DEC_B) - b0, T_in, T) for b0 in range(0, B, MAX_DEC_B))
-        packs = pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, KATT, need_grad, bf16=wbf,
-                                     need_fwd=not fwd_persist)
+        bwd_persist = need_grad and all(DecoderCore.use_persistent_bwd(lib, min(B, b0 + MAX_DEC_B) - b0, T_in, T)
+                                        for b0 in range(0, B, MAX_DEC_B))
+        if fwd_persist and (bwd_persist or not need_grad):
+            packs = (None, None, None, None)        # both passes read the nn.LSTMCell tensors themselves
+        else:
+            packs = pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, KATT, need_grad and not bwd_persist, bf16=wbf,
+                                         need_fwd=not fwd_persist)
         raw = tuple(_f32c(t.detach()) for t in (w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, wq))
         wqT = wq.detach().t().contiguous()
         bias_dec = _f32c(bias_dec.detach())
@@ -575,6 +597,7 @@ class DecoderCore(torch.autograd.Function):
         ctx.consts = (packs, bias_dec, wqT, wcomb, vv, loc_conv, loc_dense)
         ctx.wbf = wbf
         ctx.wrefs = (w_ih_att, w_hh_att, w_ih_dec, w_hh_dec)
+        ctx.raw = raw
         ctx.pre2 = pre2
         ctx.chunks = [k for _, _, k in chunks] if need_grad else None
         ctx.mark_non_differentiable(align)
@@ -607,25 +630,45 @@ class DecoderCore(torch.autograd.Function):
             dhc_c = dHC if B == Bt else dHC[:, b0:b0 + B].contiguous()
             DGA = torch.empty(T, B, G4, **f32)
             DGD = torch.empty(T, B, G4, **f32)
-            DQ = torch.empty(T, B, NS, A, 2, **f32)
             DCTX = torch.empty(T, B, E, **f32)
-            YD = torch.empty(B, XW, **f32); YA = torch.empty(B, KATT, **f32)
-            DCA = torch.empty(B, H, **f32); DCD = torch.empty(B, H, **f32)
-            GPREV = torch.empty(2, B, NS, 2, 64, **f32); GCUM = torch.empty(B * NS * tcap + 64, **f32)
             DV = torch.empty(B, NS, A, **f32)
             W = _DecWeights(_p(packF_att), _p(packF_dec), _p(packB_att), _p(packB_dec), None, _p(bias_dec),
                             _p(wqT), _p(wcomb), _p(vv), int(bool(ctx.wbf)))
             Sb = _DecTrainBufs(_p(gpre), _p(memory), _p(pm), _p(lengths), _p(XS), _p(CA), _p(CD), _p(GA), _p(GD),
                                _p(QP), _p(AL), _p(ACUM), _p(S))
-            Gb = _DecBwdBufs(_p(dhc_c), _p(DGA), _p(DGD), _p(DQ), _p(DCTX), _p(YD), _p(YA), _p(DCA),
-                             _p(DCD), _p(GPREV), _p(GCUM), _p(DV))
-            _check(lib.t2v_decoder_train_bwd(C.byref(W), C.byref(Sb), C.byref(Gb), B, T_in, T, p_att, p_dec,
-                                             (seed + 7919 * b0) & 0x7FFFFFFFFFFFFFFF, _stream()), 't2v_decoder_train_bwd')
-            _err_note('decoder backward (dq hand-off)', GCUM.view(torch.int32)[B * NS * tcap + 1:][:1])
-            if DecoderCore.keep_last and b0 == 0:
-                DecoderCore.last_bwd = (W, Sb, Gb, (B, T_in, T, p_att, p_dec, seed),
-                                        keep + (dhc_c, DGA, DGD, DQ, DCTX, YD, YA, DCA, DCD, GPREV, GCUM, DV, packs, bias_dec,
-                                                wqT, wcomb, vv))
+            if packB_att is None:
+                # the whole reverse pass as ONE persistent launch (csrc/decoder_train_bwd_persist.hip)
+                w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, wq_raw = ctx.raw
+                PW = _DecTrainPersistWeights(_p(w_ih_att), _p(w_hh_att), _p(w_ih_dec), _p(w_hh_dec), _p(bias_dec), _p(wq_raw),
+                                             _p(wcomb), _p(vv))
+                DQP = torch.empty(T, B, NS, A, **f32)
+                scratch = torch.empty(lib.t2v_decoder_bwd_achain_scratch_floats(B, T_in, T), **f32)
+                errw = torch.zeros(1, device=dev, dtype=torch.int32)
+                _check(lib.t2v_decoder_bwd_achain(C.byref(PW), None, C.byref(Sb), _p(dhc_c), _p(DGA), _p(DGD), _p(DCTX), _p(DV),
+                                                  _p(DQP), _p(scratch), _p(errw), B, T_in, T, p_att, p_dec,
+                                                  (seed + 7919 * b0) & 0x7FFFFFFFFFFFFFFF, _stream()), 't2v_decoder_bwd_achain')
+                _err_note('decoder backward (persistent kernel hand-off)', errw)
+                DecoderCore.last_bwd_mode = 'persistent'
+                dq_sum = DQP.sum(2).view(T * B, A)
+                if DecoderCore.keep_last and b0 == 0:
+                    DecoderCore.last_bwd_persist = (PW, Sb, (dhc_c, DGA, DGD, DCTX, DV, DQP, scratch, errw), (B, T_in, T, p_att, p_dec, seed),
+                                                    keep + (ctx.raw, wcomb, vv, bias_dec))
+            else:
+                DQ = torch.empty(T, B, NS, A, 2, **f32)
+                YD = torch.empty(B, XW, **f32); YA = torch.empty(B, KATT, **f32)
+                DCA = torch.empty(B, H, **f32); DCD = torch.empty(B, H, **f32)
+                GPREV = torch.empty(2, B, NS, 2, 64, **f32); GCUM = torch.empty(B * NS * tcap + 64, **f32)
+                Gb = _DecBwdBufs(_p(dhc_c), _p(DGA), _p(DGD), _p(DQ), _p(DCTX), _p(YD), _p(YA), _p(DCA),
+                                 _p(DCD), _p(GPREV), _p(GCUM), _p(DV))
+                _check(lib.t2v_decoder_train_bwd(C.byref(W), C.byref(Sb), C.byref(Gb), B, T_in, T, p_att, p_dec,
+                                                 (seed + 7919 * b0) & 0x7FFFFFFFFFFFFFFF, _stream()), 't2v_decoder_train_bwd')
+                _err_note('decoder backward (dq hand-off)', GCUM.view(torch.int32)[B * NS * tcap + 1:][:1])
+                DecoderCore.last_bwd_mode = 'launch-per-step'
+                dq_sum = DQ[..., 0].sum(2).view(T * B, A)
+                if DecoderCore.keep_last and b0 == 0:
+                    DecoderCore.last_bwd = (W, Sb, Gb, (B, T_in, T, p_att, p_dec, seed),
+                                            keep + (dhc_c, DGA, DGD, DQ, DCTX, YD, YA, DCA, DCD, GPREV, GCUM, DV, packs, bias_dec,
+                                                    wqT, wcomb, vv))
             TB = T * B
             dga2, dgd2 = DGA.view(TB, G4), DGD.view(TB, G4)
             # time-batched weight-gradient GEMMs
@@ -654,7 +697,7 @@ class DecoderCore(torch.autograd.Function):
                 gemm(dgd2.t(), x_cur[:, :KATT].t(), out=d_w_ih_dec, accumulate=not first)
                 gemm(dgd2.t(), x_cur[:, KATT:].t(), out=d_w_hh_dec, accumulate=not first)
             d_bias_dec = colsum(dgd2)
-            d_wq = gemm(DQ[..., 0].sum(2).view(TB, A).t(), x_cur[:, :H].t())            # (128,1024)
+            d_wq = gemm(dq_sum.t(), x_cur[:, :H].t())            # (128,1024)
             d_memory = torch.empty(B, T_in, E, **f32)
             for bi in range(B):                                # per item: alpha_b^T (T_in x T) · dctx_b (T x 512)
                 gemm(AL[1:, bi].t(), DCTX[:, bi].t(), out=d_memory[bi])

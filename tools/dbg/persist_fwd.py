@@ -25,11 +25,12 @@ lens = torch.tensor([max(1, T_in - 7 * i) for i in range(B)] if ragged else [T_i
 H.DecoderCore.keep_last = True
 names = ('gpre', 'memory', 'pm', 'lengths', 'XS', 'CA', 'CD', 'GA', 'GD', 'QP', 'AL', 'ACUM', 'S')
 out = {}
-for mode in (False, True):
+for mode, bmode in ((False, False), (True, False), (True, True)):
     H.DecoderCore.persistent = mode
+    H.DecoderCore.persistent_bwd = bmode
     dec._calls = 0
     mem = mem0.clone().requires_grad_(True)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     times = []
     for it in range(4):
         dec._calls = 0
@@ -46,13 +47,16 @@ for mode in (False, True):
     print('mode', H.DecoderCore.last_mode, 'forward (incl. prenet / projection GEMMs) us/step:', ['%.2f' % t for t in times], flush=True)
     keep = H.DecoderCore.last_call[3]
     arena = {n: (keep[i].clone() if torch.is_tensor(keep[i]) else None) for i, n in enumerate(names)}
+    ev[2].record()
     (mel.sum() + 0.3 * gate.sum() + (mel * mel).sum() * 0.01).backward()
+    ev[3].record()
     torch.cuda.synchronize()
+    print('   backward mode', H.DecoderCore.last_bwd_mode, 'us/step (incl. all the time-batched GEMMs of the node) %.2f' % (ev[2].elapsed_time(ev[3]) * 1e3 / T), flush=True)
     H.check_async_errors()
     grads = {n: q.grad.clone() for n, q in dec.named_parameters() if q.grad is not None}
     grads['memory'] = mem.grad.clone()
-    out[mode] = (mel.detach().clone(), gate.detach().clone(), al.detach().clone(), arena, grads)
-a, b = out[False], out[True]
+    out[(mode, bmode)] = (mel.detach().clone(), gate.detach().clone(), al.detach().clone(), arena, grads)
+a, b = out[(False, False)], out[(True, False)]
 def cmp(x, y):
     d = (x - y).abs().max().item(); s = x.abs().max().item()
     return '%.3e (scale %.3e)' % (d, s)
@@ -84,3 +88,11 @@ for n in a[4]:
     if d > 1e-3:
         print(' grad', n, 'rel diff', d)
 print('worst relative gradient difference', worst)
+c = out[(True, True)]
+worst = 0.0
+for n in a[4]:
+    d = (a[4][n] - c[4][n]).abs().max().item() / (a[4][n].abs().max().item() + 1e-30)
+    worst = max(worst, d)
+    if d > 1e-3:
+        print(' PERSISTENT-BWD grad', n, 'rel diff', d)
+print('persistent backward: worst relative gradient difference', worst)
