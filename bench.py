@@ -217,8 +217,17 @@ def roofline_table(B, T_in, T, reps=3):
     else:
         legs.append(("k_lstm_fwd256", t2v_hip.replay_fwd_kernels, 1, lstm_bytes, T + 1))
         legs.append(("k_attn_fwd", t2v_hip.replay_fwd_kernels, 2, attn_fwd_bytes, T))
-    legs.append(("k_lstm_bwd256", t2v_hip.replay_bwd_kernels, 1, lstm_bytes, T))
-    legs.append(("k_attn_cell_bwd", t2v_hip.replay_bwd_kernels, 2, attn_bwd_bytes, T + 1))
+    # the persistent reverse pass: every transposed weight column once per PASS, the saved activations in, the gate
+    # gradients / dpre / dctx / dq out
+    persist_bwd_bytes = (LSTM_WEIGHT_BYTES + f4 * (128 * 1024 + 16384 + B * T_in * 512)
+                         + f4 * (T * B * 1536 + (T + 2) * B * 2560 + 2 * (T + 1) * B * 1024 + 2 * T * B * 4096   # dHC, XS, CA/CD, GA/GD
+                                 + (T + 1) * B * T_in + T * B * T_in * 128)                                      # AL, S in
+                         + f4 * (2 * T * B * 4096 + T * B * 512 + T * B * T_in * 128 + T * B * 8 * 128))        # DGA/DGD, DCTX, dpre, dq
+    if t2v_hip.DecoderCore.last_bwd_mode == 'persistent':
+        legs.append(("k_achain_bwd", lambda _m: t2v_hip.replay_persistent_backward(), 0, persist_bwd_bytes, 1))
+    else:
+        legs.append(("k_lstm_bwd256", t2v_hip.replay_bwd_kernels, 1, lstm_bytes, T))
+        legs.append(("k_attn_cell_bwd", t2v_hip.replay_bwd_kernels, 2, attn_bwd_bytes, T + 1))
     situ, situ_src = _in_situ_durations()
     rows = []
     for name, fn, mask, nbytes, per_step in legs:
@@ -241,6 +250,11 @@ def roofline_table(B, T_in, T, reps=3):
             row["in_situ_us"] = situ[name]
             row["frac_in_situ"] = round(nbytes / (situ[name] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
             row["in_situ_source"] = situ_src
+        if name == "k_achain_bwd":
+            row["us_per_time_step"] = round(us / T, 3)
+            row["note"] = ("ONE launch for the whole reverse pass (%d time steps): all-gather of the gate gradients -> transposed "
+                           "weight columns in registers -> attention backward on position-split workgroups -> cell backward; "
+                           "latency-bound chain of hand-offs between CUs" % T)
         if name == "k_dec_train_persist":
             row["us_per_time_step"] = round(us / T, 3)
             row["note"] = ("ONE launch for all %d time steps: a chain of dependent hand-offs between CUs (attention_rnn -> "
@@ -307,7 +321,7 @@ def run_workload(args, world, rank, bf16, koemo, steps, warmup, graph):
            "final_loss": round(final_loss, 5), "step_mode": ("hip-graph replay of forward + backward, then one eager all-reduce and the fused clip + Adam"
                          if getattr(engine, 'graph_ddp', False) else "hip-graph replay") if engine.use_graph else "eager launches",
            "startup_steps": startup, "batch_per_gpu": bpg,
-           "decoder_forward": t2v_hip.DecoderCore.last_mode}
+           "decoder_forward": t2v_hip.DecoderCore.last_mode, "decoder_backward": t2v_hip.DecoderCore.last_bwd_mode}
     if engine.allreduce is not None:
         res["allreduce_exposed_ms"] = round(engine.allreduce.exposed_ms(), 3)
         res["allreduce_buckets"] = [(b[0], 4 * (b[2] - b[1])) for b in engine.allreduce.buckets]
@@ -389,7 +403,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.bf16 else "f32",
         "data": "synthetic",
-        "config": {"workload": WORKLOADS[kind], "step_mode": res["step_mode"], "decoder_forward": res["decoder_forward"],
+        "config": {"workload": WORKLOADS[kind], "step_mode": res["step_mode"], "decoder_forward": res["decoder_forward"], "decoder_backward": res["decoder_backward"],
                    "startup_steps": res["startup_steps"],
                    "global_batch": bpg * world, "frames_per_step": res["frames_per_step"],
                    "parallelism": "dp%d" % world},
@@ -427,7 +441,7 @@ def main():
                            "note": "the 67 MB weight stream of a launch is re-read every time step and is served by the "
                                    "256 MiB Infinity Cache, not by HBM proper; 8 TB/s is the HBM3E peak the guide prices against",
                            "kernels": rows,
-                           "forward_mode": t2v_hip.DecoderCore.last_mode,
+                           "forward_mode": t2v_hip.DecoderCore.last_mode, "backward_mode": t2v_hip.DecoderCore.last_bwd_mode,
                            "recurrence_us_per_time_step": round(rec_us, 2),
                            "recurrence_hbm_floor_us_per_time_step": round(len(stream_rows) * LSTM_WEIGHT_BYTES / (HBM_PEAK_GBS * 1e3), 2),
                            "end_to_end_frac": round(e2e_bytes / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -439,7 +453,7 @@ def main():
             sec = {}
             del engine
             t2v_hip.DecoderCore.keep_last = False
-            t2v_hip.DecoderCore.last_call = t2v_hip.DecoderCore.last_bwd = t2v_hip.DecoderCore.last_persist = None
+            t2v_hip.DecoderCore.last_call = t2v_hip.DecoderCore.last_bwd = t2v_hip.DecoderCore.last_persist = t2v_hip.DecoderCore.last_bwd_persist = None
             torch.cuda.empty_cache()
             for name, (b16, ko) in (("koemo", (False, True)), ("bf16", (True, False))):
                 if name == kind:
@@ -466,7 +480,7 @@ def main():
         import gc
         torch.cuda.synchronize()
         dist.barrier()
-        t2v_hip.DecoderCore.last_call = t2v_hip.DecoderCore.last_bwd = t2v_hip.DecoderCore.last_persist = None
+        t2v_hip.DecoderCore.last_call = t2v_hip.DecoderCore.last_bwd = t2v_hip.DecoderCore.last_persist = t2v_hip.DecoderCore.last_bwd_persist = None
         del engine
         gc.collect()
         torch.cuda.synchronize()

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(PB_THREADS) void k_dchain_bwd(PBDArgs a) {
         if (t < T - 1) {
             // dgd(t+1) from everybody, then this workgroup's 4 columns of W_hh_dec^T · dgd(t+1)
             const int rounds = pb_gather_row<NB>(X0, X1, rX, (unsigned)(t + 1) * PB_ROW_BYTES(NB), B, nap, a.err, flag);
-            nap = rounds > 1 ? nap + 12 * (rounds - 1) : (rounds == 0 ? max(0, nap - 6) : nap);
+            nap = t2v_adapt_nap(nap, rounds);
             __syncthreads();
             if (flag[0] != 1) return;
             pb_f32x2 acc[4][3];
@@ -488,7 +488,7 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
                     break;
                 }
             }
-            nap = rounds > 1 ? nap + 12 * (rounds - 1) : (rounds == 0 ? max(0, nap - 6) : nap);
+            nap = t2v_adapt_nap(nap, rounds);
             dctx[tid] = __uint_as_float(x);
         }
         __syncthreads();
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(PB_THREADS) void k_achain_bwd(PBAArgs a) {
             // ---- P1: ya = Wcat_att^T dga(t+1) for the own columns
             if (t < T - 1) {
                 const int rounds = pb_gather_row<NB>(X0, X1, rA, (unsigned)(t + 1) * PB_ROW_BYTES(NB), B, napA, a.err, flag);
-                napA = rounds > 1 ? napA + 12 * (rounds - 1) : (rounds == 0 ? max(0, napA - 6) : napA);
+                napA = t2v_adapt_nap(napA, rounds);
                 __syncthreads();
                 if (flag[0] != 1) return;
                 PBA_STAMP(wg == NT && t == T / 2, 1);
@@ -820,7 +820,7 @@ __global__ __launch_bounds__(PB_THREADS) void k_achain_bwd(PBAArgs a) {
                         break;
                     }
                 }
-                napQ = rounds > 1 ? napQ + 12 * (rounds - 1) : (rounds == 0 ? max(0, napQ - 6) : napQ);
+                napQ = t2v_adapt_nap(napQ, rounds);
                 *(f32x4*)(dqs + b * T2V_A + 4 * q) = sum;
             }
         }

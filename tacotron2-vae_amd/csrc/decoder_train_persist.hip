@@ -495,7 +495,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
                 PT_STAMP(wg == NT && t == T / 2, 6);
                 const int rounds = pt_gather<(NP * T2V_E + PT_THREADS - 1) / PT_THREADS, NP>(X, rG, grow, T2V_H, T2V_E, B, ctx_nap, a.err, flag);
                 // adaptive nap: wake up just before the context lands (a poll round is about 16 nap units long)
-                ctx_nap = rounds > 1 ? ctx_nap + 12 * (rounds - 1) : (rounds == 0 ? max(0, ctx_nap - 6) : ctx_nap);
+                ctx_nap = t2v_adapt_nap(ctx_nap, rounds);
                 PT_WALL(wg == NT && t == T / 2, 23);
                 if (a.prof && wg == NT && t == T / 2 && tid == 0) { a.prof[24] = (unsigned long long)rounds; a.prof[25] = (unsigned long long)ctx_nap; }
             }
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
                     break;
                 }
             }
-            h_nap = rounds > 1 ? h_nap + 12 * (rounds - 1) : (rounds == 0 ? max(0, h_nap - 6) : h_nap);
+            h_nap = t2v_adapt_nap(h_nap, rounds);
             PT_WALL(wg == 0 && t == T / 2, 21);
             if (a.prof && wg == 0 && t == T / 2 && tid == 0) { a.prof[26] = (unsigned long long)rounds; a.prof[27] = (unsigned long long)h_nap; }
             hx[tid] = v0;

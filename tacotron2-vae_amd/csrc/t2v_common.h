@@ -119,6 +119,16 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Adaptive nap ahead of a polled hand-off (s_sleep units of 64 clocks): `rounds` = failed polls of the last wait.  The nap
+// grows while polls fail, shrinks by a quarter when the data was already there, and is CLAMPED — the first wait of a
+// pass can be a hundred times longer than a steady-state one (weights still loading), and an unclamped additive rule
+// turned that into naps of hundreds of microseconds that then decayed over hundreds of steps.
+__device__ __forceinline__ int t2v_adapt_nap(int nap, int rounds) {
+    if (rounds > 1) return min(192, nap + 8 * min(rounds - 1, 4));
+    if (rounds == 0) return (3 * nap) >> 2;
+    return nap;
+}
+
 // phase stamp for the optional in-kernel profile (one thread of one workgroup)
 #define T2V_STAMP(ARGS, I)                                                                          \
     do {                                                                                            \

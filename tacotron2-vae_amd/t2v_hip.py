@@ -426,6 +426,19 @@ def replay_persistent_forward():
     return 1
 
 
+def replay_persistent_backward():
+    """Re-issue the one-launch persistent reverse pass (csrc/decoder_train_bwd_persist.hip) of the most recent
+    DecoderCore.backward on its buffers — timing only (S already holds dpre: the numbers it produces are not used)."""
+    if DecoderCore.last_bwd_persist is None:
+        raise T2VHipError("replay_persistent_backward: the last backward pass did not run on the persistent kernel (or "
+                          "DecoderCore.keep_last was off)")
+    PW, Sb, (dhc, DGA, DGD, DCTX, DV, DQP, scratch, errw), (B, T_in, T, p_att, p_dec, seed), _keep = DecoderCore.last_bwd_persist
+    _check(load_library().t2v_decoder_bwd_achain(C.byref(PW), None, C.byref(Sb), _p(dhc), _p(DGA), _p(DGD), _p(DCTX), _p(DV), _p(DQP),
+                                                 _p(scratch), _p(errw), B, T_in, T, p_att, p_dec, seed, _stream()),
+           't2v_decoder_bwd_achain')
+    return 1
+
+
 def replay_bwd_kernels(kernel_mask):
     """Re-issue the k_lstm_bwd256 (mask 1) / k_attn_cell_bwd (mask 2) launches of the most recent DecoderCore.backward
     (first batch chunk) on its buffers — timing only (bench.py roofline leg; needs DecoderCore.keep_last = True)."""
