@@ -360,7 +360,7 @@ struct PBAArgs {
     // outputs
     float* DGA; float* DGD; float* DCTX; float* DV;       // DV (B,S,128)
     // exchange (sentinel-filled): gate-gradient rows of both cells, context gradients, dq partials, window partials
-    float* GXA; float* GXD; float* CX; float* DQX; float* GPX;
+    float* GXA; float* GXD; float* CX; float* DQX; float* GPX; float* EX;      // EX (T,B,1536): E(t) = Wcat_dec[:, :1536]^T dgd(t)
     unsigned* err;
     int B, T_in, T, S_sl;
     float p_att, p_dec;
@@ -638,127 +638,134 @@ __device__ __forceinline__ void pb_gemv_cols(const pb_f32x2 (&w)[NCT][PB_KJ / 2]
         for (int i = 0; i < 3; ++i) { v[c * 8 + 2 * i] = acc[c][i][0]; v[c * 8 + 2 * i + 1] = acc[c][i][1]; }
 }
 
-// publish / gather helpers of the L role
+// ---- role split of the LSTM workgroups (NL = 256 - B*S of them).  One workgroup set per cell halves the gate-gradient
+// all-gather (a row of 4096 x B values goes to the workgroups of ITS cell only) and decouples the two chains:
+//   A role, NA = 3/8 of NL workgroups: attention_rnn.  Workgroup ja owns hidden units [ja*1024/NA, ..) (<= 14) and context
+//           columns [ja*512/NA, ..) (<= 7): their columns of Wcat_att^T in registers.  This is the per-step chain.
+//   D role, ND = NL - NA workgroups: decoder_rnn.  Workgroup jd owns units [jd*1024/ND, ..) (<= 8, both the h_att-input
+//           and the recurrent column of each) and context columns [jd*512/ND, ..) (<= 4): columns of Wcat_dec^T.  Its
+//           loop needs only dHC and its own recurrence, so it FREE-RUNS ahead of the A chain and leaves
+//           E(t) = Wcat_dec[:, :1536]^T dgd(t) — decoder_rnn's contribution to d h_att(t) / d ctx(t) — in a sentinel-filled
+//           array the A workgroups read when they get there.
+#define PBA_NUA 14
+#define PBA_NCA 7
+#define PBA_NUD 8
+#define PBA_NCD 4
+__host__ __device__ static inline int pba_na(int NL) { return (3 * NL + 4) / 8; }
+
+// final sums of a column-grouped GEMV: NCOL columns x 8 item slots -> ysum[col * 8 + b]
+__device__ __forceinline__ void pba_finish_sums(const float* part, float* ysum, int ncol) {
+    const int tid = threadIdx.x;
+    if (tid < ncol * 8) ysum[tid] = pb_sum32(part + (tid >> 5) * 1024, tid & 31);
+}
+
+// poll one word of a sentinel-filled array until it is written (bounded)
+__device__ __forceinline__ float pba_wait_word(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned* err, int* flag) {
+    unsigned x;
+    int spins = 0;
+    for (;;) {
+        x = pb_ld4(r, off);
+        if (x != PB_SENT) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > PB_SPIN || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = 0;
+            break;
+        }
+    }
+    return __uint_as_float(x);
+}
+
+// stage[u][gate][8 items] -> one 16-byte (+ one 8-byte) write-through store per gate row k = gate*1024 + U
 template <int NB>
 __device__ __forceinline__ void pba_publish_rows(__amdgpu_buffer_rsrc_t r, unsigned row_off, const float* stage, int u0, int nu) {
-    // stage[u][gate r][8 items]; thread (u, r): one 16-byte (+ one 8-byte) write-through store per gate row k = r*1024 + U
     const int tid = threadIdx.x;
-    if (tid < 20) {
+    if (tid < 4 * nu) {
         const int u = tid >> 2, rr = tid & 3;
-        if (u < nu) {
-            const int k = rr * T2V_H + u0 + u;
-            const float* sp = stage + (u * 4 + rr) * 8;
-            pb_st16(r, row_off + 16u * (unsigned)k, f32x4{sp[0], sp[1], sp[2], sp[3]});
-            if (NB > 4) pb_st8(r, row_off + 65536u + 8u * (unsigned)k, pb_f32x2{sp[4], sp[5]});
-        }
+        const int k = rr * T2V_H + u0 + u;
+        const float* sp = stage + (u * 4 + rr) * 8;
+        pb_st16(r, row_off + 16u * (unsigned)k, f32x4{sp[0], sp[1], sp[2], sp[3]});
+        if (NB > 4) pb_st8(r, row_off + 65536u + 8u * (unsigned)k, pb_f32x2{sp[4], sp[5]});
     }
 }
 
-template <int NB>      // 4: B <= 4, 6: B = 5, 6
-__global__ __launch_bounds__(PB_THREADS) void k_achain_bwd(PBAArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int B = a.B, T = a.T, S = a.S_sl;
-    const int NT = B * S, NL = T2V_NWG - NT;
-    if (wg < NT) {
-        if (a.T_in <= 128) pba_attention_role<16>(a, lds, wg / S, wg % S, NB);
-        else pba_attention_role<32>(a, lds, wg / S, wg % S, NB);
-        return;
-    }
-    // =================================================================================== L role
+// ------------------------------------------------------------------------------------------------ D role (free-running)
+template <int NB>
+__device__ __forceinline__ void pba_decoder_role(const PBAArgs& a, float* lds, const int jd, const int ND) {
     const uint64_t seed = t2v_step_seed(a.seed, a.step);
-    f32x4* X0 = (f32x4*)lds;                               // [4096] items 0..3 of the gathered gate-gradient row
-    pb_f32x2* X1 = (pb_f32x2*)(lds + 4 * T2V_G);           // [4096] items 4, 5
-    float* part = lds + (NB > 4 ? 6 : 4) * T2V_G;          // [4 groups][32 partials][32]
-    float* ysumA = part + 4 * 1024;                        // [8 cols][8]
-    float* ysumD = ysumA + 64;                             // [13 cols -> 16][8]
-    float* dhA = ysumD + 128;                              // [5][8]  yd_h(t) + ya_h(t+1)
-    float* stage = dhA + 64;                               // [5][4][8]
-    float* wqs = stage + 256;                              // [5][128] W_q^T rows of the own units
-    float* dqs = wqs + 5 * T2V_A;                          // [8][128] dq(t) per item
-    int* flag = (int*)(dqs + 8 * T2V_A);
-    const int j = wg - NT;
-    const int u0 = (j * T2V_H) / NL, nu = ((j + 1) * T2V_H) / NL - u0;      // 4 or 5 units
-    const int c0 = (j * T2V_E) / NL, nc = ((j + 1) * T2V_E) / NL - c0;      // 2 or 3 context columns
-    const __amdgpu_buffer_rsrc_t rA = pb_rsrc(a.GXA), rD = pb_rsrc(a.GXD), rC = pb_rsrc(a.CX), rQ = pb_rsrc(a.DQX);
-    // ---- transposed weight columns of this workgroup, gate rows k = tid + 512 jj
-    pb_f32x2 wA[8][PB_KJ / 2], wD[13][PB_KJ / 2];
+    const int tid = threadIdx.x;
+    const int B = a.B, T = a.T;
+    f32x4* X0 = (f32x4*)lds;
+    pb_f32x2* X1 = (pb_f32x2*)(lds + 4 * T2V_G);
+    float* part = lds + (NB > 4 ? 6 : 4) * T2V_G;          // [5 groups][32 partials][32]
+    float* ysum = part + 5 * 1024;                         // [20 cols][8]
+    float* stage = ysum + 160;                             // [8 units][4 gates][8]
+    int* flag = (int*)(stage + 256);
+    const int u0 = (jd * T2V_H) / ND, nu = ((jd + 1) * T2V_H) / ND - u0;      // <= 8 units
+    const int c0 = (jd * T2V_E) / ND, nc = ((jd + 1) * T2V_E) / ND - c0;      // <= 4 context columns
+    const __amdgpu_buffer_rsrc_t rD = pb_rsrc(a.GXD), rE = pb_rsrc(a.EX);
+    // columns: [0, 8) recurrent (W_hh_dec[k][U]), [8, 16) h_att input (W_ih_dec[k][U]), [16, 20) ctx input (W_ih_dec[k][1024 + C])
+    pb_f32x2 w[20][PB_KJ / 2];
 #pragma unroll
     for (int jj = 0; jj < PB_KJ; ++jj) {
         const size_t k = (size_t)(tid + PB_THREADS * jj);
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
+        for (int u = 0; u < PBA_NUD; ++u) {
             const bool on = u < nu;
             const int U = u0 + (on ? u : 0);
-            wA[u][jj / 2][jj & 1] = on ? a.w_hh_att[k * T2V_H + U] : 0.f;
-            wD[u][jj / 2][jj & 1] = on ? a.w_ih_dec[k * T2V_KATT + U] : 0.f;
-            wD[8 + u][jj / 2][jj & 1] = on ? a.w_hh_dec[k * T2V_H + U] : 0.f;
+            w[u][jj / 2][jj & 1] = on ? a.w_hh_dec[k * T2V_H + U] : 0.f;
+            w[8 + u][jj / 2][jj & 1] = on ? a.w_ih_dec[k * T2V_KATT + U] : 0.f;
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < PBA_NCD; ++c) {
             const bool on = c < nc;
-            const int Cc = c0 + (on ? c : 0);
-            wA[5 + c][jj / 2][jj & 1] = on ? a.w_ih_att[k * (T2V_PRE + T2V_E) + T2V_PRE + Cc] : 0.f;
-            wD[5 + c][jj / 2][jj & 1] = on ? a.w_ih_dec[k * T2V_KATT + T2V_H + Cc] : 0.f;
+            w[16 + c][jj / 2][jj & 1] = on ? a.w_ih_dec[k * T2V_KATT + T2V_H + c0 + (on ? c : 0)] : 0.f;
         }
     }
-    for (int i = tid; i < 5 * T2V_A; i += PB_THREADS) {
-        const int u = i >> 7, d = i & 127;
-        wqs[i] = u < nu ? a.wq[(size_t)d * T2V_H + u0 + u] : 0.f;
-    }
-    for (int i = tid; i < 64 + 128 + 64; i += PB_THREADS) ysumA[i] = 0.f;       // ysumA, ysumD, dhA
     if (tid == 0) flag[0] = 1;
-    // cell threads: row = tid >> 4 = u * NB + b, the thread with (tid & 15) == 0 owns (unit u, item b) for the whole pass
-    const int rowi = tid >> 4, cu = rowi / NB, cb = rowi - cu * NB;
-    const bool cell_thr = (tid & 15) == 0 && cu < nu && cb < B;
+    // cell threads: tid = u * 8 + b (u < 8): waves 0 (units 0..7 -> 64 threads)
+    const int cu = tid >> 3, cb = tid & 7;
+    const bool cell_thr = tid < 64 && cu < nu && cb < B;
     const int U = u0 + (cu < nu ? cu : 0);
     const uint32_t idx = (uint32_t)cb * T2V_H + U;
-    float dca = 0.f, dcd = 0.f;
-    int napA = 0, napQ = 0;
+    float dcd = 0.f;
+    int nap = 0;
     __syncthreads();
 
+    // iteration t: (t < T) gather dgd(t), yd = Wcat_dec^T dgd(t): publish E(t), keep the recurrent part;  (t >= 1) cell D(t-1)
     for (int t = T; t >= 0; --t) {
-        const bool do_att = t < T, do_dec = t >= 1;
-        PBA_STAMP(wg == NT && t == T / 2, 0);
-        if (do_att) {
-            // ---- P1: ya = Wcat_att^T dga(t+1) for the own columns
-            if (t < T - 1) {
-                const int rounds = pb_gather_row<NB>(X0, X1, rA, (unsigned)(t + 1) * PB_ROW_BYTES(NB), B, napA, a.err, flag);
-                napA = t2v_adapt_nap(napA, rounds);
-                __syncthreads();
-                if (flag[0] != 1) return;
-                PBA_STAMP(wg == NT && t == T / 2, 1);
-                float v[32];
-                pb_gemv_cols<8, 0, 4, NB>(wA, X0, X1, v);
-                pb_reduce32(v, part);
-                pb_gemv_cols<8, 4, 4, NB>(wA, X0, X1, v);
-                pb_reduce32(v, part + 1024);
-                __syncthreads();
-                if (tid < 64) ysumA[tid] = pb_sum32(part + (tid >> 5) * 1024, tid & 31);      // [col][8]: group col>>2, idx (col&3)*8 + b
-                __syncthreads();
-            }
-            PBA_STAMP(wg == NT && t == T / 2, 2);
-            // ---- P2: the context gradient of the own columns -> attention workgroups; d h_att partial for the cell
-            if (tid < 24) {
-                const int c = tid >> 3, b = tid & 7;
-                if (c < nc && b < B) {
-                    const float val = a.dHC[((size_t)t * B + b) * (T2V_H + T2V_E) + T2V_H + c0 + c] + ysumD[(5 + c) * 8 + b] +
-                                      (t < T - 1 ? ysumA[(5 + c) * 8 + b] : 0.f);
-                    pb_st4(rC, (unsigned)t * PB_CX_ROW_BYTES(NB) + (unsigned)((b >> 2) * T2V_E + c0 + c) * 16u + 4u * (unsigned)(b & 3), val);
-                    a.DCTX[((size_t)t * B + b) * T2V_E + c0 + c] = val;
+        if (t < T) {
+            const int rounds = pb_gather_row<NB>(X0, X1, rD, (unsigned)t * PB_ROW_BYTES(NB), B, nap, a.err, flag);
+            nap = t2v_adapt_nap(nap, rounds);
+            __syncthreads();
+            if (flag[0] != 1) return;
+            float v[32];
+            pb_gemv_cols<20, 0, 4, NB>(w, X0, X1, v);
+            pb_reduce32(v, part);
+            pb_gemv_cols<20, 4, 4, NB>(w, X0, X1, v);
+            pb_reduce32(v, part + 1024);
+            pb_gemv_cols<20, 8, 4, NB>(w, X0, X1, v);
+            pb_reduce32(v, part + 2048);
+            pb_gemv_cols<20, 12, 4, NB>(w, X0, X1, v);
+            pb_reduce32(v, part + 3072);
+            pb_gemv_cols<20, 16, 4, NB>(w, X0, X1, v);
+            pb_reduce32(v, part + 4096);
+            __syncthreads();
+            pba_finish_sums(part, ysum, 20);
+            __syncthreads();
+            // E(t): [h_att columns | ctx columns] of this workgroup, plain (T,B,1536) layout
+            if (tid >= 64 && tid < 64 + 96) {
+                const int i = tid - 64, col = i >> 3, b = i & 7;      // col 0..7: unit, 8..11: ctx column
+                if (b < B) {
+                    if (col < 8) { if (col < nu) pb_st4(rE, (unsigned)(((t * B + b) * T2V_KATT) + u0 + col) * 4u, ysum[(8 + col) * 8 + b]); }
+                    else if (col - 8 < nc) pb_st4(rE, (unsigned)(((t * B + b) * T2V_KATT) + T2V_H + c0 + col - 8) * 4u, ysum[(16 + col - 8) * 8 + b]);
                 }
-            } else if (tid >= 64 && tid < 64 + 40) {
-                const int i = tid - 64;
-                dhA[i] = ysumD[i] + (t < T - 1 ? ysumA[i] : 0.f);
             }
         }
-        PBA_STAMP(wg == NT && t == T / 2, 3);
-        if (do_dec) {
-            // ---- P3 (in the shadow of attention(t)): cell D(t-1), all-gather dgd(t-1), yd = Wcat_dec^T dgd(t-1)
-            __syncthreads();
+        if (t >= 1) {
             const int td = t - 1;
             if (cell_thr) {
-                const float dh = a.dHC[((size_t)td * B + cb) * (T2V_H + T2V_E) + U] + (t < T ? ysumD[(8 + cu) * 8 + cb] : 0.f);
+                const float dh = a.dHC[((size_t)td * B + cb) * (T2V_H + T2V_E) + U] + (t < T ? ysum[cu * 8 + cb] : 0.f);
                 const float* gp = a.GD + ((size_t)td * B + cb) * T2V_G + U;
                 const float gi = gp[0], gf = gp[T2V_H], gg = gp[2 * T2V_H], go = gp[3 * T2V_H];
                 const float cdc = a.CD[((size_t)(td + 1) * B + cb) * T2V_H + U];
@@ -777,70 +784,151 @@ __global__ __launch_bounds__(PB_THREADS) void k_achain_bwd(PBAArgs a) {
                 float* sp = stage + (cu * 4) * 8 + cb;
                 sp[0] = d0; sp[8] = d1; sp[16] = d2; sp[24] = d3;
             }
-            __syncthreads();
-            pba_publish_rows<NB>(rD, (unsigned)td * PB_ROW_BYTES(NB), stage, u0, nu);
-            if (td > 0 || true) {
-                pb_gather_row<NB>(X0, X1, rD, (unsigned)td * PB_ROW_BYTES(NB), B, 0, a.err, flag);
-                __syncthreads();
-                if (flag[0] != 1) return;
-                float v[32];
-                pb_gemv_cols<13, 0, 4, NB>(wD, X0, X1, v);
-                pb_reduce32(v, part);
-                pb_gemv_cols<13, 4, 4, NB>(wD, X0, X1, v);
-                pb_reduce32(v, part + 1024);
-                pb_gemv_cols<13, 8, 4, NB>(wD, X0, X1, v);
-                pb_reduce32(v, part + 2048);
-                pb_gemv_cols<13, 12, 1, NB>(wD, X0, X1, v);
-                pb_reduce32(v, part + 3072);
-            }
+            // (stage is written and read by wave 0 only: LDS operations of one wave complete in order)
+            if (tid < 64) pba_publish_rows<NB>(rD, (unsigned)td * PB_ROW_BYTES(NB), stage, u0, nu);
         }
-        PBA_STAMP(wg == NT && t == T / 2, 4);
-        float wq_dq = 0.f;
-        if (do_att) {
-            // ---- P4: dq(t) of every item (sum of the position slices' partial rows), W_q^T dq for the own units
-            if (tid < B * 32) {
-                const int b = tid >> 5, q = tid & 31;
-                const unsigned off = (unsigned)(((t * B + b) * S) * T2V_A + 4 * q) * 4u;
-                for (int i = 0; i < napQ; i += 8) __builtin_amdgcn_s_sleep(8);
-                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-                int rounds = 0;
-                for (;;) {
-                    bool ok = true;
-                    sum = f32x4{0.f, 0.f, 0.f, 0.f};
-                    for (int s = 0; s < S; ++s) {
-                        const f32x4 x = pb_ld16(rQ, off + (unsigned)(s * T2V_A) * 4u);
-                        ok = ok && pb_ok(x[0]) && pb_ok(x[1]) && pb_ok(x[2]) && pb_ok(x[3]);
-                        sum += x;
-                    }
-                    if (__all(ok)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++rounds > PB_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        flag[0] = 0;
-                        break;
-                    }
-                }
-                napQ = t2v_adapt_nap(napQ, rounds);
-                *(f32x4*)(dqs + b * T2V_A + 4 * q) = sum;
-            }
-        }
-        __syncthreads();            // dqs ready; the D-GEMV partials of P3 are complete
-        if (flag[0] != 1) return;
-        if (do_dec && tid < 104) ysumD[tid] = pb_sum32(part + (tid >> 5) * 1024, tid & 31);     // yd of step t-1, for the next iteration
-        PBA_STAMP(wg == NT && t == T / 2, 5);
-        if (do_att) {
-            // thread (row = (u, b), lane l of 16): 8 of the 128 attention dims
-            float acc = 0.f;
-            if (rowi < 5 * NB) {
-                const float* wr = wqs + cu * T2V_A + 8 * (tid & 15);
-                const float* dr = dqs + cb * T2V_A + 8 * (tid & 15);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ A role (the chain)
+template <int NB>
+__device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* lds, const int ja, const int NA) {
+    const uint64_t seed = t2v_step_seed(a.seed, a.step);
+    const int tid = threadIdx.x;
+    const int B = a.B, T = a.T, S = a.S_sl;
+    f32x4* X0 = (f32x4*)lds;
+    pb_f32x2* X1 = (pb_f32x2*)(lds + 4 * T2V_G);
+    float* part = lds + (NB > 4 ? 6 : 4) * T2V_G;          // [6 groups][32 partials][32]
+    float* ysum = part + 6 * 1024;                         // [21 cols -> 24][8]
+    float* dhA = ysum + 192;                               // [14 units -> 16][8]  E_h(t) + ya_h(t+1)
+    float* stage = dhA + 128;                              // [14 -> 16 units][4][8]
+    float* wqs = stage + 512;                              // [14 -> 16][128] W_q^T rows of the own units
+    float* dqs = wqs + 16 * T2V_A;                         // [8][128] dq(t) per item
+    int* flag = (int*)(dqs + 8 * T2V_A);
+    const int u0 = (ja * T2V_H) / NA, nu = ((ja + 1) * T2V_H) / NA - u0;      // <= 14 units
+    const int c0 = (ja * T2V_E) / NA, nc = ((ja + 1) * T2V_E) / NA - c0;      // <= 7 context columns
+    const __amdgpu_buffer_rsrc_t rA = pb_rsrc(a.GXA), rC = pb_rsrc(a.CX), rQ = pb_rsrc(a.DQX), rE = pb_rsrc(a.EX);
+    // columns: [0, 14) W_hh_att[k][U], [14, 21) W_ih_att[k][256 + C]
+    pb_f32x2 w[21][PB_KJ / 2];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc = fmaf(wr[i], dr[i], acc);
+    for (int jj = 0; jj < PB_KJ; ++jj) {
+        const size_t k = (size_t)(tid + PB_THREADS * jj);
+#pragma unroll
+        for (int u = 0; u < PBA_NUA; ++u) {
+            const bool on = u < nu;
+            w[u][jj / 2][jj & 1] = on ? a.w_hh_att[k * T2V_H + u0 + (on ? u : 0)] : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < PBA_NCA; ++c) {
+            const bool on = c < nc;
+            w[14 + c][jj / 2][jj & 1] = on ? a.w_ih_att[k * (T2V_PRE + T2V_E) + T2V_PRE + c0 + (on ? c : 0)] : 0.f;
+        }
+    }
+    for (int i = tid; i < 16 * T2V_A; i += PB_THREADS) {
+        const int u = i >> 7, d = i & 127;
+        wqs[i] = u < nu ? a.wq[(size_t)d * T2V_H + u0 + u] : 0.f;
+    }
+    for (int i = tid; i < 192; i += PB_THREADS) ysum[i] = 0.f;
+    if (tid == 0) flag[0] = 1;
+    // cell rows: row = tid >> 2 = u * NB + b (4 lanes per row, 32 attention dims each); lane 0 of a row owns (unit u, item b)
+    const int rowi = tid >> 2, cu = rowi / NB, cb = rowi - cu * NB;
+    const bool row_on = cu < nu;
+    const bool cell_thr = (tid & 3) == 0 && cu < nu && cb < B;
+    const int U = u0 + (cu < nu ? cu : 0);
+    const uint32_t idx = (uint32_t)cb * T2V_H + U;
+    float dca = 0.f;
+    int napA = 0, napQ = 0;
+    __syncthreads();
+
+    for (int t = T - 1; t >= 0; --t) {
+        PBA_STAMP(ja == 0 && t == T / 2, 0);
+        // ---- P1: ya = Wcat_att^T dga(t+1) for the own columns
+        if (t < T - 1) {
+            const int rounds = pb_gather_row<NB>(X0, X1, rA, (unsigned)(t + 1) * PB_ROW_BYTES(NB), B, napA, a.err, flag);
+            napA = t2v_adapt_nap(napA, rounds);
+            __syncthreads();
+            if (flag[0] != 1) return;
+            PBA_STAMP(ja == 0 && t == T / 2, 1);
+            float v[32];
+            pb_gemv_cols<21, 0, 4, NB>(w, X0, X1, v);
+            pb_reduce32(v, part);
+            pb_gemv_cols<21, 4, 4, NB>(w, X0, X1, v);
+            pb_reduce32(v, part + 1024);
+            pb_gemv_cols<21, 8, 4, NB>(w, X0, X1, v);
+            pb_reduce32(v, part + 2048);
+            pb_gemv_cols<21, 12, 4, NB>(w, X0, X1, v);
+            pb_reduce32(v, part + 3072);
+            pb_gemv_cols<21, 16, 4, NB>(w, X0, X1, v);
+            pb_reduce32(v, part + 4096);
+            pb_gemv_cols<21, 20, 1, NB>(w, X0, X1, v);
+            pb_reduce32(v, part + 5120);
+            __syncthreads();
+            pba_finish_sums(part, ysum, 21);
+            __syncthreads();
+        }
+        PBA_STAMP(ja == 0 && t == T / 2, 2);
+        // ---- P2: context gradient of the own columns -> attention workgroups; d h_att partial for the cell.  E(t) comes
+        // from the decoder_rnn workgroups, which run ahead
+        if (tid < 56) {
+            const int c = tid >> 3, b = tid & 7;
+            if (c < nc && b < B) {
+                const float e = pba_wait_word(rE, (unsigned)(((t * B + b) * T2V_KATT) + T2V_H + c0 + c) * 4u, a.err, flag);
+                const float val = a.dHC[((size_t)t * B + b) * (T2V_H + T2V_E) + T2V_H + c0 + c] + e + (t < T - 1 ? ysum[(14 + c) * 8 + b] : 0.f);
+                pb_st4(rC, (unsigned)t * PB_CX_ROW_BYTES(NB) + (unsigned)((b >> 2) * T2V_E + c0 + c) * 16u + 4u * (unsigned)(b & 3), val);
+                a.DCTX[((size_t)t * B + b) * T2V_E + c0 + c] = val;
             }
-            wq_dq = row16_sum(acc);
-            // ---- P5: cell A(t)
+        } else if (tid >= 64 && tid < 64 + 112) {
+            const int i = tid - 64, u = i >> 3, b = i & 7;
+            if (u < nu && b < B)
+                dhA[i] = pba_wait_word(rE, (unsigned)(((t * B + b) * T2V_KATT) + u0 + u) * 4u, a.err, flag) + (t < T - 1 ? ysum[i] : 0.f);
+        }
+        PBA_STAMP(ja == 0 && t == T / 2, 3);
+        // ---- P4: dq(t) of every item (sum of the position slices' partial rows)
+        if (tid >= 256 && tid < 256 + B * 32) {
+            const int i = tid - 256, b = i >> 5, q = i & 31;
+            const unsigned off = (unsigned)(((t * B + b) * S) * T2V_A + 4 * q) * 4u;
+            for (int n = 0; n < napQ; n += 8) __builtin_amdgcn_s_sleep(8);
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+            int rounds = 0;
+            for (;;) {
+                bool ok = true;
+                sum = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int s = 0; s < S; ++s) {
+                    const f32x4 x = pb_ld16(rQ, off + (unsigned)(s * T2V_A) * 4u);
+                    ok = ok && pb_ok(x[0]) && pb_ok(x[1]) && pb_ok(x[2]) && pb_ok(x[3]);
+                    sum += x;
+                }
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++rounds > PB_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    flag[0] = 0;
+                    break;
+                }
+            }
+            napQ = t2v_adapt_nap(napQ, rounds);
+            *(f32x4*)(dqs + b * T2V_A + 4 * q) = sum;
+        }
+        __syncthreads();
+        if (flag[0] != 1) return;
+        PBA_STAMP(ja == 0 && t == T / 2, 4);
+        // ---- W_q^T dq for the own units: row (u, b) x 4 lanes x 32 attention dims, quad sum; P5: cell A(t)
+        {
+            float acc = 0.f;
+            if (row_on) {
+                const float* wr = wqs + cu * T2V_A + 32 * (tid & 3);
+                const float* dr = dqs + cb * T2V_A + 32 * (tid & 3);
+#pragma unroll
+                for (int i = 0; i < 32; i += 4) {
+                    const float4 w4 = *(const float4*)(wr + i), d4 = *(const float4*)(dr + i);
+                    acc = fmaf(w4.x, d4.x, acc); acc = fmaf(w4.y, d4.y, acc); acc = fmaf(w4.z, d4.z, acc); acc = fmaf(w4.w, d4.w, acc);
+                }
+            }
+            acc = T2V_DPP_ADD(acc, 0xB1);
+            acc = T2V_DPP_ADD(acc, 0x4E);
             if (cell_thr) {
-                const float dh = dhA[cu * 8 + cb] + wq_dq;
+                const float dh = dhA[cu * 8 + cb] + acc;
                 const float* gp = a.GA + ((size_t)t * B + cb) * T2V_G + U;
                 const float gi = gp[0], gf = gp[T2V_H], gg = gp[2 * T2V_H], go = gp[3 * T2V_H];
                 const float cac = a.CA[((size_t)(t + 1) * B + cb) * T2V_H + U];
@@ -859,16 +947,31 @@ __global__ __launch_bounds__(PB_THREADS) void k_achain_bwd(PBAArgs a) {
                 float* sp = stage + (cu * 4) * 8 + cb;
                 sp[0] = d0; sp[8] = d1; sp[16] = d2; sp[24] = d3;
             }
-            __syncthreads();
-            if (t > 0) pba_publish_rows<NB>(rA, (unsigned)t * PB_ROW_BYTES(NB), stage, u0, nu);
         }
         __syncthreads();
-        PBA_STAMP(wg == NT && t == T / 2, 6);
+        if (t > 0) pba_publish_rows<NB>(rA, (unsigned)t * PB_ROW_BYTES(NB), stage, u0, nu);
+        __syncthreads();
+        PBA_STAMP(ja == 0 && t == T / 2, 6);
+    }
+}
+
+template <int NB>      // 4: B <= 4, 6: B = 5, 6
+__global__ __launch_bounds__(PB_THREADS) void k_achain_bwd(PBAArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wg = blockIdx.x;
+    const int S = a.S_sl, NT = a.B * S, NL = T2V_NWG - NT, NA = pba_na(NL), ND = NL - NA;
+    if (wg < NT) {
+        if (a.T_in <= 128) pba_attention_role<16>(a, lds, wg / S, wg % S, NB);
+        else pba_attention_role<32>(a, lds, wg / S, wg % S, NB);
+    } else if (wg < NT + NA) {
+        pba_attention_rnn_role<NB>(a, lds, wg - NT, NA);
+    } else {
+        pba_decoder_role<NB>(a, lds, wg - NT - NA, ND);
     }
 }
 
 static size_t pba_lds_bytes(int B, int T_in) {
-    const size_t lrole = (B > 4 ? 6 : 4) * T2V_G + 4 * 1024 + 64 + 128 + 64 + 256 + 5 * T2V_A + 8 * T2V_A + 4;
+    const size_t lrole = (B > 4 ? 6 : 4) * T2V_G + 6 * 1024 + 192 + 128 + 512 + 16 * T2V_A + 8 * T2V_A + 4;
     const size_t Tcap = (size_t)((T_in + 15) / 16) * 16, JS = T_in <= 128 ? 16 : 32;
     const size_t trole = 4 * Tcap + T2V_E + JS + (1 + JS / 4) * 16 + T2V_A * (JS + 1) + 64 * (JS + 1) + 2 * 8 * T2V_A + 4;
     return sizeof(float) * (lrole > trole ? lrole : trole);
@@ -880,7 +983,7 @@ extern "C" long t2v_decoder_bwd_achain_scratch_floats(int B, int T_in, int T_out
     if (B < 1 || B > PB_MAXB || T_in < 1 || T_in > PB_MAXT || T_out < 1) return 0;
     const size_t S = (size_t)t2v_attn_bwd_slices_(T_in);
     const size_t cx = (size_t)T_out * (B > 4 ? 16384 : 8192) / 4;
-    return (long)(2 * (size_t)T_out * pb_row_bytes(B) / 4 + cx + (size_t)T_out * B * S * 128);
+    return (long)(2 * (size_t)T_out * pb_row_bytes(B) / 4 + cx + (size_t)T_out * B * S * 128 + (size_t)T_out * B * T2V_KATT);
 }
 
 extern "C" int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, const float* w_unused, const t2v_dec_train_bufs* s,
@@ -897,6 +1000,7 @@ extern "C" int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, co
     const int S = t2v_attn_bwd_slices_(T_in);
     const size_t rowf = pb_row_bytes(B) / 4, cxf = (size_t)(B > 4 ? 16384 : 8192) / 4;
     const size_t n_gx = (size_t)T_out * rowf, n_cx = (size_t)T_out * cxf, n_dq = (size_t)T_out * B * S * 128, n_gp = n_dq;
+    const size_t n_ex = (size_t)T_out * B * T2V_KATT;
     if (((uintptr_t)scratch & 15) || ((uintptr_t)DQP & 15) || n_gx * 4 >= 0x7fffffffull || n_dq * 4 >= 0x7fffffffull) return T2V_ERR_ARG;
     if (pba_lds_bytes(B, T_in) > PB_LDS_MAX) return T2V_ERR_ARG;
     static bool attr_set = false;
@@ -907,14 +1011,14 @@ extern "C" int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, co
         attr_set = true;
     }
     (void)hipMemsetAsync(err_word, 0, sizeof(uint32_t), stream);
-    k_pb_fill<<<1024, 256, 0, stream>>>((uint4*)scratch, (2 * n_gx + n_cx + n_gp) / 4);
+    k_pb_fill<<<1024, 256, 0, stream>>>((uint4*)scratch, (2 * n_gx + n_cx + n_gp + n_ex) / 4);
     k_pb_fill<<<256, 256, 0, stream>>>((uint4*)DQP, n_dq / 4);
     PBAArgs a;
     a.w_ih_att = w->w_ih_att; a.w_hh_att = w->w_hh_att; a.w_ih_dec = w->w_ih_dec; a.w_hh_dec = w->w_hh_dec;
     a.wq = w->wq; a.wcomb = w->wcomb; a.v = w->v;
     a.memory = s->memory; a.XS = s->XS; a.CA = s->CA; a.CD = s->CD; a.GA = s->GA; a.GD = s->GD; a.AL = s->AL; a.S = s->S;
     a.dHC = dHC; a.DGA = DGA; a.DGD = DGD; a.DCTX = DCTX; a.DV = DV;
-    a.GXA = scratch; a.GXD = scratch + n_gx; a.CX = scratch + 2 * n_gx; a.GPX = scratch + 2 * n_gx + n_cx; a.DQX = DQP;
+    a.GXA = scratch; a.GXD = scratch + n_gx; a.CX = scratch + 2 * n_gx; a.GPX = scratch + 2 * n_gx + n_cx; a.EX = scratch + 2 * n_gx + n_cx + n_gp; a.DQX = DQP;
     a.err = err_word;
     a.B = B; a.T_in = T_in; a.T = T_out; a.S_sl = S; a.p_att = p_att; a.p_dec = p_dec; a.seed = seed;
     a.step = t2v_step_for(stream);

@@ -1,6 +1,7 @@
 """The one-launch persistent teacher-forced decoder forward (csrc/decoder_train_persist.hip) against the launch-per-step
 loop (decoder_fwd.hip + attn_fwd.hip) on the same inputs, state dropout ON: both draw the same counter-based masks, so
-every saved array of the arena (XS, CA, CD, GA, GD, AL, ACUM, S) and every gradient of the shared backward pass must
+every saved array of the arena (XS, CA, CD, GA, GD, AL, ACUM, S) and every gradient of the backward pass — the
+launch-per-step BPTT and the one-launch persistent reverse pass (csrc/decoder_train_bwd_persist.hip) alike — must
 agree to fp32 summation order — the persistent path is a re-scheduling of the same arithmetic (reference loop
 model.py:415-421), not an approximation."""
 import pytest
@@ -11,9 +12,10 @@ pytestmark = pytest.mark.gpu
 NAMES = ('gpre', 'memory', 'pm', 'lengths', 'XS', 'CA', 'CD', 'GA', 'GD', 'QP', 'AL', 'ACUM', 'S')
 
 
-def _run(dec, mode, mem0, mels, lens, T):
+def _run(dec, mode, mem0, mels, lens, T, bwd=False):
     import t2v_hip as H
     H.DecoderCore.persistent = mode
+    H.DecoderCore.persistent_bwd = bwd
     dec._calls = 0
     for q in dec.parameters():
         q.grad = None
@@ -27,7 +29,7 @@ def _run(dec, mode, mem0, mels, lens, T):
     H.check_async_errors()
     grads = {n: q.grad.clone() for n, q in dec.named_parameters() if q.grad is not None}
     grads['memory'] = mem.grad.clone()
-    return used, mel.detach(), gate.detach(), al.detach(), arena, grads
+    return used, mel.detach(), gate.detach(), al.detach(), arena, grads, H.DecoderCore.last_bwd_mode
 
 
 @pytest.mark.parametrize("B,T_in,T,ragged", [(6, 84, 40, False), (6, 84, 25, True), (1, 5, 7, False), (2, 16, 9, True),
@@ -51,7 +53,9 @@ def test_persistent_forward_equals_launch_per_step(B, T_in, T, ragged):
         lens = torch.tensor([max(1, T_in - 7 * i) for i in range(B)] if ragged else [T_in] * B).cuda()
         a = _run(dec, False, mem0, mels, lens, T)
         b = _run(dec, True, mem0, mels, lens, T)
+        c = _run(dec, True, mem0, mels, lens, T, bwd=True)       # + the one-launch persistent reverse pass
         assert a[0] == 'launch-per-step' and b[0] == 'persistent'
+        assert a[6] == 'launch-per-step' and b[6] == 'launch-per-step' and c[6] == 'persistent'
         for i, name in ((1, 'mel'), (2, 'gate'), (3, 'alignments')):
             assert (a[i] - b[i]).abs().max().item() < 2e-6, name
         for n in a[4]:
@@ -65,8 +69,10 @@ def test_persistent_forward_equals_launch_per_step(B, T_in, T, ragged):
             scale = a[5][n].abs().max().item()
             # (T_in = 1: alpha == 1, so the query / location / memory_layer gradients are rounding noise around zero)
             assert (a[5][n] - b[5][n]).abs().max().item() < 2e-5 * scale + 1e-6 * gmax + 1e-7, (n, scale, gmax)
+            assert (a[5][n] - c[5][n]).abs().max().item() < 2e-5 * scale + 1e-6 * gmax + 1e-7, ('persistent backward', n, scale, gmax)
     finally:
         M.drop_rate, H.DecoderCore.keep_last, H.DecoderCore.persistent = old_drop, old_keep, old_mode
+        H.DecoderCore.persistent_bwd = None
         H.DecoderCore.last_call = H.DecoderCore.last_bwd = None
 
 
