@@ -153,7 +153,7 @@ def decode_bench(model, T_in=200, steps=800):
                     "encoder/postnet excluded"}
 
 
-def frontend_bench(B=6, n_samples=102144, reps=20):
+def frontend_bench(B=6, n_samples=102144, reps=20, big=True):
     """STFT->mel front end (k_mel_frontend): B utterances of 102 144 int16 samples (-> 400 frames
     each), events on the launch stream.  Algorithmic bytes per frame = 256 new samples x 2 B + 80 mels x 4 B = 832 B
     (SURVEY 8(d) counts 1 344 B/frame with fp32 samples)."""
@@ -174,7 +174,12 @@ def frontend_bench(B=6, n_samples=102144, reps=20):
     torch.cuda.synchronize()
     us = 1000.0 * e0.elapsed_time(e1) / reps
     frames = B * (n_samples // 256 + 1)
-    return {"kernel": "k_mel_frontend", "frames_per_s": round(frames / (us * 1e-6), 1), "us_per_launch": round(us, 2),
+    extra = {}
+    if big:     # a batch that fills the chip (128 utterances = 51 328 wavefront-frames): the HBM-bound regime of SURVEY 8(d)
+        r = frontend_bench(B=128, n_samples=n_samples, reps=10, big=False)
+        extra = {"chip_filling_batch": {"B": 128, "us_per_launch": r["us_per_launch"], "frames_per_s": r["frames_per_s"],
+                                        "achieved_GBps": r["achieved_GBps"], "frac_of_hbm_peak": round(r["achieved_GBps"] / HBM_PEAK_GBS, 4)}}
+    return {**extra, "kernel": "k_mel_frontend", "frames_per_s": round(frames / (us * 1e-6), 1), "us_per_launch": round(us, 2),
             "frames_per_launch": frames, "bytes_per_frame": 832, "achieved_GBps": round(frames * 832 / (us * 1e-6) / 1e9, 2),
             "note": "int16 PCM in HBM -> (B,80,T) log-mel in HBM, one launch per batch; not part of the timed train step "
                     "(the synthetic batch carries mels, like the reference's collate output)"}
@@ -448,8 +453,30 @@ def main():
                            if kind == 'headline' else None}
         if not args.no_decode:
             out["decode"] = decode_bench(engine.model)
+            dec_bytes = 72.86e6      # 72.35 MB of recurrent weights + 0.51 MB of memory / processed memory per frame
+            dgbs = dec_bytes / (out["decode"]["us_per_frame"] * 1e-6) / 1e9
+            out["roofline"]["kernels"].append({
+                "kernel": "k_decode_persist", "bound": "hbm", "algorithmic_bytes_per_launch": int(dec_bytes * out["decode"]["steps"]),
+                "avg_launch_us": round(out["decode"]["us_per_frame"] * out["decode"]["steps"], 1), "achieved": round(dgbs, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dgbs / HBM_PEAK_GBS, 4), "launches_per_step": 0,
+                "us_per_frame": out["decode"]["us_per_frame"],
+                "note": "free-running decode, one launch per utterance (not part of the train step): priced against what a "
+                        "per-frame weight stream would have to move (SURVEY 8(d): 9.1 us per frame at 8 TB/s); the kernel itself "
+                        "keeps the weights in registers and is bound by the chain of hand-offs between CUs",
+                "timing": "wall clock around Decoder.inference, %d frames" % out["decode"]["steps"]})
         if world == 1 and not args.no_secondary and not args.force_dist:
             out["frontend"] = frontend_bench()
+            fe = out["frontend"]
+            for tag, us, frames in (("B=6", fe["us_per_launch"], fe["frames_per_launch"]),
+                                    ("B=128", fe["chip_filling_batch"]["us_per_launch"], 128 * (102144 // 256 + 1))):
+                gbs = frames * 832 / (us * 1e-6) / 1e9
+                out["roofline"]["kernels"].append({
+                    "kernel": "k_mel_frontend (%s)" % tag, "bound": "hbm", "algorithmic_bytes_per_launch": frames * 832,
+                    "avg_launch_us": us, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "launches_per_step": 0,
+                    "note": "STFT->mel front end, one launch per batch (not part of the timed train step): int16 PCM in, log-mel "
+                            "out = 832 B per frame; the FFT butterflies make it compute/latency-bound long before HBM",
+                    "timing": "HIP events around back-to-back launches"})
             sec = {}
             del engine
             t2v_hip.DecoderCore.keep_last = False

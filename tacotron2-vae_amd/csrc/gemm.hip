@@ -380,6 +380,107 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
 }
 
 // Backward of the relu / dropout epilogue: the stored output y already carries relu and the 1/(1-p) scaling, so
+// ---- large-tile bf16 variant for the deferred LSTM weight gradients under bf16_run (DGA^T·X, DGD^T·X: K = T·B, both
+// operands stored k-major, i.e. contiguous along their row index): 128x128x32 block tile, 2x2 waves x (2x2) accumulators
+// of v_mfma_f32_32x32x16_bf16.  fp32 operands are rounded to bf16 (RNE) while they are staged; a thread stages 4 rows x
+// 8 consecutive k of ONE operand (threads 0..127 the A tile, 128..255 the B tile: eight 16-byte global loads along the
+// rows) and writes each row's eight bf16 as one 16-byte LDS word [k-group][row] — exactly what a lane reads back as an
+// MFMA operand (conflict-free ds_read_b128), register-staged double buffering, one barrier per k-tile.
+#define GBB_BM 128
+#define GBB_BN 128
+#define GBB_BK 32
+__global__ __launch_bounds__(256) void k_gemm_bf16_big_rr(GemmArgs a) {
+    __shared__ uint4 As[2][GBB_BK / 8][GBB_BM];
+    __shared__ uint4 Bs[2][GBB_BK / 8][GBB_BN];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i0 = blockIdx.y * GBB_BM, j0 = blockIdx.x * GBB_BN;
+    const bool isB = tid >= 128;
+    const int t7 = tid & 127, r4 = t7 & 31, kg = t7 >> 5;
+    const float* P = isB ? a.B : a.A;
+    const long sk = isB ? a.sBk : a.sAk;
+    const int lim = isB ? a.N : a.M, row0 = min((isB ? j0 : i0) + 4 * r4, lim - 4);
+    const float z_row = (isB ? j0 : i0) + 4 * r4 < lim ? 1.f : 0.f;      // M, N are multiples of 4: a row quad is all in or all out
+    float4 rg[8];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rg[u] = *(const float4*)(P + (long)min(k0 + 8 * kg + u, a.K - 1) * sk + row0);
+    };
+    auto store_tiles = [&](int buf, int k0) {
+        float zk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) zk[u] = (k0 + 8 * kg + u < a.K ? 1.f : 0.f) * z_row;
+        uint4* dst = (isB ? &Bs[buf][kg][0] : &As[buf][kg][0]) + 4 * r4;
+        dst[0] = make_uint4(gemm_pack_bf16x2(rg[0].x * zk[0], rg[1].x * zk[1]), gemm_pack_bf16x2(rg[2].x * zk[2], rg[3].x * zk[3]),
+                            gemm_pack_bf16x2(rg[4].x * zk[4], rg[5].x * zk[5]), gemm_pack_bf16x2(rg[6].x * zk[6], rg[7].x * zk[7]));
+        dst[1] = make_uint4(gemm_pack_bf16x2(rg[0].y * zk[0], rg[1].y * zk[1]), gemm_pack_bf16x2(rg[2].y * zk[2], rg[3].y * zk[3]),
+                            gemm_pack_bf16x2(rg[4].y * zk[4], rg[5].y * zk[5]), gemm_pack_bf16x2(rg[6].y * zk[6], rg[7].y * zk[7]));
+        dst[2] = make_uint4(gemm_pack_bf16x2(rg[0].z * zk[0], rg[1].z * zk[1]), gemm_pack_bf16x2(rg[2].z * zk[2], rg[3].z * zk[3]),
+                            gemm_pack_bf16x2(rg[4].z * zk[4], rg[5].z * zk[5]), gemm_pack_bf16x2(rg[6].z * zk[6], rg[7].z * zk[7]));
+        dst[3] = make_uint4(gemm_pack_bf16x2(rg[0].w * zk[0], rg[1].w * zk[1]), gemm_pack_bf16x2(rg[2].w * zk[2], rg[3].w * zk[3]),
+                            gemm_pack_bf16x2(rg[4].w * zk[4], rg[5].w * zk[5]), gemm_pack_bf16x2(rg[6].w * zk[6], rg[7].w * zk[7]));
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+    const int nkt = (a.K + GBB_BK - 1) / GBB_BK;
+    load_tiles(0);
+    store_tiles(0, 0);
+    __syncthreads();
+    const int am = 64 * wm + (lane & 31), bn = 64 * wn + (lane & 31), kq = lane >> 5;
+    typedef __bf16 gbb_bf16x8 __attribute__((ext_vector_type(8)));
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tiles((kt + 1) * GBB_BK);
+        uint4 av[2][2], bv[2][2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            av[s2][0] = As[buf][2 * s2 + kq][am];
+            av[s2][1] = As[buf][2 * s2 + kq][am + 32];
+            bv[s2][0] = Bs[buf][2 * s2 + kq][bn];
+            bv[s2][1] = Bs[buf][2 * s2 + kq][bn + 32];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const gbb_bf16x8*)&av[s2][x], *(const gbb_bf16x8*)&bv[s2][y], acc[x][y], 0, 0, 0);
+        if (kt + 1 < nkt) store_tiles(buf ^ 1, (kt + 1) * GBB_BK);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int j = j0 + 64 * wn + 32 * y + (lane & 31);
+            if (j < a.N) {
+                const float bvs = a.bias ? a.bias[j] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = i0 + 64 * wm + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (i < a.M) {
+                        const size_t idx = (size_t)i * a.ldc + j;
+                        float v = acc[x][y][r] + bvs;
+                        if (a.accumulate) v += a.C[idx];
+                        a.C[idx] = v;
+                    }
+                }
+            }
+        }
+}
+static bool gemm_bf16_big_ok(const GemmArgs& a) {
+    if (a.sAi != 1 || a.sBj != 1 || a.relu || a.p_drop > 0.f) return false;
+    if (a.M < GBB_BM || a.N < GBB_BN || (a.M & 3) || (a.N & 3) || (a.sAk & 3) || (a.sBk & 3)) return false;
+    if (((uintptr_t)a.A | (uintptr_t)a.B) & 15) return false;
+    return (long)((a.M + GBB_BM - 1) / GBB_BM) * ((a.N + GBB_BN - 1) / GBB_BN) >= 128;
+}
+
 // d(pre-activation) = dy * [y != 0] * scale (reference Prenet, model.py:96-99: F.dropout(F.relu(linear(x)), p=0.5)).
 __global__ __launch_bounds__(256) void k_epilogue_bwd(const float4* __restrict__ dy, const float4* __restrict__ y,
                                                       float4* __restrict__ out, size_t n4, float scale) {
@@ -417,6 +518,11 @@ extern "C" int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B,
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
     a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
     a.kz_chunk = 0; a.part = nullptr;
+    if (gemm_bf16_big_ok(a)) {
+        dim3 gb((N + GBB_BN - 1) / GBB_BN, (M + GBB_BM - 1) / GBB_BM);
+        k_gemm_bf16_big_rr<<<gb, 256, 0, stream>>>(a);
+        return t2v_check_launch();
+    }
     dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM);
     const bool akc = sAk == 1, bkc = sBk == 1;
     if (akc && bkc) k_gemm_bf16<true, true><<<grid, 256, 0, stream>>>(a);

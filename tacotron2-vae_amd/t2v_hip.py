@@ -224,13 +224,6 @@ def bf16_enabled():
     return _BF16
 
 
-def mm_mixed(a, b):
-    """a @ b for the deferred weight-gradient GEMMs: bf16 operands / fp32 result under bf16_run, fp32 otherwise."""
-    if _BF16:
-        return (a.to(torch.bfloat16) @ b.to(torch.bfloat16)).float()
-    return a @ b
-
-
 # ---- per-step parameters in device memory (include/t2vae.h: t2v_step_params).  Kernel arguments are frozen when the
 # training step is captured into a HIP graph; the kernels read this 32-byte record at run time instead (dropout epoch,
 # Adam lr / bias corrections, KL weight).  Host values go through a ring of pinned slots: the H2D copy is asynchronous
@@ -697,20 +690,13 @@ class DecoderCore(torch.autograd.Function):
                 if ctx.pre2 is None:        # the prenet columns of attention_rnn.weight_ih get their gradient via gpre
                     wg[0][:, :PRE].zero_()
             d_w_ih_att, d_w_hh_att, d_w_ih_dec, d_w_hh_dec = wg
-            if _BF16:
-                dw_att = mm_mixed(dga2.t(), x_prev[:, :KATT])      # (4096,1536) = [dW_hh | dW_ih[:,256:]]
-                dw_dec = mm_mixed(dgd2.t(), x_cur)                 # (4096,2560) = [dW_ih | dW_hh]
-                for dst, src in ((d_w_hh_att, dw_att[:, :H]), (d_w_ih_att[:, PRE:], dw_att[:, H:]),
-                                 (d_w_ih_dec, dw_dec[:, :KATT]), (d_w_hh_dec, dw_dec[:, KATT:])):
-                    if first:
-                        dst.copy_(src)
-                    else:
-                        dst.add_(src)
-            else:           # each product lands in its own tensor: no split / copy afterwards
-                gemm(dga2.t(), x_prev[:, :H].t(), out=d_w_hh_att, accumulate=not first)
-                gemm(dga2.t(), x_prev[:, H:KATT].t(), out=d_w_ih_att[:, PRE:], accumulate=not first)
-                gemm(dgd2.t(), x_cur[:, :KATT].t(), out=d_w_ih_dec, accumulate=not first)
-                gemm(dgd2.t(), x_cur[:, KATT:].t(), out=d_w_hh_dec, accumulate=not first)
+            # each product lands in its own tensor (no split / copy afterwards).  fp32: the own large-tile fp32 MFMA GEMM;
+            # bf16_run: the own large-tile bf16 GEMM (k_gemm_bf16_big_rr: operands rounded to bf16 while staged, fp32
+            # accumulation) — no library GEMM is left in either step
+            gemm(dga2.t(), x_prev[:, :H].t(), out=d_w_hh_att, accumulate=not first)
+            gemm(dga2.t(), x_prev[:, H:KATT].t(), out=d_w_ih_att[:, PRE:], accumulate=not first)
+            gemm(dgd2.t(), x_cur[:, :KATT].t(), out=d_w_ih_dec, accumulate=not first)
+            gemm(dgd2.t(), x_cur[:, KATT:].t(), out=d_w_hh_dec, accumulate=not first)
             d_bias_dec = colsum(dgd2)
             d_wq = gemm(dq_sum.t(), x_cur[:, :H].t())            # (128,1024)
             d_memory = torch.empty(B, T_in, E, **f32)

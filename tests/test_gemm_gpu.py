@@ -114,3 +114,26 @@ def test_gemm_writes_column_block_of_wider_matrix():
     t2v_hip.gemm(A[:40, :64].cuda(), B[:30, :64].cuda(), out=small[:, 10:40])
     assert (small[:, 10:40].cpu() - A[:40, :64] @ B[:30, :64].t()).abs().max() < 1e-4
     assert float(small[:, :10].abs().max()) == 0.0 and float(small[:, 40:].abs().max()) == 0.0
+
+
+def test_bf16_big_tile_gemm_for_the_lstm_weight_gradients():
+    """bf16_run: DGA^T·X / DGD^T·X (both operands stored k-major) on the own 128x128x32 bf16 MFMA GEMM
+    (k_gemm_bf16_big_rr) — result == fp32 product of the bf16-rounded operands, incl. accumulate, a column-block output
+    (ldc > N) and a K that is not a multiple of the k-tile."""
+    import t2v_hip
+    g = torch.Generator().manual_seed(3)
+    K, M, N = 2400 + 8, 512, 1536
+    dg = torch.randn(K, M, generator=g).cuda()
+    x = torch.randn(K, 2560, generator=g).cuda()
+    want = (dg.bfloat16().float().t().double() @ x[:, 1024:1024 + N].bfloat16().float().double()).float()
+    t2v_hip.set_bf16(True)
+    try:
+        wide = torch.zeros(M, N + 256, device='cuda')
+        out = wide[:, 128:128 + N]
+        t2v_hip.gemm(dg.t(), x[:, 1024:1024 + N].t(), out=out)
+        assert (out - want).abs().max().item() < 2e-3 * want.abs().max().item()
+        assert wide[:, :128].abs().max().item() == 0.0 and wide[:, 128 + N:].abs().max().item() == 0.0
+        t2v_hip.gemm(dg.t(), x[:, 1024:1024 + N].t(), out=out, accumulate=True)
+        assert (out - 2 * want).abs().max().item() < 4e-3 * want.abs().max().item()
+    finally:
+        t2v_hip.set_bf16(False)
