@@ -154,7 +154,7 @@ def test_ctypes_structs_match_header_in_package_and_integration_stub():
     hdr = _header_structs()
     pairs = {'_DecWeights': 't2v_dec_weights', '_DecTrainBufs': 't2v_dec_train_bufs', '_DecBwdBufs': 't2v_dec_bwd_bufs',
              '_DecPersistWeights': 't2v_dec_persist_weights', '_DecPersistBufs': 't2v_dec_persist_bufs',
-             '_DecInferBufs': 't2v_dec_infer_bufs'}
+             '_DecInferBufs': 't2v_dec_infer_bufs', '_DecTrainPersistWeights': 't2v_dec_train_persist_weights'}
     for cls_name in [n for n in dir(t2v_hip) if isinstance(getattr(t2v_hip, n), type) and issubclass(getattr(t2v_hip, n), C.Structure)
                      and n != 'Structure']:
         assert cls_name in pairs or cls_name.lstrip('_') in [k.lstrip('_') for k in pairs] or cls_name.startswith('_Dec'), cls_name
