@@ -283,35 +283,11 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
         }
         PD_STAMP(0, 1);
         // ---- 2. h_att(t) for everyone (attention slices need it now, the others for decoder_rnn)
-        for (int b = 0; b < B; ++b)
-            pd_gather<2>(X + (size_t)b * PD_XW + PD_X_HA, xcur + pd_hatt(B) + (size_t)b * 1024, 1024, tag, a.err, flag);
-        __syncthreads();
-        if (flag[0] != 1) return;
-        PD_STAMP(0, 2);
+        // location features of this frame's tiles (fused filter, K = 64): they depend on the PREVIOUS frame's weights only,
+        // so the attention workgroups evaluate them while h_att(t) is still on its way (round 3, from the training kernel)
+        f32x4 lacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         if (is_attn) {
             const int g = lane >> 4, c16 = lane & 15;
-            const int len = a.lengths ? a.lengths[ab] : Tp;
-            // query slice: thread = (dim d = tid & 15, k part kp = tid >> 4 of 32 k's)
-            {
-                const int d = tid & 15, kp = tid >> 4;
-                const float* wrow = wq_s + d * 1028 + 32 * kp;
-                const float* hx = X + (size_t)ab * PD_XW + PD_X_HA + 32 * kp;
-                float acc = 0.f;
-#pragma unroll
-                for (int i = 0; i < 32; ++i) acc = fmaf(wrow[i], hx[i], acc);
-                qred[kp * 16 + d] = acc;
-            }
-            __syncthreads();
-            if (tid < 16) {
-                float acc = 0.f;
-#pragma unroll
-                for (int i = 0; i < 32; ++i) acc += qred[i * 16 + tid];
-                qv[tid] = acc;
-            }
-            __syncthreads();
-            const float4 q4 = make_float4(qv[4 * g], qv[4 * g + 1], qv[4 * g + 2], qv[4 * g + 3]);
-            // partial energies of this slice: wave -> position tiles wave, wave + 8
-            t2v_u64* exw = xcur + pd_ex(B) + ((size_t)ab * 8 + as) * 256;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int jt = wave + 8 * i;
@@ -328,7 +304,45 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                         l0 = mfma16x4(areg[st], bop[st], l0);
                         l1 = mfma16x4(areg[st + 1], bop[st + 1], l1);
                     }
-                    const f32x4 acc = l0 + l1;
+                    lacc[i] = l0 + l1;
+                }
+            }
+        }
+        for (int b = 0; b < B; ++b)
+            pd_gather<2>(X + (size_t)b * PD_XW + PD_X_HA, xcur + pd_hatt(B) + (size_t)b * 1024, 1024, tag, a.err, flag);
+        __syncthreads();
+        if (flag[0] != 1) return;
+        PD_STAMP(0, 2);
+        if (is_attn) {
+            const int g = lane >> 4, c16 = lane & 15;
+            const int len = a.lengths ? a.lengths[ab] : Tp;
+            // query slice: thread = (dim d = tid >> 5, k part kq = tid & 31): k = 4 kq + 128 i, 16-byte LDS operands; 32-lane
+            // sum = 16-lane DPP row sum + one cross-row exchange (one barrier instead of two and a 32-way tree)
+            {
+                const int d = tid >> 5, kq = tid & 31;
+                const float* wrow = wq_s + d * 1028 + 4 * kq;
+                const float* hx = X + (size_t)ab * PD_XW + PD_X_HA + 4 * kq;
+                float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4 w4 = *(const float4*)(wrow + 128 * i);
+                    const float4 h4 = *(const float4*)(hx + 128 * i);
+                    acc0 = fmaf(w4.x, h4.x, acc0); acc1 = fmaf(w4.y, h4.y, acc1);
+                    acc0 = fmaf(w4.z, h4.z, acc0); acc1 = fmaf(w4.w, h4.w, acc1);
+                }
+                float q = row16_sum(acc0 + acc1);
+                q += __shfl_xor(q, 16, 64);
+                if (kq == 0) qv[d] = q;
+            }
+            __syncthreads();
+            const float4 q4 = make_float4(qv[4 * g], qv[4 * g + 1], qv[4 * g + 2], qv[4 * g + 3]);
+            // partial energies of this slice: wave -> position tiles wave, wave + 8
+            t2v_u64* exw = xcur + pd_ex(B) + ((size_t)ab * 8 + as) * 256;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int jt = wave + 8 * i;
+                if (16 * jt < Tp) {
+                    const f32x4 acc = lacc[i];
                     const int j = 16 * jt + c16;
                     const float4 pm4 = *(const float4*)(pm_s + min(j, Tp - 1) * 16 + 4 * g);
                     const float s0 = tanhf_(q4.x + acc[0] + pm4.x), s1 = tanhf_(q4.y + acc[1] + pm4.y);
@@ -365,22 +379,34 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                 const float ev = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
                 ev0 = tid < len ? ev : -INFINITY;
             }
-            float mloc = ev0;
-            mloc = T2V_DPP_MAX(mloc, 0xB1); mloc = T2V_DPP_MAX(mloc, 0x4E);
-            mloc = T2V_DPP_MAX(mloc, 0x141); mloc = T2V_DPP_MAX(mloc, 0x140);
-            if ((lane & 15) == 0) rsm[tid >> 4] = mloc;
+            {
+                float mloc = ev0;
+                mloc = T2V_DPP_MAX(mloc, 0xB1); mloc = T2V_DPP_MAX(mloc, 0x4E);
+                mloc = T2V_DPP_MAX(mloc, 0x141); mloc = T2V_DPP_MAX(mloc, 0x140);
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                if (lane == 0) rsm[wave] = mloc;
+            }
             __syncthreads();
             if (flag[0] != 1) return;
-            float m = rsm[0];
-#pragma unroll
-            for (int u = 1; u < 32; ++u) m = fmaxf(m, rsm[u]);
+            float m;
+            {
+                const float4 a0 = *(const float4*)rsm, a1 = *(const float4*)(rsm + 4);
+                m = fmaxf(fmaxf(fmaxf(a0.x, a0.y), fmaxf(a0.z, a0.w)), fmaxf(fmaxf(a1.x, a1.y), fmaxf(a1.z, a1.w)));
+            }
             const float e0v = tid < Tp ? expf(ev0 - m) : 0.f;
-            float sloc = row16_sum(e0v);
-            if ((lane & 15) == 0) rss[tid >> 4] = sloc;
+            {
+                float sloc = row16_sum(e0v);
+                sloc += __shfl_xor(sloc, 16, 64);
+                sloc += __shfl_xor(sloc, 32, 64);
+                if (lane == 0) rss[wave] = sloc;
+            }
             __syncthreads();
-            float ssum = 0.f;
-#pragma unroll
-            for (int u = 0; u < 32; ++u) ssum += rss[u];
+            float ssum;
+            {
+                const float4 a0 = *(const float4*)rss, a1 = *(const float4*)(rss + 4);
+                ssum = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
+            }
             const float al = e0v * (1.0f / ssum);
             if (tid < Tp) {
                 eall[tid] = al;
