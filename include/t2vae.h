@@ -324,6 +324,12 @@ int t2v_bn_act_bwd(const float* y, const float* dout, const float* mean, const f
                    const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta,
                    float* dconv_bias, int B, int M, int T, int act, float p_drop, uint64_t seed,
                    uint32_t rng_stream, uint32_t rng_t, void* stream);
+/* the same for eval-mode BatchNorm (running statistics are constants: no batch-statistic terms in dy, dconv_bias =
+ * gamma rstd sum(dz) instead of zeros); mean = running_mean, rstd = 1 / sqrt(running_var + eps) */
+int t2v_bn_act_bwd_eval(const float* y, const float* dout, const float* mean, const float* rstd,
+                   const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta,
+                   float* dconv_bias, int B, int M, int T, int act, float p_drop, uint64_t seed,
+                   uint32_t rng_stream, uint32_t rng_t, void* stream);
 
 /* ------------------------------------------------------------------ symbol embedding
  * nn.Embedding(n_symbols, C) of the text encoder (model.py:474-482) as used at model.py:528

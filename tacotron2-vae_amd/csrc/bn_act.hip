@@ -132,6 +132,7 @@ struct BnBwdArgs {
     float p_drop;
     uint64_t seed; uint32_t rng_stream, rng_t;
     const t2v_step_params* step;
+    int eval_mode;           // running statistics (constants): no batch-statistic terms, the conv bias gets a gradient
 };
 
 __device__ __forceinline__ float bn_dz(const BnBwdArgs& a, size_t idx, float g, float bt, float& xhat, float mean, float rstd) {
@@ -181,9 +182,9 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd(BnBwdArgs a) {
         }
         const float S1 = block_sum_256(s1, scr);
         const float S2 = block_sum_256(s2, scr);
-        if (tid == 0) { a.dbeta[m] = S1; a.dgamma[m] = S2; if (a.dconv_bias) a.dconv_bias[m] = 0.f; }
+        if (tid == 0) { a.dbeta[m] = S1; a.dgamma[m] = S2; if (a.dconv_bias) a.dconv_bias[m] = a.eval_mode ? g * S1 : 0.f; }
         const float n = (float)a.B * (float)a.T;
-        const float m1 = S1 / n, m2 = S2 / n;
+        const float m1 = a.eval_mode ? 0.f : S1 / n, m2 = a.eval_mode ? 0.f : S2 / n;
 #pragma unroll
         for (int e = 0; e < BN_NE; ++e)
             if (tid + 256 * e < nel) a.dy[off[e]] = g * (dzv[e] - m1 - xh[e] * m2);
@@ -200,9 +201,9 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd(BnBwdArgs a) {
     }
     const float S1 = block_sum_256(s1, scr);
     const float S2 = block_sum_256(s2, scr);
-    if (tid == 0) { a.dbeta[m] = S1; a.dgamma[m] = S2; if (a.dconv_bias) a.dconv_bias[m] = 0.f; }
+    if (tid == 0) { a.dbeta[m] = S1; a.dgamma[m] = S2; if (a.dconv_bias) a.dconv_bias[m] = a.eval_mode ? g * S1 : 0.f; }
     const float n = (float)a.B * (float)a.T;
-    const float m1 = S1 / n, m2 = S2 / n;
+    const float m1 = a.eval_mode ? 0.f : S1 / n, m2 = a.eval_mode ? 0.f : S2 / n;
     for (int b = 0; b < a.B; ++b) {
         const size_t base = ((size_t)b * a.M + m) * a.T;
         for (int t = tid; t < a.T; t += 256) {
@@ -239,6 +240,25 @@ extern "C" int t2v_bn_act_bwd(const float* y, const float* dout, const float* me
     a.y = y; a.dout = dout; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.dy = dy;
     a.dgamma = dgamma; a.dbeta = dbeta; a.dconv_bias = dconv_bias; a.B = B; a.M = M; a.T = T; a.act = act; a.p_drop = p_drop;
     a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
+    a.eval_mode = 0;
+    k_bn_act_bwd<<<M, 256, 0, stream>>>(a);
+    return t2v_check_launch();
+}
+
+// eval-mode BatchNorm (model.eval(): running statistics): y = gamma (x - running_mean) rstd + beta with CONSTANT statistics,
+// so dx = gamma rstd dz without the batch-mean terms and the convolution bias in front of it does get a gradient.
+// mean = running_mean, rstd = 1 / sqrt(running_var + eps).
+extern "C" int t2v_bn_act_bwd_eval(const float* y, const float* dout, const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta,
+                                   float* dconv_bias, int B, int M, int T, int act, float p_drop, uint64_t seed,
+                                   uint32_t rng_stream, uint32_t rng_t, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!y || !dout || !mean || !rstd || !gamma || !beta || !dy || !dgamma || !dbeta) return T2V_ERR_ARG;
+    BnBwdArgs a;
+    a.y = y; a.dout = dout; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.dy = dy;
+    a.dgamma = dgamma; a.dbeta = dbeta; a.dconv_bias = dconv_bias; a.B = B; a.M = M; a.T = T; a.act = act; a.p_drop = p_drop;
+    a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
+    a.eval_mode = 1;
     k_bn_act_bwd<<<M, 256, 0, stream>>>(a);
     return t2v_check_launch();
 }

@@ -61,7 +61,7 @@ class _DecInferBufs(C.Structure):
 
 EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_pack_lstm_weights_bf16', 't2v_decoder_train_fwd',
            't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_conv1d_dw_scratch_floats', 't2v_gemm_bf16', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
-           't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats',
+           't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bn_act_bwd_eval', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats',
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_fuse_location_weights', 't2v_decoder_qp_floats',
            't2v_set_step_params', 't2v_set_step_params_stream', 't2v_decoder_replay_bwd_kernels', 't2v_embedding_fwd', 't2v_embedding_bwd', 't2v_gemm_f32_splitk', 't2v_gemm_splitk_scratch_floats',
            't2v_decoder_infer_persistent', 't2v_decoder_persist_supported', 't2v_decoder_persist_granules',
@@ -153,6 +153,7 @@ def load_library():
                                    C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, vp]
     lib.t2v_bn_act_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                    C.c_uint64, C.c_uint32, C.c_uint32, vp]
+    lib.t2v_bn_act_bwd_eval.argtypes = lib.t2v_bn_act_bwd.argtypes
     lib.t2v_bilstm_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.t2v_bilstm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.t2v_gemm_f32.argtypes = [vp, C.c_long, C.c_long, vp, C.c_long, C.c_long, vp, vp, C.c_int, C.c_int, C.c_int,
@@ -902,17 +903,18 @@ class ConvBNAct1d(torch.autograd.Function):
         B, Cin, T, Cout, KS, act, p, seed, rs, rt, training = ctx.cfg
         x, w, y, mean, rstd, gamma, beta, running_mean, running_var = ctx.keep
         f32 = dict(device=x.device, dtype=torch.float32)
-        if not training:   # eval-mode BN backward: statistics are constants
+        bn_bwd = lib.t2v_bn_act_bwd
+        if not training:   # eval-mode BN backward (model.eval() with gradients, e.g. fine-tuning with frozen statistics)
             mean = running_mean
             rstd = torch.rsqrt(running_var + 1e-5)
-            raise T2VHipError("ConvBNAct1d backward is implemented for training-mode BatchNorm only")
+            bn_bwd = lib.t2v_bn_act_bwd_eval
         dout = dout.contiguous()
         dy = torch.empty(B, Cout, T, **f32)
         # d(bias) of a conv feeding a training-mode BatchNorm is identically zero (dy has zero channel mean): the BN
-        # kernel writes those zeros along with dgamma / dbeta
+        # kernel writes those zeros along with dgamma / dbeta (eval mode: the real bias gradient)
         dgamma, dbeta, dbias = _small_grads(ctx.small, Cout, f32)
-        _check(lib.t2v_bn_act_bwd(_p(y), _p(dout), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dy), _p(dgamma),
-                                  _p(dbeta), _p(dbias), B, Cout, T, act, p, seed, rs, rt, _stream()), 't2v_bn_act_bwd')
+        _check(bn_bwd(_p(y), _p(dout), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dy), _p(dgamma),
+                      _p(dbeta), _p(dbias), B, Cout, T, act, p, seed, rs, rt, _stream()), 't2v_bn_act_bwd')
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty(B, Cin, T, **f32) if need_dx else None
         dw = grad_slot(w)
@@ -1168,6 +1170,7 @@ class Conv2dBNReLU(torch.autograd.Function):
                                   _p(rstd), _p(out), B, Cout, Ho * Wo, ACT_RELU, int(bool(training)), 0.0, 0.1, 1e-5,
                                   0, 0, 0, _stream()), 't2v_bn_act_fwd')
         ctx.keep = (x, w, y, mean, rstd, gamma, beta)
+        ctx.running = (running_mean, running_var)
         ctx.small = (gamma, beta, bias)
         ctx.cfg = (B, Cx, Hh, Ww, Cout, Ho, Wo, int(coord), bool(training))
         return out
@@ -1177,14 +1180,16 @@ class Conv2dBNReLU(torch.autograd.Function):
         lib = load_library()
         x, w, y, mean, rstd, gamma, beta = ctx.keep
         B, Cx, Hh, Ww, Cout, Ho, Wo, coord, training = ctx.cfg
-        if not training:
-            raise T2VHipError("Conv2dBNReLU backward needs training-mode BatchNorm")
+        bn_bwd = lib.t2v_bn_act_bwd
+        if not training:        # eval-mode BatchNorm2d: running statistics are constants
+            mean, rstd = ctx.running[0], torch.rsqrt(ctx.running[1] + 1e-5)
+            bn_bwd = lib.t2v_bn_act_bwd_eval
         f32 = dict(device=x.device, dtype=torch.float32)
         dout = dout.contiguous()
         dy = torch.empty_like(y)
         dgamma, dbeta, dbias = _small_grads(ctx.small, Cout, f32)
-        _check(lib.t2v_bn_act_bwd(_p(y), _p(dout), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dy), _p(dgamma),
-                                  _p(dbeta), _p(dbias), B, Cout, Ho * Wo, ACT_RELU, 0.0, 0, 0, 0, _stream()), 't2v_bn_act_bwd')
+        _check(bn_bwd(_p(y), _p(dout), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dy), _p(dgamma),
+                      _p(dbeta), _p(dbias), B, Cout, Ho * Wo, ACT_RELU, 0.0, 0, 0, 0, _stream()), 't2v_bn_act_bwd')
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = torch.empty_like(w)
         nscr = lib.t2v_conv2d_s2_dw_scratch_floats(B, Cx, Hh, Ww, Cout, coord)

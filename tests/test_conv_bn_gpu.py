@@ -94,3 +94,28 @@ def test_symbol_embedding_matches_nn_embedding():
     emb.weight.grad = None
     (emb(ids.cuda()).transpose(1, 2) * w_out.cuda()).sum().backward()
     assert torch.equal(g1, emb.weight.grad)                                        # fixed summation order
+
+
+def test_eval_mode_batchnorm_backward_matches_torch():
+    """model.eval() with gradients (fine-tuning with frozen statistics, saliency): BatchNorm uses its running statistics as
+    constants — dx has no batch-statistic terms and the convolution bias gets a real gradient (t2v_bn_act_bwd_eval)."""
+    import t2v_hip
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    B, Cin, Cout, T = 3, 80, 512, 37
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, 5, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g) * 0.1
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    rm, rv = torch.randn(Cout, generator=g) * 0.2, torch.rand(Cout, generator=g) + 0.5
+    wo = torch.randn(B, Cout, T, generator=g)
+    ref = [t.clone().requires_grad_(True) for t in (x, w, b, gamma, beta)]
+    y = torch.tanh(F.batch_norm(F.conv1d(ref[0], ref[1], ref[2], padding=2), rm.clone(), rv.clone(), ref[3], ref[4], False, 0.1, 1e-5))
+    (y * wo).sum().backward()
+    dev = [t.clone().cuda().requires_grad_(True) for t in (x, w, b, gamma, beta)]
+    out = t2v_hip.ConvBNAct1d.apply(dev[0], dev[1], dev[2], dev[3], dev[4], rm.cuda(), rv.cuda(), False, t2v_hip.ACT_TANH, 0.0, 0, 0, 0)
+    assert (out.cpu() - y).abs().max().item() < 1e-4
+    (out * wo.cuda()).sum().backward()
+    for name, r, d in zip(('x', 'weight', 'bias', 'gamma', 'beta'), ref, dev):
+        scale = r.grad.abs().max().item()
+        assert (d.grad.cpu() - r.grad).abs().max().item() < 3e-3 * scale, name
