@@ -96,6 +96,99 @@ __device__ __forceinline__ int pb_gather_row(f32x4* X0, pb_f32x2* X1, __amdgpu_b
     return rounds;
 }
 
+// ---- the one-launch reverse pass exchanges (d c, d h) of a cell instead of its four gate gradients: a row is
+//   plane 0: unit U -> 32 bytes [dc items 0..3 | dh items 0..3] at byte 32 U          (32 KB)
+//   plane 1: unit U -> 16 bytes [dc items 4, 5 | dh items 4, 5] at byte 32768 + 16 U  (16 KB, B > 4 only)
+// and the gate gradient of row k = r*1024 + U is F[k] * (r == 3 ? dh[U] : dc[U]) with the factor F a function of the
+// forward activations alone (k_pb_factors, before the pass): half the bytes on the wire, and since thread tid consumes
+// exactly the gate rows tid + 512 j — units tid and tid + 512 — it polls its own 96 bytes and nobody else's.
+#define PB_DROW_BYTES(NB) ((NB) > 4 ? 49152u : 32768u)
+// The factors do not wait for anybody: a phase early (their latency hides behind the wait for the other role) the row is
+// copied global -> LDS as it lies (planes 0 and 1 are contiguous in both), by LDS-DMA — 1 KB per wave instruction, no
+// staging registers (the 168 weight registers leave room for only a few loads in flight).  pb_build_row multiplies in
+// place; a barrier must lie between the two.
+template <int NB>
+__device__ __forceinline__ void pb_park_factors(float* ldsX, const float* Frow) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int NCH = PB_ROW_BYTES(NB) / 1024;
+#pragma unroll
+    for (int i = 0; i < NCH / 8; ++i) {
+        const int c = wave + 8 * i;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Frow + 256 * c + 4 * lane),
+                                         (__attribute__((address_space(3))) void*)(ldsX + 256 * c), 16, 0, 0);
+    }
+}
+template <int NB>
+__device__ __forceinline__ int pb_build_row(f32x4* X0, pb_f32x2* X1, __amdgpu_buffer_rsrc_t r, unsigned row_off, int B,
+                                            int nap, unsigned* err, int* flag) {
+    const int tid = threadIdx.x;
+    for (int i = 0; i < nap; i += 8) __builtin_amdgcn_s_sleep(8);
+    f32x4 dc[2], dh[2], dx[2];
+    int rounds = 0;
+    const int nw0 = min(B, 4), nw1 = B - 4;
+    for (;;) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned U = (unsigned)(tid + PB_THREADS * h);
+            dc[h] = pb_ld16(r, row_off + 32u * U);
+            dh[h] = pb_ld16(r, row_off + 32u * U + 16u);
+            if (NB > 4) dx[h] = pb_ld16(r, row_off + 32768u + 16u * U);
+        }
+        bool ok = true;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            ok = ok && pb_ok(dc[h][0]) && (nw0 < 2 || pb_ok(dc[h][1])) && (nw0 < 3 || pb_ok(dc[h][2])) && (nw0 < 4 || pb_ok(dc[h][3]));
+            ok = ok && pb_ok(dh[h][0]) && (nw0 < 2 || pb_ok(dh[h][1])) && (nw0 < 3 || pb_ok(dh[h][2])) && (nw0 < 4 || pb_ok(dh[h][3]));
+            if (NB > 4) ok = ok && pb_ok(dx[h][0]) && pb_ok(dx[h][2]) && (nw1 < 2 || (pb_ok(dx[h][1]) && pb_ok(dx[h][3])));
+        }
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++rounds > PB_SPIN || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = 0;
+            break;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PB_KJ; ++j) {
+        const int h = j & 1;
+        const f32x4 d = (j >> 1) == 3 ? dh[h] : dc[h];
+        X0[tid + PB_THREADS * j] = X0[tid + PB_THREADS * j] * d;
+        if (NB > 4) X1[tid + PB_THREADS * j] = X1[tid + PB_THREADS * j] * ((j >> 1) == 3 ? pb_f32x2{dx[h][2], dx[h][3]} : pb_f32x2{dx[h][0], dx[h][1]});
+    }
+    return rounds;
+}
+
+// F[t][k][item] of one cell: the factor that turns (d c_t, d h_t) into the gate gradient of row k (layout of a gate row)
+__global__ __launch_bounds__(256) void k_pb_factors(const float* __restrict__ G, const float* __restrict__ C, float* __restrict__ F,
+                                                    int B, int T, int nb, float p, int stream_c, uint64_t seed0,
+                                                    const t2v_step_params* step) {
+    const uint64_t seed = t2v_step_seed(seed0, step);
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)T * T2V_G) return;
+    const int t = (int)(i / T2V_G), k = (int)(i % T2V_G), r = k >> 10, U = k & (T2V_H - 1);
+    float f[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        f[b] = 0.f;
+        if (b < B) {
+            const float* gp = G + ((size_t)t * B + b) * T2V_G + U;
+            const float gi = gp[0], gf = gp[T2V_H], gg = gp[2 * T2V_H], go = gp[3 * T2V_H];
+            if (r == 0) f[b] = gg * gi * (1.0f - gi);
+            else if (r == 2) f[b] = gi * (1.0f - gg * gg);
+            else if (r == 3) f[b] = tanhf_(C[((size_t)(t + 1) * B + b) * T2V_H + U]) * go * (1.0f - go);
+            else {
+                float cprev = C[((size_t)t * B + b) * T2V_H + U];
+                if (t > 0) cprev *= t2v_drop_scale(seed, stream_c, t - 1, (uint32_t)b * T2V_H + U, p);
+                f[b] = cprev * gf * (1.0f - gf);
+            }
+        }
+    }
+    float* row = F + (size_t)t * (nb > 4 ? 6 : 4) * T2V_G;
+    *(f32x4*)(row + 4 * (size_t)k) = f32x4{f[0], f[1], f[2], f[3]};
+    if (nb > 4) *(pb_f32x2*)(row + 4 * T2V_G + 2 * (size_t)k) = pb_f32x2{f[4], f[5]};
+}
+
 // acc[c][pair] += w[c][j] * x[k_j][pair] for NC output columns: packed FMAs (two items per op, weight broadcast through
 // op_sel; even j = low word of the weight pair, odd j = high word) in volatile asm so the k loop keeps its shape.
 template <bool ODD>
@@ -360,7 +453,8 @@ struct PBAArgs {
     // outputs
     float* DGA; float* DGD; float* DCTX; float* DV;       // DV (B,S,128)
     // exchange (sentinel-filled): gate-gradient rows of both cells, context gradients, dq partials, window partials
-    float* GXA; float* GXD; float* CX; float* DQX; float* GPX; float* EX;      // EX (T,B,1536): E(t) = Wcat_dec[:, :1536]^T dgd(t)
+    float* GXA; float* GXD; float* CX; float* DQX; float* GPX; float* EX;
+    const float* FA; const float* FD;    // gate-gradient factors of both cells (k_pb_factors)      // EX (T,B,1536): E(t) = Wcat_dec[:, :1536]^T dgd(t)
     unsigned* err;
     int B, T_in, T, S_sl;
     float p_att, p_dec;
@@ -368,7 +462,12 @@ struct PBAArgs {
     const t2v_step_params* step;
     unsigned long long* prof;
 };
-#define PBA_STAMP(COND, I) do { if (a.prof && (COND) && threadIdx.x == 0) a.prof[(I)] = __builtin_readcyclecounter(); } while (0)
+// phase profile (tools/dbg/persist_bwd_prof.py): slot I accumulates, over all steps, the cycles since the previous stamp
+#define PBA_STAMP(COND, I) do { if (a.prof && (COND) && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
+        lprof_[(I)] += now_ - tprev_; tprev_ = now_; } } while (0)
+#define PBA_PROF_INIT(FLAGP) unsigned long long* lprof_ = (unsigned long long*)((FLAGP) + 4); \
+    if (threadIdx.x < 16) lprof_[threadIdx.x] = 0ull
+#define PBA_PROF_FLUSH(COND, I0, N) do { if (a.prof && (COND) && threadIdx.x < (N)) a.prof[(I0) + threadIdx.x] = lprof_[(I0) + threadIdx.x]; } while (0)
 
 // context-gradient row of a step in CX: [plane][512 columns][4 items] (16 bytes per column and plane)
 #define PB_CX_ROW_BYTES(NB) ((NB) > 4 ? 16384u : 8192u)
@@ -423,10 +522,12 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
     if (tid == 0) flag[0] = 1;
     float dvacc = 0.f;                          // tid < 128: running dv[tid] of this slice
     int nap = 0;
+    PBA_PROF_INIT(flag);
     __syncthreads();
+    unsigned long long tprev_ = __builtin_readcyclecounter();
 
     for (int t = T - 1; t >= 0; --t) {
-        PBA_STAMP(blockIdx.x == 0 && t == T / 2, 8);
+        PBA_STAMP(blockIdx.x == 0, 8);
         // ---- operands that do not wait for the context gradient: tanh outputs, alpha(t), ctx(t), window partials of step t+1
         float4 sreg[JS / 8];
         float2 ctx2 = make_float2(0.f, 0.f);
@@ -493,7 +594,7 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
         }
         __syncthreads();
         if (flag[0] != 1) return;
-        PBA_STAMP(blockIdx.x == 0 && t == T / 2, 9);
+        PBA_STAMP(blockIdx.x == 0, 9);
         // ---- dot = dctx·ctx_t + sum_j alpha_j (Gprev_j + Gcum_j); dalpha of the own positions = dctx·memory_j + G_j
         {
             float dotp = dot_g;
@@ -558,7 +659,7 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
             pb_st4(rQ, (unsigned)(((t * B + b) * S + s) * T2V_A + tid) * 4u, q);       // the cell workgroups wait for this
             dvacc += vv;
         }
-        PBA_STAMP(blockIdx.x == 0 && t == T / 2, 10);
+        PBA_STAMP(blockIdx.x == 0, 10);
         // ---- through the fused location filter on MFMA: T[(c,k)][jl] = sum_d W_comb[d][(c,k)] dpre[jl][d], K = 128
         if (act) {
 #pragma unroll
@@ -593,14 +694,15 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
             }
         }
         __syncthreads();
-        PBA_STAMP(blockIdx.x == 0 && t == T / 2, 11);
+        PBA_STAMP(blockIdx.x == 0, 11);
     }
     if (tid < T2V_A) a.DV[((size_t)b * S + s) * T2V_A + tid] = dvacc;
+    PBA_PROF_FLUSH(blockIdx.x == 0, 8, 4);
 }
 
 // y[C0 + c][pair] = sum_j w[C0 + c][j] * x[k_j][pair] for NC of the thread's columns; one LDS operand per gate row with two
 // more in flight (the 168 weight registers leave no room for all eight)
-template <int NCT, int C0, int NC, int NB>
+template <int NCT, int C0, int NC, int NB, int VS = 8>
 __device__ __forceinline__ void pb_gemv_cols(const pb_f32x2 (&w)[NCT][PB_KJ / 2], const f32x4* X0, const pb_f32x2* X1, float (&v)[32]) {
     const int tid = threadIdx.x;
     pb_f32x2 acc[NC][3];
@@ -635,7 +737,7 @@ __device__ __forceinline__ void pb_gemv_cols(const pb_f32x2 (&w)[NCT][PB_KJ / 2]
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { v[c * 8 + 2 * i] = acc[c][i][0]; v[c * 8 + 2 * i + 1] = acc[c][i][1]; }
+        for (int i = 0; i < 3; ++i) { v[c * VS + 2 * i] = acc[c][i][0]; v[c * VS + 2 * i + 1] = acc[c][i][1]; }
 }
 
 // ---- role split of the LSTM workgroups (NL = 256 - B*S of them).  One workgroup set per cell halves the gate-gradient
@@ -647,11 +749,12 @@ __device__ __forceinline__ void pb_gemv_cols(const pb_f32x2 (&w)[NCT][PB_KJ / 2]
 //           loop needs only dHC and its own recurrence, so it FREE-RUNS ahead of the A chain and leaves
 //           E(t) = Wcat_dec[:, :1536]^T dgd(t) — decoder_rnn's contribution to d h_att(t) / d ctx(t) — in a sentinel-filled
 //           array the A workgroups read when they get there.
-#define PBA_NUA 14
+#define PBA_NUA 13
 #define PBA_NCA 7
 #define PBA_NUD 8
 #define PBA_NCD 4
-__host__ __device__ static inline int pba_na(int NL) { return (3 * NL + 4) / 8; }
+// (>= 79 workgroups: at most 13 units and 7 context columns each — 20 columns = 160 weight registers per thread)
+__host__ __device__ static inline int pba_na(int NL) { const int n = (3 * NL + 4) / 8; return n < 79 ? 79 : n; }
 
 // final sums of a column-grouped GEMV: NCOL columns x 8 item slots -> ysum[col * 8 + b]
 __device__ __forceinline__ void pba_finish_sums(const float* part, float* ysum, int ncol) {
@@ -676,16 +779,15 @@ __device__ __forceinline__ float pba_wait_word(__amdgpu_buffer_rsrc_t r, unsigne
     return __uint_as_float(x);
 }
 
-// stage[u][gate][8 items] -> one 16-byte (+ one 8-byte) write-through store per gate row k = gate*1024 + U
+// stage[u][{dc, dh}][8 items] -> one 16-byte (+ one 8-byte) write-through store per unit and quantity
 template <int NB>
 __device__ __forceinline__ void pba_publish_rows(__amdgpu_buffer_rsrc_t r, unsigned row_off, const float* stage, int u0, int nu) {
     const int tid = threadIdx.x;
-    if (tid < 4 * nu) {
-        const int u = tid >> 2, rr = tid & 3;
-        const int k = rr * T2V_H + u0 + u;
-        const float* sp = stage + (u * 4 + rr) * 8;
-        pb_st16(r, row_off + 16u * (unsigned)k, f32x4{sp[0], sp[1], sp[2], sp[3]});
-        if (NB > 4) pb_st8(r, row_off + 65536u + 8u * (unsigned)k, pb_f32x2{sp[4], sp[5]});
+    if (tid < 2 * nu) {
+        const int u = tid >> 1, q = tid & 1;
+        const float* sp = stage + (u * 2 + q) * 8;
+        pb_st16(r, row_off + 32u * (unsigned)(u0 + u) + 16u * (unsigned)q, f32x4{sp[0], sp[1], sp[2], sp[3]});
+        if (NB > 4) pb_st8(r, row_off + 32768u + 16u * (unsigned)(u0 + u) + 8u * (unsigned)q, pb_f32x2{sp[4], sp[5]});
     }
 }
 
@@ -730,14 +832,15 @@ __device__ __forceinline__ void pba_decoder_role(const PBAArgs& a, float* lds, c
     const uint32_t idx = (uint32_t)cb * T2V_H + U;
     float dcd = 0.f;
     int nap = 0;
+    pb_park_factors<NB>(lds, a.FD + (size_t)(T - 1) * (PB_ROW_BYTES(NB) / 4));
     __syncthreads();
 
     // iteration t: (t < T) gather dgd(t), yd = Wcat_dec^T dgd(t): publish E(t), keep the recurrent part;  (t >= 1) cell D(t-1)
     for (int t = T; t >= 0; --t) {
         if (t < T) {
-            const int rounds = pb_gather_row<NB>(X0, X1, rD, (unsigned)t * PB_ROW_BYTES(NB), B, nap, a.err, flag);
+            const int rounds = pb_build_row<NB>(X0, X1, rD, (unsigned)t * PB_DROW_BYTES(NB), B, nap, a.err, flag);
             nap = t2v_adapt_nap(nap, rounds);
-            __syncthreads();
+            __syncthreads();                                // (operands are thread-private; the barrier only spreads a time-out)
             if (flag[0] != 1) return;
             float v[32];
             pb_gemv_cols<20, 0, 4, NB>(w, X0, X1, v);
@@ -751,6 +854,7 @@ __device__ __forceinline__ void pba_decoder_role(const PBAArgs& a, float* lds, c
             pb_gemv_cols<20, 16, 4, NB>(w, X0, X1, v);
             pb_reduce32(v, part + 4096);
             __syncthreads();
+            if (t > 0) pb_park_factors<NB>(lds, a.FD + (size_t)(t - 1) * (PB_ROW_BYTES(NB) / 4));
             pba_finish_sums(part, ysum, 20);
             __syncthreads();
             // E(t): [h_att columns | ctx columns] of this workgroup, plain (T,B,1536) layout
@@ -781,14 +885,31 @@ __device__ __forceinline__ void pba_decoder_role(const PBAArgs& a, float* lds, c
                 dcd = dct * gf;
                 float* o = a.DGD + ((size_t)td * B + cb) * T2V_G + U;
                 o[0] = d0; o[T2V_H] = d1; o[2 * T2V_H] = d2; o[3 * T2V_H] = d3;
-                float* sp = stage + (cu * 4) * 8 + cb;
-                sp[0] = d0; sp[8] = d1; sp[16] = d2; sp[24] = d3;
+                float* sp = stage + (cu * 2) * 8 + cb;
+                sp[0] = dct; sp[8] = dht;
             }
             // (stage is written and read by wave 0 only: LDS operations of one wave complete in order)
-            if (tid < 64) pba_publish_rows<NB>(rD, (unsigned)td * PB_ROW_BYTES(NB), stage, u0, nu);
+            if (tid < 64) pba_publish_rows<NB>(rD, (unsigned)td * PB_DROW_BYTES(NB), stage, u0, nu);
         }
         __syncthreads();
     }
+}
+
+// the activation-only part of attention_rnn's cell backward at step t -> cpre[row][8] = {fh, fc, go(1-tanh(c)^2), gf, e0..e3}
+__device__ __forceinline__ void pba_cell_pre(const PBAArgs& a, float* cpre, uint64_t seed, bool cell_thr, int rowi, int t, int cb, int U,
+                                             uint32_t idx) {
+    if (!cell_thr) return;
+    const int B = a.B;
+    const float* gp = a.GA + ((size_t)t * B + cb) * T2V_G + U;
+    const float gi = gp[0], gf = gp[T2V_H], gg = gp[2 * T2V_H], go = gp[3 * T2V_H];
+    const float cac = a.CA[((size_t)(t + 1) * B + cb) * T2V_H + U];
+    float cprev = a.CA[((size_t)t * B + cb) * T2V_H + U];
+    const float fh = t2v_drop_scale(seed, T2V_RNG_ATT_H, t, idx, a.p_att);
+    const float fc = t2v_drop_scale(seed, T2V_RNG_ATT_C, t, idx, a.p_att);
+    if (t > 0) cprev *= t2v_drop_scale(seed, T2V_RNG_ATT_C, t - 1, idx, a.p_att);
+    const float tc = tanhf_(cac);
+    *(float4*)(cpre + rowi * 8) = make_float4(fh, fc, go * (1.0f - tc * tc), gf);
+    *(float4*)(cpre + rowi * 8 + 4) = make_float4(gg * gi * (1.0f - gi), cprev * gf * (1.0f - gf), gi * (1.0f - gg * gg), tc * go * (1.0f - go));
 }
 
 // ------------------------------------------------------------------------------------------------ A role (the chain)
@@ -805,12 +926,14 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
     float* stage = dhA + 128;                              // [14 -> 16 units][4][8]
     float* wqs = stage + 512;                              // [14 -> 16][128] W_q^T rows of the own units
     float* dqs = wqs + 16 * T2V_A;                         // [8][128] dq(t) per item
-    int* flag = (int*)(dqs + 8 * T2V_A);
+    float* cpre = dqs + 8 * T2V_A;                         // [2][128 rows][8] activation-only factors of cell steps t, t-1
+    float* eps = cpre + 2048;                              // [256] E(t) words / dHC words of the P2 threads (thread-private)
+    int* flag = (int*)(eps + 256);
     const int u0 = (ja * T2V_H) / NA, nu = ((ja + 1) * T2V_H) / NA - u0;      // <= 14 units
     const int c0 = (ja * T2V_E) / NA, nc = ((ja + 1) * T2V_E) / NA - c0;      // <= 7 context columns
     const __amdgpu_buffer_rsrc_t rA = pb_rsrc(a.GXA), rC = pb_rsrc(a.CX), rQ = pb_rsrc(a.DQX), rE = pb_rsrc(a.EX);
     // columns: [0, 14) W_hh_att[k][U], [14, 21) W_ih_att[k][256 + C]
-    pb_f32x2 w[21][PB_KJ / 2];
+    pb_f32x2 w[20][PB_KJ / 2];
 #pragma unroll
     for (int jj = 0; jj < PB_KJ; ++jj) {
         const size_t k = (size_t)(tid + PB_THREADS * jj);
@@ -822,7 +945,7 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
 #pragma unroll
         for (int c = 0; c < PBA_NCA; ++c) {
             const bool on = c < nc;
-            w[14 + c][jj / 2][jj & 1] = on ? a.w_ih_att[k * (T2V_PRE + T2V_E) + T2V_PRE + c0 + (on ? c : 0)] : 0.f;
+            w[PBA_NUA + c][jj / 2][jj & 1] = on ? a.w_ih_att[k * (T2V_PRE + T2V_E) + T2V_PRE + c0 + (on ? c : 0)] : 0.f;
         }
     }
     for (int i = tid; i < 16 * T2V_A; i += PB_THREADS) {
@@ -837,56 +960,120 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
     const bool cell_thr = (tid & 3) == 0 && cu < nu && cb < B;
     const int U = u0 + (cu < nu ? cu : 0);
     const uint32_t idx = (uint32_t)cb * T2V_H + U;
-    float dca = 0.f;
+    float dca = 0.f, pfsink = 0.f;
     int napA = 0, napQ = 0;
+    PBA_PROF_INIT(flag);
+    pba_cell_pre(a, cpre + ((T - 1) & 1) * 1024, seed, cell_thr, rowi, T - 1, cb, U, idx);
     __syncthreads();
+    unsigned long long tprev_ = __builtin_readcyclecounter();
 
     for (int t = T - 1; t >= 0; --t) {
-        PBA_STAMP(ja == 0 && t == T / 2, 0);
-        // ---- P1: ya = Wcat_att^T dga(t+1) for the own columns
-        if (t < T - 1) {
-            const int rounds = pb_gather_row<NB>(X0, X1, rA, (unsigned)(t + 1) * PB_ROW_BYTES(NB), B, napA, a.err, flag);
-            napA = t2v_adapt_nap(napA, rounds);
-            __syncthreads();
-            if (flag[0] != 1) return;
-            PBA_STAMP(ja == 0 && t == T / 2, 1);
-            float v[32];
-            pb_gemv_cols<21, 0, 4, NB>(w, X0, X1, v);
-            pb_reduce32(v, part);
-            pb_gemv_cols<21, 4, 4, NB>(w, X0, X1, v);
-            pb_reduce32(v, part + 1024);
-            pb_gemv_cols<21, 8, 4, NB>(w, X0, X1, v);
-            pb_reduce32(v, part + 2048);
-            pb_gemv_cols<21, 12, 4, NB>(w, X0, X1, v);
-            pb_reduce32(v, part + 3072);
-            pb_gemv_cols<21, 16, 4, NB>(w, X0, X1, v);
-            pb_reduce32(v, part + 4096);
-            pb_gemv_cols<21, 20, 1, NB>(w, X0, X1, v);
-            pb_reduce32(v, part + 5120);
-            __syncthreads();
-            pba_finish_sums(part, ysum, 21);
-            __syncthreads();
-        }
-        PBA_STAMP(ja == 0 && t == T / 2, 2);
-        // ---- P2: context gradient of the own columns -> attention workgroups; d h_att partial for the cell.  E(t) comes
-        // from the decoder_rnn workgroups, which run ahead
+        PBA_STAMP(ja == 0, 0);
+        // decoder_rnn's contribution E(t) was published long ago (that role runs ahead): fetched before the chain needs it
+        unsigned e_raw = PB_SENT, e_off = 0u;
+        float dhc_pre = 0.f;
         if (tid < 56) {
             const int c = tid >> 3, b = tid & 7;
             if (c < nc && b < B) {
-                const float e = pba_wait_word(rE, (unsigned)(((t * B + b) * T2V_KATT) + T2V_H + c0 + c) * 4u, a.err, flag);
-                const float val = a.dHC[((size_t)t * B + b) * (T2V_H + T2V_E) + T2V_H + c0 + c] + e + (t < T - 1 ? ysum[(14 + c) * 8 + b] : 0.f);
-                pb_st4(rC, (unsigned)t * PB_CX_ROW_BYTES(NB) + (unsigned)((b >> 2) * T2V_E + c0 + c) * 16u + 4u * (unsigned)(b & 3), val);
-                a.DCTX[((size_t)t * B + b) * T2V_E + c0 + c] = val;
+                e_off = (unsigned)(((t * B + b) * T2V_KATT) + T2V_H + c0 + c) * 4u;
+                e_raw = pb_ld4(rE, e_off);
+                dhc_pre = a.dHC[((size_t)t * B + b) * (T2V_H + T2V_E) + T2V_H + c0 + c];
             }
         } else if (tid >= 64 && tid < 64 + 112) {
             const int i = tid - 64, u = i >> 3, b = i & 7;
-            if (u < nu && b < B)
-                dhA[i] = pba_wait_word(rE, (unsigned)(((t * B + b) * T2V_KATT) + u0 + u) * 4u, a.err, flag) + (t < T - 1 ? ysum[i] : 0.f);
+            if (u < nu && b < B) {
+                e_off = (unsigned)(((t * B + b) * T2V_KATT) + u0 + u) * 4u;
+                e_raw = pb_ld4(rE, e_off);
+            }
         }
-        PBA_STAMP(ja == 0 && t == T / 2, 3);
+        // ---- P1a: the CONTEXT columns of ya = Wcat_att^T dga(t+1) first — they are what the attention workgroups wait for
+        const bool have = t < T - 1;
+        if (have) {
+            const int rounds = pb_build_row<NB>(X0, X1, rA, (unsigned)(t + 1) * PB_DROW_BYTES(NB), B, napA, a.err, flag);
+            napA = t2v_adapt_nap(napA, rounds);
+            PBA_STAMP(ja == 0, 1);
+        }
+        // (the poll has drained the memory queue: parked in LDS, E / dHC cost no wait on the vector-memory counter later —
+        // register spills of the GEMV are stores that count there)
+        if (tid < 176) {
+            eps[tid] = __uint_as_float(e_raw);
+            if (tid < 56) eps[192 + tid] = dhc_pre;
+        }
+        if (have) {
+            float v[32];
+            pb_gemv_cols<20, 13, 4, NB>(w, X0, X1, v);
+            pb_reduce32(v, part);
+            pb_gemv_cols<20, 17, 3, NB>(w, X0, X1, v);
+            pb_reduce32(v, part + 1024);
+            __syncthreads();
+        }
+        PBA_STAMP(ja == 0, 2);
+        // ---- P2: context gradient of the own columns -> attention workgroups (E(t) comes from the decoder_rnn workgroups)
+        if (tid < 56) {
+            const int c = tid >> 3, b = tid & 7;
+            if (c < nc && b < B) {
+                float e = eps[tid];
+                if (__float_as_uint(e) == PB_SENT) e = pba_wait_word(rE, e_off, a.err, flag);
+                const float val = (e + eps[192 + tid]) + (have ? pb_sum32(part + (tid >> 5) * 1024, tid & 31) : 0.f);
+                pb_st4(rC, (unsigned)t * PB_CX_ROW_BYTES(NB) + (unsigned)((b >> 2) * T2V_E + c0 + c) * 16u + 4u * (unsigned)(b & 3), val);
+                a.DCTX[((size_t)t * B + b) * T2V_E + c0 + c] = val;
+            }
+        }
+        PBA_STAMP(ja == 0, 3);
+        // warm this XCD's L2 with the factor row that is parked one step from now (first touch comes from HBM): one word per
+        // 128-byte line, consumed only at the end of the step
+        float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f;
+        if (tid >= 192 && t >= 2) {
+            const float* fr = a.FA + (size_t)(t - 1) * (PB_ROW_BYTES(NB) / 4);
+            const int i = tid - 192;
+            constexpr int NLINE = PB_ROW_BYTES(NB) / 128;
+            pf0 = fr[32 * i];
+            if (i + 320 < NLINE) pf1 = fr[32 * (i + 320)];
+            if (i + 640 < NLINE) pf2 = fr[32 * (i + 640)];
+        } else if (tid >= 64 && tid < 64 + 36 && t >= 2) {
+            // ... and with the activation lines of cell A(t-2) (its pre-part runs at the end of the next step)
+            const int i = tid - 64, t2 = t - 2;
+            const int b = i < 24 ? i % 6 : (i - 24) % 6;
+            if (b < B) {
+                const float* q = i < 24 ? a.GA + ((size_t)t2 * B + b) * T2V_G + (i / 6) * T2V_H + u0
+                                        : a.CA + ((size_t)(t2 + (i < 30 ? 1 : 0)) * B + b) * T2V_H + u0;
+                pf0 = q[0];
+                pf1 = q[nu - 1];
+            }
+        }
+        // ---- P1b: the recurrent columns (d h_att partial for the cell) while the attention workgroups work on step t
+        if (have) {
+            float v[32];
+            pb_gemv_cols<20, 0, 4, NB>(w, X0, X1, v);
+            pb_reduce32(v, part + 2048);
+            pb_gemv_cols<20, 4, 4, NB>(w, X0, X1, v);
+            pb_reduce32(v, part + 3072);
+            pb_gemv_cols<20, 8, 4, NB>(w, X0, X1, v);
+            pb_reduce32(v, part + 4096);
+            pb_gemv_cols<20, 12, 1, NB>(w, X0, X1, v);
+            pb_reduce32(v, part + 5120);
+            __syncthreads();
+        }
+        if (tid >= 64 && tid < 64 + 112) {
+            const int i = tid - 64, u = i >> 3, b = i & 7;
+            if (u < nu && b < B) {
+                float e = eps[tid];
+                if (__float_as_uint(e) == PB_SENT) e = pba_wait_word(rE, e_off, a.err, flag);
+                dhA[i] = e + (have ? pb_sum32(part + 2048 + (i >> 5) * 1024, i & 31) : 0.f);
+            }
+        }
+        PBA_STAMP(ja == 0, 5);
+        // while dq(t) is on its way, prepare the next step: the factors of the next gather (row t) into the operand slots
+        // (the recurrent GEMV was their last reader), and the part of cell A(t-1) that does not depend on d h_att
+        if (t > 0) {
+            pb_park_factors<NB>(lds, a.FA + (size_t)t * (PB_ROW_BYTES(NB) / 4));
+            PBA_STAMP(ja == 0, 12);
+            pba_cell_pre(a, cpre + ((t - 1) & 1) * 1024, seed, cell_thr, rowi, t - 1, cb, U, idx);
+            PBA_STAMP(ja == 0, 13);
+        }
         // ---- P4: dq(t) of every item (sum of the position slices' partial rows)
-        if (tid >= 256 && tid < 256 + B * 32) {
-            const int i = tid - 256, b = i >> 5, q = i & 31;
+        if (tid >= 320 && tid < 320 + B * 32) {
+            const int i = tid - 320, b = i >> 5, q = i & 31;
             const unsigned off = (unsigned)(((t * B + b) * S) * T2V_A + 4 * q) * 4u;
             for (int n = 0; n < napQ; n += 8) __builtin_amdgcn_s_sleep(8);
             f32x4 sum = {0.f, 0.f, 0.f, 0.f};
@@ -912,7 +1099,7 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
         }
         __syncthreads();
         if (flag[0] != 1) return;
-        PBA_STAMP(ja == 0 && t == T / 2, 4);
+        PBA_STAMP(ja == 0, 4);
         // ---- W_q^T dq for the own units: row (u, b) x 4 lanes x 32 attention dims, quad sum; P5: cell A(t)
         {
             float acc = 0.f;
@@ -928,31 +1115,29 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
             acc = T2V_DPP_ADD(acc, 0xB1);
             acc = T2V_DPP_ADD(acc, 0x4E);
             if (cell_thr) {
+                const float* cp = cpre + (t & 1) * 1024 + rowi * 8;
+                const float4 c0v = *(const float4*)cp, c1v = *(const float4*)(cp + 4);
                 const float dh = dhA[cu * 8 + cb] + acc;
-                const float* gp = a.GA + ((size_t)t * B + cb) * T2V_G + U;
-                const float gi = gp[0], gf = gp[T2V_H], gg = gp[2 * T2V_H], go = gp[3 * T2V_H];
-                const float cac = a.CA[((size_t)(t + 1) * B + cb) * T2V_H + U];
-                float cprev = a.CA[((size_t)t * B + cb) * T2V_H + U];
-                const float fh = t2v_drop_scale(seed, T2V_RNG_ATT_H, t, idx, a.p_att);
-                const float fc = t2v_drop_scale(seed, T2V_RNG_ATT_C, t, idx, a.p_att);
-                if (t > 0) cprev *= t2v_drop_scale(seed, T2V_RNG_ATT_C, t - 1, idx, a.p_att);
-                const float tc = tanhf_(cac);
-                const float dht = dh * fh;
-                const float dct = dca * fc + dht * go * (1.0f - tc * tc);
-                const float d0 = dct * gg * gi * (1.0f - gi), d1 = dct * cprev * gf * (1.0f - gf);
-                const float d2 = dct * gi * (1.0f - gg * gg), d3 = dht * tc * go * (1.0f - go);
-                dca = dct * gf;
+                const float dht = dh * c0v.x;                         // cfh
+                const float dct = dca * c0v.y + dht * c0v.z;          // cfc, go (1 - tanh(c)^2)
+                const float d0 = dct * c1v.x, d1 = dct * c1v.y, d2 = dct * c1v.z, d3 = dht * c1v.w;
+                dca = dct * c0v.w;                                    // gf
                 float* o = a.DGA + ((size_t)t * B + cb) * T2V_G + U;
                 o[0] = d0; o[T2V_H] = d1; o[2 * T2V_H] = d2; o[3 * T2V_H] = d3;
-                float* sp = stage + (cu * 4) * 8 + cb;
-                sp[0] = d0; sp[8] = d1; sp[16] = d2; sp[24] = d3;
+                float* sp = stage + (cu * 2) * 8 + cb;
+                sp[0] = dct; sp[8] = dht;
             }
         }
         __syncthreads();
-        if (t > 0) pba_publish_rows<NB>(rA, (unsigned)t * PB_ROW_BYTES(NB), stage, u0, nu);
+        if (t > 0) pba_publish_rows<NB>(rA, (unsigned)t * PB_DROW_BYTES(NB), stage, u0, nu);
+        PBA_STAMP(ja == 0, 6);
+        pfsink += (pf0 + pf1) + pf2;
         __syncthreads();
-        PBA_STAMP(ja == 0 && t == T / 2, 6);
+        PBA_STAMP(ja == 0, 7);
     }
+    PBA_PROF_FLUSH(ja == 0, 0, 8);
+    PBA_PROF_FLUSH(ja == 0, 12, 4);
+    if (__float_as_uint(pfsink) == 0x7fa00001u) a.err[0] = 2u;      // never true: keeps the prefetch loads alive
 }
 
 template <int NB>      // 4: B <= 4, 6: B = 5, 6
@@ -971,9 +1156,9 @@ __global__ __launch_bounds__(PB_THREADS) void k_achain_bwd(PBAArgs a) {
 }
 
 static size_t pba_lds_bytes(int B, int T_in) {
-    const size_t lrole = (B > 4 ? 6 : 4) * T2V_G + 6 * 1024 + 192 + 128 + 512 + 16 * T2V_A + 8 * T2V_A + 4;
+    const size_t lrole = (B > 4 ? 6 : 4) * T2V_G + 6 * 1024 + 192 + 128 + 512 + 16 * T2V_A + 8 * T2V_A + 2048 + 256 + 40;
     const size_t Tcap = (size_t)((T_in + 15) / 16) * 16, JS = T_in <= 128 ? 16 : 32;
-    const size_t trole = 4 * Tcap + T2V_E + JS + (1 + JS / 4) * 16 + T2V_A * (JS + 1) + 64 * (JS + 1) + 2 * 8 * T2V_A + 4;
+    const size_t trole = 4 * Tcap + T2V_E + JS + (1 + JS / 4) * 16 + T2V_A * (JS + 1) + 64 * (JS + 1) + 2 * 8 * T2V_A + 40;
     return sizeof(float) * (lrole > trole ? lrole : trole);
 }
 
@@ -983,7 +1168,9 @@ extern "C" long t2v_decoder_bwd_achain_scratch_floats(int B, int T_in, int T_out
     if (B < 1 || B > PB_MAXB || T_in < 1 || T_in > PB_MAXT || T_out < 1) return 0;
     const size_t S = (size_t)t2v_attn_bwd_slices_(T_in);
     const size_t cx = (size_t)T_out * (B > 4 ? 16384 : 8192) / 4;
-    return (long)(2 * (size_t)T_out * pb_row_bytes(B) / 4 + cx + (size_t)T_out * B * S * 128 + (size_t)T_out * B * T2V_KATT);
+    // (dc, dh) rows of both cells (half a gate row each) + context rows + window partials + E + the two factor arrays
+    return (long)((size_t)T_out * pb_row_bytes(B) / 4 + cx + (size_t)T_out * B * S * 128 + (size_t)T_out * B * T2V_KATT +
+                  2 * (size_t)T_out * pb_row_bytes(B) / 4);
 }
 
 extern "C" int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, const float* w_unused, const t2v_dec_train_bufs* s,
@@ -999,7 +1186,7 @@ extern "C" int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, co
         return T2V_ERR_ARG;
     const int S = t2v_attn_bwd_slices_(T_in);
     const size_t rowf = pb_row_bytes(B) / 4, cxf = (size_t)(B > 4 ? 16384 : 8192) / 4;
-    const size_t n_gx = (size_t)T_out * rowf, n_cx = (size_t)T_out * cxf, n_dq = (size_t)T_out * B * S * 128, n_gp = n_dq;
+    const size_t n_gx = (size_t)T_out * rowf / 2, n_f = (size_t)T_out * rowf, n_cx = (size_t)T_out * cxf, n_dq = (size_t)T_out * B * S * 128, n_gp = n_dq;
     const size_t n_ex = (size_t)T_out * B * T2V_KATT;
     if (((uintptr_t)scratch & 15) || ((uintptr_t)DQP & 15) || n_gx * 4 >= 0x7fffffffull || n_dq * 4 >= 0x7fffffffull) return T2V_ERR_ARG;
     if (pba_lds_bytes(B, T_in) > PB_LDS_MAX) return T2V_ERR_ARG;
@@ -1019,10 +1206,18 @@ extern "C" int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, co
     a.memory = s->memory; a.XS = s->XS; a.CA = s->CA; a.CD = s->CD; a.GA = s->GA; a.GD = s->GD; a.AL = s->AL; a.S = s->S;
     a.dHC = dHC; a.DGA = DGA; a.DGD = DGD; a.DCTX = DCTX; a.DV = DV;
     a.GXA = scratch; a.GXD = scratch + n_gx; a.CX = scratch + 2 * n_gx; a.GPX = scratch + 2 * n_gx + n_cx; a.EX = scratch + 2 * n_gx + n_cx + n_gp; a.DQX = DQP;
+    float* FA = scratch + 2 * n_gx + n_cx + n_gp + n_ex;
+    float* FD = FA + n_f;
+    a.FA = FA; a.FD = FD;
     a.err = err_word;
     a.B = B; a.T_in = T_in; a.T = T_out; a.S_sl = S; a.p_att = p_att; a.p_dec = p_dec; a.seed = seed;
     a.step = t2v_step_for(stream);
     a.prof = g_t2v_prof;
+    {
+        const unsigned nblk = (unsigned)(((size_t)T_out * T2V_G + 255) / 256);
+        k_pb_factors<<<nblk, 256, 0, stream>>>(s->GA, s->CA, FA, B, T_out, B, p_att, T2V_RNG_ATT_C, seed, a.step);
+        k_pb_factors<<<nblk, 256, 0, stream>>>(s->GD, s->CD, FD, B, T_out, B, p_dec, T2V_RNG_DEC_C, seed, a.step);
+    }
     const size_t lds = pba_lds_bytes(B, T_in);
     if (B > 4) k_achain_bwd<6><<<T2V_NWG, PB_THREADS, lds, stream>>>(a);
     else k_achain_bwd<4><<<T2V_NWG, PB_THREADS, lds, stream>>>(a);

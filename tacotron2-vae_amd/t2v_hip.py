@@ -490,7 +490,7 @@ class DecoderCore(torch.autograd.Function):
     # T2V_TRAIN_PERSISTENT=0 forces the launch-per-step forward; the default takes the one-launch persistent kernel
     # (csrc/decoder_train_persist.hip) whenever t2v_decoder_train_persist_supported(B, T_in): B <= 6, T_in <= 224
     persistent = None
-    persistent_bwd = None   # same switch for the reverse pass (env T2V_BWD_PERSISTENT, default OFF: see use_persistent_bwd)
+    persistent_bwd = None   # same switch for the reverse pass (env T2V_BWD_PERSISTENT, default: as T2V_TRAIN_PERSISTENT)
     last_bwd_mode = None
     last_mode = None        # 'persistent' | 'launch-per-step' of the most recent forward chunk (bench / tests)
     last_bwd_persist = None
@@ -509,9 +509,9 @@ class DecoderCore(torch.autograd.Function):
     def use_persistent_bwd(lib, B, T_in, T):
         flag = DecoderCore.persistent_bwd
         if flag is None:
-            # measured (B = 6, T_in = 84, T = 400): 18.6 us per reverse step against 18.2 for the launch-per-step pass (two
-            # 96 KB gate-gradient all-gathers per step bound it), 17.8 vs 16.7 ms per training step: OFF unless asked for
-            flag = os.environ.get('T2V_BWD_PERSISTENT', '0') != '0'
+            # measured (B = 6, T_in = 84, T = 400, round 3): 14.1 us per reverse step against 18.2 for the launch-per-step
+            # pass.  Follows T2V_TRAIN_PERSISTENT unless set itself (both kernels want the GPU to themselves)
+            flag = os.environ.get('T2V_BWD_PERSISTENT', os.environ.get('T2V_TRAIN_PERSISTENT', '1')) != '0'
         if not (bool(flag) and bool(lib.t2v_decoder_bwd_persist_supported(int(B), int(T_in)))):
             return False
         return 4 * lib.t2v_decoder_bwd_achain_scratch_floats(int(B), int(T_in), int(T)) < 2 ** 31 - 1

@@ -25,11 +25,16 @@ for it in range(3):
 lib.t2v_set_phase_profile(None)
 for it in range(3):
     ev[0].record(); H.replay_persistent_backward(); ev[1].record(); torch.cuda.synchronize()
-    print('replay: %.2f us per reverse step' % (ev[0].elapsed_time(ev[1]) * 1e3 / T))
-pv = prof.cpu().tolist()
-L = pv[0:7]; Tt = pv[8:12]
-print('L role (cycles): gather dga %d, A-GEMV+sums %d, publish dctx %d, cell D + gather dgd + D-GEMV %d, dq gather+sync %d, Wq^T dq + cell A + publish %d | step %d'
-      % (L[1] - L[0], L[2] - L[1], L[3] - L[2], L[4] - L[3], L[5] - L[4], L[6] - L[5], L[6] - L[0]))
-print('T role (cycles): prefetch + wait dctx %d, softmax/tanh backward -> dq published %d, location backward + window partials %d | step %d'
-      % (Tt[1] - Tt[0], Tt[2] - Tt[1], Tt[3] - Tt[2], Tt[3] - Tt[0]))
+    tb = ev[0].elapsed_time(ev[1]) * 1e3 / T
+    ev[0].record(); H.replay_persistent_forward(); ev[1].record(); torch.cuda.synchronize()
+    tf = ev[0].elapsed_time(ev[1]) * 1e3 / T
+    print('replay: %.2f us per reverse step; persistent forward %.2f us per step (7.70 at nominal clocks) -> %.2f us clock-normalised'
+          % (tb, tf, tb * 7.70 / tf))
+pv = [x / T for x in prof.cpu().tolist()]
+print('A role (cycles per step, mean over the pass): loop top %d | gather d(t+1) %d | ctx-column GEMV + sync %d | publish dctx %d | recurrent GEMV + sums %d | '
+      'dq gather + sync %d | Wq^T dq + cell + publish %d | park factors + next cell pre-part %d || step %d'
+      % (pv[0], pv[1], pv[2], pv[3], pv[5], pv[4], pv[6], pv[7], sum(pv[0:8])))
+print('   inside: park %d, cell pre-part %d' % (pv[12], pv[13]))
+print('T role (cycles per step): prefetch + wait dctx %d | softmax/tanh backward -> dq published %d | location backward + window partials %d | loop top %d || step %d'
+      % (pv[9], pv[10], pv[11], pv[8], sum(pv[8:12])))
 H.check_async_errors()
