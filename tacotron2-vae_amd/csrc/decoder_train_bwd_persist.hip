@@ -465,6 +465,8 @@ struct PBAArgs {
 // phase profile (tools/dbg/persist_bwd_prof.py): slot I accumulates, over all steps, the cycles since the previous stamp
 #define PBA_STAMP(COND, I) do { if (a.prof && (COND) && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
         lprof_[(I)] += now_ - tprev_; tprev_ = now_; } } while (0)
+// per-workgroup time line of ONE step (t = T/2) on the chip-wide 100 MHz counter: prof[64 + workgroup * 8 + slot]
+#define PBA_RT(SLOT) do { if (a.prof && t == a.T / 2 && threadIdx.x == 0) a.prof[64 + blockIdx.x * 8 + (SLOT)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define PBA_PROF_INIT(FLAGP) unsigned long long* lprof_ = (unsigned long long*)((FLAGP) + 4); \
     if (threadIdx.x < 16) lprof_[threadIdx.x] = 0ull
 #define PBA_PROF_FLUSH(COND, I0, N) do { if (a.prof && (COND) && threadIdx.x < (N)) a.prof[(I0) + threadIdx.x] = lprof_[(I0) + threadIdx.x]; } while (0)
@@ -595,6 +597,7 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
         __syncthreads();
         if (flag[0] != 1) return;
         PBA_STAMP(blockIdx.x == 0, 9);
+        PBA_RT(0);
         // ---- dot = dctx·ctx_t + sum_j alpha_j (Gprev_j + Gcum_j); dalpha of the own positions = dctx·memory_j + G_j
         {
             float dotp = dot_g;
@@ -660,6 +663,7 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
             dvacc += vv;
         }
         PBA_STAMP(blockIdx.x == 0, 10);
+        PBA_RT(1);
         // ---- through the fused location filter on MFMA: T[(c,k)][jl] = sum_d W_comb[d][(c,k)] dpre[jl][d], K = 128
         if (act) {
 #pragma unroll
@@ -835,6 +839,7 @@ __device__ __forceinline__ void pba_decoder_role(const PBAArgs& a, float* lds, c
     pb_park_factors<NB>(lds, a.FD + (size_t)(T - 1) * (PB_ROW_BYTES(NB) / 4));
     __syncthreads();
 
+    if (a.prof && jd == 0 && tid == 0) a.prof[40] = __builtin_amdgcn_s_memrealtime();
     // iteration t: (t < T) gather dgd(t), yd = Wcat_dec^T dgd(t): publish E(t), keep the recurrent part;  (t >= 1) cell D(t-1)
     for (int t = T; t >= 0; --t) {
         if (t < T) {
@@ -893,6 +898,7 @@ __device__ __forceinline__ void pba_decoder_role(const PBAArgs& a, float* lds, c
         }
         __syncthreads();
     }
+    if (a.prof && jd == 0 && tid == 0) a.prof[41] = __builtin_amdgcn_s_memrealtime();
 }
 
 // the activation-only part of attention_rnn's cell backward at step t -> cpre[row][8] = {fh, fc, go(1-tanh(c)^2), gf, e0..e3}
@@ -963,12 +969,14 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
     float dca = 0.f, pfsink = 0.f;
     int napA = 0, napQ = 0;
     PBA_PROF_INIT(flag);
+    if (a.prof && ja == 0 && tid == 0) a.prof[42] = __builtin_amdgcn_s_memrealtime();
     pba_cell_pre(a, cpre + ((T - 1) & 1) * 1024, seed, cell_thr, rowi, T - 1, cb, U, idx);
     __syncthreads();
     unsigned long long tprev_ = __builtin_readcyclecounter();
 
     for (int t = T - 1; t >= 0; --t) {
         PBA_STAMP(ja == 0, 0);
+        PBA_RT(0);
         // decoder_rnn's contribution E(t) was published long ago (that role runs ahead): fetched before the chain needs it
         unsigned e_raw = PB_SENT, e_off = 0u;
         float dhc_pre = 0.f;
@@ -992,6 +1000,7 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
             const int rounds = pb_build_row<NB>(X0, X1, rA, (unsigned)(t + 1) * PB_DROW_BYTES(NB), B, napA, a.err, flag);
             napA = t2v_adapt_nap(napA, rounds);
             PBA_STAMP(ja == 0, 1);
+            PBA_RT(1);
         }
         // (the poll has drained the memory queue: parked in LDS, E / dHC cost no wait on the vector-memory counter later —
         // register spills of the GEMV are stores that count there)
@@ -1020,6 +1029,7 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
             }
         }
         PBA_STAMP(ja == 0, 3);
+        PBA_RT(2);
         // warm this XCD's L2 with the factor row that is parked one step from now (first touch comes from HBM): one word per
         // 128-byte line, consumed only at the end of the step
         float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f;
@@ -1063,6 +1073,7 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
             }
         }
         PBA_STAMP(ja == 0, 5);
+        PBA_RT(3);
         // while dq(t) is on its way, prepare the next step: the factors of the next gather (row t) into the operand slots
         // (the recurrent GEMV was their last reader), and the part of cell A(t-1) that does not depend on d h_att
         if (t > 0) {
@@ -1100,6 +1111,7 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
         __syncthreads();
         if (flag[0] != 1) return;
         PBA_STAMP(ja == 0, 4);
+        PBA_RT(4);
         // ---- W_q^T dq for the own units: row (u, b) x 4 lanes x 32 attention dims, quad sum; P5: cell A(t)
         {
             float acc = 0.f;
@@ -1131,10 +1143,12 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
         __syncthreads();
         if (t > 0) pba_publish_rows<NB>(rA, (unsigned)t * PB_DROW_BYTES(NB), stage, u0, nu);
         PBA_STAMP(ja == 0, 6);
+        PBA_RT(5);
         pfsink += (pf0 + pf1) + pf2;
         __syncthreads();
         PBA_STAMP(ja == 0, 7);
     }
+    if (a.prof && ja == 0 && tid == 0) a.prof[43] = __builtin_amdgcn_s_memrealtime();
     PBA_PROF_FLUSH(ja == 0, 0, 8);
     PBA_PROF_FLUSH(ja == 0, 12, 4);
     if (__float_as_uint(pfsink) == 0x7fa00001u) a.err[0] = 2u;      // never true: keeps the prefetch loads alive
