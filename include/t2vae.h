@@ -383,6 +383,12 @@ long t2v_gemm_splitk_scratch_floats(int M, int N, int K);
 int t2v_gemm_f32_splitk(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
                         float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
                         uint64_t seed, uint32_t rng_stream, uint32_t rng_t, float* splitk_scratch, void* stream);
+
+/* nbatch independent products C_z = A_z · B_z^T (z-th operands at A + z*sAb, B + z*sBb, C + z*sCb; element strides as in
+ * t2v_gemm_f32, no bias / epilogue) in one launch.  Replaces the per-item loop that autograd's bmm backward of
+ * `attention_context = torch.bmm(attention_weights.unsqueeze(1), memory)` (model.py:84-85) amounts to for d_memory. */
+int t2v_gemm_f32_batched(const float* A, long sAb, long sAi, long sAk, const float* B, long sBb, long sBj, long sBk,
+                         float* C, long sCb, int ldc, int nbatch, int M, int N, int K, void* stream);
 /* same contract, bf16 operands / fp32 accumulate (bf16_run) */
 int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
                   float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,

@@ -32,6 +32,7 @@ struct BnFwdArgs {
 };
 
 #define BN_NE 12      // fast path: channels of up to 256*12 values are held in registers
+#define BN_UN 8       // larger channels: loads in flight per thread and pass
 
 __global__ __launch_bounds__(256) void k_bn_act_fwd(BnFwdArgs a) {
     const int m = blockIdx.x, tid = threadIdx.x;
@@ -59,10 +60,21 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(BnFwdArgs a) {
             q = dscr[1][0];
         } else {
             // no partials (direct-form conv2d of the reference encoder): reduce the channel here
+            // (eight loads in flight per thread: one load per iteration made the 48 000-value channels of the reference
+            // encoder's first layer a 190-deep chain of memory latencies — 86 us for one launch)
             float ls = 0.f, lq = 0.f;
-            for (int b = 0; b < a.B; ++b) {
-                const size_t base = ((size_t)b * a.M + m) * a.T;
-                for (int t = tid; t < a.T; t += 256) { const float v = a.y[base + t]; ls += v; lq = fmaf(v, v, lq); }
+            const int nel = a.B * a.T;
+            for (int i0 = 0; i0 < nel; i0 += 256 * BN_UN) {
+                float v[BN_UN];
+#pragma unroll
+                for (int e = 0; e < BN_UN; ++e) {
+                    const int i = i0 + tid + 256 * e, ic = min(i, nel - 1);
+                    const int b = ic / a.T, t = ic - b * a.T;
+                    v[e] = a.y[((size_t)b * a.M + m) * a.T + t];
+                }
+#pragma unroll
+                for (int e = 0; e < BN_UN; ++e)
+                    if (i0 + tid + 256 * e < nel) { ls += v[e]; lq = fmaf(v[e], v[e], lq); }
             }
             s = (double)block_sum_256(ls, scr);
             q = (double)block_sum_256(lq, scr);
@@ -109,14 +121,25 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(BnFwdArgs a) {
         }
         return;
     }
-    for (int b = 0; b < a.B; ++b) {
-        const size_t base = ((size_t)b * a.M + m) * a.T;
-        for (int t = tid; t < a.T; t += 256) {
-            float z = fmaf(a.y[base + t], g, bt);
-            if (a.act == ACT_TANH) z = tanhf_(z);
-            else if (a.act == ACT_RELU) z = fmaxf(z, 0.f);
-            if (a.training && a.p_drop > 0.f) z *= t2v_drop_scale(t2v_step_seed(a.seed, a.step), a.rng_stream, a.rng_t, (uint32_t)(base + t), a.p_drop);
-            a.out[base + t] = z;
+    for (int i0 = 0; i0 < n; i0 += 256 * BN_UN) {
+        size_t off[BN_UN];
+        float yv[BN_UN];
+#pragma unroll
+        for (int e = 0; e < BN_UN; ++e) {
+            const int i = i0 + tid + 256 * e, ic = min(i, n - 1);
+            const int b = ic / a.T, t = ic - b * a.T;
+            off[e] = ((size_t)b * a.M + m) * a.T + t;
+            yv[e] = a.y[off[e]];
+        }
+#pragma unroll
+        for (int e = 0; e < BN_UN; ++e) {
+            if (i0 + tid + 256 * e < n) {
+                float z = fmaf(yv[e], g, bt);
+                if (a.act == ACT_TANH) z = tanhf_(z);
+                else if (a.act == ACT_RELU) z = fmaxf(z, 0.f);
+                if (a.training && a.p_drop > 0.f) z *= t2v_drop_scale(t2v_step_seed(a.seed, a.step), a.rng_stream, a.rng_t, (uint32_t)off[e], a.p_drop);
+                a.out[off[e]] = z;
+            }
         }
     }
 }
@@ -135,10 +158,8 @@ struct BnBwdArgs {
     int eval_mode;           // running statistics (constants): no batch-statistic terms, the conv bias gets a gradient
 };
 
-__device__ __forceinline__ float bn_dz(const BnBwdArgs& a, size_t idx, float g, float bt, float& xhat, float mean, float rstd) {
-    const float yv = a.y[idx];
+__device__ __forceinline__ float bn_dz_v(const BnBwdArgs& a, size_t idx, float yv, float d, float g, float bt, float& xhat, float mean, float rstd) {
     xhat = (yv - mean) * rstd;
-    float d = a.dout[idx];
     if (a.p_drop > 0.f) d *= t2v_drop_scale(t2v_step_seed(a.seed, a.step), a.rng_stream, a.rng_t, (uint32_t)idx, a.p_drop);
     const float z = fmaf(yv, g, bt);
     if (a.act == ACT_TANH) { const float th = tanhf_(z); d *= 1.0f - th * th; }
@@ -190,13 +211,25 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd(BnBwdArgs a) {
             if (tid + 256 * e < nel) a.dy[off[e]] = g * (dzv[e] - m1 - xh[e] * m2);
         return;
     }
-    for (int b = 0; b < a.B; ++b) {
-        const size_t base = ((size_t)b * a.M + m) * a.T;
-        for (int t = tid; t < a.T; t += 256) {
-            float xhat;
-            const float dz = bn_dz(a, base + t, g, bt, xhat, mean, rstd);
-            s1 += dz;
-            s2 = fmaf(dz, xhat, s2);
+    for (int i0 = 0; i0 < nel; i0 += 256 * BN_UN) {
+        float yv[BN_UN], dv[BN_UN];
+        size_t off[BN_UN];
+#pragma unroll
+        for (int e = 0; e < BN_UN; ++e) {
+            const int i = i0 + tid + 256 * e, ic = min(i, nel - 1);
+            const int b = ic / a.T, t = ic - b * a.T;
+            off[e] = ((size_t)b * a.M + m) * a.T + t;
+            yv[e] = a.y[off[e]];
+            dv[e] = a.dout[off[e]];
+        }
+#pragma unroll
+        for (int e = 0; e < BN_UN; ++e) {
+            if (i0 + tid + 256 * e < nel) {
+                float xhat;
+                const float dz = bn_dz_v(a, off[e], yv[e], dv[e], g, bt, xhat, mean, rstd);
+                s1 += dz;
+                s2 = fmaf(dz, xhat, s2);
+            }
         }
     }
     const float S1 = block_sum_256(s1, scr);
@@ -204,12 +237,24 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd(BnBwdArgs a) {
     if (tid == 0) { a.dbeta[m] = S1; a.dgamma[m] = S2; if (a.dconv_bias) a.dconv_bias[m] = a.eval_mode ? g * S1 : 0.f; }
     const float n = (float)a.B * (float)a.T;
     const float m1 = a.eval_mode ? 0.f : S1 / n, m2 = a.eval_mode ? 0.f : S2 / n;
-    for (int b = 0; b < a.B; ++b) {
-        const size_t base = ((size_t)b * a.M + m) * a.T;
-        for (int t = tid; t < a.T; t += 256) {
-            float xhat;
-            const float dz = bn_dz(a, base + t, g, bt, xhat, mean, rstd);
-            a.dy[base + t] = g * (dz - m1 - xhat * m2);
+    for (int i0 = 0; i0 < nel; i0 += 256 * BN_UN) {
+        float yv[BN_UN], dv[BN_UN];
+        size_t off[BN_UN];
+#pragma unroll
+        for (int e = 0; e < BN_UN; ++e) {
+            const int i = i0 + tid + 256 * e, ic = min(i, nel - 1);
+            const int b = ic / a.T, t = ic - b * a.T;
+            off[e] = ((size_t)b * a.M + m) * a.T + t;
+            yv[e] = a.y[off[e]];
+            dv[e] = a.dout[off[e]];
+        }
+#pragma unroll
+        for (int e = 0; e < BN_UN; ++e) {
+            if (i0 + tid + 256 * e < nel) {
+                float xhat;
+                const float dz = bn_dz_v(a, off[e], yv[e], dv[e], g, bt, xhat, mean, rstd);
+                a.dy[off[e]] = g * (dz - m1 - xhat * m2);
+            }
         }
     }
 }

@@ -23,6 +23,8 @@ struct GemmArgs {
     const t2v_step_params* step;
     int kz_chunk;          // split-K: k range per blockIdx.z (multiple of GM_BK), 0 = whole K in one block
     float* part;           // split-K partial tiles (gridDim.z, M, N) or NULL
+    int nbatch;            // > 1: blockIdx.z = independent product (no split-K), operands advance by the batch strides
+    long sAb, sBb, sCb;
 };
 
 template <bool A_KC, bool B_KC>   // operand contiguous along k?
@@ -32,6 +34,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int i0 = blockIdx.y * GM_BM, j0 = blockIdx.x * GM_BN;
+    if (a.nbatch > 1) { a.A += blockIdx.z * a.sAb; a.B += blockIdx.z * a.sBb; a.C += blockIdx.z * a.sCb; }
     const int kbeg = a.kz_chunk ? blockIdx.z * a.kz_chunk : 0, kend = a.kz_chunk ? min(a.K, kbeg + a.kz_chunk) : a.K;
     constexpr int NE = GM_BM * GM_BK / 256;   // 8
     float ra[NE], rb[NE];
@@ -122,11 +125,13 @@ __global__ void k_gemm_splitk_reduce(GemmArgs a, int nsplit) {
     if (a.p_drop > 0.f) v *= t2v_drop_scale(t2v_step_seed(a.seed, a.step), a.rng_stream, a.rng_t, (uint32_t)idx, a.p_drop);
     a.C[idx] = v;
 }
-// number of k-splits for the 64x64 kernel: fill ~256 workgroups, keep >= 8 k-tiles per split
+// number of k-splits for the 64x64 kernel: deep-K products whose tiles leave CUs idle (r3 step trace: the 2400x256,
+// K = 4096 data gradient of the Prenet ran 174 us on 152 workgroups, the 2400x81, K = 1536 projection 61 us on 76) are
+// split until ~2 workgroups per CU are in flight, with >= 8 k-tiles left per split
 static int gemm_splits(int M, int N, int K) {
     const long tiles = (long)((M + GM_BM - 1) / GM_BM) * ((N + GM_BN - 1) / GM_BN);
-    if (tiles >= 64 || K < 16 * GM_BK) return 1;
-    long ns = 256 / tiles;
+    if (tiles >= 256 || K < 16 * GM_BK) return 1;
+    long ns = 512 / tiles;
     const long maxk = K / (8 * GM_BK);
     if (ns > maxk) ns = maxk;
     if (ns > 32) ns = 32;
@@ -517,7 +522,7 @@ extern "C" int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B,
     a.A = A; a.B = B; a.bias = bias; a.C = C; a.sAi = sAi; a.sAk = sAk; a.sBj = sBj; a.sBk = sBk;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
     a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
-    a.kz_chunk = 0; a.part = nullptr;
+    a.kz_chunk = 0; a.part = nullptr; a.nbatch = 1; a.sAb = a.sBb = a.sCb = 0;
     if (gemm_bf16_big_ok(a)) {
         dim3 gb((N + GBB_BN - 1) / GBB_BN, (M + GBB_BM - 1) / GBB_BM);
         k_gemm_bf16_big_rr<<<gb, 256, 0, stream>>>(a);
@@ -556,7 +561,7 @@ static int gemm_f32_impl(const float* A, long sAi, long sAk, const float* B, lon
     a.A = A; a.B = B; a.bias = bias; a.C = C; a.sAi = sAi; a.sAk = sAk; a.sBj = sBj; a.sBk = sBk;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
     a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
-    a.kz_chunk = 0; a.part = nullptr;
+    a.kz_chunk = 0; a.part = nullptr; a.nbatch = 1; a.sAb = a.sBb = a.sCb = 0;
     const bool akc = sAk == 1, bkc = sBk == 1;
     if (gemm_big_ok(a)) {
         const bool wide = gemm_big_waste(M, N, 128) <= gemm_big_waste(M, N, 64) + 1e-6;
@@ -584,5 +589,26 @@ static int gemm_f32_impl(const float* A, long sAi, long sAk, const float* B, lon
     else if (bkc) k_gemm_f32<false, true><<<grid, 256, 0, stream>>>(a);
     else k_gemm_f32<false, false><<<grid, 256, 0, stream>>>(a);
     if (ns > 1) k_gemm_splitk_reduce<<<(unsigned)(((size_t)M * N + 255) / 256), 256, 0, stream>>>(a, ns);
+    return t2v_check_launch();
+}
+
+// nbatch independent products C_z = A_z · B_z^T in ONE launch of the 64x64 kernel (blockIdx.z = z): the per-item
+// d_memory[b] = alignments_b^T · d_ctx_b of the decoder's reverse pass (model.py:84-85 under autograd) were B launches
+// of 16 workgroups each.
+extern "C" int t2v_gemm_f32_batched(const float* A, long sAb, long sAi, long sAk, const float* B, long sBb, long sBj, long sBk,
+                                    float* C, long sCb, int ldc, int nbatch, int M, int N, int K, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!A || !B || !C || nbatch < 1 || nbatch > 65535 || M < 1 || N < 1 || K < 1 || ldc < N) return T2V_ERR_ARG;
+    GemmArgs a;
+    a.A = A; a.B = B; a.bias = nullptr; a.C = C; a.sAi = sAi; a.sAk = sAk; a.sBj = sBj; a.sBk = sBk;
+    a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = 0; a.accumulate = 0;
+    a.p_drop = 0.f; a.seed = 0; a.rng_stream = 0; a.rng_t = 0; a.step = t2v_step_for(stream);
+    a.kz_chunk = 0; a.part = nullptr; a.nbatch = nbatch; a.sAb = sAb; a.sBb = sBb; a.sCb = sCb;
+    const bool akc = sAk == 1, bkc = sBk == 1;
+    dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, nbatch);
+    if (akc && bkc) k_gemm_f32<true, true><<<grid, 256, 0, stream>>>(a);
+    else if (akc) k_gemm_f32<true, false><<<grid, 256, 0, stream>>>(a);
+    else if (bkc) k_gemm_f32<false, true><<<grid, 256, 0, stream>>>(a);
+    else k_gemm_f32<false, false><<<grid, 256, 0, stream>>>(a);
     return t2v_check_launch();
 }

@@ -63,7 +63,7 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_pack_l
            't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_conv1d_dw_scratch_floats', 't2v_gemm_bf16', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
            't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bn_act_bwd_eval', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats',
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_fuse_location_weights', 't2v_decoder_qp_floats',
-           't2v_set_step_params', 't2v_set_step_params_stream', 't2v_decoder_replay_bwd_kernels', 't2v_embedding_fwd', 't2v_embedding_bwd', 't2v_gemm_f32_splitk', 't2v_gemm_splitk_scratch_floats',
+           't2v_set_step_params', 't2v_set_step_params_stream', 't2v_decoder_replay_bwd_kernels', 't2v_embedding_fwd', 't2v_embedding_bwd', 't2v_gemm_f32_splitk', 't2v_gemm_splitk_scratch_floats', 't2v_gemm_f32_batched',
            't2v_decoder_infer_persistent', 't2v_decoder_persist_supported', 't2v_decoder_persist_granules',
            't2v_attn_bwd_slices', 't2v_colsum', 't2v_colsum_scratch_floats', 't2v_gemm_epilogue_bwd',
            't2v_decoder_train_fwd_persistent', 't2v_decoder_train_persist_supported',
@@ -160,6 +160,8 @@ def load_library():
                                  C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, vp]
     lib.t2v_gemm_bf16.argtypes = lib.t2v_gemm_f32.argtypes
     lib.t2v_gemm_f32_splitk.argtypes = lib.t2v_gemm_f32.argtypes[:-1] + [vp, vp]
+    lib.t2v_gemm_f32_batched.argtypes = [vp, C.c_long, C.c_long, C.c_long, vp, C.c_long, C.c_long, C.c_long, vp, C.c_long,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.t2v_gemm_splitk_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.t2v_gemm_splitk_scratch_floats.restype = C.c_long
     lib.t2v_attn_wgrad.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]     # 8 pointers
@@ -701,8 +703,9 @@ class DecoderCore(torch.autograd.Function):
             d_bias_dec = colsum(dgd2)
             d_wq = gemm(dq_sum.t(), x_cur[:, :H].t())            # (128,1024)
             d_memory = torch.empty(B, T_in, E, **f32)
-            for bi in range(B):                                # per item: alpha_b^T (T_in x T) · dctx_b (T x 512)
-                gemm(AL[1:, bi].t(), DCTX[:, bi].t(), out=d_memory[bi])
+            # per item: alpha_b^T (T_in x T) · dctx_b (T x 512), all items in one launch
+            _check(lib.t2v_gemm_f32_batched(_p(AL[1:]), T_in, 1, B * T_in, _p(DCTX), E, 1, B * E, _p(d_memory), T_in * E, E, B,
+                                            T_in, E, T, _stream()), 't2v_gemm_f32_batched')
             dpre = S                                   # overwritten in place by the backward kernels
             d_pm = colsum(dpre.view(T, B * T_in * A)).view(B, T_in, A)
             d_v = DV.sum((0, 1)).view(1, A)

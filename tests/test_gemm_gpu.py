@@ -137,3 +137,26 @@ def test_bf16_big_tile_gemm_for_the_lstm_weight_gradients():
         assert (out - 2 * want).abs().max().item() < 4e-3 * want.abs().max().item()
     finally:
         t2v_hip.set_bf16(False)
+
+
+@pytest.mark.parametrize("B,T_in,T", [(6, 84, 400), (3, 21, 37), (1, 200, 5)])
+def test_batched_gemm_for_the_per_item_memory_gradient(B, T_in, T):
+    """d_memory[b] = alignments_b^T (T_in x T) · d_ctx_b (T x 512) for all items in one launch (t2v_gemm_f32_batched), on the
+    strided views the decoder's reverse pass hands over: AL (T+1, B, T_in) rows 1.., DCTX (T, B, 512)."""
+    import ctypes as C
+    import t2v_hip
+    lib = t2v_hip.load_library()
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    AL, DCTX = torch.rand(T + 1, B, T_in, generator=g), torch.randn(T, B, 512, generator=g)
+    ref = torch.einsum('tbj,tbe->bje', AL[1:], DCTX)
+    dAL, dD = AL.cuda(), DCTX.cuda()
+    out = torch.full((B, T_in, 512), float('nan'), device='cuda')
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rc = lib.t2v_gemm_f32_batched(p(dAL[1:]), T_in, 1, B * T_in, p(dD), 512, 1, B * 512, p(out), T_in * 512, 512, B, T_in, 512, T,
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max() < 2e-5 * T ** 0.5 * ref.abs().max()
+    # argument checks: nothing is launched for a bad batch count / leading dimension
+    assert lib.t2v_gemm_f32_batched(p(dAL), T_in, 1, B * T_in, p(dD), 512, 1, B * 512, p(out), T_in * 512, 100, B, T_in, 512, T, None) != 0
+    assert lib.t2v_gemm_f32_batched(p(dAL), T_in, 1, B * T_in, p(dD), 512, 1, B * 512, p(out), T_in * 512, 512, 0, T_in, 512, T, None) != 0

@@ -69,3 +69,23 @@ if len(sys.argv) > 4:
         dur[k][0] += t
         dur[k][1] += c
     json.dump({k: round(t / c / 1e3, 3) for k, (t, c) in sorted(dur.items())}, open(sys.argv[4], 'w'), indent=1)
+
+# ---- optional: the launch sequence of the LAST steady step (env T2V_PROFILE_SEQ=<file>): order, name, grid, duration, gap
+import os
+if os.environ.get('T2V_PROFILE_SEQ'):
+    full = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            full.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'],
+                         r.get('Grid_Size_X', '?'), r.get('Grid_Size_Y', '?'), r.get('Grid_Size_Z', '?'), r.get('Workgroup_Size_X', '?')))
+    full.sort()
+    ad = [i for i, r in enumerate(full) if r[2].startswith('k_clip_adam')]
+    with open(os.environ['T2V_PROFILE_SEQ'], 'w') as out:
+        prev = None
+        for s_, e_, n_, gx, gy, gz, wx in full[ad[-2] + 1:ad[-1] + 1]:
+            try:
+                wgs = int(gx) * int(gy) * int(gz) // max(1, int(wx))
+            except ValueError:
+                wgs = -1
+            out.write("%8.1f us  gap %6.1f  wgs %6d x %4s  %s\n" % ((e_ - s_) / 1e3, (s_ - prev) / 1e3 if prev else 0.0, wgs, wx, n_[:90]))
+            prev = e_
