@@ -254,7 +254,7 @@ int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_infer_bufs* 
                             int external_prenet, uint64_t seed, void* stream);
 
 /* The same loop as ONE persistent launch (csrc/decoder_persist.hip): 256 workgroups stay resident for the whole
- * utterance, all weights in registers / LDS, the per-frame state vectors travel between CUs as tagged 8-byte granules,
+ * utterance, all weights in registers / LDS, the per-frame state vectors travel between CUs as 4-byte values in a sentinel-filled row per frame,
  * the loop ends on the frame the gate fires (nothing is computed after it).  Runs frames 0..t_end-1 from the zero state;
  * pre_first = Prenet(go frame).  Supported when t2v_decoder_persist_supported(B, T_in) != 0 (B <= 4 and the attention
  * operands of T_in positions fit the 160 KB LDS: T_in <= 224 at B = 1); everything else takes t2v_decoder_infer_steps.
@@ -279,10 +279,10 @@ typedef struct t2v_dec_persist_bufs {
     float* GATE;             /* (t_end,B) out */
     float* AL;               /* (t_end+1,B,T_in) out: row t+1 = attention weights of frame t */
     int32_t* stop_flag;      /* (1): first frame on which every item's gate fired (caller presets INT_MAX) */
-    void* granules;          /* t2v_decoder_persist_granules(B) x 8 bytes of exchange scratch (zeroed by the call) */
+    void* exchange;          /* t2v_decoder_persist_scratch_floats(B, t_end) floats of exchange rows, 16-byte aligned (filled by the call) */
     uint32_t* err_word;      /* (1): != 0 afterwards: a bounded spin timed out */
 } t2v_dec_persist_bufs;
-long t2v_decoder_persist_granules(int B);
+long t2v_decoder_persist_scratch_floats(int B, int t_end);
 int t2v_decoder_persist_supported(int B, int T_in);
 int t2v_decoder_infer_persistent(const t2v_dec_persist_weights* w, const t2v_dec_persist_bufs* s, int B, int T_in,
                                  int t_end, float gate_threshold, float p_prenet, uint64_t seed, void* stream);

@@ -2,9 +2,11 @@
 // synthesizer.py:139-154): 256 workgroups x 512 threads stay resident for the whole utterance, every weight of the
 // loop lives in registers / LDS, and the five dependent stages of a frame
 //     attention_rnn -> attention -> decoder_rnn -> projection (+ folded Prenet layer 0) -> Prenet layer 1
-// hand their small result vectors (1024 / 512 / 256 values per item) from CU to CU as 8-byte {value, frame tag}
-// granules (MI355X guide G16 form R2: one sc1 store per value, consumers poll the values themselves — no counters, no
-// fences, no grid barrier).  Nothing is streamed from HBM per frame: the 71 MB of LSTM weights that the launch-per-stage
+// hand their small result vectors (1024 / 512 / 256 values per item) from CU to CU as plain 4-byte values in a FRESH,
+// sentinel-filled exchange row per frame (write-through sc1 stores, sc1 loads; a word that is no longer 0xFFFFFFFF IS the
+// data — no tags, no counters, no fences, no grid barrier).  Round 3: half the bytes of the former 8-byte {value, tag}
+// granules — what a gather costs is its bytes (a CU pulls ~11 B/cycle from beyond its L2) — and an adaptive nap
+// in front of every poll, so that the first round of a gather is not the one that is bound to fail.  Nothing is streamed from HBM per frame: the 71 MB of LSTM weights that the launch-per-stage
 // loop (decoder_infer.hip) re-reads every frame are read once.
 //
 // Roles (every workgroup runs the frame loop, phases in the same order, so the waits cannot form a cycle):
@@ -52,59 +54,78 @@ struct PersistArgs {
     const float* pre_first;   // (B,256) Prenet(go frame)
     float* MEL; float* GATE; float* AL;      // (Tmax,B,80) (Tmax,B) (Tmax+1,B,T_in): AL[t+1] = weights of frame t
     int* stop_flag;
-    t2v_u64* xg;              // granule exchange, 2 parities x pd_par(B)
+    float* xg;                // exchange rows, one per frame: t_end x pd_row(B) floats, sentinel-filled by the launcher
     unsigned* err;
     int B, T_in, t_end;
     float gate_logit_thr, p_prenet;
     uint64_t seed;
     unsigned long long* prof;   // optional: stamps of frame 100 (workgroup 0 slots 0..9, workgroup 64 slots 10..13, workgroup 128 slots 14..16)
 };
+// per-workgroup time line of frame 100 on the chip-wide 100 MHz counter: prof[64 + workgroup * 16 + slot] (tools/dbg_persist.py)
+#define PD_RT(SLOT) do { if (a.prof && t == 100 && tid == 0) a.prof[64 + wg * 16 + (SLOT)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define PD_STAMP(WG, I) do { if (a.prof && t == 100 && wg == (WG) && tid == 0) a.prof[(I)] = __builtin_readcyclecounter(); } while (0)
 
-// granule offsets inside one parity block
-__host__ __device__ static inline size_t pd_hatt(int B) { (void)B; return 0; }
-__host__ __device__ static inline size_t pd_hdec(int B) { return (size_t)B * 1024; }
-__host__ __device__ static inline size_t pd_ctx(int B) { return (size_t)B * 2048; }
-__host__ __device__ static inline size_t pd_pre0(int B) { return (size_t)B * 2560; }
-__host__ __device__ static inline size_t pd_pre1(int B) { return (size_t)B * 2816; }
-__host__ __device__ static inline size_t pd_ex(int B) { return (size_t)B * 3072; }          // [b][8][256]
-__host__ __device__ static inline size_t pd_stop(int B) { return (size_t)B * 5120; }
-__host__ __device__ static inline size_t pd_par(int B) { return (size_t)B * 5120 + 8; }
+// exchange row of one frame (floats)
+__host__ __device__ static inline unsigned pd_hatt(int B) { (void)B; return 0u; }
+__host__ __device__ static inline unsigned pd_hdec(int B) { return (unsigned)B * 1024u; }
+__host__ __device__ static inline unsigned pd_ctx(int B) { return (unsigned)B * 2048u; }
+__host__ __device__ static inline unsigned pd_pre0(int B) { return (unsigned)B * 2560u; }
+__host__ __device__ static inline unsigned pd_pre1(int B) { return (unsigned)B * 2816u; }
+__host__ __device__ static inline unsigned pd_ex(int B) { return (unsigned)B * 3072u; }          // [b][8][256]
+__host__ __device__ static inline unsigned pd_stop(int B) { return (unsigned)B * 5120u; }
+__host__ __device__ static inline unsigned pd_row(int B) { return (unsigned)B * 5120u + 32u; }
 
-__device__ __forceinline__ void pd_put(t2v_u64* p, float v, unsigned tag) {
-    __hip_atomic_store(p, ((t2v_u64)tag << 32) | (t2v_u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#define PD_SENT 0xFFFFFFFFu
+#define PD_SC1 16
+typedef unsigned pd_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned pd_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pd_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
-__device__ __forceinline__ t2v_u64 pd_get(const t2v_u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// offsets in floats
+__device__ __forceinline__ void pd_put(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)(off * 4u), 0, PD_SC1);
+}
+__device__ __forceinline__ unsigned pd_get(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, (int)(off * 4u), 0, PD_SC1);
+}
+__device__ __forceinline__ pd_u32x2 pd_get2(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, (int)(off * 4u), 0, PD_SC1);
+}
+__device__ __forceinline__ pd_u32x4 pd_get4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off * 4u), 0, PD_SC1);
+}
+__device__ __forceinline__ bool pd_give_up(unsigned& spins, unsigned* err, int* flag) {
+    if (++spins > PD_SPIN || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = 0;
+        return true;
+    }
+    return false;
+}
 
-// Poll `n` granules (n <= PER * 512) until every tag matches, then copy the values to LDS.  Returns false on a timeout
-// (error word set); block-uniform through `flag` (an LDS int, 1 on entry) — the caller syncs before reading dst.
-template <int PER>
-__device__ __forceinline__ void pd_gather(float* dst, const t2v_u64* src, int n, unsigned tag, unsigned* err, int* flag) {
+// Poll the n (<= 2 * 512, even) values at `off` until none is the sentinel, then copy them to LDS: thread = two adjacent
+// values (one 8-byte load).  Naps `nap` first (adapted by the caller from the returned number of failed rounds).  On a
+// timeout the error word is set and *flag cleared (an LDS int, 1 on entry) — the caller syncs before reading dst.
+__device__ __forceinline__ int pd_gather(float* dst, __amdgpu_buffer_rsrc_t r, unsigned off, int n, int nap, unsigned* err, int* flag) {
     const int tid = threadIdx.x;
-    float v[PER];
+    for (int i = 0; i < nap; i += 4) __builtin_amdgcn_s_sleep(4);
+    const bool on = 2 * tid < n;
+    pd_u32x2 x = {0u, 0u};
     unsigned spins = 0;
     for (;;) {
-        bool ok = true;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int i = min(tid + PD_THREADS * u, n - 1);
-            const t2v_u64 x = pd_get(src + i);
-            v[u] = __uint_as_float((unsigned)x);
-            ok = ok && (unsigned)(x >> 32) == tag;
-        }
-        if (ok) break;
+        if (on) x = pd_get2(r, off + 2u * (unsigned)tid);
+        if (__all(x[0] != PD_SENT && x[1] != PD_SENT)) break;
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > PD_SPIN || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = 0;
-            break;
-        }
+        if (pd_give_up(spins, err, flag)) break;
     }
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const int i = tid + PD_THREADS * u;
-        if (i < n) dst[i] = v[u];
-    }
+    if (on) *(float2*)(dst + 2 * tid) = make_float2(__uint_as_float(x[0]), __uint_as_float(x[1]));
+    return (int)spins;
+}
+__device__ __forceinline__ int pd_adapt(int nap, int rounds) {       // units of 64 cycles; first round should just succeed
+    if (rounds > 1) return min(48, nap + 4 * min(rounds - 1, 3));
+    if (rounds == 0) return (3 * nap) >> 2;
+    return nap;
 }
 
 // LSTM gate rows of this workgroup for one cell: lane = (row r = lane>>2 (unit r>>2, gate r&3), kq = lane&3), wave = K
@@ -217,51 +238,39 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
     for (int i = tid; i < B * T2V_PRE; i += PD_THREADS) X[(i >> 8) * PD_XW + PD_X_P1 + (i & 255)] = a.pre_first[i];
     __syncthreads();
 
+    const __amdgpu_buffer_rsrc_t rx = pd_rsrc(a.xg);
+    int nap_e = 0, nap_h = 0, nap_x = 0, nap_c = 0, nap_p = 0, nap_q = 0;      // adaptive naps in front of the polls (64-cycle units)
     for (int t = 0; t < a.t_end; ++t) {
-        const unsigned tag = (unsigned)t + 1u;
-        t2v_u64* xcur = a.xg + (size_t)(t & 1) * pd_par(B);
-        const t2v_u64* xprev = a.xg + (size_t)((t + 1) & 1) * pd_par(B);
+        const unsigned xcur = (unsigned)t * pd_row(B), xprev = xcur - pd_row(B);      // float offsets of this / the previous frame's row
         // ---- frame entry (t > 0): stop decision of the previous frame, Prenet output of the new frame's input
         if (t > 0) {
-            // one polling loop for both: every thread its share of the Prenet granules, thread 0 also the stop granule
-            // (two separate polls were two serial memory round trips at the top of every frame)
-            {
-                const int n = B * 256;                          // <= 1024: two granules per thread
-                float pv[2];
-                unsigned spins = 0;
+            // Prenet output of the new frame's input + stop decision of the previous frame.  Every workgroup of the chip wants
+            // the same 1 KB (+ one word) at the same moment: with all 8 waves of all 256 workgroups polling it, the eight cache
+            // lines behind it were a hot spot that took ~4 us to hand the values over (time line of tools/dbg_persist.py).  So
+            // ONE wave per item polls (one 16-byte load per lane) and thread 0 alone watches the stop word.
+            if (tid < 64 * B) {
+                pd_u32x4 pv = {0u, 0u, 0u, 0u};
+                unsigned spins = 0, sx = 0u;
+                for (int i = 0; i < nap_e; i += 4) __builtin_amdgcn_s_sleep(4);
                 for (;;) {
-                    bool ok = true;
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int i = min(tid + PD_THREADS * u, n - 1);
-                        const t2v_u64 x = pd_get(xprev + pd_pre1(B) + i);           // [b][256] is contiguous
-                        pv[u] = __uint_as_float((unsigned)x);
-                        ok = ok && (unsigned)(x >> 32) == (unsigned)t;
-                    }
-                    const t2v_u64 sx = pd_get(xprev + pd_stop(B));
-                    const bool stop_known = (unsigned)(sx >> 32) == (unsigned)t;
-                    if (stop_known && (unsigned)sx != 0u) {         // the gate fired on the previous frame: its Prenet rows
-                        if (tid == 0) flag[0] = 2;                  // belong to a frame that will not run
-                        break;
-                    }
-                    if (ok && stop_known) break;
+                    pv = pd_get4(rx, xprev + pd_pre1(B) + 4u * (unsigned)tid);          // [b][256] is contiguous
+                    if (tid == 0) sx = pd_get(rx, xprev + pd_stop(B));
+                    if (tid == 0 && sx == 2u) flag[0] = 2;              // the gate fired on the previous frame: nothing runs after it
+                    if (__all(pv[0] != PD_SENT && pv[1] != PD_SENT && pv[2] != PD_SENT && pv[3] != PD_SENT && sx != PD_SENT)) break;
+                    if (__any(tid == 0 && sx == 2u)) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > PD_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        flag[0] = 0;
-                        break;
-                    }
+                    if (pd_give_up(spins, a.err, flag)) break;
                 }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int i = tid + PD_THREADS * u;
-                    if (i < n) X[(size_t)(i >> 8) * PD_XW + PD_X_P1 + (i & 255)] = pv[u];
-                }
+                nap_e = pd_adapt(nap_e, (int)spins);
+                const int i = 4 * tid;
+                *(float4*)(X + (size_t)(i >> 8) * PD_XW + PD_X_P1 + (i & 255)) =
+                    make_float4(__uint_as_float(pv[0]), __uint_as_float(pv[1]), __uint_as_float(pv[2]), __uint_as_float(pv[3]));
             }
             __syncthreads();
             if (flag[0] != 1) return;                          // stopped on the gate (2) or timed out (0)
         }
         PD_STAMP(0, 0); PD_STAMP(64, 10); PD_STAMP(128, 14);
+        PD_RT(0);
         // ---- 1. attention_rnn(t): gates of this workgroup's 4 units, cell update, publish h_att
         pd_gemv<PD_KATT / 32, PD_KATT>(wa, X, B, red);        // K contiguous in the LDS row: no split offset
         __syncthreads();
@@ -279,9 +288,10 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             const float gi = sigmoidf_(gp[0]), gf = sigmoidf_(gp[1]), gg = tanhf_(gp[2]), go = sigmoidf_(gp[3]);
             const float c = gf * cst[b * 4 + u] + gi * gg;
             cst[b * 4 + u] = c;
-            pd_put(xcur + pd_hatt(B) + (size_t)b * 1024 + 4 * wg + u, go * tanhf_(c), tag);
+            pd_put(rx, xcur + pd_hatt(B) + (unsigned)(b * 1024 + 4 * wg + u), go * tanhf_(c));
         }
         PD_STAMP(0, 1);
+        PD_RT(1);
         // ---- 2. h_att(t) for everyone (attention slices need it now, the others for decoder_rnn)
         // location features of this frame's tiles (fused filter, K = 64): they depend on the PREVIOUS frame's weights only,
         // so the attention workgroups evaluate them while h_att(t) is still on its way (round 3, from the training kernel)
@@ -308,11 +318,14 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                 }
             }
         }
-        for (int b = 0; b < B; ++b)
-            pd_gather<2>(X + (size_t)b * PD_XW + PD_X_HA, xcur + pd_hatt(B) + (size_t)b * 1024, 1024, tag, a.err, flag);
+        for (int b = 0; b < B; ++b) {
+            const int rounds = pd_gather(X + (size_t)b * PD_XW + PD_X_HA, rx, xcur + pd_hatt(B) + (unsigned)b * 1024u, 1024, b == 0 ? nap_h : 0, a.err, flag);
+            if (b == 0) nap_h = pd_adapt(nap_h, rounds);
+        }
         __syncthreads();
         if (flag[0] != 1) return;
         PD_STAMP(0, 2);
+        PD_RT(2);
         if (is_attn) {
             const int g = lane >> 4, c16 = lane & 15;
             const int len = a.lengths ? a.lengths[ab] : Tp;
@@ -337,7 +350,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             __syncthreads();
             const float4 q4 = make_float4(qv[4 * g], qv[4 * g + 1], qv[4 * g + 2], qv[4 * g + 3]);
             // partial energies of this slice: wave -> position tiles wave, wave + 8
-            t2v_u64* exw = xcur + pd_ex(B) + ((size_t)ab * 8 + as) * 256;
+            const unsigned exw = xcur + pd_ex(B) + (unsigned)((ab * 8 + as) * 256);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int jt = wave + 8 * i;
@@ -350,32 +363,31 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                     float esum = vr.x * s0 + vr.y * s1 + vr.z * s2 + vr.w * s3;
                     esum += __shfl_xor(esum, 16, 64);
                     esum += __shfl_xor(esum, 32, 64);
-                    if (g == 0 && j < Tp) pd_put(exw + j, esum, tag);
+                    if (g == 0 && j < Tp) pd_put(rx, exw + (unsigned)j, esum);
                 }
             }
             PD_STAMP(0, 3);
+            PD_RT(3);
             // gather the 8 partials of every position, masked softmax
             float ev0 = -INFINITY;
             if (tid < Tp) {
-                const t2v_u64* e0 = xcur + pd_ex(B) + (size_t)ab * 8 * 256 + tid;
+                const unsigned e0 = xcur + pd_ex(B) + (unsigned)(ab * 8 * 256 + tid);
                 float p[8];
                 unsigned spins = 0;
+                for (int i = 0; i < nap_x; i += 4) __builtin_amdgcn_s_sleep(4);
                 for (;;) {
                     bool ok = true;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const t2v_u64 x = pd_get(e0 + i * 256);
-                        p[i] = __uint_as_float((unsigned)x);
-                        ok = ok && (unsigned)(x >> 32) == tag;
+                        const unsigned x = pd_get(rx, e0 + (unsigned)(i * 256));
+                        p[i] = __uint_as_float(x);
+                        ok = ok && x != PD_SENT;
                     }
-                    if (ok) break;
+                    if (__all(ok)) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > PD_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        flag[0] = 0;
-                        break;
-                    }
+                    if (pd_give_up(spins, a.err, flag)) break;
                 }
+                nap_x = pd_adapt(nap_x, (int)spins);
                 const float ev = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
                 ev0 = tid < len ? ev : -INFINITY;
             }
@@ -416,6 +428,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             }
             __syncthreads();
             PD_STAMP(0, 4);
+            PD_RT(4);
             // context columns 64 as .. 64 as + 63: thread = (column c = tid & 63, part = tid >> 6)
             {
                 const int c = tid & 63, part = tid >> 6;
@@ -428,19 +441,22 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                 float acc = 0.f;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc += cred[u * 64 + tid];
-                pd_put(xcur + pd_ctx(B) + (size_t)ab * 512 + 64 * as + tid, acc, tag);
+                pd_put(rx, xcur + pd_ctx(B) + (unsigned)(ab * 512 + 64 * as + tid), acc);
             }
         }
         PD_STAMP(0, 5); PD_STAMP(64, 11);
+        PD_RT(5);
         // ---- 3. ctx(t) and h_dec(t-1) for everyone, decoder_rnn(t)
         for (int b = 0; b < B; ++b) {
-            pd_gather<1>(X + (size_t)b * PD_XW + PD_X_CX, xcur + pd_ctx(B) + (size_t)b * 512, 512, tag, a.err, flag);
+            const int rounds = pd_gather(X + (size_t)b * PD_XW + PD_X_CX, rx, xcur + pd_ctx(B) + (unsigned)b * 512u, 512, b == 0 ? nap_c : 0, a.err, flag);
+            if (b == 0) nap_c = pd_adapt(nap_c, rounds);
             if (t > 0 && !wg_proj)     // projection workgroups already hold h_dec(t-1) (they gathered it in stage 4)
-                pd_gather<2>(X + (size_t)b * PD_XW + PD_X_HD, xprev + pd_hdec(B) + (size_t)b * 1024, 1024, (unsigned)t, a.err, flag);
+                (void)pd_gather(X + (size_t)b * PD_XW + PD_X_HD, rx, xprev + pd_hdec(B) + (unsigned)b * 1024u, 1024, 0, a.err, flag);
         }
         __syncthreads();
         if (flag[0] != 1) return;
         PD_STAMP(0, 6);
+        PD_RT(6);
         pd_gemv<PD_KDEC / 32, T2V_KATT>(wd, X, B, red);       // logical k >= 1536 (h_dec) sits 256 further in the LDS row
         __syncthreads();
         if (tid < 16 * B) {
@@ -457,13 +473,16 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             const float gi = sigmoidf_(gp[0]), gf = sigmoidf_(gp[1]), gg = tanhf_(gp[2]), go = sigmoidf_(gp[3]);
             const float c = gf * cst[PD_MAXB * 4 + b * 4 + u] + gi * gg;
             cst[PD_MAXB * 4 + b * 4 + u] = c;
-            pd_put(xcur + pd_hdec(B) + (size_t)b * 1024 + 4 * wg + u, go * tanhf_(c), tag);
+            pd_put(rx, xcur + pd_hdec(B) + (unsigned)(b * 1024 + 4 * wg + u), go * tanhf_(c));
         }
         PD_STAMP(0, 7); PD_STAMP(64, 12);
+        PD_RT(7);
         // ---- 4. projection rows (mel, gate, folded Prenet layer 0)
         if (prow >= 0) {            // whole workgroup takes the branch: barriers inside are uniform
-            for (int b = 0; b < B; ++b)
-                pd_gather<2>(X + (size_t)b * PD_XW + PD_X_HD, xcur + pd_hdec(B) + (size_t)b * 1024, 1024, tag, a.err, flag);
+            for (int b = 0; b < B; ++b) {
+                const int rounds = pd_gather(X + (size_t)b * PD_XW + PD_X_HD, rx, xcur + pd_hdec(B) + (unsigned)b * 1024u, 1024, b == 0 ? nap_p : 0, a.err, flag);
+                if (b == 0) nap_p = pd_adapt(nap_p, rounds);
+            }
             __syncthreads();
             if (flag[0] != 1) return;
             if (is_proj) {
@@ -484,7 +503,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                         else {
                             const int rr = prow - (T2V_NMEL + 1);
                             const float pv = fmaxf(acc, 0.f) * t2v_drop_scale(a.seed, T2V_RNG_PRENET0, t + 1, (uint32_t)(b * T2V_PRE + rr), a.p_prenet);
-                            pd_put(xcur + pd_pre0(B) + (size_t)b * 256 + rr, pv, tag);
+                            gst[b * 8 + wave] = pv;         // published below, eight rows with ONE store instruction
                         }
                     }
                     all_fired = all_fired && acc > a.gate_logit_thr;
@@ -492,47 +511,57 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                 if (prow == T2V_NMEL && lane == 0) {
                     // stop rule sigmoid(gate) > threshold for every item (model.py:453; B == 1 in the reference)
                     if (all_fired) atomicMin(a.stop_flag, t);
-                    pd_put(xcur + pd_stop(B), __uint_as_float(all_fired ? 1u : 0u), tag);
+                    pd_put(rx, xcur + pd_stop(B), __uint_as_float(all_fired ? 2u : 1u));
                 }
             }
             __syncthreads();        // X[HD] now holds h_dec(t): the next frame's decoder_rnn input for this workgroup
+            // Prenet layer-0 rows of this workgroup: one coalesced 32-byte write per item instead of eight 4-byte writes from
+            // eight waves — 32 single-word writes per cache line from all over the chip took microseconds to land
+            if (tid < 8 * B) {
+                const int b = tid >> 3, row = (wg - PD_WG_PROJ) * 8 + (tid & 7);
+                if (row > T2V_NMEL && row < PD_NROW) pd_put(rx, xcur + pd_pre0(B) + (unsigned)(b * 256 + row - (T2V_NMEL + 1)), gst[b * 8 + (tid & 7)]);
+            }
         }
         PD_STAMP(64, 13); PD_STAMP(128, 15);
-        // ---- 5. Prenet layer 1 rows
+        PD_RT(8);
+        // ---- 5. Prenet layer 1 rows: wave 0 fetches pre0 for the whole workgroup (256 waves polling the same 1 KB were the
+        //         other hot spot of the frame)
         if (p1row >= 0) {
+            float* p0_s = w1_s + 8 * 256;                                  // [B][256]
+            if (wave == 0) {
+                unsigned spins = 0;
+                for (int i = 0; i < nap_q; i += 4) __builtin_amdgcn_s_sleep(4);
+                for (int b = 0; b < B; ++b) {
+                    const unsigned gq = xcur + pd_pre0(B) + (unsigned)(b * 256 + 4 * lane);
+                    pd_u32x4 x;
+                    for (;;) {
+                        x = pd_get4(rx, gq);
+                        if (__all(x[0] != PD_SENT && x[1] != PD_SENT && x[2] != PD_SENT && x[3] != PD_SENT)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (pd_give_up(spins, a.err, flag)) break;
+                    }
+                    *(float4*)(p0_s + b * 256 + 4 * lane) = make_float4(__uint_as_float(x[0]), __uint_as_float(x[1]), __uint_as_float(x[2]), __uint_as_float(x[3]));
+                }
+                nap_q = pd_adapt(nap_q, (int)spins);
+            }
+            __syncthreads();
+            if (flag[0] != 1) return;
             const float4 w4 = *(const float4*)(w1_s + wave * 256 + 4 * lane);
             for (int b = 0; b < B; ++b) {
-                const t2v_u64* gq = xcur + pd_pre0(B) + (size_t)b * 256 + 4 * lane;
-                float xv[4];
-                unsigned spins = 0;
-                bool dead = false;
-                for (;;) {
-                    bool ok = true;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const t2v_u64 x = pd_get(gq + i);
-                        xv[i] = __uint_as_float((unsigned)x);
-                        ok = ok && (unsigned)(x >> 32) == tag;
-                    }
-                    if (__all(ok)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > PD_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        dead = true;
-                        break;
-                    }
-                }
-                if (dead) break;
-                float acc = w4.x * xv[0];
-                acc = fmaf(w4.y, xv[1], acc); acc = fmaf(w4.z, xv[2], acc); acc = fmaf(w4.w, xv[3], acc);
+                const float4 xv = *(const float4*)(p0_s + b * 256 + 4 * lane);
+                float acc = w4.x * xv.x;
+                acc = fmaf(w4.y, xv.y, acc); acc = fmaf(w4.z, xv.z, acc); acc = fmaf(w4.w, xv.w, acc);
                 acc = wave_sum(acc);
                 if (lane == 0) {
                     acc = fmaxf(acc, 0.f) * t2v_drop_scale(a.seed, T2V_RNG_PRENET1, t + 1, (uint32_t)(b * T2V_PRE + p1row), a.p_prenet);
-                    pd_put(xcur + pd_pre1(B) + (size_t)b * 256 + p1row, acc, tag);
+                    gst[b * 8 + wave] = acc;
                 }
             }
+            __syncthreads();
+            if (tid < 8 * B) pd_put(rx, xcur + pd_pre1(B) + (unsigned)((tid >> 3) * 256 + (wg - PD_WG_PRE1) * 8 + (tid & 7)), gst[tid]);
         }
         PD_STAMP(128, 16); PD_STAMP(0, 8);
+        PD_RT(9);
     }
 }
 
@@ -546,7 +575,14 @@ static size_t pd_lds_bytes(int B, int T_in) {
 }
 #define PD_LDS_MAX (160 * 1024)
 
-extern "C" long t2v_decoder_persist_granules(int B) { return (B < 1 || B > PD_MAXB) ? 0 : (long)(2 * pd_par(B)); }
+// exchange scratch: one sentinel-filled row per frame
+extern "C" long t2v_decoder_persist_scratch_floats(int B, int t_end) {
+    return (B < 1 || B > PD_MAXB || t_end < 1) ? 0 : (long)((size_t)t_end * pd_row(B));
+}
+__global__ void k_pd_fill(uint4* p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = make_uint4(PD_SENT, PD_SENT, PD_SENT, PD_SENT);
+}
 // The workgroups of this kernel spin on each other's granules, so ALL 256 must be resident at once: one per CU on a
 // device with >= 256 CUs whose occupancy query admits this launch configuration (512 threads, the run-time LDS carve).
 // Answered once per device and (B, T_in) class; a device that is shared with other work can still fail to co-schedule
@@ -588,10 +624,11 @@ extern "C" int t2v_decoder_infer_persistent(const t2v_dec_persist_weights* w, co
     if (!w || !s || !t2v_decoder_persist_supported(B, T_in) || t_end < 1) return T2V_ERR_ARG;
     if (!w->w_ih_att || !w->w_hh_att || !w->w_ih_dec || !w->w_hh_dec || !w->bias_att || !w->bias_dec || !w->wq || !w->wcomb ||
         !w->v || !w->proj_w || !w->proj_b || !w->prenet_w1 || !s->memory || !s->pm || !s->pre_first || !s->MEL || !s->GATE ||
-        !s->AL || !s->stop_flag || !s->granules || !s->err_word)
+        !s->AL || !s->stop_flag || !s->exchange || !s->err_word)
         return T2V_ERR_ARG;
+    if (((uintptr_t)s->exchange & 15) || (size_t)t_end * pd_row(B) * 4 >= 0x7fffffffull) return T2V_ERR_ARG;      // 31-bit buffer offsets
     const size_t lds = pd_lds_bytes(B, T_in);     // (t2v_decoder_persist_supported raised the dynamic-LDS limit)
-    (void)hipMemsetAsync(s->granules, 0, sizeof(t2v_u64) * 2 * pd_par(B), stream);
+    k_pd_fill<<<1024, 256, 0, stream>>>((uint4*)s->exchange, (size_t)t_end * pd_row(B) / 4);
     (void)hipMemsetAsync(s->err_word, 0, sizeof(unsigned), stream);
     PersistArgs a;
     a.w_ih_att = w->w_ih_att; a.w_hh_att = w->w_hh_att; a.w_ih_dec = w->w_ih_dec; a.w_hh_dec = w->w_hh_dec;
@@ -599,7 +636,7 @@ extern "C" int t2v_decoder_infer_persistent(const t2v_dec_persist_weights* w, co
     a.proj_w = w->proj_w; a.proj_b = w->proj_b; a.w1 = w->prenet_w1;
     a.memory = s->memory; a.pm = s->pm; a.lengths = s->lengths; a.pre_first = s->pre_first;
     a.MEL = s->MEL; a.GATE = s->GATE; a.AL = s->AL; a.stop_flag = s->stop_flag;
-    a.xg = (t2v_u64*)s->granules; a.err = s->err_word;
+    a.xg = (float*)s->exchange; a.err = s->err_word;
     a.B = B; a.T_in = T_in; a.t_end = t_end;
     a.gate_logit_thr = gate_threshold <= 0.f ? -INFINITY : (gate_threshold >= 1.f ? INFINITY : logf(gate_threshold / (1.f - gate_threshold)));
     a.p_prenet = p_prenet; a.seed = seed;

@@ -44,7 +44,7 @@ class _DecPersistWeights(C.Structure):
 
 class _DecPersistBufs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        'memory', 'pm', 'lengths', 'pre_first', 'MEL', 'GATE', 'AL', 'stop_flag', 'granules', 'err_word')]
+        'memory', 'pm', 'lengths', 'pre_first', 'MEL', 'GATE', 'AL', 'stop_flag', 'exchange', 'err_word')]
 
 
 class _DecTrainPersistWeights(C.Structure):
@@ -64,7 +64,7 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_pack_l
            't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bn_act_bwd_eval', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats',
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_fuse_location_weights', 't2v_decoder_qp_floats',
            't2v_set_step_params', 't2v_set_step_params_stream', 't2v_decoder_replay_bwd_kernels', 't2v_embedding_fwd', 't2v_embedding_bwd', 't2v_gemm_f32_splitk', 't2v_gemm_splitk_scratch_floats', 't2v_gemm_f32_batched',
-           't2v_decoder_infer_persistent', 't2v_decoder_persist_supported', 't2v_decoder_persist_granules',
+           't2v_decoder_infer_persistent', 't2v_decoder_persist_supported', 't2v_decoder_persist_scratch_floats',
            't2v_attn_bwd_slices', 't2v_colsum', 't2v_colsum_scratch_floats', 't2v_gemm_epilogue_bwd',
            't2v_decoder_train_fwd_persistent', 't2v_decoder_train_persist_supported',
            't2v_decoder_train_persist_scratch_floats', 't2v_decoder_bwd_persist_supported',
@@ -138,8 +138,8 @@ def load_library():
     lib.t2v_decoder_infer_persistent.argtypes = [C.POINTER(_DecPersistWeights), C.POINTER(_DecPersistBufs), C.c_int, C.c_int,
                                                  C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]
     lib.t2v_decoder_persist_supported.argtypes = [C.c_int, C.c_int]
-    lib.t2v_decoder_persist_granules.argtypes = [C.c_int]
-    lib.t2v_decoder_persist_granules.restype = C.c_long
+    lib.t2v_decoder_persist_scratch_floats.argtypes = [C.c_int, C.c_int]
+    lib.t2v_decoder_persist_scratch_floats.restype = C.c_long
     lib.t2v_decoder_infer_steps.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecInferBufs), C.c_int, C.c_int, C.c_int,
                                             C.c_int, C.c_float, C.c_float, C.c_int, C.c_uint64, C.c_void_p]
     vp = C.c_void_p
@@ -827,7 +827,7 @@ class InferenceSession(object):
         lib = load_library()
         dev = self.memory.device
         if not hasattr(self, '_gran'):
-            self._gran = torch.empty(lib.t2v_decoder_persist_granules(self.B), device=dev, dtype=torch.int64)
+            self._gran = torch.empty(lib.t2v_decoder_persist_scratch_floats(self.B, self.max_steps), device=dev, dtype=torch.float32)
             self._perr = torch.zeros(1, device=dev, dtype=torch.int32)
         W = _DecPersistWeights(_p(self.raw[0]), _p(self.raw[1]), _p(self.raw[2]), _p(self.raw[3]), _p(self.b_att), _p(self.b_dec),
                                _p(self.wq), _p(self.wcomb), _p(self.v), _p(self.proj_w), _p(self.proj_b), _p(self.w1))

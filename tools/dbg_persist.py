@@ -30,7 +30,7 @@ print('us/frame:', res)
 t2v_hip.check_async_errors()
 import ctypes as C
 lib = t2v_hip.load_library()
-buf = torch.zeros(32, dtype=torch.int64, device='cuda')
+buf = torch.zeros(64 + 256 * 16, dtype=torch.int64, device='cuda')
 lib.t2v_set_phase_profile(C.c_void_p(buf.data_ptr()))
 with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
     m.decoder.inference(mem, persistent=True); torch.cuda.synchronize()
@@ -44,3 +44,18 @@ if steps > 101:
     if steps > 601 and v[23] > v[21]:
         print('500 frames = %d shader cycles = %.1f us on the 100 MHz wall clock  =>  %.2f GHz, %.2f us per frame' % (
             v[22] - v[20], (v[23] - v[21]) / 100.0, (v[22] - v[20]) / ((v[23] - v[21]) * 10.0), (v[23] - v[21]) / 100.0 / 500))
+
+if steps > 101:
+    # per-workgroup time line of frame 100 (ns after the first workgroup entered the frame)
+    rt = lambda w, k: v[64 + w * 16 + k] * 10
+    t0 = min(rt(w, 0) for w in range(256))
+    names = ['frame entry done (pre1 + stop in)', 'h_att published', 'h_att gathered', 'energies published (attention wgs)', 'softmax done (attention wgs)',
+             'ctx published / stage 3 entered', 'ctx (+ h_dec(t-1)) gathered', 'h_dec published', 'projection done (projection wgs) / stage 5 entered', 'frame end']
+    groups = {'attention wgs 0..7': range(0, 8), 'projection wgs 64..106': range(64, 107), 'Prenet-1 wgs 128..159': range(128, 160), 'plain wgs 160..255': range(160, 256)}
+    for k, nm in enumerate(names):
+        line = '  %-52s' % nm
+        for gname, ws in groups.items():
+            xs = sorted(rt(w, k) - t0 for w in ws if v[64 + w * 16 + k])
+            if xs:
+                line += ' | %s: %5d..%5d' % (gname.split()[0][:5], xs[0], xs[-1])
+        print(line)
