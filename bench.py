@@ -257,9 +257,19 @@ def roofline_table(B, T_in, T, reps=3):
             row["in_situ_source"] = situ_src
         if name == "k_achain_bwd":
             row["us_per_time_step"] = round(us / T, 3)
-            row["note"] = ("ONE launch for the whole reverse pass (%d time steps): all-gather of the gate gradients -> transposed "
-                           "weight columns in registers -> attention backward on position-split workgroups -> cell backward; "
-                           "latency-bound chain of hand-offs between CUs" % T)
+            row["note"] = ("ONE launch for the whole reverse pass (%d time steps): all-gather of (dc, dh) -> transposed weight columns "
+                           "in registers -> attention backward on position-split workgroups -> cell backward.  A chain of dependent "
+                           "hand-offs between CUs: HBM bandwidth is not what bounds it (the `frac` against 8 TB/s is reported because "
+                           "the contract asks for it)" % T)
+            # what does bound it (tools/micro/hop_latency.hip, tools/dbg/persist_bwd_prof.py): a CU pulls ~11 B/cycle
+            # from beyond its L2, a word crosses the chip in ~0.45 us, and a step needs three dependent hand-offs, a 48 KB row per
+            # attention_rnn workgroup on the chain and ~3.8 us of dependent arithmetic (context GEMV, attention slice, cell)
+            fetch_us = 48 * 1024 / 11.0 / 2400.0
+            floor_us = 3 * 0.45 + fetch_us + 3.8
+            row["latency_model"] = {"hand_offs_per_step": 3, "hand_off_us": 0.45, "row_bytes_on_chain_per_cu": 48 * 1024,
+                                    "cu_fetch_bytes_per_cycle": 11, "dependent_compute_us": 3.8, "floor_us_per_step": round(floor_us, 2),
+                                    "achieved_us_per_step": round(us / T, 2), "frac_of_floor": round(floor_us / (us / T), 3),
+                                    "source": "profiles/r03_bwd_persist_timeline.txt, profiles/r03_hop_latency.txt"}
         if name == "k_dec_train_persist":
             row["us_per_time_step"] = round(us / T, 3)
             row["note"] = ("ONE launch for all %d time steps: a chain of dependent hand-offs between CUs (attention_rnn -> "
