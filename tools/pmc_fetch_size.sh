@@ -14,7 +14,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     if r['Counter_Name'] != 'FETCH_SIZE':
         continue
     n = r['Kernel_Name']
-    for key in ('k_dec_train_persist', 'k_lstm_fwd256', 'k_lstm_bwd256', 'k_attn_fwd', 'k_attn_cell_bwd', 'k_clip_adam', 'k_attn_wgrad_part', 'k_conv5_fwd<5>', 'k_gemm_f32_big'):
+    for key in ('k_achain_bwd', 'k_dec_train_persist', 'k_lstm_fwd256', 'k_lstm_bwd256', 'k_attn_fwd', 'k_attn_cell_bwd', 'k_clip_adam', 'k_attn_wgrad_part', 'k_conv5_fwd<5>', 'k_gemm_f32_big'):
         if key in n:
             agg[key].append(float(r['Counter_Value']))
 alg = {'k_lstm_fwd256': 67108864, 'k_lstm_bwd256': 67108864, 'k_clip_adam': 462000000}
