@@ -445,6 +445,13 @@ class Tacotron2(nn.Module):
             # eagerly or as a replayed graph (and a resumed run continues with the masks of its iteration number)
             _block_calls[0] = 0
             self.decoder._calls = 0
+            if not self.training:
+                # several eval-mode forwards inside one training iteration (the validation loop; the Prenet drops out in
+                # eval mode too, model.py:102-106 of the reference) must not reuse one set of masks: they are
+                # never captured, so a host-side sequence number can offset their counters
+                self._eval_seq = (getattr(self, '_eval_seq', 0) + 1) % 4096
+                _block_calls[0] = self._eval_seq * 64
+                self.decoder._calls = self._eval_seq * 64
         # The text encoder and the reference encoder (VAE) are independent until the add below, and both are chains
         # of small latency-bound kernels (persistent BiLSTM on 16 workgroups, GRU, stride-2 convs): run the VAE
         # branch on a side stream so the two chains share the chip.  Autograd replays each node on its forward

@@ -197,3 +197,36 @@ def test_engine_step_tiny_and_odd_shapes(B, T_in, T_out):
     t2v_hip.check_async_errors()
     for o in out:
         assert torch.isfinite(o[0]).item() and torch.isfinite(o[4]).all().item()
+
+
+def test_eval_forwards_inside_one_iteration_draw_different_prenet_masks():
+    """the dropout epoch is the training iteration, and the host-side call counters restart with every forward —
+    so two validation batches of one iteration used to get the SAME Prenet masks (the Prenet drops out in eval mode too).
+    Eval-mode forwards now carry a per-forward sequence number; train-mode forwards of one iteration stay reproducible (a
+    replayed graph must issue what the eager step issued)."""
+    import sys
+    import hparams as HP
+    import train as TR
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic_batch
+    hp = HP.create_hparams("batch_size=2,anneal_function=constant")
+    torch.manual_seed(hp.seed)
+    eng = TR.TrainEngine(hp, graph=False)
+    batch = synthetic_batch(2, 17, 24, 3)
+    eng.step(batch, 0)
+    x, _ = eng.model.parse_batch(batch)
+    m = eng.model
+    with eng.stream_context():
+        m.eval()
+        with torch.no_grad():
+            a = m(x)[0].clone()
+            b = m(x)[0].clone()
+        m.train()
+        m.vae_gst.eps_override = torch.zeros(2, 32, device='cuda')
+        with torch.no_grad():
+            c = m(x)[0].clone()
+            d = m(x)[0].clone()
+        m.vae_gst.eps_override = None
+    torch.cuda.synchronize()
+    assert (a - b).abs().max().item() > 1e-4, "two eval forwards of one iteration must not share their Prenet masks"
+    assert torch.equal(c, d), "train-mode forwards of one iteration are reproducible"
