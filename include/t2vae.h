@@ -410,6 +410,16 @@ int t2v_conv2d_s2_fwd(const float* x, const float* w, const float* bias, float* 
 int t2v_conv2d_s2_dw_scratch_floats(int B, int Cx, int H, int W, int Cout, int coord);
 int t2v_conv2d_s2_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* dw_scratch,
                       int B, int Cx, int H, int W, int Cout, int coord, void* stream);
+
+/* The same convolution (forward / weight + data gradients) as batched GEMMs on the MFMA GEMM kernel (round 3; the reference
+ * encoder's late layers have <= 39 output positions per item — far too few for a thread-per-output kernel).  `scratch` holds
+ * t2v_conv2d_s2_gemm_scratch_floats(...) floats: the forward leaves the im2col matrix col[b][pos][c*9 + kh*3 + kw] there,
+ * the backward needs it (same buffer, untouched in between) and overwrites it. */
+long t2v_conv2d_s2_gemm_scratch_floats(int B, int Cx, int H, int W, int Cout, int coord);
+int t2v_conv2d_s2_fwd_gemm(const float* x, const float* w, const float* bias, float* y, float* scratch, int B, int Cx, int H, int W,
+                           int Cout, int coord, void* stream);
+int t2v_conv2d_s2_bwd_gemm(const float* x, const float* w, const float* dy, float* dx, float* dw, float* scratch, int B, int Cx, int H,
+                           int W, int Cout, int coord, void* stream);
 /* xchg: 2*16*256 floats (forward) / 2*16*768 floats (backward) exchange buffer of the 8 cooperating workgroups;
  * sync2: 2 uint32 (zeroed by the call; sync2[1] != 0 afterwards means a bounded spin timed out). */
 int t2v_gru_fwd(const float* gi, const float* whh, const float* bhh, float* hs, float* gsave, float* xchg,

@@ -25,6 +25,9 @@ struct GemmArgs {
     float* part;           // split-K partial tiles (gridDim.z, M, N) or NULL
     int nbatch;            // > 1: blockIdx.z = independent product (no split-K), operands advance by the batch strides
     long sAb, sBb, sCb;
+    int nsub;              // > 1: product z covers k-chunk z % nsub of batch item z / nsub (A, B advance by sAs, sBs per chunk)
+    long sAs, sBs;
+    int bias_row;          // bias indexed by the output ROW (a convolution's output channel) instead of the column
 };
 
 template <bool A_KC, bool B_KC>   // operand contiguous along k?
@@ -34,7 +37,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int i0 = blockIdx.y * GM_BM, j0 = blockIdx.x * GM_BN;
-    if (a.nbatch > 1) { a.A += blockIdx.z * a.sAb; a.B += blockIdx.z * a.sBb; a.C += blockIdx.z * a.sCb; }
+    if (a.nbatch > 1) {
+        const int zb = a.nsub > 1 ? blockIdx.z / a.nsub : blockIdx.z, zs = a.nsub > 1 ? blockIdx.z - zb * a.nsub : 0;
+        a.A += zb * a.sAb + zs * a.sAs; a.B += zb * a.sBb + zs * a.sBs; a.C += blockIdx.z * a.sCb;
+    }
     const int kbeg = a.kz_chunk ? blockIdx.z * a.kz_chunk : 0, kend = a.kz_chunk ? min(a.K, kbeg + a.kz_chunk) : a.K;
     constexpr int NE = GM_BM * GM_BK / 256;   // 8
     float ra[NE], rb[NE];
@@ -93,13 +99,13 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
         return;
     }
     if (j < a.N) {
-        const float bv = a.bias ? a.bias[j] : 0.f;
+        const float bv = (a.bias && !a.bias_row) ? a.bias[j] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = i0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (i < a.M) {
                 const size_t idx = (size_t)i * a.ldc + j;
-                float v = acc[r] + bv;
+                float v = acc[r] + ((a.bias && a.bias_row) ? a.bias[i] : bv);
                 if (a.accumulate) v += a.C[idx];
                 if (a.relu) v = fmaxf(v, 0.f);
                 if (a.p_drop > 0.f) v *= t2v_drop_scale(t2v_step_seed(a.seed, a.step), a.rng_stream, a.rng_t, (uint32_t)idx, a.p_drop);
@@ -522,7 +528,7 @@ extern "C" int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B,
     a.A = A; a.B = B; a.bias = bias; a.C = C; a.sAi = sAi; a.sAk = sAk; a.sBj = sBj; a.sBk = sBk;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
     a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
-    a.kz_chunk = 0; a.part = nullptr; a.nbatch = 1; a.sAb = a.sBb = a.sCb = 0;
+    a.kz_chunk = 0; a.part = nullptr; a.nbatch = 1; a.sAb = a.sBb = a.sCb = 0; a.nsub = 1; a.sAs = a.sBs = 0; a.bias_row = 0;
     if (gemm_bf16_big_ok(a)) {
         dim3 gb((N + GBB_BN - 1) / GBB_BN, (M + GBB_BM - 1) / GBB_BM);
         k_gemm_bf16_big_rr<<<gb, 256, 0, stream>>>(a);
@@ -561,7 +567,7 @@ static int gemm_f32_impl(const float* A, long sAi, long sAk, const float* B, lon
     a.A = A; a.B = B; a.bias = bias; a.C = C; a.sAi = sAi; a.sAk = sAk; a.sBj = sBj; a.sBk = sBk;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
     a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
-    a.kz_chunk = 0; a.part = nullptr; a.nbatch = 1; a.sAb = a.sBb = a.sCb = 0;
+    a.kz_chunk = 0; a.part = nullptr; a.nbatch = 1; a.sAb = a.sBb = a.sCb = 0; a.nsub = 1; a.sAs = a.sBs = 0; a.bias_row = 0;
     const bool akc = sAk == 1, bkc = sBk == 1;
     if (gemm_big_ok(a)) {
         const bool wide = gemm_big_waste(M, N, 128) <= gemm_big_waste(M, N, 64) + 1e-6;
@@ -595,20 +601,26 @@ static int gemm_f32_impl(const float* A, long sAi, long sAk, const float* B, lon
 // nbatch independent products C_z = A_z · B_z^T in ONE launch of the 64x64 kernel (blockIdx.z = z): the per-item
 // d_memory[b] = alignments_b^T · d_ctx_b of the decoder's reverse pass (model.py:84-85 under autograd) were B launches
 // of 16 workgroups each.
-extern "C" int t2v_gemm_f32_batched(const float* A, long sAb, long sAi, long sAk, const float* B, long sBb, long sBj, long sBk,
-                                    float* C, long sCb, int ldc, int nbatch, int M, int N, int K, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!A || !B || !C || nbatch < 1 || nbatch > 65535 || M < 1 || N < 1 || K < 1 || ldc < N) return T2V_ERR_ARG;
+// internal form (refenc.hip: the stride-2 convolutions of the reference encoder as batched GEMMs): per-row bias, and
+// nsub k-chunks per batch item, each an independent product with its own output block
+int t2v_gemm_f32_batched_ex(const float* A, long sAb, long sAs, long sAi, long sAk, const float* B, long sBb, long sBs, long sBj, long sBk,
+                            const float* bias_row, float* C, long sCb, int ldc, int nbatch, int nsub, int M, int N, int K, hipStream_t stream) {
+    if (!A || !B || !C || nbatch < 1 || nsub < 1 || (long)nbatch * nsub > 65535 || M < 1 || N < 1 || K < 1 || ldc < N) return T2V_ERR_ARG;
     GemmArgs a;
-    a.A = A; a.B = B; a.bias = nullptr; a.C = C; a.sAi = sAi; a.sAk = sAk; a.sBj = sBj; a.sBk = sBk;
+    a.A = A; a.B = B; a.bias = bias_row; a.C = C; a.sAi = sAi; a.sAk = sAk; a.sBj = sBj; a.sBk = sBk;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = 0; a.accumulate = 0;
     a.p_drop = 0.f; a.seed = 0; a.rng_stream = 0; a.rng_t = 0; a.step = t2v_step_for(stream);
-    a.kz_chunk = 0; a.part = nullptr; a.nbatch = nbatch; a.sAb = sAb; a.sBb = sBb; a.sCb = sCb;
+    a.kz_chunk = 0; a.part = nullptr; a.nbatch = nbatch * nsub > 1 ? nbatch * nsub : 1; a.sAb = sAb; a.sBb = sBb; a.sCb = sCb;
+    a.nsub = nsub; a.sAs = sAs; a.sBs = sBs; a.bias_row = bias_row ? 1 : 0;
     const bool akc = sAk == 1, bkc = sBk == 1;
-    dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, nbatch);
+    dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, nbatch * nsub);
     if (akc && bkc) k_gemm_f32<true, true><<<grid, 256, 0, stream>>>(a);
     else if (akc) k_gemm_f32<true, false><<<grid, 256, 0, stream>>>(a);
     else if (bkc) k_gemm_f32<false, true><<<grid, 256, 0, stream>>>(a);
     else k_gemm_f32<false, false><<<grid, 256, 0, stream>>>(a);
     return t2v_check_launch();
+}
+extern "C" int t2v_gemm_f32_batched(const float* A, long sAb, long sAi, long sAk, const float* B, long sBb, long sBj, long sBk,
+                                    float* C, long sCb, int ldc, int nbatch, int M, int N, int K, void* stream_) {
+    return t2v_gemm_f32_batched_ex(A, sAb, 0, sAi, sAk, B, sBb, 0, sBj, sBk, nullptr, C, sCb, ldc, nbatch, 1, M, N, K, (hipStream_t)stream_);
 }

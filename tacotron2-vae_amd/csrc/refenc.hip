@@ -120,8 +120,18 @@ __global__ __launch_bounds__(256) void k_conv2d_s2_dw(Conv2dArgs a, float* part,
 __global__ void k_conv2d_s2_dw_reduce(const float* __restrict__ part, float* __restrict__ dw, int n, int nsplit) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // eight partials in flight (the order of the additions stays fixed): a serial loop was one memory latency per partial —
+    // 24 us for the 96 partials of the first two layers
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
+    int k = 0;
+    for (; k + 8 <= nsplit; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nsplit; ++k) s += part[(size_t)k * n + i];
     dw[i] = s;
 }
 
@@ -169,6 +179,109 @@ extern "C" int t2v_conv2d_s2_bwd(const float* x, const float* w, const float* dy
     const int chunk = (npos + ns - 1) / ns;
     k_conv2d_s2_dw<<<dim3(Cout * Cin, ns), 256, 0, stream>>>(a, dw_scratch, chunk);
     if (ns > 1) k_conv2d_s2_dw_reduce<<<(Cout * Cin * 9 + 255) / 256, 256, 0, stream>>>(dw_scratch, dw, Cout * Cin * 9, ns);
+    return t2v_check_launch();
+}
+
+// ---- the same convolutions as batched GEMMs (round 3).  The direct-form kernels above give one output to a thread and a
+// (co, item) pair to a workgroup: the late layers (<= 39 output positions per item) leave most lanes idle and every thread
+// walks Cin*9 taps alone — 37..83 us per launch for 12..110 MFLOP.  Here the taps are gathered once (im2col, layout
+// col[b][pos][k = c*9 + kh*3 + kw], CoordConv channels included) and the three products run on the 64x64 MFMA GEMM, one
+// launch each for all items (t2v_gemm_f32_batched_ex):
+//   y_b  (Cout x P)  = W (Cout x K) · col_b^T           + bias per row
+//   dW   (Cout x K)  = sum over (item, position chunk) of  dy_b[:, chunk] · col_b[chunk, :]      (partials + fixed-order reduce)
+//   dcol_b (P x K)   = dy_b^T (P x Cout) · W             then col2im: every input pixel adds up its <= 4 taps
+int t2v_gemm_f32_batched_ex(const float* A, long sAb, long sAs, long sAi, long sAk, const float* B, long sBb, long sBs, long sBj, long sBk,
+                            const float* bias_row, float* C, long sCb, int ldc, int nbatch, int nsub, int M, int N, int K, hipStream_t stream);
+
+__global__ __launch_bounds__(256) void k_im2col_s2(Conv2dArgs a, float* __restrict__ col) {
+    const int Cin = a.Cx + (a.coord ? 3 : 0), K = Cin * 9, P = a.Ho * a.Wo;
+    const size_t n = (size_t)a.B * P * K;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const int k = (int)(e % K);
+        const size_t bp = e / K;
+        const int pos = (int)(bp % P), b = (int)(bp / P);
+        const int c = k / 9, t9 = k - c * 9, kh = t9 / 3, kw = t9 - kh * 3;
+        const int ho = pos / a.Wo, wo = pos - ho * a.Wo;
+        col[e] = refenc_in(a, b, c, 2 * ho - 1 + kh, 2 * wo - 1 + kw);
+    }
+}
+// dx[b][c][h][w] = sum of dcol[b][(ho, wo)][c*9 + kh*3 + kw] over the taps with 2ho-1+kh = h, 2wo-1+kw = w (c < Cx only)
+__global__ __launch_bounds__(256) void k_col2im_s2(Conv2dArgs a, const float* __restrict__ dcol) {
+    const int Cin = a.Cx + (a.coord ? 3 : 0), K = Cin * 9, P = a.Ho * a.Wo;
+    const size_t n = (size_t)a.B * a.Cx * a.H * a.W;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const int w = (int)(e % a.W);
+        size_t r = e / a.W;
+        const int h = (int)(r % a.H);
+        r /= a.H;
+        const int c = (int)(r % a.Cx), b = (int)(r / a.Cx);
+        float acc = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hh = h + 1 - kh;
+            if (hh < 0 || (hh & 1) || (hh >> 1) >= a.Ho) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ww = w + 1 - kw;
+                if (ww < 0 || (ww & 1) || (ww >> 1) >= a.Wo) continue;
+                acc += dcol[((size_t)b * P + (size_t)(hh >> 1) * a.Wo + (ww >> 1)) * K + c * 9 + kh * 3 + kw];
+            }
+        }
+        a.y[e] = acc;
+    }
+}
+// position chunks of the weight-gradient product: a divisor of P, chunks of >= 64 positions, <= 16 chunks
+static inline int conv2d_gemm_chunks(int P) {
+    int ns = 1;
+    while (ns < 16 && P % (2 * ns) == 0 && P / (2 * ns) >= 64) ns *= 2;
+    return ns;
+}
+// scratch of the GEMM form (floats): [col: B*P*K, reused for dcol][dW partials: B*ns*Cout*K]
+extern "C" long t2v_conv2d_s2_gemm_scratch_floats(int B, int Cx, int H, int W, int Cout, int coord) {
+    if (B < 1 || Cx < 1 || H < 1 || W < 1 || Cout < 1) return 0;
+    const long Cin = Cx + (coord ? 3 : 0), K = Cin * 9, P = (long)((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
+    return B * P * K + (long)B * conv2d_gemm_chunks((int)P) * Cout * K;
+}
+static Conv2dArgs conv2d_args(const float* x, const float* w, int B, int Cx, int H, int W, int Cout, int coord) {
+    Conv2dArgs a;
+    a.x = x; a.w = w; a.bias = nullptr; a.dy = nullptr; a.y = nullptr; a.dbias = nullptr;
+    a.B = B; a.Cx = Cx; a.H = H; a.W = W; a.Cout = Cout; a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1; a.coord = coord;
+    return a;
+}
+extern "C" int t2v_conv2d_s2_fwd_gemm(const float* x, const float* w, const float* bias, float* y, float* scratch, int B, int Cx, int H,
+                                      int W, int Cout, int coord, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !w || !y || !scratch || B < 1 || Cx < 1 || H < 1 || W < 1 || Cout < 1) return T2V_ERR_ARG;
+    if (coord && (H < 2 || W < 2)) return T2V_ERR_ARG;
+    Conv2dArgs a = conv2d_args(x, w, B, Cx, H, W, Cout, coord);
+    const int K = (Cx + (coord ? 3 : 0)) * 9, P = a.Ho * a.Wo;
+    const size_t n = (size_t)B * P * K;
+    k_im2col_s2<<<(unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256), 256, 0, stream>>>(a, scratch);
+    return t2v_gemm_f32_batched_ex(w, 0, 0, K, 1, scratch, (long)P * K, 0, K, 1, bias, y, (long)Cout * P, P, B, 1, Cout, P, K, stream);
+}
+// `scratch` must still hold the im2col of the forward pass (t2v_conv2d_s2_fwd_gemm leaves it there); it is overwritten.
+extern "C" int t2v_conv2d_s2_bwd_gemm(const float* x, const float* w, const float* dy, float* dx, float* dw, float* scratch, int B, int Cx,
+                                      int H, int W, int Cout, int coord, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !w || !dy || !dw || !scratch || B < 1) return T2V_ERR_ARG;
+    Conv2dArgs a = conv2d_args(x, w, B, Cx, H, W, Cout, coord);
+    const int K = (Cx + (coord ? 3 : 0)) * 9, P = a.Ho * a.Wo;
+    float* col = scratch;
+    float* part = scratch + (size_t)B * P * K;
+    const int ns = conv2d_gemm_chunks(P), chunk = P / ns;
+    // dW partials: item b, chunk s: dy_b[:, chunk] (Cout x chunk) · col_b[chunk, :] (as B operand: [j = k][k' = pos])
+    int rc = t2v_gemm_f32_batched_ex(dy, (long)Cout * P, chunk, P, 1, col, (long)P * K, (long)chunk * K, 1, K, nullptr, part, (long)Cout * K, K,
+                                     B, ns, Cout, K, chunk, stream);
+    if (rc != T2V_OK) return rc;
+    k_conv2d_s2_dw_reduce<<<(Cout * K + 255) / 256, 256, 0, stream>>>(part, dw, Cout * K, B * ns);
+    if (dx) {
+        // dcol_b (P x K) = dy_b^T (P x Cout) · W (as B operand: [j = k][k' = co]); overwrites col
+        rc = t2v_gemm_f32_batched_ex(dy, (long)Cout * P, 0, 1, P, w, 0, 0, 1, K, nullptr, col, (long)P * K, K, B, 1, P, K, Cout, stream);
+        if (rc != T2V_OK) return rc;
+        a.y = dx;
+        const size_t n = (size_t)B * Cx * H * W;
+        k_col2im_s2<<<(unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256), 256, 0, stream>>>(a, col);
+    }
     return t2v_check_launch();
 }
 

@@ -61,7 +61,8 @@ class _DecInferBufs(C.Structure):
 
 EXPORTS = ('t2v_version', 't2v_last_error', 't2v_pack_lstm_weights', 't2v_pack_lstm_weights_bf16', 't2v_decoder_train_fwd',
            't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_conv1d_dw_scratch_floats', 't2v_gemm_bf16', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
-           't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bn_act_bwd_eval', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats',
+           't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bn_act_bwd_eval', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats', 't2v_conv2d_s2_fwd_gemm', 't2v_conv2d_s2_bwd_gemm',
+           't2v_conv2d_s2_gemm_scratch_floats',
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_fuse_location_weights', 't2v_decoder_qp_floats',
            't2v_set_step_params', 't2v_set_step_params_stream', 't2v_decoder_replay_bwd_kernels', 't2v_embedding_fwd', 't2v_embedding_bwd', 't2v_gemm_f32_splitk', 't2v_gemm_splitk_scratch_floats', 't2v_gemm_f32_batched',
            't2v_decoder_infer_persistent', 't2v_decoder_persist_supported', 't2v_decoder_persist_scratch_floats',
@@ -168,6 +169,10 @@ def load_library():
     lib.t2v_attn_wgrad_scratch_floats.argtypes = []
     lib.t2v_conv2d_s2_fwd.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.t2v_conv2d_s2_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.t2v_conv2d_s2_fwd_gemm.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.t2v_conv2d_s2_bwd_gemm.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.t2v_conv2d_s2_gemm_scratch_floats.argtypes = [C.c_int] * 6
+    lib.t2v_conv2d_s2_gemm_scratch_floats.restype = C.c_long
     lib.t2v_conv2d_s2_dw_scratch_floats.argtypes = [C.c_int] * 6
     lib.t2v_gru_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.t2v_gru_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
@@ -1150,6 +1155,10 @@ class LinearHIP(torch.autograd.Function):
         return (dx.view(xshape) if dx is not None else None), dw, db, None, None, None, None, None
 
 
+# reference-encoder convolutions as im2col + batched GEMM (T2V_CONV2D_GEMM=0: the direct-form kernels)
+CONV2D_GEMM = os.environ.get('T2V_CONV2D_GEMM', '1') != '0'
+
+
 class Conv2dBNReLU(torch.autograd.Function):
     """relu(BatchNorm2d(Conv2d 3x3 s2 p1 (x [+ CoordConv channels]))) — one layer of the reference encoder
     (reference modules.py:68-71) on the direct-form HIP conv + the per-channel BN kernels."""
@@ -1164,8 +1173,14 @@ class Conv2dBNReLU(torch.autograd.Function):
         f32 = dict(device=x.device, dtype=torch.float32)
         w = weight.contiguous()
         y = torch.empty(B, Cout, Ho, Wo, **f32)
-        _check(lib.t2v_conv2d_s2_fwd(_p(x), _p(w), _p(bias), _p(y), B, Cx, Hh, Ww, Cout, int(coord), _stream()),
-               't2v_conv2d_s2_fwd')
+        gscr = None
+        if CONV2D_GEMM:      # im2col + batched MFMA GEMM (the im2col matrix stays in gscr for the backward pass)
+            gscr = torch.empty(lib.t2v_conv2d_s2_gemm_scratch_floats(B, Cx, Hh, Ww, Cout, int(coord)), **f32)
+            _check(lib.t2v_conv2d_s2_fwd_gemm(_p(x), _p(w), _p(bias), _p(y), _p(gscr), B, Cx, Hh, Ww, Cout, int(coord), _stream()),
+                   't2v_conv2d_s2_fwd_gemm')
+        else:
+            _check(lib.t2v_conv2d_s2_fwd(_p(x), _p(w), _p(bias), _p(y), B, Cx, Hh, Ww, Cout, int(coord), _stream()),
+                   't2v_conv2d_s2_fwd')
         mean = torch.empty(Cout, **f32) if training else None
         rstd = torch.empty(Cout, **f32) if training else None
         out = torch.empty_like(y)
@@ -1173,6 +1188,7 @@ class Conv2dBNReLU(torch.autograd.Function):
                                   _p(rstd), _p(out), B, Cout, Ho * Wo, ACT_RELU, int(bool(training)), 0.0, 0.1, 1e-5,
                                   0, 0, 0, _stream()), 't2v_bn_act_fwd')
         ctx.keep = (x, w, y, mean, rstd, gamma, beta)
+        ctx.gscr = gscr
         ctx.running = (running_mean, running_var)
         ctx.small = (gamma, beta, bias)
         ctx.cfg = (B, Cx, Hh, Ww, Cout, Ho, Wo, int(coord), bool(training))
@@ -1195,10 +1211,15 @@ class Conv2dBNReLU(torch.autograd.Function):
                       _p(dbeta), _p(dbias), B, Cout, Ho * Wo, ACT_RELU, 0.0, 0, 0, 0, _stream()), 't2v_bn_act_bwd')
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = torch.empty_like(w)
-        nscr = lib.t2v_conv2d_s2_dw_scratch_floats(B, Cx, Hh, Ww, Cout, coord)
-        scr = torch.empty(nscr, **f32) if nscr else None
-        _check(lib.t2v_conv2d_s2_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(scr), B, Cx, Hh, Ww, Cout, coord,
-                                     _stream()), 't2v_conv2d_s2_bwd')
+        if ctx.gscr is not None:
+            _check(lib.t2v_conv2d_s2_bwd_gemm(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(ctx.gscr), B, Cx, Hh, Ww, Cout, coord,
+                                              _stream()), 't2v_conv2d_s2_bwd_gemm')
+            ctx.gscr = None
+        else:
+            nscr = lib.t2v_conv2d_s2_dw_scratch_floats(B, Cx, Hh, Ww, Cout, coord)
+            scr = torch.empty(nscr, **f32) if nscr else None
+            _check(lib.t2v_conv2d_s2_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(scr), B, Cx, Hh, Ww, Cout, coord,
+                                         _stream()), 't2v_conv2d_s2_bwd')
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None
 
 

@@ -119,3 +119,52 @@ def test_eval_mode_batchnorm_backward_matches_torch():
     for name, r, d in zip(('x', 'weight', 'bias', 'gamma', 'beta'), ref, dev):
         scale = r.grad.abs().max().item()
         assert (d.grad.cpu() - r.grad).abs().max().item() < 3e-3 * scale, name
+
+
+def _coord_channels(B, H, W):
+    """CoordConv.py:42-73 (with_r): xx along H, yy along W in [-1, 1], rr = sqrt((xx-.5)^2 + (yy-.5)^2)"""
+    xx = (torch.arange(H, dtype=torch.float32) / (H - 1) * 2 - 1).view(1, 1, H, 1).expand(B, 1, H, W)
+    yy = (torch.arange(W, dtype=torch.float32) / (W - 1) * 2 - 1).view(1, 1, 1, W).expand(B, 1, H, W)
+    rr = torch.sqrt((xx - 0.5) ** 2 + (yy - 0.5) ** 2)
+    return torch.cat([xx, yy, rr], 1)
+
+
+@pytest.mark.parametrize("gemm_form", [True, False])
+@pytest.mark.parametrize("B,Cx,H,W,Cout,coord", [(6, 1, 400, 80, 32, True), (6, 32, 200, 40, 32, False), (3, 32, 100, 20, 64, False),
+                                                 (6, 64, 25, 5, 128, False), (6, 128, 13, 3, 128, False), (2, 5, 9, 7, 6, True),
+                                                 (2, 3, 2, 2, 4, False)])
+def test_conv2d_s2_bn_relu_matches_torch(B, Cx, H, W, Cout, coord, gemm_form):
+    """One reference-encoder layer (modules.py:68-71: [CoordConv +] Conv2d 3x3 stride 2 pad 1 -> BatchNorm2d (train) -> ReLU), output
+    and all five gradients, in both forms: im2col + batched MFMA GEMM (round 3, default) and the direct-form kernels."""
+    import t2v_hip
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B * 1000 + H + Cout)
+    Cin = Cx + (3 if coord else 0)
+    x = torch.randn(B, Cx, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (1.0 / (Cin * 9) ** 0.5)
+    b = torch.randn(Cout, generator=g) * 0.1
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    wo = torch.randn(B, Cout, Ho, Wo, generator=g)
+    ref = [t.clone().requires_grad_(True) for t in (x, w, b, gamma, beta)]
+    xin = torch.cat([ref[0], _coord_channels(B, H, W)], 1) if coord else ref[0]
+    rm, rv = torch.zeros(Cout), torch.ones(Cout)
+    y = torch.relu(F.batch_norm(F.conv2d(xin, ref[1], ref[2], stride=2, padding=1), rm, rv, ref[3], ref[4], True, 0.1, 1e-5))
+    (y * wo).sum().backward()
+    old = t2v_hip.CONV2D_GEMM
+    t2v_hip.CONV2D_GEMM = gemm_form
+    try:
+        dev = [t.clone().cuda().requires_grad_(True) for t in (x, w, b, gamma, beta)]
+        drm, drv = torch.zeros(Cout, device='cuda'), torch.ones(Cout, device='cuda')
+        out = t2v_hip.Conv2dBNReLU.apply(dev[0], dev[1], dev[2], dev[3], dev[4], drm, drv, True, coord)
+        (out * wo.cuda()).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        t2v_hip.CONV2D_GEMM = old
+    assert (out.cpu() - y).abs().max().item() < 2e-4 * max(1.0, y.abs().max().item())
+    assert (drm.cpu() - rm).abs().max().item() < 1e-4 and (drv.cpu() - rv).abs().max().item() < 1e-3      # running statistics (bias included)
+    for name, r, d in zip(('x', 'weight', 'bias', 'gamma', 'beta'), ref, dev):
+        if name == 'bias':
+            continue          # train-mode BatchNorm cancels the conv bias: its gradient is zero up to round-off in both
+        scale = max(r.grad.abs().max().item(), 1e-6)
+        assert (d.grad.cpu() - r.grad).abs().max().item() < 3e-3 * scale, name
