@@ -453,8 +453,10 @@ def main():
                            "launches_timed": top["launches_timed"],
                            "frac_in_situ": top.get("frac_in_situ"), "in_situ_us": top.get("in_situ_us"),
                            "in_situ_source": top.get("in_situ_source"),
-                           "note": "the 67 MB weight stream of a launch is re-read every time step and is served by the "
+                           "note": top.get("note") if top["kernel"] in ("k_achain_bwd", "k_dec_train_persist") else
+                                   "the 67 MB weight stream of a launch is re-read every time step and is served by the "
                                    "256 MiB Infinity Cache, not by HBM proper; 8 TB/s is the HBM3E peak the guide prices against",
+                           "latency_model": top.get("latency_model"), "us_per_time_step": top.get("us_per_time_step"),
                            "kernels": rows,
                            "forward_mode": t2v_hip.DecoderCore.last_mode, "backward_mode": t2v_hip.DecoderCore.last_bwd_mode,
                            "recurrence_us_per_time_step": round(rec_us, 2),

@@ -211,11 +211,22 @@ def test_eval_forwards_inside_one_iteration_draw_different_prenet_masks():
     from bench import synthetic_batch
     hp = HP.create_hparams("batch_size=2,anneal_function=constant")
     torch.manual_seed(hp.seed)
+    import model as M
+    old_rate, M.drop_rate = M.drop_rate, 0.5          # (other tests switch the dropout off module-wide for their parity runs)
     eng = TR.TrainEngine(hp, graph=False)
     batch = synthetic_batch(2, 17, 24, 3)
     eng.step(batch, 0)
     x, _ = eng.model.parse_batch(batch)
     m = eng.model
+    try:
+        a, b, c, d = _two_eval_two_train_forwards(eng, m, x)
+    finally:
+        M.drop_rate = old_rate
+    assert (a - b).abs().max().item() > 1e-4, "two eval forwards of one iteration must not share their Prenet masks"
+    assert torch.equal(c, d), "train-mode forwards of one iteration are reproducible"
+
+
+def _two_eval_two_train_forwards(eng, m, x):
     with eng.stream_context():
         m.eval()
         with torch.no_grad():
@@ -228,5 +239,4 @@ def test_eval_forwards_inside_one_iteration_draw_different_prenet_masks():
             d = m(x)[0].clone()
         m.vae_gst.eps_override = None
     torch.cuda.synchronize()
-    assert (a - b).abs().max().item() > 1e-4, "two eval forwards of one iteration must not share their Prenet masks"
-    assert torch.equal(c, d), "train-mode forwards of one iteration are reproducible"
+    return a, b, c, d
