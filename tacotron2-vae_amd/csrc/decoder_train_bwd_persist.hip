@@ -901,21 +901,36 @@ __device__ __forceinline__ void pba_decoder_role(const PBAArgs& a, float* lds, c
     if (a.prof && jd == 0 && tid == 0) a.prof[41] = __builtin_amdgcn_s_memrealtime();
 }
 
-// the activation-only part of attention_rnn's cell backward at step t -> cpre[row][8] = {fh, fc, go(1-tanh(c)^2), gf, e0..e3}
-__device__ __forceinline__ void pba_cell_pre(const PBAArgs& a, float* cpre, uint64_t seed, bool cell_thr, int rowi, int t, int cb, int U,
-                                             uint32_t idx) {
-    if (!cell_thr) return;
+// the activation-only part of attention_rnn's cell backward at step t -> cpre[row][8] = {fh, fc, go(1-tanh(c)^2), gf, e0..e3}.
+// Two halves: the loads are issued BEFORE the factor-row DMA and consumed after it — behind the DMA they queued for the
+// whole copy on the wave's in-order memory counter and in the CU's load pipe (1.7 us for six L2-warm loads).
+struct PBACellIn { float gi, gf, gg, go, cac, cprev; };
+__device__ __forceinline__ PBACellIn pba_cell_pre_load(const PBAArgs& a, bool cell_thr, int t, int cb, int U) {
+    PBACellIn r = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!cell_thr) return r;
     const int B = a.B;
     const float* gp = a.GA + ((size_t)t * B + cb) * T2V_G + U;
-    const float gi = gp[0], gf = gp[T2V_H], gg = gp[2 * T2V_H], go = gp[3 * T2V_H];
-    const float cac = a.CA[((size_t)(t + 1) * B + cb) * T2V_H + U];
-    float cprev = a.CA[((size_t)t * B + cb) * T2V_H + U];
+    r.gi = gp[0]; r.gf = gp[T2V_H]; r.gg = gp[2 * T2V_H]; r.go = gp[3 * T2V_H];
+    r.cac = a.CA[((size_t)(t + 1) * B + cb) * T2V_H + U];
+    r.cprev = a.CA[((size_t)t * B + cb) * T2V_H + U];
+    return r;
+}
+__device__ __forceinline__ void pba_cell_pre_finish(const PBAArgs& a, float* cpre, uint64_t seed, bool cell_thr, int rowi, int t, uint32_t idx,
+                                                    const PBACellIn& r) {
+    if (!cell_thr) return;
+    const float gi = r.gi, gf = r.gf, gg = r.gg, go = r.go;
+    float cprev = r.cprev;
     const float fh = t2v_drop_scale(seed, T2V_RNG_ATT_H, t, idx, a.p_att);
     const float fc = t2v_drop_scale(seed, T2V_RNG_ATT_C, t, idx, a.p_att);
     if (t > 0) cprev *= t2v_drop_scale(seed, T2V_RNG_ATT_C, t - 1, idx, a.p_att);
-    const float tc = tanhf_(cac);
+    const float tc = tanhf_(r.cac);
     *(float4*)(cpre + rowi * 8) = make_float4(fh, fc, go * (1.0f - tc * tc), gf);
     *(float4*)(cpre + rowi * 8 + 4) = make_float4(gg * gi * (1.0f - gi), cprev * gf * (1.0f - gf), gi * (1.0f - gg * gg), tc * go * (1.0f - go));
+}
+__device__ __forceinline__ void pba_cell_pre(const PBAArgs& a, float* cpre, uint64_t seed, bool cell_thr, int rowi, int t, int cb, int U,
+                                             uint32_t idx) {
+    const PBACellIn r = pba_cell_pre_load(a, cell_thr, t, cb, U);
+    pba_cell_pre_finish(a, cpre, seed, cell_thr, rowi, t, idx, r);
 }
 
 // ------------------------------------------------------------------------------------------------ A role (the chain)
@@ -1050,6 +1065,12 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
                 pf0 = q[0];
                 pf1 = q[nu - 1];
             }
+        } else if (tid >= 100 && tid < 100 + B && t >= 1) {
+            // ... and with the lines of dHC(t-1) the loop top of the next step reads (cold HBM otherwise, and the row poll
+            // right behind them waits for every older load of its wave)
+            const float* q = a.dHC + ((size_t)(t - 1) * B + (tid - 100)) * (T2V_H + T2V_E) + T2V_H + c0;
+            pf0 = q[0];
+            pf1 = q[nc - 1];
         }
         // ---- P1b: the recurrent columns (d h_att partial for the cell) while the attention workgroups work on step t
         if (have) {
@@ -1077,9 +1098,10 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
         // while dq(t) is on its way, prepare the next step: the factors of the next gather (row t) into the operand slots
         // (the recurrent GEMV was their last reader), and the part of cell A(t-1) that does not depend on d h_att
         if (t > 0) {
+            const PBACellIn cin = pba_cell_pre_load(a, cell_thr, t - 1, cb, U);
             pb_park_factors<NB>(lds, a.FA + (size_t)t * (PB_ROW_BYTES(NB) / 4));
             PBA_STAMP(ja == 0, 12);
-            pba_cell_pre(a, cpre + ((t - 1) & 1) * 1024, seed, cell_thr, rowi, t - 1, cb, U, idx);
+            pba_cell_pre_finish(a, cpre + ((t - 1) & 1) * 1024, seed, cell_thr, rowi, t - 1, idx, cin);
             PBA_STAMP(ja == 0, 13);
         }
         // ---- P4: dq(t) of every item (sum of the position slices' partial rows)
