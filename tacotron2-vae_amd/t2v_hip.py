@@ -516,7 +516,7 @@ class DecoderCore(torch.autograd.Function):
     def use_persistent_bwd(lib, B, T_in, T):
         flag = DecoderCore.persistent_bwd
         if flag is None:
-            # measured (B = 6, T_in = 84, T = 400, round 3): 14.1 us per reverse step against 18.2 for the launch-per-step
+            # measured (B = 6, T_in = 84, T = 400, round 3): 12.9 us per reverse step against 18.2 for the launch-per-step
             # pass.  Follows T2V_TRAIN_PERSISTENT unless set itself (both kernels want the GPU to themselves)
             flag = os.environ.get('T2V_BWD_PERSISTENT', os.environ.get('T2V_TRAIN_PERSISTENT', '1')) != '0'
         if not (bool(flag) and bool(lib.t2v_decoder_bwd_persist_supported(int(B), int(T_in)))):
