@@ -780,6 +780,7 @@ class InferenceSession(object):
 
     def __init__(self, memory, pm, lengths, w_ih_att, w_hh_att, b_att, w_ih_dec, w_hh_dec, b_dec, wq, loc_conv,
                  loc_dense, v, prenet_w0, prenet_w1, proj_w, proj_b, gate_w, gate_b, max_steps):
+        limit_host_threads()
         lib = _require_gpu(memory, pm, w_ih_att)
         B, T_in, _ = memory.shape
         if B > 8:
@@ -858,6 +859,20 @@ class InferenceSession(object):
                                                       int(t1), float(gate_threshold), float(p_prenet),
                                                       int(bool(external_prenet)), int(seed), _stream()),
                't2v_decoder_infer_steps')
+
+
+def limit_host_threads(n=None):
+    """Cap torch's intra-op (OpenMP) host threads for the training process (default 4, env T2V_HOST_THREADS; 0 = leave).
+    Every step touches a few host tensors (the 768 KB mel of the collated batch is copied into the pinned staging buffer
+    with a parallel copy); on a 256-thread host torch starts 128 workers for that, and they spin after the region.  The GPU
+    boxes run containers with a CPU quota (cgroup cpu.max = 16 CPUs per 100 ms): the spinning workers exhaust it and the
+    WHOLE process — the thread that feeds the GPU included — is frozen for the rest of each period.  Measured: eager steps
+    13.7, 13.7, 71 ms, ... (every ~100 ms an ~60 ms freeze; 33–39 ms per step on average) against a steady 13.7 ms with 4
+    threads; the replayed-graph step 14.07 -> 13.43 ms.  Data-loader workers are separate processes and unaffected."""
+    if n is None:
+        n = int(os.environ.get('T2V_HOST_THREADS', '2' if int(os.environ.get('WORLD_SIZE', '1')) > 1 else '4'))
+    if n > 0 and torch.get_num_threads() > n:
+        torch.set_num_threads(n)
 
 
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2

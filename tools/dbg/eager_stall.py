@@ -1,0 +1,20 @@
+import os, sys, time, cProfile, pstats, io
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, 'tacotron2-vae_amd')); sys.path.insert(0, ROOT)
+import torch, bench, hparams as HP, train as TR
+hp = HP.create_hparams("batch_size=6,anneal_function=constant")
+eng = TR.TrainEngine(hp, world_size=1, graph=False)
+batch = tuple(t.pin_memory() for t in bench.synthetic_batch(6, bench.T_IN, bench.T_OUT, 1234))
+shown = 0
+with eng.stream_context():
+    for it in range(40):
+        pr = cProfile.Profile(); pr.enable()
+        t0 = time.perf_counter()
+        eng.step(batch, it)
+        dt = (time.perf_counter() - t0) * 1e3
+        pr.disable()
+        if it > 3 and dt > 40 and shown < 3:
+            shown += 1
+            s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(6)
+            print('step %d took %.1f ms on the host:' % (it, dt)); print('\n'.join(s.getvalue().split('\n')[6:16]))
+    torch.cuda.synchronize()

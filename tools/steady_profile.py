@@ -25,6 +25,7 @@ for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(sys.argv[3])
 # few dozen dispatches on this stack; they appear with eager launches and with graph replays alike and vanish without the
 # tracer: bench.py's wall clock per step is BELOW the GPU-busy time measured here).  They are reported separately.
 gaps = collections.defaultdict(lambda: [0, 0])
+big = collections.defaultdict(lambda: [0, 0])
 prev_end = None
 stall_ns, stall_n = 0, 0
 for s_, e_, n_ in sel:
@@ -33,6 +34,8 @@ for s_, e_, n_ in sel:
         if g >= 200000:
             stall_ns += g
             stall_n += 1
+            big[n_[:50]][0] += g
+            big[n_[:50]][1] += 1
         elif g > 3000:
             gaps[n_[:50]][0] += g
             gaps[n_[:50]][1] += 1
@@ -40,6 +43,8 @@ for s_, e_, n_ in sel:
 tot = sum(v[0] for v in gaps.values()) / nsteps / 1e6
 print("tracer stalls (gaps >= 200 us): %.1f per step, %.3f ms/step; wall without them %.3f ms/step" % (
     stall_n / nsteps, stall_ns / nsteps / 1e6, wall - stall_ns / nsteps / 1e6))
+for n_, (t_, c_) in sorted(big.items(), key=lambda kv: -kv[1][0])[:6]:
+    print("   gap >= 200 us before %-50s %5.1f /step %8.3f ms/step" % (n_, c_ / nsteps, t_ / nsteps / 1e6))
 print("idle gaps 3 us .. 200 us: %.3f ms/step; top followers:" % tot)
 for n_, (t_, c_) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:12]:
     print("   %-50s %7.1f gaps/st %8.3f ms/step  avg %7.1f us" % (n_, c_ / nsteps, t_ / nsteps / 1e6, t_ / c_ / 1e3))
