@@ -456,9 +456,8 @@ class Tacotron2(nn.Module):
         # of small latency-bound kernels (persistent BiLSTM on 16 workgroups, GRU, stride-2 convs): run the VAE
         # branch on a side stream so the two chains share the chip.  Autograd replays each node on its forward
         # stream, so the backward passes of the two branches overlap the same way.
-        # ... inside a captured graph only (the dependency becomes a graph edge).  As eager launches the two cross-stream
-        # waits of a step are resolved by the runtime, and on this stack that occasionally takes 50-90 ms with the GPU idle
-        # (tools/eager_profile.sh: gaps in front of the first kernel behind each wait): 39 ms per eager step against 15.
+        # ... inside a captured graph only (the dependency becomes a graph edge); as eager launches the two cross-stream
+        # waits of a step are resolved by the runtime's host threads, which buys nothing over one in-order stream there.
         side = self._side_stream(targets) if (self.overlap_branches and targets.is_cuda and torch.cuda.is_current_stream_capturing()) else None
         if side is not None:
             main = torch.cuda.current_stream()

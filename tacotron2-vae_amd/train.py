@@ -245,9 +245,9 @@ class TrainEngine(object):
                 out = self._graph_step(x, y, iteration)
                 if out is not None:
                     return out[0], out[1], out[2], w, out[3]
-        # Eager steps: keep the host at most two steps ahead of the GPU.  A caller that never reads a result back (the
-        # reference loop does, train.py:230 `loss.item()`) would otherwise fill the hardware queue, and launches into a
-        # full queue block in millisecond quanta on this stack: measured 39 ms per eager step against 15 (bench --no-graph).
+        # Eager steps: keep the host at most two steps ahead of the GPU (it issues a step in ~5.5 ms, the GPU needs 13.5): a
+        # caller that never reads a result back (the reference loop does, train.py:230 `loss.item()`) would otherwise run
+        # hundreds of steps ahead until the hardware queue is full.
         ring = self.__dict__.setdefault('_eager_events', [])
         if len(ring) >= 2:
             ring.pop(0).synchronize()
