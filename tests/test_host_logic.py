@@ -175,3 +175,32 @@ def test_ctypes_structs_match_header_in_package_and_integration_stub():
         got = [(n, t is C.c_void_p) for n, t in ns[cls_name]._fields_]
         assert got == hdr[sname], (cls_name, got, hdr[sname])
         assert C.sizeof(ns[cls_name]) == C.sizeof(getattr(t2v_hip, {v: k for k, v in pairs.items()}[sname]))
+
+
+def test_limit_host_threads_only_lowers_and_honours_the_env(monkeypatch):
+    """The training engine / inference session cap torch's intra-op threads (128 spinning OpenMP workers exhaust
+    the CPU quota of the GPU boxes' containers and freeze the process every 100 ms).  The cap only ever LOWERS the count,
+    T2V_HOST_THREADS overrides it, 0 leaves torch alone, a multi-rank job defaults to 2 per rank."""
+    import torch
+    import t2v_hip
+    old = torch.get_num_threads()
+    try:
+        torch.set_num_threads(6)
+        monkeypatch.delenv('T2V_HOST_THREADS', raising=False)
+        monkeypatch.setenv('WORLD_SIZE', '1')
+        t2v_hip.limit_host_threads()
+        assert torch.get_num_threads() == 4
+        t2v_hip.limit_host_threads(8)                 # never raises the count
+        assert torch.get_num_threads() == 4
+        monkeypatch.setenv('WORLD_SIZE', '8')
+        t2v_hip.limit_host_threads()
+        assert torch.get_num_threads() == 2
+        torch.set_num_threads(6)
+        monkeypatch.setenv('T2V_HOST_THREADS', '0')
+        t2v_hip.limit_host_threads()
+        assert torch.get_num_threads() == 6
+        monkeypatch.setenv('T2V_HOST_THREADS', '3')
+        t2v_hip.limit_host_threads()
+        assert torch.get_num_threads() == 3
+    finally:
+        torch.set_num_threads(old)
