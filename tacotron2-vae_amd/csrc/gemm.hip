@@ -167,7 +167,19 @@ __global__ __launch_bounds__(256) void k_gemm_f32_big(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) float Bs[2][GB_BK][BN + 32];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
-    const int i0 = blockIdx.y * GB_BM, j0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the tiles of ONE XCD
+    // are made a contiguous run of the row-major tile order — a band of M-tile rows whose A rows (and the B columns that
+    // sweep past them) are re-used inside that XCD's L2 instead of being fetched by all eight.  (Bijective for any tile
+    // count: the first nb % 8 XCDs take one tile more.)
+    int by_ = blockIdx.y, bx_ = blockIdx.x;
+    {
+        const int nb = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        by_ = lin / gridDim.x;
+        bx_ = lin - by_ * gridDim.x;
+    }
+    const int i0 = by_ * GB_BM, j0 = bx_ * BN;
     float4 ra[NA], rb[NB];
     // thread -> element of the operand tile: k-contiguous operand: (row = tid/KQ + (256/KQ) e, k4 = tid%KQ);
     //                                        row-contiguous operand: (k = tid/(rows/4) + .. e, row4 = tid%(rows/4))
