@@ -1123,9 +1123,14 @@ def gemm(A, B, bias=None, out=None, relu=False, accumulate=False, p_drop=0.0, se
     assert out.shape == (M, N) and out.dtype == torch.float32 and (N == 1 or out.stride(1) == 1)
     ldc = out.stride(0) if M > 1 else max(N, out.stride(0))
     assert ldc >= N and (ldc == N or p_drop == 0.0)
-    if not _BF16:
+    # skinny deep-K product (a handful of tiles, K = T*B): split K over workgroups, fixed-order partial sum.  Under bf16_run
+    # too: the bf16 64x64 kernel has no split-K, and on 8..48 workgroups with K = 6400 these products took 190-200 us each
+    # (B = 16 step trace) against 20-30 us on the fp32 split-K kernel — fp32 operands are no loss of accuracy.
+    if True:
         nscr = lib.t2v_gemm_splitk_scratch_floats(M, N, K)
-        if nscr:        # skinny deep-K product: split K over workgroups, fixed-order partial sum
+        if nscr and _BF16 and ((M + 63) // 64) * ((N + 63) // 64) >= 64:
+            nscr = 0        # enough tiles for the bf16 kernels (the LSTM weight gradients go to the 128x128 bf16 GEMM)
+        if nscr:
             scr = torch.empty(nscr, device=A.device, dtype=torch.float32)
             _check(lib.t2v_gemm_f32_splitk(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(bias), _p(out),
                                            ldc, M, N, K, int(relu), int(accumulate), float(p_drop), int(seed), int(rng_stream),

@@ -27,9 +27,17 @@ def test_gemm_bf16(bf16_mode, M, N, K, ta, tb):
     B = (torch.randn(K, N, generator=g).t() if tb else torch.randn(N, K, generator=g)).cuda()
     bias = torch.randn(N, generator=g).cuda()
     out = t2v_hip.gemm(A, B, bias)
-    # exact reference of the kernel's arithmetic: bf16-rounded operands, fp32 (here fp64) accumulation
-    ref = (A.bfloat16().double() @ B.bfloat16().double().t() + bias.double()).float()
-    assert (out - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+    lib = t2v_hip.load_library()
+    skinny = lib.t2v_gemm_splitk_scratch_floats(M, N, K) > 0 and ((M + 63) // 64) * ((N + 63) // 64) < 64
+    if skinny:
+        # a handful of tiles with a deep K: goes to the fp32 split-K kernel under bf16_run too (the bf16 64x64 kernel has no
+        # split-K: 190-200 us per product at K = 6400 against 20-30) — the result is the plain fp32 product
+        ref = (A.double() @ B.double().t() + bias.double()).float()
+        assert (out - ref).abs().max().item() < 2e-5 * K ** 0.5 * ref.abs().max().item()
+    else:
+        # exact reference of the kernel's arithmetic: bf16-rounded operands, fp32 (here fp64) accumulation
+        ref = (A.bfloat16().double() @ B.bfloat16().double().t() + bias.double()).float()
+        assert (out - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
     # and within bf16 rounding of the fp32 product
     full = A @ B.t() + bias
     assert (out - full).abs().max().item() < 2e-2 * full.abs().max().item()
