@@ -531,6 +531,9 @@ extern "C" int t2v_gemm_epilogue_bwd(const float* dy, const float* y, float* out
     return t2v_check_launch();
 }
 
+extern "C" int t2v_gemm_f32(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
+                            float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
+                            uint64_t seed, uint32_t rng_stream, uint32_t rng_t, void* stream_);
 extern "C" int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
                              float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
                              uint64_t seed, uint32_t rng_stream, uint32_t rng_t, void* stream_) {
@@ -546,6 +549,11 @@ extern "C" int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B,
         k_gemm_bf16_big_rr<<<gb, 256, 0, stream>>>(a);
         return t2v_check_launch();
     }
+    // large products in an operand form the 128x128 bf16 kernel does not take (the hoisted attention_rnn input term and the
+    // Prenet data gradient at B = 16: 13.4 GFLOP each): the 64x64 bf16 kernel ran them at ~35 TFLOP/s (361 / 399 us), the
+    // large-tile FP32 kernel does ~100 — bf16_run takes whichever is faster, fp32 operands lose no accuracy
+    if (gemm_big_ok(a))
+        return t2v_gemm_f32(A, sAi, sAk, B, sBj, sBk, bias, C, ldc, M, N, K, relu, accumulate, p_drop, seed, rng_stream, rng_t, stream_);
     dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM);
     const bool akc = sAk == 1, bkc = sBk == 1;
     if (akc && bkc) k_gemm_bf16<true, true><<<grid, 256, 0, stream>>>(a);
