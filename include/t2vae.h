@@ -27,6 +27,9 @@ const char* t2v_last_error(void);
 /* Tracing aid: device buffer of 32 uint64 that the attention kernels fill with s_memtime stamps at
  * their phase boundaries (forward slots 0..7, backward 16..23); NULL (default) disables it. */
 void t2v_set_phase_profile(unsigned long long* dev_buf32);
+/* Measurement aid: a one-thread launch on `stream` that writes the chip-wide 100 MHz wall clock into dev_buf[slot]
+ * (phase time line of an undisturbed graph replay: tools/stamps.py). */
+int t2v_stamp(unsigned long long* dev_buf, int slot, void* stream);
 
 /* Per-step parameters in DEVICE memory (optional).  Kernel arguments are frozen when a training step is captured
  * into a HIP graph; this 32-byte record is read by the kernels at run time instead, so every replay gets fresh
@@ -299,7 +302,11 @@ int t2v_decoder_infer_persistent(const t2v_dec_persist_weights* w, const t2v_dec
  *   t2v_bn_act_bwd : dy (grad wrt the conv output), dgamma, dbeta from dout.  dconv_bias ((M) or NULL) receives the
  *                    gradient of the bias of the convolution that feeds this training-mode BatchNorm, which is
  *                    identically zero (dy has zero mean per channel): written here so the caller launches no fill.
- *   t2v_conv1d_bwd : dX (may be NULL; needs Wt_scratch of W's size) and dW (may be NULL). */
+ *   t2v_conv1d_bwd : dX (may be NULL; needs Wt_scratch of W's size) and dW (may be NULL).  W == NULL with dX: Wt_scratch
+ *                    already holds the flipped, transposed weight (t2v_conv1d_flip_weights ran earlier in the step); W is not
+ *                    read when only dW is asked for.
+ *   t2v_conv1d_flip_weights : Wt[i] (Cin, Cout, KS) = W[i] (Cout, Cin, KS) transposed with the taps reversed — the operand
+ *                    of the data-gradient convolution — for n <= 16 layers in ONE launch (host arrays of n pointers / dims). */
 int t2v_conv1d_stat_blocks(int B, int T, int Cin, int Cout, int KS);
 int t2v_conv1d_fwd(const float* W, const float* X, const float* bias, float* Y, float* stat_part,
                    int B, int Cin, int T, int Cout, int KS, void* stream);
@@ -307,6 +314,8 @@ int t2v_conv1d_dw_scratch_floats(int B, int Cin, int T, int Cout, int KS);   /* 
 int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, float* dX, float* dW, float* Wt_scratch,
                    float* dw_scratch,
                    int B, int Cin, int T, int Cout, int KS, void* stream);
+int t2v_conv1d_flip_weights(const float* const* W, float* const* Wt, const int* Cout, const int* Cin, int KS, int n,
+                            void* stream);
 /* bf16_run variants (BASELINE configs[4]; replace the reference's fp16 path, fp16_optimizer.py / loss_scaler.py):
  * fp32 tensors in and out, operands rounded to bf16 on the way into LDS, fp32 accumulation on bf16 MFMA.
  * Wp_scratch: W's element count x 2 bytes.  Forward and data gradient only (dW is computed by the fp32 kernel);

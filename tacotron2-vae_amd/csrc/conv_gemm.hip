@@ -676,6 +676,38 @@ __global__ void k_conv_flip_weight(const float* __restrict__ W, float* __restric
     Wt[((size_t)c * M + m) * KS + (KS - 1 - k)] = W[i];
 }
 
+// Several layers' weights flipped by ONE launch (grid.y = layer): a training step issues it once, on a side stream
+// during the forward pass, instead of one flip launch in front of every data-gradient convolution.
+struct ConvFlipBatch { const float* W[16]; float* Wt[16]; int M[16]; int Cin[16]; int n; int KS; };
+__global__ void k_conv_flip_weight_batched(ConvFlipBatch f) {
+    const int l = blockIdx.y;
+    const int M = f.M[l], Cin = f.Cin[l], KS = f.KS;
+    const float* __restrict__ W = f.W[l];
+    float* __restrict__ Wt = f.Wt[l];
+    const int n = M * Cin * KS;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int k = i % KS, c = (i / KS) % Cin, m = i / (KS * Cin);
+        Wt[((size_t)c * M + m) * KS + (KS - 1 - k)] = W[i];
+    }
+}
+
+extern "C" int t2v_conv1d_flip_weights(const float* const* W, float* const* Wt, const int* Cout, const int* Cin, int KS,
+                                       int n, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!W || !Wt || !Cout || !Cin || n < 1 || n > 16 || KS < 1) return T2V_ERR_ARG;
+    ConvFlipBatch f;
+    f.n = n; f.KS = KS;
+    int mx = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!W[i] || !Wt[i] || Cout[i] < 1 || Cin[i] < 1) return T2V_ERR_ARG;
+        f.W[i] = W[i]; f.Wt[i] = Wt[i]; f.M[i] = Cout[i]; f.Cin[i] = Cin[i];
+        mx = max(mx, Cout[i] * Cin[i] * KS);
+    }
+    const int bx = min(1024, (mx + 1023) / 1024);
+    k_conv_flip_weight_batched<<<dim3(bx, n), 256, 0, stream>>>(f);
+    return t2v_check_launch();
+}
+
 extern "C" int t2v_conv1d_fwd(const float* W, const float* X, const float* bias, float* Y, float* stat_part,
                               int B, int Cin, int T, int Cout, int KS, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -708,11 +740,12 @@ extern "C" int t2v_conv1d_dw_scratch_floats(int B, int Cin, int T, int Cout, int
 extern "C" int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, float* dX, float* dW, float* Wt_scratch,
                               float* dw_scratch, int B, int Cin, int T, int Cout, int KS, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!W || !X || !dY || B < 1 || Cin < 1 || T < 1 || Cout < 1 || KS < 1 || !(KS & 1)) return T2V_ERR_ARG;
+    // W == NULL: Wt_scratch already holds the flipped, transposed weight (t2v_conv1d_flip_weights ran earlier in the step)
+    if (!X || !dY || B < 1 || Cin < 1 || T < 1 || Cout < 1 || KS < 1 || !(KS & 1)) return T2V_ERR_ARG;
     if (dX) {
         if (!Wt_scratch) return T2V_ERR_ARG;
         const int n = Cout * Cin * KS;
-        k_conv_flip_weight<<<(n + 255) / 256, 256, 0, stream>>>(W, Wt_scratch, Cout, Cin, KS);
+        if (W) k_conv_flip_weight<<<(n + 255) / 256, 256, 0, stream>>>(W, Wt_scratch, Cout, Cin, KS);
         if (conv5_tiled_ok(Cout, KS)) {
             launch_conv5_fwd(Wt_scratch, dY, nullptr, dX, nullptr, B, Cout, T, Cin, stream);
         } else {

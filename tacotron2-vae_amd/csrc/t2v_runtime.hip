@@ -29,7 +29,7 @@ extern "C" void t2v_set_phase_profile(unsigned long long* dev_buf32) { g_t2v_pro
 #include <mutex>
 static const t2v_step_params* g_t2v_step = nullptr;
 static std::mutex g_step_mu;
-static struct { hipStream_t s; const t2v_step_params* p; } g_step_tab[32];
+static struct { hipStream_t s; const t2v_step_params* p; } g_step_tab[256];
 static int g_step_n = 0;
 extern "C" void t2v_set_step_params(const t2v_step_params* dev) {
     std::lock_guard<std::mutex> lk(g_step_mu);
@@ -45,7 +45,7 @@ extern "C" int t2v_set_step_params_stream(void* stream, const t2v_step_params* d
             return T2V_OK;
         }
     if (!dev) return T2V_OK;
-    if (g_step_n >= 32) return T2V_ERR_ARG;
+    if (g_step_n >= 256) return T2V_ERR_ARG;
     g_step_tab[g_step_n].s = s;
     g_step_tab[g_step_n].p = dev;
     ++g_step_n;
@@ -86,4 +86,16 @@ void t2v_zero_regions(T2VZeroRegions& z, hipStream_t stream) {
     size_t bx = (mx + 4095) / 4096;
     if (bx > 1024) bx = 1024;
     k_zero_regions<<<dim3((unsigned)bx, (unsigned)n), 256, 0, stream>>>(z);
+}
+
+// Measurement aid: one thread writes the chip-wide 100 MHz wall clock into buf[slot].  A training engine drops these
+// into its streams at phase boundaries (T2V_STAMPS=1): unlike rocprofv3 — which makes every dispatch cost >= 4.7 us and
+// graph replays wait for their predecessor — the stamps show the time line of an undisturbed replay.
+__global__ void k_stamp(unsigned long long* buf, int slot) {
+    if (threadIdx.x == 0) buf[slot] = wall_clock64();
+}
+extern "C" int t2v_stamp(unsigned long long* dev_buf, int slot, void* stream) {
+    if (!dev_buf || slot < 0) return T2V_ERR_ARG;
+    k_stamp<<<1, 64, 0, (hipStream_t)stream>>>(dev_buf, slot);
+    return t2v_check_launch();
 }

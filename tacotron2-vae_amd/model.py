@@ -57,12 +57,16 @@ class Prenet(nn.Module):
         super().__init__()
         self.layers = nn.ModuleList([LinearNorm(i, o, bias=False) for i, o in zip([in_dim] + sizes[:-1], sizes)])
 
-    def forward(self, x):
+    def forward(self, x, rng_t=None):
         # dropout stays on at inference too (reference model.py:101 hard-codes training=True);
-        # Linear + ReLU + dropout is one MFMA GEMM with a fused epilogue
-        _block_calls[0] += 1
+        # Linear + ReLU + dropout is one MFMA GEMM with a fused epilogue.  rng_t: the mask index of this call (default: the
+        # running block counter); the teacher-forced pass hands in a fixed one so that its masks do not depend on where
+        # in the forward pass the Prenet is issued
+        if rng_t is None:
+            _block_calls[0] += 1
+            rng_t = _block_calls[0]
         for i, linear in enumerate(self.layers):
-            x = t2v_hip.LinearHIP.apply(x, linear.weight, None, True, drop_rate, _drop_seed[0], 48 + i, _block_calls[0])
+            x = t2v_hip.LinearHIP.apply(x, linear.weight, None, True, drop_rate, _drop_seed[0], 48 + i, rng_t)
         return x
 
 
@@ -269,14 +273,41 @@ class Decoder(nn.Module):
         gate = s.GATE[:n].transpose(0, 1).unsqueeze(-1).contiguous()   # (B,T,1)
         return mel, gate, s.AL[1:n + 1].transpose(0, 1)
 
+    def _tf_rng_t(self):
+        """mask index of the teacher-forced Prenet call: set per model forward by Tacotron2._forward (None = the running
+        block counter, for a Decoder that is driven directly)"""
+        return self.__dict__.pop('_tf_t', None)
+
+    def prepare(self, decoder_inputs):
+        """The part of the teacher-forced pass that depends on the target frames only (reference model.py:400-404: go
+        frame + Prenet) and the Prenet term of attention_rnn's gates for all steps.  Tacotron2._forward issues it on the
+        engine's deferred-work stream BEFORE the text encoder, so it runs next to the encoder instead of behind it;
+        forward() picks the result up.  Returns nothing; a forward() without a prepare() computes the same inline."""
+        frames = self.parse_decoder_inputs(decoder_inputs)                       # (T,B,80)
+        T = frames.size(0)
+        x = torch.cat((frames.new_zeros(1, frames.size(1), frames.size(2)), frames[:T - 1]), 0)     # go frame first
+        pre = self.prenet(x, self._tf_rng_t())            # (T,B,256)
+        att = self.attention_rnn
+        gpre = t2v_hip.gemm(pre.detach().reshape(-1, pre.shape[-1]), att.weight_ih.detach()[:, :self.prenet_dim],
+                            (att.bias_ih + att.bias_hh).detach())
+        self._prepared = (decoder_inputs, pre, gpre, torch.cuda.current_stream())
+
     def forward(self, memory, decoder_inputs, memory_lengths):
         """Teacher-forced pass (reference model.py:391-426).  Returns mel (B,80,T), gate (B,T),
         alignments (B,T,T_in)."""
         B, T_in = memory.size(0), memory.size(1)
-        frames = self.parse_decoder_inputs(decoder_inputs)                       # (T,B,80)
-        T = frames.size(0)
-        x = torch.cat((self.get_go_frame(memory).unsqueeze(0), frames), 0)       # go frame first
-        pre = self.prenet(x[:T])        # (T,B,256); the dropout mask is indexed per element, so dropping the unused last row first changes nothing
+        prep = self.__dict__.pop('_prepared', None)
+        gpre = None
+        if prep is not None and prep[0] is decoder_inputs:
+            _, pre, gpre, st = prep
+            T = pre.size(0)
+            if st != torch.cuda.current_stream():
+                torch.cuda.current_stream().wait_stream(st)
+        else:
+            frames = self.parse_decoder_inputs(decoder_inputs)                       # (T,B,80)
+            T = frames.size(0)
+            x = torch.cat((self.get_go_frame(memory).unsqueeze(0), frames), 0)       # go frame first
+            pre = self.prenet(x[:T], self._tf_rng_t())        # (T,B,256); the dropout mask is indexed per element, so dropping the unused last row first changes nothing
         att = self.attention_rnn
         lin = t2v_hip.LinearHIP.apply
         pm = lin(memory, self.attention_layer.memory_layer.weight, None, False, 0.0, 0, 0, 0)
@@ -288,9 +319,11 @@ class Decoder(nn.Module):
         seed = (int(self.dropout_seed) * 1000003 + self._calls) & 0x7FFFFFFFFFFFFFFF
         # the prenet term of attention_rnn's gates (pre · weight_ih[:, :256]^T + b_ih + b_hh for all steps) is computed
         # inside the node, so weight_ih has a single gradient producer
+        t2v_hip.stamp('dec_fwd_begin')
         hc, alignments = t2v_hip.DecoderCore.apply(None, memory, pm, lengths, *self._core_weights(),
                                                    p_att, p_dec, seed, torch.is_grad_enabled(),
-                                                   pre, att.bias_ih, att.bias_hh)
+                                                   pre, att.bias_ih, att.bias_hh, gpre)
+        t2v_hip.stamp('dec_fwd_end')
         # linear_projection and gate_layer as ONE 81-column MFMA tile (reference model.py:385-388)
         w81 = torch.cat((self.linear_projection.weight, self.gate_layer.weight), 0)
         b81 = torch.cat((self.linear_projection.bias, self.gate_layer.bias), 0)
@@ -414,15 +447,6 @@ class Tacotron2(nn.Module):
 
     overlap_branches = True     # class-level switch (tests flip it to compare against the single-stream schedule)
 
-    def _side_stream(self, ref):
-        if not ref.is_cuda:
-            return None
-        st = getattr(self, '_side', None)
-        if st is None or st.device != ref.device:
-            st = torch.cuda.Stream(device=ref.device)
-            object.__setattr__(self, '_side', st)
-        return st
-
     def parse_output(self, outputs, output_lengths=None):
         """In-place on .data exactly like reference model.py:509-520 (Appendix B-5: the Postnet's
         first conv therefore sees the zero-masked decoder mel in its weight gradient)."""
@@ -458,21 +482,40 @@ class Tacotron2(nn.Module):
         # stream, so the backward passes of the two branches overlap the same way.
         # ... inside a captured graph only (the dependency becomes a graph edge); as eager launches the two cross-stream
         # waits of a step are resolved by the runtime's host threads, which buys nothing over one in-order stream there.
-        side = self._side_stream(targets) if (self.overlap_branches and targets.is_cuda and torch.cuda.is_current_stream_capturing()) else None
-        if side is not None:
+        # Round 4: the schedule belongs to the training engine (t2v_hip.Overlap, explicit side streams; forks and joins
+        # become graph edges under capture).  Three chains start here and meet in front of the decoder: Prenet -> gpre
+        # (+ the flipped conv weights of this step's backward) on the deferred-work stream, the reference encoder on its
+        # own stream, embedding -> conv bank -> BiLSTM on the current one.  Without an engine everything runs inline.
+        ov = t2v_hip.overlap()
+        if ov is not None:
+            ov.on = bool(self.overlap_branches) and targets.is_cuda and os.environ.get('T2V_OVERLAP', '1') != '0'
+        self.decoder.__dict__['_tf_t'] = (1 << 20) + _block_calls[0]
+        fork = t2v_hip.mark()
+        enc_first = os.environ.get('T2V_FWD_ORDER', 'enc_first') == 'enc_first' and fork is not None
+        if enc_first:       # the host issues the longest chain first; the side chains still fork from `fork`
+            embedded = self.transcript_embedding(text).transpose(1, 2)
+            transcript = self.encoder(embedded, input_lengths)
+        with t2v_hip.side('vae', keep=(targets,), after=fork) as forked:
+            style, mu, logvar, z = self.vae_gst(targets)
+            t2v_hip.stamp('vae_fwd_end')
+        with t2v_hip.side('w', keep=(targets,), after=fork) as forked_w:
+            if forked_w:
+                if self.training and torch.is_grad_enabled():
+                    t2v_hip.preflip_conv_weights([blk[0].conv.weight for blk in self.encoder.convolutions]
+                                                 + [blk[0].conv.weight for blk in self.postnet.convolutions])
+                self.decoder.prepare(targets)
+                t2v_hip.stamp('prenet_gpre_end')
+        if not enc_first:
+            embedded = self.transcript_embedding(text).transpose(1, 2)
+            transcript = self.encoder(embedded, input_lengths)
+        t2v_hip.stamp('encoder_end')
+        if forked:
+            ov.wait('vae')
             main = torch.cuda.current_stream()
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                style, mu, logvar, z = self.vae_gst(targets)
-        embedded = self.transcript_embedding(text).transpose(1, 2)
-        transcript = self.encoder(embedded, input_lengths)
-        if side is not None:
-            main.wait_stream(side)
             for t in (style, mu, logvar, z):
                 t.record_stream(main)
-        else:
-            style, mu, logvar, z = self.vae_gst(targets)
         memory = transcript + style.unsqueeze(1)
         mel, gate, alignments = self.decoder(memory, targets, memory_lengths=input_lengths)
         mel_post = mel + self.postnet(mel)
+        t2v_hip.stamp('postnet_fwd_end')
         return self.parse_output([mel, mel_post, gate, alignments, mu, logvar, z, emotions], output_lengths)

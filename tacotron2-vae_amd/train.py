@@ -101,7 +101,7 @@ class TrainEngine(object):
                     else None)
             self.allreduce = t2v_dist.OverlappedArenaAllReduce(
                 named, offs, self.optimizer.grads, force=bool(force_dist),
-                side_streams=lambda: [st for st in (getattr(model, '_side', None),) if st is not None],
+                side_streams=lambda: self.overlap.streams(),
                 gather=self.optimizer.gather_grads, wire_dtype=wire)
         self.use_graph = bool(getattr(hparams, 'graph_step', False) if graph is None else graph)
         # multi-rank graph mode: forward + backward + gradient gather replay as ONE graph, then the whole gradient arena
@@ -119,6 +119,10 @@ class TrainEngine(object):
         # engine's own stream when it has one, so that two engines in one process never share a record
         self.step_params = t2v_hip.step_params(fresh=True, stream=self._stream)
         self.optimizer.step_params = self.step_params
+        # round 4: the side streams of this engine's step (reference-encoder branch; deferred work = every weight gradient,
+        # Prenet -> gpre).  Created before the first eager step; kernels launched there read the engine's step record too
+        self.overlap = t2v_hip.Overlap()
+        self.step_params.bind(extra=self.overlap.streams())
         # graph engine: the forward pass of a step runs on SHADOW leaves (p.detach().requires_grad_(): same storage, own
         # autograd identity) that only this engine ever touches.  An autograd leaf's gradient sink (AccumulateGrad node)
         # keeps the stream that was current when it was created, and the engine routes gradients to it on that stream
@@ -130,11 +134,20 @@ class TrainEngine(object):
             with torch.cuda.stream(self._stream):
                 self._shadow = {n: p.detach().requires_grad_(True) for n, p in self.model.named_parameters()}
             self._shadow_live = [self._shadow[n] for n, _ in self.optimizer.arena_layout()[0]]
-        if self.use_graph and not os.environ.get('T2V_GRAPH_BRANCHES'):
-            # one stream from the first eager step on: a branch stream used before the capture would leave its
-            # AccumulateGrad nodes behind and fork the captured graph
-            self.model.overlap_branches = False
         self.model.train()
+
+    def close(self):
+        """unbind this engine's device-side step record from its streams (torch's pooled stream handles are reused)"""
+        import t2v_hip
+        sp, self.step_params = self.step_params, None
+        if sp is not None:
+            t2v_hip.drop_step_params(sp)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def stream_context(self):
         """`with engine.stream_context():` around the training loop makes the engine's stream the current one, so a step
@@ -145,12 +158,18 @@ class TrainEngine(object):
 
     # -- forward + backward + gradient gather (no collective, no optimiser): what a multi-rank engine captures
     def _body_fb(self, x, y, iteration):
+        import t2v_hip
         opt = self.optimizer
         opt.zero_grad()
+        t2v_hip.stamp('step_begin')
         y_pred = self._forward(x)
         loss, recon, kl, w = self.criterion(y_pred, y, iteration)
+        t2v_hip.stamp('loss_end')
         self._backward(loss)
+        t2v_hip.stamp('bwd_main_end')
+        self.overlap.join()         # weight gradients were produced on the deferred-work stream
         opt.gather_grads()
+        t2v_hip.stamp('grads_ready')
         return loss.detach(), recon.detach(), kl.detach()
 
     def _forward(self, x):
@@ -188,19 +207,26 @@ class TrainEngine(object):
             # rank sees different shapes), so the collective pattern must not depend on that choice — the bucketed
             # hook-issued exchange below belongs to the eager engine only
             return self._reduce_and_step(self._body_fb(x, y, iteration))
+        import t2v_hip
         opt = self.optimizer
         opt.zero_grad()
+        t2v_hip.stamp('step_begin')
         y_pred = self.model(x) if self.allreduce is not None else self._forward(x)
         loss, recon, kl, w = self.criterion(y_pred, y, iteration)
+        t2v_hip.stamp('loss_end')
         if self.allreduce is not None:
             self.allreduce.begin()
             loss.backward()         # (a multi-rank engine that reaches this line is the eager one: hook-issued buckets)
         else:
             self._backward(loss)
+        t2v_hip.stamp('bwd_main_end')
+        self.overlap.join()             # weight gradients were produced on the deferred-work stream
+        t2v_hip.stamp('grads_ready')
         if self.allreduce is not None:
             self.allreduce.finish()
             opt.mark_gathered()        # every bucket gathered its slice before it went out
         grad_norm = opt.step()
+        t2v_hip.stamp('step_end')
         return loss.detach(), recon.detach(), kl.detach(), grad_norm
 
     def _publish(self, iteration):
@@ -225,6 +251,14 @@ class TrainEngine(object):
                 out = self.step(batch, iteration, learning_rate)
             cur.wait_stream(self._stream)
             return out
+        import t2v_hip
+        prev = t2v_hip.set_overlap(self.overlap)
+        try:
+            return self._step(batch, iteration, learning_rate)
+        finally:
+            t2v_hip.set_overlap(prev)
+
+    def _step(self, batch, iteration, learning_rate):
         opt = self.optimizer
         if learning_rate is not None:
             opt.param_groups[0]['lr'] = learning_rate

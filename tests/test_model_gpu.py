@@ -157,9 +157,13 @@ def test_fused_adam_matches_oracle_formula():
     assert (dm.cpu() - m_ref).abs().max() < 1e-7 and (dv.cpu() - v_ref).abs().max() < 1e-9
 
 
-def test_branch_overlap_is_bit_identical_to_single_stream(golden_dir):
-    """encoder ‖ reference-encoder on two streams (model.py forward) vs the single-stream schedule: same bits in
-    the outputs and in every gradient (also a race detector for the cross-stream hand-offs)."""
+@pytest.mark.parametrize('graph', [True, False], ids=['graph_engine', 'eager_engine'])
+def test_branch_overlap_is_bit_identical_to_single_stream(golden_dir, graph):
+    """The engine's multi-stream schedule (t2v_hip.Overlap: encoder ‖ reference encoder ‖ Prenet -> gpre in the forward,
+    every weight gradient on the deferred-work streams in the backward) vs the single-stream schedule: same bits in
+    the outputs and in every gradient, in the graph engine (shadow leaves + autograd.grad) and in the eager engine
+    (loss.backward(): AccumulateGrad must adopt the deferred gradients without touching them) — also a race detector
+    for the cross-stream hand-offs."""
     import hparams as HP
     import model as M
     import train as TR
@@ -172,7 +176,7 @@ def test_branch_overlap_is_bit_identical_to_single_stream(golden_dir):
             M.Tacotron2.overlap_branches = mode
             hp = HP.create_hparams("anneal_function=constant,p_attention_dropout=0.0,p_decoder_dropout=0.0")
             torch.manual_seed(hp.seed)
-            eng = TR.TrainEngine(hp)
+            eng = TR.TrainEngine(hp, graph=graph)
             eng.model.vae_gst.eps_override = torch.from_numpy(g['eps']).cuda()
             batch = (torch.from_numpy(g['text']), torch.from_numpy(g['input_lengths']), torch.from_numpy(g['mel']),
                      torch.from_numpy(g['gate']), torch.from_numpy(g['output_lengths']),
