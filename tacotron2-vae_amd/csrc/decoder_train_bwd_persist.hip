@@ -189,6 +189,37 @@ __global__ __launch_bounds__(256) void k_pb_factors(const float* __restrict__ G,
     if (nb > 4) *(pb_f32x2*)(row + 4 * T2V_G + 2 * (size_t)k) = pb_f32x2{f[4], f[5]};
 }
 
+// CP[t][U][item (nb slots)][8] of one cell: everything the cell backward of (unit U, item) needs at step t that is a function
+// of the forward activations alone — {fh, fc, go (1 - tanh(c)^2), gf,  gg gi (1 - gi), c' gf (1 - gf), gi (1 - gg^2),
+// tanh(c) go (1 - go)} (fh / fc: state-dropout scales of step t, c': the cell handed to step t, dropout applied).  Round 4:
+// the attention_rnn workgroups used to compute these in the loop — three counter-based RNG draws and a tanh per
+// (unit, item) and step, 1.5 us of every 12.9 us reverse step on the chain; now they copy 32 bytes.
+__global__ __launch_bounds__(256) void k_pb_cellpre(const float* __restrict__ G, const float* __restrict__ C, float* __restrict__ CP,
+                                                    int B, int T, int nb, float p, int stream_h, int stream_c, uint64_t seed0,
+                                                    const t2v_step_params* step) {
+    const uint64_t seed = t2v_step_seed(seed0, step);
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)T * T2V_H * nb) return;
+    const int b = (int)(i % nb), U = (int)((i / nb) % T2V_H), t = (int)(i / ((size_t)nb * T2V_H));
+    float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+    if (b < B) {
+        const float* gp = G + ((size_t)t * B + b) * T2V_G + U;
+        const float gi = gp[0], gf = gp[T2V_H], gg = gp[2 * T2V_H], go = gp[3 * T2V_H];
+        const float cc = C[((size_t)(t + 1) * B + b) * T2V_H + U];
+        float cprev = C[((size_t)t * B + b) * T2V_H + U];
+        const uint32_t idx = (uint32_t)b * T2V_H + U;
+        const float fh = t2v_drop_scale(seed, stream_h, t, idx, p);
+        const float fc = t2v_drop_scale(seed, stream_c, t, idx, p);
+        if (t > 0) cprev *= t2v_drop_scale(seed, stream_c, t - 1, idx, p);
+        const float tc = tanhf_(cc);
+        c0 = make_float4(fh, fc, go * (1.0f - tc * tc), gf);
+        c1 = make_float4(gg * gi * (1.0f - gi), cprev * gf * (1.0f - gf), gi * (1.0f - gg * gg), tc * go * (1.0f - go));
+    }
+    float4* o = (float4*)(CP + i * 8);
+    o[0] = c0;
+    o[1] = c1;
+}
+
 // acc[c][pair] += w[c][j] * x[k_j][pair] for NC output columns: packed FMAs (two items per op, weight broadcast through
 // op_sel; even j = low word of the weight pair, odd j = high word) in volatile asm so the k loop keeps its shape.
 template <bool ODD>
@@ -262,6 +293,44 @@ __device__ __forceinline__ float pb_sum32(const float* part, int idx) {
     float s[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = (part[(4 * i) * 32 + idx] + part[(4 * i + 1) * 32 + idx]) + (part[(4 * i + 2) * 32 + idx] + part[(4 * i + 3) * 32 + idx]);
+    return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
+// Round 4, attention_rnn role: the same reduction over 16 values (2 columns x 8 item slots) at a time.  Twice the rounds of
+// pb_reduce32 for the same number of DPP operations, but the GEMV's working set next to the weight registers halves
+// (12 accumulator registers + 16 values instead of 24 + 32) — with 32-value rounds the role spilled loop-invariant offsets
+// and every reload sat behind an s_waitcnt vmcnt(0) on the chain.  The first two levels write complementary register banks
+// with bank-masked DPP adds (2 operations per output instead of select + select + add).  part[(wave * 4 + row) * 16 + idx].
+__device__ __forceinline__ float pb_dpp_pair_add(float lo, float hi, const int level) {
+    float t;
+    if (level == 0)
+        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_f32_dpp %0, %2, %2 row_mirror row_mask:0xf bank_mask:0xc" : "=&v"(t) : "v"(lo), "v"(hi));
+    else
+        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa" : "=&v"(t) : "v"(lo), "v"(hi));
+    return t;
+}
+__device__ __forceinline__ void pb_reduce16(float (&v)[16], float* part) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool b1 = lane & 2, b0 = lane & 1;
+    float w8[8], w4[4], w2[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w8[i] = pb_dpp_pair_add(v[i], v[8 + i], 0);          // lanes 0..7 of a row: values i, lanes 8..15: 8 + i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w4[i] = pb_dpp_pair_add(w8[i], w8[4 + i], 1);        // bit 2 of the lane picks the half
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = b1 ? w4[2 + i] : w4[i], send = b1 ? w4[i] : w4[2 + i];
+        w2[i] = keep + PB_DPP(send, 0x4E);
+    }
+    const float keep = b0 ? w2[1] : w2[0], send = b0 ? w2[0] : w2[1];
+    part[((tid >> 6) * 4 + (lane >> 4)) * 16 + (lane & 15)] = keep + PB_DPP(send, 0xB1);
+}
+__device__ __forceinline__ float pb_sum16(const float* part, int idx) {
+    float s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = (part[(4 * i) * 16 + idx] + part[(4 * i + 1) * 16 + idx]) + (part[(4 * i + 2) * 16 + idx] + part[(4 * i + 3) * 16 + idx]);
     return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
@@ -454,6 +523,8 @@ struct PBAArgs {
     float* DGA; float* DGD; float* DCTX; float* DV;       // DV (B,S,128)
     // exchange (sentinel-filled): gate-gradient rows of both cells, context gradients, dq partials, window partials
     float* GXA; float* GXD; float* CX; float* DQX; float* GPX; float* EX;
+    float* DQT;                 // (T,B,128) dq(t) summed over the position slices (published by slice 0 of each item)
+    const float* CPA;           // (T,1024,NB,8) cell-layout factors of attention_rnn (k_pb_cellpre)
     const float* FA; const float* FD;    // gate-gradient factors of both cells (k_pb_factors)      // EX (T,B,1536): E(t) = Wcat_dec[:, :1536]^T dgd(t)
     unsigned* err;
     int B, T_in, T, S_sl;
@@ -471,9 +542,14 @@ struct PBAArgs {
     if (threadIdx.x < 16) lprof_[threadIdx.x] = 0ull
 #define PBA_PROF_FLUSH(COND, I0, N) do { if (a.prof && (COND) && threadIdx.x < (N)) a.prof[(I0) + threadIdx.x] = lprof_[(I0) + threadIdx.x]; } while (0)
 
-// context-gradient row of a step in CX: [plane][512 columns][4 items] (16 bytes per column and plane)
-#define PB_CX_ROW_BYTES(NB) ((NB) > 4 ? 16384u : 8192u)
+// context-gradient row of a step in CX: [item (4 or 8 slots)][512 columns] — item-major (round 4): an attention_rnn workgroup
+// publishes its <= 7 columns of an item as ONE 16-byte store (+ <= 3 words) instead of 4-byte stores 16 bytes apart, and an
+// attention workgroup polls its item's 2 KB with 128 sixteen-byte loads instead of 512 four-byte loads spread over 8 KB
+// (second form, round 4: [item][attention_rnn workgroup (128 slots)][8 floats] — every producer owns an aligned 32-byte slot,
+// no cache line sector is ever written by two workgroups)
+#define PB_CX_ROW_BYTES(NB) ((NB) > 4 ? 32768u : 16384u)
 
+__host__ __device__ static inline int pba_na(int NL);
 template <int JS>
 __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds, const int b, const int s, const int NB) {
     constexpr int NJT = JS / 16;
@@ -484,6 +560,7 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
     const int B = a.B, Tp = a.T_in, T = a.T, S = a.S_sl, j0 = s * JS;
     const int Tcap = (Tp + 15) & ~15;
     const int nown = min(JS, Tp - j0);
+    const int NAw = pba_na(T2V_NWG - B * S);          // attention_rnn workgroups: producers of the context gradient
     // ---- LDS carve
     float* gfull0 = lds;                      // [Tcap]
     float* gfull1 = gfull0 + Tcap;            // [Tcap]
@@ -497,8 +574,7 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
     float* rq = Tl + 64 * (JS + 1);           // [8][128]
     float* rv = rq + 8 * T2V_A;               // [8][128]
     int* flag = (int*)(rv + 8 * T2V_A);
-    const __amdgpu_buffer_rsrc_t rC = pb_rsrc(a.CX), rQ = pb_rsrc(a.DQX), rP = pb_rsrc(a.GPX);
-    const int mypl = b >> 2, myw = b & 3;
+    const __amdgpu_buffer_rsrc_t rC = pb_rsrc(a.CX), rQ = pb_rsrc(a.DQX), rP = pb_rsrc(a.GPX), rQT = pb_rsrc(a.DQT);
     // ---- operands resident for the whole pass
     const int d4 = tid & 31, rg = (tid >> 5) & 7;
     float4 m0[JS / 4], m1[JS / 4];
@@ -575,24 +651,35 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
             alf[j] = al;
             dot_g = fmaf(al, gp + gc, dot_g);
         }
-        // ---- the context gradient of this item (one 4-byte word per thread), nap first
-        {
-            const unsigned off = (unsigned)t * PB_CX_ROW_BYTES(NB) + (unsigned)(mypl * T2V_E + tid) * 16u + 4u * (unsigned)myw;
+        // ---- the context gradient of this item (16 bytes per thread of waves 0 and 1), nap first
+        if (tid < 2 * NAw) {
+            const unsigned off = (unsigned)t * PB_CX_ROW_BYTES(NB) + (unsigned)b * 4096u + 16u * (unsigned)tid;
             for (int i = 0; i < nap; i += 8) __builtin_amdgcn_s_sleep(8);
-            unsigned x;
+            // TWO polls in flight, half a round trip apart (round 4): with one, a row that lands just after a poll left is
+            // only seen a full memory round trip later — this hand-off is on the chain of every reverse step
+            f32x4 x, x0 = pb_ld16(rC, off);
+            __builtin_amdgcn_s_sleep(4);
+            f32x4 x1 = pb_ld16(rC, off);
             int rounds = 0;
             for (;;) {
-                x = pb_ld4(rC, off);
-                if (__all(x != PB_SENT)) break;
-                __builtin_amdgcn_s_sleep(1);
+                if (__all(pb_ok(x0[0]) && pb_ok(x0[1]) && pb_ok(x0[2]) && pb_ok(x0[3]))) { x = x0; break; }
+                x0 = pb_ld16(rC, off);
+                if (__all(pb_ok(x1[0]) && pb_ok(x1[1]) && pb_ok(x1[2]) && pb_ok(x1[3]))) { x = x1; break; }
+                x1 = pb_ld16(rC, off);
                 if (++rounds > PB_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     flag[0] = 0;
+                    x = x0;
                     break;
                 }
             }
             nap = t2v_adapt_nap(nap, rounds);
-            dctx[tid] = __uint_as_float(x);
+            // slot (workgroup ja, half h) holds columns c0(ja) + 4 h .. of this item
+            const int ja = tid >> 1, h4 = 4 * (tid & 1);
+            const int cc0 = (ja * T2V_E) / NAw, ncc = ((ja + 1) * T2V_E) / NAw - cc0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (h4 + i < ncc) dctx[cc0 + h4 + i] = x[i];
         }
         __syncthreads();
         if (flag[0] != 1) return;
@@ -631,7 +718,6 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
         __syncthreads();
         // ---- through v·tanh(.): dpre, partial dq / dv
         if (act) {
-            float* sp = a.S + (((size_t)t * B + b) * Tp + j0) * T2V_A + 4 * d4;
             float4 dq = make_float4(0.f, 0.f, 0.f, 0.f), dv = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int i = 0; i < JS / 8; ++i) {
@@ -641,7 +727,7 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
                 float4 dp;
                 dp.x = dej * vd4.x * (1.0f - sv.x * sv.x); dp.y = dej * vd4.y * (1.0f - sv.y * sv.y);
                 dp.z = dej * vd4.z * (1.0f - sv.z * sv.z); dp.w = dej * vd4.w * (1.0f - sv.w * sv.w);
-                if (jl < nown) *(float4*)(sp + (size_t)jl * T2V_A) = dp;
+                sreg[i] = dp;           // the saved copy (operand of the d W_comb / d memory_layer products) leaves AFTER the hand-off
                 dq.x += dp.x; dq.y += dp.y; dq.z += dp.z; dq.w += dp.w;
                 dv.x = fmaf(dej, sv.x, dv.x); dv.y = fmaf(dej, sv.y, dv.y); dv.z = fmaf(dej, sv.z, dv.z); dv.w = fmaf(dej, sv.w, dv.w);
                 dpT[(4 * d4 + 0) * (JS + 1) + jl] = dp.x; dpT[(4 * d4 + 1) * (JS + 1) + jl] = dp.y;
@@ -659,11 +745,49 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
                 const float* p2 = rv + tid;
                 vv = ((p2[0] + p2[T2V_A]) + (p2[2 * T2V_A] + p2[3 * T2V_A])) + ((p2[4 * T2V_A] + p2[5 * T2V_A]) + (p2[6 * T2V_A] + p2[7 * T2V_A]));
             }
-            pb_st4(rQ, (unsigned)(((t * B + b) * S + s) * T2V_A + tid) * 4u, q);       // the cell workgroups wait for this
+            pb_st4(rQ, (unsigned)(((t * B + b) * S + s) * T2V_A + tid) * 4u, q);       // partial row (the d W_q GEMM reads them later)
             dvacc += vv;
+            if (s == 0) {
+                // Round 4: slice 0 of an item sums the S partial rows in slice order and publishes ONE row per item.  The ≥ 79
+                // attention_rnn workgroups used to pull all B*S partial rows each (18 KB per workgroup and step through the
+                // ≈ 11 B/cycle a CU gets from beyond its L2: 2.7 us from "published" to "gathered"); now they pull B rows (3 KB)
+                // (all partial rows are requested in ONE round: a round trip per slice would cost 0.45 us each)
+                constexpr int SMAX = PB_MAXT / 16;              // 14 slices at most
+                const unsigned off0 = (unsigned)(((t * B + b) * S) * T2V_A + tid) * 4u;
+                unsigned x[SMAX];
+                int spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int s2 = 1; s2 < SMAX; ++s2) {
+                        x[s2] = pb_ld4(rQ, off0 + (unsigned)(min(s2, S - 1) * T2V_A) * 4u);
+                    }
+#pragma unroll
+                    for (int s2 = 1; s2 < SMAX; ++s2) ok = ok && (s2 >= S || x[s2] != PB_SENT);
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > PB_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        flag[0] = 0;
+                        break;
+                    }
+                }
+                float tot = q;
+#pragma unroll
+                for (int s2 = 1; s2 < SMAX; ++s2) tot += s2 < S ? __uint_as_float(x[s2]) : 0.f;
+                pb_st4(rQT, (unsigned)((t * B + b) * T2V_A + tid) * 4u, tot);           // the cell workgroups wait for this
+            }
         }
         PBA_STAMP(blockIdx.x == 0, 10);
         PBA_RT(1);
+        if (act) {      // dpre rows: 8 KB of stores that must not sit in this CU's memory pipe in front of the dq words above
+            float* sp = a.S + (((size_t)t * B + b) * Tp + j0) * T2V_A + 4 * d4;
+#pragma unroll
+            for (int i = 0; i < JS / 8; ++i) {
+                const int jl = rg + 8 * i;
+                if (jl < nown) *(float4*)(sp + (size_t)jl * T2V_A) = sreg[i];
+            }
+        }
         // ---- through the fused location filter on MFMA: T[(c,k)][jl] = sum_d W_comb[d][(c,k)] dpre[jl][d], K = 128
         if (act) {
 #pragma unroll
@@ -744,6 +868,57 @@ __device__ __forceinline__ void pb_gemv_cols(const pb_f32x2 (&w)[NCT][PB_KJ / 2]
         for (int i = 0; i < 3; ++i) { v[c * VS + 2 * i] = acc[c][i][0]; v[c * VS + 2 * i + 1] = acc[c][i][1]; }
 }
 
+// the same for <= 2 columns into v[16] (two columns x 8 item slots): the operand rows are re-read per round
+template <int NCT, int C0, int NC, int NB>
+__device__ __forceinline__ void pb_gemv_cols16(const pb_f32x2 (&w)[NCT][PB_KJ / 2], const f32x4* X0, const pb_f32x2* X1, float (&v)[16]) {
+    static_assert(NC >= 1 && NC <= 2, "one or two columns");
+    const int tid = threadIdx.x;
+    pb_f32x2 acc[NC][3];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c][0] = acc[c][1] = acc[c][2] = pb_f32x2{0.f, 0.f};
+    constexpr int PF = 4;
+    f32x4 xa[PF];
+    pb_f32x2 xb[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        xa[d] = X0[tid + PB_THREADS * d];
+        xb[d] = pb_f32x2{0.f, 0.f};
+        if (NB > 4) xb[d] = X1[tid + PB_THREADS * d];
+    }
+#pragma unroll
+    for (int j = 0; j < PB_KJ; ++j) {
+        const f32x4 xc = xa[j % PF];
+        const pb_f32x2 yc = xb[j % PF];
+        const pb_f32x2 x01 = {xc[0], xc[1]}, x23 = {xc[2], xc[3]};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (j & 1) pb_pk3<true>(acc[c][0], acc[c][1], acc[c][2], w[C0 + c][j / 2], x01, x23, yc);
+            else pb_pk3<false>(acc[c][0], acc[c][1], acc[c][2], w[C0 + c][j / 2], x01, x23, yc);
+        }
+        if (j + PF < PB_KJ) {
+            xa[j % PF] = X0[tid + PB_THREADS * (j + PF)];
+            if (NB > 4) xb[j % PF] = X1[tid + PB_THREADS * (j + PF)];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { v[c * 8 + 2 * i] = acc[c][i][0]; v[c * 8 + 2 * i + 1] = acc[c][i][1]; }
+}
+
+// columns [C0, C0 + N) two at a time: round r leaves its 32 row partials x 16 values at part + 512 r
+template <int NCT, int C0, int N, int NB, int R = 0>
+__device__ __forceinline__ void pba_rounds16(const pb_f32x2 (&w)[NCT][PB_KJ / 2], const f32x4* X0, const pb_f32x2* X1, float* part) {
+    if constexpr (2 * R < N) {
+        float v[16];
+        pb_gemv_cols16<NCT, C0 + 2 * R, (N - 2 * R >= 2 ? 2 : 1), NB>(w, X0, X1, v);
+        pb_reduce16(v, part + 512 * R);
+        pba_rounds16<NCT, C0, N, NB, R + 1>(w, X0, X1, part);
+    }
+}
+
 // ---- role split of the LSTM workgroups (NL = 256 - B*S of them).  One workgroup set per cell halves the gate-gradient
 // all-gather (a row of 4096 x B values goes to the workgroups of ITS cell only) and decouples the two chains:
 //   A role, NA = 3/8 of NL workgroups: attention_rnn.  Workgroup ja owns hidden units [ja*1024/NA, ..) (<= 14) and context
@@ -758,7 +933,15 @@ __device__ __forceinline__ void pb_gemv_cols(const pb_f32x2 (&w)[NCT][PB_KJ / 2]
 #define PBA_NUD 8
 #define PBA_NCD 4
 // (>= 79 workgroups: at most 13 units and 7 context columns each — 20 columns = 160 weight registers per thread)
-__host__ __device__ static inline int pba_na(int NL) { const int n = (3 * NL + 4) / 8; return n < 79 ? 79 : n; }
+// Round 4: the decoder_rnn role needs 128 workgroups to stay at 8 units + 4 context columns (20 columns) each; every other
+// LSTM workgroup goes to the attention_rnn role, the per-step chain.  From 86 workgroups on it holds <= 12 units + 6 context
+// columns (18 columns = 144 weight registers: the slim instantiation — one reduction round less per step and 16 registers
+// fewer next to the GEMV's working set); below that the 13 + 7 form.
+__host__ __device__ static inline int pba_na(int NL) {
+    if (NL - 128 >= 86) return NL - 128;
+    const int n = (3 * NL + 4) / 8;
+    return n < 79 ? 79 : n;
+}
 
 // final sums of a column-grouped GEMV: NCOL columns x 8 item slots -> ysum[col * 8 + b]
 __device__ __forceinline__ void pba_finish_sums(const float* part, float* ysum, int ncol) {
@@ -934,8 +1117,19 @@ __device__ __forceinline__ void pba_cell_pre(const PBAArgs& a, float* cpre, uint
 }
 
 // ------------------------------------------------------------------------------------------------ A role (the chain)
-template <int NB>
+// a 4-byte word per lane global -> LDS (lane i lands at ldsbase + 4 i) without a destination register; aux: cache policy
+__device__ __forceinline__ void pb_dma4(const void* g, float* ldsbase, const int aux_sc1) {
+    if (aux_sc1)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)ldsbase, 4, 0, PB_SC1);
+    else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)ldsbase, 4, 0, 0);
+}
+
+template <int NB, int NUA, int NCA>
 __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* lds, const int ja, const int NA) {
+    constexpr int NCT = NUA + NCA;
+    static_assert(NCA > 4 && NCA <= 8 && NUA > 8 && NUA <= 16, "two context rounds, three or four recurrent rounds");
+    constexpr int NCR = (NCA + 1) / 2;                        // reduction rounds (2 columns each) of the context columns
     const uint64_t seed = t2v_step_seed(a.seed, a.step);
     const int tid = threadIdx.x;
     const int B = a.B, T = a.T, S = a.S_sl;
@@ -949,24 +1143,26 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
     float* dqs = wqs + 16 * T2V_A;                         // [8][128] dq(t) per item
     float* cpre = dqs + 8 * T2V_A;                         // [2][128 rows][8] activation-only factors of cell steps t, t-1
     float* eps = cpre + 2048;                              // [256] E(t) words / dHC words of the P2 threads (thread-private)
-    int* flag = (int*)(eps + 256);
+    int* flag = (int*)(eps + 256);                         // [4] + the phase profile (16 x 8 bytes)
+    float* dump = eps + 256 + 64;                          // [8 waves][64] landing zone of the prefetch DMAs (never read)
     const int u0 = (ja * T2V_H) / NA, nu = ((ja + 1) * T2V_H) / NA - u0;      // <= 14 units
     const int c0 = (ja * T2V_E) / NA, nc = ((ja + 1) * T2V_E) / NA - c0;      // <= 7 context columns
-    const __amdgpu_buffer_rsrc_t rA = pb_rsrc(a.GXA), rC = pb_rsrc(a.CX), rQ = pb_rsrc(a.DQX), rE = pb_rsrc(a.EX);
-    // columns: [0, 14) W_hh_att[k][U], [14, 21) W_ih_att[k][256 + C]
-    pb_f32x2 w[20][PB_KJ / 2];
+    const __amdgpu_buffer_rsrc_t rA = pb_rsrc(a.GXA), rC = pb_rsrc(a.CX), rQT = pb_rsrc(a.DQT), rE = pb_rsrc(a.EX);
+    const __amdgpu_buffer_rsrc_t rDC = pb_rsrc(a.DCTX), rDG = pb_rsrc(a.DGA);
+    // columns: [0, NUA) W_hh_att[k][U], [NUA, NUA + NCA) W_ih_att[k][256 + C]
+    pb_f32x2 w[NCT][PB_KJ / 2];
 #pragma unroll
     for (int jj = 0; jj < PB_KJ; ++jj) {
         const size_t k = (size_t)(tid + PB_THREADS * jj);
 #pragma unroll
-        for (int u = 0; u < PBA_NUA; ++u) {
+        for (int u = 0; u < NUA; ++u) {
             const bool on = u < nu;
             w[u][jj / 2][jj & 1] = on ? a.w_hh_att[k * T2V_H + u0 + (on ? u : 0)] : 0.f;
         }
 #pragma unroll
-        for (int c = 0; c < PBA_NCA; ++c) {
+        for (int c = 0; c < NCA; ++c) {
             const bool on = c < nc;
-            w[PBA_NUA + c][jj / 2][jj & 1] = on ? a.w_ih_att[k * (T2V_PRE + T2V_E) + T2V_PRE + c0 + (on ? c : 0)] : 0.f;
+            w[NUA + c][jj / 2][jj & 1] = on ? a.w_ih_att[k * (T2V_PRE + T2V_E) + T2V_PRE + c0 + (on ? c : 0)] : 0.f;
         }
     }
     for (int i = tid; i < 16 * T2V_A; i += PB_THREADS) {
@@ -975,38 +1171,51 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
     }
     for (int i = tid; i < 192; i += PB_THREADS) ysum[i] = 0.f;
     if (tid == 0) flag[0] = 1;
-    // cell rows: row = tid >> 2 = u * NB + b (4 lanes per row, 32 attention dims each); lane 0 of a row owns (unit u, item b)
-    const int rowi = tid >> 2, cu = rowi / NB, cb = rowi - cu * NB;
-    const bool row_on = cu < nu;
-    const bool cell_thr = (tid & 3) == 0 && cu < nu && cb < B;
-    const int U = u0 + (cu < nu ? cu : 0);
-    const uint32_t idx = (uint32_t)cb * T2V_H + U;
-    float dca = 0.f, pfsink = 0.f;
+    float dca = 0.f;
     int napA = 0, napQ = 0;
     PBA_PROF_INIT(flag);
     if (a.prof && ja == 0 && tid == 0) a.prof[42] = __builtin_amdgcn_s_memrealtime();
-    pba_cell_pre(a, cpre + ((T - 1) & 1) * 1024, seed, cell_thr, rowi, T - 1, cb, U, idx);
+    // cell-layout factors of the own units (k_pb_cellpre): nu * NB rows of 8 floats, contiguous per step -> thread i < 2 nu NB
+    // moves float4 number i into cpre (row = i >> 1)
+    const int ncp4 = 2 * nu * NB;
+    const float* cpa0 = a.CPA + (size_t)u0 * NB * 8;
+    constexpr size_t CPSTEP = (size_t)T2V_H * NB * 8;
+    if (tid < ncp4) *(float4*)(cpre + ((T - 1) & 1) * 1024 + 4 * tid) = *(const float4*)(cpa0 + (size_t)(T - 1) * CPSTEP + 4 * tid);
     __syncthreads();
     unsigned long long tprev_ = __builtin_readcyclecounter();
 
     for (int t = T - 1; t >= 0; --t) {
+        // Everything derived from the thread index is recomputed per step from an OPAQUE copy: hoisted out of the loop, the two
+        // dozen offsets / addresses / predicates of this body live next to 144 weight registers for the whole pass, get
+        // spilled, and every reload costs an s_waitcnt vmcnt(0) — a drain of this wave's whole memory queue — on the chain.
+        int tid_op = threadIdx.x;
+        asm volatile("" : "+v"(tid_op));
+        const int tid = tid_op;
+        // cell rows: row = tid >> 2 = u * NB + b (4 lanes per row, 32 attention dims each); lane 0 of a row owns (unit u, item b)
+        const int rowi = tid >> 2, cu = rowi / NB, cb = rowi - cu * NB;
+        const bool row_on = cu < nu;
+        const bool cell_thr = (tid & 3) == 0 && cu < nu && cb < B;
+        const int U = u0 + (cu < nu ? cu : 0);
         PBA_STAMP(ja == 0, 0);
         PBA_RT(0);
         // decoder_rnn's contribution E(t) was published long ago (that role runs ahead): fetched before the chain needs it
-        unsigned e_raw = PB_SENT, e_off = 0u;
-        float dhc_pre = 0.f;
-        if (tid < 56) {
-            const int c = tid >> 3, b = tid & 7;
-            if (c < nc && b < B) {
-                e_off = (unsigned)(((t * B + b) * T2V_KATT) + T2V_H + c0 + c) * 4u;
-                e_raw = pb_ld4(rE, e_off);
-                dhc_pre = a.dHC[((size_t)t * B + b) * (T2V_H + T2V_E) + T2V_H + c0 + c];
-            }
-        } else if (tid >= 64 && tid < 64 + 112) {
-            const int i = tid - 64, u = i >> 3, b = i & 7;
-            if (u < nu && b < B) {
-                e_off = (unsigned)(((t * B + b) * T2V_KATT) + u0 + u) * 4u;
-                e_raw = pb_ld4(rE, e_off);
+        // (LDS-DMA: no destination registers next to the weight registers; eps[tid] / eps[192 + tid] of the lanes that own a word)
+        unsigned e_off = 0u;
+        if (tid < 192) {
+            const int wv = tid >> 6;
+            if (tid < 56) {
+                const int c = tid >> 3, b = tid & 7;
+                if (c < nc && b < B) {
+                    e_off = (unsigned)(((t * B + b) * T2V_KATT) + T2V_H + c0 + c) * 4u;
+                    pb_dma4(a.EX + (e_off >> 2), eps + 64 * wv, 1);
+                    pb_dma4(a.dHC + ((size_t)t * B + b) * (T2V_H + T2V_E) + T2V_H + c0 + c, eps + 192, 0);
+                }
+            } else if (tid >= 64 && tid < 64 + 112) {
+                const int i = tid - 64, u = i >> 3, b = i & 7;
+                if (u < nu && b < B) {
+                    e_off = (unsigned)(((t * B + b) * T2V_KATT) + u0 + u) * 4u;
+                    pb_dma4(a.EX + (e_off >> 2), eps + 64 * wv, 1);
+                }
             }
         }
         // ---- P1a: the CONTEXT columns of ya = Wcat_att^T dga(t+1) first — they are what the attention workgroups wait for
@@ -1017,72 +1226,44 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
             PBA_STAMP(ja == 0, 1);
             PBA_RT(1);
         }
-        // (the poll has drained the memory queue: parked in LDS, E / dHC cost no wait on the vector-memory counter later —
-        // register spills of the GEMV are stores that count there)
-        if (tid < 176) {
-            eps[tid] = __uint_as_float(e_raw);
-            if (tid < 56) eps[192 + tid] = dhc_pre;
-        }
+        // (the poll has drained the memory queue: E / dHC are in LDS and cost no wait on the vector-memory counter later)
         if (have) {
-            float v[32];
-            pb_gemv_cols<20, 13, 4, NB>(w, X0, X1, v);
-            pb_reduce32(v, part);
-            pb_gemv_cols<20, 17, 3, NB>(w, X0, X1, v);
-            pb_reduce32(v, part + 1024);
+            pba_rounds16<NCT, NUA, NCA, NB>(w, X0, X1, part);
             __syncthreads();
         }
+        if (!have) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // first step: nothing else has waited for the E / dHC copies
         PBA_STAMP(ja == 0, 2);
         // ---- P2: context gradient of the own columns -> attention workgroups (E(t) comes from the decoder_rnn workgroups)
-        if (tid < 56) {
+        if (tid < 64) {
             const int c = tid >> 3, b = tid & 7;
-            if (c < nc && b < B) {
+            float val = 0.f;
+            const bool on = c < nc && b < B;
+            if (on) {
                 float e = eps[tid];
                 if (__float_as_uint(e) == PB_SENT) e = pba_wait_word(rE, e_off, a.err, flag);
-                const float val = (e + eps[192 + tid]) + (have ? pb_sum32(part + (tid >> 5) * 1024, tid & 31) : 0.f);
-                pb_st4(rC, (unsigned)t * PB_CX_ROW_BYTES(NB) + (unsigned)((b >> 2) * T2V_E + c0 + c) * 16u + 4u * (unsigned)(b & 3), val);
-                a.DCTX[((size_t)t * B + b) * T2V_E + c0 + c] = val;
+                val = (e + eps[192 + tid]) + (have ? pb_sum16(part + (tid >> 4) * 512, tid & 15) : 0.f);        // column c: round c / 2
             }
+            // lane b collects the columns of item b (lanes b + 8 c) and publishes them as one 16-byte store + the rest
+            float g[NCA];
+#pragma unroll
+            for (int c2 = 0; c2 < NCA; ++c2) g[c2] = __shfl(val, (tid & 7) + 8 * c2, 64);
+            if (tid < B) {
+                const unsigned o = (unsigned)t * PB_CX_ROW_BYTES(NB) + (unsigned)tid * 4096u + 32u * (unsigned)ja;
+                f32x4 hi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c2 = 4; c2 < NCA; ++c2) hi[c2 - 4] = g[c2];          // (columns past nc carry 0: val = 0 there)
+                pb_st16(rC, o, f32x4{g[0], g[1], g[2], g[3]});
+                pb_st16(rC, o + 16u, hi);
+            }
+            // (the saved copy for the d_memory GEMM goes out AFTER the hand-off, addressed off a scalar base: nothing the
+            // attention workgroups wait for may sit behind a wait on this wave's memory counter)
+            if (on) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rDC, (int)((unsigned)((t * B + b) * T2V_E + c0 + c) * 4u), 0, 0);
         }
         PBA_STAMP(ja == 0, 3);
         PBA_RT(2);
-        // warm this XCD's L2 with the factor row that is parked one step from now (first touch comes from HBM): one word per
-        // 128-byte line, consumed only at the end of the step
-        float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f;
-        if (tid >= 192 && t >= 2) {
-            const float* fr = a.FA + (size_t)(t - 1) * (PB_ROW_BYTES(NB) / 4);
-            const int i = tid - 192;
-            constexpr int NLINE = PB_ROW_BYTES(NB) / 128;
-            pf0 = fr[32 * i];
-            if (i + 320 < NLINE) pf1 = fr[32 * (i + 320)];
-            if (i + 640 < NLINE) pf2 = fr[32 * (i + 640)];
-        } else if (tid >= 64 && tid < 64 + 36 && t >= 2) {
-            // ... and with the activation lines of cell A(t-2) (its pre-part runs at the end of the next step)
-            const int i = tid - 64, t2 = t - 2;
-            const int b = i < 24 ? i % 6 : (i - 24) % 6;
-            if (b < B) {
-                const float* q = i < 24 ? a.GA + ((size_t)t2 * B + b) * T2V_G + (i / 6) * T2V_H + u0
-                                        : a.CA + ((size_t)(t2 + (i < 30 ? 1 : 0)) * B + b) * T2V_H + u0;
-                pf0 = q[0];
-                pf1 = q[nu - 1];
-            }
-        } else if (tid >= 100 && tid < 100 + B && t >= 1) {
-            // ... and with the lines of dHC(t-1) the loop top of the next step reads (cold HBM otherwise, and the row poll
-            // right behind them waits for every older load of its wave)
-            const float* q = a.dHC + ((size_t)(t - 1) * B + (tid - 100)) * (T2V_H + T2V_E) + T2V_H + c0;
-            pf0 = q[0];
-            pf1 = q[nc - 1];
-        }
         // ---- P1b: the recurrent columns (d h_att partial for the cell) while the attention workgroups work on step t
         if (have) {
-            float v[32];
-            pb_gemv_cols<20, 0, 4, NB>(w, X0, X1, v);
-            pb_reduce32(v, part + 2048);
-            pb_gemv_cols<20, 4, 4, NB>(w, X0, X1, v);
-            pb_reduce32(v, part + 3072);
-            pb_gemv_cols<20, 8, 4, NB>(w, X0, X1, v);
-            pb_reduce32(v, part + 4096);
-            pb_gemv_cols<20, 12, 1, NB>(w, X0, X1, v);
-            pb_reduce32(v, part + 5120);
+            pba_rounds16<NCT, 0, NUA, NB>(w, X0, X1, part + 512 * NCR);
             __syncthreads();
         }
         if (tid >= 64 && tid < 64 + 112) {
@@ -1090,35 +1271,60 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
             if (u < nu && b < B) {
                 float e = eps[tid];
                 if (__float_as_uint(e) == PB_SENT) e = pba_wait_word(rE, e_off, a.err, flag);
-                dhA[i] = e + (have ? pb_sum32(part + 2048 + (i >> 5) * 1024, i & 31) : 0.f);
+                dhA[i] = e + (have ? pb_sum16(part + 512 * NCR + (i >> 4) * 512, i & 15) : 0.f);                 // unit u: round u / 2
             }
         }
         PBA_STAMP(ja == 0, 5);
         PBA_RT(3);
+        // (issued HERE, not right after the context hand-off: 768 line fetches from HBM in this CU's memory pipe in front of
+        // the publishing store delayed its landing by more than a microsecond)
+        // warm this XCD's L2 with the factor row that is parked one step from now (first touch comes from HBM): one word per
+        // 128-byte line, consumed only at the end of the step
+        // (LDS-DMA into a dump area: the touched words are never read, so they need no register either)
+        {
+            float* dmp = dump + 64 * (tid >> 6);
+            if (tid >= 192 && t >= 2) {
+                const float* fr = a.FA + (size_t)(t - 1) * (PB_ROW_BYTES(NB) / 4);
+                const int i = tid - 192;
+                constexpr int NLINE = PB_ROW_BYTES(NB) / 128;
+                pb_dma4(fr + 32 * i, dmp, 0);
+                if (i + 320 < NLINE) pb_dma4(fr + 32 * (i + 320), dmp, 0);
+                if (i + 640 < NLINE) pb_dma4(fr + 32 * (i + 640), dmp, 0);
+            } else if (tid >= 64 && tid < 64 + 24 && t >= 2) {
+                // ... and with the cell-layout factor lines of step t-2 (copied into cpre at the end of the next step)
+                const int i = tid - 64;
+                if (32 * i < 4 * ncp4) pb_dma4(cpa0 + (size_t)(t - 2) * CPSTEP + 32 * i, dmp, 0);
+            } else if (tid >= 100 && tid < 100 + B && t >= 1) {
+                // ... and with the lines of dHC(t-1) the loop top of the next step reads (cold HBM otherwise, and the row poll
+                // right behind them waits for every older load of its wave)
+                const float* q = a.dHC + ((size_t)(t - 1) * B + (tid - 100)) * (T2V_H + T2V_E) + T2V_H + c0;
+                pb_dma4(q, dmp, 0);
+                pb_dma4(q + nc - 1, dmp, 0);
+            }
+        }
+
         // while dq(t) is on its way, prepare the next step: the factors of the next gather (row t) into the operand slots
         // (the recurrent GEMV was their last reader), and the part of cell A(t-1) that does not depend on d h_att
         if (t > 0) {
-            const PBACellIn cin = pba_cell_pre_load(a, cell_thr, t - 1, cb, U);
+            // cell-layout factors of step t-1 straight into cpre (16 bytes per lane), issued BEFORE the big copy: small loads
+            // behind it would queue for the whole copy on the wave's in-order memory counter
+            if (tid < ncp4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cpa0 + (size_t)(t - 1) * CPSTEP + 4 * tid),
+                                                 (__attribute__((address_space(3))) void*)(cpre + ((t - 1) & 1) * 1024 + 256 * (tid >> 6)), 16, 0, 0);
             pb_park_factors<NB>(lds, a.FA + (size_t)t * (PB_ROW_BYTES(NB) / 4));
             PBA_STAMP(ja == 0, 12);
-            pba_cell_pre_finish(a, cpre + ((t - 1) & 1) * 1024, seed, cell_thr, rowi, t - 1, idx, cin);
             PBA_STAMP(ja == 0, 13);
         }
         // ---- P4: dq(t) of every item (sum of the position slices' partial rows)
         if (tid >= 320 && tid < 320 + B * 32) {
             const int i = tid - 320, b = i >> 5, q = i & 31;
-            const unsigned off = (unsigned)(((t * B + b) * S) * T2V_A + 4 * q) * 4u;
+            const unsigned off = (unsigned)((t * B + b) * T2V_A + 4 * q) * 4u;
             for (int n = 0; n < napQ; n += 8) __builtin_amdgcn_s_sleep(8);
             f32x4 sum = {0.f, 0.f, 0.f, 0.f};
             int rounds = 0;
             for (;;) {
-                bool ok = true;
-                sum = f32x4{0.f, 0.f, 0.f, 0.f};
-                for (int s = 0; s < S; ++s) {
-                    const f32x4 x = pb_ld16(rQ, off + (unsigned)(s * T2V_A) * 4u);
-                    ok = ok && pb_ok(x[0]) && pb_ok(x[1]) && pb_ok(x[2]) && pb_ok(x[3]);
-                    sum += x;
-                }
+                sum = pb_ld16(rQT, off);
+                const bool ok = pb_ok(sum[0]) && pb_ok(sum[1]) && pb_ok(sum[2]) && pb_ok(sum[3]);
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (++rounds > PB_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -1135,6 +1341,7 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
         PBA_STAMP(ja == 0, 4);
         PBA_RT(4);
         // ---- W_q^T dq for the own units: row (u, b) x 4 lanes x 32 attention dims, quad sum; P5: cell A(t)
+        f32x4 dg4 = {0.f, 0.f, 0.f, 0.f};
         {
             float acc = 0.f;
             if (row_on) {
@@ -1156,24 +1363,28 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
                 const float dct = dca * c0v.y + dht * c0v.z;          // cfc, go (1 - tanh(c)^2)
                 const float d0 = dct * c1v.x, d1 = dct * c1v.y, d2 = dct * c1v.z, d3 = dht * c1v.w;
                 dca = dct * c0v.w;                                    // gf
-                float* o = a.DGA + ((size_t)t * B + cb) * T2V_G + U;
-                o[0] = d0; o[T2V_H] = d1; o[2 * T2V_H] = d2; o[3 * T2V_H] = d3;
                 float* sp = stage + (cu * 2) * 8 + cb;
                 sp[0] = dct; sp[8] = dht;
+                dg4 = f32x4{d0, d1, d2, d3};
             }
         }
         __syncthreads();
         if (t > 0) pba_publish_rows<NB>(rA, (unsigned)t * PB_DROW_BYTES(NB), stage, u0, nu);
+        if (cell_thr) {       // the saved gate gradients (operands of the weight-gradient GEMMs) leave after the hand-off
+            const unsigned o = (unsigned)((t * B + cb) * T2V_G + U) * 4u;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dg4[0]), rDG, (int)o, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dg4[1]), rDG, (int)(o + 4u * T2V_H), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dg4[2]), rDG, (int)(o + 8u * T2V_H), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dg4[3]), rDG, (int)(o + 12u * T2V_H), 0, 0);
+        }
         PBA_STAMP(ja == 0, 6);
         PBA_RT(5);
-        pfsink += (pf0 + pf1) + pf2;
         __syncthreads();
         PBA_STAMP(ja == 0, 7);
     }
     if (a.prof && ja == 0 && tid == 0) a.prof[43] = __builtin_amdgcn_s_memrealtime();
     PBA_PROF_FLUSH(ja == 0, 0, 8);
     PBA_PROF_FLUSH(ja == 0, 12, 4);
-    if (__float_as_uint(pfsink) == 0x7fa00001u) a.err[0] = 2u;      // never true: keeps the prefetch loads alive
 }
 
 template <int NB>      // 4: B <= 4, 6: B = 5, 6
@@ -1181,18 +1392,31 @@ __global__ __launch_bounds__(PB_THREADS) void k_achain_bwd(PBAArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wg = blockIdx.x;
     const int S = a.S_sl, NT = a.B * S, NL = T2V_NWG - NT, NA = pba_na(NL), ND = NL - NA;
+    // (-DPBA_ONLY=1..4 builds ONE role into the kernel: `hipcc -Rpass-analysis=kernel-resource-usage` then reports that role's
+    // own register pressure — the combined kernel always shows the maximum over the roles; tools/dbg/role_regs.sh)
+#if defined(PBA_ONLY) && PBA_ONLY == 1
+    pba_attention_role<16>(a, lds, wg / S, wg % S, NB);
+#elif defined(PBA_ONLY) && PBA_ONLY == 2
+    pba_attention_rnn_role<NB, 12, 6>(a, lds, wg - NT, NA);
+#elif defined(PBA_ONLY) && PBA_ONLY == 3
+    pba_attention_rnn_role<NB, PBA_NUA, PBA_NCA>(a, lds, wg - NT, NA);
+#elif defined(PBA_ONLY) && PBA_ONLY == 4
+    pba_decoder_role<NB>(a, lds, wg - NT - NA, ND);
+#else
     if (wg < NT) {
         if (a.T_in <= 128) pba_attention_role<16>(a, lds, wg / S, wg % S, NB);
         else pba_attention_role<32>(a, lds, wg / S, wg % S, NB);
     } else if (wg < NT + NA) {
-        pba_attention_rnn_role<NB>(a, lds, wg - NT, NA);
+        if (NA >= 86) pba_attention_rnn_role<NB, 12, 6>(a, lds, wg - NT, NA);
+        else pba_attention_rnn_role<NB, PBA_NUA, PBA_NCA>(a, lds, wg - NT, NA);
     } else {
         pba_decoder_role<NB>(a, lds, wg - NT - NA, ND);
     }
+#endif
 }
 
 static size_t pba_lds_bytes(int B, int T_in) {
-    const size_t lrole = (B > 4 ? 6 : 4) * T2V_G + 6 * 1024 + 192 + 128 + 512 + 16 * T2V_A + 8 * T2V_A + 2048 + 256 + 40;
+    const size_t lrole = (B > 4 ? 6 : 4) * T2V_G + 6 * 1024 + 192 + 128 + 512 + 16 * T2V_A + 8 * T2V_A + 2048 + 256 + 64 + 512;
     const size_t Tcap = (size_t)((T_in + 15) / 16) * 16, JS = T_in <= 128 ? 16 : 32;
     const size_t trole = 4 * Tcap + T2V_E + JS + (1 + JS / 4) * 16 + T2V_A * (JS + 1) + 64 * (JS + 1) + 2 * 8 * T2V_A + 40;
     return sizeof(float) * (lrole > trole ? lrole : trole);
@@ -1203,10 +1427,12 @@ static size_t pba_lds_bytes(int B, int T_in) {
 extern "C" long t2v_decoder_bwd_achain_scratch_floats(int B, int T_in, int T_out) {
     if (B < 1 || B > PB_MAXB || T_in < 1 || T_in > PB_MAXT || T_out < 1) return 0;
     const size_t S = (size_t)t2v_attn_bwd_slices_(T_in);
-    const size_t cx = (size_t)T_out * (B > 4 ? 16384 : 8192) / 4;
+    const size_t cx = (size_t)T_out * (B > 4 ? 32768 : 16384) / 4;
     // (dc, dh) rows of both cells (half a gate row each) + context rows + window partials + E + the two factor arrays
-    return (long)((size_t)T_out * pb_row_bytes(B) / 4 + cx + (size_t)T_out * B * S * 128 + (size_t)T_out * B * T2V_KATT +
-                  2 * (size_t)T_out * pb_row_bytes(B) / 4);
+    const size_t cp = (size_t)T_out * T2V_H * (B > 4 ? 6 : 4) * 8;       // cell-layout factors of attention_rnn (k_pb_cellpre)
+    const size_t dqt = (size_t)T_out * 8 * T2V_A;                         // dq(t) summed over the slices (B padded to 8: 16-byte rows)
+    return (long)((size_t)T_out * pb_row_bytes(B) / 4 + cx + (size_t)T_out * B * S * 128 + (size_t)T_out * B * T2V_KATT + dqt +
+                  2 * (size_t)T_out * pb_row_bytes(B) / 4 + cp);
 }
 
 extern "C" int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, const float* w_unused, const t2v_dec_train_bufs* s,
@@ -1221,9 +1447,9 @@ extern "C" int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, co
         !s->CD || !s->GA || !s->GD || !s->AL || !s->S)
         return T2V_ERR_ARG;
     const int S = t2v_attn_bwd_slices_(T_in);
-    const size_t rowf = pb_row_bytes(B) / 4, cxf = (size_t)(B > 4 ? 16384 : 8192) / 4;
+    const size_t rowf = pb_row_bytes(B) / 4, cxf = (size_t)(B > 4 ? 32768 : 16384) / 4;
     const size_t n_gx = (size_t)T_out * rowf / 2, n_f = (size_t)T_out * rowf, n_cx = (size_t)T_out * cxf, n_dq = (size_t)T_out * B * S * 128, n_gp = n_dq;
-    const size_t n_ex = (size_t)T_out * B * T2V_KATT;
+    const size_t n_ex = (size_t)T_out * B * T2V_KATT, n_dqt = (size_t)T_out * 8 * T2V_A;
     if (((uintptr_t)scratch & 15) || ((uintptr_t)DQP & 15) || n_gx * 4 >= 0x7fffffffull || n_dq * 4 >= 0x7fffffffull) return T2V_ERR_ARG;
     if (pba_lds_bytes(B, T_in) > PB_LDS_MAX) return T2V_ERR_ARG;
     static bool attr_set = false;
@@ -1234,7 +1460,7 @@ extern "C" int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, co
         attr_set = true;
     }
     (void)hipMemsetAsync(err_word, 0, sizeof(uint32_t), stream);
-    k_pb_fill<<<1024, 256, 0, stream>>>((uint4*)scratch, (2 * n_gx + n_cx + n_gp + n_ex) / 4);
+    k_pb_fill<<<1024, 256, 0, stream>>>((uint4*)scratch, (2 * n_gx + n_cx + n_gp + n_ex + n_dqt) / 4);
     k_pb_fill<<<256, 256, 0, stream>>>((uint4*)DQP, n_dq / 4);
     PBAArgs a;
     a.w_ih_att = w->w_ih_att; a.w_hh_att = w->w_hh_att; a.w_ih_dec = w->w_ih_dec; a.w_hh_dec = w->w_hh_dec;
@@ -1242,9 +1468,11 @@ extern "C" int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, co
     a.memory = s->memory; a.XS = s->XS; a.CA = s->CA; a.CD = s->CD; a.GA = s->GA; a.GD = s->GD; a.AL = s->AL; a.S = s->S;
     a.dHC = dHC; a.DGA = DGA; a.DGD = DGD; a.DCTX = DCTX; a.DV = DV;
     a.GXA = scratch; a.GXD = scratch + n_gx; a.CX = scratch + 2 * n_gx; a.GPX = scratch + 2 * n_gx + n_cx; a.EX = scratch + 2 * n_gx + n_cx + n_gp; a.DQX = DQP;
-    float* FA = scratch + 2 * n_gx + n_cx + n_gp + n_ex;
+    a.DQT = scratch + 2 * n_gx + n_cx + n_gp + n_ex;
+    float* FA = a.DQT + n_dqt;
     float* FD = FA + n_f;
-    a.FA = FA; a.FD = FD;
+    float* CPA = FD + n_f;
+    a.FA = FA; a.FD = FD; a.CPA = CPA;
     a.err = err_word;
     a.B = B; a.T_in = T_in; a.T = T_out; a.S_sl = S; a.p_att = p_att; a.p_dec = p_dec; a.seed = seed;
     a.step = t2v_step_for(stream);
@@ -1253,6 +1481,9 @@ extern "C" int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, co
         const unsigned nblk = (unsigned)(((size_t)T_out * T2V_G + 255) / 256);
         k_pb_factors<<<nblk, 256, 0, stream>>>(s->GA, s->CA, FA, B, T_out, B, p_att, T2V_RNG_ATT_C, seed, a.step);
         k_pb_factors<<<nblk, 256, 0, stream>>>(s->GD, s->CD, FD, B, T_out, B, p_dec, T2V_RNG_DEC_C, seed, a.step);
+        const int nbs = B > 4 ? 6 : 4;
+        const unsigned ncp = (unsigned)(((size_t)T_out * T2V_H * nbs + 255) / 256);
+        k_pb_cellpre<<<ncp, 256, 0, stream>>>(s->GA, s->CA, CPA, B, T_out, nbs, p_att, T2V_RNG_ATT_H, T2V_RNG_ATT_C, seed, a.step);
     }
     const size_t lds = pba_lds_bytes(B, T_in);
     if (B > 4) k_achain_bwd<6><<<T2V_NWG, PB_THREADS, lds, stream>>>(a);
