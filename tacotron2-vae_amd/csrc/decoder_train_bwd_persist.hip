@@ -107,6 +107,14 @@ __device__ __forceinline__ int pb_gather_row(f32x4* X0, pb_f32x2* X1, __amdgpu_b
 // copied global -> LDS as it lies (planes 0 and 1 are contiguous in both), by LDS-DMA — 1 KB per wave instruction, no
 // staging registers (the 168 weight registers leave room for only a few loads in flight).  pb_build_row multiplies in
 // place; a barrier must lie between the two.
+// a 4-byte word per lane global -> LDS (lane i lands at ldsbase + 4 i) without a destination register; aux: cache policy
+__device__ __forceinline__ void pb_dma4(const void* g, float* ldsbase, const int aux_sc1) {
+    if (aux_sc1)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)ldsbase, 4, 0, PB_SC1);
+    else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)ldsbase, 4, 0, 0);
+}
+
 template <int NB>
 __device__ __forceinline__ void pb_park_factors(float* ldsX, const float* Frow) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -525,6 +533,7 @@ struct PBAArgs {
     float* GXA; float* GXD; float* CX; float* DQX; float* GPX; float* EX;
     float* DQT;                 // (T,B,128) dq(t) summed over the position slices (published by slice 0 of each item)
     const float* CPA;           // (T,1024,NB,8) cell-layout factors of attention_rnn (k_pb_cellpre)
+    const float* CPD;           // the same for decoder_rnn
     const float* FA; const float* FD;    // gate-gradient factors of both cells (k_pb_factors)      // EX (T,B,1536): E(t) = Wcat_dec[:, :1536]^T dgd(t)
     unsigned* err;
     int B, T_in, T, S_sl;
@@ -981,107 +990,121 @@ __device__ __forceinline__ void pba_publish_rows(__amdgpu_buffer_rsrc_t r, unsig
 // ------------------------------------------------------------------------------------------------ D role (free-running)
 template <int NB>
 __device__ __forceinline__ void pba_decoder_role(const PBAArgs& a, float* lds, const int jd, const int ND) {
-    const uint64_t seed = t2v_step_seed(a.seed, a.step);
-    const int tid = threadIdx.x;
     const int B = a.B, T = a.T;
     f32x4* X0 = (f32x4*)lds;
     pb_f32x2* X1 = (pb_f32x2*)(lds + 4 * T2V_G);
-    float* part = lds + (NB > 4 ? 6 : 4) * T2V_G;          // [5 groups][32 partials][32]
-    float* ysum = part + 5 * 1024;                         // [20 cols][8]
-    float* stage = ysum + 160;                             // [8 units][4 gates][8]
-    int* flag = (int*)(stage + 256);
+    float* part = lds + (NB > 4 ? 6 : 4) * T2V_G;          // [10 rounds][32 row partials][16]
+    float* stage = part + 10 * 512;                        // [8 units][2][8]
+    float* cpd = stage + 256;                              // [2][64 rows][8] cell-layout factors of steps td, td-1 (k_pb_cellpre)
+    float* dhcs = cpd + 1024;                              // [2][64] dHC words of the cell threads
+    int* flag = (int*)(dhcs + 128);
     const int u0 = (jd * T2V_H) / ND, nu = ((jd + 1) * T2V_H) / ND - u0;      // <= 8 units
     const int c0 = (jd * T2V_E) / ND, nc = ((jd + 1) * T2V_E) / ND - c0;      // <= 4 context columns
-    const __amdgpu_buffer_rsrc_t rD = pb_rsrc(a.GXD), rE = pb_rsrc(a.EX);
+    const __amdgpu_buffer_rsrc_t rD = pb_rsrc(a.GXD), rE = pb_rsrc(a.EX), rDG = pb_rsrc(a.DGD);
     // columns: [0, 8) recurrent (W_hh_dec[k][U]), [8, 16) h_att input (W_ih_dec[k][U]), [16, 20) ctx input (W_ih_dec[k][1024 + C])
     pb_f32x2 w[20][PB_KJ / 2];
+    {
+        const int tid = threadIdx.x;
 #pragma unroll
-    for (int jj = 0; jj < PB_KJ; ++jj) {
-        const size_t k = (size_t)(tid + PB_THREADS * jj);
+        for (int jj = 0; jj < PB_KJ; ++jj) {
+            const size_t k = (size_t)(tid + PB_THREADS * jj);
 #pragma unroll
-        for (int u = 0; u < PBA_NUD; ++u) {
-            const bool on = u < nu;
-            const int U = u0 + (on ? u : 0);
-            w[u][jj / 2][jj & 1] = on ? a.w_hh_dec[k * T2V_H + U] : 0.f;
-            w[8 + u][jj / 2][jj & 1] = on ? a.w_ih_dec[k * T2V_KATT + U] : 0.f;
+            for (int u = 0; u < PBA_NUD; ++u) {
+                const bool on = u < nu;
+                const int U = u0 + (on ? u : 0);
+                w[u][jj / 2][jj & 1] = on ? a.w_hh_dec[k * T2V_H + U] : 0.f;
+                w[8 + u][jj / 2][jj & 1] = on ? a.w_ih_dec[k * T2V_KATT + U] : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < PBA_NCD; ++c) {
+                const bool on = c < nc;
+                w[16 + c][jj / 2][jj & 1] = on ? a.w_ih_dec[k * T2V_KATT + T2V_H + c0 + (on ? c : 0)] : 0.f;
+            }
         }
-#pragma unroll
-        for (int c = 0; c < PBA_NCD; ++c) {
-            const bool on = c < nc;
-            w[16 + c][jj / 2][jj & 1] = on ? a.w_ih_dec[k * T2V_KATT + T2V_H + c0 + (on ? c : 0)] : 0.f;
-        }
+        if (tid == 0) flag[0] = 1;
     }
-    if (tid == 0) flag[0] = 1;
-    // cell threads: tid = u * 8 + b (u < 8): waves 0 (units 0..7 -> 64 threads)
-    const int cu = tid >> 3, cb = tid & 7;
-    const bool cell_thr = tid < 64 && cu < nu && cb < B;
-    const int U = u0 + (cu < nu ? cu : 0);
-    const uint32_t idx = (uint32_t)cb * T2V_H + U;
     float dcd = 0.f;
     int nap = 0;
+    // cell-layout factors of the own units: nu * NB rows of 8 floats, contiguous per step (thread i < 2 nu NB moves float4 i)
+    const int ncp4 = 2 * nu * NB;
+    const float* cpd0 = a.CPD + (size_t)u0 * NB * 8;
+    constexpr size_t CPSTEP = (size_t)T2V_H * NB * 8;
+    {
+        const int tid = threadIdx.x;
+        if (tid < ncp4) *(float4*)(cpd + ((T - 1) & 1) * 512 + 4 * tid) = *(const float4*)(cpd0 + (size_t)(T - 1) * CPSTEP + 4 * tid);
+        const int cu = tid >> 3, cb = tid & 7;
+        if (tid < 64 && cu < nu && cb < B) dhcs[((T - 1) & 1) * 64 + tid] = a.dHC[((size_t)(T - 1) * B + cb) * (T2V_H + T2V_E) + u0 + cu];
+    }
     pb_park_factors<NB>(lds, a.FD + (size_t)(T - 1) * (PB_ROW_BYTES(NB) / 4));
     __syncthreads();
 
-    if (a.prof && jd == 0 && tid == 0) a.prof[40] = __builtin_amdgcn_s_memrealtime();
-    // iteration t: (t < T) gather dgd(t), yd = Wcat_dec^T dgd(t): publish E(t), keep the recurrent part;  (t >= 1) cell D(t-1)
+    if (a.prof && jd == 0 && threadIdx.x == 0) a.prof[40] = __builtin_amdgcn_s_memrealtime();
+    // iteration t: (t < T) gather (dc, dh)(t) and build dgd(t); the RECURRENT columns of Wcat_dec^T dgd(t) first — they feed cell
+    // D(t-1), whose (dc, dh) row is this role's own chain — then, behind the hand-off, the 12 columns of E(t) for the other role
+    // (round 4; before, all 20 columns and the in-loop RNG / tanh of the cell sat on the chain: 9.9 -> 8.5 us per step)
     for (int t = T; t >= 0; --t) {
+        int tid_op = threadIdx.x;
+        asm volatile("" : "+v"(tid_op));       // (see the attention_rnn role: nothing thread-derived is hoisted out of the loop)
+        const int tid = tid_op;
+        const int cu = tid >> 3, cb = tid & 7;
+        const bool cell_thr = tid < 64 && cu < nu && cb < B;
+        const int U = u0 + (cu < nu ? cu : 0);
         if (t < T) {
             const int rounds = pb_build_row<NB>(X0, X1, rD, (unsigned)t * PB_DROW_BYTES(NB), B, nap, a.err, flag);
             nap = t2v_adapt_nap(nap, rounds);
-            __syncthreads();                                // (operands are thread-private; the barrier only spreads a time-out)
-            if (flag[0] != 1) return;
-            float v[32];
-            pb_gemv_cols<20, 0, 4, NB>(w, X0, X1, v);
-            pb_reduce32(v, part);
-            pb_gemv_cols<20, 4, 4, NB>(w, X0, X1, v);
-            pb_reduce32(v, part + 1024);
-            pb_gemv_cols<20, 8, 4, NB>(w, X0, X1, v);
-            pb_reduce32(v, part + 2048);
-            pb_gemv_cols<20, 12, 4, NB>(w, X0, X1, v);
-            pb_reduce32(v, part + 3072);
-            pb_gemv_cols<20, 16, 4, NB>(w, X0, X1, v);
-            pb_reduce32(v, part + 4096);
-            __syncthreads();
-            if (t > 0) pb_park_factors<NB>(lds, a.FD + (size_t)(t - 1) * (PB_ROW_BYTES(NB) / 4));
-            pba_finish_sums(part, ysum, 20);
-            __syncthreads();
-            // E(t): [h_att columns | ctx columns] of this workgroup, plain (T,B,1536) layout
-            if (tid >= 64 && tid < 64 + 96) {
-                const int i = tid - 64, col = i >> 3, b = i & 7;      // col 0..7: unit, 8..11: ctx column
-                if (b < B) {
-                    if (col < 8) { if (col < nu) pb_st4(rE, (unsigned)(((t * B + b) * T2V_KATT) + u0 + col) * 4u, ysum[(8 + col) * 8 + b]); }
-                    else if (col - 8 < nc) pb_st4(rE, (unsigned)(((t * B + b) * T2V_KATT) + T2V_H + c0 + col - 8) * 4u, ysum[(16 + col - 8) * 8 + b]);
-                }
-            }
+            pba_rounds16<20, 0, 8, NB>(w, X0, X1, part);
         }
+        // prefetch for the NEXT cell (step t-2): its factors and its dHC words, straight into LDS
+        if (t >= 2) {
+            if (tid < ncp4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cpd0 + (size_t)(t - 2) * CPSTEP + 4 * tid),
+                                                 (__attribute__((address_space(3))) void*)(cpd + ((t - 2) & 1) * 512 + 256 * (tid >> 6)), 16, 0, 0);
+            if (cell_thr) pb_dma4(a.dHC + ((size_t)(t - 2) * B + cb) * (T2V_H + T2V_E) + U, dhcs + ((t - 2) & 1) * 64, 0);
+        }
+        __syncthreads();
+        if (flag[0] != 1) return;
+        f32x4 dg4 = {0.f, 0.f, 0.f, 0.f};
         if (t >= 1) {
             const int td = t - 1;
             if (cell_thr) {
-                const float dh = a.dHC[((size_t)td * B + cb) * (T2V_H + T2V_E) + U] + (t < T ? ysum[cu * 8 + cb] : 0.f);
-                const float* gp = a.GD + ((size_t)td * B + cb) * T2V_G + U;
-                const float gi = gp[0], gf = gp[T2V_H], gg = gp[2 * T2V_H], go = gp[3 * T2V_H];
-                const float cdc = a.CD[((size_t)(td + 1) * B + cb) * T2V_H + U];
-                float cprev = a.CD[((size_t)td * B + cb) * T2V_H + U];
-                const float fh = t2v_drop_scale(seed, T2V_RNG_DEC_H, td, idx, a.p_dec);
-                const float fc = t2v_drop_scale(seed, T2V_RNG_DEC_C, td, idx, a.p_dec);
-                if (td > 0) cprev *= t2v_drop_scale(seed, T2V_RNG_DEC_C, td - 1, idx, a.p_dec);
-                const float tc = tanhf_(cdc);
-                const float dht = dh * fh;
-                const float dct = dcd * fc + dht * go * (1.0f - tc * tc);
-                const float d0 = dct * gg * gi * (1.0f - gi), d1 = dct * cprev * gf * (1.0f - gf);
-                const float d2 = dct * gi * (1.0f - gg * gg), d3 = dht * tc * go * (1.0f - go);
-                dcd = dct * gf;
-                float* o = a.DGD + ((size_t)td * B + cb) * T2V_G + U;
-                o[0] = d0; o[T2V_H] = d1; o[2 * T2V_H] = d2; o[3 * T2V_H] = d3;
+                const float dh = dhcs[(td & 1) * 64 + tid] + (t < T ? pb_sum16(part + (cu >> 1) * 512, (cu & 1) * 8 + cb) : 0.f);
+                const float* cp = cpd + (td & 1) * 512 + (cu * NB + cb) * 8;
+                const float4 c0v = *(const float4*)cp, c1v = *(const float4*)(cp + 4);
+                const float dht = dh * c0v.x;                         // fh
+                const float dct = dcd * c0v.y + dht * c0v.z;          // fc, go (1 - tanh(c)^2)
+                dg4 = f32x4{dct * c1v.x, dct * c1v.y, dct * c1v.z, dht * c1v.w};
+                dcd = dct * c0v.w;                                    // gf
                 float* sp = stage + (cu * 2) * 8 + cb;
                 sp[0] = dct; sp[8] = dht;
             }
             // (stage is written and read by wave 0 only: LDS operations of one wave complete in order)
             if (tid < 64) pba_publish_rows<NB>(rD, (unsigned)td * PB_DROW_BYTES(NB), stage, u0, nu);
+            if (cell_thr) {       // the saved gate gradients leave after the hand-off
+                const unsigned o = (unsigned)((td * B + cb) * T2V_G + U) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dg4[0]), rDG, (int)o, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dg4[1]), rDG, (int)(o + 4u * T2V_H), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dg4[2]), rDG, (int)(o + 8u * T2V_H), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dg4[3]), rDG, (int)(o + 12u * T2V_H), 0, 0);
+            }
+        }
+        if (t < T) {
+            // ---- off the chain: E(t) = Wcat_dec[:, :1536]^T dgd(t), the decoder_rnn contribution to d h_att(t) / d ctx(t)
+            pba_rounds16<20, 8, 12, NB>(w, X0, X1, part + 4 * 512);
+            __syncthreads();
+            if (t > 0) pb_park_factors<NB>(lds, a.FD + (size_t)(t - 1) * (PB_ROW_BYTES(NB) / 4));
+            // E(t): [h_att columns | ctx columns] of this workgroup, plain (T,B,1536) layout
+            if (tid >= 64 && tid < 64 + 96) {
+                const int i = tid - 64, col = i >> 3, b = i & 7;      // col 0..7: unit, 8..11: ctx column
+                if (b < B) {
+                    const float val = pb_sum16(part + (4 + (col >> 1)) * 512, (col & 1) * 8 + b);
+                    if (col < 8) { if (col < nu) pb_st4(rE, (unsigned)(((t * B + b) * T2V_KATT) + u0 + col) * 4u, val); }
+                    else if (col - 8 < nc) pb_st4(rE, (unsigned)(((t * B + b) * T2V_KATT) + T2V_H + c0 + col - 8) * 4u, val);
+                }
+            }
         }
         __syncthreads();
     }
-    if (a.prof && jd == 0 && tid == 0) a.prof[41] = __builtin_amdgcn_s_memrealtime();
+    if (a.prof && jd == 0 && threadIdx.x == 0) a.prof[41] = __builtin_amdgcn_s_memrealtime();
 }
 
 // the activation-only part of attention_rnn's cell backward at step t -> cpre[row][8] = {fh, fc, go(1-tanh(c)^2), gf, e0..e3}.
@@ -1117,14 +1140,6 @@ __device__ __forceinline__ void pba_cell_pre(const PBAArgs& a, float* cpre, uint
 }
 
 // ------------------------------------------------------------------------------------------------ A role (the chain)
-// a 4-byte word per lane global -> LDS (lane i lands at ldsbase + 4 i) without a destination register; aux: cache policy
-__device__ __forceinline__ void pb_dma4(const void* g, float* ldsbase, const int aux_sc1) {
-    if (aux_sc1)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)ldsbase, 4, 0, PB_SC1);
-    else
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)ldsbase, 4, 0, 0);
-}
-
 template <int NB, int NUA, int NCA>
 __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* lds, const int ja, const int NA) {
     constexpr int NCT = NUA + NCA;
@@ -1429,7 +1444,7 @@ extern "C" long t2v_decoder_bwd_achain_scratch_floats(int B, int T_in, int T_out
     const size_t S = (size_t)t2v_attn_bwd_slices_(T_in);
     const size_t cx = (size_t)T_out * (B > 4 ? 32768 : 16384) / 4;
     // (dc, dh) rows of both cells (half a gate row each) + context rows + window partials + E + the two factor arrays
-    const size_t cp = (size_t)T_out * T2V_H * (B > 4 ? 6 : 4) * 8;       // cell-layout factors of attention_rnn (k_pb_cellpre)
+    const size_t cp = 2 * (size_t)T_out * T2V_H * (B > 4 ? 6 : 4) * 8;   // cell-layout factors of both cells (k_pb_cellpre)
     const size_t dqt = (size_t)T_out * 8 * T2V_A;                         // dq(t) summed over the slices (B padded to 8: 16-byte rows)
     return (long)((size_t)T_out * pb_row_bytes(B) / 4 + cx + (size_t)T_out * B * S * 128 + (size_t)T_out * B * T2V_KATT + dqt +
                   2 * (size_t)T_out * pb_row_bytes(B) / 4 + cp);
@@ -1472,7 +1487,8 @@ extern "C" int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, co
     float* FA = a.DQT + n_dqt;
     float* FD = FA + n_f;
     float* CPA = FD + n_f;
-    a.FA = FA; a.FD = FD; a.CPA = CPA;
+    float* CPD = CPA + (size_t)T_out * T2V_H * (B > 4 ? 6 : 4) * 8;
+    a.FA = FA; a.FD = FD; a.CPA = CPA; a.CPD = CPD;
     a.err = err_word;
     a.B = B; a.T_in = T_in; a.T = T_out; a.S_sl = S; a.p_att = p_att; a.p_dec = p_dec; a.seed = seed;
     a.step = t2v_step_for(stream);
@@ -1484,6 +1500,7 @@ extern "C" int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, co
         const int nbs = B > 4 ? 6 : 4;
         const unsigned ncp = (unsigned)(((size_t)T_out * T2V_H * nbs + 255) / 256);
         k_pb_cellpre<<<ncp, 256, 0, stream>>>(s->GA, s->CA, CPA, B, T_out, nbs, p_att, T2V_RNG_ATT_H, T2V_RNG_ATT_C, seed, a.step);
+        k_pb_cellpre<<<ncp, 256, 0, stream>>>(s->GD, s->CD, CPD, B, T_out, nbs, p_dec, T2V_RNG_DEC_H, T2V_RNG_DEC_C, seed, a.step);
     }
     const size_t lds = pba_lds_bytes(B, T_in);
     if (B > 4) k_achain_bwd<6><<<T2V_NWG, PB_THREADS, lds, stream>>>(a);
