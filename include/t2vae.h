@@ -227,6 +227,14 @@ int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, const float* 
                            const float* dHC, float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
                            uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
                            void* stream);
+/* The same pass as TWO launches (round 4): the attention chain on `stream`, the free-running decoder_rnn chain on `stream_d`
+ * (which this call orders behind the preparation launches on `stream`).  DGD is complete when stream_d is — the decoder_rnn
+ * weight-gradient GEMMs can be queued behind it and run while the attention chain is still going — everything else when
+ * `stream` is; the caller joins stream_d back.  stream_d NULL or == stream: one launch, as t2v_decoder_bwd_achain. */
+int t2v_decoder_bwd_achain2(const t2v_dec_train_persist_weights* w, const float* reserved, const t2v_dec_train_bufs* s,
+                           const float* dHC, float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
+                           uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
+                           void* stream, void* stream_d);
 
 /* ------------------------------------------------------------------ free-running decode
  * Decoder.inference (model.py:428-464) == the synthesizer loop (synthesizer.py:139-154): steps

@@ -70,7 +70,7 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_stamp', 't2v_pack_lstm_weights'
            't2v_decoder_train_fwd_persistent', 't2v_decoder_train_persist_supported',
            't2v_decoder_train_persist_scratch_floats', 't2v_decoder_bwd_persist_supported',
            't2v_decoder_bwd_dchain_scratch_floats', 't2v_decoder_bwd_dchain', 't2v_decoder_bwd_achain_scratch_floats',
-           't2v_decoder_bwd_achain')
+           't2v_decoder_bwd_achain', 't2v_decoder_bwd_achain2')
 
 
 def lib_path():
@@ -114,6 +114,7 @@ def load_library():
     lib.t2v_decoder_bwd_achain_scratch_floats.restype = C.c_long
     lib.t2v_decoder_bwd_achain.argtypes = [C.POINTER(_DecTrainPersistWeights), C.c_void_p, C.POINTER(_DecTrainBufs)] + [C.c_void_p] * 8 + [
         C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]
+    lib.t2v_decoder_bwd_achain2.argtypes = lib.t2v_decoder_bwd_achain.argtypes + [C.c_void_p]
     lib.t2v_decoder_replay_fwd_kernels.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecTrainBufs), C.c_int,
                                                    C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_int,
                                                    C.c_void_p]
@@ -326,7 +327,8 @@ _STEP_ALL = []
 class Overlap(object):
     # reference-encoder branch; deferred ("nobody waits for it") work: weight gradients, Prenet; the four chip-filling LSTM
     # weight-gradient GEMMs of the decoder get a stream of their own so the long tail of small deferred kernels runs next to them
-    NAMES = ('vae', 'w', 'g')
+    # 'd': the free-running decoder_rnn chain of the persistent reverse pass and, behind it, its two weight-gradient GEMMs
+    NAMES = ('vae', 'w', 'g', 'd')
 
     def __init__(self, device=None):
         self.on = True
@@ -852,9 +854,22 @@ class DecoderCore(torch.autograd.Function):
                 scratch = torch.empty(lib.t2v_decoder_bwd_achain_scratch_floats(B, T_in, T), **f32)
                 errw = torch.zeros(1, device=dev, dtype=torch.int32)
                 stamp('dec_bwd_begin')
-                _check(lib.t2v_decoder_bwd_achain(C.byref(PW), None, C.byref(Sb), _p(dhc_c), _p(DGA), _p(DGD), _p(DCTX), _p(DV),
-                                                  _p(DQP), _p(scratch), _p(errw), B, T_in, T, p_att, p_dec,
-                                                  (seed + 7919 * b0) & 0x7FFFFFFFFFFFFFFF, _stream()), 't2v_decoder_bwd_achain')
+                # T2V_BWD_SPLIT=1 (opt-in): the decoder_rnn chain as a launch of its own on stream 'd' — its END is then something
+                # the two decoder_rnn weight-gradient GEMMs can wait for, and they run on the CUs it frees while the attention
+                # chain goes on.  Measured: graph replay 11.43 -> 11.24 ms per step, eager 11.44 -> 11.77.  Not the default: the
+                # two launches need each other's progress, and a replayed HIP graph does not promise that two branches run
+                # CONCURRENTLY — with a few more nodes in the graph the executor put the attention chain BEHIND the other branch
+                # (correct, the decoder_rnn chain needs nothing from it, but 8 ms instead of 4.4); one launch has no such cliff.
+                ov = overlap()
+                st_d = ov.stream('d') if (ov is not None and ov.on and os.environ.get('T2V_BWD_SPLIT', '0') == '1') else None
+                if st_d is not None:
+                    with ov.side('d', keep=(dhc_c, DGD, scratch) + tuple(keep)):
+                        pass        # registers the stream for the engine's join (and orders it behind this point)
+                _check(lib.t2v_decoder_bwd_achain2(C.byref(PW), None, C.byref(Sb), _p(dhc_c), _p(DGA), _p(DGD), _p(DCTX), _p(DV),
+                                                   _p(DQP), _p(scratch), _p(errw), B, T_in, T, p_att, p_dec,
+                                                   (seed + 7919 * b0) & 0x7FFFFFFFFFFFFFFF, _stream(),
+                                                   None if st_d is None else C.c_void_p(st_d.cuda_stream)), 't2v_decoder_bwd_achain2')
+                split_d = st_d is not None
                 _err_note('decoder backward (persistent kernel hand-off)', errw)
                 DecoderCore.last_bwd_mode = 'persistent'
                 dq_sum = DQP.sum(2).view(T * B, A)
@@ -862,6 +877,7 @@ class DecoderCore(torch.autograd.Function):
                     DecoderCore.last_bwd_persist = (PW, Sb, (dhc_c, DGA, DGD, DCTX, DV, DQP, scratch, errw), (B, T_in, T, p_att, p_dec, seed),
                                                     keep + (ctx.raw, wcomb, vv, bias_dec))
             else:
+                split_d = False
                 DQ = torch.empty(T, B, NS, A, 2, **f32)
                 YD = torch.empty(B, XW, **f32); YA = torch.empty(B, KATT, **f32)
                 DCA = torch.empty(B, H, **f32); DCD = torch.empty(B, H, **f32)
@@ -917,14 +933,21 @@ class DecoderCore(torch.autograd.Function):
                 with side('g', after=fork):
                     gemm(dga2.t(), x_prev[:, :H].t(), out=d_w_hh_att, accumulate=not first)
                     gemm(dga2.t(), x_prev[:, H:KATT].t(), out=d_w_ih_att[:, PRE:], accumulate=not first)
-                    gemm(dgd2.t(), x_cur[:, :KATT].t(), out=d_w_ih_dec, accumulate=not first)
-                    gemm(dgd2.t(), x_cur[:, KATT:].t(), out=d_w_hh_dec, accumulate=not first)
+                    if not split_d:
+                        gemm(dgd2.t(), x_cur[:, :KATT].t(), out=d_w_ih_dec, accumulate=not first)
+                        gemm(dgd2.t(), x_cur[:, KATT:].t(), out=d_w_hh_dec, accumulate=not first)
+                if split_d:         # in order behind the decoder_rnn chain on ITS stream: they start the moment it ends
+                    with torch.cuda.stream(overlap().stream('d')):
+                        gemm(dgd2.t(), x_cur[:, :KATT].t(), out=d_w_ih_dec, accumulate=not first)
+                        gemm(dgd2.t(), x_cur[:, KATT:].t(), out=d_w_hh_dec, accumulate=not first)
                 d_wq = gemm(dq_sum.t(), x_cur[:, :H].t())            # (128,1024)
                 d_v = DV.sum((0, 1)).view(1, A)
                 d_loc_dense, d_loc_conv = attn_wgrad(dpre, AL, ACUM, loc_conv, loc_dense, B, T_in, T)
                 parts = [d_wq, d_loc_conv, d_loc_dense, d_v]
                 acc = parts if acc is None else [x + y for x, y in zip(acc, parts)]
             # bias gradients flow on through an Add node (bias_ih + bias_hh) / are handed to two inputs: node's stream
+            if split_d:
+                torch.cuda.current_stream().wait_stream(overlap().stream('d'))       # (DGD: that chain ended long before this one)
             bparts = [colsum(DGD.view(TB, G4))] + ([colsum(DGA.view(TB, G4))] if ctx.pre2 is not None else [])
             bacc = bparts if bacc is None else [x + y for x, y in zip(bacc, bparts)]
             dga_l.append(DGA)
