@@ -30,6 +30,9 @@ void t2v_set_phase_profile(unsigned long long* dev_buf32);
 /* Measurement aid: a one-thread launch on `stream` that writes the chip-wide 100 MHz wall clock into dev_buf[slot]
  * (phase time line of an undisturbed graph replay: tools/stamps.py). */
 int t2v_stamp(unsigned long long* dev_buf, int slot, void* stream);
+/* Test aid: `wgs` workgroups (256 threads each) that occupy CUs for `microseconds` doing nothing — a stand-in for a
+ * neighbour (another process, a communication kernel) while the persistent kernels start. */
+int t2v_debug_spin(int wgs, int microseconds, void* stream);
 
 /* Per-step parameters in DEVICE memory (optional).  Kernel arguments are frozen when a training step is captured
  * into a HIP graph; this 32-byte record is read by the kernels at run time instead, so every replay gets fresh
@@ -460,6 +463,14 @@ int t2v_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_a
                        float lr, float beta1, float beta2, float eps, float weight_decay,
                        float max_norm, float inv_world, float bc1, float bc2, float* partials,
                        float* norm_out, void* stream);
+/* The same step, guarded (round 4): guard[0..guard_n) are error words of the step's cooperative / persistent kernels
+ * (device memory).  If any of them is non-zero when the step runs, NOTHING is updated (parameters and both moment arenas keep
+ * their values) and norm_out[0] reads NaN: the host finds the error at its next sync, switches the persistent kernels off
+ * and runs the iteration again.  guard_n == 0: the plain step. */
+int t2v_clip_adam_step_guarded(float* params, float* grads, float* exp_avg, float* exp_avg_sq, uint64_t n,
+                               float lr, float beta1, float beta2, float eps, float weight_decay,
+                               float max_norm, float inv_world, float bc1, float bc2, float* partials,
+                               float* norm_out, const uint32_t* guard, int guard_n, void* stream);
 
 /* ------------------------------------------------------------------ STFT -> mel front end
  * TacotronSTFT.mel_spectrogram (layers.py:75-92): reflect pad n_fft/2, periodic-Hann STFT

@@ -34,11 +34,30 @@ struct AdamArgs {
     float* norm_out;          // [0] = total grad norm (after the 1/world scaling)
     float lr, b1, b2, eps, wd, max_norm, inv_world, bc1, bc2s;   // bc1 = 1-b1^t, bc2s = sqrt(1-b2^t)
     const t2v_step_params* step;     // device-side lr / bc1 / bc2s (graph replay) or NULL
+    const uint32_t* guard;           // optional: error words of the step's cooperative / persistent kernels
+    int guard_n;
 };
 
 __global__ __launch_bounds__(256) void k_clip_adam(AdamArgs a) {
     __shared__ float red[4];
     __shared__ float s_coef;
+    __shared__ int s_skip;
+    // Guarded step (round 4): a bounded spin that gave up inside one of the step's persistent / cooperative kernels leaves a
+    // non-zero error word and gradients that mean nothing.  The update is then SKIPPED on the device — parameters and both
+    // moment arenas stay untouched, norm_out reads NaN — so the host, when it reads the error ledger at its next sync, can
+    // switch that kernel family off and simply run the iteration again (train.TrainEngine.recover).
+    if (a.guard) {
+        if (threadIdx.x == 0) {
+            int bad = 0;
+            for (int i = 0; i < a.guard_n; ++i) bad |= (a.guard[i] != 0u);
+            s_skip = bad;
+        }
+        __syncthreads();
+        if (s_skip) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) a.norm_out[0] = __uint_as_float(0x7fc0beefu);     // a NaN with a payload the host recognises
+            return;
+        }
+    }
     // every block re-reduces the 1024 partials in the same order -> identical clip coefficient
     float acc = 0.f;
     for (int i = threadIdx.x; i < T2V_NORM_BLOCKS; i += 256) acc += a.partials[i];
@@ -84,11 +103,24 @@ __global__ __launch_bounds__(256) void k_clip_adam(AdamArgs a) {
     }
 }
 
+extern "C" int t2v_clip_adam_step_guarded(float* params, float* grads, float* exp_avg, float* exp_avg_sq, uint64_t n,
+                                          float lr, float beta1, float beta2, float eps, float weight_decay,
+                                          float max_norm, float inv_world, float bc1, float bc2, float* partials,
+                                          float* norm_out, const uint32_t* guard, int guard_n, void* stream_);
 extern "C" int t2v_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, uint64_t n,
                                   float lr, float beta1, float beta2, float eps, float weight_decay,
                                   float max_norm, float inv_world, float bc1, float bc2, float* partials,
                                   float* norm_out, void* stream_) {
+    return t2v_clip_adam_step_guarded(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, max_norm, inv_world,
+                                      bc1, bc2, partials, norm_out, nullptr, 0, stream_);
+}
+
+extern "C" int t2v_clip_adam_step_guarded(float* params, float* grads, float* exp_avg, float* exp_avg_sq, uint64_t n,
+                                          float lr, float beta1, float beta2, float eps, float weight_decay,
+                                          float max_norm, float inv_world, float bc1, float bc2, float* partials,
+                                          float* norm_out, const uint32_t* guard, int guard_n, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (guard_n < 0 || (guard_n > 0 && !guard)) return T2V_ERR_ARG;
     if (!params || !grads || !exp_avg || !exp_avg_sq || !partials || !norm_out || !(bc1 > 0.f) || !(bc2 > 0.f)) return T2V_ERR_ARG;
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return T2V_ERR_ARG;
     const size_t n4 = n >> 2;
@@ -101,6 +133,8 @@ extern "C" int t2v_clip_adam_step(float* params, float* grads, float* exp_avg, f
     a.bc1 = bc1;
     a.bc2s = sqrtf(bc2);
     a.step = t2v_step_for(stream);
+    a.guard = guard_n > 0 ? guard : nullptr;
+    a.guard_n = guard_n;
     k_clip_adam<<<2048, 256, 0, stream>>>(a);
     return t2v_check_launch();
 }

@@ -99,3 +99,15 @@ extern "C" int t2v_stamp(unsigned long long* dev_buf, int slot, void* stream) {
     k_stamp<<<1, 64, 0, (hipStream_t)stream>>>(dev_buf, slot);
     return t2v_check_launch();
 }
+
+// Test aid (tests/test_decoder_persist_train_gpu.py: a neighbour that holds CUs while the persistent kernels start): `wgs`
+// workgroups of 256 threads that do nothing but watch the 100 MHz clock for `microseconds`.
+__global__ __launch_bounds__(256) void k_spin(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while ((unsigned long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int t2v_debug_spin(int wgs, int microseconds, void* stream) {
+    if (wgs < 1 || wgs > 4096 || microseconds < 1 || microseconds > 200000) return T2V_ERR_ARG;
+    k_spin<<<wgs, 256, 0, (hipStream_t)stream>>>((unsigned long long)microseconds * 100ull);
+    return t2v_check_launch();
+}

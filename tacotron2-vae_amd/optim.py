@@ -48,7 +48,11 @@ class FlatAdam(object):
         self._offsets = offs
         f32 = dict(device=dev, dtype=torch.float32)
         self.params = torch.zeros(total, **f32)
-        self.grads = torch.zeros(total, **f32)
+        # (+4: one 16-byte slot behind the last gradient that is NOT part of the norm / the update.  A multi-rank engine writes
+        # "one of my persistent kernels timed out" there before the all-reduce: after the SUM every rank sees a non-zero word,
+        # every rank skips the update, every rank re-runs the iteration — train.TrainEngine.recover)
+        self._grads_full = torch.zeros(total + 4, **f32)
+        self.grads = self._grads_full[:total]
         self.exp_avg = torch.zeros(total, **f32)
         self.exp_avg_sq = torch.zeros(total, **f32)
         self._partials = torch.zeros(1024, **f32)
@@ -73,6 +77,16 @@ class FlatAdam(object):
         self.world_size = world_size
         self.step_count = 0
         self.step_params = None     # the owning engine's device-side record (train.TrainEngine), else the active one
+        self.guard = None           # int32 device view: error words of this step's persistent kernels (TrainEngine sets it)
+
+    SKIPPED_NORM_BITS = 0x7fc0beef      # grad_norm after a step the device skipped (t2v_clip_adam_step_guarded)
+
+    def poison_slot(self):
+        """the 4-float tail of the gradient arena (travels with the all-reduce when the collective covers grads_for_allreduce())"""
+        return self._grads_full[self.numel:]
+
+    def grads_for_allreduce(self):
+        return self._grads_full
 
     def live_params(self):
         return [p for _, _, p in self._live]
@@ -140,7 +154,8 @@ class FlatAdam(object):
             self.publish_step_params(sp, self.step_count)
             sp.upload()
         lib = t2v_hip.load_library()
-        rc = lib.t2v_clip_adam_step(
+        guard, self.guard = self.guard, None
+        rc = lib.t2v_clip_adam_step_guarded(
             C.c_void_p(self.params.data_ptr()), C.c_void_p(self.grads.data_ptr()),
             C.c_void_p(self.exp_avg.data_ptr()), C.c_void_p(self.exp_avg_sq.data_ptr()),
             C.c_uint64(self.numel), C.c_float(g['lr']), C.c_float(g['betas'][0]), C.c_float(g['betas'][1]),
@@ -148,6 +163,7 @@ class FlatAdam(object):
             C.c_float(self.grad_clip_thresh if self.grad_clip_thresh else 0.0),
             C.c_float(1.0 / self.world_size), C.c_float(bc1), C.c_float(bc2),
             C.c_void_p(self._partials.data_ptr()), C.c_void_p(self.grad_norm.data_ptr()),
+            None if guard is None else C.c_void_p(guard.data_ptr()), 0 if guard is None else int(guard.numel()),
             C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             raise t2v_hip.T2VHipError("t2v_clip_adam_step rc=%d" % rc)

@@ -59,8 +59,8 @@ class _DecInferBufs(C.Structure):
         'prenet_w1', 'proj_w', 'proj_b')]
 
 
-EXPORTS = ('t2v_version', 't2v_last_error', 't2v_stamp', 't2v_pack_lstm_weights', 't2v_pack_lstm_weights_bf16', 't2v_decoder_train_fwd',
-           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_conv1d_dw_scratch_floats', 't2v_conv1d_flip_weights', 't2v_gemm_bf16', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
+EXPORTS = ('t2v_version', 't2v_last_error', 't2v_stamp', 't2v_debug_spin', 't2v_pack_lstm_weights', 't2v_pack_lstm_weights_bf16', 't2v_decoder_train_fwd',
+           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_clip_adam_step_guarded', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_conv1d_dw_scratch_floats', 't2v_conv1d_flip_weights', 't2v_gemm_bf16', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
            't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bn_act_bwd_eval', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats', 't2v_conv2d_s2_fwd_gemm', 't2v_conv2d_s2_bwd_gemm',
            't2v_conv2d_s2_gemm_scratch_floats',
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_fuse_location_weights', 't2v_decoder_qp_floats',
@@ -124,6 +124,7 @@ def load_library():
     lib.t2v_clip_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float,
                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.t2v_clip_adam_step_guarded.argtypes = lib.t2v_clip_adam_step.argtypes[:-1] + [C.c_void_p, C.c_int, C.c_void_p]
     lib.t2v_embedding_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.t2v_embedding_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.t2v_gemm_epilogue_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]
@@ -138,6 +139,7 @@ def load_library():
                                      C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.t2v_set_phase_profile.argtypes = [C.c_void_p]
     lib.t2v_stamp.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.t2v_debug_spin.argtypes = [C.c_int, C.c_int, C.c_void_p]
     lib.t2v_decoder_infer_persistent.argtypes = [C.POINTER(_DecPersistWeights), C.POINTER(_DecPersistBufs), C.c_int, C.c_int,
                                                  C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]
     lib.t2v_decoder_persist_supported.argtypes = [C.c_int, C.c_int]
@@ -522,6 +524,9 @@ _ERR_SLOTS = 4096
 _ERR_STICKY = [0]      # > 0: slots [0, n) belong to captured graphs (rewritten by every replay) and are never recycled
 
 
+_ERR_INJECT = [None]    # test hook: a substring; the next ledger entry whose label contains it is recorded as a time-out
+
+
 def _err_note(label, word):
     """word: a 1-element int32 device view holding a kernel's error word (valid once the stream reaches it)"""
     key = str(word.device)
@@ -532,8 +537,28 @@ def _err_note(label, word):
         pool[1] = _ERR_STICKY[0]
     slot = pool[1]
     pool[0][slot:slot + 1].copy_(word)
+    if _ERR_INJECT[0] is not None and _ERR_INJECT[0] in label:
+        pool[0][slot:slot + 1].fill_(1)
+        _ERR_INJECT[0] = None
     pool[2][slot] = label
     pool[1] += 1
+
+
+def err_mark(device=None):
+    """position of the error ledger now: an engine takes it at the top of a step; err_range(mark) then names the ledger words
+    the step's kernels wrote (the guard of the fused optimiser step)"""
+    key = str(torch.device('cuda', torch.cuda.current_device()) if device is None else device)
+    pool = _ERR_POOL.get(key)
+    return 0 if pool is None else pool[1]
+
+
+def err_range(mark, device=None):
+    """(device pointer, count) of the ledger words written since `mark` (None when there are none or the ledger wrapped)"""
+    key = str(torch.device('cuda', torch.cuda.current_device()) if device is None else device)
+    pool = _ERR_POOL.get(key)
+    if pool is None or pool[1] <= mark:
+        return None
+    return pool[0][mark:pool[1]]
 
 
 def check_async_errors():
@@ -551,8 +576,10 @@ def check_async_errors():
         for i in [i for i in pool[2] if i >= _ERR_STICKY[0]]:
             del pool[2][i]
     if bad:
-        raise T2VHipError("cooperative kernel barrier timed out (results of that step are invalid): %s"
-                          % ", ".join(sorted(set(bad))))
+        e = T2VHipError("cooperative kernel barrier timed out (results of that step are invalid): %s"
+                        % ", ".join(sorted(set(bad))))
+        e.labels = sorted(set(bad))
+        raise e
 
 
 def err_pool_pin():

@@ -100,7 +100,7 @@ class TrainEngine(object):
             wire = (torch.bfloat16 if getattr(hparams, 'bf16_run', False) and not getattr(hparams, 'fp32_allreduce', False)
                     else None)
             self.allreduce = t2v_dist.OverlappedArenaAllReduce(
-                named, offs, self.optimizer.grads, force=bool(force_dist),
+                named, offs, self.optimizer.grads_for_allreduce(), force=bool(force_dist),
                 side_streams=lambda: self.overlap.streams(),
                 gather=self.optimizer.gather_grads, wire_dtype=wire)
         self.use_graph = bool(getattr(hparams, 'graph_step', False) if graph is None else graph)
@@ -123,6 +123,9 @@ class TrainEngine(object):
         # Prenet -> gpre).  Created before the first eager step; kernels launched there read the engine's step record too
         self.overlap = t2v_hip.Overlap()
         self.step_params.bind(extra=self.overlap.streams())
+        self._err_mark = 0
+        self._bn_snap = self._bn_bufs = None
+        self.recoveries = 0
         # graph engine: the forward pass of a step runs on SHADOW leaves (p.detach().requires_grad_(): same storage, own
         # autograd identity) that only this engine ever touches.  An autograd leaf's gradient sink (AccumulateGrad node)
         # keeps the stream that was current when it was created, and the engine routes gradients to it on that stream
@@ -192,10 +195,12 @@ class TrainEngine(object):
         """multi-rank graph mode, after the replay: one all-reduce of the arena, then clip + Adam (1/world folded in).
         no_grad: the live parameters that had no gradient when this graph was captured (FlatAdam skips them like
         torch.optim.Adam does; gather_grads() only runs at capture time, so the set travels with the graph)."""
+        self._poison()
         self.allreduce.reduce_all()
         if no_grad is not None:
             self.optimizer._no_grad = list(no_grad)
         self.optimizer.mark_gathered()
+        self.optimizer.guard = self._guard_words()
         grad_norm = self.optimizer.step()
         return out[0], out[1], out[2], grad_norm
 
@@ -223,11 +228,90 @@ class TrainEngine(object):
         self.overlap.join()             # weight gradients were produced on the deferred-work stream
         t2v_hip.stamp('grads_ready')
         if self.allreduce is not None:
+            self._poison()              # (rides in the last bucket, which finish() issues: its dead parameters never fire a hook)
             self.allreduce.finish()
             opt.mark_gathered()        # every bucket gathered its slice before it went out
+        opt.guard = self._guard_words()
         grad_norm = opt.step()
         t2v_hip.stamp('step_end')
         return loss.detach(), recon.detach(), kl.detach(), grad_norm
+
+    def _guard_words(self):
+        """the error-ledger words this step's cooperative / persistent kernels wrote so far: the fused optimiser step skips the
+        update on the device when one of them is set (a spin time-out must not reach the weights).  Multi-rank: the
+        guard is the poison slot at the tail of the gradient arena, which _poison() filled before the all-reduce — summed over
+        the ranks, so that ALL ranks skip when ONE timed out."""
+        import t2v_hip
+        if self.allreduce is not None:
+            return self.optimizer.poison_slot()[:1].view(torch.int32)
+        return t2v_hip.err_range(self._err_mark)
+
+    def _poison(self):
+        """multi-rank, before the gradient exchange: poison slot = 1.0 if any of this rank's ledger words of the step is set"""
+        import t2v_hip
+        words = t2v_hip.err_range(self._err_mark)
+        slot = self.optimizer.poison_slot()
+        if words is None:
+            slot.zero_()
+        else:
+            slot.copy_(words.ne(0).any().to(torch.float32).expand(4))
+
+    def recover(self, err):
+        """Called by the loop when check_async_errors() raised after a step.  If the time-out came from the persistent decoder
+        kernels (256 workgroups that need the whole chip to themselves: a GPU shared with another process, a communication
+        kernel holding CUs), the device skipped that step's update — weights and Adam moments are intact.  Latch the
+        launch-per-step kernels, drop the captured graphs, restore the BatchNorm running statistics (the failed forward pass
+        fed them garbage), take the optimiser's step counter back, and tell the caller to run the iteration again."""
+        import t2v_hip
+        labels = getattr(err, 'labels', None) or []
+        if not labels or not all('persistent kernel' in l for l in labels):
+            return False
+        print("Warning! persistent decoder kernels could not be co-scheduled (%s); using the launch-per-step kernels from now on"
+              % ", ".join(labels))
+        t2v_hip.DecoderCore.persistent = False
+        t2v_hip.DecoderCore.persistent_bwd = False
+        self._graphs.clear()
+        self._seen.clear()
+        if self._bn_snap is not None:
+            torch._foreach_copy_(self._bn_bufs, self._bn_snap)
+        self.optimizer.step_count = max(0, self.optimizer.step_count - 1)
+        self.recoveries += 1
+        return True
+
+    def note_good_step(self):
+        """the loop calls this after a step whose error check came back clean: one multi-tensor copy keeps a snapshot of the
+        BatchNorm running statistics for recover()"""
+        if self._bn_snap is None:
+            self._bn_bufs = [b for n, b in self.model.named_buffers() if n.endswith(('running_mean', 'running_var', 'num_batches_tracked'))]
+            self._bn_snap = [b.clone() for b in self._bn_bufs]
+        else:
+            torch._foreach_copy_(self._bn_snap, self._bn_bufs)
+
+    def step_checked(self, batch, iteration, learning_rate=None):
+        """step() + host sync + error check, with ONE automatic re-run on the launch-per-step kernels when the persistent
+        decoder kernels timed out (what reference train.py:225-230 does per iteration, loss.item() included)."""
+        import t2v_hip
+        out = self.step(batch, iteration, learning_rate)
+        err = None
+        try:
+            out[0].item()
+            t2v_hip.check_async_errors()
+        except t2v_hip.T2VHipError as e:
+            err = e
+        # every rank reads the same verdict from the device: a skipped step leaves a NaN with a known payload in grad_norm
+        # (multi-rank: the poison slot was summed over the ranks, so a time-out on ONE rank skips — and re-runs — the step on ALL)
+        skipped = (int(out[4].view(torch.int32).item()) & 0xFFFFFFFF) == self.optimizer.SKIPPED_NORM_BITS
+        if err is not None or skipped:
+            if err is None:
+                err = t2v_hip.T2VHipError("another rank's persistent decoder kernels timed out")
+                err.labels = ['decoder (persistent kernel hand-off, remote rank)']
+            if not self.recover(err):
+                raise err
+            out = self.step(batch, iteration, learning_rate)
+            out[0].item()
+            t2v_hip.check_async_errors()
+        self.note_good_step()
+        return out
 
     def _publish(self, iteration):
         """everything the kernels of this iteration read from the device record, in one upload before the first launch"""
@@ -259,6 +343,8 @@ class TrainEngine(object):
             t2v_hip.set_overlap(prev)
 
     def _step(self, batch, iteration, learning_rate):
+        import t2v_hip
+        self._err_mark = t2v_hip.err_mark()
         opt = self.optimizer
         if learning_rate is not None:
             opt.param_groups[0]['lr'] = learning_rate
@@ -465,9 +551,10 @@ def train(output_directory, log_directory, checkpoint_path, warm_start, n_gpus, 
                 train_loader.batch_sampler.set_epoch(epoch)
             for batch in train_loader:
                 start = time.perf_counter()
-                loss, recon, kl, kl_w, grad_norm = engine.step(batch, iteration, learning_rate)
+                # (syncs and checks the error ledger like the .item() of reference train.py:230; a time-out of the persistent
+                # decoder kernels re-runs the iteration once on the launch-per-step kernels)
+                loss, recon, kl, kl_w, grad_norm = engine.step_checked(batch, iteration, learning_rate)
                 reduced = (t2v_dist.reduce_tensor(loss, n_gpus) if hparams.distributed_run else loss).item()
-                t2v_hip_check()      # the .item() above synced: a cooperative-kernel timeout of this step raises here
                 if not math.isnan(reduced) and rank == 0:
                     duration = time.perf_counter() - start
                     print("Train loss {} {:.6f} Grad Norm {:.6f} {:.2f}s/it".format(

@@ -148,7 +148,7 @@ def _worker(rank, world, port, mode, out_dir):
     cur = dict(eng.model.named_parameters())
     res['dead_untouched'] = all(torch.equal(cur[n].detach(), v) for n, v in dead.items()) and len(dead) >= 4
     res['wire_bytes'] = eng.allreduce.wire_bytes()
-    res['arena_bytes'] = eng.optimizer.grads.numel() * 4
+    res['arena_bytes'] = eng.optimizer.grads_for_allreduce().numel() * 4      # gradients + the 16-byte poison slot
     res['bucket_log'] = list(eng.allreduce.launch_log)
     res['params_digest'] = float(mine.double().sum().item())
     torch.save(res, os.path.join(out_dir, 'r%d.pt' % rank))

@@ -32,7 +32,7 @@ def _run(dec, mode, mem0, mels, lens, T, bwd=False):
     return used, mel.detach(), gate.detach(), al.detach(), arena, grads, H.DecoderCore.last_bwd_mode
 
 
-@pytest.mark.parametrize("B,T_in,T,ragged", [(6, 84, 40, False), (6, 84, 25, True), (1, 5, 7, False), (2, 16, 9, True),
+@pytest.mark.parametrize("B,T_in,T,ragged", [(6, 84, 400, True), (6, 84, 40, False), (6, 84, 25, True), (1, 5, 7, False), (2, 16, 9, True),
                                              (4, 84, 12, True), (5, 130, 8, True), (6, 224, 5, True), (3, 200, 6, True),
                                              (6, 1, 4, False)])
 def test_persistent_forward_equals_launch_per_step(B, T_in, T, ragged):
@@ -96,3 +96,46 @@ def test_persistent_range_and_fallback():
     assert H.DecoderCore.last_mode == 'persistent'
     torch.cuda.synchronize()
     H.check_async_errors()
+
+
+def test_persistent_kernels_survive_a_neighbour_that_holds_cus():
+    """A 64-workgroup spinner on a side stream occupies CUs while the persistent forward / reverse pass start (a
+    communication kernel or another process on the GPU).  The 256 workgroups of a persistent launch then do not become resident
+    together: the ones that are wait for the others inside their bounded spins.  The pass must finish with the SAME bits as an
+    undisturbed one and without a time-out."""
+    import ctypes as C
+    import hparams as HP
+    import model as M
+    import t2v_hip as H
+    hp = HP.create_hparams()
+    torch.manual_seed(3)
+    dec = M.Decoder(hp).cuda().train()
+    old_drop = M.drop_rate
+    M.drop_rate = 0.0           # Prenet dropout is keyed by a per-call counter; the LSTM state dropout stays ON
+    B, T_in, T = 6, 84, 60
+    g = torch.Generator().manual_seed(5)
+    mem0 = (torch.randn(B, T_in, 512, generator=g) * 0.5).cuda()
+    mels = torch.randn(B, 80, T, generator=g).cuda()
+    lens = torch.tensor([84, 80, 71, 66, 50, 37], device='cuda')
+    H.DecoderCore.keep_last = True
+    old = (H.DecoderCore.persistent, H.DecoderCore.persistent_bwd)
+    lib = H.load_library()
+    side = torch.cuda.Stream()
+    try:
+        ref = _run(dec, True, mem0, mels, lens, T, bwd=True)
+        assert ref[0] == 'persistent' and ref[6] == 'persistent'
+        for spin_us in (300, 3000):
+            # the spinner goes first: its 64 workgroups sit on 64 CUs when the persistent launch arrives
+            H._check(lib.t2v_debug_spin(64, spin_us, C.c_void_p(side.cuda_stream)), 't2v_debug_spin')
+            got = _run(dec, True, mem0, mels, lens, T, bwd=True)
+            # ... and again in front of the reverse pass only (the forward of _run has drained the first one by then)
+            assert got[0] == 'persistent' and got[6] == 'persistent'
+            assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+            for n in ref[5]:
+                assert torch.equal(got[5][n], ref[5][n]), n
+        side.synchronize()
+    finally:
+        M.drop_rate = old_drop
+        H.DecoderCore.persistent, H.DecoderCore.persistent_bwd = old
+        H.DecoderCore.keep_last = False
+        H.DecoderCore.last_call = H.DecoderCore.last_bwd = None
