@@ -238,6 +238,15 @@ int t2v_decoder_bwd_achain2(const t2v_dec_train_persist_weights* w, const float*
                            const float* dHC, float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
                            uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
                            void* stream, void* stream_d);
+/* The preparation of that pass as a call of its own (error word, sentinel fills, the factor arrays of both cells — functions
+ * of the forward pass's saved activations alone, so a training step issues it right after the decoder forward, on a side
+ * stream, next to the Postnet), and the pass without it.  scratch / DQP / err_word: the same buffers in both calls. */
+int t2v_decoder_bwd_achain_prepare(const t2v_dec_train_bufs* s, float* DQP, float* scratch, uint32_t* err_word, int B, int T_in,
+                                   int T_out, float p_att, float p_dec, uint64_t seed, void* stream);
+int t2v_decoder_bwd_achain_prepared(const t2v_dec_train_persist_weights* w, const float* reserved, const t2v_dec_train_bufs* s,
+                           const float* dHC, float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
+                           uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
+                           void* stream, void* stream_d);
 
 /* ------------------------------------------------------------------ free-running decode
  * Decoder.inference (model.py:428-464) == the synthesizer loop (synthesizer.py:139-154): steps

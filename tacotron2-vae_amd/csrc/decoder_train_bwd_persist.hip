@@ -1487,17 +1487,18 @@ extern "C" int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, co
                                    stream_, nullptr);
 }
 
-extern "C" int t2v_decoder_bwd_achain2(const t2v_dec_train_persist_weights* w, const float* w_unused, const t2v_dec_train_bufs* s,
-                                       const float* dHC, float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
-                                       uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
-                                       void* stream_, void* stream_d_) {
-    (void)w_unused;
+// do_prepare: error word, sentinel fills, the factor arrays of both cells (functions of the forward activations alone: they may
+// run long before the reverse pass, next to the Postnet).  do_run: the pass itself.
+static int pba_launch(const t2v_dec_train_persist_weights* w, const t2v_dec_train_bufs* s,
+                      const float* dHC, float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
+                      uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
+                      void* stream_, void* stream_d_, bool do_prepare, bool do_run) {
     hipStream_t stream = (hipStream_t)stream_, stream_d = (hipStream_t)stream_d_;
-    if (!w || !s || !dHC || !DGA || !DGD || !DCTX || !DV || !DQP || !scratch || !err_word) return T2V_ERR_ARG;
+    if (!s || !DQP || !scratch || !err_word) return T2V_ERR_ARG;
+    if (do_run && (!w || !dHC || !DGA || !DGD || !DCTX || !DV)) return T2V_ERR_ARG;
     if (!t2v_decoder_bwd_persist_supported(B, T_in) || T_out < 1) return T2V_ERR_ARG;
-    if (!w->w_ih_att || !w->w_hh_att || !w->w_ih_dec || !w->w_hh_dec || !w->wq || !w->wcomb || !w->v || !s->memory || !s->XS || !s->CA ||
-        !s->CD || !s->GA || !s->GD || !s->AL || !s->S)
-        return T2V_ERR_ARG;
+    if (do_run && (!w->w_ih_att || !w->w_hh_att || !w->w_ih_dec || !w->w_hh_dec || !w->wq || !w->wcomb || !w->v)) return T2V_ERR_ARG;
+    if (!s->memory || !s->XS || !s->CA || !s->CD || !s->GA || !s->GD || !s->AL || !s->S) return T2V_ERR_ARG;
     const int S = t2v_attn_bwd_slices_(T_in);
     const size_t rowf = pb_row_bytes(B) / 4, cxf = (size_t)(B > 4 ? 32768 : 16384) / 4;
     const size_t n_gx = (size_t)T_out * rowf / 2, n_f = (size_t)T_out * rowf, n_cx = (size_t)T_out * cxf, n_dq = (size_t)T_out * B * S * 128, n_gp = n_dq;
@@ -1515,12 +1516,16 @@ extern "C" int t2v_decoder_bwd_achain2(const t2v_dec_train_persist_weights* w, c
             return t2v_check_launch();
         attr_set = true;
     }
-    (void)hipMemsetAsync(err_word, 0, sizeof(uint32_t), stream);
-    k_pb_fill<<<1024, 256, 0, stream>>>((uint4*)scratch, (2 * n_gx + n_cx + n_gp + n_ex + n_dqt) / 4);
-    k_pb_fill<<<256, 256, 0, stream>>>((uint4*)DQP, n_dq / 4);
+    if (do_prepare) {
+        (void)hipMemsetAsync(err_word, 0, sizeof(uint32_t), stream);
+        k_pb_fill<<<1024, 256, 0, stream>>>((uint4*)scratch, (2 * n_gx + n_cx + n_gp + n_ex + n_dqt) / 4);
+        k_pb_fill<<<256, 256, 0, stream>>>((uint4*)DQP, n_dq / 4);
+    }
     PBAArgs a;
-    a.w_ih_att = w->w_ih_att; a.w_hh_att = w->w_hh_att; a.w_ih_dec = w->w_ih_dec; a.w_hh_dec = w->w_hh_dec;
-    a.wq = w->wq; a.wcomb = w->wcomb; a.v = w->v;
+    if (do_run) {
+        a.w_ih_att = w->w_ih_att; a.w_hh_att = w->w_hh_att; a.w_ih_dec = w->w_ih_dec; a.w_hh_dec = w->w_hh_dec;
+        a.wq = w->wq; a.wcomb = w->wcomb; a.v = w->v;
+    }
     a.memory = s->memory; a.XS = s->XS; a.CA = s->CA; a.CD = s->CD; a.GA = s->GA; a.GD = s->GD; a.AL = s->AL; a.S = s->S;
     a.dHC = dHC; a.DGA = DGA; a.DGD = DGD; a.DCTX = DCTX; a.DV = DV;
     a.GXA = scratch; a.GXD = scratch + n_gx; a.CX = scratch + 2 * n_gx; a.GPX = scratch + 2 * n_gx + n_cx; a.EX = scratch + 2 * n_gx + n_cx + n_gp; a.DQX = DQP;
@@ -1534,7 +1539,7 @@ extern "C" int t2v_decoder_bwd_achain2(const t2v_dec_train_persist_weights* w, c
     a.B = B; a.T_in = T_in; a.T = T_out; a.S_sl = S; a.p_att = p_att; a.p_dec = p_dec; a.seed = seed;
     a.step = t2v_step_for(stream);
     a.prof = g_t2v_prof;
-    {
+    if (do_prepare) {
         const unsigned nblk = (unsigned)(((size_t)T_out * T2V_G + 255) / 256);
         k_pb_factors<<<nblk, 256, 0, stream>>>(s->GA, s->CA, FA, B, T_out, B, p_att, T2V_RNG_ATT_C, seed, a.step);
         k_pb_factors<<<nblk, 256, 0, stream>>>(s->GD, s->CD, FD, B, T_out, B, p_dec, T2V_RNG_DEC_C, seed, a.step);
@@ -1543,6 +1548,7 @@ extern "C" int t2v_decoder_bwd_achain2(const t2v_dec_train_persist_weights* w, c
         k_pb_cellpre<<<ncp, 256, 0, stream>>>(s->GA, s->CA, CPA, B, T_out, nbs, p_att, T2V_RNG_ATT_H, T2V_RNG_ATT_C, seed, a.step);
         k_pb_cellpre<<<ncp, 256, 0, stream>>>(s->GD, s->CD, CPD, B, T_out, nbs, p_dec, T2V_RNG_DEC_H, T2V_RNG_DEC_C, seed, a.step);
     }
+    if (!do_run) return t2v_check_launch();
     const size_t lds = pba_lds_bytes(B, T_in);
     if (!stream_d || stream_d == stream) {
         if (B > 4) k_achain_bwd<6><<<T2V_NWG, PB_THREADS, lds, stream>>>(a);
@@ -1563,4 +1569,27 @@ extern "C" int t2v_decoder_bwd_achain2(const t2v_dec_train_persist_weights* w, c
         k_achain_bwd_ta<4><<<NT + NA, PB_THREADS, lds, stream>>>(a);
     }
     return t2v_check_launch();
+}
+
+extern "C" int t2v_decoder_bwd_achain2(const t2v_dec_train_persist_weights* w, const float* w_unused, const t2v_dec_train_bufs* s,
+                                       const float* dHC, float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
+                                       uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
+                                       void* stream_, void* stream_d_) {
+    (void)w_unused;
+    return pba_launch(w, s, dHC, DGA, DGD, DCTX, DV, DQP, scratch, err_word, B, T_in, T_out, p_att, p_dec, seed, stream_, stream_d_, true, true);
+}
+
+// Round 4: the preparation of the reverse pass on its own (everything it needs exists when the FORWARD pass has ended) ...
+extern "C" int t2v_decoder_bwd_achain_prepare(const t2v_dec_train_bufs* s, float* DQP, float* scratch, uint32_t* err_word, int B, int T_in,
+                                              int T_out, float p_att, float p_dec, uint64_t seed, void* stream_) {
+    return pba_launch(nullptr, s, nullptr, nullptr, nullptr, nullptr, nullptr, DQP, scratch, err_word, B, T_in, T_out, p_att, p_dec, seed,
+                      stream_, nullptr, true, false);
+}
+// ... and the pass without it (same arguments as t2v_decoder_bwd_achain2; scratch / DQP / err_word as handed to _prepare)
+extern "C" int t2v_decoder_bwd_achain_prepared(const t2v_dec_train_persist_weights* w, const float* w_unused, const t2v_dec_train_bufs* s,
+                                               const float* dHC, float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
+                                               uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
+                                               void* stream_, void* stream_d_) {
+    (void)w_unused;
+    return pba_launch(w, s, dHC, DGA, DGD, DCTX, DV, DQP, scratch, err_word, B, T_in, T_out, p_att, p_dec, seed, stream_, stream_d_, false, true);
 }

@@ -70,7 +70,8 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_stamp', 't2v_debug_spin', 't2v_
            't2v_decoder_train_fwd_persistent', 't2v_decoder_train_persist_supported',
            't2v_decoder_train_persist_scratch_floats', 't2v_decoder_bwd_persist_supported',
            't2v_decoder_bwd_dchain_scratch_floats', 't2v_decoder_bwd_dchain', 't2v_decoder_bwd_achain_scratch_floats',
-           't2v_decoder_bwd_achain', 't2v_decoder_bwd_achain2')
+           't2v_decoder_bwd_achain', 't2v_decoder_bwd_achain2', 't2v_decoder_bwd_achain_prepare',
+           't2v_decoder_bwd_achain_prepared')
 
 
 def lib_path():
@@ -115,6 +116,9 @@ def load_library():
     lib.t2v_decoder_bwd_achain.argtypes = [C.POINTER(_DecTrainPersistWeights), C.c_void_p, C.POINTER(_DecTrainBufs)] + [C.c_void_p] * 8 + [
         C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]
     lib.t2v_decoder_bwd_achain2.argtypes = lib.t2v_decoder_bwd_achain.argtypes + [C.c_void_p]
+    lib.t2v_decoder_bwd_achain_prepared.argtypes = lib.t2v_decoder_bwd_achain2.argtypes
+    lib.t2v_decoder_bwd_achain_prepare.argtypes = [C.POINTER(_DecTrainBufs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                   C.c_float, C.c_float, C.c_uint64, C.c_void_p]
     lib.t2v_decoder_replay_fwd_kernels.argtypes = [C.POINTER(_DecWeights), C.POINTER(_DecTrainBufs), C.c_int,
                                                    C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_int,
                                                    C.c_void_p]
@@ -716,6 +720,7 @@ class DecoderCore(torch.autograd.Function):
     last_bwd_mode = None
     last_mode = None        # 'persistent' | 'launch-per-step' of the most recent forward chunk (bench / tests)
     last_bwd_persist = None
+    _prepared = {}          # id(XS of a chunk) -> (DQP, scratch, err word, event, stream) of an early-issued reverse-pass preparation
     last_persist = None     # keep_last: (weights, bufs, scratch, dims, tensors) of the last persistent forward, for replays
 
     @staticmethod
@@ -740,7 +745,7 @@ class DecoderCore(torch.autograd.Function):
 
     @staticmethod
     def _fwd_chunk(lib, gpre, memory, pm, lengths, packs, bias_dec, wqT, wcomb, vv, need_grad, p_att, p_dec, seed, wbf=False,
-                   raw=None):
+                   raw=None, bwd_prepare=False):
         T, B, _ = gpre.shape
         T_in = memory.shape[1]
         f32 = dict(device=gpre.device, dtype=torch.float32)
@@ -770,6 +775,21 @@ class DecoderCore(torch.autograd.Function):
             DecoderCore.last_mode = 'persistent'
             if DecoderCore.keep_last:
                 DecoderCore.last_persist = (PW, Sb, scratch, (B, T_in, T, float(p_att), float(p_dec), int(seed)), raw)
+            if need_grad and bwd_prepare and DecoderCore.use_persistent_bwd(lib, B, T_in, T):
+                # the preparation of the reverse pass (sentinel fills, factor arrays of both cells: ~150 us of launches that
+                # need nothing but this forward pass) goes out NOW, on the deferred-work stream, next to the Postnet
+                NS = lib.t2v_attn_bwd_slices(T_in)
+                DQP = torch.empty(T, B, NS, A, **f32)
+                bscr = torch.empty(lib.t2v_decoder_bwd_achain_scratch_floats(B, T_in, T), **f32)
+                errw = torch.zeros(1, device=gpre.device, dtype=torch.int32)
+                with side('w', keep=(XS, CA, CD, GA, GD)):
+                    _check(lib.t2v_decoder_bwd_achain_prepare(C.byref(Sb), _p(DQP), _p(bscr), _p(errw), B, T_in, T, float(p_att),
+                                                              float(p_dec), int(seed), _stream()), 't2v_decoder_bwd_achain_prepare')
+                    ev = torch.cuda.Event()
+                    ev.record()
+                while len(DecoderCore._prepared) >= 4:      # (forward passes whose backward never came)
+                    DecoderCore._prepared.pop(next(iter(DecoderCore._prepared)))
+                DecoderCore._prepared[id(XS)] = (DQP, bscr, errw, ev, torch.cuda.current_stream())
             return W, Sb, (gpre, memory, pm, lengths, XS, CA, CD, GA, GD, QP, AL, ACUM, S)
         _check(lib.t2v_decoder_train_fwd(C.byref(W), C.byref(Sb), B, T_in, T, float(p_att), float(p_dec),
                                          int(seed), _stream()), 't2v_decoder_train_fwd')
@@ -823,7 +843,8 @@ class DecoderCore(torch.autograd.Function):
                 g_c, m_c, pm_c = gpre[:, b0:b1].contiguous(), memory[b0:b1].contiguous(), pm[b0:b1].contiguous()
                 l_c = None if lengths is None else lengths[b0:b1].contiguous()
             chunks.append(DecoderCore._fwd_chunk(lib, g_c, m_c, pm_c, l_c, packs, bias_dec, wqT, wcomb, vv, need_grad,
-                                                 p_att, p_dec, (int(seed) + 7919 * b0) & 0x7FFFFFFFFFFFFFFF, wbf, raw))
+                                                 p_att, p_dec, (int(seed) + 7919 * b0) & 0x7FFFFFFFFFFFFFFF, wbf, raw,
+                                                 bwd_prepare=bwd_persist))
         hcs = [torch.cat((k[4][2:T + 2, :, KATT:], k[4][1:T + 1, :, H:KATT]), 2) for _, _, k in chunks]
         als = [k[10][1:].permute(1, 0, 2) for _, _, k in chunks]
         HC = hcs[0] if len(hcs) == 1 else torch.cat(hcs, 1)
@@ -877,9 +898,17 @@ class DecoderCore(torch.autograd.Function):
                 w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, wq_raw = ctx.raw
                 PW = _DecTrainPersistWeights(_p(w_ih_att), _p(w_hh_att), _p(w_ih_dec), _p(w_hh_dec), _p(bias_dec), _p(wq_raw),
                                              _p(wcomb), _p(vv))
-                DQP = torch.empty(T, B, NS, A, **f32)
-                scratch = torch.empty(lib.t2v_decoder_bwd_achain_scratch_floats(B, T_in, T), **f32)
-                errw = torch.zeros(1, device=dev, dtype=torch.int32)
+                prep = DecoderCore._prepared.pop(id(XS), None)
+                if prep is not None:
+                    DQP, scratch, errw, pev, pst = prep
+                    if pst != torch.cuda.current_stream():
+                        torch.cuda.current_stream().wait_event(pev)
+                    run_fn = lib.t2v_decoder_bwd_achain_prepared
+                else:
+                    DQP = torch.empty(T, B, NS, A, **f32)
+                    scratch = torch.empty(lib.t2v_decoder_bwd_achain_scratch_floats(B, T_in, T), **f32)
+                    errw = torch.zeros(1, device=dev, dtype=torch.int32)
+                    run_fn = lib.t2v_decoder_bwd_achain2
                 stamp('dec_bwd_begin')
                 # T2V_BWD_SPLIT=1 (opt-in): the decoder_rnn chain as a launch of its own on stream 'd' — its END is then something
                 # the two decoder_rnn weight-gradient GEMMs can wait for, and they run on the CUs it frees while the attention
@@ -892,7 +921,7 @@ class DecoderCore(torch.autograd.Function):
                 if st_d is not None:
                     with ov.side('d', keep=(dhc_c, DGD, scratch) + tuple(keep)):
                         pass        # registers the stream for the engine's join (and orders it behind this point)
-                _check(lib.t2v_decoder_bwd_achain2(C.byref(PW), None, C.byref(Sb), _p(dhc_c), _p(DGA), _p(DGD), _p(DCTX), _p(DV),
+                _check(run_fn(C.byref(PW), None, C.byref(Sb), _p(dhc_c), _p(DGA), _p(DGD), _p(DCTX), _p(DV),
                                                    _p(DQP), _p(scratch), _p(errw), B, T_in, T, p_att, p_dec,
                                                    (seed + 7919 * b0) & 0x7FFFFFFFFFFFFFFF, _stream(),
                                                    None if st_d is None else C.c_void_p(st_d.cuda_stream)), 't2v_decoder_bwd_achain2')
