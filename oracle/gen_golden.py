@@ -62,11 +62,96 @@ def digest(t):
     return [float(t.sum()), float(t.abs().sum()), float((t * t).sum())]
 
 
+def synth_fixture(m, hp, stft):
+    """The statements of the reference's `Synthesizer.synthesize` (synthesizer.py:112-160: text -> ids -> embedding ->
+    encoder.inference -> style vector (emotion-ratio mix of the centroids through fc3, or the reference encoder on a
+    reference utterance) -> add -> go frame -> stepwise prenet + decode until the gate fires or max_decoder_steps ->
+    parse_decoder_outputs -> postnet), executed here with the REAL reference modules on CPU (the class itself hard-codes
+    .cuda() and WaveGlow).  Seed-1234 weights, Prenet dropout off (R.drop_rate = 0), eval mode like `load()` leaves it.
+    Two cases: ratio mix that runs into max_decoder_steps (24), reference-audio conditioning that the reference's own stop
+    rule ends (gate bias chosen from its logit trajectory, as in (d2))."""
+    R, RT = m['model'], m['text']
+    R.drop_rate = 0.0
+    steps_before = hp.max_decoder_steps
+    text = "감정있는 한국어 목소리 생성"
+    ids = torch.from_numpy(np.array(RT.text_to_sequence(text, ['korean_cleaners']))[None, :]).long()
+    g = torch.Generator().manual_seed(11)
+    zs = torch.randn(12, 32, generator=g).numpy().astype(np.float32)
+    emotions = np.array([0, 1, 2, 3, 0, 1, 2, 3, 0, 0, 3, 1])
+    cent = [np.mean(zs[emotions == i, :], axis=0) for i in range(4)]          # neu, sad, ang, hap (synthesizer.py:107-110)
+    ratios = np.array([0.5, 0.125, 0.25, 0.125], dtype=np.float64)           # order of the call: (neu, sad, hap, ang)
+    ref_wav = (torch.clamp(0.1 * torch.randn(16000, generator=torch.Generator().manual_seed(12)), -1, 1) * 32767).to(torch.int16).numpy()
+    out = {}
+    for case in ('ratios', 'ref_audio'):
+        torch.manual_seed(hp.seed)
+        hp.max_decoder_steps = 24
+        model = R.Tacotron2(hp)
+        model.eval()
+        with torch.no_grad():
+            def run(gate_bias=None):
+                if gate_bias is not None:
+                    model.decoder.gate_layer.linear_layer.bias.fill_(gate_bias)
+                inputs = model.parse_input(ids)
+                emb = model.transcript_embedding(inputs).transpose(1, 2)
+                transcript_outputs = model.encoder.inference(emb)
+                if case == 'ref_audio':
+                    mel = stft.mel_spectrogram(torch.from_numpy(ref_wav.astype(np.float32) / hp.max_wav_value)[None])
+                    latent_vector, _, _, _ = model.vae_gst(mel)
+                    latent_vector = latent_vector.unsqueeze(1).expand_as(transcript_outputs)
+                else:
+                    lv = ratios[0] * cent[0] + ratios[1] * cent[1] + ratios[2] * cent[3] + ratios[3] * cent[2]
+                    latent_vector = model.vae_gst.fc3(torch.FloatTensor(lv))
+                encoder_outputs = transcript_outputs + latent_vector
+                decoder_input = model.decoder.get_go_frame(encoder_outputs)
+                model.decoder.initialize_decoder_states(encoder_outputs, mask=None)
+                mels, gates, aligns = [], [], []
+                while True:
+                    decoder_input = model.decoder.prenet(decoder_input)
+                    mel_output, gate_output, alignment = model.decoder.decode(decoder_input)
+                    mels += [mel_output]; gates += [gate_output]; aligns += [alignment]
+                    if torch.sigmoid(gate_output.data) > hp.gate_threshold:
+                        break
+                    if len(mels) == hp.max_decoder_steps:
+                        break
+                    decoder_input = mel_output
+                mo, go, ao = model.decoder.parse_decoder_outputs(mels, gates, aligns)
+                return mo, go, ao, mo + model.postnet(mo)
+            base = float(model.decoder.gate_layer.linear_layer.bias)
+            if case == 'ratios':
+                mo, go, ao, post = run(base - 50.0)             # never fires: the loop ends at max_decoder_steps
+                bias = base - 50.0
+            else:
+                _, gfree, _, _ = run(base - 50.0)
+                L = gfree.reshape(-1).double() + 50.0           # logits with the original bias
+                best, run_max = None, float(L[:2].max())
+                for t in range(2, 20):
+                    if float(L[t]) > run_max:
+                        if best is None or float(L[t]) - run_max > best[1]:
+                            best = (t, float(L[t]) - run_max, run_max)
+                        run_max = float(L[t])
+                assert best is not None and best[1] > 2e-3, best
+                bias = base - (float(L[best[0]]) + best[2]) / 2.0
+                mo, go, ao, post = run(bias)
+                assert mo.shape[2] == best[0] + 1, (mo.shape, best)
+        print('synthesize fixture (%s): %d frames, gate bias %.6f' % (case, mo.shape[2], bias))
+        out.update({case + '_mel': _np(mo), case + '_post': _np(post), case + '_gate': _np(go), case + '_align': _np(ao),
+                    case + '_gate_bias': np.array([bias], dtype=np.float32)})
+    np.savez_compressed(os.path.join(OUT, 'synthesize.npz'), ids=_np(ids), zs=zs, emotions=emotions, ratios=ratios,
+                        ref_wav=ref_wav, text_utf8=np.frombuffer(text.encode('utf-8'), dtype=np.uint8), **out)
+    hp.max_decoder_steps = steps_before
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     m = _refimport.load()
     R, RL, RD, RT = m['model'], m['layers'], m['data'], m['text']
     hp = m['hparams'].create_hparams()
+    if '--only-synth' in sys.argv:          # just fixture (h) (the full script takes ~3 min)
+        stft = RL.TacotronSTFT(hp.filter_length, hp.hop_length, hp.win_length, hp.n_mel_channels, hp.sampling_rate,
+                               hp.mel_fmin, hp.mel_fmax)
+        hp.p_attention_dropout = hp.p_decoder_dropout = 0.0
+        synth_fixture(m, hp, stft)
+        return
 
     # ------------------------------------------------------------------ (a) text front end KATs
     kat = [{"text": t, "ids": RT.text_to_sequence(t, ['korean_cleaners'])} for t in TEXTS]
@@ -299,6 +384,9 @@ def main():
                                 align_max=_np(al_o.max(-1).values), align_head=_np(al_o[0, :4]), align_tail=_np(al_o[0, -4:]))
     np.savez_compressed(os.path.join(OUT, 'inference_gate_stop.npz'), ids=_np(ids4), z=_np(z4),
                         **{'%s_%s' % (c, k): v for c, dct in gate_cases.items() for k, v in dct.items()})
+
+    # ------------------------------------------------------------------ (h) Synthesizer.synthesize() end to end
+    synth_fixture(m, hp, stft)
 
     # ------------------------------------------------------------------ (g) the whole koemo text front end in one hash
     import hashlib

@@ -424,7 +424,6 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                 eall[tid] = al;
                 win[15 + tid] = al;                                         // previous weights of the next frame
                 win[TW + 15 + tid] += al;                                   // cumulative weights
-                if (as == 0) a.AL[((size_t)(t + 1) * B + ab) * Tp + tid] = al;
             }
             __syncthreads();
             PD_STAMP(0, 4);
@@ -443,6 +442,8 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                 for (int u = 0; u < 8; ++u) acc += cred[u * 64 + tid];
                 pd_put(rx, xcur + pd_ctx(B) + (unsigned)(ab * 512 + 64 * as + tid), acc);
             }
+            // (the saved alignment row leaves AFTER the context hand-off: nothing sits in this CU's memory pipe in front of it)
+            if (as == 0 && tid < Tp) a.AL[((size_t)(t + 1) * B + ab) * Tp + tid] = al;
         }
         PD_STAMP(0, 5); PD_STAMP(64, 11);
         PD_RT(5);

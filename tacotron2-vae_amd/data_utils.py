@@ -64,6 +64,12 @@ class TextMelLoader(torch.utils.data.Dataset):
                     out.append(w.getnframes() // 256 + 1)
         return out
 
+    def text_lengths(self):
+        """symbol count of every entry (the decoder's T_in): the bucketed sampler keeps utterances above the persistent
+        decoder kernels' range (224 symbols) together, so that as many batches as possible stay inside it"""
+        from text import text_to_sequence
+        return [len(text_to_sequence(fields[1], self.text_cleaners)) for fields in self.audiopaths_and_text]
+
     def get_text(self, text):
         from text import text_to_sequence
         return torch.IntTensor(text_to_sequence(text, self.text_cleaners))
@@ -181,8 +187,16 @@ class BucketBatchSampler(torch.utils.data.Sampler):
     order of the batches is shuffled again.  Incomplete trailing batches are dropped (drop_last=True in the
     reference loader, train.py:62-65)."""
 
-    def __init__(self, lengths, batch_size, world_size=1, rank=0, seed=1234, window=16, shuffle=True):
+    def __init__(self, lengths, batch_size, world_size=1, rank=0, seed=1234, window=16, shuffle=True, text_lengths=None,
+                 text_cap=224):
+        """text_lengths / text_cap (round 4): the one-launch persistent decoder kernels take T_in <= 224 symbols (koemo reaches
+        555).  With text lengths given, a window is sorted by (longer than the cap?, length): the few long utterances of a
+        window share batches instead of pushing many batches over the cap.  persistent_hit_rate() reports the fraction of
+        this rank's batches that stay inside the range."""
         self.lengths = list(lengths)
+        self.text_lengths = None if text_lengths is None else list(text_lengths)
+        self.text_cap = int(text_cap)
+        assert self.text_lengths is None or len(self.text_lengths) == len(self.lengths)
         self.batch_size, self.world_size, self.rank = int(batch_size), int(world_size), int(rank)
         self.seed, self.window, self.shuffle = int(seed), int(window), bool(shuffle)
         self.epoch = 0
@@ -195,6 +209,21 @@ class BucketBatchSampler(torch.utils.data.Sampler):
     def __len__(self):
         return self.n_batches
 
+    def _key(self, i):
+        if self.text_lengths is None:
+            return (0, self.lengths[i])
+        return (1 if self.text_lengths[i] > self.text_cap else 0, self.lengths[i])
+
+    def persistent_hit_rate(self):
+        """fraction of this rank's batches (current epoch) whose longest text fits the persistent decoder kernels"""
+        if self.text_lengths is None:
+            return None
+        tot = hit = 0
+        for b in self:
+            tot += 1
+            hit += max(self.text_lengths[i] for i in b) <= self.text_cap
+        return hit / max(1, tot)
+
     def __iter__(self):
         g = torch.Generator()
         g.manual_seed(self.seed + self.epoch)
@@ -203,7 +232,7 @@ class BucketBatchSampler(torch.utils.data.Sampler):
         span = self.global_batch * self.window
         batches = []
         for lo in range(0, n, span):
-            chunk = sorted(perm[lo:lo + span], key=lambda i: self.lengths[i])
+            chunk = sorted(perm[lo:lo + span], key=self._key)
             for b in range(0, len(chunk) - self.global_batch + 1, self.global_batch):
                 batches.append(chunk[b:b + self.global_batch])
         batches = batches[:self.n_batches]

@@ -52,8 +52,10 @@ _GROUPS = {
 #                     (train.TrainEngine).  ON by default: a shape is captured the third time it is seen (at most 8
 #                     shapes), so fixed / bucketed shapes replay and ragged batches whose shapes never repeat simply
 #                     stay eager; `python train.py` then runs what bench.py measures
-#   fp32_allreduce  : under bf16_run the gradient exchange is bf16 (57.7 MB per step); True keeps it fp32 (115.5 MB)
-_EXTENSIONS = dict(device_frontend=False, bucket_batches=False, bf16_run=False, graph_step=True, fp32_allreduce=False)
+#   fp32_allreduce  : True (default, like the reference: distributed.py reduces fp32): the gradient exchange stays fp32 under
+#                     bf16_run as well (115.5 MB per step); False opts in to the bf16 wire format (57.7 MB; every slice is
+#                     rounded to bf16 and summed over the ranks in bf16: relative error ~ sqrt(world) * 2^-9 per element)
+_EXTENSIONS = dict(device_frontend=False, bucket_batches=False, bf16_run=False, graph_step=True, fp32_allreduce=True)
 
 
 def _coerce(old, text):

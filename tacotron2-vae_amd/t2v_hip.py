@@ -1072,7 +1072,8 @@ class InferenceSession(object):
 
     def __init__(self, memory, pm, lengths, w_ih_att, w_hh_att, b_att, w_ih_dec, w_hh_dec, b_dec, wq, loc_conv,
                  loc_dense, v, prenet_w0, prenet_w1, proj_w, proj_b, gate_w, gate_b, max_steps):
-        limit_host_threads()
+        if 'T2V_HOST_THREADS' in os.environ:        # (an inference session no longer throttles the host application)
+            limit_host_threads()
         lib = _require_gpu(memory, pm, w_ih_att)
         B, T_in, _ = memory.shape
         if B > 8:
@@ -1161,10 +1162,12 @@ def limit_host_threads(n=None):
     WHOLE process — the thread that feeds the GPU included — is frozen for the rest of each period.  Measured: eager steps
     13.7, 13.7, 71 ms, ... (every ~100 ms an ~60 ms freeze; 33–39 ms per step on average) against a steady 13.7 ms with 4
     threads; the replayed-graph step 14.07 -> 13.43 ms.  Data-loader workers are separate processes and unaffected."""
+    prev = torch.get_num_threads()
     if n is None:
         n = int(os.environ.get('T2V_HOST_THREADS', '2' if int(os.environ.get('WORLD_SIZE', '1')) > 1 else '4'))
-    if n > 0 and torch.get_num_threads() > n:
+    if n > 0 and prev > n:
         torch.set_num_threads(n)
+    return prev         # (the training engine restores it in close(): the cap belongs to the training loop, not to the host app)
 
 
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2

@@ -86,7 +86,7 @@ class TrainEngine(object):
 
     def __init__(self, hparams, world_size=1, graph=None, force_dist=False):
         import t2v_hip
-        t2v_hip.limit_host_threads()
+        self._host_threads = t2v_hip.limit_host_threads()
         self.hparams = hparams
         self.model = load_model(hparams)
         self.criterion = Tacotron2Loss_VAE(hparams)
@@ -145,6 +145,9 @@ class TrainEngine(object):
         sp, self.step_params = self.step_params, None
         if sp is not None:
             t2v_hip.drop_step_params(sp)
+        prev, self._host_threads = getattr(self, '_host_threads', None), None
+        if prev is not None and prev > torch.get_num_threads():
+            torch.set_num_threads(prev)         # the host-thread cap belonged to this engine's loop
 
     def __del__(self):
         try:
@@ -384,8 +387,10 @@ class TrainEngine(object):
         if entry is None:
             n = self._seen.get(key, 0)
             self._seen[key] = n + 1
-            if n < self.GRAPH_AFTER or len(self._graphs) >= self.MAX_GRAPHS:
+            if n < self.GRAPH_AFTER:
+                self._trim_seen()
                 return None
+            self._evict_graphs()
             static_buf = torch.empty(lay.nbytes, dtype=torch.uint8, device='cuda')
             lay.upload(batch, into=static_buf)
             x, y = lay.views(static_buf)
@@ -393,6 +398,7 @@ class TrainEngine(object):
             entry = self._graphs[key] = (graph, static_buf, out, no_grad)
         else:
             lay.upload(batch, into=entry[1])
+        self._graphs[key] = self._graphs.pop(key)       # most recently used last
         entry[0].replay()
         return self._after_replay(entry[2], entry[3])
 
@@ -404,16 +410,36 @@ class TrainEngine(object):
         if entry is None:
             n = self._seen.get(key, 0)
             self._seen[key] = n + 1
-            if n < self.GRAPH_AFTER or len(self._graphs) >= self.MAX_GRAPHS:
+            if n < self.GRAPH_AFTER:
+                self._trim_seen()
                 return None
+            self._evict_graphs()
             entry = self._capture(x, y, iteration)
             self._graphs[key] = entry
+        self._graphs[key] = self._graphs.pop(key)       # most recently used last
         graph, static_in, static_out, no_grad = entry
         for dst, src in zip(static_in, tensors):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         graph.replay()
         return self._after_replay(static_out, no_grad)
+
+    MAX_SEEN = 4096
+
+    def _evict_graphs(self):
+        """a ragged loader (shapes that recur now and then) must not pin MAX_GRAPHS private pools for ever — the
+        least recently replayed graph (and its activation pool) goes when a new shape wants a slot"""
+        while len(self._graphs) >= self.MAX_GRAPHS:
+            old = next(iter(self._graphs))
+            del self._graphs[old]
+            self._seen.pop(old, None)
+
+    def _trim_seen(self):
+        """... and the shape-history dictionary is bounded (one key per distinct batch shape otherwise, for the whole run)"""
+        if len(self._seen) > self.MAX_SEEN:
+            for k in list(self._seen)[:len(self._seen) // 2]:
+                if k not in self._graphs:
+                    del self._seen[k]
 
     def _after_replay(self, static_out, no_grad):
         """the captured graph writes its scalars (loss, recon, kl[, grad_norm]) into static tensors that the NEXT replay
@@ -484,7 +510,7 @@ def prepare_dataloaders(hparams):
     if getattr(hparams, 'bucket_batches', False):
         world, rank = (dist.get_world_size(), dist.get_rank()) if hparams.distributed_run else (1, 0)
         batch_sampler = BucketBatchSampler(trainset.lengths(), hparams.batch_size, world_size=world, rank=rank,
-                                           seed=hparams.seed)
+                                           seed=hparams.seed, text_lengths=trainset.text_lengths())
         loader = DataLoader(trainset, num_workers=0, batch_sampler=batch_sampler, pin_memory=False,
                             collate_fn=collate_fn)
     else:
@@ -549,6 +575,9 @@ def train(output_directory, log_directory, checkpoint_path, warm_start, n_gpus, 
             print("Epoch: {}".format(epoch))
             if hasattr(getattr(train_loader, 'batch_sampler', None), 'set_epoch'):
                 train_loader.batch_sampler.set_epoch(epoch)
+                hit = train_loader.batch_sampler.persistent_hit_rate()
+                if hit is not None and rank == 0:
+                    print("Batches inside the persistent decoder kernels' range (T_in <= 224): {:.1f} %".format(100.0 * hit))
             for batch in train_loader:
                 start = time.perf_counter()
                 # (syncs and checks the error ledger like the .item() of reference train.py:230; a time-out of the persistent

@@ -58,7 +58,7 @@ def _worker(rank, world, port, mode, out_dir):
     D.init_distributed(backend='gloo', timeout_s=300)
     graph = mode in ('graph', 'ragged')
     bf16 = mode == 'bf16'
-    extra = ',bf16_run=True' if bf16 else ''
+    extra = ',bf16_run=True,fp32_allreduce=False' if bf16 else ''      # (the bf16 wire format is opt-in since round 4)
     hp_ref = HP.create_hparams("batch_size=3,anneal_function=constant" + extra)
     hp = HP.create_hparams("batch_size=3,anneal_function=constant,distributed_run=True" + extra)
 

@@ -88,3 +88,24 @@ def test_hparams_extensions_do_not_leak_into_reference_values():
     assert hp.device_frontend is True and hp.bucket_batches is True and hp.bf16_run is False
     assert 'device_frontend' not in hp.values() and hp.values()['batch_size'] == 4
     assert set(hp.extensions()) == {'device_frontend', 'bucket_batches', 'bf16_run', 'graph_step', 'fp32_allreduce'}
+
+
+def test_bucket_sampler_keeps_long_texts_together():
+    """round 4: with text lengths given, utterances above the persistent decoder kernels' range (224 symbols) share batches
+    instead of being spread over many; every utterance is still drawn exactly once per epoch"""
+    import random
+    from data_utils import BucketBatchSampler
+    rnd = random.Random(3)
+    n, bs = 960, 6
+    lengths = [rnd.randint(100, 800) for _ in range(n)]
+    texts = [rnd.randint(230, 555) if rnd.random() < 0.1 else rnd.randint(10, 200) for _ in range(n)]
+    plain = BucketBatchSampler(lengths, bs, seed=5)
+    aware = BucketBatchSampler(lengths, bs, seed=5, text_lengths=texts)
+    seen = sorted(i for b in aware for i in b)
+    assert seen == list(range(n))
+    hit_aware = aware.persistent_hit_rate()
+    hit_plain = sum(max(texts[i] for i in b) <= 224 for b in plain) / len(plain)
+    n_long = sum(t > 224 for t in texts)
+    assert plain.persistent_hit_rate() is None
+    assert hit_aware > hit_plain + 0.2
+    assert hit_aware >= 1.0 - (n_long / bs + n // (bs * 16) + 1) / (n // bs)       # at most one mixed batch per window

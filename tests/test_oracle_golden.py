@@ -237,6 +237,36 @@ def test_oracle_gate_terminated_inference(model_sd, golden_dir, case):
     assert (al.max(-1).values - torch.from_numpy(g[case + '_align_max'])).abs().max() < tol
 
 
+@pytest.mark.parametrize("case", ['ratios', 'ref_audio'])
+def test_oracle_synthesize_call_sequence(model_sd, golden_dir, case):
+    """the reference's `Synthesizer.synthesize` statements (synthesizer.py:112-160; fixture (h) of
+    oracle/gen_golden.py, produced by the real reference) restated with the oracle: emotion-ratio mix of the centroids through
+    fc3 (run ends at max_decoder_steps = 24) and reference-audio conditioning (the stop rule ends the run)."""
+    import t2v_oracle as O
+    _, _, sd0 = model_sd
+    g = np.load(os.path.join(golden_dir, 'synthesize.npz'))
+    sd = {k: v.clone() for k, v in sd0.items()}
+    sd['decoder.gate_layer.linear_layer.bias'] = torch.from_numpy(g[case + '_gate_bias']).clone()
+    ids = torch.from_numpy(g['ids'])
+    with torch.no_grad():
+        enc = O.encoder_forward(sd, ids, torch.tensor([ids.shape[1]]), training=False)
+        if case == 'ref_audio':
+            mel_ref = O.mel_spectrogram(torch.from_numpy(g['ref_wav'].astype(np.float32) / 32768.0)[None])
+            style, _, _, _ = O.vae_gst_forward(sd, mel_ref, training=False)
+            memory = enc + style[:, None]
+        else:
+            zs, em, r = g['zs'], g['emotions'], g['ratios']
+            cent = [zs[em == i].mean(0) for i in range(4)]                     # neu, sad, ang, hap
+            mix = r[0] * cent[0] + r[1] * cent[1] + r[2] * cent[3] + r[3] * cent[2]      # call order: (neu, sad, hap, ang)
+            memory = enc + (torch.FloatTensor(mix) @ sd['vae_gst.fc3.weight'].t() + sd['vae_gst.fc3.bias'])
+        mel, gate, al = O.decoder_inference(sd, memory, max_steps=24)
+        post = mel + O.postnet_forward(sd, mel, training=False)
+    want = torch.from_numpy(g[case + '_post'])
+    assert post.shape == want.shape and (case == 'ratios') == (want.shape[2] == 24)
+    assert (post - want).abs().max() < 2e-4
+    assert (al - torch.from_numpy(g[case + '_align'])).abs().max() < 1e-5
+
+
 def test_koemo_text_front_end_hash(golden_dir):
     """every unique sentence of the koemo filelists through OUR text front end, one SHA-256 against the reference's
     (needs the read-only reference's filelists: data, present in the build container only)"""

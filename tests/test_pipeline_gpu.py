@@ -124,6 +124,46 @@ def test_synthesizer_drop_in(tmp_path):
     assert sr == 16000 and got['shape'] == (1, 80, mel3.size(2)) and len(data) == 256 * mel3.size(2)
 
 
+@pytest.mark.parametrize("case", ['ratios', 'ref_audio'])
+def test_synthesize_matches_the_reference_call_sequence(tmp_path, golden_dir, case):
+    """SURVEY 8f-2 end to end: `Synthesizer.synthesize()` against the statements of the reference's
+    own `synthesize` (synthesizer.py:112-160) executed by the REAL reference on CPU (tests/golden/synthesize.npz, written by
+    oracle/gen_golden.py (h)): emotion-ratio mix of the centroids through fc3 — the loop runs into max_decoder_steps — and
+    reference-audio conditioning — the reference's own stop rule ends the run."""
+    import hparams as HP
+    import model as M
+    import train as TR
+    from scipy.io.wavfile import write
+    from synthesizer import Synthesizer
+    g = np.load(os.path.join(golden_dir, 'synthesize.npz'))
+    text = bytes(g['text_utf8']).decode('utf-8')
+    hp = HP.create_hparams("max_decoder_steps=24")
+    old = M.drop_rate
+    M.drop_rate = 0.0
+    try:
+        torch.manual_seed(hp.seed)
+        model = TR.load_model(hp)
+        ck = str(tmp_path / 'ckpt_5')
+        torch.save({'iteration': 5, 'state_dict': {k: v.detach().clone() for k, v in model.state_dict().items()},
+                    'optimizer': {}, 'learning_rate': 1e-3}, ck)
+        fl = str(tmp_path / 'refs_test.txt')
+        np.savez(Synthesizer.centroid_cache_path(ck, fl), zs=g['zs'], emotions=g['emotions'])      # the reference's cache file
+        syn = Synthesizer(hp).load(ck, filelist_path=fl)
+        em = g['emotions']
+        assert np.allclose(syn.neu, g['zs'][em == 0].mean(0)) and np.allclose(syn.hap, g['zs'][em == 3].mean(0))
+        with torch.no_grad():
+            syn.model.decoder.gate_layer.bias.fill_(float(g[case + '_gate_bias'][0]))
+        ref = str(tmp_path / 'ref.wav')
+        write(ref, 16000, g['ref_wav'])
+        post, align = syn.synthesize(text, None, case == 'ref_audio', ref, tuple(float(r) for r in g['ratios']))
+        want_post, want_align = torch.from_numpy(g[case + '_post']), torch.from_numpy(g[case + '_align'])
+        assert post.shape == want_post.shape and align.shape == want_align.shape, (post.shape, want_post.shape)
+        assert (post.cpu() - want_post).abs().mean() < 1e-4 and (post.cpu() - want_post).abs().max() < 5e-4
+        assert (align.cpu() - want_align).abs().max() < 2e-5
+    finally:
+        M.drop_rate = old
+
+
 def test_bucket_order_on_the_real_model():
     """1-rank RCCL group on the real model: the Postnet slice of the gradient arena is issued from a hook while
     backward is still running, before the decoder slice, before the encoder slice."""
