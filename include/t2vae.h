@@ -226,6 +226,9 @@ int t2v_decoder_bwd_dchain(const float* w_hh_dec, const float* dHC, const float*
  * w: the struct of the persistent forward (bias_dec unused); s: the forward pass's arena (gpre, QP unused);
  * scratch: t2v_decoder_bwd_achain_scratch_floats(B, T_in, T_out) floats, 16-byte aligned; DQP 16-byte aligned. */
 long t2v_decoder_bwd_achain_scratch_floats(int B, int T_in, int T_out);
+/* position slices per item of the ONE-LAUNCH reverse pass (second-to-last dimension of its DQP (T,B,S,128) and DV (B,S,128)):
+ * 1 up to 96 symbols (one workgroup per item), else t2v_attn_bwd_slices(T_in) */
+int t2v_decoder_bwd_persist_slices(int T_in);
 int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, const float* reserved, const t2v_dec_train_bufs* s,
                            const float* dHC, float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
                            uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,

@@ -18,6 +18,12 @@
 #include "t2v_common.h"
 #include "t2v_kernels.h"
 
+#ifndef PBA_WHOLE_ITEM
+#define PBA_WHOLE_ITEM 0      // 1 (measurement): ONE attention workgroup per item up to 96 symbols instead of 16-position slices
+#endif
+#ifndef PBA_DQ_DIRECT
+#define PBA_DQ_DIRECT 0       // 1 (measurement): the attention_rnn workgroups sum the slices' partial dq rows themselves
+#endif
 #define PB_THREADS 512
 #define PB_MAXB 6
 #define PB_MAXT 224
@@ -559,12 +565,20 @@ struct PBAArgs {
 #define PB_CX_ROW_BYTES(NB) ((NB) > 4 ? 32768u : 16384u)
 
 __host__ __device__ static inline int pba_na(int NL);
-template <int JS>
+// JS: positions per slice (16 / 32: position-split slices on 4 waves; 96 (round 4): ONE workgroup per item on all 8 waves for
+// T_in <= 96 — no partial dq rows to sum, no window partials to exchange: one dependent hand-off less per reverse step).
+// NWV: waves that compute (4 or 8).  GPW: floats per channel of a slice's window-partial row in GPX.
+template <int JS, int NWV>
 __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds, const int b, const int s, const int NB) {
     constexpr int NJT = JS / 16;
     constexpr int PW = JS + 30;
+    constexpr int GPW = PW <= 64 ? 64 : 128;
+    constexpr int NRG = 2 * NWV;                     // row groups of 32 lanes in the dpre loop
+    constexpr int DPS = JS == 96 ? JS + 17 : JS + 1; // row stride of dpT: = 17 mod 32, the four k-rows of an MFMA operand read land in
+                                                     // disjoint banks (JS + 1 = 97 = 1 mod 32 made that read 4-way conflicted)
+    static_assert(JS % NRG == 0 && JS % NWV == 0 && PW <= GPW, "slice geometry");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool act = tid < 256;
+    const bool act = tid < 64 * NWV;
     const int g = lane >> 4, c16 = lane & 15;
     const int B = a.B, Tp = a.T_in, T = a.T, S = a.S_sl, j0 = s * JS;
     const int Tcap = (Tp + 15) & ~15;
@@ -577,34 +591,43 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
     float* gcum = alf + Tcap;                 // [Tcap] running cumulative-weights gradient (this workgroup's copy)
     float* dctx = gcum + Tcap;                // [512]
     float* de = dctx + T2V_E;                 // [JS]
-    float* red = de + JS;                     // [1 + JS/4][16]
-    float* dpT = red + (1 + JS / 4) * 16;     // [128][JS+1]
-    float* Tl = dpT + T2V_A * (JS + 1);       // [64][JS+1]
-    float* rq = Tl + 64 * (JS + 1);           // [8][128]
-    float* rv = rq + 8 * T2V_A;               // [8][128]
-    int* flag = (int*)(rv + 8 * T2V_A);
+    float* red = de + JS;                     // [1 + JS/NWV][4 NWV]
+    float* dpT = red + (1 + JS / NWV) * 4 * NWV;     // [128][JS+1]
+    float* Tl = dpT + T2V_A * DPS;            // [64][JS+1]
+    float* rq = Tl + 64 * (JS + 1);           // [NRG][128] (also: the 32 row partials of the dot product)
+    float* rv = rq + NRG * T2V_A;             // [NRG][128]
+    int* flag = (int*)(rv + NRG * T2V_A);
+    // (8-wave form: the W_comb^T operand tile of the location backward lives in LDS, not in 32 registers per thread — next to the
+    // 96 registers of memory rows they spilled)
+    constexpr bool AREG_LDS = NWV == 8;
+    float* wcs = (float*)(flag + 40);         // [64 rows (c,k)][128] when AREG_LDS
     const __amdgpu_buffer_rsrc_t rC = pb_rsrc(a.CX), rQ = pb_rsrc(a.DQX), rP = pb_rsrc(a.GPX), rQT = pb_rsrc(a.DQT);
     // ---- operands resident for the whole pass
-    const int d4 = tid & 31, rg = (tid >> 5) & 7;
-    float4 m0[JS / 4], m1[JS / 4];
-    float areg[32];
+    const int d4 = tid & 31, rg = (tid >> 5) & (NRG - 1);
+    float4 m0[JS / NWV], m1[JS / NWV];
+    float areg[AREG_LDS ? 1 : 32];
     float4 vd4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (act) {
 #pragma unroll
-        for (int r = 0; r < JS / 4; ++r) {
-            const int jl = wave + 4 * r;
+        for (int r = 0; r < JS / NWV; ++r) {
+            const int jl = wave + NWV * r;
             const float* mrow = a.memory + ((size_t)b * Tp + j0 + (jl < nown ? jl : 0)) * T2V_E + lane * 4;
             m0[r] = *(const float4*)mrow;
             m1[r] = *(const float4*)(mrow + 256);
         }
-        const float4* wp = (const float4*)(a.wcomb + T2V_A * 64 + (16 * wave + c16) * 128 + 32 * g);
+        if (!AREG_LDS) {
+            const float4* wp = (const float4*)(a.wcomb + T2V_A * 64 + (16 * (wave & 3) + c16) * 128 + 32 * g);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float4 w4 = wp[u];
-            areg[4 * u + 0] = w4.x; areg[4 * u + 1] = w4.y; areg[4 * u + 2] = w4.z; areg[4 * u + 3] = w4.w;
+            for (int u = 0; u < 8; ++u) {
+                const float4 w4 = wp[u];
+                areg[4 * u + 0] = w4.x; areg[4 * u + 1] = w4.y; areg[4 * u + 2] = w4.z; areg[4 * u + 3] = w4.w;
+            }
         }
         vd4 = *(const float4*)(a.v + 4 * d4);
     }
+    if (AREG_LDS)
+        for (int i = tid; i < 64 * 128; i += PB_THREADS)          // row stride 132, 33 floats per k-group: conflict-free operand reads
+            wcs[(i >> 7) * 132 + ((i & 127) >> 5) * 33 + (i & 31)] = a.wcomb[T2V_A * 64 + i];
     for (int j = tid; j < Tcap; j += PB_THREADS) gcum[j] = 0.f;
     if (tid == 0) flag[0] = 1;
     float dvacc = 0.f;                          // tid < 128: running dv[tid] of this slice
@@ -614,18 +637,26 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
     unsigned long long tprev_ = __builtin_readcyclecounter();
 
     for (int t = T - 1; t >= 0; --t) {
+        // (thread-derived indices are recomputed per step from an opaque copy — see the attention_rnn role: hoisted, they are
+        // spilled next to the 96 registers of memory rows, and every reload is a drain of the wave's memory queue)
+        int tid_op = threadIdx.x;
+        asm volatile("" : "+v"(tid_op));
+        const int tid = tid_op, lane = tid & 63, wave = tid >> 6;
+        const bool act = tid < 64 * NWV;
+        const int g = lane >> 4, c16 = lane & 15;
+        const int d4 = tid & 31, rg = (tid >> 5) & (NRG - 1);
         PBA_STAMP(blockIdx.x == 0, 8);
         // ---- operands that do not wait for the context gradient: tanh outputs, alpha(t), ctx(t), window partials of step t+1
-        float4 sreg[JS / 8];
+        float4 sreg[JS / NRG];
         float2 ctx2 = make_float2(0.f, 0.f);
         if (act) {
             const float* sp = a.S + (((size_t)t * B + b) * Tp + j0) * T2V_A + 4 * d4;
 #pragma unroll
-            for (int i = 0; i < JS / 8; ++i) {
-                const int jl = rg + 8 * i;
+            for (int i = 0; i < JS / NRG; ++i) {
+                const int jl = rg + NRG * i;
                 sreg[i] = *(const float4*)(sp + (size_t)min(jl, nown - 1) * T2V_A);
             }
-            ctx2 = *(const float2*)(a.XS + ((size_t)(t + 1) * B + b) * T2V_XW + T2V_H + 2 * tid);
+            if (tid < 256) ctx2 = *(const float2*)(a.XS + ((size_t)(t + 1) * B + b) * T2V_XW + T2V_H + 2 * tid);
         }
         float dot_g = 0.f;
         for (int j = tid; j < Tp; j += PB_THREADS) {
@@ -635,12 +666,12 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
                 for (int sp2 = lo; sp2 <= hi; ++sp2) {
                     const int jj = j - sp2 * JS + 15;
                     if (jj < 0 || jj >= PW) continue;
-                    const unsigned off = (unsigned)((((t + 1) * B + b) * S + sp2) * 128 + jj) * 4u;
+                    const unsigned off = (unsigned)((((t + 1) * B + b) * S + sp2) * (2 * GPW) + jj) * 4u;
                     unsigned x0, x1;
                     int spins = 0;
                     for (;;) {          // published at the end of the previous reverse step: almost always there
                         x0 = pb_ld4(rP, off);
-                        x1 = pb_ld4(rP, off + 256u);
+                        x1 = pb_ld4(rP, off + 4u * GPW);
                         if (x0 != PB_SENT && x1 != PB_SENT) break;
                         __builtin_amdgcn_s_sleep(1);
                         if (++spins > PB_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -697,20 +728,20 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
         // ---- dot = dctx·ctx_t + sum_j alpha_j (Gprev_j + Gcum_j); dalpha of the own positions = dctx·memory_j + G_j
         {
             float dotp = dot_g;
-            if (act) dotp += dctx[2 * tid] * ctx2.x + dctx[2 * tid + 1] * ctx2.y;
+            if (tid < 256) dotp += dctx[2 * tid] * ctx2.x + dctx[2 * tid + 1] * ctx2.y;
             dotp = row16_sum(dotp);
             // 32 row partials (8 waves x 4 rows): waves 4..7 carry only their share of dot_g
             if (c16 == 0) rq[4 * wave + g] = dotp;
             if (act) {
                 const float4 d0 = *(const float4*)(dctx + lane * 4), d1 = *(const float4*)(dctx + 256 + lane * 4);
 #pragma unroll
-                for (int r = 0; r < JS / 4; ++r) {
+                for (int r = 0; r < JS / NWV; ++r) {
                     float acc = m0[r].x * d0.x;
                     acc = fmaf(m0[r].y, d0.y, acc); acc = fmaf(m0[r].z, d0.z, acc); acc = fmaf(m0[r].w, d0.w, acc);
                     acc = fmaf(m1[r].x, d1.x, acc); acc = fmaf(m1[r].y, d1.y, acc);
                     acc = fmaf(m1[r].z, d1.z, acc); acc = fmaf(m1[r].w, d1.w, acc);
                     acc = row16_sum(acc);
-                    if (c16 == 0) red[(1 + r) * 16 + 4 * wave + g] = acc;
+                    if (c16 == 0) red[(1 + r) * 4 * NWV + 4 * wave + g] = acc;
                 }
             }
         }
@@ -719,8 +750,8 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
             float dsum = 0.f;
 #pragma unroll
             for (int u = 0; u < 32; ++u) dsum += rq[u];
-            const int wv = tid & 3, r = tid >> 2;
-            const float* rr = red + (1 + r) * 16 + 4 * wv;
+            const int wv = tid % NWV, r = tid / NWV;              // position tid = wv + NWV r
+            const float* rr = red + (1 + r) * 4 * NWV + 4 * wv;
             const float dalv = ((rr[0] + rr[1]) + (rr[2] + rr[3])) + gfull0[j0 + min(tid, nown - 1)] + gfull1[j0 + min(tid, nown - 1)];
             de[tid] = tid < nown ? alf[j0 + tid] * (dalv - dsum) : 0.f;
         }
@@ -729,8 +760,8 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
         if (act) {
             float4 dq = make_float4(0.f, 0.f, 0.f, 0.f), dv = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int i = 0; i < JS / 8; ++i) {
-                const int jl = rg + 8 * i;
+            for (int i = 0; i < JS / NRG; ++i) {
+                const int jl = rg + NRG * i;
                 const float dej = de[jl];
                 const float4 sv = sreg[i];
                 float4 dp;
@@ -739,8 +770,8 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
                 sreg[i] = dp;           // the saved copy (operand of the d W_comb / d memory_layer products) leaves AFTER the hand-off
                 dq.x += dp.x; dq.y += dp.y; dq.z += dp.z; dq.w += dp.w;
                 dv.x = fmaf(dej, sv.x, dv.x); dv.y = fmaf(dej, sv.y, dv.y); dv.z = fmaf(dej, sv.z, dv.z); dv.w = fmaf(dej, sv.w, dv.w);
-                dpT[(4 * d4 + 0) * (JS + 1) + jl] = dp.x; dpT[(4 * d4 + 1) * (JS + 1) + jl] = dp.y;
-                dpT[(4 * d4 + 2) * (JS + 1) + jl] = dp.z; dpT[(4 * d4 + 3) * (JS + 1) + jl] = dp.w;
+                dpT[(4 * d4 + 0) * DPS + jl] = dp.x; dpT[(4 * d4 + 1) * DPS + jl] = dp.y;
+                dpT[(4 * d4 + 2) * DPS + jl] = dp.z; dpT[(4 * d4 + 3) * DPS + jl] = dp.w;
             }
             *(float4*)&rq[rg * T2V_A + 4 * d4] = dq;
             *(float4*)&rv[rg * T2V_A + 4 * d4] = dv;
@@ -753,10 +784,15 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
                 q = ((p[0] + p[T2V_A]) + (p[2 * T2V_A] + p[3 * T2V_A])) + ((p[4 * T2V_A] + p[5 * T2V_A]) + (p[6 * T2V_A] + p[7 * T2V_A]));
                 const float* p2 = rv + tid;
                 vv = ((p2[0] + p2[T2V_A]) + (p2[2 * T2V_A] + p2[3 * T2V_A])) + ((p2[4 * T2V_A] + p2[5 * T2V_A]) + (p2[6 * T2V_A] + p2[7 * T2V_A]));
+                if (NRG > 8) {
+                    p += 8 * T2V_A; p2 += 8 * T2V_A;
+                    q += ((p[0] + p[T2V_A]) + (p[2 * T2V_A] + p[3 * T2V_A])) + ((p[4 * T2V_A] + p[5 * T2V_A]) + (p[6 * T2V_A] + p[7 * T2V_A]));
+                    vv += ((p2[0] + p2[T2V_A]) + (p2[2 * T2V_A] + p2[3 * T2V_A])) + ((p2[4 * T2V_A] + p2[5 * T2V_A]) + (p2[6 * T2V_A] + p2[7 * T2V_A]));
+                }
             }
             pb_st4(rQ, (unsigned)(((t * B + b) * S + s) * T2V_A + tid) * 4u, q);       // partial row (the d W_q GEMM reads them later)
             dvacc += vv;
-            if (s == 0) {
+            if (s == 0 && !PBA_DQ_DIRECT) {
                 // Round 4: slice 0 of an item sums the S partial rows in slice order and publishes ONE row per item.  The ≥ 79
                 // attention_rnn workgroups used to pull all B*S partial rows each (18 KB per workgroup and step through the
                 // ≈ 11 B/cycle a CU gets from beyond its L2: 2.7 us from "published" to "gathered"); now they pull B rows (3 KB)
@@ -792,29 +828,32 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
         if (act) {      // dpre rows: 8 KB of stores that must not sit in this CU's memory pipe in front of the dq words above
             float* sp = a.S + (((size_t)t * B + b) * Tp + j0) * T2V_A + 4 * d4;
 #pragma unroll
-            for (int i = 0; i < JS / 8; ++i) {
-                const int jl = rg + 8 * i;
+            for (int i = 0; i < JS / NRG; ++i) {
+                const int jl = rg + NRG * i;
                 if (jl < nown) *(float4*)(sp + (size_t)jl * T2V_A) = sreg[i];
             }
         }
         // ---- through the fused location filter on MFMA: T[(c,k)][jl] = sum_d W_comb[d][(c,k)] dpre[jl][d], K = 128
         if (act) {
 #pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) {
+            for (int jt = (wave >> 2); jt < NJT; jt += NWV / 4) {     // (8 waves: waves 4..7 take the odd position tiles)
                 f32x4 ac4[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) ac4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int st = 0; st < 32; ++st) ac4[st & 3] = mfma16x4(areg[st], dpT[(4 * st + g) * (JS + 1) + 16 * jt + c16], ac4[st & 3]);
+                for (int st = 0; st < 32; ++st) {
+                    const float av = AREG_LDS ? wcs[(16 * (wave & 3) + c16) * 132 + 33 * g + st] : areg[AREG_LDS ? 0 : st];
+                    ac4[st & 3] = mfma16x4(av, dpT[(4 * st + g) * DPS + 16 * jt + c16], ac4[st & 3]);
+                }
                 const f32x4 acc = (ac4[0] + ac4[1]) + (ac4[2] + ac4[3]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Tl[(16 * wave + 4 * g + r) * (JS + 1) + 16 * jt + c16] = acc[r];
+                for (int r = 0; r < 4; ++r) Tl[(16 * (wave & 3) + 4 * g + r) * (JS + 1) + 16 * jt + c16] = acc[r];
             }
         }
         __syncthreads();
         // ---- gradient wrt the alignment window of this slice -> the slices of step t-1 (their window partials)
-        if (tid < 2 * 64 && t > 0) {
-            const int c = tid >> 6, jj = tid & 63;
+        if (tid < 2 * GPW && t > 0) {
+            const int c = tid / GPW, jj = tid % GPW;
             if (jj < PW) {
                 float tt[T2V_KS];
 #pragma unroll
@@ -827,7 +866,7 @@ __device__ __forceinline__ void pba_attention_role(const PBAArgs& a, float* lds,
 #pragma unroll
                 for (int k = 0; k + 3 < T2V_KS; k += 4) { acc0 += tt[k]; acc1 += tt[k + 1]; acc2 += tt[k + 2]; acc3 += tt[k + 3]; }
                 acc0 += tt[28]; acc1 += tt[29]; acc2 += tt[30];
-                pb_st4(rP, (unsigned)(((t * B + b) * S + s) * 128 + c * 64 + jj) * 4u, (acc0 + acc1) + (acc2 + acc3));
+                pb_st4(rP, (unsigned)(((t * B + b) * S + s) * (2 * GPW) + c * GPW + jj) * 4u, (acc0 + acc1) + (acc2 + acc3));
             }
         }
         __syncthreads();
@@ -1162,7 +1201,12 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
     float* dump = eps + 256 + 64;                          // [8 waves][64] landing zone of the prefetch DMAs (never read)
     const int u0 = (ja * T2V_H) / NA, nu = ((ja + 1) * T2V_H) / NA - u0;      // <= 14 units
     const int c0 = (ja * T2V_E) / NA, nc = ((ja + 1) * T2V_E) / NA - c0;      // <= 7 context columns
-    const __amdgpu_buffer_rsrc_t rA = pb_rsrc(a.GXA), rC = pb_rsrc(a.CX), rQT = pb_rsrc(a.DQT), rE = pb_rsrc(a.EX);
+    const __amdgpu_buffer_rsrc_t rA = pb_rsrc(a.GXA), rC = pb_rsrc(a.CX), rE = pb_rsrc(a.EX);
+#if PBA_DQ_DIRECT
+    const __amdgpu_buffer_rsrc_t rQ = pb_rsrc(a.DQX);
+#else
+    const __amdgpu_buffer_rsrc_t rQT = pb_rsrc(a.DQT);
+#endif
     const __amdgpu_buffer_rsrc_t rDC = pb_rsrc(a.DCTX), rDG = pb_rsrc(a.DGA);
     // columns: [0, NUA) W_hh_att[k][U], [NUA, NUA + NCA) W_ih_att[k][256 + C]
     pb_f32x2 w[NCT][PB_KJ / 2];
@@ -1331,6 +1375,38 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
             PBA_STAMP(ja == 0, 13);
         }
         // ---- P4: dq(t) of every item (sum of the position slices' partial rows)
+#if PBA_DQ_DIRECT
+        // (measurement variant: the attention_rnn workgroups sum the S partial rows of every item themselves — one hop less than
+        // through slice 0, but B*S*512 bytes per workgroup and step instead of B*512)
+        if (tid >= 320 && tid < 320 + B * 32) {
+            const int i = tid - 320, b = i >> 5, q = i & 31;
+            const unsigned off = (unsigned)(((t * B + b) * S) * T2V_A + 4 * q) * 4u;
+            for (int n = 0; n < napQ; n += 8) __builtin_amdgcn_s_sleep(8);
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+            int rounds = 0;
+            for (;;) {
+                constexpr int SMAX = PB_MAXT / 16;
+                f32x4 x[SMAX];
+#pragma unroll
+                for (int k = 0; k < SMAX; ++k)
+                    if (k < S) x[k] = pb_ld16(rQ, off + (unsigned)(k * T2V_A) * 4u);
+                bool ok = true;
+                sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < SMAX; ++k)
+                    if (k < S) { ok = ok && pb_ok(x[k][0]) && pb_ok(x[k][1]) && pb_ok(x[k][2]) && pb_ok(x[k][3]); sum += x[k]; }
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++rounds > PB_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    flag[0] = 0;
+                    break;
+                }
+            }
+            napQ = t2v_adapt_nap(napQ, rounds);
+            *(f32x4*)(dqs + b * T2V_A + 4 * q) = sum;
+        }
+#else
         if (tid >= 320 && tid < 320 + B * 32) {
             const int i = tid - 320, b = i >> 5, q = i & 31;
             const unsigned off = (unsigned)((t * B + b) * T2V_A + 4 * q) * 4u;
@@ -1351,6 +1427,7 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
             napQ = t2v_adapt_nap(napQ, rounds);
             *(f32x4*)(dqs + b * T2V_A + 4 * q) = sum;
         }
+#endif
         __syncthreads();
         if (flag[0] != 1) return;
         PBA_STAMP(ja == 0, 4);
@@ -1410,7 +1487,7 @@ __global__ __launch_bounds__(PB_THREADS) void k_achain_bwd(PBAArgs a) {
     // (-DPBA_ONLY=1..4 builds ONE role into the kernel: `hipcc -Rpass-analysis=kernel-resource-usage` then reports that role's
     // own register pressure — the combined kernel always shows the maximum over the roles; tools/dbg/role_regs.sh)
 #if defined(PBA_ONLY) && PBA_ONLY == 1
-    pba_attention_role<16>(a, lds, wg / S, wg % S, NB);
+    if (PBA_WHOLE_ITEM) pba_attention_role<96, 8>(a, lds, wg / S, wg % S, NB); else pba_attention_role<16, 4>(a, lds, wg / S, wg % S, NB);
 #elif defined(PBA_ONLY) && PBA_ONLY == 2
     pba_attention_rnn_role<NB, 12, 6>(a, lds, wg - NT, NA);
 #elif defined(PBA_ONLY) && PBA_ONLY == 3
@@ -1419,10 +1496,12 @@ __global__ __launch_bounds__(PB_THREADS) void k_achain_bwd(PBAArgs a) {
     pba_decoder_role<NB>(a, lds, wg - NT - NA, ND);
 #else
     if (wg < NT) {
-        if (a.T_in <= 128) pba_attention_role<16>(a, lds, wg / S, wg % S, NB);
-        else pba_attention_role<32>(a, lds, wg / S, wg % S, NB);
+        if (PBA_WHOLE_ITEM && a.T_in <= 96) pba_attention_role<96, 8>(a, lds, wg / S, wg % S, NB);
+        else if (a.T_in <= 128) pba_attention_role<16, 4>(a, lds, wg / S, wg % S, NB);
+        else pba_attention_role<32, 4>(a, lds, wg / S, wg % S, NB);
     } else if (wg < NT + NA) {
-        if (NA >= 86) pba_attention_rnn_role<NB, 12, 6>(a, lds, wg - NT, NA);
+        if (NA >= 114) pba_attention_rnn_role<NB, 9, 5>(a, lds, wg - NT, NA);
+        else if (NA >= 86) pba_attention_rnn_role<NB, 12, 6>(a, lds, wg - NT, NA);
         else pba_attention_rnn_role<NB, PBA_NUA, PBA_NCA>(a, lds, wg - NT, NA);
     } else {
         pba_decoder_role<NB>(a, lds, wg - NT - NA, ND);
@@ -1441,10 +1520,12 @@ __global__ __launch_bounds__(PB_THREADS) void k_achain_bwd_ta(PBAArgs a) {
     const int wg = blockIdx.x;
     const int S = a.S_sl, NT = a.B * S, NL = T2V_NWG - NT, NA = pba_na(NL);
     if (wg < NT) {
-        if (a.T_in <= 128) pba_attention_role<16>(a, lds, wg / S, wg % S, NB);
-        else pba_attention_role<32>(a, lds, wg / S, wg % S, NB);
+        if (PBA_WHOLE_ITEM && a.T_in <= 96) pba_attention_role<96, 8>(a, lds, wg / S, wg % S, NB);
+        else if (a.T_in <= 128) pba_attention_role<16, 4>(a, lds, wg / S, wg % S, NB);
+        else pba_attention_role<32, 4>(a, lds, wg / S, wg % S, NB);
     } else {
-        if (NA >= 86) pba_attention_rnn_role<NB, 12, 6>(a, lds, wg - NT, NA);
+        if (NA >= 114) pba_attention_rnn_role<NB, 9, 5>(a, lds, wg - NT, NA);
+        else if (NA >= 86) pba_attention_rnn_role<NB, 12, 6>(a, lds, wg - NT, NA);
         else pba_attention_rnn_role<NB, PBA_NUA, PBA_NCA>(a, lds, wg - NT, NA);
     }
 }
@@ -1455,10 +1536,19 @@ __global__ __launch_bounds__(PB_THREADS) void k_dchain_bwd_free(PBAArgs a) {
     pba_decoder_role<NB>(a, lds, blockIdx.x, ND);
 }
 
+// slice geometry of the one-launch reverse pass: ONE workgroup per item up to 96 symbols, else the launch-per-step geometry
+// (PBA_WHOLE_ITEM: measured at B = 6, T_in = 84 — 11.0 us per reverse step against 10.4 with six 16-position slices per item:
+// the hand-off through slice 0 disappears (-1.4 us), but ONE workgroup needs 3.3 us from "context gradient seen" to "dq
+// published" (1.3 with slices) and 11 us for its whole loop, so it becomes the chain.  Parity-green, kept for the record.)
+static inline int pba_js(int T_in) { return (PBA_WHOLE_ITEM && T_in <= 96) ? 96 : t2v_attn_bwd_js(T_in); }
+static inline int pba_slices(int T_in) { const int js = pba_js(T_in); return (T_in + js - 1) / js; }
+extern "C" int t2v_decoder_bwd_persist_slices(int T_in) { return T_in < 1 ? 0 : pba_slices(T_in); }
+
 static size_t pba_lds_bytes(int B, int T_in) {
     const size_t lrole = (B > 4 ? 6 : 4) * T2V_G + 6 * 1024 + 192 + 128 + 512 + 16 * T2V_A + 8 * T2V_A + 2048 + 256 + 64 + 512;
-    const size_t Tcap = (size_t)((T_in + 15) / 16) * 16, JS = T_in <= 128 ? 16 : 32;
-    const size_t trole = 4 * Tcap + T2V_E + JS + (1 + JS / 4) * 16 + T2V_A * (JS + 1) + 64 * (JS + 1) + 2 * 8 * T2V_A + 40;
+    const size_t Tcap = (size_t)((T_in + 15) / 16) * 16, JS = (size_t)pba_js(T_in), NWV = JS == 96 ? 8 : 4;
+    const size_t trole = 4 * Tcap + T2V_E + JS + (1 + JS / NWV) * 4 * NWV + T2V_A * (JS == 96 ? JS + 17 : JS + 1) + 64 * (JS + 1) +
+                         2 * 2 * NWV * T2V_A + 40 + (NWV == 8 ? 64 * 132 : 0);
     return sizeof(float) * (lrole > trole ? lrole : trole);
 }
 
@@ -1466,12 +1556,12 @@ static size_t pba_lds_bytes(int B, int T_in) {
 // The dq partials (T,B,S,128) are an OUTPUT (the caller reduces them into d W_q) and are passed separately.
 extern "C" long t2v_decoder_bwd_achain_scratch_floats(int B, int T_in, int T_out) {
     if (B < 1 || B > PB_MAXB || T_in < 1 || T_in > PB_MAXT || T_out < 1) return 0;
-    const size_t S = (size_t)t2v_attn_bwd_slices_(T_in);
+    const size_t S = (size_t)pba_slices(T_in), gpw = pba_js(T_in) + 30 <= 64 ? 64 : 128;
     const size_t cx = (size_t)T_out * (B > 4 ? 32768 : 16384) / 4;
     // (dc, dh) rows of both cells (half a gate row each) + context rows + window partials + E + the two factor arrays
     const size_t cp = 2 * (size_t)T_out * T2V_H * (B > 4 ? 6 : 4) * 8;   // cell-layout factors of both cells (k_pb_cellpre)
     const size_t dqt = (size_t)T_out * 8 * T2V_A;                         // dq(t) summed over the slices (B padded to 8: 16-byte rows)
-    return (long)((size_t)T_out * pb_row_bytes(B) / 4 + cx + (size_t)T_out * B * S * 128 + (size_t)T_out * B * T2V_KATT + dqt +
+    return (long)((size_t)T_out * pb_row_bytes(B) / 4 + cx + (size_t)T_out * B * S * 2 * gpw + (size_t)T_out * B * T2V_KATT + dqt +
                   2 * (size_t)T_out * pb_row_bytes(B) / 4 + cp);
 }
 
@@ -1499,9 +1589,11 @@ static int pba_launch(const t2v_dec_train_persist_weights* w, const t2v_dec_trai
     if (!t2v_decoder_bwd_persist_supported(B, T_in) || T_out < 1) return T2V_ERR_ARG;
     if (do_run && (!w->w_ih_att || !w->w_hh_att || !w->w_ih_dec || !w->w_hh_dec || !w->wq || !w->wcomb || !w->v)) return T2V_ERR_ARG;
     if (!s->memory || !s->XS || !s->CA || !s->CD || !s->GA || !s->GD || !s->AL || !s->S) return T2V_ERR_ARG;
-    const int S = t2v_attn_bwd_slices_(T_in);
+    const int S = pba_slices(T_in);
+    const size_t gpw = pba_js(T_in) + 30 <= 64 ? 64 : 128;
     const size_t rowf = pb_row_bytes(B) / 4, cxf = (size_t)(B > 4 ? 32768 : 16384) / 4;
-    const size_t n_gx = (size_t)T_out * rowf / 2, n_f = (size_t)T_out * rowf, n_cx = (size_t)T_out * cxf, n_dq = (size_t)T_out * B * S * 128, n_gp = n_dq;
+    const size_t n_gx = (size_t)T_out * rowf / 2, n_f = (size_t)T_out * rowf, n_cx = (size_t)T_out * cxf, n_dq = (size_t)T_out * B * S * 128;
+    const size_t n_gp = (size_t)T_out * B * S * 2 * gpw;
     const size_t n_ex = (size_t)T_out * B * T2V_KATT, n_dqt = (size_t)T_out * 8 * T2V_A;
     if (((uintptr_t)scratch & 15) || ((uintptr_t)DQP & 15) || n_gx * 4 >= 0x7fffffffull || n_dq * 4 >= 0x7fffffffull) return T2V_ERR_ARG;
     if (pba_lds_bytes(B, T_in) > PB_LDS_MAX) return T2V_ERR_ARG;

@@ -71,7 +71,7 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_stamp', 't2v_debug_spin', 't2v_
            't2v_decoder_train_persist_scratch_floats', 't2v_decoder_bwd_persist_supported',
            't2v_decoder_bwd_dchain_scratch_floats', 't2v_decoder_bwd_dchain', 't2v_decoder_bwd_achain_scratch_floats',
            't2v_decoder_bwd_achain', 't2v_decoder_bwd_achain2', 't2v_decoder_bwd_achain_prepare',
-           't2v_decoder_bwd_achain_prepared')
+           't2v_decoder_bwd_achain_prepared', 't2v_decoder_bwd_persist_slices')
 
 
 def lib_path():
@@ -116,6 +116,7 @@ def load_library():
     lib.t2v_decoder_bwd_achain.argtypes = [C.POINTER(_DecTrainPersistWeights), C.c_void_p, C.POINTER(_DecTrainBufs)] + [C.c_void_p] * 8 + [
         C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]
     lib.t2v_decoder_bwd_achain2.argtypes = lib.t2v_decoder_bwd_achain.argtypes + [C.c_void_p]
+    lib.t2v_decoder_bwd_persist_slices.argtypes = [C.c_int]
     lib.t2v_decoder_bwd_achain_prepared.argtypes = lib.t2v_decoder_bwd_achain2.argtypes
     lib.t2v_decoder_bwd_achain_prepare.argtypes = [C.POINTER(_DecTrainBufs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                    C.c_float, C.c_float, C.c_uint64, C.c_void_p]
@@ -778,7 +779,7 @@ class DecoderCore(torch.autograd.Function):
             if need_grad and bwd_prepare and DecoderCore.use_persistent_bwd(lib, B, T_in, T):
                 # the preparation of the reverse pass (sentinel fills, factor arrays of both cells: ~150 us of launches that
                 # need nothing but this forward pass) goes out NOW, on the deferred-work stream, next to the Postnet
-                NS = lib.t2v_attn_bwd_slices(T_in)
+                NS = lib.t2v_decoder_bwd_persist_slices(T_in)
                 DQP = torch.empty(T, B, NS, A, **f32)
                 bscr = torch.empty(lib.t2v_decoder_bwd_achain_scratch_floats(B, T_in, T), **f32)
                 errw = torch.zeros(1, device=gpre.device, dtype=torch.int32)
@@ -888,6 +889,8 @@ class DecoderCore(torch.autograd.Function):
             DGA = torch.empty(T, B, G4, **f32)
             DGD = torch.empty(T, B, G4, **f32)
             DCTX = torch.empty(T, B, E, **f32)
+            if packB_att is None:       # the one-launch reverse pass has its own slice geometry (one workgroup per item up to 96 symbols)
+                NS = lib.t2v_decoder_bwd_persist_slices(T_in)
             DV = torch.empty(B, NS, A, **f32)
             W = _DecWeights(_p(packF_att), _p(packF_dec), _p(packB_att), _p(packB_dec), None, _p(bias_dec),
                             _p(wqT), _p(wcomb), _p(vv), int(bool(ctx.wbf)))
