@@ -389,8 +389,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
                 __syncthreads();
                 PT_STAMP(wg == NT && t == T / 2, 17);
                 if (wave == 0) {
-                    float hd = 0.f, csav = 0.f;
-                    f32x4 sav = {0.f, 0.f, 0.f, 0.f};
+                    float hd = 0.f;
                     if (cell_on) {
                         float s[4];
 #pragma unroll
@@ -404,9 +403,13 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
                         if (t > 0) cprev *= t2v_drop_scale(seed, T2V_RNG_ATT_C, t - 1, idx, a.p_att);
                         const float c = gf * cprev + gi * gg;
                         cst[tid] = c;
-                        sav = f32x4{gi, gf, gg, go};
-                        csav = c;
+                        a.CA[((size_t)(t + 1) * B + cb) * T2V_H + U] = c;
+                        if (a.GA) {
+                            float* gs = a.GA + ((size_t)t * B + cb) * T2V_G + U;
+                            gs[0] = gi; gs[T2V_H] = gf; gs[2 * T2V_H] = gg; gs[3 * T2V_H] = go;
+                        }
                         hd = go * tanhf_(c) * t2v_drop_scale(seed, T2V_RNG_ATT_H, t, idx, a.p_att);
+                        a.XS[((size_t)(t + 1) * B + cb) * T2V_XW + U] = hd;
                     }
                     // publish FIRST (the write-through store is what attention(t) waits for): lane (u, plane) sends the 4
                     // items of its plane as one 16-byte store; the saved activations follow
@@ -420,15 +423,6 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
                     }
                     if (lane < PT_MAXU * NP && pu < nu) pt_st16(rG, grow + (unsigned)(pp * T2V_XW + u0 + pu) * 16u, v4);
                     PT_WALL(wg == NT && t == T / 2, 20);
-                    if (cell_on) {      // (round 4: really AFTER the publish — six scattered stores per cell thread in front of it
-                        // delayed the landing of the row every attention workgroup waits for)
-                        a.CA[((size_t)(t + 1) * B + cb) * T2V_H + U] = csav;
-                        if (a.GA) {
-                            float* gs = a.GA + ((size_t)t * B + cb) * T2V_G + U;
-                            gs[0] = sav[0]; gs[T2V_H] = sav[1]; gs[2 * T2V_H] = sav[2]; gs[3 * T2V_H] = sav[3];
-                        }
-                        a.XS[((size_t)(t + 1) * B + cb) * T2V_XW + U] = hd;
-                    }
                 }
             }
             PT_STAMP(wg == NT && t == T / 2, 1);
@@ -441,8 +435,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
                 pt_reduce_store<NB>(accD, red);
                 __syncthreads();
                 if (wave == 0) {
-                    float hd = 0.f, csav = 0.f;
-                    f32x4 sav = {0.f, 0.f, 0.f, 0.f};
+                    float hd = 0.f;
                     if (cell_on) {
                         float s[4];
 #pragma unroll
@@ -457,9 +450,13 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
                         if (tt > 0) cprev *= t2v_drop_scale(seed, T2V_RNG_DEC_C, tt - 1, idx, a.p_dec);
                         const float c = gf * cprev + gi * gg;
                         cst[32 + tid] = c;
-                        sav = f32x4{gi, gf, gg, go};
-                        csav = c;
+                        a.CD[((size_t)t * B + cb) * T2V_H + U] = c;
+                        if (a.GD) {
+                            float* gs = a.GD + ((size_t)tt * B + cb) * T2V_G + U;
+                            gs[0] = gi; gs[T2V_H] = gf; gs[2 * T2V_H] = gg; gs[3 * T2V_H] = go;
+                        }
                         hd = go * tanhf_(c) * t2v_drop_scale(seed, T2V_RNG_DEC_H, tt, idx, a.p_dec);
+                        a.XS[((size_t)(t + 1) * B + cb) * T2V_XW + T2V_KATT + U] = hd;
                     }
                     const int pu = lane / NP, pp = lane - pu * NP;
                     f32x4 v4;
@@ -470,15 +467,6 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
                         v4[i] = bb < B ? x : 0.f;
                     }
                     if (t < T && lane < PT_MAXU * NP && pu < nu) pt_st16(rG, grow + (unsigned)(pp * T2V_XW + T2V_KATT + u0 + pu) * 16u, v4);
-                    if (cell_on) {      // saved activations after the hand-off
-                        const int tt = t - 1;
-                        a.CD[((size_t)t * B + cb) * T2V_H + U] = csav;
-                        if (a.GD) {
-                            float* gs = a.GD + ((size_t)tt * B + cb) * T2V_G + U;
-                            gs[0] = sav[0]; gs[T2V_H] = sav[1]; gs[2 * T2V_H] = sav[2]; gs[3 * T2V_H] = sav[3];
-                        }
-                        a.XS[((size_t)(t + 1) * B + cb) * T2V_XW + T2V_KATT + U] = hd;
-                    }
                 }
             } else if (wave == 0) {
                 // t = 0: h_dec(-1) = 0 (XS row 1 was cleared by the reset launch)
@@ -629,11 +617,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
         PT_STAMP(wg == 0 && t == T / 2, 13);
         // ---- partial energies of this slice
         const unsigned exw = (unsigned)(((t * B + ab) * 8 + as) * Tcap) * 4u;
-        float4 svk[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int jt = wave + 8 * i;
-            svk[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (16 * jt < Tp) {
                 const f32x4 acc = lacc[i];
                 const int jp = 16 * jt + c16;
@@ -645,14 +631,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
                 esum += __shfl_xor(esum, 16, 64);
                 esum += __shfl_xor(esum, 32, 64);
                 if (g == 0 && jp < Tp) pt_st4(rE, exw + 4u * (unsigned)jp, esum);
-                svk[i] = sv;
-            }
-        }
-        if (a.S) {      // (round 4) the saved tanh rows leave AFTER the partial energies the other seven slices wait for
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int jt = wave + 8 * i, jp = 16 * jt + c16;
-                if (16 * jt < Tp && jp < Tp) *(float4*)(a.S + (((size_t)t * B + ab) * Tp + jp) * T2V_A + 16 * as + 4 * g) = svk[i];
+                if (a.S && jp < Tp) *(float4*)(a.S + (((size_t)t * B + ab) * Tp + jp) * T2V_A + 16 * as + 4 * g) = sv;
             }
         }
         PT_STAMP(wg == 0 && t == T / 2, 10);
@@ -711,12 +690,15 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
             ssum = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
         }
         const float al = e0v * (1.0f / ssum);
-        float cumk = 0.f;
         if (tid < Tp) {
             eall[tid] = al;
             win[15 + tid] = al;                                        // previous weights of the next step
-            cumk = win[TW + 15 + tid] + al;                            // cumulative weights
-            win[TW + 15 + tid] = cumk;
+            const float cum = win[TW + 15 + tid] + al;                 // cumulative weights
+            win[TW + 15 + tid] = cum;
+            if (as == 0) {
+                a.AL[((size_t)(t + 1) * B + ab) * Tp + tid] = al;
+                a.ACUM[((size_t)(t + 1) * B + ab) * Tp + tid] = cum;
+            }
         }
         __syncthreads();
         PT_STAMP(wg == 0 && t == T / 2, 11);
@@ -734,10 +716,6 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
             for (int u = 0; u < 8; ++u) acc += cred[u * 64 + tid];
             pt_st4(rG, grow + (unsigned)(mypl * T2V_XW + T2V_H + 64 * as + tid) * 16u + 4u * (unsigned)myw, acc);
             a.XS[((size_t)(t + 1) * B + ab) * T2V_XW + T2V_H + 64 * as + tid] = acc;       // (after the publish)
-        }
-        if (as == 0 && tid < Tp) {          // saved weights: after the publish as well
-            a.AL[((size_t)(t + 1) * B + ab) * Tp + tid] = al;
-            a.ACUM[((size_t)(t + 1) * B + ab) * Tp + tid] = cumk;
         }
         PT_WALL(wg == 0 && t == T / 2, 22);
         PT_STAMP(wg == 0 && t == T / 2, 12);

@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, 'libt2vae_hip.so')
+# (T2V_LIB: another build of the same library — A/B measurements of two kernel variants on ONE GPU box, tools/dbg/ab_lib.sh)
+_LIB_PATH = os.environ.get('T2V_LIB') or os.path.join(_HERE, 'libt2vae_hip.so')
 _lib = None
 
 H, E, PRE, A, F_LOC, KS, XW, KATT, KATT_INF, G4 = 1024, 512, 256, 128, 32, 31, 2560, 1536, 1792, 4096
