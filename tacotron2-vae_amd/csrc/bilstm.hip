@@ -95,12 +95,18 @@ __global__ __launch_bounds__(256) void k_bilstm_fwd(BiLstmFwdArgs a) {
             const int U = j * BL_UNITS + (BL_NT * wave + tt) * 4 + g;
             if (bvalid) {
                 float hnew = hbuf[b][U];                       // frozen once the sequence has ended
+                float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, c = 0.f;
                 if (active) {
-                    const float gi = sigmoidf_(acc[0] + gxv[tt][0]), gf = sigmoidf_(acc[1] + gxv[tt][1]);
-                    const float gg = tanhf_(acc[2] + gxv[tt][2]), go = sigmoidf_(acc[3] + gxv[tt][3]);
-                    const float c = gf * cst[tt] + gi * gg;
+                    gi = sigmoidf_(acc[0] + gxv[tt][0]); gf = sigmoidf_(acc[1] + gxv[tt][1]);
+                    gg = tanhf_(acc[2] + gxv[tt][2]); go = sigmoidf_(acc[3] + gxv[tt][3]);
+                    c = gf * cst[tt] + gi * gg;
                     cst[tt] = c;
                     hnew = go * tanhf_(c);
+                }
+                // the hand-off first (round 4: the granule every workgroup of this direction polls must not sit behind six
+                // scattered stores in this CU's memory pipe), the saved activations after it
+                bl_put(hx_w + (size_t)b * BL_H + U, hnew, (unsigned)step + 1u);
+                if (active) {
                     a.y[((size_t)b * a.T + t) * (2 * BL_H) + dir * BL_H + U] = hnew;
                     if (a.gates) {
                         float* gs = a.gates + (((size_t)dir * a.B + b) * a.T + t) * BL_G + U;
@@ -108,7 +114,6 @@ __global__ __launch_bounds__(256) void k_bilstm_fwd(BiLstmFwdArgs a) {
                         a.cells[(((size_t)dir * a.B + b) * a.T + t) * BL_H + U] = c;
                     }
                 }
-                bl_put(hx_w + (size_t)b * BL_H + U, hnew, (unsigned)step + 1u);
             }
         }
         if (step + 1 == a.T) break;
@@ -243,8 +248,10 @@ __global__ __launch_bounds__(256) void k_bilstm_bwd(BiLstmBwdArgs a) {
             df = dct * cprev * gf * (1.f - gf);
             dgg = dct * gi * (1.f - gg * gg);
             dcrec = dct * gf;
-            float* o = a.dg + idx * BL_G + U;
-            o[0] = di; o[BL_H] = df; o[2 * BL_H] = dgg; o[3 * BL_H] = dob;
+            if (step == 0) {
+                float* o = a.dg + idx * BL_G + U;
+                o[0] = di; o[BL_H] = df; o[2 * BL_H] = dgg; o[3 * BL_H] = dob;
+            }
         }
         if (live) { dgl[bb][uu] = di; dgl[bb][16 + uu] = df; dgl[bb][32 + uu] = dgg; dgl[bb][48 + uu] = dob; }
         __syncthreads();
@@ -270,6 +277,10 @@ __global__ __launch_bounds__(256) void k_bilstm_bwd(BiLstmBwdArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) bl_put(dst + 16 * tt + r, acc[tt][r], tag);
             }
+        }
+        if (on) {       // the saved gate gradients leave AFTER the hand-off (round 4)
+            float* o = a.dg + idx * BL_G + U;
+            o[0] = di; o[BL_H] = df; o[2 * BL_H] = dgg; o[3 * BL_H] = dob;
         }
         __syncthreads();        // dgl is rewritten by the next iteration
     }

@@ -11,6 +11,7 @@
 // The forward epilogue also emits per-channel partial sums / sums of squares of the conv output
 // (BatchNorm training statistics, biased variance over B*T incl. padded frames — Appendix B-3)
 // so BN needs no extra pass over Y.
+#include <stdlib.h>
 #include "t2v_common.h"
 #include "t2v_kernels.h"
 
@@ -623,6 +624,7 @@ static inline int conv5_dw_splits(int B, int Cin, int T, int Cout) {
 }
 
 static inline int conv5_pick_bn(int T, int B, int M) {
+    if (const char* e = getenv("T2V_CONV_BN")) { const int v = atoi(e); if (v == 32 || v == 48 || v == 64 || v == 80 || v == 96) return v; }
     const int cands[5] = {32, 48, 64, 80, 96};
     int best = 80;
     long best_cost = -1;
