@@ -6,6 +6,7 @@
 // 64x64x32 block tile, 256 threads (2x2 waves, one 32x32 accumulator each), operands staged k-major in
 // LDS, next tile's global loads in flight during the MFMAs.  Threads run along whichever index of an
 // operand is contiguous in memory so the staging loads are coalesced.
+#include <stdlib.h>
 #include "t2v_common.h"
 #include "t2v_kernels.h"
 
@@ -590,7 +591,10 @@ static int gemm_f32_impl(const float* A, long sAi, long sAk, const float* B, lon
     a.kz_chunk = 0; a.part = nullptr; a.nbatch = 1; a.sAb = a.sBb = a.sCb = 0; a.nsub = 1; a.sAs = a.sBs = 0; a.bias_row = 0;
     const bool akc = sAk == 1, bkc = sBk == 1;
     if (gemm_big_ok(a)) {
-        const bool wide = gemm_big_waste(M, N, 128) <= gemm_big_waste(M, N, 64) + 1e-6;
+        // (T2V_GEMM_NARROW=1, measurement: always the 128x64 tile — twice the tiles, so a launch that shares CUs with long
+        // small-grid kernels balances itself instead of waiting for its slowest single-tile workgroup)
+        static const int narrow = getenv("T2V_GEMM_NARROW") ? atoi(getenv("T2V_GEMM_NARROW")) : 0;
+        const bool wide = !narrow && gemm_big_waste(M, N, 128) <= gemm_big_waste(M, N, 64) + 1e-6;
         const int BN = wide ? 128 : 64;
         dim3 gb((N + BN - 1) / BN, (M + GB_BM - 1) / GB_BM);
 #define T2V_BIG(AK, BK)                                                             \
