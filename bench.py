@@ -188,13 +188,69 @@ def frontend_bench(B=6, n_samples=102144, reps=20, big=True):
 def _in_situ_durations():
     """per-kernel average durations of a traced steady-state step (rocprofv3 --kernel-trace over graph replays of the same
     command, committed under profiles/ by tools/round_profile.sh): the in-situ counterpart of the replay timings below"""
-    for fn in ('r03_kernel_durations.json', 'r02_kernel_durations.json'):
+    for fn in ('r04_kernel_durations.json', 'r03_kernel_durations.json', 'r02_kernel_durations.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', fn)) as f:
                 return json.load(f), 'profiles/' + fn
         except Exception:
             pass
     return {}, None
+
+
+def _steady_state_rows():
+    """{kernel name without 'void ' and arguments: (launches per step, ms per step)} of profiles/r04_steady_state.txt"""
+    import re
+    rows = {}
+    with open(os.path.join(ROOT, 'profiles', 'r04_steady_state.txt')) as f:
+        for l in f.read().split('\n')[2:]:
+            t = l.split()
+            m = re.search(r'(k_\w+(?:<[^>]*>)?)', l)
+            if m is None or len(t) < 4:
+                continue
+            try:
+                c, ms = float(t[-3]), float(t[-2])
+            except ValueError:
+                continue
+            k = m.group(1)
+            rows[k] = (rows.get(k, (0, 0))[0] + c, rows.get(k, (0, 0))[1] + ms)
+    return rows
+
+
+def _whole_step_counters(ms_per_step):
+    """what the step as a whole does to the two roofs, from the committed PMC passes of the same code (profiles/r04_pmc_*.json,
+    tools/pmc_fetch_size.sh / pmc_mfma.sh: separate rocprofv3 --pmc runs) and the traced launches per step: bytes of 128-byte
+    lines fetched per step (FETCH_SIZE x 2048, calibrated for polled loads in profiles/r04_fetch_calib.txt) over the kernels the
+    PMC pass lists, and the time-weighted MFMA-busy fraction over the whole step"""
+    res = {}
+    try:
+        rows = _steady_state_rows()
+
+        def launches(key):          # "k_conv5_fwd<5>" matches that instantiation, "k_gemm_f32_big" every instantiation
+            return sum(c for k, (c, _) in rows.items() if k == key or k.split('<')[0] == key)
+
+        def ms(key):
+            return sum(m for k, (_, m) in rows.items() if k == key or k.split('<')[0] == key)
+    except Exception:
+        return res
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r04_pmc_fetch_size.json')) as f:
+            fs = json.load(f)["kernels"]
+        tot = sum(e["corrected_bytes_per_launch"] * launches(k) for k, e in fs.items())
+        res["measured_fetch_bytes_per_step"] = int(tot)
+        res["measured_fetch_frac_of_hbm_peak"] = round(tot / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        res["measured_fetch_kernels"] = sorted(fs)
+        res["measured_fetch_source"] = "profiles/r04_pmc_fetch_size.json x launches/step of profiles/r04_steady_state.txt"
+    except Exception:
+        pass
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r04_pmc_mfma.json')) as f:
+            mf = json.load(f)["kernels"]
+        busy = sum(e["mfma_busy_frac"] * ms(k) for k, e in mf.items() if "mfma_busy_frac" in e)
+        res["mfma_busy_frac_over_step"] = round(busy / ms_per_step, 4)
+        res["mfma_busy_source"] = "profiles/r04_pmc_mfma.json x ms/step of profiles/r04_steady_state.txt"
+    except Exception:
+        pass
+    return res
 
 
 def roofline_table(B, T_in, T, reps=3):
@@ -264,12 +320,15 @@ def roofline_table(B, T_in, T, reps=3):
             # what does bound it (tools/micro/hop_latency.hip, tools/dbg/persist_bwd_prof.py): a CU pulls ~11 B/cycle
             # from beyond its L2, a word crosses the chip in ~0.45 us, and a step needs three dependent hand-offs, a 48 KB row per
             # attention_rnn workgroup on the chain and ~3.8 us of dependent arithmetic (context GEMV, attention slice, cell)
+            # round 4 (profiles/r04_bwd_persist_timeline.txt): FOUR dependent hand-offs per step — (dc, dh) row -> attention_rnn
+            # workgroups, context gradient -> attention slices, partial dq -> slice 0 of the item, summed dq -> attention_rnn
+            # workgroups — and, between them, the context-column GEMV (1.2 us), the attention slice (1.2 us) and the cell (1.0 us)
             fetch_us = 48 * 1024 / 11.0 / 2400.0
-            floor_us = 3 * 0.45 + fetch_us + 3.8
-            row["latency_model"] = {"hand_offs_per_step": 3, "hand_off_us": 0.45, "row_bytes_on_chain_per_cu": 48 * 1024,
-                                    "cu_fetch_bytes_per_cycle": 11, "dependent_compute_us": 3.8, "floor_us_per_step": round(floor_us, 2),
+            floor_us = 4 * 0.45 + fetch_us + 3.4
+            row["latency_model"] = {"hand_offs_per_step": 4, "hand_off_us": 0.45, "row_bytes_on_chain_per_cu": 48 * 1024,
+                                    "cu_fetch_bytes_per_cycle": 11, "dependent_compute_us": 3.4, "floor_us_per_step": round(floor_us, 2),
                                     "achieved_us_per_step": round(us / T, 2), "frac_of_floor": round(floor_us / (us / T), 3),
-                                    "source": "profiles/r03_bwd_persist_timeline.txt, profiles/r03_hop_latency.txt"}
+                                    "source": "profiles/r04_bwd_persist_timeline.txt, profiles/r03_hop_latency.txt"}
         if name == "k_dec_train_persist":
             row["us_per_time_step"] = round(us / T, 3)
             row["note"] = ("ONE launch for all %d time steps: a chain of dependent hand-offs between CUs (attention_rnn -> "
@@ -364,8 +423,8 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=8,
                     help='torch CPU threads for the baseline leg (the M=6 GEMVs of this model stop scaling\n'
                          'around 8 threads on this EPYC host: 8 → 3.7 s/it, 16 → 4.2, 32 → 7.4, all cores ≈ 40)')
-    ap.add_argument('--cpu-all-cores', action='store_true',
-                    help='additionally time ONE oracle step with every host core (≈40 s on the 128-core host)')
+    ap.add_argument('--no-cpu-all-cores', action='store_true',
+                    help='skip the second CPU figure (ONE oracle step with every host core, ≈40 s on the 128-core host)')
     ap.add_argument('--no-decode', action='store_true')
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the secondary workloads (koemo length profile, bf16 B=16) and the front-end leg')
@@ -435,7 +494,7 @@ def main():
         rows = roofline_table(bpg, T_IN, T_OUT)
         top = rows[0]                   # the kernel with the most time per step
         traffic, tsrc = None, None      # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, corrected)
-        for fn in ('r03_pmc_fetch_size.json', 'r02_pmc_fetch_size.json', 'r01_pmc_fetch_size.json'):
+        for fn in ('r04_pmc_fetch_size.json', 'r03_pmc_fetch_size.json', 'r02_pmc_fetch_size.json', 'r01_pmc_fetch_size.json'):
             try:
                 with open(os.path.join(ROOT, 'profiles', fn)) as f:
                     traffic = json.load(f)["kernels"][top["kernel"]]["corrected_bytes_per_launch"]
@@ -460,9 +519,12 @@ def main():
                            "kernels": rows,
                            "forward_mode": t2v_hip.DecoderCore.last_mode, "backward_mode": t2v_hip.DecoderCore.last_bwd_mode,
                            "recurrence_us_per_time_step": round(rec_us, 2),
-                           "recurrence_hbm_floor_us_per_time_step": round(len(stream_rows) * LSTM_WEIGHT_BYTES / (HBM_PEAK_GBS * 1e3), 2),
-                           "end_to_end_frac": round(e2e_bytes / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                           # NOT a utilisation: SURVEY 8(d) prices an iteration at 58.9 GB under the launch-per-step formulation
+                           # (67 MB of LSTM weights re-read 801 times); the persistent kernels keep the weights in registers and
+                           # do not move those bytes at all — this is the step's speed relative to that streaming model
+                           "speed_vs_survey_streaming_model": round(e2e_bytes / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                            if kind == 'headline' else None}
+        out["roofline"].update(_whole_step_counters(out["ms_per_step"]))
         if not args.no_decode:
             out["decode"] = decode_bench(engine.model)
             dec_bytes = 72.86e6      # 72.35 MB of recurrent weights + 0.51 MB of memory / processed memory per frame
@@ -501,13 +563,24 @@ def main():
                 _, r2 = run_workload(args, world, rank, b16, ko, max(10, args.steps // 2), 3, not args.no_graph)
                 r2["workload"] = WORKLOADS[name]
                 r2["unit"] = "mel-frames/s"
+                if name == 'bf16':
+                    try:        # its own roofline rows: MFMA counters of the bf16 step, separate PMC pass
+                        with open(os.path.join(ROOT, 'profiles', 'r04_pmc_mfma_bf16.json')) as f:
+                            mb = json.load(f)["kernels"]
+                        r2["roofline_kernels"] = [
+                            {"kernel": k, "bound": "mfma", "achieved": e.get("tflops_at_2.4GHz"), "unit": "TFLOP/s",
+                             "peak": 2500.0 if 'bf16' in k else 157.0, "mfma_busy_frac": e.get("mfma_busy_frac"),
+                             "dispatches_in_profile": e.get("dispatches"), "source": "profiles/r04_pmc_mfma_bf16.json"}
+                            for k, e in mb.items() if "mfma_busy_frac" in e]
+                    except Exception:
+                        pass
                 sec[name] = r2
                 t2v_hip.set_bf16(False)
             out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(steps=args.cpu_steps, warmup=args.cpu_warmup, threads=args.cpu_threads)
             out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-            if args.cpu_all_cores:
+            if not args.no_cpu_all_cores:       # SURVEY 8(d) says "all cores": reported next to the fastest thread count
                 allc = cpu_baseline(steps=1, warmup=0, threads=os.cpu_count())
                 out["cpu_baseline"]["all_cores"] = {"value": allc["value"], "cores": allc["cores"], "s_per_it": allc["s_per_it"],
                                                     "sample": "ONE timed step, no warm-up, every host core"}

@@ -14,12 +14,12 @@ for r in csv.DictReader(open(sys.argv[1])):
     if r['Counter_Name'] != 'FETCH_SIZE':
         continue
     n = r['Kernel_Name']
-    for key in ('k_achain_bwd', 'k_dec_train_persist', 'k_lstm_fwd256', 'k_lstm_bwd256', 'k_attn_fwd', 'k_attn_cell_bwd', 'k_clip_adam', 'k_attn_wgrad_part', 'k_conv5_fwd<5>', 'k_gemm_f32_big'):
+    for key in ('k_achain_bwd', 'k_dec_train_persist', 'k_lstm_fwd256', 'k_lstm_bwd256', 'k_attn_fwd', 'k_attn_cell_bwd', 'k_clip_adam', 'k_attn_wgrad_part', 'k_conv5_fwd<5>', 'k_conv5_dw', 'k_gemm_f32_big', 'k_pb_factors', 'k_pb_cellpre', 'k_pb_fill', 'k_bilstm_fwd', 'k_bilstm_bwd'):
         if key in n:
             agg[key].append(float(r['Counter_Value']))
-alg = {'k_lstm_fwd256': 67108864, 'k_lstm_bwd256': 67108864, 'k_clip_adam': 462000000}
-out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode --no-secondary --no-graph  (round 3, MI355X, separate PMC-only pass, tools/pmc_fetch_size.sh)",
-       "unit_note": "FETCH_SIZE is reported in KB and, on gfx950, counts 64 B per 128-B request for wide coalesced streams: bytes = 2 * 1024 * FETCH_SIZE (MI355X_MICROARCH.md, HBM section)",
+alg = {'k_lstm_fwd256': 67108864, 'k_lstm_bwd256': 67108864, 'k_clip_adam': 462000000, 'k_achain_bwd': 507200000, 'k_dec_train_persist': 335500000}
+out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode --no-secondary --no-graph  (MI355X, separate PMC-only pass, tools/pmc_fetch_size.sh; calibration of the x2048 correction for 4-byte / 16-byte sc1 polled loads: profiles/r04_fetch_calib.txt)",
+       "unit_note": "FETCH_SIZE is reported in KB and, on gfx950, counts 64 B per 128-byte LINE fetched, whatever the width of the load that asked for it (tools/micro/fetch_calib.hip: 16-byte streams, 4-byte and 16-byte sc1 loads, one 4-byte sc1 word per line all read 2048 x FETCH_SIZE = bytes of lines touched): bytes = 2 * 1024 * FETCH_SIZE",
        "kernels": {}}
 for k, v in agg.items():
     e = {"dispatches": len(v), "avg_FETCH_SIZE_KB": round(sum(v) / len(v), 1), "corrected_bytes_per_launch": int(2 * 1024 * sum(v) / len(v))}

@@ -16,14 +16,14 @@ python - "$F" "$EXTRA" > $REPO/gpurun_out/${TAG}_pmc_mfma$SUF.json <<'PY'
 import csv, sys, json, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 keys = ('k_gemm_f32_big', 'k_gemm_bf16_big', 'k_gemm_f32', 'k_gemm_bf16', 'k_conv5_fwd_bf16', 'k_conv5_fwd', 'k_conv5_dw', 'k_lstm_bwd256', 'k_lstm_fwd256',
-        'k_dec_train_persist', 'k_attn_cell_bwd', 'Cijk')
+        'k_dec_train_persist', 'k_achain_bwd', 'k_attn_cell_bwd', 'k_bilstm_fwd', 'k_bilstm_bwd', 'Cijk')
 for r in csv.DictReader(open(sys.argv[1])):
     n = r['Kernel_Name']
     for key in keys:
         if key in n:
             agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
             break
-out = {"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode --no-secondary --no-graph %s (round 3, MI355X, separate PMC-only pass, tools/pmc_mfma.sh)" % sys.argv[2],
+out = {"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode --no-secondary --no-graph %s (MI355X, separate PMC-only pass, tools/pmc_mfma.sh)" % sys.argv[2],
        "formula": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): the CSV reports GRBM_GUI_ACTIVE summed over the 8 XCDs (cross-check: MOPS x 512 / cycles reproduces the event-timed TFLOP/s); mean over the dispatches of a kernel",
        "kernels": {}}
 for k, c in agg.items():

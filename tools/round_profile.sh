@@ -1,5 +1,5 @@
 # usage: bash tools/round_profile.sh <tag>   (on the GPU box) -> gpurun_out/<tag>_*.{csv,txt}
-TAG=${1:-r03}
+TAG=${1:-r04}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 REPO=$(pwd)
