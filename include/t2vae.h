@@ -233,6 +233,9 @@ int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, const float* 
                            const float* dHC, float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
                            uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
                            void* stream);
+/* float offset inside `scratch` of dq(t) summed over the position slices, (T_out,B,128) floats, valid when the pass has ended
+ * (-1: shape outside the persistent range) */
+long t2v_decoder_bwd_achain_dq_offset(int B, int T_in, int T_out);
 /* The same pass as TWO launches (round 4): the attention chain on `stream`, the free-running decoder_rnn chain on `stream_d`
  * (which this call orders behind the preparation launches on `stream`).  DGD is complete when stream_d is — the decoder_rnn
  * weight-gradient GEMMs can be queued behind it and run while the attention chain is still going — everything else when
@@ -382,6 +385,22 @@ int t2v_gemm_epilogue_bwd(const float* dy, const float* y, float* out, size_t n,
  * scratch: t2v_colsum_scratch_floats(M,N) floats (may be 0 -> NULL). */
 long t2v_colsum_scratch_floats(long M, long N);
 int t2v_colsum(const float* A, long lda, long M, long N, float* scratch, float* out, void* stream);
+
+/* ------------------------------------------------------------------ fused epilogues (round 4, csrc/glue.hip)
+ * t2v_mask_outputs: Tacotron2.parse_output (model.py:509-520) in one launch — mel (B,C,T) and mel_post (B,C,T) := 0,
+ * gate (B,T) := gate_fill (1e3) at frames t >= lengths[b]; in place (the reference fills `.data`).
+ * t2v_reparam_fwd / _bwd: VAE_GST.reparameterize (modules.py:74-81): z = eps * exp(0.5 logvar) + mu over n floats, and
+ * dlogvar = dz * eps * exp(0.5 logvar) * 0.5 (dmu = dz needs no launch).
+ * t2v_gather_words: *dst[i] = *src[i] for n four-byte device words (16 per launch): the asynchronous error ledger of the
+ * host mirror collects the error words of a step's cooperative kernels with it. */
+int t2v_mask_outputs(float* mel, float* mel_post, float* gate, const int* lengths, int B, int C, int T, float gate_fill,
+                     void* stream);
+int t2v_reparam_fwd(const float* eps, const float* mu, const float* logvar, float* z, long n, void* stream);
+int t2v_reparam_bwd(const float* dz, const float* eps, const float* logvar, float* dlogvar, long n, void* stream);
+int t2v_gather_words(const void* const* src, void* const* dst, int n, void* stream);
+/* out[r] = [a[r][0..na) | b[r][0..nb)], rows of float4-aligned widths / strides (lda, ldb in floats): the (h_dec, context) input
+ * rows of linear_projection + gate_layer (model.py:385-388) gathered from the decoder arena in one launch */
+int t2v_concat2_rows(const float* a, long lda, int na, const float* b, long ldb, int nb, float* out, long rows, void* stream);
 
 /* ------------------------------------------------------------------ encoder BiLSTM recurrence
  * nn.LSTM(512, 256, bidirectional) on a packed sequence (model.py:171-173, 183-190), recurrent part only:

@@ -5,6 +5,7 @@
 // ascending order — no atomics.
 #include "t2v_common.h"
 #include "t2v_kernels.h"
+#include "t2v_coop.h"
 
 #define CS_COLS 64      // columns per workgroup: one 256-byte row segment
 #define CS_ROWL 16      // row lanes per workgroup
@@ -19,9 +20,11 @@ static int colsum_slices_(long M, long N) {
 }
 
 // grid = (ceil(N/64), RS), block = 256: thread = (column quad cq = tid & 15, row lane rl = tid >> 4)
+// (round 4: with more than one row slice, the slice that arrives LAST at its column block's counter adds the gridDim.y
+// partial rows in ascending order and writes the result — one launch, the same fixed-order sum as the former finishing launch)
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ A, long lda, int M, int N, int rows_per_slice,
-                                                float* __restrict__ dst) {
+                                                float* __restrict__ dst, float* __restrict__ out, unsigned* __restrict__ ctr) {
     const int tid = threadIdx.x, cq = tid & 15, rl = tid >> 4;
     const int j0 = blockIdx.x * CS_COLS + 4 * cq;
     const int r0 = blockIdx.y * rows_per_slice, r1 = min(M, r0 + rows_per_slice);
@@ -61,16 +64,26 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ A, lon
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < CS_ROWL; ++r) s += rf[r * CS_COLS + tid];
-        if (j < N) dst[(size_t)blockIdx.y * N + j] = s;
+        if (j < N) { if (ctr) st_sc1(dst + (size_t)blockIdx.y * N + j, s); else dst[(size_t)blockIdx.y * N + j] = s; }
     }
-}
-
-__global__ __launch_bounds__(256) void k_colsum_finish(const float* __restrict__ part, int N, int RS, float* __restrict__ out) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= N) return;
-    float s = 0.f;
-    for (int r = 0; r < RS; ++r) s += part[(size_t)r * N + j];
-    out[j] = s;
+    if (!ctr) return;
+    // (write-through partials + sc1 loads instead of a fence: see the split-K epilogue in gemm.hip)
+    __shared__ unsigned last_;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) last_ = __hip_atomic_fetch_add(ctr + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.y - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last_) return;
+    if (tid == 0) __hip_atomic_store(ctr + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < CS_COLS) {
+        const int j = blockIdx.x * CS_COLS + tid;
+        if (j < N) {
+            float s = 0.f;
+            const int RS = (int)gridDim.y;
+            for (int r = 0; r < RS; ++r) s += ld_sc1(dst + (size_t)r * N + j);
+            out[j] = s;
+        }
+    }
 }
 
 extern "C" long t2v_colsum_scratch_floats(long M, long N) {
@@ -88,8 +101,13 @@ extern "C" int t2v_colsum(const float* A, long lda, long M, long N, float* scrat
     const bool vec = !(N & 3) && !(lda & 3) && !((uintptr_t)A & 15);
     const dim3 grid((unsigned)((N + CS_COLS - 1) / CS_COLS), (unsigned)rs);
     float* dst = rs > 1 ? scratch : out;
-    if (vec) k_colsum<true><<<grid, 256, 0, stream>>>(A, lda, (int)M, (int)N, rows, dst);
-    else k_colsum<false><<<grid, 256, 0, stream>>>(A, lda, (int)M, (int)N, rows, dst);
-    if (rs > 1) k_colsum_finish<<<(unsigned)((N + 255) / 256), 256, 0, stream>>>(scratch, (int)N, rs, out);
+    unsigned* ctr = nullptr;
+    if (rs > 1) {
+        if (grid.x > 4096) return T2V_ERR_ARG;
+        ctr = t2v_arrival_counters((int)grid.x);
+        if (!ctr) return T2V_ERR_LAUNCH;
+    }
+    if (vec) k_colsum<true><<<grid, 256, 0, stream>>>(A, lda, (int)M, (int)N, rows, dst, out, ctr);
+    else k_colsum<false><<<grid, 256, 0, stream>>>(A, lda, (int)M, (int)N, rows, dst, out, ctr);
     return t2v_check_launch();
 }

@@ -1565,6 +1565,18 @@ extern "C" long t2v_decoder_bwd_achain_scratch_floats(int B, int T_in, int T_out
                   2 * (size_t)T_out * pb_row_bytes(B) / 4 + cp);
 }
 
+// float offset, inside `scratch`, of dq(t) summed over the position slices — (T_out, B, 128), complete when the pass has ended:
+// the d W_q product of the caller reads it there (the sum over the slice axis of DQP was a reduction launch behind the pass)
+extern "C" long t2v_decoder_bwd_achain_dq_offset(int B, int T_in, int T_out) {
+    if (!t2v_decoder_bwd_persist_supported(B, T_in) || T_out < 1) return -1;
+    const int S = pba_slices(T_in);
+    const size_t gpw = pba_js(T_in) + 30 <= 64 ? 64 : 128;
+    const size_t rowf = pb_row_bytes(B) / 4, cxf = (size_t)(B > 4 ? 32768 : 16384) / 4;
+    const size_t n_gx = (size_t)T_out * rowf / 2, n_cx = (size_t)T_out * cxf, n_gp = (size_t)T_out * B * S * 2 * gpw;
+    const size_t n_ex = (size_t)T_out * B * T2V_KATT;
+    return (long)(2 * n_gx + n_cx + n_gp + n_ex);
+}
+
 extern "C" int t2v_decoder_bwd_achain2(const t2v_dec_train_persist_weights* w, const float* w_unused, const t2v_dec_train_bufs* s,
                                        const float* dHC, float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
                                        uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,

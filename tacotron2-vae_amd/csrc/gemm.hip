@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include "t2v_common.h"
 #include "t2v_kernels.h"
+#include "t2v_coop.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GM_BM 64
@@ -29,6 +30,7 @@ struct GemmArgs {
     int nsub;              // > 1: product z covers k-chunk z % nsub of batch item z / nsub (A, B advance by sAs, sBs per chunk)
     long sAs, sBs;
     int bias_row;          // bias indexed by the output ROW (a convolution's output channel) instead of the column
+    unsigned* tile_ctr;    // split-K: one arrival counter per output tile (zero before and after the launch)
 };
 
 template <bool A_KC, bool B_KC>   // operand contiguous along k?
@@ -89,15 +91,54 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
         __syncthreads();
     }
     const int j = j0 + 32 * wn + (lane & 31);
-    if (a.part) {      // split-K: raw partial tile, epilogue in k_gemm_splitk_reduce
+    if (a.part) {
+        // split-K: the raw partial tile goes to scratch; the workgroup that arrives LAST at its tile's counter (round 4: no
+        // second launch) adds the gridDim.z partials in the fixed order z = 0, 1, ... — the same sum, bit for bit, whichever
+        // workgroup happens to do it — and applies the epilogue.  The counter is left at zero for the next launch.
         if (j < a.N) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = i0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (i < a.M) a.part[((size_t)blockIdx.z * a.M + i) * a.N + j] = acc[r];
+                if (i < a.M) st_sc1(a.part + ((size_t)blockIdx.z * a.M + i) * a.N + j, acc[r]);
             }
         }
-        return;
+        // (no __threadfence(): at agent scope it writes back and invalidates the XCD's whole L2 — with a dozen split-K and
+        // column-sum launches per step that cost 1.3 ms of cache misses in the kernels running next to them.  The partials
+        // are write-through stores (sc1) and are read back with sc1 loads, like the exchange rows of the persistent kernels;
+        // the arrival is counted once this wave's stores have been acknowledged.)
+        __shared__ unsigned last_;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* ctr = a.tile_ctr + blockIdx.y * gridDim.x + blockIdx.x;
+        if (tid == 0) last_ = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.z - 1 ? 1u : 0u;
+        __syncthreads();
+        if (!last_) return;
+        if (tid == 0) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nz = (int)gridDim.z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (j < a.N) {
+            // four partial tiles (64 loads per thread) are requested before the first add: one memory round trip per four
+            // splits instead of one per split; the adds keep the order z = 0, 1, 2, ...
+            for (int z0 = 0; z0 < nz; z0 += 4) {
+                float v[4][16];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int z = min(z0 + u, nz - 1);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int i = min(i0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), a.M - 1);
+                        v[u][r] = ld_sc1(a.part + ((size_t)z * a.M + i) * a.N + j);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (z0 + u < nz) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[r] += v[u][r];
+                    }
+            }
+        }
     }
     if (j < a.N) {
         const float bv = (a.bias && !a.bias_row) ? a.bias[j] : 0.f;
@@ -119,18 +160,37 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
 // ---- split-K for the skinny deep-K products (weight gradients of the Prenet / projection / GRU / VAE head: a handful of
 // 64x64 tiles with K = T*B = 2400): the k range is cut over gridDim.z, partial tiles are summed in a fixed order
 // (deterministic) together with the bias / ReLU / dropout / accumulate epilogue.
-__global__ void k_gemm_splitk_reduce(GemmArgs a, int nsplit) {
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (size_t)a.M * a.N) return;
-    const int i = (int)(e / a.N), j = (int)(e - (size_t)i * a.N);
-    float v = 0.f;
-    for (int z = 0; z < nsplit; ++z) v += a.part[(size_t)z * a.M * a.N + e];
-    const size_t idx = (size_t)i * a.ldc + j;
-    if (a.bias) v += a.bias[j];
-    if (a.accumulate) v += a.C[idx];
-    if (a.relu) v = fmaxf(v, 0.f);
-    if (a.p_drop > 0.f) v *= t2v_drop_scale(t2v_step_seed(a.seed, a.step), a.rng_stream, a.rng_t, (uint32_t)idx, a.p_drop);
-    a.C[idx] = v;
+// arrival counters of the split-K tiles (and of colsum.hip's column blocks): slices of one zero-initialised ring (every launch takes the next `tiles` words and
+// leaves them at zero; a slice comes round again 64 K tiles later, long after its launch has retired; a captured graph keeps
+// the slices of its nodes, and the launches of different graphs / eager steps of one engine never run at the same time)
+#include <atomic>
+#define GM_CTR_RING (1 << 16)
+unsigned* t2v_arrival_counters(int tiles) {
+    static unsigned* ring = nullptr;
+    static std::atomic<unsigned> pos{0};
+    static std::atomic<int> state{0};
+    if (tiles > GM_CTR_RING) return nullptr;
+    int st = state.load(std::memory_order_acquire);
+    if (st != 2) {
+        int expect = 0;
+        if (state.compare_exchange_strong(expect, 1)) {
+            unsigned* p = nullptr;
+            if (hipMalloc((void**)&p, GM_CTR_RING * sizeof(unsigned)) != hipSuccess || hipMemset(p, 0, GM_CTR_RING * sizeof(unsigned)) != hipSuccess
+                || hipDeviceSynchronize() != hipSuccess) { state.store(0); return nullptr; }
+            ring = p;
+            state.store(2, std::memory_order_release);
+        } else {
+            while (state.load(std::memory_order_acquire) == 1) { }
+            if (state.load() != 2) return nullptr;
+        }
+    }
+    unsigned at = pos.fetch_add((unsigned)tiles);
+    at %= GM_CTR_RING;
+    if (at + (unsigned)tiles > GM_CTR_RING) {         // would wrap inside the slice: start over at the top
+        pos.store((unsigned)tiles);
+        at = 0;
+    }
+    return ring + at;
 }
 // number of k-splits for the 64x64 kernel: deep-K products whose tiles leave CUs idle (r3 step trace: the 2400x256,
 // K = 4096 data gradient of the Prenet ran 174 us on 152 workgroups, the 2400x81, K = 1536 projection 61 us on 76) are
@@ -544,7 +604,7 @@ extern "C" int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B,
     a.A = A; a.B = B; a.bias = bias; a.C = C; a.sAi = sAi; a.sAk = sAk; a.sBj = sBj; a.sBk = sBk;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
     a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
-    a.kz_chunk = 0; a.part = nullptr; a.nbatch = 1; a.sAb = a.sBb = a.sCb = 0; a.nsub = 1; a.sAs = a.sBs = 0; a.bias_row = 0;
+    a.kz_chunk = 0; a.part = nullptr; a.nbatch = 1; a.sAb = a.sBb = a.sCb = 0; a.nsub = 1; a.sAs = a.sBs = 0; a.bias_row = 0; a.tile_ctr = nullptr;
     if (gemm_bf16_big_ok(a)) {
         dim3 gb((N + GBB_BN - 1) / GBB_BN, (M + GBB_BM - 1) / GBB_BM);
         k_gemm_bf16_big_rr<<<gb, 256, 0, stream>>>(a);
@@ -588,7 +648,7 @@ static int gemm_f32_impl(const float* A, long sAi, long sAk, const float* B, lon
     a.A = A; a.B = B; a.bias = bias; a.C = C; a.sAi = sAi; a.sAk = sAk; a.sBj = sBj; a.sBk = sBk;
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
     a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
-    a.kz_chunk = 0; a.part = nullptr; a.nbatch = 1; a.sAb = a.sBb = a.sCb = 0; a.nsub = 1; a.sAs = a.sBs = 0; a.bias_row = 0;
+    a.kz_chunk = 0; a.part = nullptr; a.nbatch = 1; a.sAb = a.sBb = a.sCb = 0; a.nsub = 1; a.sAs = a.sBs = 0; a.bias_row = 0; a.tile_ctr = nullptr;
     const bool akc = sAk == 1, bkc = sBk == 1;
     if (gemm_big_ok(a)) {
         // (T2V_GEMM_NARROW=1, measurement: always the 128x64 tile — twice the tiles, so a launch that shares CUs with long
@@ -608,17 +668,18 @@ static int gemm_f32_impl(const float* A, long sAi, long sAk, const float* B, lon
         return t2v_check_launch();
     }
     const int ns = splitk_scratch ? gemm_splits(M, N, K) : 1;
+    dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, ns);
     if (ns > 1) {
         const int tiles_k = (K + GM_BK - 1) / GM_BK;
         a.kz_chunk = ((tiles_k + ns - 1) / ns) * GM_BK;
         a.part = splitk_scratch;
+        a.tile_ctr = t2v_arrival_counters((int)(grid.x * grid.y));
+        if (!a.tile_ctr) return T2V_ERR_LAUNCH;
     }
-    dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, ns);
     if (akc && bkc) k_gemm_f32<true, true><<<grid, 256, 0, stream>>>(a);
     else if (akc) k_gemm_f32<true, false><<<grid, 256, 0, stream>>>(a);
     else if (bkc) k_gemm_f32<false, true><<<grid, 256, 0, stream>>>(a);
     else k_gemm_f32<false, false><<<grid, 256, 0, stream>>>(a);
-    if (ns > 1) k_gemm_splitk_reduce<<<(unsigned)(((size_t)M * N + 255) / 256), 256, 0, stream>>>(a, ns);
     return t2v_check_launch();
 }
 
@@ -635,7 +696,7 @@ int t2v_gemm_f32_batched_ex(const float* A, long sAb, long sAs, long sAi, long s
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = 0; a.accumulate = 0;
     a.p_drop = 0.f; a.seed = 0; a.rng_stream = 0; a.rng_t = 0; a.step = t2v_step_for(stream);
     a.kz_chunk = 0; a.part = nullptr; a.nbatch = nbatch * nsub > 1 ? nbatch * nsub : 1; a.sAb = sAb; a.sBb = sBb; a.sCb = sCb;
-    a.nsub = nsub; a.sAs = sAs; a.sBs = sBs; a.bias_row = bias_row ? 1 : 0;
+    a.nsub = nsub; a.sAs = sAs; a.sBs = sBs; a.bias_row = bias_row ? 1 : 0; a.tile_ctr = nullptr;
     const bool akc = sAk == 1, bkc = sBk == 1;
     dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, nbatch * nsub);
     if (akc && bkc) k_gemm_f32<true, true><<<grid, 256, 0, stream>>>(a);

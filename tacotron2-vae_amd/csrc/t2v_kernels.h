@@ -8,6 +8,9 @@ enum { T2V_RNG_ATT_H = 1, T2V_RNG_ATT_C = 2, T2V_RNG_DEC_H = 3, T2V_RNG_DEC_C = 
        T2V_RNG_PRENET0 = 5, T2V_RNG_PRENET1 = 6 };
 
 int t2v_check_launch();
+// gemm.hip: `n` zeroed arrival counters for a launch whose workgroups find out which of them finishes last (split-K tiles,
+// column-sum slices); the launch leaves them at zero
+unsigned* t2v_arrival_counters(int n);
 extern unsigned long long* g_t2v_prof;   // device buffer of 32 u64 or NULL (t2v_set_phase_profile)                 // records hipGetLastError() for t2v_last_error()
 const t2v_step_params* t2v_step_for(hipStream_t stream);   // device-side per-step parameters bound to this stream, else the process default, else NULL
 

@@ -127,7 +127,7 @@ class Encoder(nn.Module):
     def forward(self, x, input_lengths):
         """conv bank → BiLSTM over each sequence's own length (packed semantics), zero at padding."""
         x = self._convs(x)
-        return self._bilstm(x, input_lengths.to(device=x.device, dtype=torch.int32))
+        return self._bilstm(x, lengths_i32(input_lengths, x.device))
 
     def inference(self, x):
         x = self._convs(x)
@@ -185,9 +185,9 @@ class Decoder(nn.Module):
         mel_outputs = mel_outputs.view(mel_outputs.size(0), -1, self.n_mel_channels).transpose(1, 2)
         return mel_outputs, gate_outputs, alignments
 
-    def _core_weights(self):
+    def _core_weights(self, b_dec=None):
         a, att, dec = self.attention_layer, self.attention_rnn, self.decoder_rnn
-        return (att.weight_ih, att.weight_hh, dec.weight_ih, dec.weight_hh, dec.bias_ih + dec.bias_hh,
+        return (att.weight_ih, att.weight_hh, dec.weight_ih, dec.weight_hh, dec.bias_ih + dec.bias_hh if b_dec is None else b_dec,
                 a.query_layer.weight, a.location_layer.location_conv.conv.weight,
                 a.location_layer.location_dense.weight, a.v.weight)
 
@@ -290,7 +290,16 @@ class Decoder(nn.Module):
         att = self.attention_rnn
         gpre = t2v_hip.gemm(pre.detach().reshape(-1, pre.shape[-1]), att.weight_ih.detach()[:, :self.prenet_dim],
                             (att.bias_ih + att.bias_hh).detach())
-        self._prepared = (decoder_inputs, pre, gpre, torch.cuda.current_stream())
+        self._prepared = (decoder_inputs, pre, gpre, torch.cuda.current_stream(), self._param_operands())
+
+    def _param_operands(self):
+        """operands that depend on the parameters only: decoder_rnn's summed bias, linear_projection and gate_layer as one
+        81-row matrix (reference model.py:385-388).  With a prepare() they are made on the deferred-work stream while the
+        encoder runs (autograd runs their backward there, too) instead of as five launches in front of / behind the decoder."""
+        dec = self.decoder_rnn
+        return (dec.bias_ih + dec.bias_hh,
+                torch.cat((self.linear_projection.weight, self.gate_layer.weight), 0),
+                torch.cat((self.linear_projection.bias, self.gate_layer.bias), 0))
 
     def forward(self, memory, decoder_inputs, memory_lengths):
         """Teacher-forced pass (reference model.py:391-426).  Returns mel (B,80,T), gate (B,T),
@@ -298,11 +307,14 @@ class Decoder(nn.Module):
         B, T_in = memory.size(0), memory.size(1)
         prep = self.__dict__.pop('_prepared', None)
         gpre = None
+        operands = None
         if prep is not None and prep[0] is decoder_inputs:
-            _, pre, gpre, st = prep
+            _, pre, gpre, st, operands = prep
             T = pre.size(0)
             if st != torch.cuda.current_stream():
                 torch.cuda.current_stream().wait_stream(st)
+                for t in operands:
+                    t.record_stream(torch.cuda.current_stream())
         else:
             frames = self.parse_decoder_inputs(decoder_inputs)                       # (T,B,80)
             T = frames.size(0)
@@ -311,7 +323,7 @@ class Decoder(nn.Module):
         att = self.attention_rnn
         lin = t2v_hip.LinearHIP.apply
         pm = lin(memory, self.attention_layer.memory_layer.weight, None, False, 0.0, 0, 0, 0)
-        lengths = memory_lengths.to(device=memory.device, dtype=torch.int32)
+        lengths = lengths_i32(memory_lengths, memory.device)
         training = self.training
         p_att = self.p_attention_dropout if training else 0.0
         p_dec = self.p_decoder_dropout if training else 0.0
@@ -320,13 +332,12 @@ class Decoder(nn.Module):
         # the prenet term of attention_rnn's gates (pre · weight_ih[:, :256]^T + b_ih + b_hh for all steps) is computed
         # inside the node, so weight_ih has a single gradient producer
         t2v_hip.stamp('dec_fwd_begin')
-        hc, alignments = t2v_hip.DecoderCore.apply(None, memory, pm, lengths, *self._core_weights(),
+        b_dec, w81, b81 = operands if operands is not None else self._param_operands()
+        hc, alignments = t2v_hip.DecoderCore.apply(None, memory, pm, lengths, *self._core_weights(b_dec),
                                                    p_att, p_dec, seed, torch.is_grad_enabled(),
                                                    pre, att.bias_ih, att.bias_hh, gpre)
         t2v_hip.stamp('dec_fwd_end')
         # linear_projection and gate_layer as ONE 81-column MFMA tile (reference model.py:385-388)
-        w81 = torch.cat((self.linear_projection.weight, self.gate_layer.weight), 0)
-        b81 = torch.cat((self.linear_projection.bias, self.gate_layer.bias), 0)
         out = lin(hc, w81, b81, False, 0.0, 0, 0, 0)                              # (T,B,81)
         mel = out[..., :self.n_mel_channels].permute(1, 2, 0).contiguous()       # (B,80,T)
         gate = out[..., self.n_mel_channels].transpose(0, 1).contiguous()        # (B,T)
@@ -339,6 +350,14 @@ class SymbolEmbedding(nn.Embedding):
 
     def forward(self, ids):
         return t2v_hip.SymbolEmbedding.apply(ids, self.weight)       # raises T2VHipError for CPU tensors: no CPU fallback
+
+
+def lengths_i32(lengths, device):
+    """int32 device copy of a length vector: the one BatchLayout uploaded next to it, else a conversion"""
+    v = getattr(lengths, '_i32', None)
+    if v is not None and v.device == device:
+        return v
+    return lengths.to(device=device, dtype=torch.int32)
 
 
 class BatchLayout(object):
@@ -368,6 +387,13 @@ class BatchLayout(object):
             nb = t.numel() * (8 if dt == torch.int64 else 4)
             self.fields.append((off, nb, dt, tuple(t.shape)))
             off += (nb + 15) & ~15
+        # (round 4) int32 copies of both length vectors ride along: the kernels take int32 lengths, and converting on the
+        # device cost two launches per step on the critical path
+        self.i32 = []
+        for idx in (1, 4):
+            nb = batch[idx].numel() * 4
+            self.i32.append((idx, off, nb))
+            off += (nb + 15) & ~15
         self.nbytes = max(off, 16)
         self.key = tuple(f[3] for f in self.fields) + (self.max_len,)
 
@@ -384,6 +410,9 @@ class BatchLayout(object):
         for t, (off, nb, dt, shape) in zip(batch, self.fields):
             if nb:
                 host[off:off + nb].view(dt).view(shape).copy_(t)      # dtype conversion happens here, on the host
+        for idx, off, nb in self.i32:
+            if nb:
+                host[off:off + nb].view(torch.int32).copy_(batch[idx].reshape(-1))
         dev = into if into is not None else torch.empty(self.nbytes, dtype=torch.uint8, device='cuda')
         assert dev.numel() == self.nbytes and dev.dtype == torch.uint8
         dev.copy_(host, non_blocking=True)
@@ -396,6 +425,9 @@ class BatchLayout(object):
         """((text, input_lengths, mel, max_len, output_lengths, speakers, emotions), (mel, gate)) over `dev`"""
         v = [dev[off:off + nb].view(dt).view(shape) if nb else torch.empty(shape, dtype=dt, device=dev.device)
              for off, nb, dt, shape in self.fields]
+        for idx, off, nb in self.i32:
+            if nb:
+                v[idx]._i32 = dev[off:off + nb].view(torch.int32)
         text, input_lengths, mel, gate, output_lengths, speakers, emotions = v
         return ((text, input_lengths, mel, self.max_len, output_lengths, speakers, emotions), (mel, gate))
 
@@ -451,10 +483,15 @@ class Tacotron2(nn.Module):
         """In-place on .data exactly like reference model.py:509-520 (Appendix B-5: the Postnet's
         first conv therefore sees the zero-masked decoder mel in its weight gradient)."""
         if self.mask_padding and output_lengths is not None:
-            pad = ~get_mask_from_lengths(output_lengths, outputs[0].size(2))
-            outputs[0].data.masked_fill_(pad.unsqueeze(1), 0.0)
-            outputs[1].data.masked_fill_(pad.unsqueeze(1), 0.0)
-            outputs[2].data.masked_fill_(pad, 1e3)
+            mel, mel_post, gate = outputs[0].data, outputs[1].data, outputs[2].data
+            if mel.is_cuda and mel.is_contiguous() and mel_post.is_contiguous() and gate.is_contiguous():
+                # the three fills as ONE launch straight from the lengths (was arange, lt, not and three masked_fill_)
+                t2v_hip.mask_outputs(mel, mel_post, gate, lengths_i32(output_lengths, mel.device))
+            else:
+                pad = ~get_mask_from_lengths(output_lengths, outputs[0].size(2))
+                mel.masked_fill_(pad.unsqueeze(1), 0.0)
+                mel_post.masked_fill_(pad.unsqueeze(1), 0.0)
+                gate.masked_fill_(pad, 1e3)
         return outputs
 
     def forward(self, inputs):
@@ -492,6 +529,11 @@ class Tacotron2(nn.Module):
         self.decoder.__dict__['_tf_t'] = (1 << 20) + _block_calls[0]
         fork = t2v_hip.mark()
         enc_first = os.environ.get('T2V_FWD_ORDER', 'enc_first') == 'enc_first' and fork is not None
+        with t2v_hip.side('w', after=fork) as forked_p:
+            if forked_p:    # parameter-only operands of the BiLSTM, ready long before the conv bank in front of it is done
+                l = self.encoder.lstm
+                t2v_hip.BiLSTM.prepare(l.weight_hh_l0, l.bias_ih_l0, l.bias_hh_l0, l.weight_hh_l0_reverse, l.bias_ih_l0_reverse,
+                                       l.bias_hh_l0_reverse)
         if enc_first:       # the host issues the longest chain first; the side chains still fork from `fork`
             embedded = self.transcript_embedding(text).transpose(1, 2)
             transcript = self.encoder(embedded, input_lengths)

@@ -64,7 +64,8 @@ class VAE_GST(nn.Module):
         if not self.training:
             return mu
         eps = self.eps_override if self.eps_override is not None else torch.randn_like(mu)
-        return eps * torch.exp(0.5 * logvar) + mu
+        import t2v_hip
+        return t2v_hip.Reparam.apply(eps, mu, logvar)      # eps * exp(0.5 logvar) + mu, one launch (raises for CPU tensors)
 
     def forward(self, inputs):
         import t2v_hip

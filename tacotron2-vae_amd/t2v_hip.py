@@ -72,7 +72,8 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_stamp', 't2v_debug_spin', 't2v_
            't2v_decoder_train_persist_scratch_floats', 't2v_decoder_bwd_persist_supported',
            't2v_decoder_bwd_dchain_scratch_floats', 't2v_decoder_bwd_dchain', 't2v_decoder_bwd_achain_scratch_floats',
            't2v_decoder_bwd_achain', 't2v_decoder_bwd_achain2', 't2v_decoder_bwd_achain_prepare',
-           't2v_decoder_bwd_achain_prepared', 't2v_decoder_bwd_persist_slices')
+           't2v_decoder_bwd_achain_prepared', 't2v_decoder_bwd_persist_slices', 't2v_decoder_bwd_achain_dq_offset', 't2v_mask_outputs', 't2v_reparam_fwd',
+           't2v_reparam_bwd', 't2v_gather_words', 't2v_concat2_rows')
 
 
 def lib_path():
@@ -118,6 +119,8 @@ def load_library():
         C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]
     lib.t2v_decoder_bwd_achain2.argtypes = lib.t2v_decoder_bwd_achain.argtypes + [C.c_void_p]
     lib.t2v_decoder_bwd_persist_slices.argtypes = [C.c_int]
+    lib.t2v_decoder_bwd_achain_dq_offset.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.t2v_decoder_bwd_achain_dq_offset.restype = C.c_long
     lib.t2v_decoder_bwd_achain_prepared.argtypes = lib.t2v_decoder_bwd_achain2.argtypes
     lib.t2v_decoder_bwd_achain_prepare.argtypes = [C.POINTER(_DecTrainBufs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                    C.c_float, C.c_float, C.c_uint64, C.c_void_p]
@@ -131,6 +134,11 @@ def load_library():
                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.t2v_clip_adam_step_guarded.argtypes = lib.t2v_clip_adam_step.argtypes[:-1] + [C.c_void_p, C.c_int, C.c_void_p]
+    lib.t2v_mask_outputs.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    lib.t2v_reparam_fwd.argtypes = [C.c_void_p] * 4 + [C.c_long, C.c_void_p]
+    lib.t2v_reparam_bwd.argtypes = [C.c_void_p] * 4 + [C.c_long, C.c_void_p]
+    lib.t2v_concat2_rows.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_void_p]
+    lib.t2v_gather_words.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
     lib.t2v_embedding_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.t2v_embedding_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.t2v_gemm_epilogue_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]
@@ -414,6 +422,8 @@ class Overlap(object):
         self._used = []
         self._keep = []
         _PREFLIP.clear()        # flipped conv weights belong to the step that made them
+        BiLSTM._prep.clear()
+        flush_err_notes()       # every stream that wrote an error word has been joined: one gather launch for the step
 
 
 # ---- phase stamps (T2V_STAMPS=1): one-thread launches that write the 100 MHz wall clock at named points of the step
@@ -542,12 +552,43 @@ def _err_note(label, word):
     if pool[1] >= _ERR_SLOTS:
         pool[1] = _ERR_STICKY[0]
     slot = pool[1]
-    pool[0][slot:slot + 1].copy_(word)
-    if _ERR_INJECT[0] is not None and _ERR_INJECT[0] in label:
-        pool[0][slot:slot + 1].fill_(1)
+    # (round 4) the 4-byte copy into the ledger is deferred: flush_err_notes() moves up to 16 words per launch (a step has
+    # six or seven cooperative launches; each copy was a launch of its own on the critical path)
+    inject = _ERR_INJECT[0] is not None and _ERR_INJECT[0] in label
+    if inject:
         _ERR_INJECT[0] = None
+    _ERR_PENDING.setdefault(key, []).append((slot, word, torch.cuda.current_stream(word.device), inject))
     pool[2][slot] = label
     pool[1] += 1
+    if len(_ERR_PENDING[key]) >= 16:
+        flush_err_notes()
+
+
+_ERR_PENDING = {}
+
+
+def flush_err_notes():
+    """copy the pending error words into the ledger with one launch per 16 words, on the current stream (which first waits
+    for any other stream a pending word was written on).  The training engine calls it where its side streams have joined;
+    check_async_errors() calls it before it reads the ledger."""
+    for key, pend in list(_ERR_PENDING.items()):
+        if not pend:
+            continue
+        pool = _ERR_POOL[key]
+        dev = pool[0].device
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            for st in {id(p[2]): p[2] for p in pend if p[2] != cur}.values():
+                cur.wait_stream(st)
+            n = len(pend)
+            src = (C.c_void_p * n)(*[p[1].data_ptr() for p in pend])
+            dst = (C.c_void_p * n)(*[pool[0].data_ptr() + 4 * p[0] for p in pend])
+            _check(load_library().t2v_gather_words(src, dst, n, _stream()), 't2v_gather_words')
+            for p in pend:
+                p[1].record_stream(cur)
+                if p[3]:
+                    pool[0][p[0]:p[0] + 1].fill_(1)
+        del pend[:]
 
 
 def err_mark(device=None):
@@ -570,6 +611,7 @@ def err_range(mark, device=None):
 def check_async_errors():
     """Raise T2VHipError if any cooperative kernel since the last check reported a barrier timeout (syncs)."""
     bad = []
+    flush_err_notes()
     for key, pool in _ERR_POOL.items():
         n = min(pool[1], _ERR_SLOTS)
         if n == 0:
@@ -847,7 +889,14 @@ class DecoderCore(torch.autograd.Function):
             chunks.append(DecoderCore._fwd_chunk(lib, g_c, m_c, pm_c, l_c, packs, bias_dec, wqT, wcomb, vv, need_grad,
                                                  p_att, p_dec, (int(seed) + 7919 * b0) & 0x7FFFFFFFFFFFFFFF, wbf, raw,
                                                  bwd_prepare=bwd_persist))
-        hcs = [torch.cat((k[4][2:T + 2, :, KATT:], k[4][1:T + 1, :, H:KATT]), 2) for _, _, k in chunks]
+        hcs = []
+        for b0c, b1c, k in chunks:          # (h_dec(t), context(t)) rows of the projection, gathered from the arena in one launch
+            XSc = k[4]
+            Bc, XWc = XSc.size(1), XSc.size(2)
+            hc_c = torch.empty(T, Bc, XWc - H, device=XSc.device, dtype=torch.float32)
+            _check(lib.t2v_concat2_rows(_p(XSc[2:, :, KATT:]), XWc, XWc - KATT, _p(XSc[1:, :, H:KATT]), XWc, KATT - H, _p(hc_c),
+                                        T * Bc, _stream()), 't2v_concat2_rows')
+            hcs.append(hc_c)
         als = [k[10][1:].permute(1, 0, 2) for _, _, k in chunks]
         HC = hcs[0] if len(hcs) == 1 else torch.cat(hcs, 1)
         align = als[0] if len(als) == 1 else torch.cat(als, 0)
@@ -932,7 +981,8 @@ class DecoderCore(torch.autograd.Function):
                 split_d = st_d is not None
                 _err_note('decoder backward (persistent kernel hand-off)', errw)
                 DecoderCore.last_bwd_mode = 'persistent'
-                dq_sum = DQP.sum(2).view(T * B, A)
+                dq_off = lib.t2v_decoder_bwd_achain_dq_offset(B, T_in, T)      # slice 0 of every item has summed the slices already
+                dq_sum = scratch[dq_off:dq_off + T * B * A].view(T * B, A)
                 if DecoderCore.keep_last and b0 == 0:
                     DecoderCore.last_bwd_persist = (PW, Sb, (dhc_c, DGA, DGD, DCTX, DV, DQP, scratch, errw), (B, T_in, T, p_att, p_dec, seed),
                                                     keep + (ctx.raw, wcomb, vv, bias_dec))
@@ -1333,11 +1383,55 @@ class SymbolEmbedding(torch.autograd.Function):
         return None, dW
 
 
+def mask_outputs(mel, mel_post, gate, lengths_i32, gate_fill=1e3):
+    """Tacotron2.parse_output's three in-place fills (reference model.py:513-517) as one launch"""
+    lib = _require_gpu(mel, mel_post, gate, lengths_i32)
+    assert mel.is_contiguous() and mel_post.is_contiguous() and gate.is_contiguous() and lengths_i32.dtype == torch.int32
+    assert mel.dtype == torch.float32 and mel_post.shape == mel.shape and gate.shape == (mel.size(0), mel.size(2))
+    B, Cn, T = mel.shape
+    _check(lib.t2v_mask_outputs(_p(mel), _p(mel_post), _p(gate), _p(lengths_i32), B, Cn, T, float(gate_fill), _stream()),
+           't2v_mask_outputs')
+
+
+class Reparam(torch.autograd.Function):
+    """z = eps * exp(0.5 logvar) + mu (reference modules.py:74-81) and its gradient, one launch each"""
+
+    @staticmethod
+    def forward(ctx, eps, mu, logvar):
+        lib = _require_gpu(eps, mu, logvar)
+        eps, mu, logvar = _f32c(eps), _f32c(mu), _f32c(logvar)
+        z = torch.empty_like(mu)
+        _check(lib.t2v_reparam_fwd(_p(eps), _p(mu), _p(logvar), _p(z), mu.numel(), _stream()), 't2v_reparam_fwd')
+        ctx.save_for_backward(eps, logvar)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        eps, logvar = ctx.saved_tensors
+        dz = _f32c(dz)
+        dlv = torch.empty_like(logvar)
+        _check(load_library().t2v_reparam_bwd(_p(dz), _p(eps), _p(logvar), _p(dlv), dz.numel(), _stream()), 't2v_reparam_bwd')
+        return None, dz, dlv
+
+
 class BiLSTM(torch.autograd.Function):
     """Encoder BiLSTM over per-sequence lengths (== pack_padded_sequence → nn.LSTM → pad_packed_sequence,
     reference model.py:183-190).  Input projections / weight gradients are time-batched GEMMs; the
     recurrence (forward and BPTT) runs in the persistent cooperative kernels of csrc/bilstm.hip, 16 sequences per
     call (larger batches run as independent chunks)."""
+
+    _prep = {}      # id(w_hh) -> (whh, bias, bias_r, event): see prepare()
+
+    @staticmethod
+    def prepare(w_hh, b_ih, b_hh, w_hh_r, b_ih_r, b_hh_r):
+        """the parameter-only operands of forward() (both W_hh stacked, b_ih + b_hh per direction), computed ahead — the
+        model issues this on the deferred-work stream at the top of a step, the encoder reaches its BiLSTM 250 us later"""
+        with torch.no_grad():
+            whh = torch.stack((w_hh, w_hh_r)).contiguous()
+            bias, bias_r = b_ih + b_hh, b_ih_r + b_hh_r
+        ev = torch.cuda.Event()
+        ev.record()
+        BiLSTM._prep[id(w_hh)] = (whh, bias, bias_r, ev)
 
     @staticmethod
     def forward(ctx, x, lengths, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, save):
@@ -1345,9 +1439,17 @@ class BiLSTM(torch.autograd.Function):
         B, T, _ = x.shape
         f32 = dict(device=x.device, dtype=torch.float32)
         x = _f32c(x)
-        whh = torch.stack((w_hh, w_hh_r)).contiguous()
+        prep = BiLSTM._prep.pop(id(w_hh), None)
+        if prep is not None:        # stacked recurrent weights / summed biases of this step, made ahead on a side stream
+            whh, bias, bias_r, ev = prep
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            for t in (whh, bias, bias_r):
+                t.record_stream(cur)
+        else:
+            whh = torch.stack((w_hh, w_hh_r)).contiguous()
+            bias, bias_r = b_ih + b_hh, b_ih_r + b_hh_r
         y = torch.empty(B, T, 512, **f32)       # cleared by t2v_bilstm_fwd's reset launch
-        bias, bias_r = b_ih + b_hh, b_ih_r + b_hh_r
         chunks = []
         for b0 in range(0, B, MAX_DEC_B):
             b1 = min(B, b0 + MAX_DEC_B)
