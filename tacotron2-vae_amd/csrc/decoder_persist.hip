@@ -86,6 +86,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pd_rsrc(const void* base) {
 __device__ __forceinline__ void pd_put(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)(off * 4u), 0, PD_SC1);
 }
+__device__ __forceinline__ void pd_put4(__amdgpu_buffer_rsrc_t r, unsigned off, float v0, float v1, float v2, float v3) {
+    const pd_u32x4 x = {__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), __float_as_uint(v3)};
+    __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)(off * 4u), 0, PD_SC1);
+}
 __device__ __forceinline__ unsigned pd_get(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_amdgcn_raw_buffer_load_b32(r, (int)(off * 4u), 0, PD_SC1);
 }
@@ -149,6 +153,54 @@ __device__ __forceinline__ void pd_gemv(const float (&wreg)[NJ], const float* X,
     }
 }
 
+// Round 4: the two LSTM GEMVs of a frame are cut by WHEN their inputs exist, so that only the columns of the value that has
+// just arrived are left on the frame's dependency chain:
+//   attention_rnn(t+1) = [h_att(t) | ctx(t)] (1536 columns, known when ctx(t) has been gathered: evaluated in the shadow of
+//                        the projection / Prenet stages of frame t)  +  Prenet output (256 columns: the chain)
+//   decoder_rnn(t)     = h_dec(t-1) (1024 columns, known since the previous frame)  +  h_att(t) (1024, evaluated while the
+//                        attention workgroups work)  +  ctx(t) (512 columns: the chain)
+// Every wave owns an eighth of EACH part, so a late part is spread over all 8 waves of the workgroup.  Weight register j of a
+// lane (wave w, k quarter kq) <-> logical column:
+//   attention_rnn  j < 48: 192 w + 4 j + kq                      j >= 48: 1536 + 32 w + 4 (j - 48) + kq        [h_att|ctx] , [pre1]
+//   decoder_rnn    j < 32: 128 w + 4 j + kq (h_att)   j < 64: 1536 + 128 w + 4 (j - 32) + kq (h_dec)   else: 1024 + 64 w + 4 (j - 64) + kq (ctx)
+__device__ __forceinline__ int pd_ka(int wave, int j, int kq) { return j < 48 ? 192 * wave + 4 * j + kq : 1536 + 32 * wave + 4 * (j - 48) + kq; }
+__device__ __forceinline__ int pd_kd(int wave, int j, int kq) {
+    return j < 32 ? 128 * wave + 4 * j + kq : (j < 64 ? 1536 + 128 * wave + 4 * (j - 32) + kq : 1024 + 64 * wave + 4 * (j - 64) + kq);
+}
+// acc[b] += sum_{j in [J0, J1)} wreg[j] * x_b[column of j]   (DEC: decoder_rnn mapping; its h_dec columns sit 256 further in the LDS row)
+template <int NJ, int J0, int J1, bool DEC>
+__device__ __forceinline__ void pd_gemv_part(const float (&wreg)[NJ], const float* X, int B, float (&acc)[PD_MAXB]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kq = lane & 3;
+#pragma unroll
+    for (int b = 0; b < PD_MAXB; ++b) {
+        if (b < B) {
+            const float* xb = X + (size_t)b * PD_XW;
+            float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+            for (int j = J0; j < J1; j += 2) {
+                const int k0 = DEC ? pd_kd(wave, j, kq) : pd_ka(wave, j, kq), k1 = DEC ? pd_kd(wave, j + 1, kq) : pd_ka(wave, j + 1, kq);
+                acc0 = fmaf(wreg[j], xb[k0 + ((DEC && j >= 32 && j < 64) ? 256 : 0)], acc0);
+                acc1 = fmaf(wreg[j + 1], xb[k1 + ((DEC && j + 1 >= 32 && j + 1 < 64) ? 256 : 0)], acc1);
+            }
+            acc[b] += acc0 + acc1;
+        }
+    }
+}
+// quad sum of the lanes of a gate row -> red[wave][r][b]; the accumulators start the next frame at zero
+__device__ __forceinline__ void pd_gemv_finish(float (&acc)[PD_MAXB], int B, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kq = lane & 3, r = lane >> 2;
+#pragma unroll
+    for (int b = 0; b < PD_MAXB; ++b) {
+        if (b < B) {
+            float v = acc[b];
+            v = T2V_DPP_ADD(v, 0xB1);
+            v = T2V_DPP_ADD(v, 0x4E);
+            if (kq == 0) red[(wave * 16 + r) * PD_MAXB + b] = v;
+        }
+        acc[b] = 0.f;
+    }
+}
+
 __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wg = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -191,13 +243,13 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
     float wa[PD_KATT / 32], wd[PD_KDEC / 32];
 #pragma unroll
     for (int j = 0; j < PD_KATT / 32; ++j) {
-        const int k = wave * (PD_KATT / 8) + 4 * j + kq;                // [h_att | ctx | pre1]
+        const int k = pd_ka(wave, j, kq);                                // [h_att | ctx | pre1]
         wa[j] = k < T2V_H ? a.w_hh_att[(size_t)grow * T2V_H + k]
                           : (k < T2V_KATT ? a.w_ih_att[(size_t)grow * 768 + T2V_PRE + (k - T2V_H)] : a.w_ih_att[(size_t)grow * 768 + (k - T2V_KATT)]);
     }
 #pragma unroll
     for (int j = 0; j < PD_KDEC / 32; ++j) {
-        const int k = wave * (PD_KDEC / 8) + 4 * j + kq;                // [h_att | ctx | h_dec]
+        const int k = pd_kd(wave, j, kq);                                // [h_att | ctx | h_dec]
         wd[j] = k < T2V_KATT ? a.w_ih_dec[(size_t)grow * T2V_KATT + k] : a.w_hh_dec[(size_t)grow * T2V_H + (k - T2V_KATT)];
     }
     float bias_a = 0.f, bias_d = 0.f;                                   // threads 0..15: gate row biases
@@ -210,9 +262,9 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
     if (tid < 2 * PD_MAXB * 4) cst[tid] = 0.f;
     if (tid == 0) flag[0] = 1;
     // role operands
-    float areg[16];
-#pragma unroll
-    for (int st = 0; st < 16; ++st) areg[st] = 0.f;
+    // (round 4: the fused location filter's MFMA operand lives in LDS — 16 registers per lane that only the attention
+    // workgroups used, next to 136 weight registers and the carried partial gate sums, made the kernel spill)
+    float* areg_s = rss + 32;                              // [16 steps][64 lanes]
     float4 vr = make_float4(0.f, 0.f, 0.f, 0.f);
     if (is_attn) {
         for (int i = tid; i < 16 * 1024; i += PD_THREADS) wq_s[(i >> 10) * 1028 + (i & 1023)] = a.wq[(size_t)(16 * as) * 1024 + i];
@@ -221,10 +273,13 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
         for (int i = tid; i < 2 * TW; i += PD_THREADS) win[i] = 0.f;
         const int g = lane >> 4, c16 = lane & 15;
         const float4* wp = (const float4*)(a.wcomb + (16 * as + c16) * 64 + 16 * g);
+        if (wave == 0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float4 w4 = wp[u];
-            areg[4 * u] = w4.x; areg[4 * u + 1] = w4.y; areg[4 * u + 2] = w4.z; areg[4 * u + 3] = w4.w;
+            for (int u = 0; u < 4; ++u) {
+                const float4 w4 = wp[u];
+                areg_s[(4 * u) * 64 + lane] = w4.x; areg_s[(4 * u + 1) * 64 + lane] = w4.y;
+                areg_s[(4 * u + 2) * 64 + lane] = w4.z; areg_s[(4 * u + 3) * 64 + lane] = w4.w;
+            }
         }
         vr = *(const float4*)(a.v + 16 * as + 4 * g);
     } else if (prow >= 0) {
@@ -240,6 +295,11 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
 
     const __amdgpu_buffer_rsrc_t rx = pd_rsrc(a.xg);
     int nap_e = 0, nap_h = 0, nap_x = 0, nap_c = 0, nap_p = 0, nap_q = 0;      // adaptive naps in front of the polls (64-cycle units)
+    // partial gate sums carried from where their inputs appear to where the gates are needed (see pd_gemv_part); frame 0
+    // starts from h_att = ctx = h_dec = 0, i.e. from zero partial sums
+    float ea[PD_MAXB], ed[PD_MAXB];
+#pragma unroll
+    for (int b = 0; b < PD_MAXB; ++b) ea[b] = ed[b] = 0.f;
     for (int t = 0; t < a.t_end; ++t) {
         const unsigned xcur = (unsigned)t * pd_row(B), xprev = xcur - pd_row(B);      // float offsets of this / the previous frame's row
         // ---- frame entry (t > 0): stop decision of the previous frame, Prenet output of the new frame's input
@@ -271,8 +331,13 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
         }
         PD_STAMP(0, 0); PD_STAMP(64, 10); PD_STAMP(128, 14);
         PD_RT(0);
+        if (a.prof && wg == 0 && tid == 0 && (t == 100 || t == 600)) {       // steady-state frame period: 500 frames between two stamps
+            a.prof[t == 100 ? 20 : 22] = __builtin_readcyclecounter();
+            a.prof[t == 100 ? 21 : 23] = __builtin_amdgcn_s_memrealtime();
+        }
         // ---- 1. attention_rnn(t): gates of this workgroup's 4 units, cell update, publish h_att
-        pd_gemv<PD_KATT / 32, PD_KATT>(wa, X, B, red);        // K contiguous in the LDS row: no split offset
+        pd_gemv_part<PD_KATT / 32, 48, 56, false>(wa, X, B, ea);      // the Prenet columns; [h_att | ctx] were added during frame t-1
+        pd_gemv_finish(ea, B, red);
         __syncthreads();
         if (tid < 16 * B) {                                    // thread = (row r = tid & 15, item b = tid >> 4)
             const int r = tid & 15, b = tid >> 4;
@@ -288,7 +353,11 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             const float gi = sigmoidf_(gp[0]), gf = sigmoidf_(gp[1]), gg = tanhf_(gp[2]), go = sigmoidf_(gp[3]);
             const float c = gf * cst[b * 4 + u] + gi * gg;
             cst[b * 4 + u] = c;
-            pd_put(rx, xcur + pd_hatt(B) + (unsigned)(b * 1024 + 4 * wg + u), go * tanhf_(c));
+            // the four units of an item leave as ONE 16-byte store (round 4: four 4-byte stores from four lanes were four
+            // write-through transactions into the same 32-byte sector)
+            const float h = go * tanhf_(c);
+            const float h1 = __shfl_down(h, 1, 4), h2 = __shfl_down(h, 2, 4), h3 = __shfl_down(h, 3, 4);
+            if (u == 0) pd_put4(rx, xcur + pd_hatt(B) + (unsigned)(b * 1024 + 4 * wg), h, h1, h2, h3);
         }
         PD_STAMP(0, 1);
         PD_RT(1);
@@ -311,21 +380,39 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                     f32x4 l0 = {0.f, 0.f, 0.f, 0.f}, l1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int st = 0; st < 16; st += 2) {
-                        l0 = mfma16x4(areg[st], bop[st], l0);
-                        l1 = mfma16x4(areg[st + 1], bop[st + 1], l1);
+                        l0 = mfma16x4(areg_s[st * 64 + lane], bop[st], l0);
+                        l1 = mfma16x4(areg_s[(st + 1) * 64 + lane], bop[st + 1], l1);
                     }
                     lacc[i] = l0 + l1;
                 }
             }
         }
         for (int b = 0; b < B; ++b) {
-            const int rounds = pd_gather(X + (size_t)b * PD_XW + PD_X_HA, rx, xcur + pd_hatt(B) + (unsigned)b * 1024u, 1024, b == 0 ? nap_h : 0, a.err, flag);
-            if (b == 0) nap_h = pd_adapt(nap_h, rounds);
+            // (only the attention workgroups need h_att(t) NOW; everybody else uses it for decoder_rnn microseconds later and
+            // comes for it late, with a fixed nap — 256 workgroups polling the same 32 lines the moment they land made this the
+            // longest hand-off of the frame)
+            const int rounds = pd_gather(X + (size_t)b * PD_XW + PD_X_HA, rx, xcur + pd_hatt(B) + (unsigned)b * 1024u, 1024,
+                                         b == 0 ? (is_attn ? nap_h : 80) : 0, a.err, flag);
+            if (b == 0 && is_attn) nap_h = pd_adapt(nap_h, rounds);
         }
         __syncthreads();
         if (flag[0] != 1) return;
         PD_STAMP(0, 2);
         PD_RT(2);
+        // decoder_rnn(t), part 2: the h_att(t) columns — now, while the attention workgroups are busy (they do theirs behind
+        // their context hand-off, in the shadow of the context gather)
+        if (!is_attn) {
+            pd_gemv_part<PD_KDEC / 32, 0, 32, true>(wd, X, B, ed);
+            // ... and the h_dec(t-1) columns: the other workgroups fetch that row only now, a frame after it was published and
+            // long after the projection workgroups (who needed it at once) are done with it
+            if (t > 0 && !wg_proj) {
+                for (int b = 0; b < B; ++b)
+                    (void)pd_gather(X + (size_t)b * PD_XW + PD_X_HD, rx, xprev + pd_hdec(B) + (unsigned)b * 1024u, 1024, 0, a.err, flag);
+                __syncthreads();
+                if (flag[0] != 1) return;
+                pd_gemv_part<PD_KDEC / 32, 32, 64, true>(wd, X, B, ed);
+            }
+        }
         if (is_attn) {
             const int g = lane >> 4, c16 = lane & 15;
             const int len = a.lengths ? a.lengths[ab] : Tp;
@@ -447,18 +534,18 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
         }
         PD_STAMP(0, 5); PD_STAMP(64, 11);
         PD_RT(5);
-        // ---- 3. ctx(t) and h_dec(t-1) for everyone, decoder_rnn(t)
+        if (is_attn) pd_gemv_part<PD_KDEC / 32, 0, 32, true>(wd, X, B, ed);      // (the context of the other items is in flight meanwhile)
+        // ---- 3. ctx(t) for everyone, the context columns of decoder_rnn(t)
         for (int b = 0; b < B; ++b) {
             const int rounds = pd_gather(X + (size_t)b * PD_XW + PD_X_CX, rx, xcur + pd_ctx(B) + (unsigned)b * 512u, 512, b == 0 ? nap_c : 0, a.err, flag);
             if (b == 0) nap_c = pd_adapt(nap_c, rounds);
-            if (t > 0 && !wg_proj)     // projection workgroups already hold h_dec(t-1) (they gathered it in stage 4)
-                (void)pd_gather(X + (size_t)b * PD_XW + PD_X_HD, rx, xprev + pd_hdec(B) + (unsigned)b * 1024u, 1024, 0, a.err, flag);
         }
         __syncthreads();
         if (flag[0] != 1) return;
         PD_STAMP(0, 6);
         PD_RT(6);
-        pd_gemv<PD_KDEC / 32, T2V_KATT>(wd, X, B, red);       // logical k >= 1536 (h_dec) sits 256 further in the LDS row
+        pd_gemv_part<PD_KDEC / 32, 64, 80, true>(wd, X, B, ed);
+        pd_gemv_finish(ed, B, red);
         __syncthreads();
         if (tid < 16 * B) {
             const int r = tid & 15, b = tid >> 4;
@@ -474,12 +561,34 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             const float gi = sigmoidf_(gp[0]), gf = sigmoidf_(gp[1]), gg = tanhf_(gp[2]), go = sigmoidf_(gp[3]);
             const float c = gf * cst[PD_MAXB * 4 + b * 4 + u] + gi * gg;
             cst[PD_MAXB * 4 + b * 4 + u] = c;
-            pd_put(rx, xcur + pd_hdec(B) + (unsigned)(b * 1024 + 4 * wg + u), go * tanhf_(c));
+            const float h = go * tanhf_(c);
+            const float h1 = __shfl_down(h, 1, 4), h2 = __shfl_down(h, 2, 4), h3 = __shfl_down(h, 3, 4);
+            if (u == 0) pd_put4(rx, xcur + pd_hdec(B) + (unsigned)(b * 1024 + 4 * wg), h, h1, h2, h3);
         }
         PD_STAMP(0, 7); PD_STAMP(64, 12);
         PD_RT(7);
+        // attention_rnn(t+1), the [h_att(t) | ctx(t)] columns: in the shadow of the projection / Prenet stages (the projection
+        // workgroups do theirs once their rows are out)
+        if (!wg_proj) pd_gemv_part<PD_KATT / 32, 0, 48, false>(wa, X, B, ea);
         // ---- 4. projection rows (mel, gate, folded Prenet layer 0)
         if (prow >= 0) {            // whole workgroup takes the branch: barriers inside are uniform
+            // the context columns of the rows first: h_dec(t) is still on its way
+            float pacc[PD_MAXB];
+#pragma unroll
+            for (int b = 0; b < PD_MAXB; ++b) pacc[b] = 0.f;
+            if (is_proj) {
+                const float* wr = prow_s + wave * 1536;
+#pragma unroll
+                for (int b = 0; b < PD_MAXB; ++b) {
+                    if (b < B) {
+                        const float* xb = X + (size_t)b * PD_XW;
+                        float acc = 0.f;
+#pragma unroll
+                        for (int i = 16; i < 24; ++i) acc = fmaf(wr[lane + 64 * i], xb[PD_X_CX + (lane + 64 * i - T2V_H)], acc);
+                        pacc[b] = acc;
+                    }
+                }
+            }
             for (int b = 0; b < B; ++b) {
                 const int rounds = pd_gather(X + (size_t)b * PD_XW + PD_X_HD, rx, xcur + pd_hdec(B) + (unsigned)b * 1024u, 1024, b == 0 ? nap_p : 0, a.err, flag);
                 if (b == 0) nap_p = pd_adapt(nap_p, rounds);
@@ -489,14 +598,18 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             if (is_proj) {
                 const float* wr = prow_s + wave * 1536;
                 bool all_fired = true;
-                for (int b = 0; b < B; ++b) {
-                    const float* xb = X + (size_t)b * PD_XW;
-                    float acc = 0.f;
+                // (an opaque copy of the row number: the output addresses derived from it are rebuilt per frame instead of being
+                // hoisted out of the frame loop, spilled, and reloaded from scratch in front of every store)
+                int prow_o = prow;
+                asm volatile("" : "+v"(prow_o));
+                const int prow = prow_o;
 #pragma unroll
-                    for (int i = 0; i < 24; ++i) {
-                        const int k = lane + 64 * i;                         // [h_dec (1024) | ctx (512)]
-                        acc = fmaf(wr[k], k < T2V_H ? xb[PD_X_HD + k] : xb[PD_X_CX + (k - T2V_H)], acc);
-                    }
+                for (int b = 0; b < PD_MAXB; ++b) {
+                    if (b >= B) continue;
+                    const float* xb = X + (size_t)b * PD_XW;
+                    float acc = pacc[b];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc = fmaf(wr[lane + 64 * i], xb[PD_X_HD + lane + 64 * i], acc);      // the h_dec columns
                     acc = wave_sum(acc) + pbias;
                     if (lane == 0) {
                         if (prow < T2V_NMEL) a.MEL[((size_t)t * B + b) * T2V_NMEL + prow] = acc;
@@ -522,7 +635,18 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                 const int b = tid >> 3, row = (wg - PD_WG_PROJ) * 8 + (tid & 7);
                 if (row > T2V_NMEL && row < PD_NROW) pd_put(rx, xcur + pd_pre0(B) + (unsigned)(b * 256 + row - (T2V_NMEL + 1)), gst[b * 8 + (tid & 7)]);
             }
+            pd_gemv_part<PD_KATT / 32, 0, 48, false>(wa, X, B, ea);
+        } else if (is_attn && t + 1 < a.t_end) {
+            // decoder_rnn(t+1), part 1 (the h_dec(t) columns) of the ATTENTION workgroups: in the tail of this frame — at the top
+            // of the next one they go straight from "h_att published" to their gather of it and the attention (the chain).  The
+            // projection workgroups are gathering the same row right now and ARE the chain: let them go first.
+            __builtin_amdgcn_s_sleep(48);
+            for (int b = 0; b < B; ++b)
+                (void)pd_gather(X + (size_t)b * PD_XW + PD_X_HD, rx, xcur + pd_hdec(B) + (unsigned)b * 1024u, 1024, 0, a.err, flag);
+            __syncthreads();
+            if (flag[0] != 1) return;
         }
+        if ((is_attn || wg_proj) && t + 1 < a.t_end) pd_gemv_part<PD_KDEC / 32, 32, 64, true>(wd, X, B, ed);
         PD_STAMP(64, 13); PD_STAMP(128, 15);
         PD_RT(8);
         // ---- 5. Prenet layer 1 rows: wave 0 fetches pre0 for the whole workgroup (256 waves polling the same 1 KB were the
@@ -569,7 +693,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
 static size_t pd_lds_bytes(int B, int T_in) {
     const size_t Tcap = (size_t)((T_in + 15) / 16) * 16;
     size_t f = (size_t)B * PD_XW + 8 * 16 * PD_MAXB + PD_MAXB * 16 + 2 * PD_MAXB * 4 + 4;
-    const size_t attn = 16 * 1028 + Tcap * 64 + Tcap * 16 + 2 * (Tcap + 32) + Tcap + 16 + 32 * 16 + 8 * 64 + 64;
+    const size_t attn = 16 * 1028 + Tcap * 64 + Tcap * 16 + 2 * (Tcap + 32) + Tcap + 16 + 32 * 16 + 8 * 64 + 64 + 16 * 64;
     const size_t proj = 8 * 1536;
     f += attn > proj ? attn : proj;
     return f * sizeof(float);

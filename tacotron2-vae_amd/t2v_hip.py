@@ -1139,9 +1139,9 @@ class InferenceSession(object):
         self.B, self.T_in, self.max_steps = B, T_in, int(max_steps)
         T = self.max_steps
         self.memory, self.pm, self.lengths = _f32c(memory.detach()), _f32c(pm.detach()), lengths
-        self.packF_att, self.packF_dec, _, _ = pack_decoder_weights(w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, KATT_INF,
-                                                                    False)
-        # the persistent one-launch loop reads the nn.LSTMCell tensors themselves (weights stay in registers)
+        # the persistent one-launch loop reads the nn.LSTMCell tensors themselves (weights stay in registers); the 71 MB pack
+        # of the launch-per-stage loop is built by the first run() that needs it (round 4: it cost every utterance ~0.1 ms)
+        self.packF_att = self.packF_dec = self.W = None
         self.raw = tuple(_f32c(t.detach()) for t in (w_ih_att, w_hh_att, w_ih_dec, w_hh_dec))
         self.wq = _f32c(wq.detach())
         self.b_att, self.b_dec = _f32c(b_att.detach()), _f32c(b_dec.detach())
@@ -1166,8 +1166,6 @@ class InferenceSession(object):
         self.MEL = torch.empty(T, B, 80, **f32)
         self.GATE = torch.empty(T, B, **f32)
         self.stop = torch.full((1,), self.INT_MAX, device=dev, dtype=torch.int32)
-        self.W = _DecWeights(_p(self.packF_att), _p(self.packF_dec), None, None, _p(self.b_att), _p(self.b_dec),
-                             _p(self.wqT), _p(self.wcomb), _p(self.v))
         self.S = _DecInferBufs(_p(self.memory), _p(self.pm), _p(self.lengths), _p(self.XS), _p(self.CA), _p(self.CD),
                                _p(self.QP), _p(self.AL), _p(self.ACUM), _p(self.PRE), _p(self.MEL), _p(self.GATE),
                                _p(self.stop), _p(self.w1), _p(self.proj_w), _p(self.proj_b))
@@ -1204,6 +1202,11 @@ class InferenceSession(object):
         self._perr.zero_()
 
     def run(self, t0, t1, gate_threshold, p_prenet, external_prenet, seed):
+        if self.W is None:
+            self.packF_att, self.packF_dec, _, _ = pack_decoder_weights(self.raw[0], self.raw[1], self.raw[2], self.raw[3], KATT_INF,
+                                                                        False)
+            self.W = _DecWeights(_p(self.packF_att), _p(self.packF_dec), None, None, _p(self.b_att), _p(self.b_dec),
+                                 _p(self.wqT), _p(self.wcomb), _p(self.v))
         _check(load_library().t2v_decoder_infer_steps(C.byref(self.W), C.byref(self.S), self.B, self.T_in, int(t0),
                                                       int(t1), float(gate_threshold), float(p_prenet),
                                                       int(bool(external_prenet)), int(seed), _stream()),
