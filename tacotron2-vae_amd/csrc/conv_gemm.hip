@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include "t2v_common.h"
 #include "t2v_kernels.h"
+#include "t2v_coop.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -187,6 +188,8 @@ struct ConvTiledArgs {
     float* stat_part;    // fwd: (gridDim.x, M, 2) or NULL
     int B, Cin, T, M, tiles_per_item;
     unsigned long long* prof;   // optional: [0..1] shader-clock stamps, [2..3] 100 MHz stamps of workgroup (0,0)
+    float* ks_part;      // fwd, gridDim.z == 2 (input channels cut in halves): raw accumulator tiles [z][tile][256 threads][4 NTW]
+    unsigned* ks_ctr;    // ... and one arrival counter per output tile (zero before and after the launch)
 };
 
 template <int NTW>
@@ -202,9 +205,13 @@ __global__ __launch_bounds__(256) void k_conv5_fwd(ConvTiledArgs a) {
     const int bb = blockIdx.x / a.tiles_per_item, t0 = (blockIdx.x % a.tiles_per_item) * BN;
     const int m0 = blockIdx.y * CT_BM;
     const int CK = a.Cin * 5;
-    const int nkt = a.Cin / 16;
+    // gridDim.z == 2 (round 4, launches that fill half the chip or less — the encoder bank's 6 x 84 positions are 144
+    // workgroups): each half of the input channels in its own workgroup, the one that finishes second adds the other's tile
+    const int nkt_all = a.Cin / 16;
+    const int kt0 = gridDim.z > 1 ? (int)blockIdx.z * (nkt_all / 2) : 0;
+    const int nkt = gridDim.z > 1 ? (blockIdx.z == 0 ? nkt_all / 2 : nkt_all - nkt_all / 2) : nkt_all;
 
-    const bool stamp = a.prof && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0;
+    const bool stamp = a.prof && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
     if (stamp) { a.prof[0] = __builtin_readcyclecounter(); a.prof[2] = wall_clock64(); }
     // ---- staging plan (everything that does not depend on the k-tile is computed once; no branches around loads:
     //      rows past M are clamped — their outputs are never stored — and out-of-range positions are selected to 0)
@@ -233,9 +240,9 @@ __global__ __launch_bounds__(256) void k_conv5_fwd(ConvTiledArgs a) {
     }
     auto load_one = [&](int kt, int q) {          // q-th global load of tile kt (q compile-time after unrolling)
         if (q < 5) {
-            ra[q] = *(const float4*)(a_row + 80 * kt + 16 * q);
+            ra[q] = *(const float4*)(a_row + 80 * (kt0 + kt) + 16 * q);
         } else {
-            const float v = x_item[(size_t)16 * kt * a.T + x_goff[q - 5]];
+            const float v = x_item[(size_t)16 * (kt0 + kt) * a.T + x_goff[q - 5]];
             rx[q - 5] = x_ok[q - 5] ? v : 0.f;
         }
     };
@@ -295,6 +302,33 @@ __global__ __launch_bounds__(256) void k_conv5_fwd(ConvTiledArgs a) {
         __syncthreads();
     }
     if (stamp) { a.prof[1] = __builtin_readcyclecounter(); a.prof[3] = wall_clock64(); }
+    if (gridDim.z > 1) {
+        // write-through partial, arrival counter, and the second arriver adds the first one's tile (a + b == b + a: the same
+        // bits whichever half comes second); no fence — see the split-K epilogue of gemm.hip
+        const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x, ntile = (size_t)gridDim.x * gridDim.y;
+        float* mine = a.ks_part + ((blockIdx.z * ntile + tile) * 256 + tid) * (4 * NTW);
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st_sc1(mine + 4 * n + r, acc[n][r]);
+        __shared__ unsigned second_;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) second_ = __hip_atomic_fetch_add(a.ks_ctr + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (second_ == 0u) return;
+        if (tid == 0) __hip_atomic_store(a.ks_ctr + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float* other = a.ks_part + (((1 - blockIdx.z) * ntile + tile) * 256 + tid) * (4 * NTW);
+        float o[NTW][4];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[n][r] = ld_sc1(other + 4 * n + r);
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[n][r] += o[n][r];
+    }
     // epilogue: lane holds rows m0 + 16w + 4kq + r (r = 0..3) of column t0 + 16n + j
     float psum[4] = {0.f, 0.f, 0.f, 0.f}, psq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -623,6 +657,33 @@ static inline int conv5_dw_splits(int B, int Cin, int T, int Cout) {
     return ns;
 }
 
+// scratch of the split launches: slices of one ring (a captured graph keeps the slices of its nodes; a slice comes round again
+// 64 MB of partial tiles later, long after its launch has retired)
+#include <atomic>
+static float* conv_ks_scratch(size_t floats) {
+    constexpr size_t RING = (size_t)16 << 20;       // floats (64 MB)
+    static float* ring = nullptr;
+    static std::atomic<size_t> pos{0};
+    static std::atomic<int> state{0};
+    floats = (floats + 63) & ~(size_t)63;
+    if (floats > RING / 4) return nullptr;
+    if (state.load(std::memory_order_acquire) != 2) {
+        int expect = 0;
+        if (state.compare_exchange_strong(expect, 1)) {
+            float* p = nullptr;
+            if (hipMalloc((void**)&p, RING * sizeof(float)) != hipSuccess) { state.store(0); return nullptr; }
+            ring = p;
+            state.store(2, std::memory_order_release);
+        } else {
+            while (state.load(std::memory_order_acquire) == 1) { }
+            if (state.load() != 2) return nullptr;
+        }
+    }
+    size_t at = pos.fetch_add(floats) % RING;
+    if (at + floats > RING) { pos.store(floats); at = 0; }
+    return ring + at;
+}
+
 static inline int conv5_pick_bn(int T, int B, int M) {
     if (const char* e = getenv("T2V_CONV_BN")) { const int v = atoi(e); if (v == 32 || v == 48 || v == 64 || v == 80 || v == 96) return v; }
     const int cands[5] = {32, 48, 64, 80, 96};
@@ -636,16 +697,47 @@ static inline int conv5_pick_bn(int T, int B, int M) {
     }
     return best;
 }
+// forward tiles with the optional cut of the input channels in two: the same cost model, a split launch does half the k-tiles
+// per workgroup (+ ~8 columns' worth of exchange) but only pays when all its workgroups get a CU of their own
+static inline int conv5_pick_bn_ks(int T, int B, int M, int Cin, int* ks) {
+    static const int ksplit_on = getenv("T2V_CONV_KSPLIT") ? atoi(getenv("T2V_CONV_KSPLIT")) : 1;
+    *ks = 1;
+    const int bn1 = conv5_pick_bn(T, B, M);
+    if (!ksplit_on || Cin < 256 || getenv("T2V_CONV_BN")) return bn1;
+    const int cands[5] = {32, 48, 64, 80, 96};
+    const long w1 = (long)B * ((T + bn1 - 1) / bn1) * ((M + CT_BM - 1) / CT_BM);
+    long best_cost = 2 * ((w1 + T2V_NWG - 1) / T2V_NWG) * (bn1 + 40);         // (costs doubled: halves stay integers)
+    int best = bn1;
+    for (int i = 0; i < 5; ++i) {
+        const int bn = cands[i];
+        const long wgs = 2 * (long)B * ((T + bn - 1) / bn) * ((M + CT_BM - 1) / CT_BM);
+        if (wgs > T2V_NWG) continue;
+        const long cost = (bn + 40) + 16;
+        if (cost < best_cost) { best = bn; best_cost = cost; *ks = 2; }
+    }
+    return best;
+}
 static inline bool conv5_tiled_ok(int Cin, int KS) { return KS == 5 && Cin % 16 == 0; }
 
 static void launch_conv5_fwd(const float* W, const float* X, const float* bias, float* Y, float* stat_part, int B,
                              int Cin, int T, int M, hipStream_t stream) {
-    const int BN = conv5_pick_bn(T, B, M);
+    int ks = 1;
+    const int BN = conv5_pick_bn_ks(T, B, M, Cin, &ks);
     ConvTiledArgs a;
     a.W = W; a.X = X; a.dY = nullptr; a.bias = bias; a.Y = Y; a.stat_part = stat_part;
     a.B = B; a.Cin = Cin; a.T = T; a.M = M; a.tiles_per_item = (T + BN - 1) / BN;
     a.prof = g_t2v_prof;
+    a.ks_part = nullptr; a.ks_ctr = nullptr;
     dim3 grid(B * a.tiles_per_item, (M + CT_BM - 1) / CT_BM);
+    // a launch that leaves half the chip idle and has a deep K: the input channels are cut in two (T2V_CONV_KSPLIT=0 switches
+    // it off for measurements)
+    const long ntile = (long)grid.x * grid.y;
+    if (ks == 2) {
+        const size_t pf = (size_t)2 * ntile * 256 * 4 * (BN / 16);
+        a.ks_part = conv_ks_scratch(pf);
+        a.ks_ctr = a.ks_part ? t2v_arrival_counters((int)ntile) : nullptr;
+        if (a.ks_part && a.ks_ctr) grid.z = 2; else a.ks_part = nullptr;
+    }
     if (BN == 32) k_conv5_fwd<2><<<grid, 256, 0, stream>>>(a);
     else if (BN == 48) k_conv5_fwd<3><<<grid, 256, 0, stream>>>(a);
     else if (BN == 64) k_conv5_fwd<4><<<grid, 256, 0, stream>>>(a);
@@ -658,7 +750,8 @@ static void launch_conv5_fwd_bf16(const float* W, int flipT, unsigned short* Wp,
                                   hipStream_t stream) {
     const size_t n = (size_t)W_M * W_Cin * 5;
     k_conv5_pack_bf16<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(W, Wp, W_M, W_Cin, flipT);
-    const int BN = conv5_pick_bn(T, B, M);
+    int ks_unused = 1;      // (the same tile width as the fp32 launch: t2v_conv1d_stat_blocks answers for both)
+    const int BN = conv5_pick_bn_ks(T, B, M, Cin, &ks_unused);
     ConvBf16Args a;
     a.Wp = Wp; a.X = X; a.bias = bias; a.Y = Y; a.stat_part = stat_part;
     a.B = B; a.Cin = Cin; a.T = T; a.M = M; a.tiles_per_item = (T + BN - 1) / BN;
@@ -729,7 +822,7 @@ extern "C" int t2v_conv1d_fwd(const float* W, const float* X, const float* bias,
 }
 
 extern "C" int t2v_conv1d_stat_blocks(int B, int T, int Cin, int Cout, int KS) {
-    if (conv5_tiled_ok(Cin, KS)) { const int BN = conv5_pick_bn(T, B, Cout); return B * ((T + BN - 1) / BN); }
+    if (conv5_tiled_ok(Cin, KS)) { int ks; const int BN = conv5_pick_bn_ks(T, B, Cout, Cin, &ks); return B * ((T + BN - 1) / BN); }
     return (B * T + CG_BN - 1) / CG_BN;
 }
 
@@ -764,7 +857,7 @@ extern "C" int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, f
         ConvTiledArgs a;
         a.W = nullptr; a.X = X; a.dY = dY; a.bias = nullptr; a.Y = dW; a.stat_part = nullptr;
         a.B = B; a.Cin = Cin; a.T = T; a.M = Cout; a.tiles_per_item = 0;
-        a.prof = nullptr;
+        a.prof = nullptr; a.ks_part = nullptr; a.ks_ctr = nullptr;
         const int ns = conv5_dw_splits(B, Cin, T, Cout);
         if (ns > 1 && !dw_scratch) return T2V_ERR_ARG;
         if (ns > 1) a.Y = dw_scratch;

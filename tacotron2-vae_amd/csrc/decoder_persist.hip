@@ -76,6 +76,9 @@ __host__ __device__ static inline unsigned pd_stop(int B) { return (unsigned)B *
 __host__ __device__ static inline unsigned pd_row(int B) { return (unsigned)B * 5120u + 32u; }
 
 #define PD_SENT 0xFFFFFFFFu
+#ifndef PD_POLL2
+#define PD_POLL2 0
+#endif
 #define PD_SC1 16
 typedef unsigned pd_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned pd_u32x4 __attribute__((ext_vector_type(4)));
@@ -117,12 +120,28 @@ __device__ __forceinline__ int pd_gather(float* dst, __amdgpu_buffer_rsrc_t r, u
     const bool on = 2 * tid < n;
     pd_u32x2 x = {0u, 0u};
     unsigned spins = 0;
+#if PD_POLL2
+    // two polls in flight, half a round trip apart: a row that lands just after one poll left is seen by the other one
+    // a quarter of a round trip later on average, not a full one
+    pd_u32x2 x0 = {PD_SENT, PD_SENT}, x1 = {PD_SENT, PD_SENT};
+    if (on) x0 = pd_get2(r, off + 2u * (unsigned)tid);
+    __builtin_amdgcn_s_sleep(4);
+    if (on) x1 = pd_get2(r, off + 2u * (unsigned)tid);
+    for (;;) {
+        if (__all(!on || (x0[0] != PD_SENT && x0[1] != PD_SENT))) { x = x0; break; }
+        if (on) x0 = pd_get2(r, off + 2u * (unsigned)tid);
+        if (__all(!on || (x1[0] != PD_SENT && x1[1] != PD_SENT))) { x = x1; break; }
+        if (on) x1 = pd_get2(r, off + 2u * (unsigned)tid);
+        if (pd_give_up(spins, err, flag)) break;
+    }
+#else
     for (;;) {
         if (on) x = pd_get2(r, off + 2u * (unsigned)tid);
         if (__all(x[0] != PD_SENT && x[1] != PD_SENT)) break;
         __builtin_amdgcn_s_sleep(1);
         if (pd_give_up(spins, err, flag)) break;
     }
+#endif
     if (on) *(float2*)(dst + 2 * tid) = make_float2(__uint_as_float(x[0]), __uint_as_float(x[1]));
     return (int)spins;
 }
