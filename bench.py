@@ -115,6 +115,29 @@ def cpu_baseline(steps=5, warmup=2, threads=None):
                       % (steps, warmup, torch.get_num_threads())}
 
 
+def _cpu_all_cores_leg(limit_s):
+    """ONE oracle step with every host core, in a child process with a time limit: a GPU box that runs its containers under a
+    CPU quota throttles 256 spinning OpenMP threads to a crawl (minutes per step), and the default bench run must stay
+    within a few minutes — the leg then reports that it was cut off instead of holding the line back"""
+    import subprocess
+    code = ("import json, os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import bench; "
+            "r = bench.cpu_baseline(steps=1, warmup=0, threads=os.cpu_count()); print('ALLCORES ' + json.dumps(r))"
+            % (ROOT, os.path.join(ROOT, 'tacotron2-vae_amd')))
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=limit_s)
+        for line in p.stdout.split('\n'):
+            if line.startswith('ALLCORES '):
+                r = json.loads(line[9:])
+                return {"value": r["value"], "cores": r["cores"], "s_per_it": r["s_per_it"],
+                        "sample": "ONE timed step, no warm-up, every host core (child process)"}
+        return {"value": None, "cores": os.cpu_count(), "error": (p.stderr or p.stdout)[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "cores": os.cpu_count(), "timed_out_after_s": round(time.perf_counter() - t0, 1),
+                "note": "one step with every host core did not finish inside the limit (CPU quota of the container); "
+                        "the figure with the fastest thread count is the one above"}
+
+
 def decode_bench(model, T_in=200, steps=800):
     """BASELINE.json configs[3]: B=1, 200-symbol utterance, exactly `steps` free-running decoder steps
     (gate ignored), style = fc3(z), z ~ N(0,I) seed 7.  Secondary figure: frames/s of the decode loop."""
@@ -423,6 +446,7 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=8,
                     help='torch CPU threads for the baseline leg (the M=6 GEMVs of this model stop scaling\n'
                          'around 8 threads on this EPYC host: 8 → 3.7 s/it, 16 → 4.2, 32 → 7.4, all cores ≈ 40)')
+    ap.add_argument('--cpu-all-cores-timeout', type=float, default=75.0)
     ap.add_argument('--no-cpu-all-cores', action='store_true',
                     help='skip the second CPU figure (ONE oracle step with every host core, ≈40 s on the 128-core host)')
     ap.add_argument('--no-decode', action='store_true')
@@ -581,9 +605,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(steps=args.cpu_steps, warmup=args.cpu_warmup, threads=args.cpu_threads)
             out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
             if not args.no_cpu_all_cores:       # SURVEY 8(d) says "all cores": reported next to the fastest thread count
-                allc = cpu_baseline(steps=1, warmup=0, threads=os.cpu_count())
-                out["cpu_baseline"]["all_cores"] = {"value": allc["value"], "cores": allc["cores"], "s_per_it": allc["s_per_it"],
-                                                    "sample": "ONE timed step, no warm-up, every host core"}
+                out["cpu_baseline"]["all_cores"] = _cpu_all_cores_leg(args.cpu_all_cores_timeout)
         print(json.dumps(out))
     if dist.is_initialized():
         # orderly teardown of a rank: captured graphs and their arenas go first, then the communicator; the process then

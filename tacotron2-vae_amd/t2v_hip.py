@@ -348,7 +348,10 @@ class Overlap(object):
 
     def __init__(self, device=None):
         self.on = True
-        self._streams = {n: torch.cuda.Stream(device=device) for n in self.NAMES}
+        # (T2V_STREAM_PRIO=1, measurement: the engine's own stream at high priority, the side streams below it — the deferred
+        # weight-gradient GEMMs then yield CUs to the dependent chain on the main stream)
+        lo = int(os.environ.get('T2V_SIDE_PRIO', '0'))
+        self._streams = {n: torch.cuda.Stream(device=device, priority=lo) for n in self.NAMES}
         self._used = []
         self._keep = []
 

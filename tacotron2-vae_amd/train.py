@@ -114,7 +114,7 @@ class TrainEngine(object):
         # graph mode: EVERY step of this engine (the eager warm-up ones too) runs on one dedicated stream — autograd's
         # AccumulateGrad nodes remember the stream of their first backward, and a capture that has to synchronise with
         # the legacy default stream is illegal
-        self._stream = torch.cuda.Stream() if self.use_graph else None
+        self._stream = torch.cuda.Stream(priority=int(os.environ.get('T2V_MAIN_PRIO', '0'))) if self.use_graph else None
         # this engine's device-side step record (dropout epoch, lr, Adam bias corrections, KL weight): bound to the
         # engine's own stream when it has one, so that two engines in one process never share a record
         self.step_params = t2v_hip.step_params(fresh=True, stream=self._stream)
