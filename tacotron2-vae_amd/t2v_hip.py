@@ -1159,20 +1159,30 @@ class InferenceSession(object):
         b0p = gemm(w0, pb.view(1, -1)).view(-1)                                  # (256) = W0 · b
         self.proj_w = torch.cat((pw, gate_w.detach(), w0p), 0).contiguous()      # (337,1536)
         self.proj_b = torch.cat((pb, gate_b.detach(), b0p), 0).contiguous()
-        self.XS = torch.empty(T + 2, B, XW, **f32); self.XS[0:2].zero_()
-        self.CA = torch.empty(T + 1, B, H, **f32); self.CA[0].zero_()
-        self.CD = torch.empty(T + 1, B, H, **f32); self.CD[0].zero_()
-        self.QP = torch.empty(lib.t2v_decoder_qp_floats(B, T_in), **f32)
+        # the persistent launch keeps the recurrent state on chip: it needs PRE[0] and writes MEL / GATE / AL / stop.  The state
+        # arenas of the launch-per-stage loop (XS, CA, CD, QP, ACUM: 20 MB, five clears) are made by the first run() (round 4)
+        self.XS = self.CA = self.CD = self.QP = self.ACUM = self.S = None
         self.AL = torch.empty(T + 1, B, T_in, **f32); self.AL[0].zero_()
-        self.ACUM = torch.empty(T + 1, B, T_in, **f32); self.ACUM[0].zero_()
         self.PRE = torch.empty(T + 1, B, PRE, **f32)
         self.MEL = torch.empty(T, B, 80, **f32)
         self.GATE = torch.empty(T, B, **f32)
         self.stop = torch.full((1,), self.INT_MAX, device=dev, dtype=torch.int32)
+        self.t = 0
+
+    def _stage_arena(self):
+        if self.S is not None:
+            return
+        lib = load_library()
+        B, T_in, T = self.B, self.T_in, self.max_steps
+        f32 = dict(device=self.memory.device, dtype=torch.float32)
+        self.XS = torch.empty(T + 2, B, XW, **f32); self.XS[0:2].zero_()
+        self.CA = torch.empty(T + 1, B, H, **f32); self.CA[0].zero_()
+        self.CD = torch.empty(T + 1, B, H, **f32); self.CD[0].zero_()
+        self.QP = torch.empty(lib.t2v_decoder_qp_floats(B, T_in), **f32)
+        self.ACUM = torch.empty(T + 1, B, T_in, **f32); self.ACUM[0].zero_()
         self.S = _DecInferBufs(_p(self.memory), _p(self.pm), _p(self.lengths), _p(self.XS), _p(self.CA), _p(self.CD),
                                _p(self.QP), _p(self.AL), _p(self.ACUM), _p(self.PRE), _p(self.MEL), _p(self.GATE),
                                _p(self.stop), _p(self.w1), _p(self.proj_w), _p(self.proj_b))
-        self.t = 0
 
     def persistent_supported(self):
         return bool(load_library().t2v_decoder_persist_supported(self.B, self.T_in))
@@ -1205,6 +1215,7 @@ class InferenceSession(object):
         self._perr.zero_()
 
     def run(self, t0, t1, gate_threshold, p_prenet, external_prenet, seed):
+        self._stage_arena()
         if self.W is None:
             self.packF_att, self.packF_dec, _, _ = pack_decoder_weights(self.raw[0], self.raw[1], self.raw[2], self.raw[3], KATT_INF,
                                                                         False)
