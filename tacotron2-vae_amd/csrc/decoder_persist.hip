@@ -121,8 +121,8 @@ __device__ __forceinline__ int pd_gather(float* dst, __amdgpu_buffer_rsrc_t r, u
     pd_u32x2 x = {0u, 0u};
     unsigned spins = 0;
 #if PD_POLL2
-    // two polls in flight, half a round trip apart: a row that lands just after one poll left is seen by the other one
-    // a quarter of a round trip later on average, not a full one
+    // (measurement variant, -DPD_POLL2=1: two polls in flight, half a round trip apart.  Same-box A/B: 14.68 vs 14.39 us per
+    // frame — twice the requests on lines that 256 workgroups already poll cost more than the quarter round trip they save)
     pd_u32x2 x0 = {PD_SENT, PD_SENT}, x1 = {PD_SENT, PD_SENT};
     if (on) x0 = pd_get2(r, off + 2u * (unsigned)tid);
     __builtin_amdgcn_s_sleep(4);
@@ -151,27 +151,8 @@ __device__ __forceinline__ int pd_adapt(int nap, int rounds) {       // units of
     return nap;
 }
 
-// LSTM gate rows of this workgroup for one cell: lane = (row r = lane>>2 (unit r>>2, gate r&3), kq = lane&3), wave = K
-// eighth; weights wreg[j] <-> logical k = wave*KW + 4j + kq.  Partial dot products -> red[wave][r][b].
-template <int NJ, int KSPLIT>   // NJ = K/32 weights per lane; KSPLIT: logical k >= KSPLIT sits 256 further in the LDS row
-__device__ __forceinline__ void pd_gemv(const float (&wreg)[NJ], const float* X, int B, float* red) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kq = lane & 3, r = lane >> 2;
-    for (int b = 0; b < B; ++b) {
-        const float* xb = X + (size_t)b * PD_XW;
-        float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll
-        for (int j = 0; j < NJ; j += 2) {
-            const int k0 = wave * (4 * NJ) + 4 * j + kq, k1 = k0 + 4;
-            acc0 = fmaf(wreg[j], xb[k0 + (k0 >= KSPLIT ? 256 : 0)], acc0);
-            acc1 = fmaf(wreg[j + 1], xb[k1 + (k1 >= KSPLIT ? 256 : 0)], acc1);
-        }
-        float acc = acc0 + acc1;
-        acc = T2V_DPP_ADD(acc, 0xB1);        // quad: lanes kq = 0..3 of a row
-        acc = T2V_DPP_ADD(acc, 0x4E);
-        if (kq == 0) red[(wave * 16 + r) * PD_MAXB + b] = acc;
-    }
-}
-
+// LSTM gate rows of this workgroup for one cell: lane = (row r = lane>>2 (unit r>>2, gate r&3), kq = lane&3); weights in
+// registers, VALU dot products against the LDS copy of the state vectors, partial dot products -> red[wave][r][b].
 // Round 4: the two LSTM GEMVs of a frame are cut by WHEN their inputs exist, so that only the columns of the value that has
 // just arrived are left on the frame's dependency chain:
 //   attention_rnn(t+1) = [h_att(t) | ctx(t)] (1536 columns, known when ctx(t) has been gathered: evaluated in the shadow of
