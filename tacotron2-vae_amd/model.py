@@ -233,7 +233,17 @@ class Decoder(nn.Module):
 
     def inference(self, memory, chunk=32, persistent=None):
         """reference model.py:428-464: decode until sigmoid(gate) > gate_threshold or max_decoder_steps.
-        The loop runs on the GPU in chunks of `chunk` frames between stop-flag reads."""
+        The loop runs on the GPU in chunks of `chunk` frames between stop-flag reads.
+        More than 8 utterances (the decode kernels take 8 per call; the reference's own loop only works for one) are decoded
+        8 at a time, each group until all of ITS gates have fired, and padded to the longest group: mel 0, gate logit +1e3
+        (fired), attention weights 0 (round 4; it used to raise)."""
+        if memory.size(0) > 8:
+            outs = [self.inference(memory[b0:b0 + 8], chunk, persistent) for b0 in range(0, memory.size(0), 8)]
+            n = max(o[0].size(2) for o in outs)
+            F_pad = torch.nn.functional.pad
+            return (torch.cat([F_pad(o[0], (0, n - o[0].size(2))) for o in outs], 0),
+                    torch.cat([F_pad(o[1], (0, 0, 0, n - o[1].size(1)), value=1e3) for o in outs], 0),
+                    torch.cat([F_pad(o[2], (0, 0, 0, n - o[2].size(1))) for o in outs], 0))
         self.initialize_decoder_states(memory, mask=None)
         s = self._sess
         s.PRE[0].copy_(self.prenet(self.get_go_frame(memory)))

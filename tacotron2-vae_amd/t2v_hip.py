@@ -1136,7 +1136,7 @@ class InferenceSession(object):
         lib = _require_gpu(memory, pm, w_ih_att)
         B, T_in, _ = memory.shape
         if B > 8:
-            raise T2VHipError("free-running decode supports B <= 8")
+            raise T2VHipError("one decode session takes B <= 8 utterances (Decoder.inference runs larger batches 8 at a time)")
         dev = memory.device
         f32 = dict(device=dev, dtype=torch.float32)
         self.B, self.T_in, self.max_steps = B, T_in, int(max_steps)

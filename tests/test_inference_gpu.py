@@ -154,7 +154,26 @@ def test_cfg4_decode_800_steps_matches_oracle():
         M.drop_rate = old
 
 
-@pytest.mark.parametrize("T_in,B", [(1, 1), (3, 1), (16, 2), (224, 1), (225, 1)])
+def test_more_than_eight_utterances_are_decoded_in_groups(model):
+    """B = 11: groups of 8 + 3, each through the kernels it qualifies for, same values as decoding the groups by hand"""
+    g = torch.Generator().manual_seed(77)
+    memory = (torch.randn(11, 40, 512, generator=g) * 0.5).cuda()
+    dec = model.decoder
+    old_thr = dec.gate_threshold
+    dec.gate_threshold = 1.0                                        # never stop: all frames of max_decoder_steps
+    try:
+        with torch.no_grad():
+            mel, gate, al = dec.inference(memory)
+            parts = [dec.inference(memory[:8]), dec.inference(memory[8:])]
+    finally:
+        dec.gate_threshold = old_thr
+    n = parts[0][0].size(2)
+    assert mel.shape == (11, 80, n) and gate.shape == (11, n, 1) and al.shape == (11, n, 40)
+    for i, ref in enumerate((torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]), torch.cat([p[2] for p in parts]))):
+        assert (ref - (mel, gate, al)[i]).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("T_in,B", [(1, 1), (3, 1), (16, 2), (224, 1), (225, 1), (40, 8)])
 def test_short_and_limit_texts_both_decode_paths_agree(model, T_in, B):
     """Free-running decode at the edges of the persistent kernel's range (one symbol; one 16-position tile; T_in = 224 is
     its LDS limit, 225 falls back to the launch-per-stage path): persistent == launch-per-stage == oracle."""
