@@ -539,6 +539,7 @@ class Tacotron2(nn.Module):
         self.decoder.__dict__['_tf_t'] = (1 << 20) + _block_calls[0]
         fork = t2v_hip.mark()
         enc_first = os.environ.get('T2V_FWD_ORDER', 'enc_first') == 'enc_first' and fork is not None
+        t2v_hip.BiLSTM._prep.clear()        # (nothing of a step that was abandoned half-way may be picked up by this one)
         with t2v_hip.side('w', after=fork) as forked_p:
             if forked_p:    # parameter-only operands of the BiLSTM, ready long before the conv bank in front of it is done
                 l = self.encoder.lstm
