@@ -711,8 +711,9 @@ static inline int conv5_pick_bn_ks(int T, int B, int M, int Cin, int* ks) {
     for (int i = 0; i < 5; ++i) {
         const int bn = cands[i];
         const long wgs = 2 * (long)B * ((T + bn - 1) / bn) * ((M + CT_BM - 1) / CT_BM);
-        if (wgs > T2V_NWG) continue;
-        const long cost = (bn + 40) + 16;
+        // (T2V_CONV_KSPLIT=2, measurement: also split launches that then put TWO half-size workgroups on a CU)
+        if (wgs > (ksplit_on == 2 ? 2 * T2V_NWG : T2V_NWG)) continue;
+        const long cost = ((wgs + T2V_NWG - 1) / T2V_NWG) * ((bn + 40) + 16);
         if (cost < best_cost) { best = bn; best_cost = cost; *ks = 2; }
     }
     return best;
