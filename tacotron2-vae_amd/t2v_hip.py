@@ -1045,10 +1045,15 @@ class DecoderCore(torch.autograd.Function):
                 # accumulation) — no library GEMM is left in either step
                 # (measured round 4: without these four products the step is 0.71 ms shorter, alone they take 0.82 ms — they run
                 # NEXT to the other chains but the chip is shared, so almost all of their time is still on the step's clock)
+                two = os.environ.get('T2V_DW_TWO_STREAMS', '0') == '1' and not split_d      # measurement: the two pairs side by side
                 with side('g', after=fork):
                     gemm(dga2.t(), x_prev[:, :H].t(), out=d_w_hh_att, accumulate=not first)
                     gemm(dga2.t(), x_prev[:, H:KATT].t(), out=d_w_ih_att[:, PRE:], accumulate=not first)
-                    if not split_d:
+                    if not split_d and not two:
+                        gemm(dgd2.t(), x_cur[:, :KATT].t(), out=d_w_ih_dec, accumulate=not first)
+                        gemm(dgd2.t(), x_cur[:, KATT:].t(), out=d_w_hh_dec, accumulate=not first)
+                if two:
+                    with side('d', keep=(DGD, dgd2), after=fork):
                         gemm(dgd2.t(), x_cur[:, :KATT].t(), out=d_w_ih_dec, accumulate=not first)
                         gemm(dgd2.t(), x_cur[:, KATT:].t(), out=d_w_hh_dec, accumulate=not first)
                 if split_d:         # in order behind the decoder_rnn chain on ITS stream: they start the moment it ends
