@@ -407,6 +407,15 @@ class BatchLayout(object):
         self.nbytes = max(off, 16)
         self.key = tuple(f[3] for f in self.fields) + (self.max_len,)
 
+    def pack_into(self, host, batch):
+        """write the seven tensors (+ the int32 copies of both length vectors) into a uint8 host buffer of `nbytes`"""
+        for t, (off, nb, dt, shape) in zip(batch, self.fields):
+            if nb:
+                host[off:off + nb].view(dt).view(shape).copy_(t)      # dtype conversion happens here, on the host
+        for idx, off, nb in self.i32:
+            if nb:
+                host[off:off + nb].view(torch.int32).copy_(batch[idx].reshape(-1))
+
     def upload(self, batch, into=None):
         ring = self._ring.get(self.nbytes)
         if ring is None:
@@ -417,12 +426,7 @@ class BatchLayout(object):
         if ring[1][slot] is not None:
             ring[1][slot].synchronize()        # the copy that last read this pinned slot has finished
         host = ring[0][slot]
-        for t, (off, nb, dt, shape) in zip(batch, self.fields):
-            if nb:
-                host[off:off + nb].view(dt).view(shape).copy_(t)      # dtype conversion happens here, on the host
-        for idx, off, nb in self.i32:
-            if nb:
-                host[off:off + nb].view(torch.int32).copy_(batch[idx].reshape(-1))
+        self.pack_into(host, batch)
         dev = into if into is not None else torch.empty(self.nbytes, dtype=torch.uint8, device='cuda')
         assert dev.numel() == self.nbytes and dev.dtype == torch.uint8
         dev.copy_(host, non_blocking=True)

@@ -204,3 +204,31 @@ def test_limit_host_threads_only_lowers_and_honours_the_env(monkeypatch):
         assert torch.get_num_threads() == 3
     finally:
         torch.set_num_threads(old)
+
+
+def test_batch_layout_packs_the_seven_tensors_and_int32_lengths():
+    """model.BatchLayout (the one-buffer form of reference model.py:486-503 parse_batch): every field 16-byte aligned, dtypes
+    converted on the host, views read back what was packed, and both length vectors additionally as int32 (round 4)"""
+    import model as M
+    g = torch.Generator().manual_seed(0)
+    text = torch.randint(0, 70, (3, 11), generator=g)
+    in_len = torch.tensor([11, 9, 4])
+    mel = torch.randn(3, 80, 17, generator=g)
+    gate = torch.rand(3, 17, generator=g)
+    out_len = torch.tensor([17, 12, 5])
+    spk = torch.zeros(3, 4, dtype=torch.long); spk[:, 1] = 1
+    emo = torch.zeros(3, 5, dtype=torch.long); emo[:, 2] = 1
+    batch = (text, in_len, mel, gate, out_len, spk, emo)
+    lay = M.BatchLayout(batch)
+    assert lay.nbytes % 16 == 0 and all(off % 16 == 0 for off, _, _, _ in lay.fields) and all(off % 16 == 0 for _, off, _ in lay.i32)
+    host = torch.zeros(lay.nbytes, dtype=torch.uint8)
+    lay.pack_into(host, batch)
+    (t2, l2, m2, max_len, o2, s2, e2), (m3, g3) = lay.views(host)
+    assert max_len == 11 and torch.equal(t2, text) and torch.equal(l2, in_len) and torch.equal(o2, out_len)
+    assert torch.equal(m2, mel) and torch.equal(g3, gate) and m3 is m2
+    assert s2.dtype == torch.float32 and torch.equal(s2, spk.float()) and torch.equal(e2, emo.float())
+    assert l2._i32.dtype == torch.int32 and l2._i32.tolist() == [11, 9, 4] and o2._i32.tolist() == [17, 12, 5]
+    assert M.lengths_i32(l2, torch.device('cpu')) is l2._i32
+    plain = torch.tensor([3, 2])
+    assert M.lengths_i32(plain, torch.device('cpu')).dtype == torch.int32         # no companion: converted
+    assert lay.key == M.BatchLayout(batch).key
