@@ -39,16 +39,19 @@ __device__ __forceinline__ void bl_put(t2v_u64* p, float v, unsigned tag) {
 }
 
 template <int BQ>       // batch rounded up to a multiple of 4: items polled per thread
-__global__ __launch_bounds__(256) void k_bilstm_fwd(BiLstmFwdArgs a) {
+// Round 4: 8 waves — waves 4..7 take the upper half of K (h_att columns 128..255) of the same tiles as waves 0..3, so the
+// chain of dependent MFMAs of a step is 32 long instead of 64 (0.85 -> 0.43 us); their partial tiles cross through LDS.
+__global__ __launch_bounds__(512) void k_bilstm_fwd(BiLstmFwdArgs a) {
     const int dir = blockIdx.x / BL_NW, j = blockIdx.x % BL_NW;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = (tid >> 6) & 3, kh = tid >> 8, lane = tid & 63;
     const int b = lane & 15, g = lane >> 4;
     const bool bvalid = b < a.B;
     __shared__ float hbuf[16][BL_H + 4];
+    __shared__ f32x4 kpart[4][BL_NT][64];
     __shared__ int ok_flag;
     if (tid == 0) ok_flag = 1;
     // recurrent weights of this wave's two 16-row tiles (4 units x 4 gates each) as MFMA A fragments
-    float wreg[BL_NT][64];
+    float wreg[BL_NT][32];
     {
         const float* W = a.whh + (size_t)dir * BL_G * BL_H;
 #pragma unroll
@@ -56,10 +59,10 @@ __global__ __launch_bounds__(256) void k_bilstm_fwd(BiLstmFwdArgs a) {
             const int unit = j * BL_UNITS + (BL_NT * wave + tt) * 4 + ((lane & 15) >> 2);
             const int row = (lane & 3) * BL_H + unit;
 #pragma unroll
-            for (int s = 0; s < 64; ++s) wreg[tt][s] = W[(size_t)row * BL_H + 4 * s + g];
+            for (int s = 0; s < 32; ++s) wreg[tt][s] = W[(size_t)row * BL_H + 4 * (32 * kh + s) + g];
         }
     }
-    for (int i = tid; i < 16 * (BL_H + 4); i += 256) (&hbuf[0][0])[i] = 0.f;
+    for (int i = tid; i < 16 * (BL_H + 4); i += 512) (&hbuf[0][0])[i] = 0.f;
     const int len = bvalid ? a.lengths[b] : 0;
     float cst[BL_NT];
 #pragma unroll
@@ -76,24 +79,33 @@ __global__ __launch_bounds__(256) void k_bilstm_fwd(BiLstmFwdArgs a) {
             const int U = j * BL_UNITS + (BL_NT * wave + tt) * 4 + g;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                gxv[tt][r] = active ? a.gx[(((size_t)dir * a.B + b) * a.T + t) * BL_G + r * BL_H + U] : 0.f;
+                gxv[tt][r] = (active && kh == 0) ? a.gx[(((size_t)dir * a.B + b) * a.T + t) * BL_G + r * BL_H + U] : 0.f;
         }
         f32x4 accv[BL_NT];
 #pragma unroll
         for (int tt = 0; tt < BL_NT; ++tt) accv[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* hrow = &hbuf[b][g];
+        const float* hrow = &hbuf[b][g + 128 * kh];
 #pragma unroll
-        for (int s = 0; s < 64; ++s) {
+        for (int s = 0; s < 32; ++s) {
             const float hv = hrow[4 * s];
 #pragma unroll
             for (int tt = 0; tt < BL_NT; ++tt) accv[tt] = mfma16x4(wreg[tt][s], hv, accv[tt]);
+        }
+        if (kh == 1) {
+#pragma unroll
+            for (int tt = 0; tt < BL_NT; ++tt) kpart[wave][tt][lane] = accv[tt];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int tt = 0; tt < BL_NT; ++tt) accv[tt] += kpart[wave][tt][lane];
         }
         t2v_u64* hx_w = a.hx + ((size_t)(dir * 2 + (step & 1)) * 16) * BL_H;
 #pragma unroll
         for (int tt = 0; tt < BL_NT; ++tt) {
             const f32x4 acc = accv[tt];
             const int U = j * BL_UNITS + (BL_NT * wave + tt) * 4 + g;
-            if (bvalid) {
+            if (bvalid && kh == 0) {
                 float hnew = hbuf[b][U];                       // frozen once the sequence has ended
                 float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, c = 0.f;
                 if (active) {
@@ -117,10 +129,10 @@ __global__ __launch_bounds__(256) void k_bilstm_fwd(BiLstmFwdArgs a) {
             }
         }
         if (step + 1 == a.T) break;
-        {   // gather the new hidden state of every item (thread = unit tid, items 0..BQ-1): poll until every tag matches
+        {   // gather the new hidden state of every item (thread = unit tid < 256, items 0..BQ-1): poll until every tag matches
             float hv[BQ];
             unsigned spins = 0;
-            for (;;) {
+            for (; tid < BL_H;) {
                 bool ok = true;
 #pragma unroll
                 for (int u = 0; u < BQ; ++u) {
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(256) void k_bilstm_fwd(BiLstmFwdArgs a) {
             __syncthreads();           // every wave is done reading hbuf of this step
 #pragma unroll
             for (int u = 0; u < BQ; ++u)
-                if (u < a.B) hbuf[u][tid] = hv[u];
+                if (u < a.B && tid < BL_H) hbuf[u][tid] = hv[u];
         }
         __syncthreads();
         if (!ok_flag) return;
@@ -166,15 +178,17 @@ struct BiLstmBwdArgs {
 // gradients (an all-gather) before it could start its matrix product.  Per workgroup and step: 256 B stores + 256 B
 // loads, the loads being the only round trip on the critical path.
 #define BLB_GR ((size_t)16 * 16 * BL_H)     // granules per (direction, parity)
-__global__ __launch_bounds__(256) void k_bilstm_bwd(BiLstmBwdArgs a) {
+// (round 4: 8 waves x 2 column tiles instead of 4 x 4 — the 64 MFMAs of a wave per step become 32; the cell backward stays on
+// threads 0..255)
+__global__ __launch_bounds__(512) void k_bilstm_bwd(BiLstmBwdArgs a) {
     const int dir = blockIdx.x / BL_NW, j = blockIdx.x % BL_NW;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = lane & 15, g = lane >> 4;
     __shared__ __attribute__((aligned(16))) float dgl[16][64 + 4];      // own gate gradients [item][k = gate*16 + unit]
     __shared__ int ok_flag;
     if (tid == 0) ok_flag = 1;
-    // A fragments of W_hh^T: tile tt of this wave = units 64 wave + 16 tt .. +16, k-step s covers own rows k = 4s + g
-    float wreg[4][16];
+    // A fragments of W_hh^T: tile tt of this wave = units 32 wave + 16 tt .. +16, k-step s covers own rows k = 4s + g
+    float wreg[2][16];
     {
         const float* W = a.whh + (size_t)dir * BL_G * BL_H;
 #pragma unroll
@@ -182,10 +196,10 @@ __global__ __launch_bounds__(256) void k_bilstm_bwd(BiLstmBwdArgs a) {
             const int k = 4 * s + g;
             const int row = (k >> 4) * BL_H + j * BL_UNITS + (k & 15);
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) wreg[tt][s] = W[(size_t)row * BL_H + 64 * wave + 16 * tt + (lane & 15)];
+            for (int tt = 0; tt < 2; ++tt) wreg[tt][s] = W[(size_t)row * BL_H + 32 * wave + 16 * tt + (lane & 15)];
         }
     }
-    for (int i = tid; i < 16 * 68; i += 256) (&dgl[0][0])[i] = 0.f;
+    for (int i = tid; i < 16 * 68; i += 512) (&dgl[0][0])[i] = 0.f;
     // cell-backward ownership: thread -> (item bb = tid / 16, unit uu = tid % 16)
     const int uu = tid & 15, bb = tid >> 4, U = j * BL_UNITS + uu;
     const bool live = bb < a.B;
@@ -263,17 +277,17 @@ __global__ __launch_bounds__(256) void k_bilstm_bwd(BiLstmBwdArgs a) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) bop[s] = dgl[b][4 * s + g];
             __builtin_amdgcn_sched_barrier(0);
-            f32x4 acc[4];
+            f32x4 acc[2];
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int tt = 0; tt < 2; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 16; ++s)
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) acc[tt] = mfma16x4(wreg[tt][s], bop[s], acc[tt]);
+                for (int tt = 0; tt < 2; ++tt) acc[tt] = mfma16x4(wreg[tt][s], bop[s], acc[tt]);
             if (b < a.B) {
-                t2v_u64* dst = a.dgx + (size_t)(dir * 2 + (step & 1)) * BLB_GR + ((size_t)j * 16 + b) * BL_H + 64 * wave + 4 * g;
+                t2v_u64* dst = a.dgx + (size_t)(dir * 2 + (step & 1)) * BLB_GR + ((size_t)j * 16 + b) * BL_H + 32 * wave + 4 * g;
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt)
+                for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) bl_put(dst + 16 * tt + r, acc[tt][r], tag);
             }
@@ -299,10 +313,10 @@ extern "C" int t2v_bilstm_fwd(const float* gx, const float* whh, const int32_t* 
     BiLstmFwdArgs a;
     a.gx = gx; a.whh = whh; a.lengths = lengths; a.y = y; a.gates = gates; a.cells = cells; a.hx = (t2v_u64*)hx_scratch;
     a.sync = sync3; a.B = B; a.T = T;
-    if (B <= 4) k_bilstm_fwd<4><<<2 * BL_NW, 256, 0, stream>>>(a);
-    else if (B <= 8) k_bilstm_fwd<8><<<2 * BL_NW, 256, 0, stream>>>(a);
-    else if (B <= 12) k_bilstm_fwd<12><<<2 * BL_NW, 256, 0, stream>>>(a);
-    else k_bilstm_fwd<16><<<2 * BL_NW, 256, 0, stream>>>(a);
+    if (B <= 4) k_bilstm_fwd<4><<<2 * BL_NW, 512, 0, stream>>>(a);
+    else if (B <= 8) k_bilstm_fwd<8><<<2 * BL_NW, 512, 0, stream>>>(a);
+    else if (B <= 12) k_bilstm_fwd<12><<<2 * BL_NW, 512, 0, stream>>>(a);
+    else k_bilstm_fwd<16><<<2 * BL_NW, 512, 0, stream>>>(a);
     return t2v_check_launch();
 }
 
@@ -320,6 +334,6 @@ extern "C" int t2v_bilstm_bwd(const float* whh, const int32_t* lengths, const fl
     BiLstmBwdArgs a;
     a.whh = whh; a.lengths = lengths; a.dy = dy; a.gates = gates; a.cells = cells; a.dg = dg; a.dgx = (t2v_u64*)dgx_scratch;
     a.sync = sync3; a.B = B; a.T = T;
-    k_bilstm_bwd<<<2 * BL_NW, 256, 0, stream>>>(a);
+    k_bilstm_bwd<<<2 * BL_NW, 512, 0, stream>>>(a);
     return t2v_check_launch();
 }
