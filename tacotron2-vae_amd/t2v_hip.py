@@ -348,8 +348,8 @@ class Overlap(object):
 
     def __init__(self, device=None):
         self.on = True
-        # (T2V_STREAM_PRIO=1, measurement: the engine's own stream at high priority, the side streams below it — the deferred
-        # weight-gradient GEMMs then yield CUs to the dependent chain on the main stream)
+        # (T2V_MAIN_PRIO / T2V_SIDE_PRIO, measurement: stream priorities of the engine's own stream and of the side streams —
+        # three same-box pairs showed no difference)
         lo = int(os.environ.get('T2V_SIDE_PRIO', '0'))
         self._streams = {n: torch.cuda.Stream(device=device, priority=lo) for n in self.NAMES}
         self._used = []
