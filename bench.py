@@ -115,14 +115,15 @@ def cpu_baseline(steps=5, warmup=2, threads=None):
                       % (steps, warmup, torch.get_num_threads())}
 
 
-def _cpu_all_cores_leg(limit_s):
-    """ONE oracle step with every host core, in a child process with a time limit: a GPU box that runs its containers under a
-    CPU quota throttles 256 spinning OpenMP threads to a crawl (minutes per step), and the default bench run must stay
-    within a few minutes — the leg then reports that it was cut off instead of holding the line back"""
+def _cpu_threads_leg(limit_s, threads=None):
+    """ONE oracle step with `threads` host threads (None: every host core), in a child process with a time limit.  Default
+    run (round 5): a 16-thread probe (a few seconds: shows that more threads than the fastest count do not help these M=6
+    GEMVs).  The every-core figure SURVEY 8(d) names is opt-in (--cpu-all-cores): a GPU box that runs its containers under a
+    CPU quota throttles 256 spinning OpenMP threads to a crawl — it burnt 75 s of every default run to report `null`."""
     import subprocess
     code = ("import json, os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import bench; "
-            "r = bench.cpu_baseline(steps=1, warmup=0, threads=os.cpu_count()); print('ALLCORES ' + json.dumps(r))"
-            % (ROOT, os.path.join(ROOT, 'tacotron2-vae_amd')))
+            "r = bench.cpu_baseline(steps=1, warmup=0, threads=%s); print('ALLCORES ' + json.dumps(r))"
+            % (ROOT, os.path.join(ROOT, 'tacotron2-vae_amd'), 'os.cpu_count()' if threads is None else str(int(threads))))
     t0 = time.perf_counter()
     try:
         p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=limit_s)
@@ -130,15 +131,53 @@ def _cpu_all_cores_leg(limit_s):
             if line.startswith('ALLCORES '):
                 r = json.loads(line[9:])
                 return {"value": r["value"], "cores": r["cores"], "s_per_it": r["s_per_it"],
-                        "sample": "ONE timed step, no warm-up, every host core (child process)"}
-        return {"value": None, "cores": os.cpu_count(), "error": (p.stderr or p.stdout)[-300:]}
+                        "sample": "ONE timed step, no warm-up, %s (child process)"
+                                  % ("every host core" if threads is None else "%d torch threads" % threads)}
+        return {"value": None, "cores": threads or os.cpu_count(), "error": (p.stderr or p.stdout)[-300:]}
     except subprocess.TimeoutExpired:
-        return {"value": None, "cores": os.cpu_count(), "timed_out_after_s": round(time.perf_counter() - t0, 1),
-                "note": "one step with every host core did not finish inside the limit (CPU quota of the container); "
+        return {"value": None, "cores": threads or os.cpu_count(), "timed_out_after_s": round(time.perf_counter() - t0, 1),
+                "note": "one step did not finish inside the limit (CPU quota of the container); "
                         "the figure with the fastest thread count is the one above"}
 
 
-def decode_bench(model, T_in=200, steps=800):
+def decode_cpu_baseline(T_in=200, frames=100, reps=3, threads=8):
+    """the CPU figure of cfg-4 beside the GPU one — the oracle's free-running decode loop
+    (oracle/t2v_oracle.py:decoder_inference, reference model.py:428-464) on the same 200-symbol input shape, random-init
+    weights of seed 1234, style = fc3(z) with z ~ N(0, I) seed 7, `threads` torch threads; median of `reps` runs of
+    `frames` frames each after one warm-up run (bounded sample: ≈ 1 s of CPU work)."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        import t2v_oracle as O
+        import hparams as HP
+        import model as M
+        hp = HP.create_hparams()
+        torch.manual_seed(hp.seed)
+        sd = {k: v.detach().clone() for k, v in M.Tacotron2(hp).state_dict().items()}
+        g = torch.Generator().manual_seed(1234)
+        ids = torch.randint(2, 80, (1, T_in), generator=g)
+        z = torch.randn(1, 32, generator=torch.Generator().manual_seed(7))
+        with torch.no_grad():
+            enc = O.encoder_forward(sd, ids, torch.tensor([T_in]), training=False)
+            style = torch.nn.functional.linear(z, sd['vae_gst.fc3.weight'], sd['vae_gst.fc3.bias'])
+            memory = enc + style.unsqueeze(1)
+            times = []
+            for i in range(reps + 1):
+                t0 = time.perf_counter()
+                O.decoder_inference(sd, memory, max_steps=frames, gate_threshold=1.0, stop_on_gate=False)
+                times.append(time.perf_counter() - t0)
+        t = sorted(times[1:])[reps // 2]
+    finally:
+        torch.set_num_threads(prev)
+    return {"frames_per_s": round(frames / t, 1), "us_per_frame": round(1e6 * t / frames, 1), "cores": threads, "kind": "port",
+            "host_cpu": _cpu_model(),
+            "sample": "median of %d runs of %d free-running frames (after one warm-up run), B=1, %d symbols, "
+                      "oracle/t2v_oracle.py:decoder_inference, stock torch CPU fp32 ops, %d torch threads"
+                      % (reps, frames, T_in, threads)}
+
+
+def decode_bench(model, T_in=200, steps=800, reps=5):
     """BASELINE.json configs[3]: B=1, 200-symbol utterance, exactly `steps` free-running decoder steps
     (gate ignored), style = fc3(z), z ~ N(0,I) seed 7.  Secondary figure: frames/s of the decode loop."""
     import model as M
@@ -157,13 +196,17 @@ def decode_bench(model, T_in=200, steps=800):
             import contextlib, io
             res = {}
             with contextlib.redirect_stdout(io.StringIO()):
-                for name, flag in (("persistent", True), ("launch_per_stage", False)):
+                for name, flag, runs in (("persistent", True, reps), ("launch_per_stage", False, 3)):
                     dec.inference(memory, chunk=steps, persistent=flag)                  # warm-up
                     torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    mel, _, _ = dec.inference(memory, chunk=steps, persistent=flag)
-                    torch.cuda.synchronize()
-                    res[name] = time.perf_counter() - t0
+                    ts = []
+                    for _ in range(runs):
+                        t0 = time.perf_counter()
+                        mel, _, _ = dec.inference(memory, chunk=steps, persistent=flag)
+                        torch.cuda.synchronize()
+                        ts.append(time.perf_counter() - t0)
+                    res[name] = sorted(ts)[len(ts) // 2]
+                    res[name + "_all"] = ts
             dt = res["persistent"]
     finally:
         dec.max_decoder_steps, dec.gate_threshold = old_steps, old_thr
@@ -171,6 +214,8 @@ def decode_bench(model, T_in=200, steps=800):
             model.train()
     return {"frames_per_s": round(steps / dt, 1), "us_per_frame": round(1e6 * dt / steps, 2), "B": 1, "T_in": T_in,
             "steps": steps, "mode": "one persistent launch, weights resident on chip (csrc/decoder_persist.hip)",
+            "timing": "median of %d runs (wall clock around Decoder.inference, synchronised)" % reps,
+            "us_per_frame_runs": [round(1e6 * t / steps, 2) for t in res["persistent_all"]],
             "launch_per_stage_us_per_frame": round(1e6 * res["launch_per_stage"] / steps, 2),
             "note": "decoder loop only (incl. session set-up: weight packing, memory_layer, one-time weight load); "
                     "encoder/postnet excluded"}
@@ -211,7 +256,7 @@ def frontend_bench(B=6, n_samples=102144, reps=20, big=True):
 def _in_situ_durations():
     """per-kernel average durations of a traced steady-state step (rocprofv3 --kernel-trace over graph replays of the same
     command, committed under profiles/ by tools/round_profile.sh): the in-situ counterpart of the replay timings below"""
-    for fn in ('r04_kernel_durations.json', 'r03_kernel_durations.json', 'r02_kernel_durations.json'):
+    for fn in ('r05_kernel_durations.json', 'r04_kernel_durations.json', 'r03_kernel_durations.json', 'r02_kernel_durations.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', fn)) as f:
                 return json.load(f), 'profiles/' + fn
@@ -220,11 +265,20 @@ def _in_situ_durations():
     return {}, None
 
 
+def _profile_file(suffix):
+    """the newest committed profiles/r0N_<suffix> (this round's evidence when it exists, else the previous round's)"""
+    for r in ('r05', 'r04', 'r03'):
+        fn = os.path.join(ROOT, 'profiles', '%s_%s' % (r, suffix))
+        if os.path.isfile(fn):
+            return fn
+    raise FileNotFoundError(suffix)
+
+
 def _steady_state_rows():
-    """{kernel name without 'void ' and arguments: (launches per step, ms per step)} of profiles/r04_steady_state.txt"""
+    """{kernel name without 'void ' and arguments: (launches per step, ms per step)} of profiles/r0N_steady_state.txt"""
     import re
     rows = {}
-    with open(os.path.join(ROOT, 'profiles', 'r04_steady_state.txt')) as f:
+    with open(_profile_file('steady_state.txt')) as f:
         for l in f.read().split('\n')[2:]:
             t = l.split()
             m = re.search(r'(k_\w+(?:<[^>]*>)?)', l)
@@ -256,21 +310,23 @@ def _whole_step_counters(ms_per_step):
     except Exception:
         return res
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r04_pmc_fetch_size.json')) as f:
+        fsrc = _profile_file('pmc_fetch_size.json')
+        with open(fsrc) as f:
             fs = json.load(f)["kernels"]
         tot = sum(e["corrected_bytes_per_launch"] * launches(k) for k, e in fs.items())
         res["measured_fetch_bytes_per_step"] = int(tot)
         res["measured_fetch_frac_of_hbm_peak"] = round(tot / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         res["measured_fetch_kernels"] = sorted(fs)
-        res["measured_fetch_source"] = "profiles/r04_pmc_fetch_size.json x launches/step of profiles/r04_steady_state.txt"
+        res["measured_fetch_source"] = "%s x launches/step of %s" % (os.path.relpath(fsrc, ROOT), os.path.relpath(_profile_file('steady_state.txt'), ROOT))
     except Exception:
         pass
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r04_pmc_mfma.json')) as f:
+        msrc = _profile_file('pmc_mfma.json')
+        with open(msrc) as f:
             mf = json.load(f)["kernels"]
         busy = sum(e["mfma_busy_frac"] * ms(k) for k, e in mf.items() if "mfma_busy_frac" in e)
         res["mfma_busy_frac_over_step"] = round(busy / ms_per_step, 4)
-        res["mfma_busy_source"] = "profiles/r04_pmc_mfma.json x ms/step of profiles/r04_steady_state.txt"
+        res["mfma_busy_source"] = "%s x ms/step of %s" % (os.path.relpath(msrc, ROOT), os.path.relpath(_profile_file('steady_state.txt'), ROOT))
     except Exception:
         pass
     return res
@@ -362,7 +418,7 @@ def roofline_table(B, T_in, T, reps=3):
     return rows
 
 
-def run_workload(args, world, rank, bf16, koemo, steps, warmup, graph):
+def run_workload(args, world, rank, bf16, koemo, steps, warmup, graph, eager_steps=0):
     """one timed configuration; returns (engine, result dict)"""
     import hparams as HP
     import t2v_hip
@@ -406,10 +462,34 @@ def run_workload(args, world, rank, bf16, koemo, steps, warmup, graph):
             it += 1
         sync()
         elapsed = time.perf_counter() - t0
+        # a rank's own clock up to ITS last step's completion would need a sync before the barrier; what a straggler shows
+        # in is the per-rank time to issue + finish its steps, taken around the same region with a device sync only
+        eager_ms = None
+        if engine.use_graph and eager_steps > 0:
+            # the same step issued eagerly (one host launch per kernel) by the same engine, in the same run: a replayed graph
+            # whose branches the executor decided to serialise shows up as graph >> eager
+            engine.use_graph = False
+            try:
+                for _ in range(2):
+                    engine.step(batch, it)
+                    it += 1
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(eager_steps):
+                    engine.step(batch, it)
+                    it += 1
+                sync()
+                eager_ms = 1000.0 * (time.perf_counter() - t1) / eager_steps
+            finally:
+                engine.use_graph = True
+    rank_ms = None
     if world > 1:
-        tt = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        mine = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per = [1000.0 * float(t.item()) / steps for t in allt]
+        rank_ms = {"min": round(min(per), 3), "max": round(max(per), 3), "per_rank": [round(x, 3) for x in per]}
+        elapsed = max(float(t.item()) for t in allt)
     final_loss = float(loss.item())
     t2v_hip.check_async_errors()     # any bounded-spin timeout inside the timed steps invalidates the run
     frames = (sum(koemo_out) if koemo else bpg * T_OUT) * world      # koemo: valid (unpadded) frames, like the metric
@@ -419,6 +499,13 @@ def run_workload(args, world, rank, bf16, koemo, steps, warmup, graph):
                          if getattr(engine, 'graph_ddp', False) else "hip-graph replay") if engine.use_graph else "eager launches",
            "startup_steps": startup, "batch_per_gpu": bpg,
            "decoder_forward": t2v_hip.DecoderCore.last_mode, "decoder_backward": t2v_hip.DecoderCore.last_bwd_mode}
+    if eager_ms is not None:
+        res["graph_vs_eager_ms"] = {"graph": round(ms, 3), "eager": round(eager_ms, 3), "eager_steps": eager_steps,
+                                    "graph_replay_serialised": bool(ms > eager_ms + 0.5),
+                                    "note": "the same engine, the same step, issued eagerly right after the timed replays: a "
+                                            "graph whose branches were serialised by the executor would read graph >> eager"}
+    if rank_ms is not None:
+        res["ms_per_step_ranks"] = rank_ms
     if engine.allreduce is not None:
         res["allreduce_exposed_ms"] = round(engine.allreduce.exposed_ms(), 3)
         res["allreduce_buckets"] = [(b[0], 4 * (b[2] - b[1])) for b in engine.allreduce.buckets]
@@ -447,8 +534,13 @@ def main():
                     help='torch CPU threads for the baseline leg (the M=6 GEMVs of this model stop scaling\n'
                          'around 8 threads on this EPYC host: 8 → 3.7 s/it, 16 → 4.2, 32 → 7.4, all cores ≈ 40)')
     ap.add_argument('--cpu-all-cores-timeout', type=float, default=75.0)
-    ap.add_argument('--no-cpu-all-cores', action='store_true',
-                    help='skip the second CPU figure (ONE oracle step with every host core, ≈40 s on the 128-core host)')
+    ap.add_argument('--cpu-all-cores', action='store_true',
+                    help='also time ONE oracle step with every host core (opt-in: ≈40 s on an unthrottled 128-core host, cut off\n'
+                         'after --cpu-all-cores-timeout on the quota-limited GPU boxes)')
+    ap.add_argument('--cpu-probe-threads', type=int, default=16,
+                    help='second CPU figure of the default run: ONE oracle step with this many threads (0 = skip)')
+    ap.add_argument('--eager-steps', type=int, default=5,
+                    help='eager steps timed next to the graph replays (graph_vs_eager_ms; 0 = skip)')
     ap.add_argument('--no-decode', action='store_true')
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the secondary workloads (koemo length profile, bf16 B=16) and the front-end leg')
@@ -493,7 +585,7 @@ def main():
     t2v_hip.DecoderCore.keep_last = True       # the roofline leg replays the last step's kernels on its arena
     kind = 'bf16' if args.bf16 else ('koemo' if args.koemo else 'headline')
     engine, res = run_workload(args, world, rank, args.bf16, args.koemo and not args.bf16, args.steps, args.warmup,
-                               not args.no_graph)
+                               not args.no_graph, eager_steps=args.eager_steps)
     bpg = res["batch_per_gpu"]
     out = {
         "metric": "mel-frames/s (train step, batch=%d, 80-mel)" % bpg, "value": res["value"],
@@ -507,6 +599,10 @@ def main():
                    "parallelism": "dp%d" % world},
         "final_loss": res["final_loss"],
     }
+    if "graph_vs_eager_ms" in res:
+        out["graph_vs_eager_ms"] = res["graph_vs_eager_ms"]
+    if "ms_per_step_ranks" in res:      # per-rank step time next to the max the value is computed from: a straggler is visible
+        out["ms_per_step_ranks"] = res["ms_per_step_ranks"]
     if dist.is_initialized():
         out["rccl_ranks"] = dist.get_world_size()
         if "allreduce_exposed_ms" in res:
@@ -518,7 +614,7 @@ def main():
         rows = roofline_table(bpg, T_IN, T_OUT)
         top = rows[0]                   # the kernel with the most time per step
         traffic, tsrc = None, None      # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, corrected)
-        for fn in ('r04_pmc_fetch_size.json', 'r03_pmc_fetch_size.json', 'r02_pmc_fetch_size.json', 'r01_pmc_fetch_size.json'):
+        for fn in ('r05_pmc_fetch_size.json', 'r04_pmc_fetch_size.json', 'r03_pmc_fetch_size.json', 'r02_pmc_fetch_size.json', 'r01_pmc_fetch_size.json'):
             try:
                 with open(os.path.join(ROOT, 'profiles', fn)) as f:
                     traffic = json.load(f)["kernels"][top["kernel"]]["corrected_bytes_per_launch"]
@@ -589,12 +685,13 @@ def main():
                 r2["unit"] = "mel-frames/s"
                 if name == 'bf16':
                     try:        # its own roofline rows: MFMA counters of the bf16 step, separate PMC pass
-                        with open(os.path.join(ROOT, 'profiles', 'r04_pmc_mfma_bf16.json')) as f:
+                        bsrc = _profile_file('pmc_mfma_bf16.json')
+                        with open(bsrc) as f:
                             mb = json.load(f)["kernels"]
                         r2["roofline_kernels"] = [
                             {"kernel": k, "bound": "mfma", "achieved": e.get("tflops_at_2.4GHz"), "unit": "TFLOP/s",
                              "peak": 2500.0 if 'bf16' in k else 157.0, "mfma_busy_frac": e.get("mfma_busy_frac"),
-                             "dispatches_in_profile": e.get("dispatches"), "source": "profiles/r04_pmc_mfma_bf16.json"}
+                             "dispatches_in_profile": e.get("dispatches"), "source": os.path.relpath(bsrc, ROOT)}
                             for k, e in mb.items() if "mfma_busy_frac" in e]
                     except Exception:
                         pass
@@ -604,8 +701,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(steps=args.cpu_steps, warmup=args.cpu_warmup, threads=args.cpu_threads)
             out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-            if not args.no_cpu_all_cores:       # SURVEY 8(d) says "all cores": reported next to the fastest thread count
-                out["cpu_baseline"]["all_cores"] = _cpu_all_cores_leg(args.cpu_all_cores_timeout)
+            if args.cpu_probe_threads and args.cpu_probe_threads != args.cpu_threads:
+                out["cpu_baseline"]["probe_%d_threads" % args.cpu_probe_threads] = _cpu_threads_leg(30.0, args.cpu_probe_threads)
+            if args.cpu_all_cores:              # SURVEY 8(d) says "all cores": opt-in, see _cpu_threads_leg
+                out["cpu_baseline"]["all_cores"] = _cpu_threads_leg(args.cpu_all_cores_timeout)
+            if "decode" in out:                 # cfg-4 gets its CPU figure beside it as well
+                out["decode"]["cpu_baseline"] = decode_cpu_baseline(threads=args.cpu_threads)
+                out["decode"]["speedup_vs_cpu"] = round(out["decode"]["frames_per_s"] / out["decode"]["cpu_baseline"]["frames_per_s"], 1)
         print(json.dumps(out))
     if dist.is_initialized():
         # orderly teardown of a rank: captured graphs and their arenas go first, then the communicator; the process then

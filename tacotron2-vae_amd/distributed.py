@@ -115,11 +115,16 @@ class OverlappedArenaAllReduce(object):
     One collective per bucket on a point-to-point fabric: few, large messages (xGMI rings are per-link bound)."""
 
     def __init__(self, named_params, offsets, flat, group=None, min_bucket=1 << 16, force=False, side_streams=None,
-                 gather=None, wire_dtype=None):
+                 gather=None, wire_dtype=None, tail=0):
         """named_params: [(name, param)] in arena order; offsets: start of each param inside `flat`.
         wire_dtype=torch.bfloat16 (bf16_run, SURVEY 8(e): 57.7 MB instead of 115.5 MB per step): every slice is rounded
-        into a bf16 wire buffer, summed over the ranks in bf16, and widened back into the fp32 arena."""
+        into a bf16 wire buffer, summed over the ranks in bf16, and widened back into the fp32 arena.
+        tail: the last `tail` elements of `flat` are no gradients (the engine's poison slot: "a kernel of mine timed out").
+        They belong to NO hook-issued bucket — a bucket leaves while backward is still running, before the step's error
+        words exist (ADVICE r4) — and are reduced by finish() in a small collective of their own, in fp32 on any wire format;
+        reduce_all() carries them with the arena."""
         self.flat, self.group = flat, group
+        self.tail = int(tail)
         self.wire = None
         if wire_dtype is not None and wire_dtype != flat.dtype:
             self.wire = torch.empty(flat.numel(), dtype=wire_dtype, device=flat.device)
@@ -153,7 +158,7 @@ class OverlappedArenaAllReduce(object):
             buckets[-1][2] = last[2]
             buckets[-1][3] += last[3]
         if buckets:
-            buckets[-1][2] = flat.numel()
+            buckets[-1][2] = flat.numel() - self.tail
         self.buckets = [(b[0], b[1], b[2], len(b[3])) for b in buckets]
         self._bucket_params = [list(b[3]) for b in buckets]
         self._pending = [0] * len(buckets)
@@ -227,14 +232,20 @@ class OverlappedArenaAllReduce(object):
             return
         for bi in range(len(self.buckets)):
             self._launch(bi, False)
+        tail_work = None
+        if self.tail:       # written by the caller after backward, on the current stream: the collective is ordered behind it
+            tail_work = all_reduce_sum(self.flat[self.flat.numel() - self.tail:], group=self.group, async_op=True)
         timed = self.flat.is_cuda
         if timed:       # the compute stream stalls exactly between these two events: the EXPOSED part of the exchange
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         for w in self._works:
             w.wait()
+        if tail_work is not None:
+            tail_work.wait()
         if self.wire is not None:           # the waits above ordered the compute stream behind the collectives
-            self.flat.copy_(self.wire)
+            n = self.flat.numel() - self.tail
+            self.flat[:n].copy_(self.wire[:n])
         if timed:
             e1.record()
             self._exposed.append((e0, e1))

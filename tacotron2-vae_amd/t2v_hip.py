@@ -536,33 +536,90 @@ def release_step_params():
 # ---- asynchronous error ledger.  The cooperative kernels (BiLSTM, GRU, attention exchange, reverse-step hand-off)
 # use bounded spins: on a timeout they set an error word and leave instead of hanging.  Reading those words right
 # away would force a device sync per call, so the wrappers copy each word (device-to-device, 4 bytes) into a small
-# per-device pool and `check_async_errors()` — called by the training loop where it syncs anyway (loss.item()),
-# by validate(), bench.py and the tests — reads the pool once and raises if any call reported a timeout.
+# per-device ledger and `check_async_errors()` — called by the training loop where it syncs anyway (loss.item()),
+# by validate(), bench.py and the tests — reads the ledger once and raises if any call reported a timeout.
+#
+# Layout of the ledger (round 5): two regions.
+#   [0, _ERR_GRAPH_SLOTS)            blocks of _ERR_BLOCK slots, one block per CAPTURED graph.  The gather launches of a
+#                                    captured step write their words into the graph's own block on every replay, so the block
+#                                    stays reserved while the graph lives and goes back to the free list when the graph is
+#                                    evicted (err_capture_begin / err_capture_end / err_release).  A training engine reads
+#                                    `err_words(span)` of the graph it just replayed: that is the guard of the optimiser step.
+#   [_ERR_GRAPH_SLOTS, _ERR_SLOTS)   eager notes.  A step reserves a contiguous run (err_mark: when fewer than
+#                                    _ERR_STEP_RESERVE slots are left the ledger is checked — a sync, and a raise if a word
+#                                    is set — and the cursor goes back to the start of the region), so err_range(mark) never
+#                                    spans a wrap and no slot index ever reaches _ERR_SLOTS.
 _ERR_POOL = {}
 _ERR_SLOTS = 4096
-_ERR_STICKY = [0]      # > 0: slots [0, n) belong to captured graphs (rewritten by every replay) and are never recycled
+_ERR_BLOCK = 32             # ledger words of one captured graph (a step has six or seven cooperative launches)
+_ERR_GRAPH_SLOTS = 2048     # 64 captured graphs alive at once, over all engines of the process
+_ERR_STEP_RESERVE = 64
 
 
-_ERR_INJECT = [None]    # test hook: a substring; the next ledger entry whose label contains it is recorded as a time-out
+# test hook: a substring — the next ledger entry whose label contains it is recorded as a time-out — or (substring, label): the
+# entry is recorded as a time-out under that label (two ranks sharing one GPU cannot run the persistent kernels, but the
+# recovery path keys on their label)
+_ERR_INJECT = [None]
+
+
+class _ErrPool(object):
+    def __init__(self, device):
+        self.words = torch.zeros(_ERR_SLOTS, device=device, dtype=torch.int32)
+        self.cursor = _ERR_GRAPH_SLOTS          # next eager slot
+        self.labels = {}
+        self.free_blocks = list(range(0, _ERR_GRAPH_SLOTS, _ERR_BLOCK))
+        self.capture = None                     # [lo, next, hi] of the block the running capture writes
+        self.used_hi = _ERR_GRAPH_SLOTS         # eager slots [GRAPH_SLOTS, used_hi) may hold unchecked words
+
+
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def _err_pool(device=None):
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type == 'cuda' and dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    key = str(dev)
+    pool = _ERR_POOL.get(key)
+    if pool is None:
+        pool = _ERR_POOL[key] = _ErrPool(dev)
+    return key, pool
+
+
+def _err_take_slot(pool):
+    if pool.capture is not None:
+        lo, nxt, hi = pool.capture
+        if nxt >= hi:
+            raise T2VHipError("more than %d cooperative launches inside one captured graph" % _ERR_BLOCK)
+        pool.capture[1] = nxt + 1
+        return nxt
+    if pool.cursor >= _ERR_SLOTS:
+        # a loop that never checks its errors: check now (syncs; raises if a kernel timed out), then start over
+        if _capturing():
+            raise T2VHipError("error ledger full inside a graph capture that did not reserve a block")
+        check_async_errors()
+    slot = pool.cursor
+    pool.cursor += 1
+    pool.used_hi = max(pool.used_hi, pool.cursor)
+    return slot
 
 
 def _err_note(label, word):
     """word: a 1-element int32 device view holding a kernel's error word (valid once the stream reaches it)"""
-    key = str(word.device)
-    if key not in _ERR_POOL:
-        _ERR_POOL[key] = [torch.zeros(_ERR_SLOTS, device=word.device, dtype=torch.int32), 0, {}]
-    pool = _ERR_POOL[key]
-    if pool[1] >= _ERR_SLOTS:
-        pool[1] = _ERR_STICKY[0]
-    slot = pool[1]
+    key, pool = _err_pool(word.device)
+    slot = _err_take_slot(pool)
+    assert 0 <= slot < _ERR_SLOTS
     # (round 4) the 4-byte copy into the ledger is deferred: flush_err_notes() moves up to 16 words per launch (a step has
     # six or seven cooperative launches; each copy was a launch of its own on the critical path)
-    inject = _ERR_INJECT[0] is not None and _ERR_INJECT[0] in label
+    want = _ERR_INJECT[0]
+    inject = want is not None and (want if isinstance(want, str) else want[0]) in label
     if inject:
+        if not isinstance(want, str):
+            label = want[1]
         _ERR_INJECT[0] = None
     _ERR_PENDING.setdefault(key, []).append((slot, word, torch.cuda.current_stream(word.device), inject))
-    pool[2][slot] = label
-    pool[1] += 1
+    pool.labels[slot] = label
     if len(_ERR_PENDING[key]) >= 16:
         flush_err_notes()
 
@@ -578,37 +635,93 @@ def flush_err_notes():
         if not pend:
             continue
         pool = _ERR_POOL[key]
-        dev = pool[0].device
+        dev = pool.words.device
         with torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
             for st in {id(p[2]): p[2] for p in pend if p[2] != cur}.values():
                 cur.wait_stream(st)
             n = len(pend)
             src = (C.c_void_p * n)(*[p[1].data_ptr() for p in pend])
-            dst = (C.c_void_p * n)(*[pool[0].data_ptr() + 4 * p[0] for p in pend])
+            dst = (C.c_void_p * n)(*[pool.words.data_ptr() + 4 * p[0] for p in pend])
             _check(load_library().t2v_gather_words(src, dst, n, _stream()), 't2v_gather_words')
             for p in pend:
                 p[1].record_stream(cur)
                 if p[3]:
-                    pool[0][p[0]:p[0] + 1].fill_(1)
+                    pool.words[p[0]:p[0] + 1].fill_(1)
         del pend[:]
 
 
 def err_mark(device=None):
     """position of the error ledger now: an engine takes it at the top of a step; err_range(mark) then names the ledger words
-    the step's kernels wrote (the guard of the fused optimiser step)"""
-    key = str(torch.device('cuda', torch.cuda.current_device()) if device is None else device)
-    pool = _ERR_POOL.get(key)
-    return 0 if pool is None else pool[1]
+    the step's kernels wrote (the guard of the fused optimiser step).  Reserves a contiguous run for the step: with fewer
+    than _ERR_STEP_RESERVE eager slots left the ledger is checked (sync; raises on a recorded time-out) and restarted."""
+    _, pool = _err_pool(device)
+    if pool.capture is not None:
+        return pool.capture[1]
+    if pool.cursor + _ERR_STEP_RESERVE > _ERR_SLOTS and not _capturing():
+        check_async_errors()
+    return pool.cursor
 
 
 def err_range(mark, device=None):
-    """(device pointer, count) of the ledger words written since `mark` (None when there are none or the ledger wrapped)"""
-    key = str(torch.device('cuda', torch.cuda.current_device()) if device is None else device)
-    pool = _ERR_POOL.get(key)
-    if pool is None or pool[1] <= mark:
+    """int32 device view of the ledger words written since `mark` (None when there are none)"""
+    _, pool = _err_pool(device)
+    cur = pool.capture[1] if pool.capture is not None else pool.cursor
+    if cur <= mark:
         return None
-    return pool[0][mark:pool[1]]
+    return pool.words[mark:cur]
+
+
+def err_words(span, device=None):
+    """int32 device view of the ledger block (lo, hi) of a captured graph (None for an empty block)"""
+    if span is None or span[1] <= span[0]:
+        return None
+    _, pool = _err_pool(device)
+    return pool.words[span[0]:span[1]]
+
+
+def err_capture_begin(device=None):
+    """right before a graph capture: reserve a ledger block for the graph.  The notes of the capture land in it (and every
+    replay rewrites them there).  Returns False when no block is free — the caller then does not capture (the step runs
+    eagerly), instead of pinning ledger slots without bound."""
+    _, pool = _err_pool(device)
+    if pool.capture is not None:
+        raise T2VHipError("nested graph captures share no error-ledger block")
+    flush_err_notes()               # eager notes still pending must not be swept into the captured gather
+    if not pool.free_blocks:
+        return False
+    lo = pool.free_blocks.pop(0)
+    pool.capture = [lo, lo, lo + _ERR_BLOCK]
+    return True
+
+
+def err_capture_end(device=None, keep=True):
+    """after the capture: (lo, hi) of the words the graph writes on every replay; keep=False (capture failed) frees the block"""
+    key, pool = _err_pool(device)
+    if pool.capture is None:
+        return None
+    lo, nxt, _hi = pool.capture
+    pool.capture = None
+    if _ERR_PENDING.get(key):       # notes of a capture that died before its flush: their words never get written
+        _ERR_PENDING[key] = [p for p in _ERR_PENDING[key] if not (lo <= p[0] < lo + _ERR_BLOCK)]
+    if not keep:
+        err_release((lo, nxt), device)
+        return None
+    return (lo, nxt)
+
+
+def err_release(span, device=None):
+    """the graph that owned ledger block `span` is gone: labels dropped, block back on the free list"""
+    if span is None:
+        return
+    _, pool = _err_pool(device)
+    lo = span[0] - span[0] % _ERR_BLOCK
+    for i in range(lo, lo + _ERR_BLOCK):
+        pool.labels.pop(i, None)
+    if lo not in pool.free_blocks and 0 <= lo < _ERR_GRAPH_SLOTS:
+        pool.words[lo:lo + _ERR_BLOCK].zero_()
+        pool.free_blocks.append(lo)
+        pool.free_blocks.sort()
 
 
 def check_async_errors():
@@ -616,28 +729,19 @@ def check_async_errors():
     bad = []
     flush_err_notes()
     for key, pool in _ERR_POOL.items():
-        n = min(pool[1], _ERR_SLOTS)
-        if n == 0:
-            continue
-        vals = pool[0][:n].cpu()
+        n = max(pool.used_hi, pool.cursor)
+        vals = pool.words[:n].cpu()
         for i in torch.nonzero(vals).flatten().tolist():
-            bad.append(pool[2].get(i, '?'))
-        pool[0].zero_()
-        pool[1] = _ERR_STICKY[0]
-        for i in [i for i in pool[2] if i >= _ERR_STICKY[0]]:
-            del pool[2][i]
+            bad.append(pool.labels.get(i, '?'))
+        pool.words[:n].zero_()
+        pool.cursor = pool.used_hi = _ERR_GRAPH_SLOTS
+        for i in [i for i in pool.labels if i >= _ERR_GRAPH_SLOTS]:
+            del pool.labels[i]
     if bad:
         e = T2VHipError("cooperative kernel barrier timed out (results of that step are invalid): %s"
                         % ", ".join(sorted(set(bad))))
         e.labels = sorted(set(bad))
         raise e
-
-
-def err_pool_pin():
-    """called right after a graph capture: the ledger slots written so far are rewritten by every replay of that graph,
-    so they stay reserved (and keep their labels) for the life of the process"""
-    for pool in _ERR_POOL.values():
-        _ERR_STICKY[0] = max(_ERR_STICKY[0], pool[1])
 
 
 def _require_gpu(*tensors):
@@ -767,7 +871,6 @@ class DecoderCore(torch.autograd.Function):
     last_bwd_mode = None
     last_mode = None        # 'persistent' | 'launch-per-step' of the most recent forward chunk (bench / tests)
     last_bwd_persist = None
-    _prepared = {}          # id(XS of a chunk) -> (DQP, scratch, err word, event, stream) of an early-issued reverse-pass preparation
     last_persist = None     # keep_last: (weights, bufs, scratch, dims, tensors) of the last persistent forward, for replays
 
     @staticmethod
@@ -834,15 +937,16 @@ class DecoderCore(torch.autograd.Function):
                                                               float(p_dec), int(seed), _stream()), 't2v_decoder_bwd_achain_prepare')
                     ev = torch.cuda.Event()
                     ev.record()
-                while len(DecoderCore._prepared) >= 4:      # (forward passes whose backward never came)
-                    DecoderCore._prepared.pop(next(iter(DecoderCore._prepared)))
-                DecoderCore._prepared[id(XS)] = (DQP, bscr, errw, ev, torch.cuda.current_stream())
-            return W, Sb, (gpre, memory, pm, lengths, XS, CA, CD, GA, GD, QP, AL, ACUM, S)
+                # (the prepared buffers travel with the chunk on the autograd ctx — a process-wide table keyed by id(XS) could hand
+                # a later chunk the scratch of a forward pass whose backward never ran)
+                prep = (DQP, bscr, errw, ev, torch.cuda.current_stream())
+                return W, Sb, (gpre, memory, pm, lengths, XS, CA, CD, GA, GD, QP, AL, ACUM, S), prep
+            return W, Sb, (gpre, memory, pm, lengths, XS, CA, CD, GA, GD, QP, AL, ACUM, S), None
         _check(lib.t2v_decoder_train_fwd(C.byref(W), C.byref(Sb), B, T_in, T, float(p_att), float(p_dec),
                                          int(seed), _stream()), 't2v_decoder_train_fwd')
         _err_note('decoder forward (attention exchange)', QP.view(torch.int32)[B * 256 * A + 31:][:1])
         DecoderCore.last_mode = 'launch-per-step'
-        return W, Sb, (gpre, memory, pm, lengths, XS, CA, CD, GA, GD, QP, AL, ACUM, S)
+        return W, Sb, (gpre, memory, pm, lengths, XS, CA, CD, GA, GD, QP, AL, ACUM, S), None
 
     @staticmethod
     def forward(ctx, gpre, memory, pm, lengths, w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, bias_dec,
@@ -893,14 +997,14 @@ class DecoderCore(torch.autograd.Function):
                                                  p_att, p_dec, (int(seed) + 7919 * b0) & 0x7FFFFFFFFFFFFFFF, wbf, raw,
                                                  bwd_prepare=bwd_persist))
         hcs = []
-        for b0c, b1c, k in chunks:          # (h_dec(t), context(t)) rows of the projection, gathered from the arena in one launch
+        for _w, _s, k, _prep in chunks:          # (h_dec(t), context(t)) rows of the projection, gathered from the arena in one launch
             XSc = k[4]
             Bc, XWc = XSc.size(1), XSc.size(2)
             hc_c = torch.empty(T, Bc, XWc - H, device=XSc.device, dtype=torch.float32)
             _check(lib.t2v_concat2_rows(_p(XSc[2:, :, KATT:]), XWc, XWc - KATT, _p(XSc[1:, :, H:KATT]), XWc, KATT - H, _p(hc_c),
                                         T * Bc, _stream()), 't2v_concat2_rows')
             hcs.append(hc_c)
-        als = [k[10][1:].permute(1, 0, 2) for _, _, k in chunks]
+        als = [k[10][1:].permute(1, 0, 2) for _, _, k, _ in chunks]
         HC = hcs[0] if len(hcs) == 1 else torch.cat(hcs, 1)
         align = als[0] if len(als) == 1 else torch.cat(als, 0)
         ctx.dims = (B, T_in, T, float(p_att), float(p_dec), int(seed))
@@ -910,10 +1014,11 @@ class DecoderCore(torch.autograd.Function):
         ctx.raw = raw
         ctx.pre2 = pre2
         ctx.pre_on_side = gpre_ready is not None     # Decoder.prepare ran the Prenet on the engine's deferred-work stream
-        ctx.chunks = [k for _, _, k in chunks] if need_grad else None
+        ctx.chunks = [k for _, _, k, _ in chunks] if need_grad else None
+        ctx.prepared = [pr for _, _, _, pr in chunks] if need_grad else None
         ctx.mark_non_differentiable(align)
         if DecoderCore.keep_last:
-            W0, S0, k0 = chunks[0]
+            W0, S0, k0, _ = chunks[0]
             DecoderCore.last_call = (W0, S0, (k0[0].shape[1], T_in, T, float(p_att), float(p_dec), int(seed)),
                                      k0 + (packs, bias_dec, wqT, wcomb, vv))
         return HC, align
@@ -935,7 +1040,7 @@ class DecoderCore(torch.autograd.Function):
         wg = None
         dga_l, dmem_l, dpm_l, dpre_l = [], [], [], []
         b0 = 0
-        for keep in ctx.chunks:
+        for ci, keep in enumerate(ctx.chunks):
             gpre, memory, pm, lengths, XS, CA, CD, GA, GD, QP, AL, ACUM, S = keep
             B = gpre.shape[1]
             dhc_c = dHC if B == Bt else dHC[:, b0:b0 + B].contiguous()
@@ -954,7 +1059,7 @@ class DecoderCore(torch.autograd.Function):
                 w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, wq_raw = ctx.raw
                 PW = _DecTrainPersistWeights(_p(w_ih_att), _p(w_hh_att), _p(w_ih_dec), _p(w_hh_dec), _p(bias_dec), _p(wq_raw),
                                              _p(wcomb), _p(vv))
-                prep = DecoderCore._prepared.pop(id(XS), None)
+                prep, ctx.prepared[ci] = ctx.prepared[ci], None
                 if prep is not None:
                     DQP, scratch, errw, pev, pst = prep
                     if pst != torch.cuda.current_stream():
@@ -1072,7 +1177,7 @@ class DecoderCore(torch.autograd.Function):
             bacc = bparts if bacc is None else [x + y for x, y in zip(bacc, bparts)]
             dga_l.append(DGA)
             b0 += B
-        ctx.chunks = None          # the arena is released as soon as the backward has consumed it (side-stream readers: keep=)
+        ctx.chunks = ctx.prepared = None   # the arena is released as soon as the backward has consumed it (side-stream readers: keep=)
         d_wq, d_loc_conv, d_loc_dense, d_v = acc
         d_bias_dec = bacc[0]
         d_w_ih_att, d_w_hh_att, d_w_ih_dec, d_w_hh_dec = wg

@@ -102,7 +102,7 @@ class TrainEngine(object):
             self.allreduce = t2v_dist.OverlappedArenaAllReduce(
                 named, offs, self.optimizer.grads_for_allreduce(), force=bool(force_dist),
                 side_streams=lambda: self.overlap.streams(),
-                gather=self.optimizer.gather_grads, wire_dtype=wire)
+                gather=self.optimizer.gather_grads, wire_dtype=wire, tail=self.optimizer.poison_slot().numel())
         self.use_graph = bool(getattr(hparams, 'graph_step', False) if graph is None else graph)
         # multi-rank graph mode: forward + backward + gradient gather replay as ONE graph, then the whole gradient arena
         # crosses xGMI in one eager all-reduce and the fused clip + Adam runs eagerly (2 launches).  The hook-issued
@@ -124,6 +124,7 @@ class TrainEngine(object):
         self.overlap = t2v_hip.Overlap()
         self.step_params.bind(extra=self.overlap.streams())
         self._err_mark = 0
+        self._err_span = None       # ledger block of the graph that was just replayed (multi-rank graph engine: the poison source)
         self._bn_snap = self._bn_bufs = None
         self.recoveries = 0
         # graph engine: the forward pass of a step runs on SHADOW leaves (p.detach().requires_grad_(): same storage, own
@@ -138,6 +139,7 @@ class TrainEngine(object):
                 self._shadow = {n: p.detach().requires_grad_(True) for n, p in self.model.named_parameters()}
             self._shadow_live = [self._shadow[n] for n, _ in self.optimizer.arena_layout()[0]]
         self.model.train()
+        self.note_good_step()       # BatchNorm statistics as loaded: a time-out on the very first step has something to restore
 
     def close(self):
         """unbind this engine's device-side step record from its streams (torch's pooled stream handles are reused)"""
@@ -145,6 +147,7 @@ class TrainEngine(object):
         sp, self.step_params = self.step_params, None
         if sp is not None:
             t2v_hip.drop_step_params(sp)
+        self._drop_graphs()         # (their error-ledger blocks go back to the free list)
         prev, self._host_threads = getattr(self, '_host_threads', None), None
         if prev is not None and prev > torch.get_num_threads():
             torch.set_num_threads(prev)         # the host-thread cap belonged to this engine's loop
@@ -231,7 +234,9 @@ class TrainEngine(object):
         self.overlap.join()             # weight gradients were produced on the deferred-work stream
         t2v_hip.stamp('grads_ready')
         if self.allreduce is not None:
-            self._poison()              # (rides in the last bucket, which finish() issues: its dead parameters never fire a hook)
+            # the poison slot is NOT part of a hook-issued bucket (the last bucket leaves during backward, before this
+            # step's ledger words exist): finish() reduces the 16-byte tail by itself, after _poison() has written it
+            self._poison()
             self.allreduce.finish()
             opt.mark_gathered()        # every bucket gathered its slice before it went out
         opt.guard = self._guard_words()
@@ -247,12 +252,19 @@ class TrainEngine(object):
         import t2v_hip
         if self.allreduce is not None:
             return self.optimizer.poison_slot()[:1].view(torch.int32)
+        return self._step_words()
+
+    def _step_words(self):
+        """ledger words of THIS step: the block of the graph that was just replayed (a replay runs no host code, so it leaves
+        no eager notes — its gather launches rewrite the graph's own block), else the eager notes since the step's mark"""
+        import t2v_hip
+        if self._err_span is not None:
+            return t2v_hip.err_words(self._err_span)
         return t2v_hip.err_range(self._err_mark)
 
     def _poison(self):
         """multi-rank, before the gradient exchange: poison slot = 1.0 if any of this rank's ledger words of the step is set"""
-        import t2v_hip
-        words = t2v_hip.err_range(self._err_mark)
+        words = self._step_words()
         slot = self.optimizer.poison_slot()
         if words is None:
             slot.zero_()
@@ -273,7 +285,7 @@ class TrainEngine(object):
               % ", ".join(labels))
         t2v_hip.DecoderCore.persistent = False
         t2v_hip.DecoderCore.persistent_bwd = False
-        self._graphs.clear()
+        self._drop_graphs()
         self._seen.clear()
         if self._bn_snap is not None:
             torch._foreach_copy_(self._bn_bufs, self._bn_snap)
@@ -313,6 +325,10 @@ class TrainEngine(object):
             out = self.step(batch, iteration, learning_rate)
             out[0].item()
             t2v_hip.check_async_errors()
+            # the re-run must have been applied: a second skip (another rank timed out again, a stale poison word) would lose
+            # the update silently
+            if (int(out[4].view(torch.int32).item()) & 0xFFFFFFFF) == self.optimizer.SKIPPED_NORM_BITS:
+                raise t2v_hip.T2VHipError("the re-run of iteration %d on the launch-per-step kernels was skipped as well" % iteration)
         self.note_good_step()
         return out
 
@@ -348,6 +364,7 @@ class TrainEngine(object):
     def _step(self, batch, iteration, learning_rate):
         import t2v_hip
         self._err_mark = t2v_hip.err_mark()
+        self._err_span = None
         opt = self.optimizer
         if learning_rate is not None:
             opt.param_groups[0]['lr'] = learning_rate
@@ -394,13 +411,16 @@ class TrainEngine(object):
             static_buf = torch.empty(lay.nbytes, dtype=torch.uint8, device='cuda')
             lay.upload(batch, into=static_buf)
             x, y = lay.views(static_buf)
-            graph, out, no_grad = self._capture_static(x, y, iteration)
-            entry = self._graphs[key] = (graph, static_buf, out, no_grad)
+            cap = self._capture_static(x, y, iteration)
+            if cap is None:
+                return None
+            graph, out, no_grad, span = cap
+            entry = self._graphs[key] = (graph, static_buf, out, no_grad, span)
         else:
             lay.upload(batch, into=entry[1])
         self._graphs[key] = self._graphs.pop(key)       # most recently used last
         entry[0].replay()
-        return self._after_replay(entry[2], entry[3])
+        return self._after_replay(entry[2], entry[3], entry[4])
 
     def _graph_step(self, x, y, iteration):
         import t2v_hip
@@ -415,24 +435,34 @@ class TrainEngine(object):
                 return None
             self._evict_graphs()
             entry = self._capture(x, y, iteration)
+            if entry is None:
+                return None
             self._graphs[key] = entry
         self._graphs[key] = self._graphs.pop(key)       # most recently used last
-        graph, static_in, static_out, no_grad = entry
+        graph, static_in, static_out, no_grad, span = entry
         for dst, src in zip(static_in, tensors):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         graph.replay()
-        return self._after_replay(static_out, no_grad)
+        return self._after_replay(static_out, no_grad, span)
 
     MAX_SEEN = 4096
 
     def _evict_graphs(self):
         """a ragged loader (shapes that recur now and then) must not pin MAX_GRAPHS private pools for ever — the
         least recently replayed graph (and its activation pool) goes when a new shape wants a slot"""
+        import t2v_hip
         while len(self._graphs) >= self.MAX_GRAPHS:
             old = next(iter(self._graphs))
+            t2v_hip.err_release(self._graphs[old][-1])       # its ledger block goes back to the free list (ADVICE r4)
             del self._graphs[old]
             self._seen.pop(old, None)
+
+    def _drop_graphs(self):
+        import t2v_hip
+        for entry in self._graphs.values():
+            t2v_hip.err_release(entry[-1])
+        self._graphs.clear()
 
     def _trim_seen(self):
         """... and the shape-history dictionary is bounded (one key per distinct batch shape otherwise, for the whole run)"""
@@ -441,10 +471,14 @@ class TrainEngine(object):
                 if k not in self._graphs:
                     del self._seen[k]
 
-    def _after_replay(self, static_out, no_grad):
+    def _after_replay(self, static_out, no_grad, span=None):
         """the captured graph writes its scalars (loss, recon, kl[, grad_norm]) into static tensors that the NEXT replay
         overwrites: hand the caller fresh copies (one small launch), like the eager path does"""
         vals = torch.cat([t.reshape(1) for t in static_out])
+        self._err_span = span       # the words this replay wrote: what _poison() / the optimiser guard read (ADVICE r4, high)
+        hook = self.__dict__.get('_test_after_replay')
+        if hook is not None:        # (tests: a time-out inside a REPLAY — no host code runs there that could be intercepted)
+            hook(span)
         if self.graph_ddp:
             return self._reduce_and_step((vals[0], vals[1], vals[2]), no_grad)
         self.optimizer.step_count += 1
@@ -455,11 +489,18 @@ class TrainEngine(object):
         static_x = tuple(t.clone() if torch.is_tensor(t) else t for t in x)
         static_y = tuple(t.clone() for t in y)
         static_in = [t for t in static_x if torch.is_tensor(t)] + list(static_y)
-        graph, out, no_grad = self._capture_static(static_x, static_y, iteration)
-        return graph, static_in, out, no_grad
+        cap = self._capture_static(static_x, static_y, iteration)
+        if cap is None:
+            return None
+        graph, out, no_grad, span = cap
+        return graph, static_in, out, no_grad, span
 
     def _capture_static(self, static_x, static_y, iteration):
         import t2v_hip
+        # the ledger words of the captured launches live in a block of their own, rewritten by every replay and released when
+        # the graph is evicted; with no block free the shape simply keeps running eagerly
+        if not t2v_hip.err_capture_begin():
+            return None
         torch.cuda.synchronize()
         count0 = self.optimizer.step_count
         graph = torch.cuda.CUDAGraph()
@@ -468,12 +509,18 @@ class TrainEngine(object):
         # one of five runs); 'thread_local' restricts the check to this thread — the launches of the autograd worker
         # thread are still captured (capture follows the stream, not the thread)
         mode = 'thread_local' if self.allreduce is not None else 'global'
-        with torch.cuda.graph(graph, stream=self._stream, capture_error_mode=mode):
-            out = (self._body_fb if self.graph_ddp else self._body)(static_x, static_y, iteration)
+        span = None
+        try:
+            self._err_mark = t2v_hip.err_mark()     # (inside the block: the captured optimiser guard reads these words)
+            with torch.cuda.graph(graph, stream=self._stream, capture_error_mode=mode):
+                out = (self._body_fb if self.graph_ddp else self._body)(static_x, static_y, iteration)
+            span = t2v_hip.err_capture_end()
+        finally:
+            if span is None:
+                t2v_hip.err_capture_end(keep=False)
         self.optimizer.step_count = count0      # capture executes nothing; the replay below is this iteration's step
         no_grad = list(self.optimizer._no_grad) if self.graph_ddp else None
-        t2v_hip.err_pool_pin()
-        return graph, tuple(out), no_grad
+        return graph, tuple(out), no_grad, span
 
 
 def prepare_directories_and_logger(output_directory, log_directory, rank):

@@ -170,3 +170,66 @@ def test_bf16_wire_exchange_whole_arena_and_buckets(tmp_path):
     want = (r['mine'].bfloat16() + other.bfloat16()).float()
     assert torch.equal(r['whole'], want)
     assert torch.equal(r['bucketed'], want)
+
+
+def _tail_worker(rank, world, port, out, wire):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tacotron2-vae_amd'))
+    import distributed as D
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    D.init_distributed(backend='gloo', timeout_s=60)
+    torch.manual_seed(0)
+    net = torch.nn.ModuleDict(dict(encoder=torch.nn.Linear(6, 300), decoder=torch.nn.Linear(300, 300),
+                                   postnet=torch.nn.Linear(300, 300)))
+    named = list(net.named_parameters())
+    offs, total = [], 0
+    for _, p in named:
+        offs.append(total)
+        total += (p.numel() + 3) & ~3
+    full = torch.zeros(total + 4)                       # gradients + the engine's 4-float poison slot
+    for (_, p), o in zip(named, offs):
+        p.grad = full[o:o + p.numel()].view_as(p)
+    ar = D.OverlappedArenaAllReduce(named, offs, full, min_bucket=64, tail=4,
+                                    wire_dtype=torch.bfloat16 if wire else None)
+    x = torch.randn(5, 6, generator=torch.Generator().manual_seed(10 + rank))
+    seen_by_hooked_bucket = []
+    rec = {}
+    for step, poisoned_rank in enumerate((None, 1, None)):
+        full.zero_()
+        full[total:] = 123.0                            # a stale value from the previous step: must never be summed
+        ar.begin()
+        y = net['postnet'](torch.tanh(net['decoder'](torch.tanh(net['encoder'](x)))))
+        y.pow(2).sum().backward()
+        # every bucket left from a hook, i.e. BEFORE the engine knows this step's error words
+        seen_by_hooked_bucket.append(len(ar.launch_log))
+        full[total:] = 1.0 if poisoned_rank == rank else 0.0        # TrainEngine._poison()
+        ar.finish()
+        rec[step] = full[total:].clone()
+    # the graph engine's exchange carries the slot inside its ONE whole-arena collective
+    full[total:] = 1.0 if rank == 0 else 0.0
+    ar.reduce_all()
+    rec['whole'] = full[total:].clone()
+    if rank == 0:
+        torch.save(dict(rec=rec, buckets=ar.buckets, total=total, hooked=seen_by_hooked_bucket), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_poison_slot_is_reduced_after_backward_not_with_a_hook_issued_bucket(tmp_path):
+    """the 16-byte poison slot behind the gradients ("one of my persistent kernels timed out") used to
+    ride in the last bucket, which a hook issues DURING backward — before the step's error words exist.  It now belongs to
+    no bucket; finish() sums it over the ranks by itself: a flag raised on ONE rank after backward is seen by BOTH, a stale
+    value is never re-summed, and the next step starts clean.  fp32 and bf16 wire formats."""
+    for wire in (False, True):
+        world, port = 2, _free_port()
+        out = str(tmp_path / ('r0_%d.pt' % wire))
+        mp.spawn(_tail_worker, args=(world, port, out, wire), nprocs=world, join=True)
+        r = torch.load(out, weights_only=False)
+        assert r['buckets'][-1][2] == r['total']                       # no bucket reaches into the slot
+        assert r['hooked'] == [3, 3, 3]                                # all three buckets left from hooks each step
+        assert torch.equal(r['rec'][0], torch.zeros(4))                # nobody poisoned: stays zero (the stale 123 is gone)
+        assert torch.equal(r['rec'][1], torch.ones(4))                 # rank 1 raised it, rank 0 reads it
+        assert torch.equal(r['rec'][2], torch.zeros(4))                # and it does not leak into the next step
+        assert torch.equal(r['rec']['whole'], torch.ones(4))

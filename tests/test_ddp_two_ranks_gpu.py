@@ -56,7 +56,7 @@ def _worker(rank, world, port, mode, out_dir):
     from bench import synthetic_batch
     torch.cuda.set_device(0)
     D.init_distributed(backend='gloo', timeout_s=300)
-    graph = mode in ('graph', 'ragged')
+    graph = mode in ('graph', 'ragged', 'poison_graph')
     bf16 = mode == 'bf16'
     extra = ',bf16_run=True,fp32_allreduce=False' if bf16 else ''      # (the bf16 wire format is opt-in since round 4)
     hp_ref = HP.create_hparams("batch_size=3,anneal_function=constant" + extra)
@@ -138,6 +138,40 @@ def _worker(rank, world, port, mode, out_dir):
         losses.append(float(out[0].item()))
     torch.cuda.synchronize()
     t2v_hip.check_async_errors()
+    if mode.startswith('poison'):
+        # ---- a persistent-kernel time-out on rank 1 ONLY: the flag must reach rank 0
+        # through the poison slot, BOTH ranks must skip the update on the device, both must re-run the same iteration with
+        # the same collectives, and the weights must stay in lock-step.  (Two ranks share this GPU, so the persistent kernels
+        # are off: the injected word is filed under their label, which is what recover() keys on.)
+        PLABEL = 'decoder forward (persistent kernel hand-off)'
+        res['n_graphs_before'] = len(eng._graphs)
+        p_pre = eng.optimizer.params.detach().clone()
+        count_pre = eng.optimizer.step_count
+        it = n_steps
+        if rank == 1:
+            if graph:       # the step is a REPLAY: no host code runs that could be intercepted — set the graph's ledger word
+                def after_replay(span):
+                    _, pool = t2v_hip._err_pool()
+                    t2v_hip.err_words(span)[:1].fill_(1)
+                    pool.labels[span[0]] = PLABEL
+                    eng.__dict__.pop('_test_after_replay', None)
+                eng._test_after_replay = after_replay
+            else:
+                t2v_hip._ERR_INJECT[0] = ('decoder forward', PLABEL)
+        out = eng.step_checked(batch_for(it), it)
+        res['poison_loss'] = float(out[0].item())
+        res['recoveries'] = eng.recoveries
+        res['steps_applied'] = eng.optimizer.step_count - count_pre          # skipped + re-run = ONE optimiser step
+        res['moved_by_rerun'] = float((eng.optimizer.params - p_pre).abs().max().item())
+        res['n_graphs_after'] = len(eng._graphs)
+        res['slot_after'] = float(eng.optimizer.poison_slot().abs().max().item())
+        # the next steps run clean: nothing stays poisoned, nobody recovers again
+        for it in range(n_steps + 1, n_steps + 3):
+            out = eng.step_checked(batch_for(it), it)
+            losses.append(float(out[0].item()))
+        res['recoveries_end'] = eng.recoveries
+        res['steps_total'] = eng.optimizer.step_count
+        res['slot_end'] = float(eng.optimizer.poison_slot().abs().max().item())
     res['losses'] = losses
     res['n_graphs'] = len(eng._graphs)
     mine = eng.optimizer.params.detach().cpu()
@@ -209,3 +243,23 @@ def test_two_ranks_bf16_run_exchanges_bf16_gradients(tmp_path):
     _common_checks(rs, bf16=True)
     for r in rs:
         assert r['wire_bytes'] * 2 == r['arena_bytes']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['poison_eager', 'poison_graph'])
+def test_timeout_on_one_rank_skips_and_reruns_the_step_on_both(tmp_path, mode):
+    """ADVICE r4 (high / medium), VERDICT r4 item 7c.  Eager engine: the poison slot is reduced after backward (it used to leave
+    with a hook-issued bucket, stale).  Graph engine: the flag is read from the replayed graph's OWN ledger block (a replay
+    leaves no eager notes, the slot used to be zeroed every step and the bad update was applied on every rank)."""
+    rs = _run(mode, tmp_path)
+    _common_checks(rs)
+    for r in rs:
+        assert r['recoveries'] == 1 and r['recoveries_end'] == 1, (r['recoveries'], r['recoveries_end'])
+        assert r['steps_applied'] == 1           # the skipped update was never applied, the re-run once
+        assert r['moved_by_rerun'] > 1e-5
+        assert r['poison_loss'] == r['poison_loss']
+        assert r['slot_end'] == 0.0
+    if mode == 'poison_graph':
+        for r in rs:
+            assert r['n_graphs_before'] == 1 and r['n_graphs_after'] == 0      # recover() drops the captured graphs
+    assert rs[0]['steps_total'] == rs[1]['steps_total']

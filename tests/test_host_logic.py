@@ -232,3 +232,62 @@ def test_batch_layout_packs_the_seven_tensors_and_int32_lengths():
     plain = torch.tensor([3, 2])
     assert M.lengths_i32(plain, torch.device('cpu')).dtype == torch.int32         # no companion: converted
     assert lay.key == M.BatchLayout(batch).key
+
+
+def test_error_ledger_blocks_are_recycled_and_slots_stay_in_bounds():
+    """captured graphs used to pin ledger slots for the life of the process while an LRU evicted the
+    graphs themselves — a ragged loader walked the write index past the 4096-word ledger.  Now a graph owns a fixed block
+    that goes back to a free list when the graph is evicted, eager notes live in their own region, a step reserves a
+    contiguous run (the ledger is checked and restarted before it would wrap), and a capture without a free block is refused.
+    Pure host logic: exercised here on a CPU-resident ledger."""
+    import t2v_hip as H
+    dev = torch.device('cpu')
+    H._ERR_POOL.pop('cpu', None)
+    _, pool = H._err_pool(dev)
+    n_blocks = H._ERR_GRAPH_SLOTS // H._ERR_BLOCK
+    # captures: each takes a block; its notes land inside; the span is what the engine reads after a replay
+    spans = []
+    for g in range(n_blocks):
+        assert H.err_capture_begin(dev)
+        m = H.err_mark(dev)
+        for k in range(7):
+            s = H._err_take_slot(pool)
+            pool.labels[s] = 'graph %d note %d' % (g, k)
+            assert m <= s < m + H._ERR_BLOCK <= H._ERR_GRAPH_SLOTS
+        assert H.err_range(m, dev).numel() == 7
+        spans.append(H.err_capture_end(dev))
+        assert spans[-1] == (m, m + 7)
+    assert len({s[0] for s in spans}) == n_blocks
+    assert not H.err_capture_begin(dev)                 # no block left: the engine keeps that shape eager
+    # an evicted graph frees its block (labels gone, words cleared), the next capture gets it
+    pool.words[spans[3][0]] = 1
+    H.err_release(spans[3], dev)
+    assert spans[3][0] not in pool.labels and int(pool.words[spans[3][0]]) == 0
+    assert H.err_capture_begin(dev)
+    assert H.err_mark(dev) == spans[3][0]
+    # a capture that outgrows its block is an error, not a silent walk into the neighbour's words
+    for _ in range(H._ERR_BLOCK):
+        H._err_take_slot(pool)
+    with pytest.raises(H.T2VHipError):
+        H._err_take_slot(pool)
+    assert H.err_capture_end(dev, keep=False) is None
+    assert spans[3][0] in pool.free_blocks
+    # eager notes: never below the graph region, never at or past the end; a step's run is contiguous
+    seen = []
+    for step in range(3000):
+        m = H.err_mark(dev)
+        assert H._ERR_GRAPH_SLOTS <= m and m + H._ERR_STEP_RESERVE <= H._ERR_SLOTS
+        for _ in range(7):
+            s = H._err_take_slot(pool)
+            assert m <= s < H._ERR_SLOTS
+            seen.append(s)
+        r = H.err_range(m, dev)
+        assert r is not None and r.numel() == 7
+    assert min(seen) == H._ERR_GRAPH_SLOTS and max(seen) < H._ERR_SLOTS
+    # a set word anywhere (graph block or eager region) is reported by the next check, with its label, and cleared
+    pool.words[spans[5][0] + 2] = 1
+    with pytest.raises(H.T2VHipError) as ei:
+        H.check_async_errors()
+    assert 'graph 5 note 2' in str(ei.value)
+    H.check_async_errors()
+    H._ERR_POOL.pop('cpu', None)
