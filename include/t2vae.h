@@ -150,6 +150,18 @@ long t2v_decoder_train_persist_scratch_floats(int B, int T_in, int T_out);
 int t2v_decoder_train_fwd_persistent(const t2v_dec_train_persist_weights* w, const t2v_dec_train_bufs* s, float* scratch,
                                      int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed, void* stream);
 
+/* The same pass for hparams.bf16_run (BASELINE configs[4]: B = 16 per GPU; replaces reference fp16_optimizer.py:51-382 /
+ * train.py:22-28 on the decoder loop model.py:415-421, 346-389): B <= 16, T_in <= 224.  The LSTM weights are rounded to bf16
+ * (RNE, as t2v_pack_lstm_weights_bf16) into MFMA tiles that stay in registers for the whole pass — a workgroup owns 8 hidden
+ * units of both cells, the batch is the N dimension of v_mfma_f32_16x16x32_bf16 — the recurrent state travels between the
+ * workgroups as bf16 rows laid out as the MFMA's B operand; fp32 accumulation, cell state, attention and saved activations,
+ * i.e. the arithmetic of t2v_decoder_train_fwd with bf16 packs (packs_bf16 = 1).  Same arena, same dropout masks.
+ * scratch: t2v_decoder_train_persist16_scratch_floats(B, T_in, T_out) floats, 16-byte aligned (filled by the call). */
+int t2v_decoder_train_persist16_supported(int B, int T_in);
+long t2v_decoder_train_persist16_scratch_floats(int B, int T_in, int T_out);
+int t2v_decoder_train_fwd_persistent16(const t2v_dec_train_persist_weights* w, const t2v_dec_train_bufs* s, float* scratch,
+                                       int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed, void* stream);
+
 /* Measurement aid for bench.py: re-issues only the selected kernels of a finished forward pass on
  * its saved arena (bit0 = k_lstm_fwd256 (both LSTM cells), bit1 = k_attn_fwd),
  * so their average launch duration can be bracketed with events on `stream`.  Results are

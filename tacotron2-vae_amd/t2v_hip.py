@@ -73,7 +73,9 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_stamp', 't2v_debug_spin', 't2v_
            't2v_decoder_bwd_dchain_scratch_floats', 't2v_decoder_bwd_dchain', 't2v_decoder_bwd_achain_scratch_floats',
            't2v_decoder_bwd_achain', 't2v_decoder_bwd_achain2', 't2v_decoder_bwd_achain_prepare',
            't2v_decoder_bwd_achain_prepared', 't2v_decoder_bwd_persist_slices', 't2v_decoder_bwd_achain_dq_offset', 't2v_mask_outputs', 't2v_reparam_fwd',
-           't2v_reparam_bwd', 't2v_gather_words', 't2v_concat2_rows')
+           't2v_reparam_bwd', 't2v_gather_words', 't2v_concat2_rows',
+           't2v_decoder_train_fwd_persistent16', 't2v_decoder_train_persist16_supported',
+           't2v_decoder_train_persist16_scratch_floats')
 
 
 def lib_path():
@@ -107,6 +109,10 @@ def load_library():
     lib.t2v_decoder_train_fwd_persistent.argtypes = [C.POINTER(_DecTrainPersistWeights), C.POINTER(_DecTrainBufs), C.c_void_p,
                                                      C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]
     lib.t2v_decoder_train_persist_supported.argtypes = [C.c_int, C.c_int]
+    lib.t2v_decoder_train_fwd_persistent16.argtypes = lib.t2v_decoder_train_fwd_persistent.argtypes
+    lib.t2v_decoder_train_persist16_supported.argtypes = [C.c_int, C.c_int]
+    lib.t2v_decoder_train_persist16_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.t2v_decoder_train_persist16_scratch_floats.restype = C.c_long
     lib.t2v_decoder_train_persist_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.t2v_decoder_train_persist_scratch_floats.restype = C.c_long
     lib.t2v_decoder_bwd_persist_supported.argtypes = [C.c_int, C.c_int]
@@ -792,8 +798,9 @@ def replay_persistent_forward():
         raise T2VHipError("replay_persistent_forward: the last forward pass did not run on the persistent kernel (or "
                           "DecoderCore.keep_last was off)")
     PW, Sb, scratch, (B, T_in, T, p_att, p_dec, seed), _keep = DecoderCore.last_persist
-    _check(load_library().t2v_decoder_train_fwd_persistent(C.byref(PW), C.byref(Sb), _p(scratch), B, T_in, T, p_att, p_dec,
-                                                           seed, _stream()), 't2v_decoder_train_fwd_persistent')
+    lib = load_library()
+    fn = lib.t2v_decoder_train_fwd_persistent16 if DecoderCore.last_kernel == 'k_dec_train_persist16' else lib.t2v_decoder_train_fwd_persistent
+    _check(fn(C.byref(PW), C.byref(Sb), _p(scratch), B, T_in, T, p_att, p_dec, seed, _stream()), 't2v_decoder_train_fwd_persistent')
     return 1
 
 
@@ -872,6 +879,27 @@ class DecoderCore(torch.autograd.Function):
     last_mode = None        # 'persistent' | 'launch-per-step' of the most recent forward chunk (bench / tests)
     last_bwd_persist = None
     last_persist = None     # keep_last: (weights, bufs, scratch, dims, tensors) of the last persistent forward, for replays
+    # round 5: under bf16_run, batches of 7..16 items take the MFMA-batched persistent forward (csrc/decoder_train_persist16.hip:
+    # bf16 weight tiles in registers, the batch is the N dimension of the MFMA).  None: on (env T2V_PERSIST16=0 switches it
+    # off); False: off; 'force': also for B <= 6, where the fp32-weight kernel is the default (tests)
+    persistent16 = None
+    last_kernel = None      # name of the forward kernel of the most recent chunk
+
+    @staticmethod
+    def use_persistent16(lib, B, T_in, T):
+        flag = DecoderCore.persistent16
+        if flag is None:
+            flag = os.environ.get('T2V_PERSIST16', '1') != '0'
+        if not flag or not _BF16:
+            return False
+        gate = DecoderCore.persistent
+        if gate is None:
+            gate = os.environ.get('T2V_TRAIN_PERSISTENT', '1') != '0'
+        if not gate or not lib.t2v_decoder_train_persist16_supported(int(B), int(T_in)):
+            return False
+        if flag != 'force' and DecoderCore.use_persistent(lib, B, T_in, T):
+            return False            # B <= 6: the fp32-weight persistent kernel
+        return 4 * lib.t2v_decoder_train_persist16_scratch_floats(int(B), int(T_in), int(T)) < 2 ** 31 - 1
 
     @staticmethod
     def use_persistent(lib, B, T_in, T):
@@ -914,15 +942,19 @@ class DecoderCore(torch.autograd.Function):
                         _p(wqT), _p(wcomb), _p(vv), int(bool(wbf)))
         Sb = _DecTrainBufs(_p(gpre), _p(memory), _p(pm), _p(lengths), _p(XS), _p(CA), _p(CD), _p(GA), _p(GD),
                            _p(QP), _p(AL), _p(ACUM), _p(S))
-        if raw is not None and DecoderCore.use_persistent(lib, B, T_in, T):
+        p16 = raw is not None and DecoderCore.use_persistent16(lib, B, T_in, T)
+        if p16 or (raw is not None and DecoderCore.use_persistent(lib, B, T_in, T)):
             w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, wq = raw
-            scratch = torch.empty(lib.t2v_decoder_train_persist_scratch_floats(B, T_in, T), **f32)
+            nscr = (lib.t2v_decoder_train_persist16_scratch_floats if p16 else lib.t2v_decoder_train_persist_scratch_floats)(B, T_in, T)
+            scratch = torch.empty(nscr, **f32)
             PW = _DecTrainPersistWeights(_p(w_ih_att), _p(w_hh_att), _p(w_ih_dec), _p(w_hh_dec), _p(bias_dec), _p(wq),
                                          _p(wcomb), _p(vv))
-            _check(lib.t2v_decoder_train_fwd_persistent(C.byref(PW), C.byref(Sb), _p(scratch), B, T_in, T, float(p_att),
-                                                        float(p_dec), int(seed), _stream()), 't2v_decoder_train_fwd_persistent')
+            run = lib.t2v_decoder_train_fwd_persistent16 if p16 else lib.t2v_decoder_train_fwd_persistent
+            _check(run(C.byref(PW), C.byref(Sb), _p(scratch), B, T_in, T, float(p_att), float(p_dec), int(seed), _stream()),
+                   't2v_decoder_train_fwd_persistent')
             _err_note('decoder forward (persistent kernel hand-off)', QP.view(torch.int32)[B * 256 * A + 31:][:1])
             DecoderCore.last_mode = 'persistent'
+            DecoderCore.last_kernel = 'k_dec_train_persist16' if p16 else 'k_dec_train_persist'
             if DecoderCore.keep_last:
                 DecoderCore.last_persist = (PW, Sb, scratch, (B, T_in, T, float(p_att), float(p_dec), int(seed)), raw)
             if need_grad and bwd_prepare and DecoderCore.use_persistent_bwd(lib, B, T_in, T):
@@ -946,6 +978,7 @@ class DecoderCore(torch.autograd.Function):
                                          int(seed), _stream()), 't2v_decoder_train_fwd')
         _err_note('decoder forward (attention exchange)', QP.view(torch.int32)[B * 256 * A + 31:][:1])
         DecoderCore.last_mode = 'launch-per-step'
+        DecoderCore.last_kernel = 'k_lstm_fwd256 + k_attn_fwd'
         return W, Sb, (gpre, memory, pm, lengths, XS, CA, CD, GA, GD, QP, AL, ACUM, S), None
 
     @staticmethod
@@ -972,7 +1005,8 @@ class DecoderCore(torch.autograd.Function):
         wbf = bool(_BF16)
         # the persistent forward reads the nn.LSTMCell tensors themselves; the forward packs are only built when some
         # chunk takes the launch-per-step path (the transposed packs of the backward are always needed)
-        fwd_persist = all(DecoderCore.use_persistent(lib, min(B, b0 + MAX_DEC_B) - b0, T_in, T) for b0 in range(0, B, MAX_DEC_B))
+        fwd_persist = all(DecoderCore.use_persistent(lib, min(B, b0 + MAX_DEC_B) - b0, T_in, T) or
+                          DecoderCore.use_persistent16(lib, min(B, b0 + MAX_DEC_B) - b0, T_in, T) for b0 in range(0, B, MAX_DEC_B))
         bwd_persist = need_grad and all(DecoderCore.use_persistent_bwd(lib, min(B, b0 + MAX_DEC_B) - b0, T_in, T)
                                         for b0 in range(0, B, MAX_DEC_B))
         if fwd_persist and (bwd_persist or not need_grad):

@@ -1,0 +1,105 @@
+"""bf16_run (BASELINE configs[4], B = 16 per GPU): the MFMA-batched persistent decoder forward (csrc/decoder_train_persist16.hip:
+bf16 weight tiles register-resident, the batch is the N dimension of v_mfma_f32_16x16x32_bf16, B <= 16) against the
+launch-per-step bf16 loop (k_lstm_fwd256<true> + k_attn_fwd) on the same inputs, state dropout ON.  Both round the same fp32
+master weights to bf16 (RNE), round the recurrent state to bf16 in front of every product, accumulate in fp32 and keep cell
+state, attention and saved activations in fp32 — the same arithmetic in a different summation order (8-wave K split instead
+of 4).  Unlike the fp32 pair of test_decoder_persist_train_gpu.py the two do NOT agree to 1e-6: a last-bit fp32 difference in
+a state value now and then crosses a bf16 rounding boundary (2^-9 relative) and is carried on by the recurrence.  The bounds
+below are therefore a few bf16 ulps of the state on the worst element and 1e-4-ish on the mean; the bf16 path as a whole is
+bounded against the fp32 build in test_bf16_gpu.py (reference fp16_optimizer.py:51-382 is what bf16_run replaces)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ('gpre', 'memory', 'pm', 'lengths', 'XS', 'CA', 'CD', 'GA', 'GD', 'QP', 'AL', 'ACUM', 'S')
+
+
+def _run(dec, p16, mem0, mels, lens, T):
+    import t2v_hip as H
+    H.DecoderCore.persistent16 = p16
+    H.DecoderCore.persistent = None if p16 else False
+    H.DecoderCore.persistent_bwd = False
+    dec._calls = 0
+    for q in dec.parameters():
+        q.grad = None
+    mem = mem0.clone().requires_grad_(True)
+    mel, gate, al = dec(mem, mels, lens)
+    used, kern = H.DecoderCore.last_mode, H.DecoderCore.last_kernel
+    keep = H.DecoderCore.last_call[3]
+    arena = {n: keep[i].clone() for i, n in enumerate(NAMES) if torch.is_tensor(keep[i]) and n in ('XS', 'CA', 'CD', 'GA', 'GD', 'AL', 'ACUM', 'S')}
+    (mel.sum() + 0.3 * gate.sum() + 0.01 * (mel * mel).sum()).backward()
+    torch.cuda.synchronize()
+    H.check_async_errors()
+    grads = {n: q.grad.clone() for n, q in dec.named_parameters() if q.grad is not None}
+    grads['memory'] = mem.grad.clone()
+    return used, kern, mel.detach(), gate.detach(), al.detach(), arena, grads
+
+
+@pytest.mark.parametrize("B,T_in,T,ragged", [(16, 84, 400, False), (16, 84, 30, True), (7, 40, 9, True), (12, 130, 8, True),
+                                             (16, 224, 5, True), (9, 1, 4, False), (16, 5, 7, True), (3, 16, 6, True), (8, 84, 12, False)])
+def test_persistent16_forward_matches_launch_per_step_bf16(B, T_in, T, ragged):
+    import hparams as HP
+    import model as M
+    import t2v_hip as H
+    assert H.load_library().t2v_decoder_train_persist16_supported(B, T_in) == 1
+    old = (M.drop_rate, H.DecoderCore.keep_last, H.DecoderCore.persistent, H.DecoderCore.persistent16, H.bf16_enabled())
+    M.drop_rate = 0.0           # Prenet dropout is keyed by a per-call counter; the LSTM state dropout below stays ON
+    H.DecoderCore.keep_last = True
+    H.set_bf16(True)
+    try:
+        torch.manual_seed(0)
+        dec = M.Decoder(HP.create_hparams("bf16_run=True")).cuda().train()
+        dec.p_attention_dropout = dec.p_decoder_dropout = 0.1
+        g = torch.Generator().manual_seed(1)
+        mem0 = (torch.randn(B, T_in, 512, generator=g) * 0.5).cuda()
+        mels = torch.randn(B, 80, T, generator=g).cuda()
+        lens = torch.tensor([max(1, T_in - (7 * i) % max(T_in, 1)) for i in range(B)] if ragged else [T_in] * B).cuda()
+        a = _run(dec, False, mem0, mels, lens, T)
+        b = _run(dec, 'force', mem0, mels, lens, T)
+        b2 = _run(dec, 'force', mem0, mels, lens, T)
+        assert a[0] == 'launch-per-step' and b[0] == 'persistent' and b[1] == 'k_dec_train_persist16', (a[:2], b[:2])
+        # the persistent pass is bit-reproducible (doubles as the race detector of the hand-offs)
+        for i in (2, 3, 4):
+            assert torch.equal(b[i], b2[i])
+        for n in b[5]:
+            x, y = b[5][n], b2[5][n]
+            if n == 'XS':
+                x, y = torch.cat((x[:T + 1].flatten(), x[T + 1][:, 1536:].flatten())), torch.cat((y[:T + 1].flatten(), y[T + 1][:, 1536:].flatten()))
+            assert torch.equal(x, y), n
+        worst = {}
+        for i, name in ((2, 'mel'), (3, 'gate'), (4, 'alignments')):
+            d = (a[i] - b[i]).abs()
+            worst[name] = (d.max().item(), d.mean().item())
+            assert d.max().item() < 1e-2 * max(1.0, a[i].abs().max().item()) and d.mean().item() < 3e-4, (name, worst[name])
+        for n in a[5]:
+            x, y = a[5][n], b[5][n]
+            if n == 'XS':               # row T+1 carries h_dec(T-1) only; its other columns are never written
+                x, y = torch.cat((x[:T + 1].flatten(), x[T + 1][:, 1536:].flatten())), torch.cat((y[:T + 1].flatten(), y[T + 1][:, 1536:].flatten()))
+            assert not torch.isnan(y).any(), n
+            d = (x - y).abs()
+            worst[n] = (d.max().item(), d.mean().item())
+            assert d.max().item() < 2e-2 * max(1.0, x.abs().max().item()), (n, worst[n])
+            assert d.mean().item() < 2e-4 * max(1.0, x.abs().mean().item()), (n, worst[n])
+        gmax = max(v.abs().max().item() for v in a[6].values())
+        for n in a[6]:
+            scale = a[6][n].abs().max().item()
+            d = (a[6][n] - b[6][n]).abs()
+            worst['d_' + n] = (d.max().item() / (scale + 1e-12), d.mean().item() / (scale + 1e-12))
+            assert d.max().item() < 3e-2 * scale + 1e-3 * gmax + 1e-7, (n, scale, gmax, worst['d_' + n])
+        print("persist16 vs launch-per-step bf16 (B=%d T_in=%d T=%d): " % (B, T_in, T) +
+              ", ".join("%s %.1e/%.1e" % (k, v[0], v[1]) for k, v in worst.items()))
+    finally:
+        M.drop_rate, H.DecoderCore.keep_last, H.DecoderCore.persistent, H.DecoderCore.persistent16 = old[:4]
+        H.set_bf16(old[4])
+        H.DecoderCore.persistent_bwd = None
+        H.DecoderCore.last_call = H.DecoderCore.last_bwd = None
+
+
+def test_persistent16_range():
+    import t2v_hip as H
+    lib = H.load_library()
+    assert lib.t2v_decoder_train_persist16_supported(16, 224) == 1
+    assert lib.t2v_decoder_train_persist16_supported(17, 84) == 0
+    assert lib.t2v_decoder_train_persist16_supported(16, 225) == 0
+    assert lib.t2v_decoder_train_persist16_scratch_floats(16, 84, 400) == 402 * 20480 + 400 * 16384 + 400 * 16 * 8 * 96
