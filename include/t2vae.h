@@ -245,6 +245,24 @@ int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, const float* 
                            const float* dHC, float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
                            uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
                            void* stream);
+/* The reverse pass for hparams.bf16_run, B <= 16 (BASELINE configs[4]; the bf16 counterpart of t2v_decoder_bwd_achain: same
+ * arithmetic as t2v_decoder_train_bwd with bf16 packs — transposed LSTM weights and gate gradients rounded to bf16 in front of
+ * every product, fp32 accumulation, fp32 cell / attention backward).  ONE persistent launch: Wcat^T lives in registers as bf16
+ * MFMA tiles, cut into 128-column x 1024-row blocks (48 + 80 workgroups publish partial column sums), 16 + 16 workgroups run
+ * the cells of 64 hidden units each, B * S workgroups the attention backward (S = t2v_decoder_bwd_persist16_slices(T_in):
+ * slices of 16 positions up to 96 symbols, else 32).  Supported when B <= 16, T_in <= 224 and B * S <= 96.
+ * DV (B,S,128), DQP (T_out,B,S,128), scratch: t2v_decoder_bwd_persist16_scratch_floats() floats, 16-byte aligned (filled by
+ * the call); dq(t) summed over the slices lies at float offset t2v_decoder_bwd_persist16_dq_offset() of scratch as
+ * (T_out, 16, 128).  err_word: set to 1 when a bounded spin gave up (results invalid). */
+int t2v_decoder_bwd_persist16_supported(int B, int T_in);
+int t2v_decoder_bwd_persist16_slices(int T_in);
+long t2v_decoder_bwd_persist16_scratch_floats(int B, int T_in, int T_out);
+long t2v_decoder_bwd_persist16_dq_offset(int B, int T_in, int T_out);
+int t2v_decoder_bwd_persistent16(const t2v_dec_train_persist_weights* w, const t2v_dec_train_bufs* s, const float* dHC,
+                                 float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
+                                 uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
+                                 void* stream);
+
 /* float offset inside `scratch` of dq(t) summed over the position slices, (T_out,B,128) floats, valid when the pass has ended
  * (-1: shape outside the persistent range) */
 long t2v_decoder_bwd_achain_dq_offset(int B, int T_in, int T_out);

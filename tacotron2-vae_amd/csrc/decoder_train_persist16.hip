@@ -30,6 +30,7 @@
 // decoder_rnn(t-1) finishes behind the same barrier, everything else (h_att / h_dec parts of both products) runs in the shadow
 // of attention(t).  Writes the same arena as the launch-per-step loop (XS, CA, CD, GA, GD, AL, ACUM, S), same counter-based
 // dropout masks: either backward runs on it.
+#include <stdlib.h>
 #include "t2v_common.h"
 #include "t2v_kernels.h"
 
@@ -57,9 +58,14 @@ struct P16Args {
     uint64_t seed;
     const t2v_step_params* step;
     unsigned long long* prof;
+    int flags;                // measurement switches (env T2V_P16_FLAGS): bit 0 two ctx polls in flight, bit 1 two h_att polls in flight
+                              // (attention slices), bit 2 the gentler nap rule
 };
 #define P16_STAMP(COND, I) do { if (a.prof && (COND) && (threadIdx.x & 63) == 0) a.prof[(I)] = __builtin_readcyclecounter(); } while (0)
 #define P16_WALL(COND, I) do { if (a.prof && (COND) && (threadIdx.x & 63) == 0) a.prof[(I)] = wall_clock64(); } while (0)
+// per-workgroup time line of ONE step (t = T/2) on the chip-wide 100 MHz counter: prof[64 + workgroup * 8 + slot]
+// (tools/dbg/persist16_prof.py passes a buffer of 64 + 256 * 8 words)
+#define P16_RT(SLOT) do { if (a.prof && t == a.T_out / 2 && threadIdx.x == 0) a.prof[64 + blockIdx.x * 8 + (SLOT)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 typedef unsigned p16_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned p16_u32x2 __attribute__((ext_vector_type(2)));
@@ -89,6 +95,15 @@ __device__ __forceinline__ f32x4 p16_mfma(p16_u32x4 w, p16_u32x4 x, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(t2v_bf16x8, w), __builtin_bit_cast(t2v_bf16x8, x), c, 0, 0, 0);
 }
 
+// nap ahead of a polled hand-off (s_sleep units of 64 clocks): aims at ONE failed look — a failed round costs a whole memory
+// round trip (~1 us under load), so the nap may only grow while looks keep failing more than once, and gives back a quarter
+// as soon as the data was there at the first look
+__device__ __forceinline__ int p16_adapt_nap(int nap, int rounds) {
+    if (rounds > 1) return min(160, nap + 4 * min(rounds - 1, 4));
+    if (rounds == 0) return (3 * nap) >> 2;
+    return nap;
+}
+
 // Poll N consecutive k-blocks of one GH row straight into MFMA B operands.  off = row + kb0 * 1024 + 16 * lane.  A lane
 // whose item does not exist (live == false) never waits and reads zeros.  Wave-uniform loop; returns the failed rounds.
 template <int N>
@@ -104,6 +119,80 @@ __device__ __forceinline__ int p16_poll(p16_u32x4 (&x)[N], __amdgpu_buffer_rsrc_
         for (int i = 0; i < N; ++i) ok = ok && p16_ok4(x[i]);
         if (__all(ok || !live)) break;
         __builtin_amdgcn_s_sleep(2);
+        if (++rounds > (int)(P16_SPIN / 4) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = 0;
+            break;
+        }
+    }
+    if (!live) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = p16_u32x4{0u, 0u, 0u, 0u};
+    }
+    return rounds;
+}
+
+// The same, but a k-block that has arrived is not fetched again: a failed look re-polls only the blocks whose producers are
+// still missing, so the stragglers' wait costs a fraction of the row's fabric traffic (every failed look of p16_poll
+// re-fetches all N KB; a look takes ~1 us of round trip under load, and that round trip grows with the polling traffic).
+template <int N>
+__device__ __forceinline__ int p16_poll_sel(p16_u32x4 (&x)[N], __amdgpu_buffer_rsrc_t rG, unsigned off, bool live, int nap,
+                                            unsigned* err, int* flag) {
+    for (int i = 0; i < nap; i += 8) __builtin_amdgcn_s_sleep(8);
+    int rounds = 0;
+    unsigned pending = (1u << N) - 1u;           // wave-uniform
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (pending & (1u << i)) x[i] = p16_ld16(rG, off + 1024u * (unsigned)i);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if ((pending & (1u << i)) && __all(p16_ok4(x[i]) || !live)) pending &= ~(1u << i);
+        if (!pending) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++rounds > (int)(P16_SPIN / 4) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = 0;
+            break;
+        }
+    }
+    if (!live) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = p16_u32x4{0u, 0u, 0u, 0u};
+    }
+    return rounds;
+}
+
+// The same with TWO polls in flight, `gap` sleep units apart: a row that lands just after a poll left is otherwise only seen a
+// full memory round trip (~1 us under load) later — for the hand-offs that sit on the chain of every step.
+template <int N>
+__device__ __forceinline__ int p16_poll2(p16_u32x4 (&x)[N], __amdgpu_buffer_rsrc_t rG, unsigned off, bool live, int nap, int gap,
+                                         unsigned* err, int* flag) {
+    for (int i = 0; i < nap; i += 8) __builtin_amdgcn_s_sleep(8);
+    p16_u32x4 y[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = p16_ld16(rG, off + 1024u * (unsigned)i);
+    for (int i = 0; i < gap; i += 4) __builtin_amdgcn_s_sleep(4);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = p16_ld16(rG, off + 1024u * (unsigned)i);
+    int rounds = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) ok = ok && p16_ok4(x[i]);
+        if (__all(ok || !live)) break;
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = p16_ld16(rG, off + 1024u * (unsigned)i);
+        ok = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) ok = ok && p16_ok4(y[i]);
+        if (__all(ok || !live)) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) x[i] = y[i];
+            break;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) y[i] = p16_ld16(rG, off + 1024u * (unsigned)i);
         if (++rounds > (int)(P16_SPIN / 4) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
             __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *flag = 0;
@@ -187,12 +276,17 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
         f32x4 pA[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};         // h_att part of attention_rnn(t)
         f32x4 pD[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};         // h_att + h_dec parts of decoder_rnn(t-1)
         int nap_h = 0, nap_c = 0;
+        // state-dropout factors of the NEXT cell evaluation of this lane (counter-based: functions of (seed, t, unit, item) alone),
+        // drawn in the shadow of attention(t) instead of on the chain: two 64-bit hash rounds per cell and step
+        float f_c = 1.0f, f_h = 1.0f;
+        if (cell_on && ccell == 0) f_h = t2v_drop_scale(seed, T2V_RNG_ATT_H, 0, (uint32_t)n * T2V_H + U, a.p_att);
 
         for (int t = 0; t <= T; ++t) {
             const bool do_att = t < T, do_dec = t >= 1;
             const unsigned grow = (unsigned)(t + 1) * (unsigned)P16_GROW;          // row t+1 = [h_att(t) | ctx(t) | h_dec(t-1)]
             f32x4* redp = red + (size_t)(t & 1) * (2 * 8 * 2 * 64);
             P16_STAMP(wg == P16_L0 && wave == 0 && t == T / 2, 0);
+            P16_RT(0);
             // Prenet term of this step for the attention_rnn cell lanes (issued before the products: latency hidden)
             float gp[4] = {0.f, 0.f, 0.f, 0.f};
             if (cell_on && ccell == 0 && do_att) {
@@ -220,10 +314,12 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
             __syncthreads();
             if (flag[0] != 1) return;
             P16_STAMP(wg == P16_L0 && wave == 0 && t == T / 2, 2);
+            P16_RT(1);
             // ---- cell update + publish (4 waves, one tile of one cell each)
             if (is_cell && (ccell == 0 ? do_att : do_dec)) {
                 const f32x4* rp = redp + ((ccell * 8) * 2 + cm) * 64 + lane;       // wave stride: 2 * 64
                 const f32x4 s4 = ((rp[0] + rp[128]) + (rp[256] + rp[384])) + ((rp[512] + rp[640]) + (rp[768] + rp[896]));
+                P16_STAMP(wg == P16_L0 && wave == 0 && t == T / 2 && s4[0] != 123.f, 13);
                 const int tt = ccell == 0 ? t : t - 1;
                 float hd = 0.f, c = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
                 if (cell_on) {
@@ -231,14 +327,11 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
                     gf = sigmoidf_(s4[1] + (ccell == 0 ? gp[1] : bias[1]));
                     gg = tanhf_(s4[2] + (ccell == 0 ? gp[2] : bias[2]));
                     go = sigmoidf_(s4[3] + (ccell == 0 ? gp[3] : bias[3]));
-                    const uint32_t idx = (uint32_t)n * T2V_H + U;
-                    const float p = ccell == 0 ? a.p_att : a.p_dec;
-                    float cprev = cst;
-                    if (tt > 0) cprev *= t2v_drop_scale(seed, ccell == 0 ? T2V_RNG_ATT_C : T2V_RNG_DEC_C, tt - 1, idx, p);
-                    c = gf * cprev + gi * gg;
+                    c = gf * (cst * f_c) + gi * gg;
                     cst = c;
-                    hd = go * tanhf_(c) * t2v_drop_scale(seed, ccell == 0 ? T2V_RNG_ATT_H : T2V_RNG_DEC_H, tt, idx, p);
+                    hd = go * tanhf_(c) * f_h;
                 }
+                P16_STAMP(wg == P16_L0 && wave == 0 && t == T / 2 && hd != 123.f, 14);
                 // publish FIRST (the write-through store is what attention(t) waits for): lane b < B of this wave sends item b's
                 // 4 units of the tile — 8 bytes of bf16 into the state row (+ 16 bytes of fp32 into HX for the attention slices);
                 // the LDS round trip stays inside the wave (in-order), no barrier
@@ -252,6 +345,7 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
                         p16_st16(rH, (unsigned)t * (unsigned)P16_HROW + (unsigned)(lane * T2V_H + u0 + 4 * cm) * 4u,
                                  p16_u32x4{__float_as_uint(hv4.x), __float_as_uint(hv4.y), __float_as_uint(hv4.z), __float_as_uint(hv4.w)});
                 }
+                P16_STAMP(wg == P16_L0 && wave == 0 && t == T / 2, 15);
                 if (cell_on) {          // the saved activations follow (plain stores)
                     if (ccell == 0) a.CA[((size_t)(t + 1) * B + n) * T2V_H + U] = c;
                     else a.CD[((size_t)t * B + n) * T2V_H + U] = c;
@@ -265,12 +359,21 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
             }
             if (t == T) break;
             P16_STAMP(wg == P16_L0 && wave == 0 && t == T / 2, 3);
+            P16_RT(2);
+            if (cell_on) {          // dropout factors of this lane's next cell evaluation: step tt' = t + 1 (attention_rnn) / t (decoder_rnn)
+                const int ntt = ccell == 0 ? t + 1 : t;
+                const uint32_t idx = (uint32_t)n * T2V_H + U;
+                const float p = ccell == 0 ? a.p_att : a.p_dec;
+                f_c = ntt > 0 ? t2v_drop_scale(seed, ccell == 0 ? T2V_RNG_ATT_C : T2V_RNG_DEC_C, ntt - 1, idx, p) : 1.0f;
+                f_h = t2v_drop_scale(seed, ccell == 0 ? T2V_RNG_ATT_H : T2V_RNG_DEC_H, ntt, idx, p);
+            }
             // ---- row t+1 in the shadow of attention(t): h_att(t) -> its share of attention_rnn(t+1) and decoder_rnn(t);
             // h_dec(t-1) -> decoder_rnn(t); ctx(t) last (the chain)
             {
                 p16_u32x4 xh[4];
-                const int rounds = p16_poll<4>(xh, rG, grow + off_h, live, nap_h, a.err, flag);
-                nap_h = t2v_adapt_nap(nap_h, rounds);
+                const int rounds = (a.flags & 8) ? p16_poll_sel<4>(xh, rG, grow + off_h, live, nap_h, a.err, flag)
+                                                 : p16_poll<4>(xh, rG, grow + off_h, live, nap_h, a.err, flag);
+                nap_h = (a.flags & 4) ? p16_adapt_nap(nap_h, rounds) : t2v_adapt_nap(nap_h, rounds);
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accD = {0.f, 0.f, 0.f, 0.f};
@@ -284,19 +387,26 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
                 }
             }
             P16_STAMP(wg == P16_L0 && wave == 0 && t == T / 2, 4);
+            P16_RT(3);
             if (t >= 1) {
                 p16_u32x4 xd[4];
-                p16_poll<4>(xd, rG, grow + off_d, live, 0, a.err, flag);
+                if (a.flags & 8) p16_poll_sel<4>(xd, rG, grow + off_d, live, 0, a.err, flag);
+                else p16_poll<4>(xd, rG, grow + off_d, live, 0, a.err, flag);
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) pD[m] = p16_mfma(wd[m][6 + i], xd[i], pD[m]);
             }
             P16_STAMP(wg == P16_L0 && wave == 0 && t == T / 2, 5);
+            P16_RT(4);
             {
-                const int rounds = p16_poll<2>(xc, rG, grow + off_c, live, nap_c, a.err, flag);
-                nap_c = t2v_adapt_nap(nap_c, rounds);
+                const int rounds = (a.flags & 1) ? p16_poll2<2>(xc, rG, grow + off_c, live, nap_c, 8, a.err, flag)
+                                 : (a.flags & 8) ? p16_poll_sel<2>(xc, rG, grow + off_c, live, nap_c, a.err, flag)
+                                                 : p16_poll<2>(xc, rG, grow + off_c, live, nap_c, a.err, flag);
+                nap_c = (a.flags & 4) ? p16_adapt_nap(nap_c, rounds) : t2v_adapt_nap(nap_c, rounds);
+                if (a.prof && t == T / 2 && tid == 0) { a.prof[64 + wg * 8 + 6] = (unsigned long long)rounds; a.prof[64 + wg * 8 + 7] = (unsigned long long)nap_c; }
             }
+            P16_RT(5);
             P16_WALL(wg == P16_L0 && wave == 0 && t == T / 2, 23);
         }
         return;
@@ -346,6 +456,7 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
     for (int t = 0; t < T; ++t) {
         const unsigned grow = (unsigned)(t + 1) * (unsigned)P16_GROW;
         P16_STAMP(wg == 0 && wave == 0 && t == T / 2, 8);
+        P16_RT(0);
         // ---- location features of this step's tiles (fused filter, K = 64): they depend on alpha(t-1) only
         f32x4 lacc[2];
 #pragma unroll
@@ -373,19 +484,29 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
             const unsigned s0 = (unsigned)t * (unsigned)P16_HROW + (unsigned)(ab * T2V_H + 4 * tid) * 4u;
             p16_u32x4 v;
             for (int i = 0; i < h_nap; i += 8) __builtin_amdgcn_s_sleep(8);
+            const bool two = a.flags & 2;
+            p16_u32x4 v0 = p16_ld16(rH, s0);
+            if (two) __builtin_amdgcn_s_sleep(8);
+            p16_u32x4 v1 = p16_ld16(rH, s0);
             int rounds = 0;
-            for (;;) {
-                v = p16_ld16(rH, s0);
-                if (__all(p16_ok4(v))) break;
-                __builtin_amdgcn_s_sleep(1);
+            for (;;) {          // (two polls in flight, half a round trip apart)
+                if (__all(p16_ok4(v0))) { v = v0; break; }
+                if (two) v0 = p16_ld16(rH, s0);
+                if (__all(p16_ok4(v1))) { v = v1; break; }
+                if (!two) __builtin_amdgcn_s_sleep(1);
+                v1 = p16_ld16(rH, s0);
+                if (!two) v0 = v1;
                 if (++rounds > (int)(P16_SPIN / 4) || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     flag[0] = 0;
+                    v = v0;
                     break;
                 }
             }
-            h_nap = t2v_adapt_nap(h_nap, rounds);
+            h_nap = (a.flags & 4) ? p16_adapt_nap(h_nap, rounds) : t2v_adapt_nap(h_nap, rounds);
             P16_WALL(wg == 0 && wave == 0 && t == T / 2, 21);
+            P16_RT(1);
+            if (a.prof && t == T / 2 && tid == 0) { a.prof[64 + wg * 8 + 6] = (unsigned long long)rounds; a.prof[64 + wg * 8 + 7] = (unsigned long long)h_nap; }
             *(float4*)(hx + 4 * tid) = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
         __syncthreads();
@@ -430,6 +551,7 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
             }
         }
         P16_STAMP(wg == 0 && wave == 0 && t == T / 2, 10);
+        P16_RT(2);
         // ---- the 8 partials of every position (fixed order), masked softmax
         float ev0 = -INFINITY;
         if (tid < Tp) {
@@ -455,6 +577,7 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
                              ((__uint_as_float(p[4]) + __uint_as_float(p[5])) + (__uint_as_float(p[6]) + __uint_as_float(p[7])));
             ev0 = tid < len ? ev : -INFINITY;
         }
+        P16_RT(3);
         {
             float mloc = ev0;
             mloc = T2V_DPP_MAX(mloc, 0xB1); mloc = T2V_DPP_MAX(mloc, 0x4E);
@@ -496,6 +619,7 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
         }
         __syncthreads();
         P16_STAMP(wg == 0 && wave == 0 && t == T / 2, 11);
+        P16_RT(4);
         // ---- context columns [64 as, 64 as + 64): thread = (column c = tid & 63, part = tid >> 6)
         {
             const int c = tid & 63, part = tid >> 6;
@@ -521,6 +645,7 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
         }
         P16_WALL(wg == 0 && wave == 0 && t == T / 2, 22);
         P16_STAMP(wg == 0 && wave == 0 && t == T / 2, 12);
+        P16_RT(5);
     }
 #endif
 }
@@ -611,6 +736,10 @@ extern "C" int t2v_decoder_train_fwd_persistent16(const t2v_dec_train_persist_we
     a.B = B; a.T_in = T_in; a.T_out = T_out; a.p_att = p_att; a.p_dec = p_dec; a.seed = seed;
     a.step = t2v_step_for(stream);
     a.prof = g_t2v_prof;
+    {
+        static const int fl = getenv("T2V_P16_FLAGS") ? atoi(getenv("T2V_P16_FLAGS")) : 0;
+        a.flags = fl;
+    }
     k_dec_train_persist16<<<T2V_NWG, P16_THREADS, p16_lds_bytes(T_in), stream>>>(a);
     return t2v_check_launch();
 }

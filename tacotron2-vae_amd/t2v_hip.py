@@ -75,7 +75,8 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_stamp', 't2v_debug_spin', 't2v_
            't2v_decoder_bwd_achain_prepared', 't2v_decoder_bwd_persist_slices', 't2v_decoder_bwd_achain_dq_offset', 't2v_mask_outputs', 't2v_reparam_fwd',
            't2v_reparam_bwd', 't2v_gather_words', 't2v_concat2_rows',
            't2v_decoder_train_fwd_persistent16', 't2v_decoder_train_persist16_supported',
-           't2v_decoder_train_persist16_scratch_floats')
+           't2v_decoder_train_persist16_scratch_floats', 't2v_decoder_bwd_persistent16', 't2v_decoder_bwd_persist16_supported',
+           't2v_decoder_bwd_persist16_scratch_floats', 't2v_decoder_bwd_persist16_dq_offset', 't2v_decoder_bwd_persist16_slices')
 
 
 def lib_path():
@@ -113,6 +114,14 @@ def load_library():
     lib.t2v_decoder_train_persist16_supported.argtypes = [C.c_int, C.c_int]
     lib.t2v_decoder_train_persist16_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.t2v_decoder_train_persist16_scratch_floats.restype = C.c_long
+    lib.t2v_decoder_bwd_persistent16.argtypes = [C.POINTER(_DecTrainPersistWeights), C.POINTER(_DecTrainBufs)] + [C.c_void_p] * 8 + [
+        C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]
+    lib.t2v_decoder_bwd_persist16_supported.argtypes = [C.c_int, C.c_int]
+    lib.t2v_decoder_bwd_persist16_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.t2v_decoder_bwd_persist16_scratch_floats.restype = C.c_long
+    lib.t2v_decoder_bwd_persist16_dq_offset.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.t2v_decoder_bwd_persist16_dq_offset.restype = C.c_long
+    lib.t2v_decoder_bwd_persist16_slices.argtypes = [C.c_int]
     lib.t2v_decoder_train_persist_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.t2v_decoder_train_persist_scratch_floats.restype = C.c_long
     lib.t2v_decoder_bwd_persist_supported.argtypes = [C.c_int, C.c_int]
@@ -811,6 +820,11 @@ def replay_persistent_backward():
         raise T2VHipError("replay_persistent_backward: the last backward pass did not run on the persistent kernel (or "
                           "DecoderCore.keep_last was off)")
     PW, Sb, (dhc, DGA, DGD, DCTX, DV, DQP, scratch, errw), (B, T_in, T, p_att, p_dec, seed), _keep = DecoderCore.last_bwd_persist
+    if DecoderCore.last_bwd_kernel == 'k_bwd_persist16':
+        _check(load_library().t2v_decoder_bwd_persistent16(C.byref(PW), C.byref(Sb), _p(dhc), _p(DGA), _p(DGD), _p(DCTX), _p(DV), _p(DQP),
+                                                           _p(scratch), _p(errw), B, T_in, T, p_att, p_dec, seed, _stream()),
+               't2v_decoder_bwd_persistent16')
+        return 1
     _check(load_library().t2v_decoder_bwd_achain(C.byref(PW), None, C.byref(Sb), _p(dhc), _p(DGA), _p(DGD), _p(DCTX), _p(DV), _p(DQP),
                                                  _p(scratch), _p(errw), B, T_in, T, p_att, p_dec, seed, _stream()),
            't2v_decoder_bwd_achain')
@@ -884,6 +898,7 @@ class DecoderCore(torch.autograd.Function):
     # off); False: off; 'force': also for B <= 6, where the fp32-weight kernel is the default (tests)
     persistent16 = None
     last_kernel = None      # name of the forward kernel of the most recent chunk
+    last_bwd_kernel = None
 
     @staticmethod
     def use_persistent16(lib, B, T_in, T):
@@ -920,6 +935,24 @@ class DecoderCore(torch.autograd.Function):
         if not (bool(flag) and bool(lib.t2v_decoder_bwd_persist_supported(int(B), int(T_in)))):
             return False
         return 4 * lib.t2v_decoder_bwd_achain_scratch_floats(int(B), int(T_in), int(T)) < 2 ** 31 - 1
+
+    @staticmethod
+    def use_persistent16_bwd(lib, B, T_in, T):
+        """bf16_run, B <= 16: the MFMA-batched one-launch reverse pass (csrc/decoder_train_bwd_persist16.hip).  Follows
+        persistent16 / T2V_PERSIST16 and the reverse-pass switches; B <= 6 keeps the fp32-weight reverse pass unless forced."""
+        flag = DecoderCore.persistent16
+        if flag is None:
+            flag = os.environ.get('T2V_PERSIST16', '1') != '0'
+        if not flag or not _BF16 or os.environ.get('T2V_PERSIST16_BWD', '1') == '0':
+            return False
+        gate = DecoderCore.persistent_bwd
+        if gate is None:
+            gate = os.environ.get('T2V_BWD_PERSISTENT', os.environ.get('T2V_TRAIN_PERSISTENT', '1')) != '0'
+        if not gate or not lib.t2v_decoder_bwd_persist16_supported(int(B), int(T_in)):
+            return False
+        if flag != 'force' and DecoderCore.use_persistent_bwd(lib, B, T_in, T):
+            return False
+        return 4 * lib.t2v_decoder_bwd_persist16_scratch_floats(int(B), int(T_in), int(T)) < 2 ** 33      # (per-array offsets are checked by the library)
 
     @staticmethod
     def _fwd_chunk(lib, gpre, memory, pm, lengths, packs, bias_dec, wqT, wcomb, vv, need_grad, p_att, p_dec, seed, wbf=False,
@@ -1007,7 +1040,8 @@ class DecoderCore(torch.autograd.Function):
         # chunk takes the launch-per-step path (the transposed packs of the backward are always needed)
         fwd_persist = all(DecoderCore.use_persistent(lib, min(B, b0 + MAX_DEC_B) - b0, T_in, T) or
                           DecoderCore.use_persistent16(lib, min(B, b0 + MAX_DEC_B) - b0, T_in, T) for b0 in range(0, B, MAX_DEC_B))
-        bwd_persist = need_grad and all(DecoderCore.use_persistent_bwd(lib, min(B, b0 + MAX_DEC_B) - b0, T_in, T)
+        bwd_persist = need_grad and all(DecoderCore.use_persistent_bwd(lib, min(B, b0 + MAX_DEC_B) - b0, T_in, T) or
+                                        DecoderCore.use_persistent16_bwd(lib, min(B, b0 + MAX_DEC_B) - b0, T_in, T)
                                         for b0 in range(0, B, MAX_DEC_B))
         if fwd_persist and (bwd_persist or not need_grad):
             packs = (None, None, None, None)        # both passes read the nn.LSTMCell tensors themselves
@@ -1081,15 +1115,40 @@ class DecoderCore(torch.autograd.Function):
             DGA = torch.empty(T, B, G4, **f32)
             DGD = torch.empty(T, B, G4, **f32)
             DCTX = torch.empty(T, B, E, **f32)
-            if packB_att is None:       # the one-launch reverse pass has its own slice geometry (one workgroup per item up to 96 symbols)
+            p16b = packB_att is None and DecoderCore.use_persistent16_bwd(lib, B, T_in, T)
+            if p16b:
+                NS = lib.t2v_decoder_bwd_persist16_slices(T_in)
+            elif packB_att is None:     # the one-launch reverse pass has its own slice geometry (one workgroup per item up to 96 symbols)
                 NS = lib.t2v_decoder_bwd_persist_slices(T_in)
             DV = torch.empty(B, NS, A, **f32)
             W = _DecWeights(_p(packF_att), _p(packF_dec), _p(packB_att), _p(packB_dec), None, _p(bias_dec),
                             _p(wqT), _p(wcomb), _p(vv), int(bool(ctx.wbf)))
             Sb = _DecTrainBufs(_p(gpre), _p(memory), _p(pm), _p(lengths), _p(XS), _p(CA), _p(CD), _p(GA), _p(GD),
                                _p(QP), _p(AL), _p(ACUM), _p(S))
-            if packB_att is None:
+            if p16b:
+                # bf16_run, B <= 16: the whole reverse pass as ONE persistent launch on bf16 MFMA tiles (csrc/decoder_train_bwd_persist16.hip)
+                w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, wq_raw = ctx.raw
+                PW = _DecTrainPersistWeights(_p(w_ih_att), _p(w_hh_att), _p(w_ih_dec), _p(w_hh_dec), _p(bias_dec), _p(wq_raw),
+                                             _p(wcomb), _p(vv))
+                DQP = torch.empty(T, B, NS, A, **f32)
+                scratch = torch.empty(lib.t2v_decoder_bwd_persist16_scratch_floats(B, T_in, T), **f32)
+                errw = torch.zeros(1, device=dev, dtype=torch.int32)
+                stamp('dec_bwd_begin')
+                _check(lib.t2v_decoder_bwd_persistent16(C.byref(PW), C.byref(Sb), _p(dhc_c), _p(DGA), _p(DGD), _p(DCTX), _p(DV), _p(DQP),
+                                                        _p(scratch), _p(errw), B, T_in, T, p_att, p_dec,
+                                                        (seed + 7919 * b0) & 0x7FFFFFFFFFFFFFFF, _stream()), 't2v_decoder_bwd_persistent16')
+                split_d = False
+                _err_note('decoder backward (persistent kernel hand-off)', errw)
+                DecoderCore.last_bwd_mode = 'persistent'
+                DecoderCore.last_bwd_kernel = 'k_bwd_persist16'
+                dq_off = lib.t2v_decoder_bwd_persist16_dq_offset(B, T_in, T)      # (T, 16, 128): slice 0 of every item has summed the slices
+                dq_sum = scratch[dq_off:dq_off + T * 16 * A].view(T, 16, A)[:, :B].reshape(T * B, A)
+                if DecoderCore.keep_last and b0 == 0:
+                    DecoderCore.last_bwd_persist = (PW, Sb, (dhc_c, DGA, DGD, DCTX, DV, DQP, scratch, errw), (B, T_in, T, p_att, p_dec, seed),
+                                                    keep + (ctx.raw, wcomb, vv, bias_dec))
+            elif packB_att is None:
                 # the whole reverse pass as ONE persistent launch (csrc/decoder_train_bwd_persist.hip)
+                DecoderCore.last_bwd_kernel = 'k_achain_bwd'
                 w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, wq_raw = ctx.raw
                 PW = _DecTrainPersistWeights(_p(w_ih_att), _p(w_hh_att), _p(w_ih_dec), _p(w_hh_dec), _p(bias_dec), _p(wq_raw),
                                              _p(wcomb), _p(vv))
@@ -1140,6 +1199,7 @@ class DecoderCore(torch.autograd.Function):
                                                  (seed + 7919 * b0) & 0x7FFFFFFFFFFFFFFF, _stream()), 't2v_decoder_train_bwd')
                 _err_note('decoder backward (dq hand-off)', GCUM.view(torch.int32)[B * NS * tcap + 1:][:1])
                 DecoderCore.last_bwd_mode = 'launch-per-step'
+                DecoderCore.last_bwd_kernel = 'k_lstm_bwd256 + k_attn_cell_bwd'
                 dq_sum = DQ[..., 0].sum(2).view(T * B, A)
                 if DecoderCore.keep_last and b0 == 0:
                     DecoderCore.last_bwd = (W, Sb, Gb, (B, T_in, T, p_att, p_dec, seed),

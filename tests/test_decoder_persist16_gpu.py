@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 NAMES = ('gpre', 'memory', 'pm', 'lengths', 'XS', 'CA', 'CD', 'GA', 'GD', 'QP', 'AL', 'ACUM', 'S')
 
 
-def _run(dec, p16, mem0, mels, lens, T):
+def _run(dec, p16, mem0, mels, lens, T, bwd=False):
     import t2v_hip as H
     H.DecoderCore.persistent16 = p16
     H.DecoderCore.persistent = None if p16 else False
-    H.DecoderCore.persistent_bwd = False
+    H.DecoderCore.persistent_bwd = None if bwd else False
     dec._calls = 0
     for q in dec.parameters():
         q.grad = None
@@ -33,7 +33,7 @@ def _run(dec, p16, mem0, mels, lens, T):
     H.check_async_errors()
     grads = {n: q.grad.clone() for n, q in dec.named_parameters() if q.grad is not None}
     grads['memory'] = mem.grad.clone()
-    return used, kern, mel.detach(), gate.detach(), al.detach(), arena, grads
+    return used, kern, mel.detach(), gate.detach(), al.detach(), arena, grads, H.DecoderCore.last_bwd_mode, H.DecoderCore.last_bwd_kernel
 
 
 @pytest.mark.parametrize("B,T_in,T,ragged", [(16, 84, 400, False), (16, 84, 30, True), (7, 40, 9, True), (12, 130, 8, True),
@@ -59,6 +59,17 @@ def test_persistent16_forward_matches_launch_per_step_bf16(B, T_in, T, ragged):
         b = _run(dec, 'force', mem0, mels, lens, T)
         b2 = _run(dec, 'force', mem0, mels, lens, T)
         assert a[0] == 'launch-per-step' and b[0] == 'persistent' and b[1] == 'k_dec_train_persist16', (a[:2], b[:2])
+        assert a[7] == 'launch-per-step' and b[7] == 'launch-per-step'
+        # + the one-launch reverse pass on the same (persistent) forward: its gradients against the launch-per-step reverse pass
+        # of run b — same arena bit for bit, so only the reverse pass differs
+        bwd_ok = H.load_library().t2v_decoder_bwd_persist16_supported(B, T_in) == 1
+        if bwd_ok:
+            c = _run(dec, 'force', mem0, mels, lens, T, bwd=True)
+            c2 = _run(dec, 'force', mem0, mels, lens, T, bwd=True)
+            assert c[7] == 'persistent' and c[8] == 'k_bwd_persist16', c[7:]
+            assert torch.equal(c[2], b[2])
+            for n in c[6]:
+                assert torch.equal(c[6][n], c2[6][n]), ('reverse pass not reproducible', n)
         # the persistent pass is bit-reproducible (doubles as the race detector of the hand-offs)
         for i in (2, 3, 4):
             assert torch.equal(b[i], b2[i])
@@ -87,8 +98,18 @@ def test_persistent16_forward_matches_launch_per_step_bf16(B, T_in, T, ragged):
             d = (a[6][n] - b[6][n]).abs()
             worst['d_' + n] = (d.max().item() / (scale + 1e-12), d.mean().item() / (scale + 1e-12))
             assert d.max().item() < 3e-2 * scale + 1e-3 * gmax + 1e-7, (n, scale, gmax, worst['d_' + n])
-        print("persist16 vs launch-per-step bf16 (B=%d T_in=%d T=%d): " % (B, T_in, T) +
-              ", ".join("%s %.1e/%.1e" % (k, v[0], v[1]) for k, v in worst.items()))
+            if bwd_ok:
+                d = (b[6][n] - c[6][n]).abs()
+                worst['r_' + n] = (d.max().item() / (scale + 1e-12), d.mean().item() / (scale + 1e-12))
+                assert d.max().item() < 3e-2 * scale + 1e-3 * gmax + 1e-7, ('persistent reverse pass', n, scale, gmax, worst['r_' + n])
+        print("persist16 vs launch-per-step bf16 (B=%d T_in=%d T=%d), max/mean abs: " % (B, T_in, T) +
+              ", ".join("%s %.1e/%.1e" % (k, v[0], v[1]) for k, v in worst.items() if not k.startswith(('d_', 'r_'))))
+        for tag, what in (('d_', 'gradients, persistent vs launch-per-step forward (both launch-per-step reverse)'),
+                          ('r_', 'gradients, persistent vs launch-per-step REVERSE pass (same forward)')):
+            ks = [k for k in worst if k.startswith(tag)]
+            if ks:
+                km = max(ks, key=lambda k: worst[k][0] if worst[k][0] < 0.5 else 0.0)
+                print("   %s: worst relative max %.1e (%s), mean of relative means %.1e" % (what, worst[km][0], km[2:], sum(worst[k][1] for k in ks) / len(ks)))
     finally:
         M.drop_rate, H.DecoderCore.keep_last, H.DecoderCore.persistent, H.DecoderCore.persistent16 = old[:4]
         H.set_bf16(old[4])
