@@ -353,7 +353,7 @@ def roofline_table(B, T_in, T, reps=3):
     persistent = t2v_hip.DecoderCore.last_mode == 'persistent'
     legs = []
     if persistent:
-        legs.append(("k_dec_train_persist", lambda _m: t2v_hip.replay_persistent_forward(), 0, persist_bytes, 1))
+        legs.append((t2v_hip.DecoderCore.last_kernel or "k_dec_train_persist", lambda _m: t2v_hip.replay_persistent_forward(), 0, persist_bytes, 1))
     else:
         legs.append(("k_lstm_fwd256", t2v_hip.replay_fwd_kernels, 1, lstm_bytes, T + 1))
         legs.append(("k_attn_fwd", t2v_hip.replay_fwd_kernels, 2, attn_fwd_bytes, T))
@@ -364,7 +364,7 @@ def roofline_table(B, T_in, T, reps=3):
                                  + (T + 1) * B * T_in + T * B * T_in * 128)                                      # AL, S in
                          + f4 * (2 * T * B * 4096 + T * B * 512 + T * B * T_in * 128 + T * B * 8 * 128))        # DGA/DGD, DCTX, dpre, dq
     if t2v_hip.DecoderCore.last_bwd_mode == 'persistent':
-        legs.append(("k_achain_bwd", lambda _m: t2v_hip.replay_persistent_backward(), 0, persist_bwd_bytes, 1))
+        legs.append((t2v_hip.DecoderCore.last_bwd_kernel or "k_achain_bwd", lambda _m: t2v_hip.replay_persistent_backward(), 0, persist_bwd_bytes, 1))
     else:
         legs.append(("k_lstm_bwd256", t2v_hip.replay_bwd_kernels, 1, lstm_bytes, T))
         legs.append(("k_attn_cell_bwd", t2v_hip.replay_bwd_kernels, 2, attn_bwd_bytes, T + 1))
@@ -408,6 +408,19 @@ def roofline_table(B, T_in, T, reps=3):
                                     "cu_fetch_bytes_per_cycle": 11, "dependent_compute_us": 3.4, "floor_us_per_step": round(floor_us, 2),
                                     "achieved_us_per_step": round(us / T, 2), "frac_of_floor": round(floor_us / (us / T), 3),
                                     "source": "profiles/r04_bwd_persist_timeline.txt, profiles/r03_hop_latency.txt"}
+        if name == "k_bwd_persist16":
+            row["us_per_time_step"] = round(us / T, 3)
+            row["note"] = ("bf16_run, B <= 16: ONE launch for the whole reverse pass (%d time steps) — Wcat^T as register-resident bf16 MFMA "
+                           "tiles cut 128 columns x 1024 rows (48 + 80 workgroups publish partial column sums), 16 + 16 cell workgroups, "
+                           "B*S attention-backward workgroups; per step a chain of four hand-offs (gate gradients -> partial sums -> context "
+                           "gradient -> dq -> cells), latency-bound: the `frac` against 8 TB/s is reported because the contract asks for it"
+                           % T)
+        if name == "k_dec_train_persist16":
+            row["us_per_time_step"] = round(us / T, 3)
+            row["note"] = ("bf16_run, B <= 16: ONE launch for all %d time steps — the LSTM weights as register-resident bf16 MFMA tiles "
+                           "(8 hidden units of both cells per workgroup, the batch is the N dimension of v_mfma_f32_16x16x32_bf16), the "
+                           "state rows exchanged in MFMA-operand order and polled straight into registers; a chain of dependent hand-offs "
+                           "(attention_rnn -> attention -> attention_rnn), latency-bound by construction" % T)
         if name == "k_dec_train_persist":
             row["us_per_time_step"] = round(us / T, 3)
             row["note"] = ("ONE launch for all %d time steps: a chain of dependent hand-offs between CUs (attention_rnn -> "
@@ -632,7 +645,7 @@ def main():
                            "launches_timed": top["launches_timed"],
                            "frac_in_situ": top.get("frac_in_situ"), "in_situ_us": top.get("in_situ_us"),
                            "in_situ_source": top.get("in_situ_source"),
-                           "note": top.get("note") if top["kernel"] in ("k_achain_bwd", "k_dec_train_persist") else
+                           "note": top.get("note") if top.get("note") else
                                    "the 67 MB weight stream of a launch is re-read every time step and is served by the "
                                    "256 MiB Infinity Cache, not by HBM proper; 8 TB/s is the HBM3E peak the guide prices against",
                            "latency_model": top.get("latency_model"), "us_per_time_step": top.get("us_per_time_step"),

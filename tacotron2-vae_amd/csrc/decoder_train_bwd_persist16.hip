@@ -61,8 +61,10 @@ struct Q16Args {
     const t2v_step_params* step;
     unsigned long long* prof;
 };
-// per-workgroup time line of ONE step (t = T/2) on the chip-wide 100 MHz counter: prof[64 + workgroup * 8 + slot]
-#define Q16_RT(SLOT) do { if (a.prof && t == a.T / 2 && threadIdx.x == 0) a.prof[64 + blockIdx.x * 8 + (SLOT)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// per-workgroup time line of TWO consecutive steps (t = T/2 + 1: slots 4..7, t = T/2: slots 0..3) on the chip-wide 100 MHz
+// counter: prof[64 + workgroup * 8 + slot] (tools/dbg/persist16_bwd_prof.py follows one turn of the chain through the roles)
+#define Q16_RT(SLOT) do { if (a.prof && (t == a.T / 2 || t == a.T / 2 + 1) && threadIdx.x == 0) \
+        a.prof[64 + blockIdx.x * 8 + (SLOT) + (t == a.T / 2 ? 0 : 4)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 typedef unsigned q16_u32x4 __attribute__((ext_vector_type(4)));
 #define Q16_SC1 16

@@ -127,7 +127,10 @@ def test_model_bf16_vs_fp32_build(golden_dir):
 
 def test_bf16_at_config5_shape_b16_t400():
     """BASELINE configs[4] shape on one GPU: bf16_run with B = 16, T_in = 84, T_out = 400 (bf16 and B = 16 combined):
-    same step as the fp32 build within the stated bf16 bound, two optimiser steps stay finite."""
+    same step as the fp32 build within the stated bf16 bound, two optimiser steps stay finite.  Round 5: the bf16 build must
+    take the MFMA-batched persistent decoder kernels (forward AND reverse pass) at this shape, and its GRADIENTS are checked
+    against the fp32 build tensor by tensor (no bf16 gradient used to be compared with anything): norm within 3 %
+    and direction (cosine over the whole tensor) above 0.995 for every parameter tensor whose gradient is not rounding noise."""
     import sys
     import hparams as HP
     import model as M
@@ -139,7 +142,7 @@ def test_bf16_at_config5_shape_b16_t400():
     old = M.drop_rate
     M.drop_rate = 0.0
     try:
-        outs, losses = {}, {}
+        outs, losses, grads, kernels = {}, {}, {}, {}
         for mode in ('fp32', 'bf16'):
             hp = HP.create_hparams("batch_size=16,anneal_function=constant,p_attention_dropout=0.0,p_decoder_dropout=0.0,"
                                    "bf16_run=%s" % (mode == 'bf16'))
@@ -150,12 +153,21 @@ def test_bf16_at_config5_shape_b16_t400():
             with torch.no_grad():
                 y_pred = eng.model(x)
             outs[mode] = [t.detach().float().cpu() for t in y_pred[:4]]
+            # one forward + backward without an update: the gradient arena of this build
+            eng._publish(0)
+            eng._body_fb(x, y, 0)
+            torch.cuda.synchronize()
+            named, offs = eng.optimizer.arena_layout()
+            grads[mode] = {n: eng.optimizer.grads[o:o + p.numel()].detach().float().cpu().clone() for (n, p), o in zip(named, offs)}
+            kernels[mode] = (t2v_hip.DecoderCore.last_mode, t2v_hip.DecoderCore.last_kernel, t2v_hip.DecoderCore.last_bwd_mode,
+                             t2v_hip.DecoderCore.last_bwd_kernel)
             l0 = eng.step(batch, 0)
             l1 = eng.step(batch, 1)
             torch.cuda.synchronize()
             t2v_hip.check_async_errors()
             losses[mode] = [float(l0[0]), float(l1[0])]
             assert all(np.isfinite(losses[mode])) and float(l1[4]) > 0
+            eng.close()
             del eng
         assert outs['fp32'][0].shape == (16, 80, 400)
         d_mel = (outs['bf16'][0] - outs['fp32'][0]).abs().mean().item()
@@ -166,6 +178,35 @@ def test_bf16_at_config5_shape_b16_t400():
         assert (outs['bf16'][3] - outs['fp32'][3]).abs().max().item() < 2e-2          # alignments
         for a, b in zip(losses['bf16'], losses['fp32']):
             assert abs(a - b) < 2e-2 * abs(b)
+        # the bf16 build ran the persistent bf16 kernels in both directions, the fp32 build (B = 16 is outside its persistent
+        # range) the launch-per-step loop
+        assert kernels['bf16'] == ('persistent', 'k_dec_train_persist16', 'persistent', 'k_bwd_persist16'), kernels['bf16']
+        assert kernels['fp32'][0] == 'launch-per-step' and kernels['fp32'][2] == 'launch-per-step', kernels['fp32']
+        # gradients, tensor by tensor
+        gmax = max(v.norm().item() for v in grads['fp32'].values())
+        worst_n, worst_c = (0.0, ''), (1.0, '')
+        stats = []
+        for n, g32 in grads['fp32'].items():
+            g16 = grads['bf16'][n]
+            n32, n16 = g32.norm().item(), g16.norm().item()
+            if n32 < 1e-4 * gmax:           # (a gradient that is rounding noise in the fp32 build too)
+                continue
+            rel = abs(n16 / n32 - 1.0)
+            cos = float((g16.double() * g32.double()).sum() / (g16.double().norm() * g32.double().norm()))
+            if rel > worst_n[0]:
+                worst_n = (rel, n)
+            if cos < worst_c[0]:
+                worst_c = (cos, n)
+            stats.append((n, rel, cos))
+        print('bf16 vs fp32 gradients (B=16, T=400): worst norm deviation %.2e (%s), worst cosine %.5f (%s)'
+              % (worst_n[0], worst_n[1], worst_c[0], worst_c[1]))
+        dec = [x for x in stats if x[0].startswith('decoder.')]
+        print('   decoder tensors (the persistent bf16 kernels): worst norm deviation %.2e, worst cosine %.5f'
+              % (max(x[1] for x in dec), min(x[2] for x in dec)))
+        for n, rel, cos in stats:
+            assert rel < 3e-2, ('gradient norm', n, rel)
+            # (BatchNorm shifts of the text encoder: sums over all positions of a channel with heavy cancellation)
+            assert cos > (0.99 if '.bias' in n and 'convolutions' in n else 0.995), ('gradient direction', n, cos)
     finally:
         M.drop_rate = old
         t2v_hip.set_bf16(False)
