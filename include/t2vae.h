@@ -262,6 +262,13 @@ int t2v_decoder_bwd_persistent16(const t2v_dec_train_persist_weights* w, const t
                                  float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
                                  uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
                                  void* stream);
+/* Its preparation (error word, sentinel fills of scratch and DQP: functions of nothing but the buffers, so a training step
+ * issues it on a side stream right behind the decoder forward) as a call of its own, and the pass without it. */
+int t2v_decoder_bwd_persistent16_prepare(float* DQP, float* scratch, uint32_t* err_word, int B, int T_in, int T_out, void* stream);
+int t2v_decoder_bwd_persistent16_prepared(const t2v_dec_train_persist_weights* w, const t2v_dec_train_bufs* s, const float* dHC,
+                                          float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
+                                          uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
+                                          void* stream);
 
 /* float offset inside `scratch` of dq(t) summed over the position slices, (T_out,B,128) floats, valid when the pass has ended
  * (-1: shape outside the persistent range) */

@@ -734,10 +734,25 @@ extern "C" long t2v_decoder_bwd_persist16_dq_offset(int B, int T_in, int T_out) 
     return (long)(n[0] + n[1] + n[2] + n[3] + n[4]);
 }
 
-extern "C" int t2v_decoder_bwd_persistent16(const t2v_dec_train_persist_weights* w, const t2v_dec_train_bufs* s, const float* dHC,
-                                            float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
-                                            uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
-                                            void* stream_) {
+// The preparation of the pass (error word, sentinel fills: 1.4 MB per time step) as a call of its own: it needs nothing but the
+// buffers, so a training step issues it on a side stream right behind the decoder forward, next to the Postnet
+extern "C" int t2v_decoder_bwd_persistent16_prepare(float* DQP, float* scratch, uint32_t* err_word, int B, int T_in, int T_out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!DQP || !scratch || !err_word || !t2v_decoder_bwd_persist16_supported(B, T_in) || T_out < 1) return T2V_ERR_ARG;
+    if (((uintptr_t)scratch & 15) || ((uintptr_t)DQP & 15)) return T2V_ERR_ARG;
+    size_t n[6];
+    q16_layout(B, T_in, T_out, n);
+    const size_t n_dq = (size_t)T_out * B * q16_slices(T_in) * 128;
+    (void)hipMemsetAsync(err_word, 0, sizeof(uint32_t), stream);
+    k_q16_fill<<<2048, 256, 0, stream>>>((uint4*)scratch, (n[0] + n[1] + n[2] + n[3] + n[4] + n[5]) / 4);
+    k_q16_fill<<<256, 256, 0, stream>>>((uint4*)DQP, n_dq / 4);
+    return t2v_check_launch();
+}
+
+static int q16_run(const t2v_dec_train_persist_weights* w, const t2v_dec_train_bufs* s, const float* dHC,
+                   float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
+                   uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
+                   void* stream_, bool prepare) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!w || !s || !dHC || !DGA || !DGD || !DCTX || !DV || !DQP || !scratch || !err_word) return T2V_ERR_ARG;
     if (!t2v_decoder_bwd_persist16_supported(B, T_in) || T_out < 1) return T2V_ERR_ARG;
@@ -751,9 +766,10 @@ extern "C" int t2v_decoder_bwd_persistent16(const t2v_dec_train_persist_weights*
     for (int i = 0; i < 6; ++i)
         if (n[i] * 4 >= 0x7fffffffull) return T2V_ERR_ARG;              // 31-bit buffer offsets
     if (n_dq * 4 >= 0x7fffffffull) return T2V_ERR_ARG;
-    (void)hipMemsetAsync(err_word, 0, sizeof(uint32_t), stream);
-    k_q16_fill<<<2048, 256, 0, stream>>>((uint4*)scratch, (n[0] + n[1] + n[2] + n[3] + n[4] + n[5]) / 4);
-    k_q16_fill<<<256, 256, 0, stream>>>((uint4*)DQP, n_dq / 4);
+    if (prepare) {
+        const int rc = t2v_decoder_bwd_persistent16_prepare(DQP, scratch, err_word, B, T_in, T_out, stream_);
+        if (rc != T2V_OK) return rc;
+    }
     Q16Args a;
     a.w_ih_att = w->w_ih_att; a.w_hh_att = w->w_hh_att; a.w_ih_dec = w->w_ih_dec; a.w_hh_dec = w->w_hh_dec;
     a.wq = w->wq; a.wcomb = w->wcomb; a.v = w->v;
@@ -773,4 +789,18 @@ extern "C" int t2v_decoder_bwd_persistent16(const t2v_dec_train_persist_weights*
     a.prof = g_t2v_prof;
     k_bwd_persist16<<<T2V_NWG, Q16_THREADS, q16_lds_bytes(T_in), stream>>>(a);
     return t2v_check_launch();
+}
+
+extern "C" int t2v_decoder_bwd_persistent16(const t2v_dec_train_persist_weights* w, const t2v_dec_train_bufs* s, const float* dHC,
+                                            float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
+                                            uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
+                                            void* stream_) {
+    return q16_run(w, s, dHC, DGA, DGD, DCTX, DV, DQP, scratch, err_word, B, T_in, T_out, p_att, p_dec, seed, stream_, true);
+}
+// ... the pass without its preparation (scratch / DQP / err_word as handed to t2v_decoder_bwd_persistent16_prepare)
+extern "C" int t2v_decoder_bwd_persistent16_prepared(const t2v_dec_train_persist_weights* w, const t2v_dec_train_bufs* s, const float* dHC,
+                                                     float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
+                                                     uint32_t* err_word, int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed,
+                                                     void* stream_) {
+    return q16_run(w, s, dHC, DGA, DGD, DCTX, DV, DQP, scratch, err_word, B, T_in, T_out, p_att, p_dec, seed, stream_, false);
 }

@@ -76,7 +76,8 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_stamp', 't2v_debug_spin', 't2v_
            't2v_reparam_bwd', 't2v_gather_words', 't2v_concat2_rows',
            't2v_decoder_train_fwd_persistent16', 't2v_decoder_train_persist16_supported',
            't2v_decoder_train_persist16_scratch_floats', 't2v_decoder_bwd_persistent16', 't2v_decoder_bwd_persist16_supported',
-           't2v_decoder_bwd_persist16_scratch_floats', 't2v_decoder_bwd_persist16_dq_offset', 't2v_decoder_bwd_persist16_slices')
+           't2v_decoder_bwd_persist16_scratch_floats', 't2v_decoder_bwd_persist16_dq_offset', 't2v_decoder_bwd_persist16_slices',
+           't2v_decoder_bwd_persistent16_prepare', 't2v_decoder_bwd_persistent16_prepared')
 
 
 def lib_path():
@@ -116,6 +117,8 @@ def load_library():
     lib.t2v_decoder_train_persist16_scratch_floats.restype = C.c_long
     lib.t2v_decoder_bwd_persistent16.argtypes = [C.POINTER(_DecTrainPersistWeights), C.POINTER(_DecTrainBufs)] + [C.c_void_p] * 8 + [
         C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_void_p]
+    lib.t2v_decoder_bwd_persistent16_prepared.argtypes = lib.t2v_decoder_bwd_persistent16.argtypes
+    lib.t2v_decoder_bwd_persistent16_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.t2v_decoder_bwd_persist16_supported.argtypes = [C.c_int, C.c_int]
     lib.t2v_decoder_bwd_persist16_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.t2v_decoder_bwd_persist16_scratch_floats.restype = C.c_long
@@ -990,6 +993,19 @@ class DecoderCore(torch.autograd.Function):
             DecoderCore.last_kernel = 'k_dec_train_persist16' if p16 else 'k_dec_train_persist'
             if DecoderCore.keep_last:
                 DecoderCore.last_persist = (PW, Sb, scratch, (B, T_in, T, float(p_att), float(p_dec), int(seed)), raw)
+            if need_grad and bwd_prepare and DecoderCore.use_persistent16_bwd(lib, B, T_in, T):
+                # bf16 reverse pass: its sentinel fills (1.4 MB per time step) go out NOW, on the deferred-work stream
+                NS = lib.t2v_decoder_bwd_persist16_slices(T_in)
+                DQP = torch.empty(T, B, NS, A, **f32)
+                bscr = torch.empty(lib.t2v_decoder_bwd_persist16_scratch_floats(B, T_in, T), **f32)
+                errw = torch.zeros(1, device=gpre.device, dtype=torch.int32)
+                with side('w', keep=(XS,)):
+                    _check(lib.t2v_decoder_bwd_persistent16_prepare(_p(DQP), _p(bscr), _p(errw), B, T_in, T, _stream()),
+                           't2v_decoder_bwd_persistent16_prepare')
+                    ev = torch.cuda.Event()
+                    ev.record()
+                prep = (DQP, bscr, errw, ev, torch.cuda.current_stream())
+                return W, Sb, (gpre, memory, pm, lengths, XS, CA, CD, GA, GD, QP, AL, ACUM, S), prep
             if need_grad and bwd_prepare and DecoderCore.use_persistent_bwd(lib, B, T_in, T):
                 # the preparation of the reverse pass (sentinel fills, factor arrays of both cells: ~150 us of launches that
                 # need nothing but this forward pass) goes out NOW, on the deferred-work stream, next to the Postnet
@@ -1130,11 +1146,19 @@ class DecoderCore(torch.autograd.Function):
                 w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, wq_raw = ctx.raw
                 PW = _DecTrainPersistWeights(_p(w_ih_att), _p(w_hh_att), _p(w_ih_dec), _p(w_hh_dec), _p(bias_dec), _p(wq_raw),
                                              _p(wcomb), _p(vv))
-                DQP = torch.empty(T, B, NS, A, **f32)
-                scratch = torch.empty(lib.t2v_decoder_bwd_persist16_scratch_floats(B, T_in, T), **f32)
-                errw = torch.zeros(1, device=dev, dtype=torch.int32)
+                prep, ctx.prepared[ci] = ctx.prepared[ci], None
+                if prep is not None:
+                    DQP, scratch, errw, pev, pst = prep
+                    if pst != torch.cuda.current_stream():
+                        torch.cuda.current_stream().wait_event(pev)
+                    run16 = lib.t2v_decoder_bwd_persistent16_prepared
+                else:
+                    DQP = torch.empty(T, B, NS, A, **f32)
+                    scratch = torch.empty(lib.t2v_decoder_bwd_persist16_scratch_floats(B, T_in, T), **f32)
+                    errw = torch.zeros(1, device=dev, dtype=torch.int32)
+                    run16 = lib.t2v_decoder_bwd_persistent16
                 stamp('dec_bwd_begin')
-                _check(lib.t2v_decoder_bwd_persistent16(C.byref(PW), C.byref(Sb), _p(dhc_c), _p(DGA), _p(DGD), _p(DCTX), _p(DV), _p(DQP),
+                _check(run16(C.byref(PW), C.byref(Sb), _p(dhc_c), _p(DGA), _p(DGD), _p(DCTX), _p(DV), _p(DQP),
                                                         _p(scratch), _p(errw), B, T_in, T, p_att, p_dec,
                                                         (seed + 7919 * b0) & 0x7FFFFFFFFFFFFFFF, _stream()), 't2v_decoder_bwd_persistent16')
                 split_d = False
