@@ -15,7 +15,7 @@ mkdir -p $REPO/gpurun_out
 python - "$F" "$EXTRA" > $REPO/gpurun_out/${TAG}_pmc_mfma$SUF.json <<'PY'
 import csv, sys, json, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-keys = ('k_gemm_f32_big', 'k_gemm_bf16_big', 'k_gemm_f32', 'k_gemm_bf16', 'k_conv5_fwd_bf16', 'k_conv5_fwd', 'k_conv5_dw', 'k_lstm_bwd256', 'k_lstm_fwd256',
+keys = ('k_bwd_persist16', 'k_dec_train_persist16', 'k_gemm_f32_big', 'k_gemm_bf16_big', 'k_gemm_f32', 'k_gemm_bf16', 'k_conv5_fwd_bf16', 'k_conv5_fwd', 'k_conv5_dw', 'k_lstm_bwd256', 'k_lstm_fwd256',
         'k_dec_train_persist', 'k_achain_bwd', 'k_attn_cell_bwd', 'k_bilstm_fwd', 'k_bilstm_bwd', 'Cijk')
 for r in csv.DictReader(open(sys.argv[1])):
     n = r['Kernel_Name']
