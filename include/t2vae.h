@@ -381,7 +381,8 @@ int t2v_conv1d_flip_weights(const float* const* W, float* const* Wt, const int* 
                             void* stream);
 /* bf16_run variants (BASELINE configs[4]; replace the reference's fp16 path, fp16_optimizer.py / loss_scaler.py):
  * fp32 tensors in and out, operands rounded to bf16 on the way into LDS, fp32 accumulation on bf16 MFMA.
- * Wp_scratch: W's element count x 2 bytes.  Forward and data gradient only (dW is computed by the fp32 kernel);
+ * Wp_scratch: W's element count x 2 bytes.  Round 5: the weight gradient as well (dY and X rounded to bf16 while staged,
+ * v_mfma_f32_16x16x16_bf16; W and Wp_scratch are not needed for a dW-only call, dw_scratch as t2v_conv1d_dw_scratch_floats);
  * T2V_ERR_DIMS unless KS == 5 and the reduction channel count is a multiple of 16. */
 int t2v_conv1d_fwd_bf16(const float* W, const float* X, const float* bias, float* Y, float* stat_part,
                         void* Wp_scratch, int B, int Cin, int T, int Cout, int KS, void* stream);

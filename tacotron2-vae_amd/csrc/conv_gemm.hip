@@ -634,6 +634,129 @@ __global__ __launch_bounds__(256) void k_conv5_fwd_bf16(ConvBf16Args a) {
     }
 }
 
+// bf16 weight gradient (round 5; hparams bf16_run): the tile of k_conv5_dw — 64 rows m x 16 channels (80 columns n = 5c + kx),
+// K over (utterance, BT positions) — on v_mfma_f32_16x16x16_bf16 (16 positions per MFMA instead of 4).  dY and X are rounded
+// to bf16 (RNE) on their way into LDS, products accumulate in fp32.  Both operands are K-major in memory already ((B, C, T):
+// positions contiguous), so nothing is transposed while staging: a dY float4 becomes one 8-byte LDS store, and an MFMA operand
+// is one ds_read_b64.  The tap shift would misalign the B reads (4 bf16 from position 4x + kx): X is staged as FOUR copies,
+// copy r holding x[p + r] at index p, so tap kx reads copy kx & 3 at an 8-byte-aligned index.
+template <int BT>
+__global__ __launch_bounds__(256) void k_conv5_dw_bf16(ConvTiledArgs a) {
+    constexpr int RS = BT + 8;                           // As row stride (bf16): 44 / 52 words -> 16 rows x 2 k-groups in disjoint bank pairs
+    constexpr int XL = BT + 8;                           // staged positions per channel and copy
+    constexpr int NA = BT / 16;                          // float4 of dY per thread (64 rows x BT / 4 / 256)
+    constexpr int NQ = XL / 4;                           // 4-position groups per channel
+    constexpr int NXI = (16 * NQ + 255) / 256;           // (channel, group) items per thread
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][64][RS];
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[2][4][16][XL];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int kq = lane >> 4, j = lane & 15;
+    const int c0 = blockIdx.x * 16, m0 = blockIdx.y * CT_BM;
+    const int CK = a.Cin * 5;
+    const int tiles = (a.T + BT - 1) / BT, nkt_all = a.B * tiles;
+    const int per = (nkt_all + gridDim.z - 1) / gridDim.z;
+    const int kt_lo = blockIdx.z * per, kt_hi = min(nkt_all, kt_lo + per);
+    const bool vec = (a.T & 3) == 0;
+
+    float4 ra[NA];
+    float rx[NXI][7];
+    const int a_m = tid & 63;
+    const bool a_ok = m0 + a_m < a.M;
+    auto load_tiles = [&](int kt) {
+        const int bb = kt / tiles, t0 = (kt - bb * tiles) * BT;
+        const float* arow = a.dY + ((size_t)bb * a.M + (a_ok ? m0 + a_m : 0)) * a.T;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int t = t0 + 4 * ((tid >> 6) + 4 * i);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_ok) {
+                if (vec) {
+                    if (t < a.T) v = *(const float4*)(arow + t);
+                } else {
+                    if (t < a.T) v.x = arow[t];
+                    if (t + 1 < a.T) v.y = arow[t + 1];
+                    if (t + 2 < a.T) v.z = arow[t + 2];
+                    if (t + 3 < a.T) v.w = arow[t + 3];
+                }
+            }
+            ra[i] = v;
+        }
+        const float* x_item = a.X + ((size_t)bb * a.Cin + c0) * a.T;
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+            const int e = tid + 256 * i;
+            const int c = min(e / NQ, 15), q = e - (e / NQ) * NQ;
+            const float* xr = x_item + (size_t)c * a.T;
+#pragma unroll
+            for (int d = 0; d < 7; ++d) {
+                const int pz = 4 * q + d, t = t0 - 2 + pz;           // staged position pz <-> time t0 - 2 + pz (2-halo)
+                const bool ok = e < 16 * NQ && pz < BT + 4 && t >= 0 && t < a.T;
+                const float v = xr[min(max(t, 0), a.T - 1)];
+                rx[i][d] = ok ? v : 0.f;
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int k = 4 * ((tid >> 6) + 4 * i);
+            *(uint2*)&As[buf][a_m][k] = make_uint2(pack_bf16x2(ra[i].x, ra[i].y), pack_bf16x2(ra[i].z, ra[i].w));
+        }
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+            const int e = tid + 256 * i;
+            const int c = e / NQ, q = e - c * NQ;
+            if (c < 16) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *(uint2*)&Xs[buf][r][c][4 * q] = make_uint2(pack_bf16x2(rx[i][r], rx[i][r + 1]), pack_bf16x2(rx[i][r + 2], rx[i][r + 3]));
+            }
+        }
+    };
+
+    // column n = 16*nt + j of the 80-wide tile -> (channel, tap); B operand of k-step s: copy kx & 3, positions 16 s + 4 kq + (kx & 4)
+    int boff[5];
+#pragma unroll
+    for (int n = 0; n < 5; ++n) {
+        const int nl = 16 * n + j, c = nl / 5, kx = nl - 5 * c;
+        boff[n] = ((kx & 3) * 16 + c) * XL + 4 * kq + (kx & 4);
+    }
+    f32x4 acc[5];
+#pragma unroll
+    for (int n = 0; n < 5; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (kt_lo < kt_hi) {
+        load_tiles(kt_lo);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+        const int buf = (kt - kt_lo) & 1;
+        if (kt + 1 < kt_hi) load_tiles(kt + 1);
+        const unsigned short* ap = &As[buf][16 * wave + j][4 * kq];
+        const unsigned short* xp = &Xs[buf][0][0][0];
+#pragma unroll
+        for (int s = 0; s < BT / 16; ++s) {
+            const s16x4 av = *(const s16x4*)(ap + 16 * s);
+#pragma unroll
+            for (int n = 0; n < 5; ++n) {
+                const s16x4 bv = *(const s16x4*)(xp + boff[n] + 16 * s);
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bv, acc[n], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < kt_hi) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 16 * wave + 4 * kq + r;
+        if (m < a.M) {
+            float* drow = a.Y + (size_t)blockIdx.z * a.M * CK + (size_t)m * CK + 5 * c0;   // split partials are stacked
+#pragma unroll
+            for (int n = 0; n < 5; ++n) drow[16 * n + j] = acc[n][r];
+        }
+    }
+}
+
 // Output positions per workgroup (BN = 32/48/64/80/96).  Cost model: workgroups run in rounds of one per CU; a
 // workgroup's time per k-tile is its MFMA work (~BN) plus the fixed staging cost (~40 in the same units).  Small
 // problems (encoder bank: 6 x 84 positions; 80-row layers) therefore take narrow tiles — more workgroups in the one
@@ -833,6 +956,7 @@ extern "C" int t2v_conv1d_dw_scratch_floats(int B, int Cin, int T, int Cout, int
     return ns > 1 ? ns * Cout * Cin * 5 : 0;
 }
 
+static thread_local bool g_conv_dw_bf16 = false;     // set by t2v_conv1d_bwd_bf16 around its call of t2v_conv1d_bwd (weight gradient on bf16 MFMA)
 extern "C" int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, float* dX, float* dW, float* Wt_scratch,
                               float* dw_scratch, int B, int Cin, int T, int Cout, int KS, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -855,6 +979,7 @@ extern "C" int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, f
         }
     }
     if (dW && conv5_tiled_ok(Cin, KS)) {
+        const bool dw_bf16 = g_conv_dw_bf16;
         ConvTiledArgs a;
         a.W = nullptr; a.X = X; a.dY = dY; a.bias = nullptr; a.Y = dW; a.stat_part = nullptr;
         a.B = B; a.Cin = Cin; a.T = T; a.M = Cout; a.tiles_per_item = 0;
@@ -864,7 +989,10 @@ extern "C" int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, f
         if (ns > 1) a.Y = dw_scratch;
         dim3 grid(Cin / 16, (Cout + CT_BM - 1) / CT_BM, ns);
         const int c80 = ((T + 79) / 80) * 80, c96 = ((T + 95) / 96) * 96;
-        if (c80 <= c96) k_conv5_dw<80><<<grid, 256, 0, stream>>>(a);
+        if (dw_bf16) {
+            if (c80 <= c96) k_conv5_dw_bf16<80><<<grid, 256, 0, stream>>>(a);
+            else k_conv5_dw_bf16<96><<<grid, 256, 0, stream>>>(a);
+        } else if (c80 <= c96) k_conv5_dw<80><<<grid, 256, 0, stream>>>(a);
         else k_conv5_dw<96><<<grid, 256, 0, stream>>>(a);
         if (ns > 1) {
             const int n = Cout * Cin * 5;
@@ -898,12 +1026,17 @@ extern "C" int t2v_conv1d_bwd_bf16(const float* W, const float* X, const float* 
                                    void* Wp_scratch, float* dw_scratch, int B, int Cin, int T, int Cout, int KS,
                                    void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!W || !X || !dY || B < 1 || Cin < 1 || T < 1 || Cout < 1) return T2V_ERR_ARG;
-    if (!conv5_tiled_ok(Cin, KS) || !conv5_tiled_ok(Cout, KS)) return T2V_ERR_DIMS;
+    if (!X || !dY || B < 1 || Cin < 1 || T < 1 || Cout < 1) return T2V_ERR_ARG;
+    if (!conv5_tiled_ok(Cin, KS) || (dX && !conv5_tiled_ok(Cout, KS))) return T2V_ERR_DIMS;
     if (dX) {
-        if (!Wp_scratch) return T2V_ERR_ARG;
+        if (!W || !Wp_scratch) return T2V_ERR_ARG;
         launch_conv5_fwd_bf16(W, 1, (unsigned short*)Wp_scratch, dY, nullptr, dX, nullptr, B, Cout, T, Cin, Cout, Cin, stream);
     }
-    if (dW) return t2v_conv1d_bwd(W, X, dY, nullptr, dW, nullptr, dw_scratch, B, Cin, T, Cout, KS, stream_);
+    if (dW) {           // (round 5) the weight gradient on bf16 MFMA as well: same tiling / K-splits as the fp32 kernel
+        g_conv_dw_bf16 = true;
+        const int rc = t2v_conv1d_bwd(W, X, dY, nullptr, dW, nullptr, dw_scratch, B, Cin, T, Cout, KS, stream_);
+        g_conv_dw_bf16 = false;
+        return rc;
+    }
     return t2v_check_launch();
 }

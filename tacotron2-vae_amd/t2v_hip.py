@@ -1594,8 +1594,13 @@ class ConvBNAct1d(torch.autograd.Function):
             dw = torch.empty_like(w) if dw is None else dw
             nscr = lib.t2v_conv1d_dw_scratch_floats(B, Cin, T, Cout, KS)
             scr = torch.empty(nscr, **f32) if nscr else None
-            _check(lib.t2v_conv1d_bwd(None, _p(x), _p(dy), None, _p(dw), None, _p(scr), B, Cin, T, Cout, KS,
-                                      _stream()), 't2v_conv1d_bwd')
+            if _BF16 and KS == 5 and Cin % 16 == 0 and os.environ.get('T2V_CONV_DW_BF16', '1') != '0':
+                # (round 5) bf16_run: the weight gradient on bf16 MFMA too (dY, X rounded while staged; fp32 accumulation)
+                _check(lib.t2v_conv1d_bwd_bf16(None, _p(x), _p(dy), None, _p(dw), None, _p(scr), B, Cin, T, Cout, KS,
+                                               _stream()), 't2v_conv1d_bwd_bf16')
+            else:
+                _check(lib.t2v_conv1d_bwd(None, _p(x), _p(dy), None, _p(dw), None, _p(scr), B, Cin, T, Cout, KS,
+                                          _stream()), 't2v_conv1d_bwd')
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 

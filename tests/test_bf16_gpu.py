@@ -76,6 +76,39 @@ def test_conv_bf16_forward_and_data_gradient(bf16_mode, B, Cin, Cout, T):
     assert (gw.grad.cpu() - w32.grad).abs().max().item() < 3e-2 * sw
 
 
+@pytest.mark.parametrize("B,Cin,Cout,T", [(16, 512, 512, 400), (6, 512, 80, 400), (6, 80, 512, 400), (3, 512, 256, 37), (2, 128, 512, 85),
+                                          (1, 16, 64, 7)])
+def test_conv_bf16_weight_gradient(B, Cin, Cout, T):
+    """Round 5: the k = 5 Conv1d weight gradient on bf16 MFMA (k_conv5_dw_bf16: dY and X rounded to bf16 while staged, fp32
+    accumulation, the four shifted copies of X that keep the tap-shifted operand reads aligned) against the same contraction
+    of the ROUNDED operands in fp64 — incl. the 80-channel Postnet ends, a partial row tile, ragged T and the K-split launches."""
+    import ctypes as C
+    import t2v_hip
+    lib = t2v_hip.load_library()
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    dy = torch.randn(B, Cout, T, generator=g)
+    xr, dyr = x.bfloat16().double(), dy.bfloat16().double()
+    xp = F.pad(xr, (2, 2))
+    want = torch.stack([torch.einsum('bmt,bct->mc', dyr, xp[:, :, k:k + T]) for k in range(5)], dim=2)       # (Cout, Cin, 5)
+    gx, gdy = x.cuda(), dy.cuda()
+    dw = torch.full((Cout, Cin, 5), float('nan'), device='cuda')
+    nscr = lib.t2v_conv1d_dw_scratch_floats(B, Cin, T, Cout, 5)
+    scr = torch.empty(max(nscr, 1), device='cuda')
+    rc = lib.t2v_conv1d_bwd_bf16(None, C.c_void_p(gx.data_ptr()), C.c_void_p(gdy.data_ptr()), None, C.c_void_p(dw.data_ptr()), None,
+                                 C.c_void_p(scr.data_ptr()), B, Cin, T, Cout, 5, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = dw.cpu().double()
+    assert not torch.isnan(got).any()
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() < 2e-5 * scale + 1e-4 * (B * T) ** 0.5 * 1e-2, ((got - want).abs().max().item(), scale)
+    # ... and within bf16 rounding of the unrounded contraction (what the fp32 kernel computes)
+    xp32 = F.pad(x.double(), (2, 2))
+    full = torch.stack([torch.einsum('bmt,bct->mc', dy.double(), xp32[:, :, k:k + T]) for k in range(5)], dim=2)
+    assert (got - full).abs().max().item() < 3e-2 * full.abs().max().item()
+
+
 def test_model_bf16_vs_fp32_build(golden_dir):
     """The golden batch through the fp32 build and the bf16 build (same weights, dropout off, same epsilon)."""
     import hparams as HP
