@@ -771,12 +771,21 @@ __global__ void k_conv5_dw_reduce(const float* __restrict__ part, float* __restr
 }
 
 // K-splits of the weight gradient: only when the (row tile, channel block) grid is far from filling the chip
-static inline int conv5_dw_splits(int B, int Cin, int T, int Cout) {
+// Round 5: with ONE workgroup per CU every k-tile waits for its own global loads (one tile of prefetch); cut along K until several
+// workgroups share a CU, the launch alone runs 512->512 at B = 6, T = 400 in 83 instead of 107 us (fp32) and 62 instead of 100 us
+// (bf16 tiles), at B = 16 in 208 / 137 instead of 286 / 265 us (tools/dbg/conv_dw_time.py).  INSIDE the step it pays only for
+// the bf16 kernel (bf16 B = 16 step 13.84 -> 13.78 ms): behind the reverse pass four streams share the chip and already fill each
+// other's stalls — the fp32 step got 0.06 ms SLOWER with the extra workgroups and reduce launches (same-box A/B against the
+// round-4 tree), so the fp32 kernel keeps its rule (split only while the launch does not fill the chip)
+static inline int conv5_dw_splits(int B, int Cin, int T, int Cout, bool bf16 = false) {
     const int wgs = (Cin / 16) * ((Cout + CT_BM - 1) / CT_BM);
     const int c80 = ((T + 79) / 80), c96 = ((T + 95) / 96);
     const int nkt = B * (c80 * 80 <= c96 * 96 ? c80 : c96);
+    // (T2V_CONV_DW_SPLITS = target workgroups per launch, measurement override)
+    static const int want_env = getenv("T2V_CONV_DW_SPLITS") ? atoi(getenv("T2V_CONV_DW_SPLITS")) : 0;
+    const int want = want_env > 0 ? want_env : (bf16 ? 8 * T2V_NWG : T2V_NWG);
     int ns = 1;
-    while (wgs * ns * 2 <= T2V_NWG && ns * 2 <= nkt && ns < 8) ns *= 2;
+    while (wgs * ns * 2 <= want && ns * 2 <= nkt && ns < 8) ns *= 2;
     return ns;
 }
 
@@ -952,7 +961,7 @@ extern "C" int t2v_conv1d_stat_blocks(int B, int T, int Cin, int Cout, int KS) {
 
 extern "C" int t2v_conv1d_dw_scratch_floats(int B, int Cin, int T, int Cout, int KS) {
     if (!conv5_tiled_ok(Cin, KS)) return 0;
-    const int ns = conv5_dw_splits(B, Cin, T, Cout);
+    const int ns = conv5_dw_splits(B, Cin, T, Cout, true);        // (the bf16 kernel splits at least as far as the fp32 one)
     return ns > 1 ? ns * Cout * Cin * 5 : 0;
 }
 
@@ -984,7 +993,7 @@ extern "C" int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, f
         a.W = nullptr; a.X = X; a.dY = dY; a.bias = nullptr; a.Y = dW; a.stat_part = nullptr;
         a.B = B; a.Cin = Cin; a.T = T; a.M = Cout; a.tiles_per_item = 0;
         a.prof = nullptr; a.ks_part = nullptr; a.ks_ctr = nullptr;
-        const int ns = conv5_dw_splits(B, Cin, T, Cout);
+        const int ns = conv5_dw_splits(B, Cin, T, Cout, dw_bf16);
         if (ns > 1 && !dw_scratch) return T2V_ERR_ARG;
         if (ns > 1) a.Y = dw_scratch;
         dim3 grid(Cin / 16, (Cout + CT_BM - 1) / CT_BM, ns);
