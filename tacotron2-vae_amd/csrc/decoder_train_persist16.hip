@@ -30,7 +30,11 @@
 // decoder_rnn(t-1) finishes behind the same barrier, everything else (h_att / h_dec parts of both products) runs in the shadow
 // of attention(t).  Writes the same arena as the launch-per-step loop (XS, CA, CD, GA, GD, AL, ACUM, S), same counter-based
 // dropout masks: either backward runs on it.
-#include <stdlib.h>
+//
+// Measured on the way (same-box A/B through a run-time switch, B = 16, T_in = 84, T = 400; none kept): TWO polls in flight on
+// the ctx / h_att hand-offs 9.63 -> 10.2 / 9.9 us per step (the polling traffic is what stretches a look's round trip to ~1 us);
+// re-polling only the k-blocks that are still missing 9.63 -> 9.65; partial energies as 16-byte stores + 16-byte polls through
+// an LDS transpose 9.51 -> 9.63 (the extra barrier costs more than the narrower stores); a gentler nap rule: no change.
 #include "t2v_common.h"
 #include "t2v_kernels.h"
 
@@ -58,8 +62,6 @@ struct P16Args {
     uint64_t seed;
     const t2v_step_params* step;
     unsigned long long* prof;
-    int flags;                // measurement switches (env T2V_P16_FLAGS): bit 0 two ctx polls in flight, bit 1 two h_att polls in flight
-                              // (attention slices), bit 2 the gentler nap rule
 };
 #define P16_STAMP(COND, I) do { if (a.prof && (COND) && (threadIdx.x & 63) == 0) a.prof[(I)] = __builtin_readcyclecounter(); } while (0)
 #define P16_WALL(COND, I) do { if (a.prof && (COND) && (threadIdx.x & 63) == 0) a.prof[(I)] = wall_clock64(); } while (0)
@@ -95,15 +97,6 @@ __device__ __forceinline__ f32x4 p16_mfma(p16_u32x4 w, p16_u32x4 x, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(t2v_bf16x8, w), __builtin_bit_cast(t2v_bf16x8, x), c, 0, 0, 0);
 }
 
-// nap ahead of a polled hand-off (s_sleep units of 64 clocks): aims at ONE failed look — a failed round costs a whole memory
-// round trip (~1 us under load), so the nap may only grow while looks keep failing more than once, and gives back a quarter
-// as soon as the data was there at the first look
-__device__ __forceinline__ int p16_adapt_nap(int nap, int rounds) {
-    if (rounds > 1) return min(160, nap + 4 * min(rounds - 1, 4));
-    if (rounds == 0) return (3 * nap) >> 2;
-    return nap;
-}
-
 // Poll N consecutive k-blocks of one GH row straight into MFMA B operands.  off = row + kb0 * 1024 + 16 * lane.  A lane
 // whose item does not exist (live == false) never waits and reads zeros.  Wave-uniform loop; returns the failed rounds.
 template <int N>
@@ -119,80 +112,6 @@ __device__ __forceinline__ int p16_poll(p16_u32x4 (&x)[N], __amdgpu_buffer_rsrc_
         for (int i = 0; i < N; ++i) ok = ok && p16_ok4(x[i]);
         if (__all(ok || !live)) break;
         __builtin_amdgcn_s_sleep(2);
-        if (++rounds > (int)(P16_SPIN / 4) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = 0;
-            break;
-        }
-    }
-    if (!live) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) x[i] = p16_u32x4{0u, 0u, 0u, 0u};
-    }
-    return rounds;
-}
-
-// The same, but a k-block that has arrived is not fetched again: a failed look re-polls only the blocks whose producers are
-// still missing, so the stragglers' wait costs a fraction of the row's fabric traffic (every failed look of p16_poll
-// re-fetches all N KB; a look takes ~1 us of round trip under load, and that round trip grows with the polling traffic).
-template <int N>
-__device__ __forceinline__ int p16_poll_sel(p16_u32x4 (&x)[N], __amdgpu_buffer_rsrc_t rG, unsigned off, bool live, int nap,
-                                            unsigned* err, int* flag) {
-    for (int i = 0; i < nap; i += 8) __builtin_amdgcn_s_sleep(8);
-    int rounds = 0;
-    unsigned pending = (1u << N) - 1u;           // wave-uniform
-    for (;;) {
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-            if (pending & (1u << i)) x[i] = p16_ld16(rG, off + 1024u * (unsigned)i);
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-            if ((pending & (1u << i)) && __all(p16_ok4(x[i]) || !live)) pending &= ~(1u << i);
-        if (!pending) break;
-        __builtin_amdgcn_s_sleep(2);
-        if (++rounds > (int)(P16_SPIN / 4) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = 0;
-            break;
-        }
-    }
-    if (!live) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) x[i] = p16_u32x4{0u, 0u, 0u, 0u};
-    }
-    return rounds;
-}
-
-// The same with TWO polls in flight, `gap` sleep units apart: a row that lands just after a poll left is otherwise only seen a
-// full memory round trip (~1 us under load) later — for the hand-offs that sit on the chain of every step.
-template <int N>
-__device__ __forceinline__ int p16_poll2(p16_u32x4 (&x)[N], __amdgpu_buffer_rsrc_t rG, unsigned off, bool live, int nap, int gap,
-                                         unsigned* err, int* flag) {
-    for (int i = 0; i < nap; i += 8) __builtin_amdgcn_s_sleep(8);
-    p16_u32x4 y[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = p16_ld16(rG, off + 1024u * (unsigned)i);
-    for (int i = 0; i < gap; i += 4) __builtin_amdgcn_s_sleep(4);
-#pragma unroll
-    for (int i = 0; i < N; ++i) y[i] = p16_ld16(rG, off + 1024u * (unsigned)i);
-    int rounds = 0;
-    for (;;) {
-        bool ok = true;
-#pragma unroll
-        for (int i = 0; i < N; ++i) ok = ok && p16_ok4(x[i]);
-        if (__all(ok || !live)) break;
-#pragma unroll
-        for (int i = 0; i < N; ++i) x[i] = p16_ld16(rG, off + 1024u * (unsigned)i);
-        ok = true;
-#pragma unroll
-        for (int i = 0; i < N; ++i) ok = ok && p16_ok4(y[i]);
-        if (__all(ok || !live)) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) x[i] = y[i];
-            break;
-        }
-#pragma unroll
-        for (int i = 0; i < N; ++i) y[i] = p16_ld16(rG, off + 1024u * (unsigned)i);
         if (++rounds > (int)(P16_SPIN / 4) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
             __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *flag = 0;
@@ -371,9 +290,8 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
             // h_dec(t-1) -> decoder_rnn(t); ctx(t) last (the chain)
             {
                 p16_u32x4 xh[4];
-                const int rounds = (a.flags & 8) ? p16_poll_sel<4>(xh, rG, grow + off_h, live, nap_h, a.err, flag)
-                                                 : p16_poll<4>(xh, rG, grow + off_h, live, nap_h, a.err, flag);
-                nap_h = (a.flags & 4) ? p16_adapt_nap(nap_h, rounds) : t2v_adapt_nap(nap_h, rounds);
+                const int rounds = p16_poll<4>(xh, rG, grow + off_h, live, nap_h, a.err, flag);
+                nap_h = t2v_adapt_nap(nap_h, rounds);
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accD = {0.f, 0.f, 0.f, 0.f};
@@ -390,8 +308,7 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
             P16_RT(3);
             if (t >= 1) {
                 p16_u32x4 xd[4];
-                if (a.flags & 8) p16_poll_sel<4>(xd, rG, grow + off_d, live, 0, a.err, flag);
-                else p16_poll<4>(xd, rG, grow + off_d, live, 0, a.err, flag);
+                p16_poll<4>(xd, rG, grow + off_d, live, 0, a.err, flag);
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -400,10 +317,8 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
             P16_STAMP(wg == P16_L0 && wave == 0 && t == T / 2, 5);
             P16_RT(4);
             {
-                const int rounds = (a.flags & 1) ? p16_poll2<2>(xc, rG, grow + off_c, live, nap_c, 8, a.err, flag)
-                                 : (a.flags & 8) ? p16_poll_sel<2>(xc, rG, grow + off_c, live, nap_c, a.err, flag)
-                                                 : p16_poll<2>(xc, rG, grow + off_c, live, nap_c, a.err, flag);
-                nap_c = (a.flags & 4) ? p16_adapt_nap(nap_c, rounds) : t2v_adapt_nap(nap_c, rounds);
+                const int rounds = p16_poll<2>(xc, rG, grow + off_c, live, nap_c, a.err, flag);
+                nap_c = t2v_adapt_nap(nap_c, rounds);
                 if (a.prof && t == T / 2 && tid == 0) { a.prof[64 + wg * 8 + 6] = (unsigned long long)rounds; a.prof[64 + wg * 8 + 7] = (unsigned long long)nap_c; }
             }
             P16_RT(5);
@@ -484,26 +399,18 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
             const unsigned s0 = (unsigned)t * (unsigned)P16_HROW + (unsigned)(ab * T2V_H + 4 * tid) * 4u;
             p16_u32x4 v;
             for (int i = 0; i < h_nap; i += 8) __builtin_amdgcn_s_sleep(8);
-            const bool two = a.flags & 2;
-            p16_u32x4 v0 = p16_ld16(rH, s0);
-            if (two) __builtin_amdgcn_s_sleep(8);
-            p16_u32x4 v1 = p16_ld16(rH, s0);
             int rounds = 0;
-            for (;;) {          // (two polls in flight, half a round trip apart)
-                if (__all(p16_ok4(v0))) { v = v0; break; }
-                if (two) v0 = p16_ld16(rH, s0);
-                if (__all(p16_ok4(v1))) { v = v1; break; }
-                if (!two) __builtin_amdgcn_s_sleep(1);
-                v1 = p16_ld16(rH, s0);
-                if (!two) v0 = v1;
+            for (;;) {
+                v = p16_ld16(rH, s0);
+                if (__all(p16_ok4(v))) break;
+                __builtin_amdgcn_s_sleep(1);
                 if (++rounds > (int)(P16_SPIN / 4) || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     flag[0] = 0;
-                    v = v0;
                     break;
                 }
             }
-            h_nap = (a.flags & 4) ? p16_adapt_nap(h_nap, rounds) : t2v_adapt_nap(h_nap, rounds);
+            h_nap = t2v_adapt_nap(h_nap, rounds);
             P16_WALL(wg == 0 && wave == 0 && t == T / 2, 21);
             P16_RT(1);
             if (a.prof && t == T / 2 && tid == 0) { a.prof[64 + wg * 8 + 6] = (unsigned long long)rounds; a.prof[64 + wg * 8 + 7] = (unsigned long long)h_nap; }
@@ -736,10 +643,6 @@ extern "C" int t2v_decoder_train_fwd_persistent16(const t2v_dec_train_persist_we
     a.B = B; a.T_in = T_in; a.T_out = T_out; a.p_att = p_att; a.p_dec = p_dec; a.seed = seed;
     a.step = t2v_step_for(stream);
     a.prof = g_t2v_prof;
-    {
-        static const int fl = getenv("T2V_P16_FLAGS") ? atoi(getenv("T2V_P16_FLAGS")) : 0;
-        a.flags = fl;
-    }
     k_dec_train_persist16<<<T2V_NWG, P16_THREADS, p16_lds_bytes(T_in), stream>>>(a);
     return t2v_check_launch();
 }
