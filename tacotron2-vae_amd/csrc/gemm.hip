@@ -473,6 +473,10 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
 #define GBB_BM 128
 #define GBB_BN 128
 #define GBB_BK 32
+// Round 5: an operand may also be k-contiguous (A_KC / B_KC: activations stored (rows, K) row-major — the Prenet output in
+// front of the hoisted attention_rnn input term, the gate gradients in front of the Prenet data gradient); its staging
+// threads then run along k (4 lanes cover 32 consecutive k of a row: 128 contiguous bytes) and read two float4 per row.
+template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void k_gemm_bf16_big_rr(GemmArgs a) {
     __shared__ uint4 As[2][GBB_BK / 8][GBB_BM];
     __shared__ uint4 Bs[2][GBB_BK / 8][GBB_BN];
@@ -480,21 +484,41 @@ __global__ __launch_bounds__(256) void k_gemm_bf16_big_rr(GemmArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int i0 = blockIdx.y * GBB_BM, j0 = blockIdx.x * GBB_BN;
     const bool isB = tid >= 128;
-    const int t7 = tid & 127, r4 = t7 & 31, kg = t7 >> 5;
+    const bool kc = isB ? B_KC : A_KC;                  // wave-uniform (waves 0, 1 stage A, waves 2, 3 stage B)
+    const int t7 = tid & 127;
+    const int r4 = kc ? t7 >> 2 : t7 & 31, kg = kc ? t7 & 3 : t7 >> 5;
     const float* P = isB ? a.B : a.A;
-    const long sk = isB ? a.sBk : a.sAk;
+    const long sk = isB ? a.sBk : a.sAk, si = isB ? a.sBj : a.sAi;
     const int lim = isB ? a.N : a.M, row0 = min((isB ? j0 : i0) + 4 * r4, lim - 4);
     const float z_row = (isB ? j0 : i0) + 4 * r4 < lim ? 1.f : 0.f;      // M, N are multiples of 4: a row quad is all in or all out
     float4 rg[8];
     auto load_tiles = [&](int k0) {
+        if (kc) {           // rows row0 .. row0 + 3, k = k0 + 8 kg .. + 7 (K is a multiple of 32 on this path)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) rg[u] = *(const float4*)(P + (long)min(k0 + 8 * kg + u, a.K - 1) * sk + row0);
+            for (int rr = 0; rr < 4; ++rr) {
+                const float* q = P + (long)(row0 + rr) * si + k0 + 8 * kg;
+                rg[2 * rr] = *(const float4*)q;
+                rg[2 * rr + 1] = *(const float4*)(q + 4);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rg[u] = *(const float4*)(P + (long)min(k0 + 8 * kg + u, a.K - 1) * sk + row0);
+        }
     };
     auto store_tiles = [&](int buf, int k0) {
+        uint4* dst = (isB ? &Bs[buf][kg][0] : &As[buf][kg][0]) + 4 * r4;
+        if (kc) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float4 lo = rg[2 * rr], hi = rg[2 * rr + 1];
+                dst[rr] = make_uint4(gemm_pack_bf16x2(lo.x * z_row, lo.y * z_row), gemm_pack_bf16x2(lo.z * z_row, lo.w * z_row),
+                                     gemm_pack_bf16x2(hi.x * z_row, hi.y * z_row), gemm_pack_bf16x2(hi.z * z_row, hi.w * z_row));
+            }
+            return;
+        }
         float zk[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) zk[u] = (k0 + 8 * kg + u < a.K ? 1.f : 0.f) * z_row;
-        uint4* dst = (isB ? &Bs[buf][kg][0] : &As[buf][kg][0]) + 4 * r4;
         dst[0] = make_uint4(gemm_pack_bf16x2(rg[0].x * zk[0], rg[1].x * zk[1]), gemm_pack_bf16x2(rg[2].x * zk[2], rg[3].x * zk[3]),
                             gemm_pack_bf16x2(rg[4].x * zk[4], rg[5].x * zk[5]), gemm_pack_bf16x2(rg[6].x * zk[6], rg[7].x * zk[7]));
         dst[1] = make_uint4(gemm_pack_bf16x2(rg[0].y * zk[0], rg[1].y * zk[1]), gemm_pack_bf16x2(rg[2].y * zk[2], rg[3].y * zk[3]),
@@ -558,11 +582,20 @@ __global__ __launch_bounds__(256) void k_gemm_bf16_big_rr(GemmArgs a) {
             }
         }
 }
-static bool gemm_bf16_big_ok(const GemmArgs& a) {
-    if (a.sAi != 1 || a.sBj != 1 || a.relu || a.p_drop > 0.f) return false;
-    if (a.M < GBB_BM || a.N < GBB_BN || (a.M & 3) || (a.N & 3) || (a.sAk & 3) || (a.sBk & 3)) return false;
+// an operand is staged by 16-byte loads either along its rows (row-contiguous: stride 1 between rows, a multiple of 4 between k)
+// or along k (k-contiguous: the other way round, and K a multiple of the k-tile)
+static bool gemm_bf16_big_operand_ok(long s_row, long s_k, int K, bool* kc) {
+    if (s_row == 1 && !(s_k & 3)) { *kc = false; return true; }
+    if (s_k == 1 && !(s_row & 3) && !(K % GBB_BK)) { *kc = true; return true; }
+    return false;
+}
+static bool gemm_bf16_big_ok(const GemmArgs& a, bool* akc, bool* bkc) {
+    if (a.relu || a.p_drop > 0.f) return false;
+    if (!gemm_bf16_big_operand_ok(a.sAi, a.sAk, a.K, akc) || !gemm_bf16_big_operand_ok(a.sBj, a.sBk, a.K, bkc)) return false;
+    if (a.M < GBB_BM || a.N < GBB_BN || (a.M & 3) || (a.N & 3)) return false;
     if (((uintptr_t)a.A | (uintptr_t)a.B) & 15) return false;
-    return (long)((a.M + GBB_BM - 1) / GBB_BM) * ((a.N + GBB_BN - 1) / GBB_BN) >= 128;
+    // (round 5: from 64 tiles on — the 64x64 kernel it would fall to runs these shapes at 20-35 TFLOP/s)
+    return (long)((a.M + GBB_BM - 1) / GBB_BM) * ((a.N + GBB_BN - 1) / GBB_BN) >= 64;
 }
 
 // d(pre-activation) = dy * [y != 0] * scale (reference Prenet, model.py:96-99: F.dropout(F.relu(linear(x)), p=0.5)).
@@ -605,9 +638,13 @@ extern "C" int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B,
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
     a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
     a.kz_chunk = 0; a.part = nullptr; a.nbatch = 1; a.sAb = a.sBb = a.sCb = 0; a.nsub = 1; a.sAs = a.sBs = 0; a.bias_row = 0; a.tile_ctr = nullptr;
-    if (gemm_bf16_big_ok(a)) {
+    bool big_akc = false, big_bkc = false;
+    if (gemm_bf16_big_ok(a, &big_akc, &big_bkc)) {
         dim3 gb((N + GBB_BN - 1) / GBB_BN, (M + GBB_BM - 1) / GBB_BM);
-        k_gemm_bf16_big_rr<<<gb, 256, 0, stream>>>(a);
+        if (big_akc && big_bkc) k_gemm_bf16_big_rr<true, true><<<gb, 256, 0, stream>>>(a);
+        else if (big_akc) k_gemm_bf16_big_rr<true, false><<<gb, 256, 0, stream>>>(a);
+        else if (big_bkc) k_gemm_bf16_big_rr<false, true><<<gb, 256, 0, stream>>>(a);
+        else k_gemm_bf16_big_rr<false, false><<<gb, 256, 0, stream>>>(a);
         return t2v_check_launch();
     }
     // large products in an operand form the 128x128 bf16 kernel does not take (the hoisted attention_rnn input term and the

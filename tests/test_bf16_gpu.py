@@ -19,7 +19,10 @@ def bf16_mode():
 
 
 @pytest.mark.parametrize("M,N,K,ta,tb", [(2400, 81, 1536, False, False), (100, 256, 80, False, False),
-                                         (256, 80, 2400, True, True), (37, 129, 515, False, True)])
+                                         (256, 80, 2400, True, True), (37, 129, 515, False, True),
+                                         # the 128x128-tile kernel in its four operand forms (row- / k-contiguous A and B), ragged edges
+                                         (6400, 4096, 256, False, False), (1156, 1028, 96, False, True), (1156, 1028, 96, True, False),
+                                         (1156, 1028, 100, True, True), (1024, 1152, 4096, False, False)])
 def test_gemm_bf16(bf16_mode, M, N, K, ta, tb):
     import t2v_hip
     g = torch.Generator().manual_seed(M + N)
