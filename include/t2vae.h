@@ -482,6 +482,14 @@ int t2v_gemm_f32_batched(const float* A, long sAb, long sAi, long sAk, const flo
 int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
                   float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
                   uint64_t seed, uint32_t rng_stream, uint32_t rng_t, void* stream);
+/* bf16 product with split-K for the 128x128-tile kernel (the deferred LSTM weight gradients of the decoder, model.py:221-226
+ * under autograd: 64 .. 384 tiles with K = T*B): when t2v_gemm_bf16_splitk_scratch_floats(M,N,K) > 0 and `splitk_scratch` holds
+ * that many floats, the k range is cut over gridDim.z, the partial accumulators are summed in a fixed order (deterministic)
+ * with the epilogue; otherwise identical to t2v_gemm_bf16. */
+long t2v_gemm_bf16_splitk_scratch_floats(int M, int N, int K);
+int t2v_gemm_bf16_splitk(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
+                         float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
+                         uint64_t seed, uint32_t rng_stream, uint32_t rng_t, float* splitk_scratch, void* stream);
 
 
 /* ------------------------------------------------------------------ reference encoder / VAE / loss

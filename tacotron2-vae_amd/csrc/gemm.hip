@@ -408,13 +408,36 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
     const float* a_p = a.A + (long)min(i0 + a_r, a.M - 1) * a.sAi;
     const float* b_p = a.B + (long)min(j0 + b_r, a.N - 1) * a.sBj;
     float ra[8], rb[8];
+    // a k-contiguous operand whose rows start 16-byte aligned is read as two float4 per thread (round 5: the eight strided
+    // scalar loads made the projection GEMM of the B = 16 step — 6400 x 81, K = 1536 — a 200 us launch)
+    const bool a_vec = A_KC && a.sAk == 1 && !(a.sAi & 3) && !((uintptr_t)a.A & 15);
+    const bool b_vec = B_KC && a.sBk == 1 && !(a.sBj & 3) && !((uintptr_t)a.B & 15);
     auto load_tiles = [&](int k0) {
+        if (a_vec && k0 + a_k + 8 <= a.K) {
+            const float4 lo = *(const float4*)(a_p + k0 + a_k), hi = *(const float4*)(a_p + k0 + a_k + 4);
+            const float z = a_rok ? 1.f : 0.f;
+            ra[0] = lo.x * z; ra[1] = lo.y * z; ra[2] = lo.z * z; ra[3] = lo.w * z;
+            ra[4] = hi.x * z; ra[5] = hi.y * z; ra[6] = hi.z * z; ra[7] = hi.w * z;
+        } else {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int ka = k0 + a_k + u, kb = k0 + b_k + u;
-            const float va = a_p[(long)min(ka, a.K - 1) * a.sAk], vb = b_p[(long)min(kb, a.K - 1) * a.sBk];
-            ra[u] = (a_rok && ka < a.K) ? va : 0.f;
-            rb[u] = (b_rok && kb < a.K) ? vb : 0.f;
+            for (int u = 0; u < 8; ++u) {
+                const int ka = k0 + a_k + u;
+                const float va = a_p[(long)min(ka, a.K - 1) * a.sAk];
+                ra[u] = (a_rok && ka < a.K) ? va : 0.f;
+            }
+        }
+        if (b_vec && k0 + b_k + 8 <= a.K) {
+            const float4 lo = *(const float4*)(b_p + k0 + b_k), hi = *(const float4*)(b_p + k0 + b_k + 4);
+            const float z = b_rok ? 1.f : 0.f;
+            rb[0] = lo.x * z; rb[1] = lo.y * z; rb[2] = lo.z * z; rb[3] = lo.w * z;
+            rb[4] = hi.x * z; rb[5] = hi.y * z; rb[6] = hi.z * z; rb[7] = hi.w * z;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kb = k0 + b_k + u;
+                const float vb = b_p[(long)min(kb, a.K - 1) * a.sBk];
+                rb[u] = (b_rok && kb < a.K) ? vb : 0.f;
+            }
         }
     };
     auto store_tiles = [&](int buf) {
@@ -491,9 +514,13 @@ __global__ __launch_bounds__(256) void k_gemm_bf16_big_rr(GemmArgs a) {
     const long sk = isB ? a.sBk : a.sAk, si = isB ? a.sBj : a.sAi;
     const int lim = isB ? a.N : a.M, row0 = min((isB ? j0 : i0) + 4 * r4, lim - 4);
     const float z_row = (isB ? j0 : i0) + 4 * r4 < lim ? 1.f : 0.f;      // M, N are multiples of 4: a row quad is all in or all out
+    // split-K (round 5): blockIdx.z takes the k range [kbeg, kend) — the deferred LSTM weight gradients are 64 .. 384 tiles with
+    // K = T*B = 6400, and a workgroup with ONE tile of prefetch is bound by the memory round trip per k-tile (200 k-tiles x
+    // ~1.3 us = the 260-420 us these launches took), so the k range is cut until ~3 workgroups per CU are in flight
+    const int kbeg = a.kz_chunk ? blockIdx.z * a.kz_chunk : 0, kend = a.kz_chunk ? min(a.K, kbeg + a.kz_chunk) : a.K;
     float4 rg[8];
     auto load_tiles = [&](int k0) {
-        if (kc) {           // rows row0 .. row0 + 3, k = k0 + 8 kg .. + 7 (K is a multiple of 32 on this path)
+        if (kc) {           // rows row0 .. row0 + 3, k = k0 + 8 kg .. + 7 (K and the split are multiples of 32 on this path)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const float* q = P + (long)(row0 + rr) * si + k0 + 8 * kg;
@@ -502,7 +529,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16_big_rr(GemmArgs a) {
             }
         } else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) rg[u] = *(const float4*)(P + (long)min(k0 + 8 * kg + u, a.K - 1) * sk + row0);
+            for (int u = 0; u < 8; ++u) rg[u] = *(const float4*)(P + (long)min(k0 + 8 * kg + u, kend - 1) * sk + row0);
         }
     };
     auto store_tiles = [&](int buf, int k0) {
@@ -518,7 +545,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16_big_rr(GemmArgs a) {
         }
         float zk[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) zk[u] = (k0 + 8 * kg + u < a.K ? 1.f : 0.f) * z_row;
+        for (int u = 0; u < 8; ++u) zk[u] = (k0 + 8 * kg + u < kend ? 1.f : 0.f) * z_row;
         dst[0] = make_uint4(gemm_pack_bf16x2(rg[0].x * zk[0], rg[1].x * zk[1]), gemm_pack_bf16x2(rg[2].x * zk[2], rg[3].x * zk[3]),
                             gemm_pack_bf16x2(rg[4].x * zk[4], rg[5].x * zk[5]), gemm_pack_bf16x2(rg[6].x * zk[6], rg[7].x * zk[7]));
         dst[1] = make_uint4(gemm_pack_bf16x2(rg[0].y * zk[0], rg[1].y * zk[1]), gemm_pack_bf16x2(rg[2].y * zk[2], rg[3].y * zk[3]),
@@ -535,15 +562,15 @@ __global__ __launch_bounds__(256) void k_gemm_bf16_big_rr(GemmArgs a) {
         for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
-    const int nkt = (a.K + GBB_BK - 1) / GBB_BK;
-    load_tiles(0);
-    store_tiles(0, 0);
+    const int nkt = (kend - kbeg + GBB_BK - 1) / GBB_BK;
+    load_tiles(kbeg);
+    store_tiles(0, kbeg);
     __syncthreads();
     const int am = 64 * wm + (lane & 31), bn = 64 * wn + (lane & 31), kq = lane >> 5;
     typedef __bf16 gbb_bf16x8 __attribute__((ext_vector_type(8)));
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tiles((kt + 1) * GBB_BK);
+        if (kt + 1 < nkt) load_tiles(kbeg + (kt + 1) * GBB_BK);
         uint4 av[2][2], bv[2][2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -559,8 +586,65 @@ __global__ __launch_bounds__(256) void k_gemm_bf16_big_rr(GemmArgs a) {
 #pragma unroll
                 for (int y = 0; y < 2; ++y)
                     acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const gbb_bf16x8*)&av[s2][x], *(const gbb_bf16x8*)&bv[s2][y], acc[x][y], 0, 0, 0);
-        if (kt + 1 < nkt) store_tiles(buf ^ 1, (kt + 1) * GBB_BK);
+        if (kt + 1 < nkt) store_tiles(buf ^ 1, kbeg + (kt + 1) * GBB_BK);
         __syncthreads();
+    }
+    if (a.part) {
+        // the raw accumulators go to scratch in ACCUMULATOR order ([split][tile][16-byte group g = 0..15][thread]: a wave's
+        // store / load is 1 KB contiguous), write-through; the workgroup that arrives LAST at its tile's counter adds the
+        // partials in the fixed order z = 0, 1, ... (bit-identical whichever workgroup does it) and runs the epilogue
+        typedef unsigned gbb_u32x4 __attribute__((ext_vector_type(4)));
+        const size_t tiles = (size_t)gridDim.x * gridDim.y, tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        {
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part + (blockIdx.z * tiles + tile) * (GBB_BM * GBB_BN), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        gbb_u32x4 v;
+                        v.x = __float_as_uint(acc[x][y][4 * q]); v.y = __float_as_uint(acc[x][y][4 * q + 1]);
+                        v.z = __float_as_uint(acc[x][y][4 * q + 2]); v.w = __float_as_uint(acc[x][y][4 * q + 3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((((x * 2 + y) * 4 + q) * 256) + tid) * 16, 0, 16);
+                    }
+        }
+        __shared__ unsigned last_;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* ctr = a.tile_ctr + tile;
+        if (tid == 0) last_ = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.z - 1 ? 1u : 0u;
+        __syncthreads();
+        if (!last_) return;
+        if (tid == 0) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nz = (int)gridDim.z;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+        for (int z0 = 0; z0 < nz; z0 += 2) {            // two partial tiles (32 loads per thread) requested before the first add
+            gbb_u32x4 v[2][16];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int z = min(z0 + u, nz - 1);
+                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part + (z * tiles + tile) * (GBB_BM * GBB_BN), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+                for (int g = 0; g < 16; ++g) v[u][g] = __builtin_amdgcn_raw_buffer_load_b128(rs, (g * 256 + tid) * 16, 0, 16);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (z0 + u < nz) {
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        acc[g >> 3][(g >> 2) & 1][4 * (g & 3)] += __uint_as_float(v[u][g].x);
+                        acc[g >> 3][(g >> 2) & 1][4 * (g & 3) + 1] += __uint_as_float(v[u][g].y);
+                        acc[g >> 3][(g >> 2) & 1][4 * (g & 3) + 2] += __uint_as_float(v[u][g].z);
+                        acc[g >> 3][(g >> 2) & 1][4 * (g & 3) + 3] += __uint_as_float(v[u][g].w);
+                    }
+                }
+        }
     }
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -597,6 +681,24 @@ static bool gemm_bf16_big_ok(const GemmArgs& a, bool* akc, bool* bkc) {
     // (round 5: from 64 tiles on — the 64x64 kernel it would fall to runs these shapes at 20-35 TFLOP/s)
     return (long)((a.M + GBB_BM - 1) / GBB_BM) * ((a.N + GBB_BN - 1) / GBB_BN) >= 64;
 }
+// k-splits of the 128x128 bf16 kernel: until ~3 workgroups per CU (its occupancy) are in flight, >= 16 k-tiles per split, <= 8
+// partial tiles for the last workgroup of a tile to add
+static int gemm_bf16_big_splits(int M, int N, int K) {
+    const long tiles = (long)((M + GBB_BM - 1) / GBB_BM) * ((N + GBB_BN - 1) / GBB_BN);
+    const int nkt = (K + GBB_BK - 1) / GBB_BK;
+    if (tiles < 64 || tiles >= 512 || nkt < 32) return 1;
+    static const int forced = getenv("T2V_GEMM_BF16_SPLITS") ? atoi(getenv("T2V_GEMM_BF16_SPLITS")) : 0;     // measurement
+    long ns = forced > 0 ? forced : (768 + tiles - 1) / tiles;
+    if (ns > nkt / 16) ns = nkt / 16;
+    if (ns > 8) ns = 8;
+    return ns < 2 ? 1 : (int)ns;
+}
+extern "C" long t2v_gemm_bf16_splitk_scratch_floats(int M, int N, int K) {
+    if (M < GBB_BM || N < GBB_BN || K < 1 || (M & 3) || (N & 3)) return 0;
+    const int ns = gemm_bf16_big_splits(M, N, K);
+    const long tiles = (long)((M + GBB_BM - 1) / GBB_BM) * ((N + GBB_BN - 1) / GBB_BN);
+    return ns > 1 ? (long)ns * tiles * GBB_BM * GBB_BN : 0;
+}
 
 // d(pre-activation) = dy * [y != 0] * scale (reference Prenet, model.py:96-99: F.dropout(F.relu(linear(x)), p=0.5)).
 __global__ __launch_bounds__(256) void k_epilogue_bwd(const float4* __restrict__ dy, const float4* __restrict__ y,
@@ -628,9 +730,22 @@ extern "C" int t2v_gemm_epilogue_bwd(const float* dy, const float* y, float* out
 extern "C" int t2v_gemm_f32(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
                             float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
                             uint64_t seed, uint32_t rng_stream, uint32_t rng_t, void* stream_);
+static int gemm_bf16_impl(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
+                          float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
+                          uint64_t seed, uint32_t rng_stream, uint32_t rng_t, float* splitk_scratch, void* stream_);
 extern "C" int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
                              float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
                              uint64_t seed, uint32_t rng_stream, uint32_t rng_t, void* stream_) {
+    return gemm_bf16_impl(A, sAi, sAk, B, sBj, sBk, bias, C, ldc, M, N, K, relu, accumulate, p_drop, seed, rng_stream, rng_t, nullptr, stream_);
+}
+extern "C" int t2v_gemm_bf16_splitk(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
+                                    float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
+                                    uint64_t seed, uint32_t rng_stream, uint32_t rng_t, float* splitk_scratch, void* stream_) {
+    return gemm_bf16_impl(A, sAi, sAk, B, sBj, sBk, bias, C, ldc, M, N, K, relu, accumulate, p_drop, seed, rng_stream, rng_t, splitk_scratch, stream_);
+}
+static int gemm_bf16_impl(const float* A, long sAi, long sAk, const float* B, long sBj, long sBk, const float* bias,
+                          float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
+                          uint64_t seed, uint32_t rng_stream, uint32_t rng_t, float* splitk_scratch, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!A || !B || !C || M < 1 || N < 1 || K < 1 || ldc < N) return T2V_ERR_ARG;
     GemmArgs a;
@@ -640,7 +755,17 @@ extern "C" int t2v_gemm_bf16(const float* A, long sAi, long sAk, const float* B,
     a.kz_chunk = 0; a.part = nullptr; a.nbatch = 1; a.sAb = a.sBb = a.sCb = 0; a.nsub = 1; a.sAs = a.sBs = 0; a.bias_row = 0; a.tile_ctr = nullptr;
     bool big_akc = false, big_bkc = false;
     if (gemm_bf16_big_ok(a, &big_akc, &big_bkc)) {
-        dim3 gb((N + GBB_BN - 1) / GBB_BN, (M + GBB_BM - 1) / GBB_BM);
+        const int ns = splitk_scratch ? gemm_bf16_big_splits(M, N, K) : 1;
+        dim3 gb((N + GBB_BN - 1) / GBB_BN, (M + GBB_BM - 1) / GBB_BM, ns);
+        if (ns > 1) {
+            const int tiles_k = (K + GBB_BK - 1) / GBB_BK;
+            a.kz_chunk = ((tiles_k + ns - 1) / ns) * GBB_BK;
+            gb.z = (unsigned)((K + a.kz_chunk - 1) / a.kz_chunk);      // no empty split
+            a.part = splitk_scratch;
+            a.tile_ctr = t2v_arrival_counters((int)(gb.x * gb.y));
+            if (!a.tile_ctr) return T2V_ERR_LAUNCH;
+            if (gb.z < 2) { a.kz_chunk = 0; a.part = nullptr; a.tile_ctr = nullptr; gb.z = 1; }
+        }
         if (big_akc && big_bkc) k_gemm_bf16_big_rr<true, true><<<gb, 256, 0, stream>>>(a);
         else if (big_akc) k_gemm_bf16_big_rr<true, false><<<gb, 256, 0, stream>>>(a);
         else if (big_bkc) k_gemm_bf16_big_rr<false, true><<<gb, 256, 0, stream>>>(a);

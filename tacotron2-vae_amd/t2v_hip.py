@@ -61,7 +61,7 @@ class _DecInferBufs(C.Structure):
 
 
 EXPORTS = ('t2v_version', 't2v_last_error', 't2v_stamp', 't2v_debug_spin', 't2v_pack_lstm_weights', 't2v_pack_lstm_weights_bf16', 't2v_decoder_train_fwd',
-           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_clip_adam_step_guarded', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_conv1d_dw_scratch_floats', 't2v_conv1d_flip_weights', 't2v_gemm_bf16', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
+           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_clip_adam_step_guarded', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_conv1d_dw_scratch_floats', 't2v_conv1d_flip_weights', 't2v_gemm_bf16', 't2v_gemm_bf16_splitk', 't2v_gemm_bf16_splitk_scratch_floats', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
            't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bn_act_bwd_eval', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats', 't2v_conv2d_s2_fwd_gemm', 't2v_conv2d_s2_bwd_gemm',
            't2v_conv2d_s2_gemm_scratch_floats',
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_fuse_location_weights', 't2v_decoder_qp_floats',
@@ -197,6 +197,9 @@ def load_library():
     lib.t2v_gemm_f32.argtypes = [vp, C.c_long, C.c_long, vp, C.c_long, C.c_long, vp, vp, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, vp]
     lib.t2v_gemm_bf16.argtypes = lib.t2v_gemm_f32.argtypes
+    lib.t2v_gemm_bf16_splitk.argtypes = lib.t2v_gemm_f32.argtypes[:-1] + [vp, vp]
+    lib.t2v_gemm_bf16_splitk_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.t2v_gemm_bf16_splitk_scratch_floats.restype = C.c_long
     lib.t2v_gemm_f32_splitk.argtypes = lib.t2v_gemm_f32.argtypes[:-1] + [vp, vp]
     lib.t2v_gemm_f32_batched.argtypes = [vp, C.c_long, C.c_long, C.c_long, vp, C.c_long, C.c_long, C.c_long, vp, C.c_long,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
@@ -1839,6 +1842,14 @@ def gemm(A, B, bias=None, out=None, relu=False, accumulate=False, p_drop=0.0, se
             _check(lib.t2v_gemm_f32_splitk(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(bias), _p(out),
                                            ldc, M, N, K, int(relu), int(accumulate), float(p_drop), int(seed), int(rng_stream),
                                            int(rng_t), _p(scr), _stream()), 't2v_gemm_f32_splitk')
+            return out
+    if _BF16 and not relu and p_drop == 0.0:
+        # the 128x128-tile bf16 kernel on a grid that leaves CUs idle with a deep K (the deferred LSTM weight gradients)
+        nscr = lib.t2v_gemm_bf16_splitk_scratch_floats(M, N, K)
+        if nscr:
+            scr = torch.empty(nscr, device=A.device, dtype=torch.float32)
+            _check(lib.t2v_gemm_bf16_splitk(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(bias), _p(out),
+                                            ldc, M, N, K, 0, int(accumulate), 0.0, 0, 0, 0, _p(scr), _stream()), 't2v_gemm_bf16_splitk')
             return out
     fn = lib.t2v_gemm_bf16 if _BF16 else lib.t2v_gemm_f32
     _check(fn(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(bias), _p(out), ldc,

@@ -22,7 +22,10 @@ def bf16_mode():
                                          (256, 80, 2400, True, True), (37, 129, 515, False, True),
                                          # the 128x128-tile kernel in its four operand forms (row- / k-contiguous A and B), ragged edges
                                          (6400, 4096, 256, False, False), (1156, 1028, 96, False, True), (1156, 1028, 96, True, False),
-                                         (1156, 1028, 100, True, True), (1024, 1152, 4096, False, False)])
+                                         (1156, 1028, 100, True, True), (1024, 1152, 4096, False, False),
+                                         # ... and split over k (deferred LSTM weight gradients, Prenet data gradient)
+                                         (4096, 256, 6400, True, True), (1156, 1028, 1000, True, True), (6400, 256, 4096, False, True),
+                                         (1024, 1152, 4096, True, False)])
 def test_gemm_bf16(bf16_mode, M, N, K, ta, tb):
     import t2v_hip
     g = torch.Generator().manual_seed(M + N)
@@ -44,6 +47,28 @@ def test_gemm_bf16(bf16_mode, M, N, K, ta, tb):
     # and within bf16 rounding of the fp32 product
     full = A @ B.t() + bias
     assert (out - full).abs().max().item() < 2e-2 * full.abs().max().item()
+
+
+def test_gemm_bf16_split_k_accumulates_into_a_column_block_deterministically(bf16_mode):
+    """the [weight_ih | weight_hh] halves of one LSTM weight gradient: out is a column block of a wider matrix, the second
+    chunk accumulates; split-K partials are added in a fixed order, so two runs agree bit for bit"""
+    import t2v_hip
+    lib = t2v_hip.load_library()
+    M, N, K, LD = 4096, 512, 3200, 768
+    assert lib.t2v_gemm_bf16_splitk_scratch_floats(M, N, K) > 0
+    g = torch.Generator().manual_seed(5)
+    dg = torch.randn(2, K, M, generator=g).cuda()
+    x = torch.randn(2, K, LD, generator=g).cuda()
+    outs = []
+    for _ in range(2):
+        W = torch.full((M, LD), 7.0, device='cuda')
+        for c in range(2):
+            t2v_hip.gemm(dg[c].t(), x[c][:, 256:].t(), out=W[:, 256:], accumulate=c > 0)
+        outs.append(W.clone())
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0][:, :256] == 7.0).all()
+    ref = sum(dg[c].bfloat16().double().t() @ x[c][:, 256:].bfloat16().double() for c in range(2)).float()
+    assert (outs[0][:, 256:] - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("B,Cin,Cout,T", [(6, 512, 512, 400), (3, 512, 256, 37), (2, 128, 512, 84)])
