@@ -33,63 +33,8 @@ struct GemmArgs {
     unsigned* tile_ctr;    // split-K: one arrival counter per output tile (zero before and after the launch)
 };
 
-template <bool A_KC, bool B_KC>   // operand contiguous along k?
-__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
-    __shared__ float As[2][GM_BK][GM_BM + 1];
-    __shared__ float Bs[2][GM_BK][GM_BN + 1];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int i0 = blockIdx.y * GM_BM, j0 = blockIdx.x * GM_BN;
-    if (a.nbatch > 1) {
-        const int zb = a.nsub > 1 ? blockIdx.z / a.nsub : blockIdx.z, zs = a.nsub > 1 ? blockIdx.z - zb * a.nsub : 0;
-        a.A += zb * a.sAb + zs * a.sAs; a.B += zb * a.sBb + zs * a.sBs; a.C += blockIdx.z * a.sCb;
-    }
-    const int kbeg = a.kz_chunk ? blockIdx.z * a.kz_chunk : 0, kend = a.kz_chunk ? min(a.K, kbeg + a.kz_chunk) : a.K;
-    constexpr int NE = GM_BM * GM_BK / 256;   // 8
-    float ra[NE], rb[NE];
-    auto load_tiles = [&](int k0) {
-#pragma unroll
-        for (int e8 = 0; e8 < NE; ++e8) {
-            const int e = tid + 256 * e8;
-            {
-                const int kk = A_KC ? (e & (GM_BK - 1)) : (e >> 6);
-                const int ii = A_KC ? (e >> 5) : (e & (GM_BM - 1));
-                const int i = i0 + ii, k = k0 + kk;
-                ra[e8] = (i < a.M && k < kend) ? a.A[(long)i * a.sAi + (long)k * a.sAk] : 0.f;
-            }
-            {
-                const int kk = B_KC ? (e & (GM_BK - 1)) : (e >> 6);
-                const int jj = B_KC ? (e >> 5) : (e & (GM_BN - 1));
-                const int j = j0 + jj, k = k0 + kk;
-                rb[e8] = (j < a.N && k < kend) ? a.B[(long)j * a.sBj + (long)k * a.sBk] : 0.f;
-            }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int e8 = 0; e8 < NE; ++e8) {
-            const int e = tid + 256 * e8;
-            if (A_KC) As[buf][e & (GM_BK - 1)][e >> 5] = ra[e8]; else As[buf][e >> 6][e & (GM_BM - 1)] = ra[e8];
-            if (B_KC) Bs[buf][e & (GM_BK - 1)][e >> 5] = rb[e8]; else Bs[buf][e >> 6][e & (GM_BN - 1)] = rb[e8];
-        }
-    };
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int nkt = (kend - kbeg + GM_BK - 1) / GM_BK;
-    load_tiles(kbeg);
-    store_tiles(0);
-    __syncthreads();
-    const int ai = 32 * wm + (lane & 31), bj = 32 * wn + (lane & 31), kh = lane >> 5;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tiles(kbeg + (kt + 1) * GM_BK);
-#pragma unroll
-        for (int s = 0; s < GM_BK / 2; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][2 * s + kh][ai], Bs[buf][2 * s + kh][bj], acc, 0, 0, 0);
-        if (kt + 1 < nkt) store_tiles(buf ^ 1);
-        __syncthreads();
-    }
+// epilogue of the 64x64 kernels (fp32 and bf16 operands share the accumulator layout: wave (wm, wn) owns a 32x32 patch)
+__device__ __forceinline__ void gemm64_epilogue(const GemmArgs& a, f32x16& acc, int i0, int j0, int wm, int wn, int lane, int tid) {
     const int j = j0 + 32 * wn + (lane & 31);
     if (a.part) {
         // split-K: the raw partial tile goes to scratch; the workgroup that arrives LAST at its tile's counter (round 4: no
@@ -155,6 +100,66 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
             }
         }
     }
+}
+
+template <bool A_KC, bool B_KC>   // operand contiguous along k?
+__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a) {
+    __shared__ float As[2][GM_BK][GM_BM + 1];
+    __shared__ float Bs[2][GM_BK][GM_BN + 1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i0 = blockIdx.y * GM_BM, j0 = blockIdx.x * GM_BN;
+    if (a.nbatch > 1) {
+        const int zb = a.nsub > 1 ? blockIdx.z / a.nsub : blockIdx.z, zs = a.nsub > 1 ? blockIdx.z - zb * a.nsub : 0;
+        a.A += zb * a.sAb + zs * a.sAs; a.B += zb * a.sBb + zs * a.sBs; a.C += blockIdx.z * a.sCb;
+    }
+    const int kbeg = a.kz_chunk ? blockIdx.z * a.kz_chunk : 0, kend = a.kz_chunk ? min(a.K, kbeg + a.kz_chunk) : a.K;
+    constexpr int NE = GM_BM * GM_BK / 256;   // 8
+    float ra[NE], rb[NE];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int e8 = 0; e8 < NE; ++e8) {
+            const int e = tid + 256 * e8;
+            {
+                const int kk = A_KC ? (e & (GM_BK - 1)) : (e >> 6);
+                const int ii = A_KC ? (e >> 5) : (e & (GM_BM - 1));
+                const int i = i0 + ii, k = k0 + kk;
+                ra[e8] = (i < a.M && k < kend) ? a.A[(long)i * a.sAi + (long)k * a.sAk] : 0.f;
+            }
+            {
+                const int kk = B_KC ? (e & (GM_BK - 1)) : (e >> 6);
+                const int jj = B_KC ? (e >> 5) : (e & (GM_BN - 1));
+                const int j = j0 + jj, k = k0 + kk;
+                rb[e8] = (j < a.N && k < kend) ? a.B[(long)j * a.sBj + (long)k * a.sBk] : 0.f;
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int e8 = 0; e8 < NE; ++e8) {
+            const int e = tid + 256 * e8;
+            if (A_KC) As[buf][e & (GM_BK - 1)][e >> 5] = ra[e8]; else As[buf][e >> 6][e & (GM_BM - 1)] = ra[e8];
+            if (B_KC) Bs[buf][e & (GM_BK - 1)][e >> 5] = rb[e8]; else Bs[buf][e >> 6][e & (GM_BN - 1)] = rb[e8];
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nkt = (kend - kbeg + GM_BK - 1) / GM_BK;
+    load_tiles(kbeg);
+    store_tiles(0);
+    __syncthreads();
+    const int ai = 32 * wm + (lane & 31), bj = 32 * wn + (lane & 31), kh = lane >> 5;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tiles(kbeg + (kt + 1) * GM_BK);
+#pragma unroll
+        for (int s = 0; s < GM_BK / 2; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][2 * s + kh][ai], Bs[buf][2 * s + kh][bj], acc, 0, 0, 0);
+        if (kt + 1 < nkt) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    gemm64_epilogue(a, acc, i0, j0, wm, wn, lane, tid);
 }
 
 // ---- split-K for the skinny deep-K products (weight gradients of the Prenet / projection / GRU / VAE head: a handful of
@@ -408,12 +413,14 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
     const float* a_p = a.A + (long)min(i0 + a_r, a.M - 1) * a.sAi;
     const float* b_p = a.B + (long)min(j0 + b_r, a.N - 1) * a.sBj;
     float ra[8], rb[8];
+    // split-K (round 5, as in k_gemm_f32): blockIdx.z takes the k range [kbeg, kend)
+    const int kbeg = a.kz_chunk ? blockIdx.z * a.kz_chunk : 0, kend = a.kz_chunk ? min(a.K, kbeg + a.kz_chunk) : a.K;
     // a k-contiguous operand whose rows start 16-byte aligned is read as two float4 per thread (round 5: the eight strided
     // scalar loads made the projection GEMM of the B = 16 step — 6400 x 81, K = 1536 — a 200 us launch)
     const bool a_vec = A_KC && a.sAk == 1 && !(a.sAi & 3) && !((uintptr_t)a.A & 15);
     const bool b_vec = B_KC && a.sBk == 1 && !(a.sBj & 3) && !((uintptr_t)a.B & 15);
     auto load_tiles = [&](int k0) {
-        if (a_vec && k0 + a_k + 8 <= a.K) {
+        if (a_vec && k0 + a_k + 8 <= kend) {
             const float4 lo = *(const float4*)(a_p + k0 + a_k), hi = *(const float4*)(a_p + k0 + a_k + 4);
             const float z = a_rok ? 1.f : 0.f;
             ra[0] = lo.x * z; ra[1] = lo.y * z; ra[2] = lo.z * z; ra[3] = lo.w * z;
@@ -422,11 +429,11 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int ka = k0 + a_k + u;
-                const float va = a_p[(long)min(ka, a.K - 1) * a.sAk];
-                ra[u] = (a_rok && ka < a.K) ? va : 0.f;
+                const float va = a_p[(long)min(ka, kend - 1) * a.sAk];
+                ra[u] = (a_rok && ka < kend) ? va : 0.f;
             }
         }
-        if (b_vec && k0 + b_k + 8 <= a.K) {
+        if (b_vec && k0 + b_k + 8 <= kend) {
             const float4 lo = *(const float4*)(b_p + k0 + b_k), hi = *(const float4*)(b_p + k0 + b_k + 4);
             const float z = b_rok ? 1.f : 0.f;
             rb[0] = lo.x * z; rb[1] = lo.y * z; rb[2] = lo.z * z; rb[3] = lo.w * z;
@@ -435,8 +442,8 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int kb = k0 + b_k + u;
-                const float vb = b_p[(long)min(kb, a.K - 1) * a.sBk];
-                rb[u] = (b_rok && kb < a.K) ? vb : 0.f;
+                const float vb = b_p[(long)min(kb, kend - 1) * a.sBk];
+                rb[u] = (b_rok && kb < kend) ? vb : 0.f;
             }
         }
     };
@@ -451,14 +458,14 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int nkt = (a.K + GM_BK - 1) / GM_BK;
-    load_tiles(0);
+    const int nkt = (kend - kbeg + GM_BK - 1) / GM_BK;
+    load_tiles(kbeg);
     store_tiles(0);
     __syncthreads();
     const int ai = 32 * wm + (lane & 31), bj = 32 * wn + (lane & 31), kh = lane >> 5;
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tiles((kt + 1) * GM_BK);
+        if (kt + 1 < nkt) load_tiles(kbeg + (kt + 1) * GM_BK);
 #pragma unroll
         for (int s4 = 0; s4 < GM_BK / 8; ++s4) {
             const s16x4 av = *(const s16x4*)&As[buf][ai][8 * s4 + 4 * kh];
@@ -468,22 +475,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
         if (kt + 1 < nkt) store_tiles(buf ^ 1);
         __syncthreads();
     }
-    const int j = j0 + 32 * wn + (lane & 31);
-    if (j < a.N) {
-        const float bv = a.bias ? a.bias[j] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = i0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (i < a.M) {
-                const size_t idx = (size_t)i * a.ldc + j;
-                float v = acc[r] + bv;
-                if (a.accumulate) v += a.C[idx];
-                if (a.relu) v = fmaxf(v, 0.f);
-                if (a.p_drop > 0.f) v *= t2v_drop_scale(t2v_step_seed(a.seed, a.step), a.rng_stream, a.rng_t, (uint32_t)idx, a.p_drop);
-                a.C[idx] = v;
-            }
-        }
-    }
+    gemm64_epilogue(a, acc, i0, j0, wm, wn, lane, tid);
 }
 
 // Backward of the relu / dropout epilogue: the stored output y already carries relu and the 1/(1-p) scaling, so
@@ -693,11 +685,18 @@ static int gemm_bf16_big_splits(int M, int N, int K) {
     if (ns > 8) ns = 8;
     return ns < 2 ? 1 : (int)ns;
 }
+// (whether the 128x128 or the 64x64 kernel takes a product also depends on its strides: the scratch covers either)
 extern "C" long t2v_gemm_bf16_splitk_scratch_floats(int M, int N, int K) {
-    if (M < GBB_BM || N < GBB_BN || K < 1 || (M & 3) || (N & 3)) return 0;
-    const int ns = gemm_bf16_big_splits(M, N, K);
-    const long tiles = (long)((M + GBB_BM - 1) / GBB_BM) * ((N + GBB_BN - 1) / GBB_BN);
-    return ns > 1 ? (long)ns * tiles * GBB_BM * GBB_BN : 0;
+    if (M < 1 || N < 1 || K < 1) return 0;
+    long big = 0;
+    if (M >= GBB_BM && N >= GBB_BN && !(M & 3) && !(N & 3)) {
+        const int ns = gemm_bf16_big_splits(M, N, K);
+        const long tiles = (long)((M + GBB_BM - 1) / GBB_BM) * ((N + GBB_BN - 1) / GBB_BN);
+        big = ns > 1 ? (long)ns * tiles * GBB_BM * GBB_BN : 0;
+    }
+    const int ns64 = gemm_splits(M, N, K);
+    const long small = ns64 > 1 ? (long)ns64 * M * N : 0;
+    return big > small ? big : small;
 }
 
 // d(pre-activation) = dy * [y != 0] * scale (reference Prenet, model.py:96-99: F.dropout(F.relu(linear(x)), p=0.5)).
@@ -777,7 +776,20 @@ static int gemm_bf16_impl(const float* A, long sAi, long sAk, const float* B, lo
     // large-tile FP32 kernel does ~100 — bf16_run takes whichever is faster, fp32 operands lose no accuracy
     if (gemm_big_ok(a))
         return t2v_gemm_f32(A, sAi, sAk, B, sBj, sBk, bias, C, ldc, M, N, K, relu, accumulate, p_drop, seed, rng_stream, rng_t, stream_);
-    dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM);
+    // the 64x64 kernel: one tile of prefetch per workgroup, so a grid of less than one workgroup per CU with a deep K is bound
+    // by the memory round trip per k-tile (the BiLSTM data gradients at B = 16: 168 workgroups, 32 k-tiles, 90-120 us for
+    // 1.4 GFLOP) — split over k like the fp32 kernel
+    const int ns = splitk_scratch ? gemm_splits(M, N, K) : 1;
+    dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, ns);
+    if (ns > 1) {
+        const int tiles_k = (K + GM_BK - 1) / GM_BK;
+        a.kz_chunk = ((tiles_k + ns - 1) / ns) * GM_BK;
+        grid.z = (unsigned)((K + a.kz_chunk - 1) / a.kz_chunk);
+        a.part = splitk_scratch;
+        a.tile_ctr = t2v_arrival_counters((int)(grid.x * grid.y));
+        if (!a.tile_ctr) return T2V_ERR_LAUNCH;
+        if (grid.z < 2) { a.kz_chunk = 0; a.part = nullptr; a.tile_ctr = nullptr; grid.z = 1; }
+    }
     const bool akc = sAk == 1, bkc = sBk == 1;
     if (akc && bkc) k_gemm_bf16<true, true><<<grid, 256, 0, stream>>>(a);
     else if (akc) k_gemm_bf16<true, false><<<grid, 256, 0, stream>>>(a);

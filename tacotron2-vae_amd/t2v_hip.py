@@ -996,7 +996,14 @@ class DecoderCore(torch.autograd.Function):
             DecoderCore.last_kernel = 'k_dec_train_persist16' if p16 else 'k_dec_train_persist'
             if DecoderCore.keep_last:
                 DecoderCore.last_persist = (PW, Sb, scratch, (B, T_in, T, float(p_att), float(p_dec), int(seed)), raw)
-            if need_grad and bwd_prepare and DecoderCore.use_persistent16_bwd(lib, B, T_in, T):
+            early, DecoderCore._early = DecoderCore._early, None
+            if need_grad and bwd_prepare and early is not None and early[0] == (B, T_in, T, gpre.device):
+                # the sentinel fills of the bf16 reverse pass went out at the top of the step (prepare_bwd16_early)
+                prep = early[1]
+                for t_ in prep[:3]:
+                    t_.record_stream(torch.cuda.current_stream())
+                return W, Sb, (gpre, memory, pm, lengths, XS, CA, CD, GA, GD, QP, AL, ACUM, S), prep
+            elif need_grad and bwd_prepare and DecoderCore.use_persistent16_bwd(lib, B, T_in, T):
                 # bf16 reverse pass: its sentinel fills (1.4 MB per time step) go out NOW, on the deferred-work stream
                 NS = lib.t2v_decoder_bwd_persist16_slices(T_in)
                 DQP = torch.empty(T, B, NS, A, **f32)
@@ -1032,6 +1039,30 @@ class DecoderCore(torch.autograd.Function):
         DecoderCore.last_mode = 'launch-per-step'
         DecoderCore.last_kernel = 'k_lstm_fwd256 + k_attn_fwd'
         return W, Sb, (gpre, memory, pm, lengths, XS, CA, CD, GA, GD, QP, AL, ACUM, S), None
+
+    _early = None       # ((B, T_in, T, device), prep) of prepare_bwd16_early, consumed (or dropped) by the next forward
+
+    @staticmethod
+    def prepare_bwd16_early(B, T_in, T, device):
+        """The sentinel fills of the bf16 one-launch reverse pass (560 MB at B = 16, T = 400: ~100 us of HBM bandwidth) need
+        nothing but their buffers.  Issued right behind the decoder forward they ran next to the projection GEMM the Postnet
+        waits for; Tacotron2._forward issues them on a side stream at the TOP of the step instead, next to the latency-bound
+        encoder kernels.  Call inside the side-stream context; the buffers belong to that stream until the forward adopts them."""
+        DecoderCore._early = None
+        lib = load_library()
+        if B > MAX_DEC_B or not DecoderCore.use_persistent16(lib, B, T_in, T) or not DecoderCore.use_persistent16_bwd(lib, B, T_in, T):
+            return False
+        f32 = dict(device=device, dtype=torch.float32)
+        NS = lib.t2v_decoder_bwd_persist16_slices(T_in)
+        DQP = torch.empty(T, B, NS, A, **f32)
+        bscr = torch.empty(lib.t2v_decoder_bwd_persist16_scratch_floats(B, T_in, T), **f32)
+        errw = torch.zeros(1, device=device, dtype=torch.int32)
+        _check(lib.t2v_decoder_bwd_persistent16_prepare(_p(DQP), _p(bscr), _p(errw), B, T_in, T, _stream()),
+               't2v_decoder_bwd_persistent16_prepare')
+        ev = torch.cuda.Event()
+        ev.record()
+        DecoderCore._early = ((B, T_in, T, torch.device(device)), (DQP, bscr, errw, ev, torch.cuda.current_stream()))
+        return True
 
     @staticmethod
     def forward(ctx, gpre, memory, pm, lengths, w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, bias_dec,
@@ -1152,8 +1183,7 @@ class DecoderCore(torch.autograd.Function):
                 prep, ctx.prepared[ci] = ctx.prepared[ci], None
                 if prep is not None:
                     DQP, scratch, errw, pev, pst = prep
-                    if pst != torch.cuda.current_stream():
-                        torch.cuda.current_stream().wait_event(pev)
+                    torch.cuda.current_stream().wait_event(pev)     # (always: the preparation ran on a side stream)
                     run16 = lib.t2v_decoder_bwd_persistent16_prepared
                 else:
                     DQP = torch.empty(T, B, NS, A, **f32)
@@ -1182,8 +1212,7 @@ class DecoderCore(torch.autograd.Function):
                 prep, ctx.prepared[ci] = ctx.prepared[ci], None
                 if prep is not None:
                     DQP, scratch, errw, pev, pst = prep
-                    if pst != torch.cuda.current_stream():
-                        torch.cuda.current_stream().wait_event(pev)
+                    torch.cuda.current_stream().wait_event(pev)     # (always: the preparation ran on a side stream)
                     run_fn = lib.t2v_decoder_bwd_achain_prepared
                 else:
                     DQP = torch.empty(T, B, NS, A, **f32)
@@ -1286,11 +1315,16 @@ class DecoderCore(torch.autograd.Function):
                     with torch.cuda.stream(overlap().stream('d')):
                         gemm(dgd2.t(), x_cur[:, :KATT].t(), out=d_w_ih_dec, accumulate=not first)
                         gemm(dgd2.t(), x_cur[:, KATT:].t(), out=d_w_hh_dec, accumulate=not first)
-                d_wq = gemm(dq_sum.t(), x_cur[:, :H].t())            # (128,1024)
-                d_v = DV.sum((0, 1)).view(1, A)
-                d_loc_dense, d_loc_conv = attn_wgrad(dpre, AL, ACUM, loc_conv, loc_dense, B, T_in, T)
-                parts = [d_wq, d_loc_conv, d_loc_dense, d_v]
-                acc = parts if acc is None else [x + y for x, y in zip(acc, parts)]
+                # the attention weight gradients on a stream of their own (round 5: the captured DAG's longest path behind the
+                # reverse pass was THIS stream's serial order — Prenet data gradient, these ~450 us, the Prenet backward, the
+                # BiLSTM and encoder-conv weight gradients, 1.74 ms — with 0.26 ms of slack on the encoder's backward chain;
+                # tools/graph_critical_path.py)
+                with side('d', keep=(dq_sum, DV, dpre, AL, ACUM), after=fork):
+                    d_wq = gemm(dq_sum.t(), x_cur[:, :H].t())            # (128,1024)
+                    d_v = DV.sum((0, 1)).view(1, A)
+                    d_loc_dense, d_loc_conv = attn_wgrad(dpre, AL, ACUM, loc_conv, loc_dense, B, T_in, T)
+                    parts = [d_wq, d_loc_conv, d_loc_dense, d_v]
+                    acc = parts if acc is None else [x + y for x, y in zip(acc, parts)]
             # bias gradients flow on through an Add node (bias_ih + bias_hh) / are handed to two inputs: node's stream
             if split_d:
                 torch.cuda.current_stream().wait_stream(overlap().stream('d'))       # (DGD: that chain ended long before this one)
@@ -1735,6 +1769,7 @@ class BiLSTM(torch.autograd.Function):
         dy = _f32c(dy)
         dg = torch.empty(2, B, T, 1024, **f32) if len(chunks) == 1 else None     # cleared by t2v_bilstm_bwd
         dgs = []
+        stamp('bilstm_bwd_begin')
         for b0, b1, gates, cells, sync in chunks:
             Bc = b1 - b0
             dg_c = dg if dg is not None else torch.empty(2, Bc, T, 1024, **f32)
@@ -1743,6 +1778,7 @@ class BiLSTM(torch.autograd.Function):
                                       _p(sync), Bc, T, _stream()), 't2v_bilstm_bwd')
             _err_note('BiLSTM backward', sync[2:3])
             dgs.append(dg_c)
+        stamp('bilstm_bwd_end')
         BT = B * T
         if dg is None:
             dg = torch.cat(dgs, 1)
@@ -1843,13 +1879,15 @@ def gemm(A, B, bias=None, out=None, relu=False, accumulate=False, p_drop=0.0, se
                                            ldc, M, N, K, int(relu), int(accumulate), float(p_drop), int(seed), int(rng_stream),
                                            int(rng_t), _p(scr), _stream()), 't2v_gemm_f32_splitk')
             return out
-    if _BF16 and not relu and p_drop == 0.0:
-        # the 128x128-tile bf16 kernel on a grid that leaves CUs idle with a deep K (the deferred LSTM weight gradients)
+    if _BF16:
+        # a bf16 kernel on a grid that leaves CUs idle with a deep K (the deferred LSTM weight gradients on the 128x128 tile; the
+        # projection, the BiLSTM data / weight gradients on the 64x64 tile): split over k, fixed-order sum of the partials
         nscr = lib.t2v_gemm_bf16_splitk_scratch_floats(M, N, K)
         if nscr:
             scr = torch.empty(nscr, device=A.device, dtype=torch.float32)
             _check(lib.t2v_gemm_bf16_splitk(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(bias), _p(out),
-                                            ldc, M, N, K, 0, int(accumulate), 0.0, 0, 0, 0, _p(scr), _stream()), 't2v_gemm_bf16_splitk')
+                                            ldc, M, N, K, int(relu), int(accumulate), float(p_drop), int(seed), int(rng_stream),
+                                            int(rng_t), _p(scr), _stream()), 't2v_gemm_bf16_splitk')
             return out
     fn = lib.t2v_gemm_bf16 if _BF16 else lib.t2v_gemm_f32
     _check(fn(_p(A), A.stride(0), A.stride(1), _p(B), B.stride(0), B.stride(1), _p(bias), _p(out), ldc,

@@ -503,7 +503,8 @@ class TrainEngine(object):
             return None
         torch.cuda.synchronize()
         count0 = self.optimizer.step_count
-        graph = torch.cuda.CUDAGraph()
+        dot = os.environ.get('T2V_GRAPH_DOT')       # measurement (tools/graph_critical_path.py): the captured DAG as a DOT file
+        graph = torch.cuda.CUDAGraph(keep_graph=True) if dot else torch.cuda.CUDAGraph()
         # with a process group alive its watchdog thread polls events while this thread captures: under the default
         # 'global' error mode such a query from ANOTHER thread aborts the process now and then (seen as exit code -6 in
         # one of five runs); 'thread_local' restricts the check to this thread — the launches of the autograd worker
@@ -515,6 +516,11 @@ class TrainEngine(object):
             with torch.cuda.graph(graph, stream=self._stream, capture_error_mode=mode):
                 out = (self._body_fb if self.graph_ddp else self._body)(static_x, static_y, iteration)
             span = t2v_hip.err_capture_end()
+            if dot:
+                import ctypes
+                hip = ctypes.CDLL('libamdhip64.so')
+                rc = hip.hipGraphDebugDotPrint(ctypes.c_void_p(graph.raw_cuda_graph()), dot.encode(), ctypes.c_uint(1))
+                print("hipGraphDebugDotPrint -> %d (%s)" % (rc, dot), flush=True)
         finally:
             if span is None:
                 t2v_hip.err_capture_end(keep=False)
