@@ -634,6 +634,135 @@ __global__ __launch_bounds__(256) void k_conv5_fwd_bf16(ConvBf16Args a) {
     }
 }
 
+// Round 5, second forward / data-gradient kernel for Cin % 32 == 0 (every wide convolution of the model): the same output tile and
+// launch geometry, but (1) a k-tile is 32 input channels x 5 taps on v_mfma_f32_16x16x32_bf16 (twice the rate of the 16x16x16
+// instruction, half the barriers), operands 16 bytes per lane ([tap][row][32 channels] / [position][32 channels], row stride 80 B:
+// conflict-free ds_read_b128), and (2) TWO k-tiles of global loads are in flight behind the one being multiplied (two register
+// sets, loop unrolled by two): the 16-channel kernel above spent ~3 us per k-tile — one memory round trip under load — for 400
+// cycles of MFMA work (the B = 16 Postnet convolution: 16.8 GFLOP in 97 us).
+#define CB2_RS 40    // LDS row stride in bf16 elements (80 B)
+typedef __bf16 cb2_bf16x8 __attribute__((ext_vector_type(8)));
+template <int NTW>
+__global__ __launch_bounds__(256) void k_conv5_fwd_bf16k32(ConvBf16Args a) {
+    constexpr int BN = 16 * NTW;
+    constexpr int XW = BN + 4;
+    constexpr int NXP = (16 * XW + 255) / 256;           // channel PAIRS x positions staged per thread
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][5][CT_BM][CB2_RS];
+    __shared__ __attribute__((aligned(16))) unsigned short Xt[2][XW][CB2_RS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int kq = lane >> 4, j = lane & 15;
+    const int bb = blockIdx.x / a.tiles_per_item, t0 = (blockIdx.x % a.tiles_per_item) * BN;
+    const int m0 = blockIdx.y * CT_BM;
+    const int ncb = a.Cin / 16, nkt = a.Cin / 32;
+
+    // staging plan: A = 1280 chunks of 16 B per k-tile (row = q/20, chunk = q%20 -> channel block = chunk/10, tap = (chunk%10)/2,
+    // half = chunk&1; a row's 20 chunks are 320 contiguous bytes of Wp)
+    const unsigned short* a_src[5];
+    int a_lds[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int q = tid + 256 * i;
+        const int row = q / 20, ch = q - row * 20;
+        a_src[i] = a.Wp + (size_t)min(m0 + row, a.M - 1) * ncb * 80 + ch * 8;      // + 160 * kt
+        a_lds[i] = (((ch % 10) >> 1) * CT_BM + row) * CB2_RS + 16 * (ch / 10) + 8 * (ch & 1);
+    }
+    const float* x_item = a.X + (size_t)bb * a.Cin * a.T;
+    int x_goff[NXP], x_lds[NXP];
+    bool x_ok[NXP];
+#pragma unroll
+    for (int i = 0; i < NXP; ++i) {
+        const int e = tid + 256 * i;
+        const int cp = min(e / XW, 15), pos = e - (e / XW) * XW;
+        const int t = t0 - 2 + pos;
+        x_ok[i] = e < 16 * XW && t >= 0 && t < a.T;
+        x_goff[i] = 2 * cp * a.T + min(max(t, 0), a.T - 1);
+        x_lds[i] = e < 16 * XW ? pos * CB2_RS + 2 * cp : -1;
+    }
+    uint4 ra0[5], ra1[5];
+    float rx0[NXP][2], rx1[NXP][2];
+    auto load_tiles = [&](uint4 (&ra)[5], float (&rx)[NXP][2], int kt) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) ra[i] = *(const uint4*)(a_src[i] + 160 * kt);
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+            const float* px = x_item + (size_t)32 * kt * a.T + x_goff[i];
+            const float v0 = px[0], v1 = px[a.T];
+            rx[i][0] = x_ok[i] ? v0 : 0.f;
+            rx[i][1] = x_ok[i] ? v1 : 0.f;
+        }
+    };
+    auto store_tiles = [&](const uint4 (&ra)[5], const float (&rx)[NXP][2], int buf) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) *(uint4*)(&As[buf][0][0][0] + a_lds[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NXP; ++i)
+            if (x_lds[i] >= 0) *(unsigned*)(&Xt[buf][0][0] + x_lds[i]) = pack_bf16x2(rx[i][0], rx[i][1]);
+    };
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto multiply = [&](int buf) {
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+            const cb2_bf16x8 av = *(const cb2_bf16x8*)&As[buf][kx][16 * wave + j][8 * kq];
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const cb2_bf16x8 bv = *(const cb2_bf16x8*)&Xt[buf][16 * n + j + kx][8 * kq];
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[n], 0, 0, 0);
+            }
+        }
+    };
+    const int last = nkt - 1;
+    load_tiles(ra0, rx0, 0);
+    store_tiles(ra0, rx0, 0);
+    load_tiles(ra0, rx0, min(1, last));
+    load_tiles(ra1, rx1, min(2, last));
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2) {
+        // tile kt is in buffer 0, tile kt+1 in set 0 (in flight), tile kt+2 in set 1 (in flight)
+        multiply(0);
+        store_tiles(ra0, rx0, 1);                       // waits for set 0 only: set 1 stays in flight
+        load_tiles(ra0, rx0, min(kt + 3, last));
+        __syncthreads();
+        if (kt + 1 < nkt) multiply(1);
+        store_tiles(ra1, rx1, 0);
+        load_tiles(ra1, rx1, min(kt + 4, last));
+        __syncthreads();
+    }
+
+    float psum[4] = {0.f, 0.f, 0.f, 0.f}, psq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 16 * wave + 4 * kq + r;
+        if (m < a.M) {
+            const float bv = a.bias ? a.bias[m] : 0.f;
+            float* yrow = a.Y + ((size_t)bb * a.M + m) * a.T;
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const int t = t0 + 16 * n + j;
+                if (t < a.T) {
+                    const float v = acc[n][r] + bv;
+                    yrow[t] = v;
+                    psum[r] += v;
+                    psq[r] = fmaf(v, v, psq[r]);
+                }
+            }
+        }
+    }
+    if (a.stat_part) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float s1 = row16_sum(psum[r]), s2 = row16_sum(psq[r]);
+            const int m = m0 + 16 * wave + 4 * kq + r;
+            if (j == 0 && m < a.M) {
+                float* dst = a.stat_part + ((size_t)blockIdx.x * a.M + m) * 2;
+                dst[0] = s1;
+                dst[1] = s2;
+            }
+        }
+    }
+}
+
 // bf16 weight gradient (round 5; hparams bf16_run): the tile of k_conv5_dw — 64 rows m x 16 channels (80 columns n = 5c + kx),
 // K over (utterance, BT positions) — on v_mfma_f32_16x16x16_bf16 (16 positions per MFMA instead of 4).  dY and X are rounded
 // to bf16 (RNE) on their way into LDS, products accumulate in fp32.  Both operands are K-major in memory already ((B, C, T):
@@ -889,6 +1018,15 @@ static void launch_conv5_fwd_bf16(const float* W, int flipT, unsigned short* Wp,
     a.Wp = Wp; a.X = X; a.bias = bias; a.Y = Y; a.stat_part = stat_part;
     a.B = B; a.Cin = Cin; a.T = T; a.M = M; a.tiles_per_item = (T + BN - 1) / BN;
     dim3 grid(B * a.tiles_per_item, (M + CT_BM - 1) / CT_BM);
+    static const int k32 = getenv("T2V_CONV_BF16_K32") ? atoi(getenv("T2V_CONV_BF16_K32")) : 1;      // 0: the 16-channel kernel (measurement)
+    if (k32 && Cin % 32 == 0) {
+        if (BN == 32) k_conv5_fwd_bf16k32<2><<<grid, 256, 0, stream>>>(a);
+        else if (BN == 48) k_conv5_fwd_bf16k32<3><<<grid, 256, 0, stream>>>(a);
+        else if (BN == 64) k_conv5_fwd_bf16k32<4><<<grid, 256, 0, stream>>>(a);
+        else if (BN == 80) k_conv5_fwd_bf16k32<5><<<grid, 256, 0, stream>>>(a);
+        else k_conv5_fwd_bf16k32<6><<<grid, 256, 0, stream>>>(a);
+        return;
+    }
     if (BN == 32) k_conv5_fwd_bf16<2><<<grid, 256, 0, stream>>>(a);
     else if (BN == 48) k_conv5_fwd_bf16<3><<<grid, 256, 0, stream>>>(a);
     else if (BN == 64) k_conv5_fwd_bf16<4><<<grid, 256, 0, stream>>>(a);
