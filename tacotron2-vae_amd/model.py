@@ -562,11 +562,6 @@ class Tacotron2(nn.Module):
                                                  + [blk[0].conv.weight for blk in self.postnet.convolutions])
                 self.decoder.prepare(targets)
                 t2v_hip.stamp('prenet_gpre_end')
-        t2v_hip.DecoderCore._early = None
-        if self.training and torch.is_grad_enabled() and os.environ.get('T2V_BWD16_EARLY_FILL', '1') != '0':
-            with t2v_hip.side('g', after=fork) as forked_g:
-                if forked_g:        # sentinel fills of the bf16 one-launch reverse pass: they need only their buffers
-                    t2v_hip.DecoderCore.prepare_bwd16_early(targets.size(0), text.size(1), targets.size(2), targets.device)
         if not enc_first:
             embedded = self.transcript_embedding(text).transpose(1, 2)
             transcript = self.encoder(embedded, input_lengths)

@@ -996,15 +996,10 @@ class DecoderCore(torch.autograd.Function):
             DecoderCore.last_kernel = 'k_dec_train_persist16' if p16 else 'k_dec_train_persist'
             if DecoderCore.keep_last:
                 DecoderCore.last_persist = (PW, Sb, scratch, (B, T_in, T, float(p_att), float(p_dec), int(seed)), raw)
-            early, DecoderCore._early = DecoderCore._early, None
-            if need_grad and bwd_prepare and early is not None and early[0] == (B, T_in, T, gpre.device):
-                # the sentinel fills of the bf16 reverse pass went out at the top of the step (prepare_bwd16_early)
-                prep = early[1]
-                for t_ in prep[:3]:
-                    t_.record_stream(torch.cuda.current_stream())
-                return W, Sb, (gpre, memory, pm, lengths, XS, CA, CD, GA, GD, QP, AL, ACUM, S), prep
-            elif need_grad and bwd_prepare and DecoderCore.use_persistent16_bwd(lib, B, T_in, T):
+            if need_grad and bwd_prepare and DecoderCore.use_persistent16_bwd(lib, B, T_in, T):
                 # bf16 reverse pass: its sentinel fills (1.4 MB per time step) go out NOW, on the deferred-work stream
+                # (round 5, measured: issued at the TOP of the step instead, next to the encoder, the step time does not change —
+                # 12.90 vs 12.91 ms — so the buffers are not held for the whole forward pass)
                 NS = lib.t2v_decoder_bwd_persist16_slices(T_in)
                 DQP = torch.empty(T, B, NS, A, **f32)
                 bscr = torch.empty(lib.t2v_decoder_bwd_persist16_scratch_floats(B, T_in, T), **f32)
@@ -1039,30 +1034,6 @@ class DecoderCore(torch.autograd.Function):
         DecoderCore.last_mode = 'launch-per-step'
         DecoderCore.last_kernel = 'k_lstm_fwd256 + k_attn_fwd'
         return W, Sb, (gpre, memory, pm, lengths, XS, CA, CD, GA, GD, QP, AL, ACUM, S), None
-
-    _early = None       # ((B, T_in, T, device), prep) of prepare_bwd16_early, consumed (or dropped) by the next forward
-
-    @staticmethod
-    def prepare_bwd16_early(B, T_in, T, device):
-        """The sentinel fills of the bf16 one-launch reverse pass (560 MB at B = 16, T = 400: ~100 us of HBM bandwidth) need
-        nothing but their buffers.  Issued right behind the decoder forward they ran next to the projection GEMM the Postnet
-        waits for; Tacotron2._forward issues them on a side stream at the TOP of the step instead, next to the latency-bound
-        encoder kernels.  Call inside the side-stream context; the buffers belong to that stream until the forward adopts them."""
-        DecoderCore._early = None
-        lib = load_library()
-        if B > MAX_DEC_B or not DecoderCore.use_persistent16(lib, B, T_in, T) or not DecoderCore.use_persistent16_bwd(lib, B, T_in, T):
-            return False
-        f32 = dict(device=device, dtype=torch.float32)
-        NS = lib.t2v_decoder_bwd_persist16_slices(T_in)
-        DQP = torch.empty(T, B, NS, A, **f32)
-        bscr = torch.empty(lib.t2v_decoder_bwd_persist16_scratch_floats(B, T_in, T), **f32)
-        errw = torch.zeros(1, device=device, dtype=torch.int32)
-        _check(lib.t2v_decoder_bwd_persistent16_prepare(_p(DQP), _p(bscr), _p(errw), B, T_in, T, _stream()),
-               't2v_decoder_bwd_persistent16_prepare')
-        ev = torch.cuda.Event()
-        ev.record()
-        DecoderCore._early = ((B, T_in, T, torch.device(device)), (DQP, bscr, errw, ev, torch.cuda.current_stream()))
-        return True
 
     @staticmethod
     def forward(ctx, gpre, memory, pm, lengths, w_ih_att, w_hh_att, w_ih_dec, w_hh_dec, bias_dec,

@@ -26,5 +26,21 @@ if [ "$MODE" = "full" ]; then
   T2V_STAMP_ONLY=step_begin,dec_bwd_end,side_vae_end,side_w_end,side_g_end,step_end python tools/stamps.py --bf16 >> gpurun_out/r05_phase_stamps_bf16.txt 2>&1
   python tools/dbg/persist16_prof.py 16 84 400 > gpurun_out/r05_persist16_fwd_timeline.txt 2>&1
   python tools/dbg/persist16_bwd_prof.py 16 84 400 > gpurun_out/r05_persist16_bwd_timeline.txt 2>&1
-  grep -h "graph step\|kernel k_" gpurun_out/r05_phase_stamps*.txt gpurun_out/r05_persist16_*_timeline.txt
+  # the captured DAG of both steps: critical path (perfect scheduler, traced durations) and per-node ready-vs-start waits
+  export TMPDIR=/tmp
+  REPO=$(pwd)
+  for cfg in f32 bf16; do
+    FLAG=""; ANCHOR="void k_achain_bwd"; [ $cfg = bf16 ] && FLAG="--bf16" && ANCHOR="k_bwd_persist16"
+    rm -rf /tmp/prof_g
+    (cd /tmp && T2V_GRAPH_DOT=$REPO/gpurun_out/r05_step_graph_$cfg.dot timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_g -o g -- python $REPO/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-decode --no-secondary $FLAG > /tmp/prof_g.log 2>&1)
+    KT=$(find /tmp/prof_g -name '*kernel_trace.csv' | head -1)
+    python tools/graph_critical_path.py gpurun_out/r05_step_graph_$cfg.dot $KT "$ANCHOR" > gpurun_out/r05_critical_path_$cfg.txt 2>&1
+    python tools/graph_node_waits.py gpurun_out/r05_step_graph_$cfg.dot $KT 40 > gpurun_out/r05_node_waits_$cfg.txt 2>&1
+  done
+  T2V_STAMP_ONLY=step_begin,dec_bwd_end,bilstm_bwd_begin,bilstm_bwd_end,bwd_main_end,grads_ready,step_end python tools/stamps.py >> gpurun_out/r05_phase_stamps.txt 2>&1
+  T2V_STAMP_ONLY=step_begin,dec_bwd_end,bilstm_bwd_begin,bilstm_bwd_end,bwd_main_end,grads_ready,step_end python tools/stamps.py --bf16 >> gpurun_out/r05_phase_stamps_bf16.txt 2>&1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_peak.hip -o /tmp/mfma_peak && timeout 120 /tmp/mfma_peak > gpurun_out/r05_mfma_peak.txt 2>&1
+  python tools/dbg/gemm_time.py > gpurun_out/r05_gemm_time.txt 2>&1
+  python tools/dbg/gemm_time.py --bf16 >> gpurun_out/r05_gemm_time.txt 2>&1
+  grep -h "graph step\|kernel k_\|critical path [0-9]" gpurun_out/r05_phase_stamps*.txt gpurun_out/r05_persist16_*_timeline.txt gpurun_out/r05_critical_path_*.txt
 fi
