@@ -512,6 +512,14 @@ def run_workload(args, world, rank, bf16, koemo, steps, warmup, graph, eager_ste
                          if getattr(engine, 'graph_ddp', False) else "hip-graph replay") if engine.use_graph else "eager launches",
            "startup_steps": startup, "batch_per_gpu": bpg,
            "decoder_forward": t2v_hip.DecoderCore.last_mode, "decoder_backward": t2v_hip.DecoderCore.last_bwd_mode}
+    if getattr(engine, 'graph_fallbacks', 0):
+        # the engine's replay watchdog (train.TrainEngine._probe_end) found the captured graph slower than the eager step and
+        # dropped it: the timed steps above were eager launches
+        rp, eg = list(engine._no_graph.values())[-1]
+        res["step_mode"] = "eager launches (replay watchdog: the captured graph replayed in %.2f ms, the eager step took %.2f ms)" % (rp, eg)
+        res["graph_watchdog"] = {"fallbacks": int(engine.graph_fallbacks), "replay_ms": round(rp, 3), "eager_ms": round(eg, 3)}
+    elif engine.use_graph and getattr(engine, 'graph_watchdog', False):
+        res["graph_watchdog"] = {"fallbacks": 0}
     if eager_ms is not None:
         res["graph_vs_eager_ms"] = {"graph": round(ms, 3), "eager": round(eager_ms, 3), "eager_steps": eager_steps,
                                     "graph_replay_serialised": bool(ms > eager_ms + 0.5),
@@ -614,6 +622,8 @@ def main():
     }
     if "graph_vs_eager_ms" in res:
         out["graph_vs_eager_ms"] = res["graph_vs_eager_ms"]
+    if "graph_watchdog" in res:
+        out["graph_watchdog"] = res["graph_watchdog"]
     if "ms_per_step_ranks" in res:      # per-rank step time next to the max the value is computed from: a straggler is visible
         out["ms_per_step_ranks"] = res["ms_per_step_ranks"]
     if dist.is_initialized():

@@ -111,6 +111,20 @@ class TrainEngine(object):
         self.graph_ddp = self.use_graph and self.allreduce is not None
         self._graphs = {}
         self._seen = {}
+        # round 5: the replay watchdog.  A captured step is a DAG of ~220 nodes and ROCm's graph executor decides how its branches
+        # share the runtime's queues (four by default; DESIGN 4.0f: the same graph replays in 11.3 ms on 4 queues, 13.5 ms on 6) —
+        # a replay that is SLOWER than the same step issued eagerly means the executor serialised independent branches.  The second
+        # and third replay of every new graph are timed with events, the step after them is issued EAGERLY once (a valid training
+        # step like any other — the warm-up executions before the capture are no baseline: allocator growth and lazy initialisation
+        # make them several times slower) and timed the same way; a graph that loses by more than WATCHDOG_MS (+ 5 %) is dropped and
+        # the shape keeps running eagerly (one host sync per captured shape; T2V_GRAPH_WATCHDOG=0 switches it off).  Rank-local in a
+        # multi-rank job: replay-or-eager is every rank's own choice already (see _body).
+        self.graph_watchdog = os.environ.get('T2V_GRAPH_WATCHDOG', '1') != '0'
+        self._probe = {}            # shape key -> [(start, end) events of the first replays] (None entries once decided)
+        self._no_graph = {}         # shape key -> (replay ms, eager ms) of a graph that was dropped
+        self._pending_key = None
+        self.graph_fallbacks = 0
+        self._test_replay_drag_us = 0   # tests: a kernel that holds 8 workgroups for this long behind every probed replay
         # graph mode: EVERY step of this engine (the eager warm-up ones too) runs on one dedicated stream — autograd's
         # AccumulateGrad nodes remember the stream of their first backward, and a capture that has to synchronise with
         # the legacy default stream is illegal
@@ -391,15 +405,24 @@ class TrainEngine(object):
         ring = self.__dict__.setdefault('_eager_events', [])
         if len(ring) >= 2:
             ring.pop(0).synchronize()
+        key, self._pending_key = self._pending_key, None
+        t0 = None
+        if key is not None and self.graph_watchdog:      # the calibration step of a freshly captured shape (see __init__)
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record()
         loss, recon, kl, grad_norm = self._body(x, y, iteration)
-        ev = torch.cuda.Event()
+        ev = torch.cuda.Event(enable_timing=t0 is not None)
         ev.record()
+        if t0 is not None:
+            self._watchdog_decide(key, t0, ev)
         ring.append(ev)
         return loss, recon, kl, w, grad_norm
 
     # -- graph path
     def _graph_step_staged(self, lay, batch, iteration):
         key = ('staged',) + lay.key
+        if key in self._no_graph:
+            return None
         entry = self._graphs.get(key)
         if entry is None:
             n = self._seen.get(key, 0)
@@ -416,16 +439,23 @@ class TrainEngine(object):
                 return None
             graph, out, no_grad, span = cap
             entry = self._graphs[key] = (graph, static_buf, out, no_grad, span)
+        elif self._calibration_due(key):
+            return None                                 # this one step runs eagerly and is timed
         else:
             lay.upload(batch, into=entry[1])
         self._graphs[key] = self._graphs.pop(key)       # most recently used last
+        t0 = self._probe_begin(key)
         entry[0].replay()
-        return self._after_replay(entry[2], entry[3], entry[4])
+        out = self._after_replay(entry[2], entry[3], entry[4])
+        self._probe_end(key, t0)
+        return out
 
     def _graph_step(self, x, y, iteration):
         import t2v_hip
         tensors = [t for t in x if torch.is_tensor(t)] + list(y)
         key = tuple((tuple(t.shape), str(t.dtype)) for t in tensors) + (int(x[3]),)
+        if key in self._no_graph:
+            return None
         entry = self._graphs.get(key)
         if entry is None:
             n = self._seen.get(key, 0)
@@ -438,13 +468,66 @@ class TrainEngine(object):
             if entry is None:
                 return None
             self._graphs[key] = entry
+        elif self._calibration_due(key):
+            return None
         self._graphs[key] = self._graphs.pop(key)       # most recently used last
         graph, static_in, static_out, no_grad, span = entry
         for dst, src in zip(static_in, tensors):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
+        t0 = self._probe_begin(key)
         graph.replay()
-        return self._after_replay(static_out, no_grad, span)
+        out = self._after_replay(static_out, no_grad, span)
+        self._probe_end(key, t0)
+        return out
+
+    # -- replay watchdog (see __init__)
+    PROBE_REPLAYS = 3           # the first replay (executor set-up) is not counted
+    WATCHDOG_MS = 0.5
+
+    def _probe_begin(self, key):
+        if not self.graph_watchdog or len(self._probe.get(key, ())) >= self.PROBE_REPLAYS:
+            return None
+        t0 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        return t0
+
+    def _probe_end(self, key, t0):
+        if t0 is None:
+            return
+        import t2v_hip
+        if self._test_replay_drag_us:
+            t2v_hip.load_library().t2v_debug_spin(8, int(self._test_replay_drag_us), t2v_hip._stream())
+        t1 = torch.cuda.Event(enable_timing=True)
+        t1.record()
+        self._probe.setdefault(key, []).append((t0, t1))
+
+    def _calibration_due(self, key):
+        """True exactly once per captured shape: when its probed replays are in and the eager comparison step is still to come"""
+        probes = self._probe.get(key)
+        if not self.graph_watchdog or probes is None or len(probes) < self.PROBE_REPLAYS or probes[-1] is None:
+            return False
+        self._pending_key = key
+        return True
+
+    def _watchdog_decide(self, key, e0, e1):
+        import t2v_hip
+        probes = self._probe.get(key)
+        if not probes or probes[-1] is None:
+            return
+        e1.synchronize()
+        eager_ms = e0.elapsed_time(e1)
+        replay_ms = min(a.elapsed_time(b) for a, b in probes[1:])
+        self._probe[key] = [None] * self.PROBE_REPLAYS          # (events released; the count stops further probing)
+        if replay_ms > eager_ms * 1.05 + self.WATCHDOG_MS:
+            entry = self._graphs.pop(key, None)
+            if entry is not None:
+                t2v_hip.err_release(entry[-1])
+            self._no_graph[key] = (replay_ms, eager_ms)
+            self.graph_fallbacks += 1
+            print("TrainEngine: the captured graph of this batch shape replays in %.2f ms, the same step issued eagerly takes "
+                  "%.2f ms — the graph executor serialised independent branches; the shape keeps running eagerly" % (replay_ms, eager_ms),
+                  flush=True)
 
     MAX_SEEN = 4096
 
@@ -457,6 +540,7 @@ class TrainEngine(object):
             t2v_hip.err_release(self._graphs[old][-1])       # its ledger block goes back to the free list
             del self._graphs[old]
             self._seen.pop(old, None)
+            self._probe.pop(old, None)          # (a shape that comes back is warmed up, captured and probed again)
 
     def _drop_graphs(self):
         import t2v_hip
@@ -470,6 +554,10 @@ class TrainEngine(object):
             for k in list(self._seen)[:len(self._seen) // 2]:
                 if k not in self._graphs:
                     del self._seen[k]
+                    self._probe.pop(k, None)
+        if len(self._no_graph) > self.MAX_SEEN:
+            for k in list(self._no_graph)[:len(self._no_graph) // 2]:
+                del self._no_graph[k]
 
     def _after_replay(self, static_out, no_grad, span=None):
         """the captured graph writes its scalars (loss, recon, kl[, grad_norm]) into static tensors that the NEXT replay
