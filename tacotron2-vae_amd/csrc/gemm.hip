@@ -202,6 +202,18 @@ unsigned* t2v_arrival_counters(int tiles) {
 // split until ~2 workgroups per CU are in flight, with >= 8 k-tiles left per split
 static int gemm_splits(int M, int N, int K) {
     const long tiles = (long)((M + GM_BM - 1) / GM_BM) * ((N + GM_BN - 1) / GM_BN);
+    // round 5: also launches of up to one workgroup per CU, from 4 k-tiles per split on — the Prenet weight gradient (256 tiles,
+    // K = T*B), the BiLSTM weight gradients (128 tiles, K = B*T_in = 504): 11.34 -> 11.29 ms per fp32 step, two alternating pairs
+    // (T2V_GEMM_SPLIT_POLICY=0: the round-4 rule below)
+    static const int wide = getenv("T2V_GEMM_SPLIT_POLICY") ? atoi(getenv("T2V_GEMM_SPLIT_POLICY")) : 1;
+    if (wide) {
+        if (tiles > 256 || K < 8 * GM_BK) return 1;
+        long ns2 = (512 + tiles - 1) / tiles;
+        const long maxk2 = K / (4 * GM_BK);
+        if (ns2 > maxk2) ns2 = maxk2;
+        if (ns2 > 32) ns2 = 32;
+        return ns2 < 2 ? 1 : (int)ns2;
+    }
     if (tiles >= 256 || K < 16 * GM_BK) return 1;
     long ns = 512 / tiles;
     const long maxk = K / (8 * GM_BK);

@@ -379,6 +379,7 @@ class TrainEngine(object):
         import t2v_hip
         self._err_mark = t2v_hip.err_mark()
         self._err_span = None
+        self._pending_key = None        # (a calibration request never outlives the step that made it)
         opt = self.optimizer
         if learning_rate is not None:
             opt.param_groups[0]['lr'] = learning_rate
