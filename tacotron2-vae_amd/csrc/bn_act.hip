@@ -29,7 +29,36 @@ struct BnFwdArgs {
     float p_drop, momentum, eps;
     uint64_t seed; uint32_t rng_stream, rng_t;
     const t2v_step_params* step;
+    int chunk;               // gridDim.y > 1: elements of a channel per workgroup (blockIdx.y takes [y*chunk, (y+1)*chunk))
 };
+
+// Partial statistics of wide channels (round 5): the reference encoder's first two layers have 32 channels of B*H*W = 48 000
+// (B = 6) .. 128 000 (B = 16) values; one workgroup per channel made k_bn_act_fwd a 46 .. 105 us launch on 32 CUs, on the chain
+// that bounds the start of the decoder.  Workgroup (m, s) sums elements [s*chunk, (s+1)*chunk) of channel m; k_bn_act_fwd
+// finalises them like a convolution's partials and applies the normalisation with the same (m, s) grid.
+__global__ __launch_bounds__(256) void k_bn_stat_part(const float* __restrict__ y, float* __restrict__ part, int B, int M, int T, int chunk) {
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const int nel = B * T, lo = blockIdx.y * chunk, hi = min(nel, lo + chunk);
+    __shared__ float scr[4];
+    float ls = 0.f, lq = 0.f;
+    for (int i0 = lo; i0 < hi; i0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i = i0 + tid + 256 * e, ic = min(i, hi - 1);
+            const int b = ic / T, t = ic - b * T;
+            v[e] = y[((size_t)b * M + m) * T + t];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (i0 + tid + 256 * e < hi) { ls += v[e]; lq = fmaf(v[e], v[e], lq); }
+    }
+    const float s = block_sum_256(ls, scr), q = block_sum_256(lq, scr);
+    if (tid == 0) {
+        part[((size_t)blockIdx.y * M + m) * 2] = s;
+        part[((size_t)blockIdx.y * M + m) * 2 + 1] = q;
+    }
+}
 
 #define BN_NE 12      // fast path: channels of up to 256*12 values are held in registers
 #define BN_UN 8       // larger channels: loads in flight per thread and pass
@@ -85,7 +114,7 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(BnFwdArgs a) {
         if (var < 0.0) var = 0.0;
         mean = (float)mu;
         rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-        if (tid == 0) {
+        if (tid == 0 && blockIdx.y == 0) {
             a.mean_out[m] = mean;
             a.rstd_out[m] = rstd;
             a.running_mean[m] = (1.f - a.momentum) * a.running_mean[m] + a.momentum * mean;
@@ -96,6 +125,31 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(BnFwdArgs a) {
         rstd = 1.0f / sqrtf(a.running_var[m] + a.eps);
     }
     const float g = a.gamma[m] * rstd, bt = a.beta[m] - mean * a.gamma[m] * rstd;
+    if (gridDim.y > 1) {        // a slice of a wide channel
+        const int nel = a.B * a.T, lo = blockIdx.y * a.chunk, hi = min(nel, lo + a.chunk);
+        for (int i0 = lo; i0 < hi; i0 += 256 * BN_UN) {
+            size_t off[BN_UN];
+            float yv[BN_UN];
+#pragma unroll
+            for (int e = 0; e < BN_UN; ++e) {
+                const int i = i0 + tid + 256 * e, ic = min(i, hi - 1);
+                const int b = ic / a.T, t = ic - b * a.T;
+                off[e] = ((size_t)b * a.M + m) * a.T + t;
+                yv[e] = a.y[off[e]];
+            }
+#pragma unroll
+            for (int e = 0; e < BN_UN; ++e) {
+                if (i0 + tid + 256 * e < hi) {
+                    float z = fmaf(yv[e], g, bt);
+                    if (a.act == ACT_TANH) z = tanhf_(z);
+                    else if (a.act == ACT_RELU) z = fmaxf(z, 0.f);
+                    if (a.training && a.p_drop > 0.f) z *= t2v_drop_scale(t2v_step_seed(a.seed, a.step), a.rng_stream, a.rng_t, (uint32_t)off[e], a.p_drop);
+                    a.out[off[e]] = z;
+                }
+            }
+        }
+        return;
+    }
     const int n = a.B * a.T;
     if (n <= 256 * BN_NE) {
         // a channel is only a few thousand values: every thread requests ALL of its elements before touching any
@@ -259,6 +313,33 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd(BnBwdArgs a) {
     }
 }
 
+// library-owned ring for the partial statistics above (a few hundred floats per launch; a slice comes round again 4 MB later —
+// a captured graph keeps the slices of its nodes, and graphs / eager steps of one engine never run at the same time)
+#include <atomic>
+static float* bn_part_scratch(size_t floats) {
+    constexpr size_t RING = (size_t)1 << 20;
+    static float* ring = nullptr;
+    static std::atomic<size_t> pos{0};
+    static std::atomic<int> state{0};
+    floats = (floats + 63) & ~(size_t)63;
+    if (floats > RING / 4) return nullptr;
+    if (state.load(std::memory_order_acquire) != 2) {
+        int expect = 0;
+        if (state.compare_exchange_strong(expect, 1)) {
+            float* p = nullptr;
+            if (hipMalloc((void**)&p, RING * sizeof(float)) != hipSuccess) { state.store(0); return nullptr; }
+            ring = p;
+            state.store(2, std::memory_order_release);
+        } else {
+            while (state.load(std::memory_order_acquire) == 1) { }
+            if (state.load() != 2) return nullptr;
+        }
+    }
+    size_t at = pos.fetch_add(floats) % RING;
+    if (at + floats > RING) { pos.store(floats); at = 0; }
+    return ring + at;
+}
+
 extern "C" int t2v_bn_act_fwd(const float* y, const float* stat_part, int nblk, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float* mean_out, float* rstd_out, float* out,
                               int B, int M, int T, int act, int training, float p_drop, float momentum, float eps,
@@ -271,6 +352,29 @@ extern "C" int t2v_bn_act_fwd(const float* y, const float* stat_part, int nblk, 
     a.running_mean = running_mean; a.running_var = running_var; a.mean_out = mean_out; a.rstd_out = rstd_out;
     a.out = out; a.B = B; a.M = M; a.T = T; a.act = act; a.training = training; a.p_drop = p_drop;
     a.momentum = momentum; a.eps = eps; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
+    a.chunk = 0;
+    // few wide channels without partials from a convolution's epilogue (BatchNorm2d of the reference encoder): cut every channel
+    // over gridDim.y (T2V_BN_SPLIT=0: one workgroup per channel as before)
+    static const int split_on = getenv("T2V_BN_SPLIT") ? atoi(getenv("T2V_BN_SPLIT")) : 1;
+    const long nel = (long)B * T;
+    if (split_on && training && !stat_part && M <= 128 && nel >= 16384) {
+        long S = (nel + 4095) / 4096;                   // >= 4096 values per workgroup ...
+        if (S * M > 1024) S = 1024 / M;                 // ... and at most ~4 workgroups per CU
+        if (S > 64) S = 64;
+        if (S >= 2) {
+            float* part = bn_part_scratch((size_t)S * M * 2);
+            if (part) {
+                a.chunk = (int)(((nel + S - 1) / S + 255) / 256 * 256);
+                const int Sy = (int)((nel + a.chunk - 1) / a.chunk);
+                k_bn_stat_part<<<dim3(M, Sy), 256, 0, stream>>>(y, part, B, M, T, a.chunk);
+                a.stat_part = part;
+                a.nblk = Sy;
+                k_bn_act_fwd<<<dim3(M, Sy), 256, 0, stream>>>(a);
+                return t2v_check_launch();
+            }
+            a.chunk = 0;
+        }
+    }
     k_bn_act_fwd<<<M, 256, 0, stream>>>(a);
     return t2v_check_launch();
 }

@@ -132,7 +132,9 @@ def _coord_channels(B, H, W):
 @pytest.mark.parametrize("gemm_form", [True, False])
 @pytest.mark.parametrize("B,Cx,H,W,Cout,coord", [(6, 1, 400, 80, 32, True), (6, 32, 200, 40, 32, False), (3, 32, 100, 20, 64, False),
                                                  (6, 64, 25, 5, 128, False), (6, 128, 13, 3, 128, False), (2, 5, 9, 7, 6, True),
-                                                 (2, 3, 2, 2, 4, False)])
+                                                 (2, 3, 2, 2, 4, False),
+                                                 # B = 16 (configs[4]): the wide channels whose BatchNorm is cut over several workgroups
+                                                 (16, 1, 400, 80, 32, True), (16, 32, 200, 40, 32, False), (5, 32, 199, 41, 32, False)])
 def test_conv2d_s2_bn_relu_matches_torch(B, Cx, H, W, Cout, coord, gemm_form):
     """One reference-encoder layer (modules.py:68-71: [CoordConv +] Conv2d 3x3 stride 2 pad 1 -> BatchNorm2d (train) -> ReLU), output
     and all five gradients, in both forms: im2col + batched MFMA GEMM (round 3, default) and the direct-form kernels."""
