@@ -132,29 +132,39 @@ __device__ __forceinline__ void q16_gemv_role(const Q16Args& a, float* lds, cons
     // ---- weights: tile m, A row = output column col = 128 cg + 16 m + (lane & 15); this wave's k-blocks kb = 32 q + 4 wave + i,
     // 8 consecutive k = 32 kb + 8 g + e -> unit = k >> 2, gate = k & 3 -> gate row gate * 1024 + unit
     q16_u32x4 wreg[8][4];
+    {
+        // (32-bit buffer offsets, one tile's 32 values in flight at a time: with 64-bit addresses the compiler kept the 32 row offsets
+        // of BOTH matrices live across the unrolled tiles, ran out of registers and spilled every loaded value on arrival — 256
+        // serialised round trips per launch and 280 B/lane of scratch in the kernel's resource record)
+        const __amdgpu_buffer_rsrc_t rHH = q16_rsrc(DEC ? a.w_hh_dec : a.w_hh_att), rIH = q16_rsrc(DEC ? a.w_ih_dec : a.w_ih_att);
+        unsigned chain = 0;     // always 0, but data-dependent on the previous tile's last packed word: its address arithmetic cannot be hoisted
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const int col = 128 * cg + 16 * m + n;
-        const float* base;
-        size_t ld;
-        if (!DEC) {
-            if (col < T2V_H) { base = a.w_hh_att + col; ld = T2V_H; }
-            else { base = a.w_ih_att + T2V_PRE + (col - T2V_H); ld = T2V_PRE + T2V_E; }
-        } else {
-            if (col < T2V_H) { base = a.w_hh_dec + col; ld = T2V_H; }
-            else { base = a.w_ih_dec + (col - T2V_H); ld = T2V_KATT; }
-        }
+        for (int m = 0; m < 8; ++m) {
+            const int col = 128 * cg + 16 * m + n;
+            const bool hh = 128 * cg + 16 * m < T2V_H;         // (a 16-column tile never straddles the two matrices)
+            const unsigned ld = hh ? (unsigned)T2V_H : (DEC ? (unsigned)T2V_KATT : (unsigned)(T2V_PRE + T2V_E));
+            const unsigned c0 = hh ? (unsigned)col : (DEC ? (unsigned)(col - T2V_H) : (unsigned)(T2V_PRE + col - T2V_H));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k0 = 32 * (32 * q + 4 * wave + i) + 8 * g;
-            float wv[8];
+            for (int h = 0; h < 2; ++h) {               // two k-blocks = 16 values in flight, then the next two
+                float wv[2][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = k0 + e;
-                wv[e] = base[(size_t)((k & 3) * T2V_H + (k >> 2)) * ld];
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int i = 2 * h + ii;
+                    const unsigned unit0 = (unsigned)(32 * (32 * q + 4 * wave + i) + 8 * g) >> 2;     // k = 4 unit + gate; 8 k = 2 units x 4 gates
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned row = (unsigned)(e & 3) * T2V_H + unit0 + (unsigned)(e >> 2);
+                        const unsigned off = (row * ld + c0) * 4u + chain;
+                        wv[ii][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(hh ? rHH : rIH, (int)off, 0, 0));
+                    }
+                }
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const uint4 u = t2v_pack_bf16x8(make_float4(wv[ii][0], wv[ii][1], wv[ii][2], wv[ii][3]), make_float4(wv[ii][4], wv[ii][5], wv[ii][6], wv[ii][7]));
+                    wreg[m][2 * h + ii] = q16_u32x4{u.x, u.y, u.z, u.w};
+                }
+                asm volatile("v_and_b32 %0, 0, %1" : "=v"(chain) : "v"(wreg[m][2 * h + 1].x));
             }
-            const uint4 u = t2v_pack_bf16x8(make_float4(wv[0], wv[1], wv[2], wv[3]), make_float4(wv[4], wv[5], wv[6], wv[7]));
-            wreg[m][i] = q16_u32x4{u.x, u.y, u.z, u.w};
         }
     }
     if (tid == 0) flag[0] = 1;
