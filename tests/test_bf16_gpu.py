@@ -175,7 +175,7 @@ def test_model_bf16_vs_fp32_build(golden_dir):
         print('bf16 vs fp32: mel L1 %.4f, postnet-out L1 %.4f (mean |postnet out| %.3f)' % (
             (outs['bf16'][0] - outs['fp32'][0]).abs().mean().item(), d_post, outs['fp32'][1].abs().mean().item()))
         # random-init Postnet: five BatchNorm layers re-normalise (and so amplify) the rounding noise
-        assert d_post < 3e-2 * max(1.0, outs['fp32'][1].abs().mean().item())
+        assert d_post < 2e-2            # (the same 2e-2 behind the Postnet; measured 0.0123 at mean |out| 0.80)
         assert (outs['bf16'][3] - outs['fp32'][3]).abs().max().item() < 2e-2         # alignments
         # same optimisation trajectory to within bf16 noise
         for a, b in zip(losses['bf16'], losses['fp32']):
@@ -235,7 +235,7 @@ def test_bf16_at_config5_shape_b16_t400():
         d_post = (outs['bf16'][1] - outs['fp32'][1]).abs().mean().item()
         print('bf16 B=16 T=400: mel L1 %.4f, postnet-out L1 %.4f' % (d_mel, d_post))
         assert d_mel < 2e-2                                              # SURVEY cfg-5 bound on the decoder mel
-        assert d_post < 3e-2 * max(1.0, outs['fp32'][1].abs().mean().item())
+        assert d_post < 2e-2                                             # ... and behind the Postnet (measured 0.0122)
         assert (outs['bf16'][3] - outs['fp32'][3]).abs().max().item() < 2e-2          # alignments
         for a, b in zip(losses['bf16'], losses['fp32']):
             assert abs(a - b) < 2e-2 * abs(b)
