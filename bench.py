@@ -487,7 +487,7 @@ def run_workload(args, world, rank, bf16, koemo, steps, warmup, graph, eager_ste
                     engine.step(batch, it)
                     it += 1
                 sync()
-                t1 = time.perf_counter()
+                t1 = time.perf_counter()        # (host clock from a drained queue: includes the issue time of the first step)
                 for _ in range(eager_steps):
                     engine.step(batch, it)
                     it += 1
@@ -560,8 +560,9 @@ def main():
                          'after --cpu-all-cores-timeout on the quota-limited GPU boxes)')
     ap.add_argument('--cpu-probe-threads', type=int, default=16,
                     help='second CPU figure of the default run: ONE oracle step with this many threads (0 = skip)')
-    ap.add_argument('--eager-steps', type=int, default=5,
-                    help='eager steps timed next to the graph replays (graph_vs_eager_ms; 0 = skip)')
+    ap.add_argument('--eager-steps', type=int, default=30,
+                    help='eager steps timed next to the graph replays (graph_vs_eager_ms; 0 = skip).  30: the first eager steps '
+                         'after a sync refill the launch queue — with 5 steps that start-up read as +0.4 ms per step')
     ap.add_argument('--no-decode', action='store_true')
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the secondary workloads (koemo length profile, bf16 B=16) and the front-end leg')
