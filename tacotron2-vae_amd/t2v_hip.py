@@ -1286,11 +1286,12 @@ class DecoderCore(torch.autograd.Function):
                     with torch.cuda.stream(overlap().stream('d')):
                         gemm(dgd2.t(), x_cur[:, :KATT].t(), out=d_w_ih_dec, accumulate=not first)
                         gemm(dgd2.t(), x_cur[:, KATT:].t(), out=d_w_hh_dec, accumulate=not first)
-                # the attention weight gradients on a stream of their own (round 5: the captured DAG's longest path behind the
-                # reverse pass was THIS stream's serial order — Prenet data gradient, these ~450 us, the Prenet backward, the
-                # BiLSTM and encoder-conv weight gradients, 1.74 ms — with 0.26 ms of slack on the encoder's backward chain;
-                # tools/graph_critical_path.py)
-                with side('d', keep=(dq_sum, DV, dpre, AL, ACUM), after=fork):
+                # the attention weight gradients stay on the deferred-work stream.  (Round 5: the captured DAG's longest path behind the
+                # reverse pass is this stream's serial order — Prenet data gradient, these ~450 us, the Prenet backward, the BiLSTM
+                # and encoder-conv weight gradients: 1.3 .. 1.7 ms — so they were tried on a stream of their own, T2V_ATTN_WGRAD_STREAM=d:
+                # fp32 step 11.24 -> 11.36 ms, bf16 12.86 -> 12.91, two alternating pairs of 60 steps.  A fifth concurrent branch on
+                # the graph executor's four queues costs more than the shorter path buys; tools/graph_critical_path.py)
+                with side(os.environ.get('T2V_ATTN_WGRAD_STREAM', 'w'), keep=(dq_sum, DV, dpre, AL, ACUM), after=fork):
                     d_wq = gemm(dq_sum.t(), x_cur[:, :H].t())            # (128,1024)
                     d_v = DV.sum((0, 1)).view(1, A)
                     d_loc_dense, d_loc_conv = attn_wgrad(dpre, AL, ACUM, loc_conv, loc_dense, B, T_in, T)

@@ -122,6 +122,7 @@ class TrainEngine(object):
         self.graph_watchdog = os.environ.get('T2V_GRAPH_WATCHDOG', '1') != '0'
         self._probe = {}            # shape key -> [(start, end) events of the first replays] (None entries once decided)
         self._no_graph = {}         # shape key -> (replay ms, eager ms) of a graph that was dropped
+        self._suspect = {}          # shape key -> eager ms of a graph that lost the first comparison and is being re-timed
         self._pending_key = None
         self.graph_fallbacks = 0
         self._test_replay_drag_us = 0   # tests: a kernel that holds 8 workgroups for this long behind every probed replay
@@ -484,10 +485,13 @@ class TrainEngine(object):
 
     # -- replay watchdog (see __init__)
     PROBE_REPLAYS = 3           # the first replay (executor set-up) is not counted
+    PROBE_CONFIRM = 3           # replays timed behind the eager comparison step before a suspect graph is dropped
     WATCHDOG_MS = 0.5
 
     def _probe_begin(self, key):
-        if not self.graph_watchdog or len(self._probe.get(key, ())) >= self.PROBE_REPLAYS:
+        # PROBE_REPLAYS replays in front of the eager comparison step, PROBE_CONFIRM more behind it (a suspect graph only)
+        n = len(self._probe.get(key, ()))
+        if not self.graph_watchdog or n >= self.PROBE_REPLAYS + self.PROBE_CONFIRM or (n >= self.PROBE_REPLAYS and key not in self._suspect):
             return None
         t0 = torch.cuda.Event(enable_timing=True)
         t0.record()
@@ -501,34 +505,50 @@ class TrainEngine(object):
             t2v_hip.load_library().t2v_debug_spin(8, int(self._test_replay_drag_us), t2v_hip._stream())
         t1 = torch.cuda.Event(enable_timing=True)
         t1.record()
-        self._probe.setdefault(key, []).append((t0, t1))
+        probes = self._probe.setdefault(key, [])
+        probes.append((t0, t1))
+        if key in self._suspect and len(probes) == self.PROBE_REPLAYS + self.PROBE_CONFIRM:
+            self._watchdog_confirm(key)
 
     def _calibration_due(self, key):
         """True exactly once per captured shape: when its probed replays are in and the eager comparison step is still to come"""
         probes = self._probe.get(key)
-        if not self.graph_watchdog or probes is None or len(probes) < self.PROBE_REPLAYS or probes[-1] is None:
+        if (not self.graph_watchdog or probes is None or len(probes) != self.PROBE_REPLAYS or probes[-1] is None
+                or key in self._suspect):
             return False
         self._pending_key = key
         return True
 
     def _watchdog_decide(self, key, e0, e1):
-        import t2v_hip
+        """after the eager comparison step: a graph that lost is SUSPECT — PROBE_CONFIRM more replays are timed before it is dropped
+        (one slow pair of replays next to one lucky eager step is noise, e.g. with a neighbour process on the GPU)"""
         probes = self._probe.get(key)
         if not probes or probes[-1] is None:
             return
         e1.synchronize()
         eager_ms = e0.elapsed_time(e1)
         replay_ms = min(a.elapsed_time(b) for a, b in probes[1:])
-        self._probe[key] = [None] * self.PROBE_REPLAYS          # (events released; the count stops further probing)
+        if replay_ms > eager_ms * 1.05 + self.WATCHDOG_MS:
+            self._suspect[key] = eager_ms
+        else:
+            self._probe[key] = [None] * (self.PROBE_REPLAYS + self.PROBE_CONFIRM)       # (events released; the count stops further probing)
+
+    def _watchdog_confirm(self, key):
+        import t2v_hip
+        probes = self._probe[key]
+        probes[-1][1].synchronize()
+        eager_ms = self._suspect.pop(key)
+        replay_ms = min(a.elapsed_time(b) for a, b in probes[1:])
+        self._probe[key] = [None] * (self.PROBE_REPLAYS + self.PROBE_CONFIRM)
         if replay_ms > eager_ms * 1.05 + self.WATCHDOG_MS:
             entry = self._graphs.pop(key, None)
             if entry is not None:
                 t2v_hip.err_release(entry[-1])
             self._no_graph[key] = (replay_ms, eager_ms)
             self.graph_fallbacks += 1
-            print("TrainEngine: the captured graph of this batch shape replays in %.2f ms, the same step issued eagerly takes "
-                  "%.2f ms — the graph executor serialised independent branches; the shape keeps running eagerly" % (replay_ms, eager_ms),
-                  flush=True)
+            print("TrainEngine: the captured graph of this batch shape replays in %.2f ms (best of %d), the same step issued eagerly takes "
+                  "%.2f ms — the graph executor serialised independent branches; the shape keeps running eagerly" % (
+                      replay_ms, len(probes) - 1, eager_ms), flush=True)
 
     MAX_SEEN = 4096
 
@@ -542,6 +562,7 @@ class TrainEngine(object):
             del self._graphs[old]
             self._seen.pop(old, None)
             self._probe.pop(old, None)          # (a shape that comes back is warmed up, captured and probed again)
+            self._suspect.pop(old, None)
 
     def _drop_graphs(self):
         import t2v_hip

@@ -45,8 +45,10 @@ def _worker(rank, world, port, mode, out_dir):
     # T2V_TRAIN_PERSISTENT=0: the two ranks of this test share ONE GPU; the persistent decoder forward needs all 256 CUs
     # to itself (its workgroups spin on each other), so two of them launched by two processes can starve each other
     # until the bounded spins give up.  One process per GPU — the production layout — has no such neighbour.
+    # T2V_GRAPH_WATCHDOG=0: for the same reason step times here are noise (50 .. 60 ms with the neighbour's kernels in between), and a
+    # replay that happens to lose to one eager step by 10 % must not make the engine under test drop its graph
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0', T2V_TRAIN_PERSISTENT='0')
+                      LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0', T2V_TRAIN_PERSISTENT='0', T2V_GRAPH_WATCHDOG='0')
     import torch.distributed as dist
     import distributed as D
     import hparams as HP

@@ -311,7 +311,8 @@ def test_persistent_timeout_skips_the_update_and_the_engine_reruns_the_step(grap
 def test_replay_watchdog_drops_a_graph_that_is_slower_than_the_eager_step():
     """VERDICT r4 weak 8 / DESIGN 4.0f: how the branches of a captured step share the runtime's queues is the graph executor's
     decision.  The engine times the second / third replay of a new graph, issues the step after them eagerly once and times it
-    the same way; a graph that loses by more than 0.5 ms + 5 % is dropped and the shape keeps running eagerly.  Here the probed replays are made slow by a kernel that holds 8 workgroups for 4 ms behind each of them; the training
+    the same way; a graph that loses by more than 0.5 ms + 5 % is suspect, three more replays are timed, and if the best of all
+    still loses the graph is dropped and the shape keeps running eagerly.  Here the probed replays are made slow by a kernel that holds 8 workgroups for 4 ms behind each of them; the training
     trajectory must not notice (graph and eager steps are the same arithmetic, bit for bit)."""
     import hparams as HP
     import train as TR
@@ -328,7 +329,7 @@ def test_replay_watchdog_drops_a_graph_that_is_slower_than_the_eager_step():
         eng.model.vae_gst.eps_override = torch.full((3, 32), 0.125, device='cuda')
         losses = []
         with eng.stream_context():
-            for it in range(8):
+            for it in range(12):       # 2 warm-ups, capture + 3 timed replays, 1 eager comparison step, 3 confirming replays, 2 more
                 losses.append(eng.step(batch, it)[0])
         torch.cuda.synchronize()
         return eng, [float(x) for x in losses], eng.optimizer.params.clone()
