@@ -134,7 +134,8 @@ def _coord_channels(B, H, W):
                                                  (6, 64, 25, 5, 128, False), (6, 128, 13, 3, 128, False), (2, 5, 9, 7, 6, True),
                                                  (2, 3, 2, 2, 4, False),
                                                  # B = 16 (configs[4]): the wide channels whose BatchNorm is cut over several workgroups
-                                                 (16, 1, 400, 80, 32, True), (16, 32, 200, 40, 32, False), (5, 32, 199, 41, 32, False)])
+                                                 (16, 1, 400, 80, 32, True), (16, 32, 200, 40, 32, False), (5, 32, 199, 41, 32, False),
+                                                 (9, 1, 100, 80, 6, True)])
 def test_conv2d_s2_bn_relu_matches_torch(B, Cx, H, W, Cout, coord, gemm_form):
     """One reference-encoder layer (modules.py:68-71: [CoordConv +] Conv2d 3x3 stride 2 pad 1 -> BatchNorm2d (train) -> ReLU), output
     and all five gradients, in both forms: im2col + batched MFMA GEMM (round 3, default) and the direct-form kernels."""
@@ -148,11 +149,14 @@ def test_conv2d_s2_bn_relu_matches_torch(B, Cx, H, W, Cout, coord, gemm_form):
     gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     wo = torch.randn(B, Cout, Ho, Wo, generator=g)
-    ref = [t.clone().requires_grad_(True) for t in (x, w, b, gamma, beta)]
-    xin = torch.cat([ref[0], _coord_channels(B, H, W)], 1) if coord else ref[0]
-    rm, rv = torch.zeros(Cout), torch.ones(Cout)
+    # the reference in float64: torch's fp32 BatchNorm backward on the CPU is itself off by up to 6e-2 of the largest x-gradient on
+    # few wide channels (seen at B=9, 1+3 -> 6 channels of 18 000 values: the HIP kernels sat 1e-7 from the fp64 result, the fp32
+    # reference 6e-2 — found by tools/dbg/fuzz_bn2d.py)
+    ref = [t.clone().double().requires_grad_(True) for t in (x, w, b, gamma, beta)]
+    xin = torch.cat([ref[0], _coord_channels(B, H, W).double()], 1) if coord else ref[0]
+    rm, rv = torch.zeros(Cout, dtype=torch.float64), torch.ones(Cout, dtype=torch.float64)
     y = torch.relu(F.batch_norm(F.conv2d(xin, ref[1], ref[2], stride=2, padding=1), rm, rv, ref[3], ref[4], True, 0.1, 1e-5))
-    (y * wo).sum().backward()
+    (y * wo.double()).sum().backward()
     old = t2v_hip.CONV2D_GEMM
     t2v_hip.CONV2D_GEMM = gemm_form
     try:
@@ -163,10 +167,10 @@ def test_conv2d_s2_bn_relu_matches_torch(B, Cx, H, W, Cout, coord, gemm_form):
         torch.cuda.synchronize()
     finally:
         t2v_hip.CONV2D_GEMM = old
-    assert (out.cpu() - y).abs().max().item() < 2e-4 * max(1.0, y.abs().max().item())
-    assert (drm.cpu() - rm).abs().max().item() < 1e-4 and (drv.cpu() - rv).abs().max().item() < 1e-3      # running statistics (bias included)
+    assert (out.cpu().double() - y).abs().max().item() < 2e-5 * max(1.0, y.abs().max().item())
+    assert (drm.cpu().double() - rm).abs().max().item() < 1e-5 and (drv.cpu().double() - rv).abs().max().item() < 1e-4      # running statistics (bias included)
     for name, r, d in zip(('x', 'weight', 'bias', 'gamma', 'beta'), ref, dev):
         if name == 'bias':
             continue          # train-mode BatchNorm cancels the conv bias: its gradient is zero up to round-off in both
         scale = max(r.grad.abs().max().item(), 1e-6)
-        assert (d.grad.cpu() - r.grad).abs().max().item() < 3e-3 * scale, name
+        assert (d.grad.cpu().double() - r.grad).abs().max().item() < 3e-4 * scale + 2e-7, name      # (+ an fp32 floor for gradients that all but cancel)
