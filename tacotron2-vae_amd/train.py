@@ -178,7 +178,23 @@ class TrainEngine(object):
         needs no hand-over with the caller's stream (an event round trip through the legacy default stream costs
         ≈1.7 ms per step on this stack — measured, tools/graph_probe.py).  No-op for an eager engine."""
         import contextlib
-        return torch.cuda.stream(self._stream) if self._stream is not None else contextlib.nullcontext()
+        if self._stream is None:
+            return contextlib.nullcontext()
+
+        @contextlib.contextmanager
+        def ctx():
+            # Round 5 (found by tools/dbg/fuzz_engine.py): the engine's stream is a non-blocking one — it does NOT order itself behind
+            # the legacy default stream.  Whatever the caller issued there so far (parameter initialisation, load_state_dict, the
+            # optimiser's arena copy, an eps_override) has to be finished before the first step reads it: without this wait the very
+            # first step of an engine that is stepped right after its construction could read half-initialised weights (one run in
+            # two on a small batch: loss 36.57 instead of 36.31, gradient norm 1e8, NaN from the second step on).  And the other way
+            # round on exit: the caller's stream waits for the steps before it reads the weights (checkpoint, validation).
+            outer = torch.cuda.current_stream()
+            self._stream.wait_stream(outer)
+            with torch.cuda.stream(self._stream):
+                yield
+            outer.wait_stream(self._stream)
+        return ctx()
 
     # -- forward + backward + gradient gather (no collective, no optimiser): what a multi-rank engine captures
     def _body_fb(self, x, y, iteration):

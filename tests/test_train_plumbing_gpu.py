@@ -344,3 +344,42 @@ def test_replay_watchdog_drops_a_graph_that_is_slower_than_the_eager_step():
     e2, l2, p2 = run(4000, watchdog=False)
     assert e2.graph_fallbacks == 0 and len(e2._graphs) == 1                            # switched off: nothing is probed
     assert l2 == l0
+
+
+def test_engine_stream_is_ordered_behind_what_the_caller_issued_before_the_first_step():
+    """Found by tools/dbg/fuzz_engine.py: the graph engine runs every step on a non-blocking stream of its own, which does not order
+    itself behind the legacy default stream.  Work the caller issued there before entering `stream_context()` — parameter
+    initialisation, load_state_dict, the optimiser's arena copy — must be finished before the first step reads it, and the
+    caller's stream must see the finished steps when the context is left.  Here a parameter holds a placeholder (1e4) and its real
+    value is written on the default stream BEHIND a kernel that keeps that stream busy for 5 ms; an engine stream that does not
+    wait reads the placeholder (round-4 form of stream_context(): loss 1.6e8 instead of 34.32)."""
+    import hparams as HP
+    import t2v_hip as H
+    import train as TR
+    from bench import synthetic_batch
+    batch = synthetic_batch(3, 30, 40, 5, lens_in=[30, 22, 17], lens_out=[40, 33, 25])
+
+    def run(racy):
+        hp = HP.create_hparams("batch_size=3,anneal_function=constant,graph_step=True")
+        torch.manual_seed(hp.seed)
+        torch.cuda.manual_seed(hp.seed)
+        eng = TR.TrainEngine(hp)
+        eng.model.vae_gst.eps_override = torch.full((3, 32), 0.125, device='cuda')
+        p = eng.model.decoder.linear_projection.bias
+        good = p.data.clone()
+        torch.cuda.synchronize()
+        if racy:
+            p.data.fill_(1e4)
+            torch.cuda.synchronize()
+            H.load_library().t2v_debug_spin(8, 5000, H._stream())       # the default stream is busy for 5 ms ...
+            p.data.copy_(good)                                          # ... and only then writes what the first step reads
+        with eng.stream_context():
+            out = eng.step(batch, 0)
+            loss = out[0]
+        w = eng.optimizer.params.clone()        # (on the caller's stream, right after the context: must see the finished step)
+        torch.cuda.synchronize()
+        return float(loss), w
+
+    l0, w0 = run(False)
+    l1, w1 = run(True)
+    assert l1 == l0 and torch.equal(w1, w0), (l0, l1)
