@@ -383,3 +383,47 @@ def test_engine_stream_is_ordered_behind_what_the_caller_issued_before_the_first
     l0, w0 = run(False)
     l1, w1 = run(True)
     assert l1 == l0 and torch.equal(w1, w0), (l0, l1)
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=['fp32', 'bf16_run'])
+def test_recurring_ragged_shapes_graph_engine_equals_eager_engine(bf16):
+    """One engine, a stream of batches whose shapes recur irregularly — more distinct shapes (10) than the engine keeps graphs for
+    (8): capture on the third sighting, replay, eviction of the least recently used graph, re-capture, the replay watchdog's eager
+    comparison steps in between.  The trajectory must equal the eager engine's on the same batches bit for bit."""
+    import random
+    import hparams as HP
+    import t2v_hip as H
+    import train as TR
+    from bench import synthetic_batch
+    rng = random.Random(1)
+    B = 16 if bf16 else 6
+    shapes = []
+    for i in range(10):
+        T_in, T_out, Bs = rng.choice([5, 17, 33, 84, 130]), rng.randint(3, 20), rng.choice([B, B, max(1, B // 2), B - 1])
+        shapes.append((Bs, T_in, T_out, sorted([rng.randint(1, T_in) for _ in range(Bs - 1)] + [T_in], reverse=True),
+                       [T_out] + [rng.randint(1, T_out) for _ in range(Bs - 1)]))
+    order = [rng.randrange(len(shapes)) if rng.random() < 0.7 else rng.randrange(3) for _ in range(60)]
+    batches = {i: synthetic_batch(s[0], s[1], s[2], 10 + i, lens_in=s[3], lens_out=s[4]) for i, s in enumerate(shapes)}
+    res = {}
+    try:
+        for graph in (False, True):
+            hp = HP.create_hparams("batch_size=%d,anneal_function=constant%s" % (B, ",bf16_run=True" if bf16 else ""))
+            torch.manual_seed(hp.seed)
+            torch.cuda.manual_seed(hp.seed)
+            eng = TR.TrainEngine(hp, graph=graph)
+            # one eps tensor per batch size, alive for the whole run: a captured graph keeps the ADDRESS of the tensor it was captured with
+            eps = {b: torch.full((b, 32), 0.125, device='cuda') for b in {s[0] for s in shapes}}
+            losses = []
+            with eng.stream_context():
+                for it, k in enumerate(order):
+                    eng.model.vae_gst.eps_override = eps[shapes[k][0]]
+                    losses.append(eng.step(batches[k], it)[0].clone())
+            torch.cuda.synchronize()
+            H.check_async_errors()
+            res[graph] = ([float(x) for x in losses], eng.optimizer.params.clone(), len(eng._graphs))
+            eng.close()
+    finally:
+        H.set_bf16(False)
+    assert res[True][2] == TR.TrainEngine.MAX_GRAPHS                     # every slot in use: graphs were evicted and re-captured
+    assert res[True][0] == res[False][0]
+    assert torch.equal(res[True][1], res[False][1])
