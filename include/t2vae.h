@@ -256,6 +256,9 @@ int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, const float* 
  * (T_out, 16, 128).  err_word: set to 1 when a bounded spin gave up (results invalid). */
 int t2v_decoder_bwd_persist16_supported(int B, int T_in);
 int t2v_decoder_bwd_persist16_slices(int T_in);
+/* ... and at this T_out: 1 when every exchange array stays below the 2^31-byte reach of the kernel's buffer offsets (the widest
+ * one reaches it at T_out = 3 277) — what a caller asks before its FORWARD pass commits to this reverse pass. */
+int t2v_decoder_bwd_persist16_fits(int B, int T_in, int T_out);
 long t2v_decoder_bwd_persist16_scratch_floats(int B, int T_in, int T_out);
 long t2v_decoder_bwd_persist16_dq_offset(int B, int T_in, int T_out);
 int t2v_decoder_bwd_persistent16(const t2v_dec_train_persist_weights* w, const t2v_dec_train_bufs* s, const float* dHC,

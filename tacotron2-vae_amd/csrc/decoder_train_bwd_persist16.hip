@@ -744,11 +744,26 @@ extern "C" long t2v_decoder_bwd_persist16_dq_offset(int B, int T_in, int T_out) 
     return (long)(n[0] + n[1] + n[2] + n[3] + n[4]);
 }
 
+// 1 when the pass can run at this T_out as well: every array of the layout above (and DQP) is addressed with 31-bit buffer offsets.
+// What q16_run checks — exported so that a caller can choose the launch-per-step pass BEFORE the forward commits to this one
+// (the PD array reaches 2 GB at T_out = 3 277).
+static bool q16_offsets_ok(int B, int T_in, int T_out) {
+    size_t n[6];
+    q16_layout(B, T_in, T_out, n);
+    for (int i = 0; i < 6; ++i)
+        if (n[i] * 4 >= 0x7fffffffull) return false;
+    return (size_t)T_out * B * q16_slices(T_in) * 128 * 4 < 0x7fffffffull;
+}
+extern "C" int t2v_decoder_bwd_persist16_fits(int B, int T_in, int T_out) {
+    if (T_out < 1 || !t2v_decoder_bwd_persist16_supported(B, T_in)) return 0;
+    return q16_offsets_ok(B, T_in, T_out) ? 1 : 0;
+}
+
 // The preparation of the pass (error word, sentinel fills: 1.4 MB per time step) as a call of its own: it needs nothing but the
 // buffers, so a training step issues it on a side stream right behind the decoder forward, next to the Postnet
 extern "C" int t2v_decoder_bwd_persistent16_prepare(float* DQP, float* scratch, uint32_t* err_word, int B, int T_in, int T_out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!DQP || !scratch || !err_word || !t2v_decoder_bwd_persist16_supported(B, T_in) || T_out < 1) return T2V_ERR_ARG;
+    if (!DQP || !scratch || !err_word || !t2v_decoder_bwd_persist16_fits(B, T_in, T_out)) return T2V_ERR_ARG;
     if (((uintptr_t)scratch & 15) || ((uintptr_t)DQP & 15)) return T2V_ERR_ARG;
     size_t n[6];
     q16_layout(B, T_in, T_out, n);
@@ -773,9 +788,7 @@ static int q16_run(const t2v_dec_train_persist_weights* w, const t2v_dec_train_b
     const int S = q16_slices(T_in);
     const size_t n_dq = (size_t)T_out * B * S * 128;
     if (((uintptr_t)scratch & 15) || ((uintptr_t)DQP & 15)) return T2V_ERR_ARG;
-    for (int i = 0; i < 6; ++i)
-        if (n[i] * 4 >= 0x7fffffffull) return T2V_ERR_ARG;              // 31-bit buffer offsets
-    if (n_dq * 4 >= 0x7fffffffull) return T2V_ERR_ARG;
+    if (!q16_offsets_ok(B, T_in, T_out)) return T2V_ERR_ARG;              // 31-bit buffer offsets
     if (prepare) {
         const int rc = t2v_decoder_bwd_persistent16_prepare(DQP, scratch, err_word, B, T_in, T_out, stream_);
         if (rc != T2V_OK) return rc;

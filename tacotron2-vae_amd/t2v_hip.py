@@ -77,6 +77,7 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_stamp', 't2v_debug_spin', 't2v_
            't2v_decoder_train_fwd_persistent16', 't2v_decoder_train_persist16_supported',
            't2v_decoder_train_persist16_scratch_floats', 't2v_decoder_bwd_persistent16', 't2v_decoder_bwd_persist16_supported',
            't2v_decoder_bwd_persist16_scratch_floats', 't2v_decoder_bwd_persist16_dq_offset', 't2v_decoder_bwd_persist16_slices',
+           't2v_decoder_bwd_persist16_fits',
            't2v_decoder_bwd_persistent16_prepare', 't2v_decoder_bwd_persistent16_prepared')
 
 
@@ -125,6 +126,7 @@ def load_library():
     lib.t2v_decoder_bwd_persist16_dq_offset.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.t2v_decoder_bwd_persist16_dq_offset.restype = C.c_long
     lib.t2v_decoder_bwd_persist16_slices.argtypes = [C.c_int]
+    lib.t2v_decoder_bwd_persist16_fits.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.t2v_decoder_train_persist_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.t2v_decoder_train_persist_scratch_floats.restype = C.c_long
     lib.t2v_decoder_bwd_persist_supported.argtypes = [C.c_int, C.c_int]
@@ -954,11 +956,13 @@ class DecoderCore(torch.autograd.Function):
         gate = DecoderCore.persistent_bwd
         if gate is None:
             gate = os.environ.get('T2V_BWD_PERSISTENT', os.environ.get('T2V_TRAIN_PERSISTENT', '1')) != '0'
-        if not gate or not lib.t2v_decoder_bwd_persist16_supported(int(B), int(T_in)):
+        # ..._fits = supported(B, T_in) AND every exchange array below the kernel's 31-bit buffer offsets at this T_out (the
+        # same test q16_run makes: a long utterance falls back to the launch-per-step pass HERE, not after the forward)
+        if not gate or not lib.t2v_decoder_bwd_persist16_fits(int(B), int(T_in), int(T)):
             return False
         if flag != 'force' and DecoderCore.use_persistent_bwd(lib, B, T_in, T):
             return False
-        return 4 * lib.t2v_decoder_bwd_persist16_scratch_floats(int(B), int(T_in), int(T)) < 2 ** 33      # (per-array offsets are checked by the library)
+        return True
 
     @staticmethod
     def _fwd_chunk(lib, gpre, memory, pm, lengths, packs, bias_dec, wqT, wcomb, vv, need_grad, p_att, p_dec, seed, wbf=False,

@@ -154,7 +154,9 @@ class TrainEngine(object):
                 self._shadow = {n: p.detach().requires_grad_(True) for n, p in self.model.named_parameters()}
             self._shadow_live = [self._shadow[n] for n, _ in self.optimizer.arena_layout()[0]]
         self.model.train()
-        self.note_good_step()       # BatchNorm statistics as loaded: a time-out on the very first step has something to restore
+        # (the first BatchNorm snapshot for recover() is taken at the top of the FIRST step, not here: train() builds the engine and
+        # only then loads the checkpoint / warm start — a snapshot from construction time would hold freshly initialised statistics
+        # and a time-out on the first step after a resume would copy them over the loaded ones)
 
     def close(self):
         """unbind this engine's device-side step record from its streams (torch's pooled stream handles are reused)"""
@@ -248,7 +250,11 @@ class TrainEngine(object):
             # replayed step.  Ranks choose replay-or-eager from their own batch-shape history (ragged batches: every
             # rank sees different shapes), so the collective pattern must not depend on that choice — the bucketed
             # hook-issued exchange below belongs to the eager engine only
-            return self._reduce_and_step(self._body_fb(x, y, iteration))
+            fb = self._body_fb(x, y, iteration)
+            if self.__dict__.get('_calib_want'):      # the watchdog's eager comparison step: timed up to here, like a probed replay
+                self._calib_end = torch.cuda.Event(enable_timing=True)
+                self._calib_end.record()
+            return self._reduce_and_step(fb)
         import t2v_hip
         opt = self.optimizer
         opt.zero_grad()
@@ -318,6 +324,12 @@ class TrainEngine(object):
         t2v_hip.DecoderCore.persistent_bwd = False
         self._drop_graphs()
         self._seen.clear()
+        # the watchdog's timings belong to the graphs (and the kernel set) that just went: a re-captured graph on the launch-per-step
+        # kernels is probed from scratch, and a shape dropped because it lost against the old eager step gets another chance
+        self._probe.clear()
+        self._suspect.clear()
+        self._no_graph.clear()
+        self._pending_key = None
         if self._bn_snap is not None:
             torch._foreach_copy_(self._bn_bufs, self._bn_snap)
         self.optimizer.step_count = max(0, self.optimizer.step_count - 1)
@@ -397,6 +409,13 @@ class TrainEngine(object):
         self._err_mark = t2v_hip.err_mark()
         self._err_span = None
         self._pending_key = None        # (a calibration request never outlives the step that made it)
+        self._calib_end = None
+        for span in self.__dict__.pop('_release_later', ()):
+            t2v_hip.err_release(span)   # ledger block of a graph the watchdog dropped during the PREVIOUS step (its words were
+                                        # still that step's error record: released only now, after the caller's check)
+        if self._bn_snap is None:
+            self.note_good_step()       # BatchNorm statistics as loaded (checkpoint / warm start included): what a time-out on
+                                        # the very first step restores
         opt = self.optimizer
         if learning_rate is not None:
             opt.param_groups[0]['lr'] = learning_rate
@@ -428,11 +447,13 @@ class TrainEngine(object):
         if key is not None and self.graph_watchdog:      # the calibration step of a freshly captured shape (see __init__)
             t0 = torch.cuda.Event(enable_timing=True)
             t0.record()
+        self._calib_want = t0 is not None
         loss, recon, kl, grad_norm = self._body(x, y, iteration)
+        self._calib_want = False
         ev = torch.cuda.Event(enable_timing=t0 is not None)
         ev.record()
         if t0 is not None:
-            self._watchdog_decide(key, t0, ev)
+            self._watchdog_decide(key, t0, self._calib_end or ev)
         ring.append(ev)
         return loss, recon, kl, w, grad_norm
 
@@ -464,8 +485,9 @@ class TrainEngine(object):
         self._graphs[key] = self._graphs.pop(key)       # most recently used last
         t0 = self._probe_begin(key)
         entry[0].replay()
+        t1 = self._probe_mark(t0)
         out = self._after_replay(entry[2], entry[3], entry[4])
-        self._probe_end(key, t0)
+        self._probe_end(key, t0, t1)
         return out
 
     def _graph_step(self, x, y, iteration):
@@ -495,8 +517,9 @@ class TrainEngine(object):
                 dst.copy_(src, non_blocking=True)
         t0 = self._probe_begin(key)
         graph.replay()
+        t1 = self._probe_mark(t0)
         out = self._after_replay(static_out, no_grad, span)
-        self._probe_end(key, t0)
+        self._probe_end(key, t0, t1)
         return out
 
     # -- replay watchdog (see __init__)
@@ -513,14 +536,22 @@ class TrainEngine(object):
         t0.record()
         return t0
 
-    def _probe_end(self, key, t0):
+    def _probe_mark(self, t0):
+        """end of the probed region = right behind the replay, BEFORE _after_replay: in the multi-rank graph engine that call runs
+        the whole-arena all-reduce, whose duration depends on what the peer ranks are doing (warm-up, capture, their own
+        calibration) — the watchdog compares what this rank's executor did with the graph, nothing else"""
         if t0 is None:
-            return
+            return None
         import t2v_hip
         if self._test_replay_drag_us:
             t2v_hip.load_library().t2v_debug_spin(8, int(self._test_replay_drag_us), t2v_hip._stream())
         t1 = torch.cuda.Event(enable_timing=True)
         t1.record()
+        return t1
+
+    def _probe_end(self, key, t0, t1):
+        if t0 is None:
+            return
         probes = self._probe.setdefault(key, [])
         probes.append((t0, t1))
         if key in self._suspect and len(probes) == self.PROBE_REPLAYS + self.PROBE_CONFIRM:
@@ -559,7 +590,9 @@ class TrainEngine(object):
         if replay_ms > eager_ms * 1.05 + self.WATCHDOG_MS:
             entry = self._graphs.pop(key, None)
             if entry is not None:
-                t2v_hip.err_release(entry[-1])
+                # NOT released here: this is the graph that was replayed in this very step — its block holds the step's error
+                # words until the caller's check_async_errors() has run (_step releases it at the top of the next step)
+                self.__dict__.setdefault('_release_later', []).append(entry[-1])
             self._no_graph[key] = (replay_ms, eager_ms)
             self.graph_fallbacks += 1
             print("TrainEngine: the captured graph of this batch shape replays in %.2f ms (best of %d), the same step issued eagerly takes "

@@ -271,3 +271,113 @@ def test_bf16_at_config5_shape_b16_t400():
     finally:
         M.drop_rate = old
         t2v_hip.set_bf16(False)
+
+
+def test_config5_shape_both_builds_against_the_cpu_oracle():
+    """ONE run of the CPU oracle (the pinned restatement of the reference) at the configs[4] shape
+    (16, 84, 400), dropout off, and BOTH HIP builds compared with it DIRECTLY — the fp32 build (B = 16 is outside its persistent
+    range: launch-per-step kernels) at the fp32 bounds of the koemo test (mel-L1 < 1e-4, gradients within 3e-3 of a tensor's scale),
+    the bf16 build (k_dec_train_persist16 / k_bwd_persist16) at the stated bf16 bounds.
+
+    bf16 error model behind those bounds: under bf16_run every recurrent / dense product rounds both operands to bf16 (8 significant
+    bits, RNE: relative error <= 2^-9 per operand, rms 2^-9 / sqrt(3)) and accumulates in fp32, so one product term is off by
+    <= 2^-8 = 3.9e-3 relative, rms 1.6e-3, with independent signs.  A gradient ELEMENT is a sum over K >= 256 such terms (times
+    T·B = 6 400 for a weight gradient): its random part shrinks with sqrt(K), what survives in a tensor's NORM is the part of the
+    error that is correlated over the tensor (the rounded weights themselves, reused by every term), bounded by one operand's
+    2^-9·rms... <= 1 % with a factor 2.5 for the chain of products a gradient passes per time step; the DIRECTION error of a tensor is
+    eps_rel^2 / 2 with eps_rel = ||g16 - g_ref|| / ||g_ref|| <= 4.4e-2 => cosine >= 0.999.  Decoder tensors (what the two
+    persistent bf16 kernels and the LSTM dW GEMMs produce) are held to exactly that: norm within 1 %, cosine >= 0.999; tensors
+    behind five re-normalising BatchNorm layers (Postnet) or sums with heavy cancellation keep round 5's 3 % / 0.995."""
+    import sys
+    import hparams as HP
+    import model as M
+    import t2v_hip
+    import t2v_oracle as O
+    import train as TR
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic_batch
+    B, T_in, T = 16, 84, 400
+    batch = synthetic_batch(B, T_in, T, 77)
+    eps = torch.randn(B, 32, generator=torch.Generator().manual_seed(5))
+    old = M.drop_rate
+    M.drop_rate = 0.0
+    try:
+        res = {}
+        sd = None
+        for mode in ('fp32', 'bf16'):
+            hp = HP.create_hparams("batch_size=16,anneal_function=constant,p_attention_dropout=0.0,p_decoder_dropout=0.0,"
+                                   "bf16_run=%s" % (mode == 'bf16'))
+            torch.manual_seed(hp.seed)
+            eng = TR.TrainEngine(hp, graph=False)
+            eng.model.vae_gst.eps_override = eps.cuda()
+            if sd is None:
+                sd = {k: v.detach().cpu().clone() for k, v in eng.model.state_dict().items()}
+            eng.optimizer.zero_grad()
+            x, y = eng.model.parse_batch(batch)
+            y_pred = eng.model(x)
+            loss = eng.criterion(y_pred, y, 0)[0]
+            loss.backward()
+            torch.cuda.synchronize()
+            t2v_hip.check_async_errors()
+            res[mode] = dict(loss=float(loss), out=[t.detach().float().cpu() for t in y_pred[:4]],
+                             grads={n: p.grad.detach().float().cpu().clone() for n, p in eng.model.named_parameters() if p.grad is not None},
+                             kernels=(t2v_hip.DecoderCore.last_mode, t2v_hip.DecoderCore.last_kernel,
+                                      t2v_hip.DecoderCore.last_bwd_mode, t2v_hip.DecoderCore.last_bwd_kernel))
+            eng.close()
+            del eng, y_pred, loss
+        assert res['bf16']['kernels'] == ('persistent', 'k_dec_train_persist16', 'persistent', 'k_bwd_persist16'), res['bf16']['kernels']
+        assert res['fp32']['kernels'][0] == 'launch-per-step' and res['fp32']['kernels'][2] == 'launch-per-step'
+        # ---- the oracle, once (8 threads)
+        nthreads = torch.get_num_threads()
+        torch.set_num_threads(8)
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and 'running_' not in k}
+        osd = dict(sd)
+        osd.update(leaves)
+        text, lin, mel, gate, lout = batch[0].long(), batch[1].long(), batch[2].float(), batch[3].float(), batch[4].long()
+        o = O.tacotron2_forward(osd, text, lin, mel, lout, training=True, eps=eps)
+        o_loss = O.loss_forward(o, mel, gate, 0, anneal_function='constant')[0]
+        o_loss.backward()
+        torch.set_num_threads(nthreads)
+        ref = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+        gmax = max(float(v.norm()) for v in ref.values())
+        # ---- fp32 build: the fp32 bounds
+        r = res['fp32']
+        assert abs(r['loss'] - float(o_loss)) < 1e-4 * abs(float(o_loss))
+        assert (r['out'][0] - o[0].detach()).abs().mean().item() < 1e-4           # mel-L1 (BASELINE.json)
+        assert (r['out'][1] - o[1].detach()).abs().mean().item() < 1e-4
+        assert (r['out'][3] - o[3].detach()).abs().max().item() < 5e-5            # alignments
+        checked = 0
+        for n, g in r['grads'].items():
+            if n not in ref:
+                continue
+            scale = max(float(ref[n].norm()), 1e-4 * gmax)
+            assert float((g - ref[n]).norm()) < 3e-3 * scale, ('fp32 build', n)
+            checked += 1
+        assert checked >= 90
+        # ---- bf16 build: the stated bf16 bounds, against the ORACLE
+        r = res['bf16']
+        d_mel = (r['out'][0] - o[0].detach()).abs().mean().item()
+        d_post = (r['out'][1] - o[1].detach()).abs().mean().item()
+        assert d_mel < 2e-2 and d_post < 2e-2, (d_mel, d_post)                    # SURVEY cfg-5
+        assert (r['out'][3] - o[3].detach()).abs().max().item() < 2e-2
+        assert abs(r['loss'] - float(o_loss)) < 2e-2 * abs(float(o_loss))
+        worst = {'dec': [0.0, 1.0], 'other': [0.0, 1.0]}
+        for n, g in r['grads'].items():
+            if n not in ref or float(ref[n].norm()) < 1e-4 * gmax:
+                continue
+            g64, r64 = g.double(), ref[n].double()
+            rel = abs(float(g64.norm() / r64.norm()) - 1.0)
+            cos = float((g64 * r64).sum() / (g64.norm() * r64.norm()))
+            grp = 'dec' if n.startswith('decoder.') else 'other'
+            worst[grp][0] = max(worst[grp][0], rel)
+            worst[grp][1] = min(worst[grp][1], cos)
+            if grp == 'dec':
+                assert rel < 1e-2 and cos > 0.999, ('bf16 build, decoder tensor', n, rel, cos)
+            else:
+                assert rel < 3e-2, ('bf16 build', n, rel)
+                assert cos > (0.99 if '.bias' in n and 'convolutions' in n else 0.995), ('bf16 build', n, cos)
+        print('bf16 persist16 build vs CPU oracle at (16, 84, 400): mel L1 %.2e, postnet L1 %.2e; decoder tensors worst norm dev %.2e '
+              'cos %.5f; other tensors %.2e / %.5f' % (d_mel, d_post, worst['dec'][0], worst['dec'][1], worst['other'][0], worst['other'][1]))
+    finally:
+        M.drop_rate = old
+        t2v_hip.set_bf16(False)

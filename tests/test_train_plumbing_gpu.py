@@ -308,6 +308,55 @@ def test_persistent_timeout_skips_the_update_and_the_engine_reruns_the_step(grap
         H._ERR_INJECT[0] = None
 
 
+def test_timeout_on_the_first_step_after_a_resume_restores_the_loaded_batchnorm_statistics():
+    """train() builds the engine and THEN loads the checkpoint.  The BatchNorm snapshot recover() restores
+    from is therefore taken at the top of the first step, not at construction: a time-out on step 0 of a resumed run must bring
+    back the LOADED running statistics, not freshly initialised ones."""
+    import hparams as HP
+    import t2v_hip as H
+    import train as TR
+    from bench import synthetic_batch
+    batch = synthetic_batch(3, 30, 40, 11, lens_in=[30, 22, 17], lens_out=[40, 33, 25])
+    old = (H.DecoderCore.persistent, H.DecoderCore.persistent_bwd)
+    try:
+        hp = HP.create_hparams("batch_size=3,anneal_function=constant,graph_step=False")
+        torch.manual_seed(hp.seed)
+        torch.cuda.manual_seed(hp.seed)
+        eng = TR.TrainEngine(hp)
+        eng.model.vae_gst.eps_override = torch.full((3, 32), 0.125, device='cuda')
+        # "load a checkpoint" after construction: distinctive running statistics in every BatchNorm
+        sd = eng.model.state_dict()
+        loaded = {}
+        for n, b in sd.items():
+            if n.endswith('running_mean'):
+                loaded[n] = torch.full_like(b, 0.375)
+            elif n.endswith('running_var'):
+                loaded[n] = torch.full_like(b, 2.5)
+            elif n.endswith('num_batches_tracked'):
+                loaded[n] = torch.full_like(b, 1234)
+        assert len(loaded) >= 3 * 14
+        sd.update(loaded)
+        eng.model.load_state_dict(sd)
+        before = eng.optimizer.params.clone()
+        H._ERR_INJECT[0] = 'persistent kernel'
+        out = eng.step(batch, 0)                       # the failing first step, by hand (as in the test above)
+        torch.cuda.synchronize()
+        assert torch.equal(eng.optimizer.params, before)
+        moved = [n for n, b in eng.model.named_buffers() if n in loaded and not torch.equal(b, loaded[n])]
+        assert moved, "the failed forward pass must have touched the running statistics, else this test checks nothing"
+        with pytest.raises(H.T2VHipError) as ei:
+            H.check_async_errors()
+        assert eng.recover(ei.value)
+        for n, b in eng.model.named_buffers():
+            if n in loaded:
+                assert torch.equal(b, loaded[n]), n
+        # the watchdog forgets what it knew about the graphs that went (ADVICE r5, low)
+        assert not eng._probe and not eng._suspect and not eng._no_graph and eng._pending_key is None
+    finally:
+        H.DecoderCore.persistent, H.DecoderCore.persistent_bwd = old
+        H._ERR_INJECT[0] = None
+
+
 def test_replay_watchdog_drops_a_graph_that_is_slower_than_the_eager_step():
     """VERDICT r4 weak 8 / DESIGN 4.0f: how the branches of a captured step share the runtime's queues is the graph executor's
     decision.  The engine times the second / third replay of a new graph, issues the step after them eagerly once and times it
