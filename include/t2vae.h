@@ -476,6 +476,14 @@ int t2v_gemm_f32_splitk(const float* A, long sAi, long sAk, const float* B, long
                         float* C, int ldc, int M, int N, int K, int relu, int accumulate, float p_drop,
                         uint64_t seed, uint32_t rng_stream, uint32_t rng_t, float* splitk_scratch, void* stream);
 
+/* Round 6: how the LARGE fp32 products (>= 64 tiles of 128x128, 16-byte-aligned operand runs) are computed.
+ * mode 1 (default; T2V_F32_GEMM=native selects 0): "x3" — every fp32 operand is cut exactly into three bf16 values
+ * (a = a0 + a1 + a2) and the product is accumulated in fp32 from six v_mfma_f32_32x32x16_bf16 per k-block; the omitted
+ * cross terms are <= 2^-25 |a b|, below the rounding of one fp32 product: fp32-class results (same error bound against fp64
+ * as the fp32-MFMA kernel, tests/test_gemm_gpu.py) at up to 2.7x the fp32 matrix peak of gfx950 (which has no TF32 path).
+ * mode 0: v_mfma_f32_32x32x2_f32 for every product.  Pass -1 to query.  Returns the previous mode.  Process-wide. */
+int t2v_gemm_f32_set_mode(int x3);
+
 /* nbatch independent products C_z = A_z · B_z^T (z-th operands at A + z*sAb, B + z*sBb, C + z*sCb; element strides as in
  * t2v_gemm_f32, no bias / epilogue) in one launch.  Replaces the per-item loop that autograd's bmm backward of
  * `attention_context = torch.bmm(attention_weights.unsqueeze(1), memory)` (model.py:84-85) amounts to for d_memory. */

@@ -7,6 +7,7 @@
 // LDS, next tile's global loads in flight during the MFMAs.  Threads run along whichever index of an
 // operand is contiguous in memory so the staging loads are coalesced.
 #include <stdlib.h>
+#include <string.h>
 #include "t2v_common.h"
 #include "t2v_kernels.h"
 #include "t2v_coop.h"
@@ -221,8 +222,14 @@ static int gemm_splits(int M, int N, int K) {
     if (ns > 32) ns = 32;
     return ns < 2 ? 1 : (int)ns;
 }
+static bool gemm_x3_shape_ok(int M, int N, int K);
+static long gemm_x3_scratch_floats(int M, int N, int K);
+static int gemm_x3_mode();
 extern "C" long t2v_gemm_splitk_scratch_floats(int M, int N, int K) {
-    const int ns = (M < 1 || N < 1 || K < 1) ? 1 : gemm_splits(M, N, K);
+    if (M < 1 || N < 1 || K < 1) return 0;
+    // round 6: the x3 path takes the large products — its scratch holds the bf16 planes of both operands (+ split-K partial tiles)
+    if (gemm_x3_mode() && gemm_x3_shape_ok(M, N, K)) return gemm_x3_scratch_floats(M, N, K);
+    const int ns = gemm_splits(M, N, K);
     return ns > 1 ? (long)ns * M * N : 0;
 }
 
@@ -711,6 +718,316 @@ extern "C" long t2v_gemm_bf16_splitk_scratch_floats(int M, int N, int K) {
     return big > small ? big : small;
 }
 
+// ---- Round 6: fp32 GEMM on the bf16 matrix cores — "x3": every fp32 operand is cut, EXACTLY, into three bf16 values
+//      a = a0 + a1 + a2   (a0 = RNE_bf16(a), a1 = RNE_bf16(a - a0), a2 = a - a0 - a1: three 8-bit significands = the 24 bits of a float;
+//      both subtractions are exact in fp32, a2 is exactly representable in bf16)
+// and the product is accumulated in fp32 from SIX bf16 MFMAs per k-block:  a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0.
+// The three terms left out (a1b2, a2b1, a2b2) are <= 2^-25 |a b| each (|a1| <= 2^-9 |a|, |a2| <= 2^-17 |a|, random sign) — below the
+// rounding of ONE fp32 product (2^-24), so the result is fp32-class: the error against an fp64 reference is SMALLER than that of the
+// fp32 MFMA kernel above (v_mfma_f32_32x32x2_f32 rounds the running sum once per k, i.e. K times; here it is rounded six times per
+// SIXTEEN k) — measured 0.3x .. 0.8x, tests/test_gemm_gpu.py::test_x3_gemm_is_fp32_class holds both to the same bound.  Why: gfx950 has
+// no TF32 path and its fp32 MFMA runs at the vector rate (157 TFLOP/s), bf16 MFMA at 16x that — six bf16 MFMAs per fp32 product block
+// are 2.7x the fp32 matrix peak.  T2V_F32_GEMM=native (or t2v_gemm_f32_set_mode(0)) takes the fp32-MFMA kernels instead.
+//
+// Two launches per operand pair.  (1) k_x3_split: each operand ONCE — split, zero-padded to whole tiles and written K-major as the three
+// planes [plane][k-group of 8][row] of 16-byte words (= a lane's MFMA operand), whatever its strides were.  A first version split
+// inside the GEMM while staging: every 128x128 tile split its operand rows again (24x redundant at the LSTM weight-gradient shapes:
+// 400 VALU-cycles per MFMA-cycle... 183 us of split + LDS stores next to 120 us of MFMA work) and reached 120 TFLOP/s; the split pass
+// moves 10 B per element once.  (2) k_gemm_x3p: 128x128 tile, 256 threads = 2x2 waves x (2x2) accumulators of
+// v_mfma_f32_32x32x16_bf16, stages of 16 k; the planes go global -> LDS by LDS-DMA (1 KB per wave instruction, no staging registers, no
+// ds_write pass), double-buffered per stage: 48 KB of LDS and < 168 registers, so three workgroups share a CU and fill each other's
+// barrier / DMA waits.
+#define GX_BM 128
+#define GX_BN 128
+#define GX_SK 16                    // k per stage (two k-groups of 8)
+typedef __bf16 gx_bf16x8 __attribute__((ext_vector_type(8)));
+// 8 consecutive-k fp32 values of one operand row -> the row's 16-byte word in each of the three planes
+__device__ __forceinline__ void gx_split8(const float (&v)[8], uint4& p0, uint4& p1, uint4& p2) {
+    unsigned q0[4], q1[4], q2[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float x = v[2 * c], y = v[2 * c + 1];
+        const unsigned h = gemm_pack_bf16x2(x, y);
+        const float r1x = x - __uint_as_float(h << 16), r1y = y - __uint_as_float(h & 0xffff0000u);
+        const unsigned m = gemm_pack_bf16x2(r1x, r1y);
+        const float r2x = r1x - __uint_as_float(m << 16), r2y = r1y - __uint_as_float(m & 0xffff0000u);
+        q0[c] = h; q1[c] = m; q2[c] = gemm_pack_bf16x2(r2x, r2y);
+    }
+    p0 = make_uint4(q0[0], q0[1], q0[2], q0[3]);
+    p1 = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+    p2 = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+}
+// planes of an operand with `rows` rows and K columns: Rp = rows rounded up to 128, G = k-groups rounded up to 4 (32 k);
+// plane p, k-group g, row r -> 16-byte slot (p * G + g) * Rp + r.  Rows >= rows and k >= K are zero.
+static inline long gx_rp(int rows) { return ((long)rows + 127) / 128 * 128; }
+static inline long gx_groups(int K) { return ((long)K + 31) / 32 * 4; }
+static inline long gx_plane_slots(int rows, int K) { return 3 * gx_groups(K) * gx_rp(rows); }
+// grid (Rp / 64, G / 4): a workgroup splits 64 rows x 32 k.  KC: the operand is contiguous along k (two float4 per row and k-group when
+// aligned), else along its rows (or neither: scalar loads either way).  Every word crosses LDS once so that the plane stores run along
+// the rows (1 KB contiguous per wave) whichever way the loads ran.
+template <bool KC>
+__global__ __launch_bounds__(256) void k_x3_split(const float* __restrict__ src, long s_row, long s_k, int rows, int K, uint4* __restrict__ dst,
+                                                  long Rp, long G) {
+    __shared__ uint4 sm[3][4][64];
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * 64, g0 = blockIdx.y * 4;
+    const int r = KC ? tid >> 2 : tid & 63, g = KC ? tid & 3 : tid >> 6;
+    const int row = row0 + r, k0 = 8 * (g0 + g);
+    float v[8];
+    const bool rin = row < rows;
+    const float* base = src + (long)min(row, rows - 1) * s_row;
+    if (KC && s_k == 1 && !(s_row & 3) && !((uintptr_t)src & 15) && k0 + 8 <= K) {
+        const float4 lo = *(const float4*)(base + k0), hi = *(const float4*)(base + k0 + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = rin ? v[u] : 0.f;
+    } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float x = base[(long)min(k0 + u, K - 1) * s_k];
+            v[u] = (rin && k0 + u < K) ? x : 0.f;
+        }
+    }
+    uint4 p0, p1, p2;
+    gx_split8(v, p0, p1, p2);
+    sm[0][g][r] = p0; sm[1][g][r] = p1; sm[2][g][r] = p2;
+    __syncthreads();
+    const int g2 = tid >> 6, r2 = tid & 63;
+    if (row0 + r2 < Rp && g0 + g2 < G) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dst[(p * G + g0 + g2) * Rp + row0 + r2] = sm[p][g2][r2];
+    }
+}
+struct GemmX3Args {
+    const uint4* Ap; const uint4* Bp;      // planes (gx_plane_slots)
+    long RpA, RpB, G;
+    const float* bias; float* C;
+    int M, N, ldc, relu, accumulate;
+    float p_drop; uint64_t seed; uint32_t rng_stream, rng_t;
+    const t2v_step_params* step;
+    int st_chunk;           // split-K: stages per blockIdx.z (0 = all)
+    float* part; unsigned* tile_ctr;
+    int dbg;
+};
+__global__ __launch_bounds__(256, 3) void k_gemm_x3p(GemmX3Args a) {
+    __shared__ uint4 As[2][3][2][GX_BM];
+    __shared__ uint4 Bs[2][3][2][GX_BN];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile order (as in k_gemm_f32_big): the tiles of one XCD are a contiguous run of the row-major tile order
+    int by_ = blockIdx.y, bx_ = blockIdx.x;
+    {
+        const int nb = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        by_ = lin / gridDim.x;
+        bx_ = lin - by_ * gridDim.x;
+    }
+    const int i0 = by_ * GX_BM, j0 = bx_ * GX_BN;
+    const int nst_all = (int)(a.G / 2);
+    const int st0 = a.st_chunk ? blockIdx.z * a.st_chunk : 0, st1 = a.st_chunk ? min(nst_all, st0 + a.st_chunk) : nst_all;
+    // DMA plan of a stage: 24 pieces of 1 KB = {A, B} x 3 planes x 2 k-groups x 2 row halves; wave w issues pieces w, w + 4, ..., w + 20
+    auto stage_dma = [&](int st, int buf) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int q = wave + 4 * i;
+            const int op = q / 12, rem = q - 12 * op, p = rem >> 2, g = (rem >> 1) & 1, half = rem & 1;
+            const uint4* src = op ? a.Bp + (p * a.G + 2 * st + g) * a.RpB + j0 + 64 * half + lane
+                                  : a.Ap + (p * a.G + 2 * st + g) * a.RpA + i0 + 64 * half + lane;
+            uint4* dst = op ? &Bs[buf][p][g][64 * half] : &As[buf][p][g][64 * half];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+    const int am = 64 * wm + (lane & 31), bn = 64 * wn + (lane & 31), kq = lane >> 5;
+#define GX_MFMA(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const gx_bf16x8*)&(A_), *(const gx_bf16x8*)&(B_), C_, 0, 0, 0)
+    stage_dma(st0, 0);
+    __syncthreads();            // (carries the s_waitcnt vmcnt(0) that orders this wave's DMA writes in front of the barrier)
+    for (int st = st0; st < st1; ++st) {
+        const int buf = (st - st0) & 1;
+        // the next stage goes into the other buffer: everybody left it at the barrier that ended the previous stage
+        if (st + 1 < st1) stage_dma(st + 1, buf ^ 1);
+        uint4 av[3][2], bv[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            av[p][0] = As[buf][p][kq][am];
+            av[p][1] = As[buf][p][kq][am + 32];
+            bv[p][0] = Bs[buf][p][kq][bn];
+            bv[p][1] = Bs[buf][p][kq][bn + 32];
+        }
+        // small terms first; product-major, so that consecutive MFMAs go to different accumulators
+#define GX_ALL(PA, PB)                                      \
+        GX_MFMA(av[PA][0], bv[PB][0], acc[0][0]); GX_MFMA(av[PA][0], bv[PB][1], acc[0][1]); \
+        GX_MFMA(av[PA][1], bv[PB][0], acc[1][0]); GX_MFMA(av[PA][1], bv[PB][1], acc[1][1])
+        GX_ALL(2, 0); GX_ALL(0, 2); GX_ALL(1, 1); GX_ALL(1, 0); GX_ALL(0, 1); GX_ALL(0, 0);
+#undef GX_ALL
+        __syncthreads();        // this stage's reads are done AND the next stage's DMA has landed (vmcnt(0) in front of the barrier)
+    }
+#undef GX_MFMA
+    if (a.part) {
+        // split-K exactly as in k_gemm_bf16_big_rr: raw accumulators to scratch in accumulator order (write-through), the workgroup
+        // that arrives last at its tile's counter adds the partials in the fixed order z = 0, 1, ... and runs the epilogue
+        typedef unsigned gx_u32x4 __attribute__((ext_vector_type(4)));
+        const size_t tiles = (size_t)gridDim.x * gridDim.y, tile = (size_t)by_ * gridDim.x + bx_;
+        {
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part + (blockIdx.z * tiles + tile) * (GX_BM * GX_BN), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        gx_u32x4 v;
+                        v.x = __float_as_uint(acc[x][y][4 * q]); v.y = __float_as_uint(acc[x][y][4 * q + 1]);
+                        v.z = __float_as_uint(acc[x][y][4 * q + 2]); v.w = __float_as_uint(acc[x][y][4 * q + 3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((((x * 2 + y) * 4 + q) * 256) + tid) * 16, 0, 16);
+                    }
+        }
+        __shared__ unsigned last_;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* ctr = a.tile_ctr + tile;
+        if (tid == 0) last_ = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.z - 1 ? 1u : 0u;
+        __syncthreads();
+        if (!last_) return;
+        if (tid == 0) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nz = (int)gridDim.z;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+        for (int z0 = 0; z0 < nz; z0 += 2) {
+            gx_u32x4 v[2][16];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int z = min(z0 + u, nz - 1);
+                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.part + (z * tiles + tile) * (GX_BM * GX_BN), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+                for (int g = 0; g < 16; ++g) v[u][g] = __builtin_amdgcn_raw_buffer_load_b128(rs, (g * 256 + tid) * 16, 0, 16);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (z0 + u < nz) {
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        acc[g >> 3][(g >> 2) & 1][4 * (g & 3)] += __uint_as_float(v[u][g].x);
+                        acc[g >> 3][(g >> 2) & 1][4 * (g & 3) + 1] += __uint_as_float(v[u][g].y);
+                        acc[g >> 3][(g >> 2) & 1][4 * (g & 3) + 2] += __uint_as_float(v[u][g].z);
+                        acc[g >> 3][(g >> 2) & 1][4 * (g & 3) + 3] += __uint_as_float(v[u][g].w);
+                    }
+                }
+        }
+    }
+    const uint64_t seed = t2v_step_seed(a.seed, a.step);
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int j = j0 + 64 * wn + 32 * y + (lane & 31);
+            if (j < a.N) {
+                const float bvs = a.bias ? a.bias[j] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = i0 + 64 * wm + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (i < a.M) {
+                        const size_t idx = (size_t)i * a.ldc + j;
+                        float v = acc[x][y][r] + bvs;
+                        if (a.accumulate) v += a.C[idx];
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        if (a.p_drop > 0.f) v *= t2v_drop_scale(seed, a.rng_stream, a.rng_t, (uint32_t)idx, a.p_drop);
+                        a.C[idx] = v;
+                    }
+                }
+            }
+        }
+}
+// 1 = the x3 kernel takes the large fp32 products (default), 0 = the fp32-MFMA kernels only
+static int g_f32_gemm_x3 = -1;
+static int gemm_x3_mode() {
+    if (g_f32_gemm_x3 < 0) {
+        const char* e = getenv("T2V_F32_GEMM");
+        g_f32_gemm_x3 = (e && (!strcmp(e, "native") || !strcmp(e, "0"))) ? 0 : 1;
+    }
+    return g_f32_gemm_x3;
+}
+extern "C" int t2v_gemm_f32_set_mode(int x3) {
+    const int prev = gemm_x3_mode();
+    if (x3 >= 0) g_f32_gemm_x3 = x3 ? 1 : 0;
+    return prev;
+}
+// the x3 path takes a product from 64 tiles of 128x128 on, whatever its strides (the split pass reads any layout)
+static bool gemm_x3_shape_ok(int M, int N, int K) {
+    if (M < GX_BM || N < GX_BN || K < 32) return false;
+    return (long)((M + GX_BM - 1) / GX_BM) * ((N + GX_BN - 1) / GX_BN) >= 64;
+}
+// k-splits of the x3 kernel.  Three of its workgroups share a CU and hide each other's barrier / DMA waits, so a launch wants whole
+// rounds of 768 units; a unit costs its share of K plus a fixed part (prologue, epilogue, raw tile to scratch and back), a split a
+// little on top.  cost(ns) = ceil(tiles * ns / 768) * (1 / ns + 0.08) + 0.03 (ns - 1) reproduces the measured order of ns = 1..4 on
+// 128 / 256 / 384 / 640 tiles at K = 2400 (tools/dbg/x3_time.py with T2V_GEMM_X3_SPLITS: 165 96 83 71 | 171 122 113 136 | 201 152 173
+// 164 | 269 257 271 291 us)
+static int gemm_x3_splits(int M, int N, int K) {
+    const long tiles = (long)((M + GX_BM - 1) / GX_BM) * ((N + GX_BN - 1) / GX_BN);
+    const int nst = (int)(gx_groups(K) / 2);
+    static const int forced = getenv("T2V_GEMM_X3_SPLITS") ? atoi(getenv("T2V_GEMM_X3_SPLITS")) : 0;     // measurement
+    if (forced > 0) return forced > nst ? nst : forced;
+    int best = 1;
+    double best_w = 1e30;
+    for (int ns = 1; ns <= 6 && (ns == 1 || nst / ns >= 16); ++ns) {
+        const double rounds = (double)((tiles * ns + 767) / 768);
+        const double w = rounds * (1.0 / ns + 0.08) + 0.03 * (ns - 1);
+        if (w < best_w - 1e-9) { best_w = w; best = ns; }
+    }
+    return best;
+}
+// floats of caller scratch the x3 path needs for (M, N, K): the planes of both operands + the split-K partial tiles
+static long gemm_x3_plane_floats(int M, int N, int K) { return 4 * (gx_plane_slots(M, K) + gx_plane_slots(N, K)); }
+static long gemm_x3_scratch_floats(int M, int N, int K) {
+    const int ns = gemm_x3_splits(M, N, K);
+    const long tiles = (long)((M + GX_BM - 1) / GX_BM) * ((N + GX_BN - 1) / GX_BN);
+    return gemm_x3_plane_floats(M, N, K) + (ns > 1 ? (long)ns * tiles * GX_BM * GX_BN : 0);
+}
+static int gemm_x3_run(const GemmArgs& g, float* scratch, hipStream_t stream) {
+    const int M = g.M, N = g.N, K = g.K;
+    uint4* Ap = (uint4*)scratch;
+    uint4* Bp = Ap + gx_plane_slots(M, K);
+    const long G = gx_groups(K), RpA = gx_rp(M), RpB = gx_rp(N);
+    static const int skip_env = getenv("T2V_X3_SKIP") ? atoi(getenv("T2V_X3_SKIP")) : 0;     // measurement: 1 = no split passes, 2 = no GEMM, 4 = split passes in every 23rd call only
+    static int calls = 0;
+    const int skip = (skip_env & 4) ? ((calls++ % 23) ? 1 : 0) : skip_env;
+    if (skip & 1) { }
+    else if (g.sAk == 1) k_x3_split<true><<<dim3((unsigned)(RpA / 64), (unsigned)(G / 4)), 256, 0, stream>>>(g.A, g.sAi, g.sAk, M, K, Ap, RpA, G);
+    else k_x3_split<false><<<dim3((unsigned)(RpA / 64), (unsigned)(G / 4)), 256, 0, stream>>>(g.A, g.sAi, g.sAk, M, K, Ap, RpA, G);
+    if (skip & 1) { }
+    else if (g.sBk == 1) k_x3_split<true><<<dim3((unsigned)(RpB / 64), (unsigned)(G / 4)), 256, 0, stream>>>(g.B, g.sBj, g.sBk, N, K, Bp, RpB, G);
+    else k_x3_split<false><<<dim3((unsigned)(RpB / 64), (unsigned)(G / 4)), 256, 0, stream>>>(g.B, g.sBj, g.sBk, N, K, Bp, RpB, G);
+    GemmX3Args a;
+    a.Ap = Ap; a.Bp = Bp; a.RpA = RpA; a.RpB = RpB; a.G = G; a.bias = g.bias; a.C = g.C;
+    a.M = M; a.N = N; a.ldc = g.ldc; a.relu = g.relu; a.accumulate = g.accumulate;
+    a.p_drop = g.p_drop; a.seed = g.seed; a.rng_stream = g.rng_stream; a.rng_t = g.rng_t; a.step = g.step;
+    a.st_chunk = 0; a.part = nullptr; a.tile_ctr = nullptr;
+    dim3 gb((N + GX_BN - 1) / GX_BN, (M + GX_BM - 1) / GX_BM, 1);
+    const int ns = gemm_x3_splits(M, N, K);
+    if (ns > 1) {
+        const int nst = (int)(G / 2);
+        a.st_chunk = (nst + ns - 1) / ns;
+        gb.z = (unsigned)((nst + a.st_chunk - 1) / a.st_chunk);         // no empty split
+        a.part = scratch + gemm_x3_plane_floats(M, N, K);
+        a.tile_ctr = t2v_arrival_counters((int)(gb.x * gb.y));
+        if (!a.tile_ctr) return T2V_ERR_LAUNCH;
+        if (gb.z < 2) { a.st_chunk = 0; a.part = nullptr; a.tile_ctr = nullptr; gb.z = 1; }
+    }
+    if (!(skip & 2)) k_gemm_x3p<<<gb, 256, 0, stream>>>(a);
+    return t2v_check_launch();
+}
+
 // d(pre-activation) = dy * [y != 0] * scale (reference Prenet, model.py:96-99: F.dropout(F.relu(linear(x)), p=0.5)).
 __global__ __launch_bounds__(256) void k_epilogue_bwd(const float4* __restrict__ dy, const float4* __restrict__ y,
                                                       float4* __restrict__ out, size_t n4, float scale) {
@@ -836,6 +1153,8 @@ static int gemm_f32_impl(const float* A, long sAi, long sAk, const float* B, lon
     a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
     a.kz_chunk = 0; a.part = nullptr; a.nbatch = 1; a.sAb = a.sBb = a.sCb = 0; a.nsub = 1; a.sAs = a.sBs = 0; a.bias_row = 0; a.tile_ctr = nullptr;
     const bool akc = sAk == 1, bkc = sBk == 1;
+    if (splitk_scratch && gemm_x3_mode() && gemm_x3_shape_ok(M, N, K) && !((uintptr_t)splitk_scratch & 15))
+        return gemm_x3_run(a, splitk_scratch, stream);
     if (gemm_big_ok(a)) {
         // (T2V_GEMM_NARROW=1, measurement: always the 128x64 tile — twice the tiles, so a launch that shares CUs with long
         // small-grid kernels balances itself instead of waiting for its slowest single-tile workgroup)

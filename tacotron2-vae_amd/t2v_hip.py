@@ -77,7 +77,7 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_stamp', 't2v_debug_spin', 't2v_
            't2v_decoder_train_fwd_persistent16', 't2v_decoder_train_persist16_supported',
            't2v_decoder_train_persist16_scratch_floats', 't2v_decoder_bwd_persistent16', 't2v_decoder_bwd_persist16_supported',
            't2v_decoder_bwd_persist16_scratch_floats', 't2v_decoder_bwd_persist16_dq_offset', 't2v_decoder_bwd_persist16_slices',
-           't2v_decoder_bwd_persist16_fits',
+           't2v_decoder_bwd_persist16_fits', 't2v_gemm_f32_set_mode',
            't2v_decoder_bwd_persistent16_prepare', 't2v_decoder_bwd_persistent16_prepared')
 
 
@@ -127,6 +127,7 @@ def load_library():
     lib.t2v_decoder_bwd_persist16_dq_offset.restype = C.c_long
     lib.t2v_decoder_bwd_persist16_slices.argtypes = [C.c_int]
     lib.t2v_decoder_bwd_persist16_fits.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.t2v_gemm_f32_set_mode.argtypes = [C.c_int]
     lib.t2v_decoder_train_persist_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.t2v_decoder_train_persist_scratch_floats.restype = C.c_long
     lib.t2v_decoder_bwd_persist_supported.argtypes = [C.c_int, C.c_int]
@@ -1826,6 +1827,12 @@ def _small_grads(params, n, f32):
         g = grad_slot(p) if p is not None else None
         out.append(torch.empty(n, **f32) if g is None else g)
     return out
+
+
+def set_f32_gemm_mode(x3):
+    """True (default): the large fp32 products run as six bf16 MFMAs on exactly 3-way-split operands (fp32-class accuracy, see
+    include/t2vae.h: t2v_gemm_f32_set_mode); False: fp32 MFMA only; None: query.  Returns the previous setting."""
+    return bool(load_library().t2v_gemm_f32_set_mode(-1 if x3 is None else int(bool(x3))))
 
 
 def gemm(A, B, bias=None, out=None, relu=False, accumulate=False, p_drop=0.0, seed=0, rng_stream=0, rng_t=0):

@@ -33,7 +33,18 @@ def test_reverse_pass_geometry(lib):
 
 def test_scratch_size_answers_are_monotonic(lib):
     assert lib.t2v_gemm_splitk_scratch_floats(81, 1536, 2400) > 0            # the projection's weight gradient is split
-    assert lib.t2v_gemm_splitk_scratch_floats(4096, 2560, 2400) == 0         # large products are not
+    # large products: no scratch for the fp32-MFMA kernels; the x3 path (round 6) keeps the bf16 planes of both operands there
+    # (6 bytes per element, padded to whole tiles) + the raw tiles of its k-splits
+    prev = lib.t2v_gemm_f32_set_mode(0)
+    try:
+        assert lib.t2v_gemm_splitk_scratch_floats(4096, 2560, 2400) == 0
+        lib.t2v_gemm_f32_set_mode(1)
+        planes = 6 * (4096 + 2560) * 2400 // 4
+        got = lib.t2v_gemm_splitk_scratch_floats(4096, 2560, 2400)
+        assert planes <= got <= planes + 4 * 4096 * 2560
+        assert lib.t2v_gemm_splitk_scratch_floats(81, 1536, 2400) > 0 and lib.t2v_gemm_splitk_scratch_floats(128, 128, 2400) > 0   # small: fp32 split-K
+    finally:
+        lib.t2v_gemm_f32_set_mode(prev)
     assert lib.t2v_colsum_scratch_floats(2400, 4096) >= 4096 and lib.t2v_colsum_scratch_floats(1, 7) == 0
     a, b = lib.t2v_decoder_train_persist_scratch_floats(6, 84, 100), lib.t2v_decoder_train_persist_scratch_floats(6, 84, 400)
     assert 0 < a < b

@@ -265,3 +265,43 @@ def test_timeout_on_one_rank_skips_and_reruns_the_step_on_both(tmp_path, mode):
         for r in rs:
             assert r['n_graphs_before'] == 1 and r['n_graphs_after'] == 0      # recover() drops the captured graphs
     assert rs[0]['steps_total'] == rs[1]['steps_total']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('graph', [True, False], ids=['graph_engine', 'eager_engine'])
+def test_bench_entry_with_two_ranks_prints_the_multi_gpu_line(graph):
+    """VERDICT r5 next 7 (reference distributed.py:137-162, train.py:31-50, multiproc.py:1-23): `python bench.py --gpus 2` — the
+    command the driver runs for the scaling curve — self-launches two ranks under torch.distributed.run, and rank 0 prints ONE JSON
+    line whose multi-rank keys parse.  The two ranks share the one GPU of the test box (T2V_BENCH_SHARE_GPU=1) over gloo
+    (T2V_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device) on the launch-per-step kernels, like the tests above; what is
+    pinned is the PLUMBING of the N > 1 line — rendezvous, barrier + max over ranks, weak-scaling frame count, per-rank step
+    times / step modes, the exposed all-reduce time — so that the day a node exists the SCALE line does not fail on it."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0', T2V_BENCH_SHARE_GPU='1', T2V_BENCH_BACKEND='gloo', T2V_TRAIN_PERSISTENT='0',
+               T2V_GRAPH_WATCHDOG='0')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--settle', '1',
+           '--no-cpu-baseline', '--no-decode', '--no-secondary', '--eager-steps', '0'] + ([] if graph else ['--no-graph'])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, "rank 0 alone prints the line"
+    d = json.loads(lines[0])
+    assert list(d)[:7] == ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step"]
+    assert d['n_gpus'] == 2 and d['rccl_ranks'] == 2 and d['steps'] == 3 and d['warmup'] == 1
+    assert d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp2' and d['config']['global_batch'] == 12
+    assert d['config']['frames_per_step'] == 2 * 6 * 400
+    assert abs(d['value'] - d['config']['frames_per_step'] / (d['ms_per_step'] * 1e-3)) < 1e-3 * d['value']
+    per = d['ms_per_step_ranks']['per_rank']
+    assert len(per) == 2 and d['ms_per_step_ranks']['max'] == max(per) and abs(d['ms_per_step'] - max(per)) < 1e-2
+    assert d['allreduce_exposed_ms'] >= 0.0
+    assert sum(b[1] for b in d['allreduce_buckets_bytes']) > 100e6
+    ranks = d['ranks']
+    assert [r['rank'] for r in ranks] == [0, 1] and d['ranks_disagree'] is False
+    for r in ranks:
+        assert r['decoder_forward'] == 'launch-per-step' and r['decoder_backward'] == 'launch-per-step' and r['recoveries'] == 0
+        assert r['step_mode'].startswith('hip-graph replay of forward + backward' if graph else 'eager launches')
+    assert d['final_loss'] == d['final_loss']        # finite

@@ -160,3 +160,72 @@ def test_batched_gemm_for_the_per_item_memory_gradient(B, T_in, T):
     # argument checks: nothing is launched for a bad batch count / leading dimension
     assert lib.t2v_gemm_f32_batched(p(dAL), T_in, 1, B * T_in, p(dD), 512, 1, B * 512, p(out), T_in * 512, 100, B, T_in, 512, T, None) != 0
     assert lib.t2v_gemm_f32_batched(p(dAL), T_in, 1, B * T_in, p(dD), 512, 1, B * 512, p(out), T_in * 512, 512, 0, T_in, 512, T, None) != 0
+
+
+@pytest.mark.parametrize("M,N,K,form", [(4096, 2560, 2400, 'rr'), (4096, 1536, 2400, 'rr'), (2400, 4096, 256, 'kk'), (1340, 1536, 2404, 'rr'),
+                                        (2000, 1028, 52, 'rr'), (2400, 1024, 4096, 'kr'), (1024, 2048, 512, 'rk'), (1156, 1284, 40, 'kk')])
+def test_x3_gemm_is_fp32_class(M, N, K, form):
+    """Round 6: the large fp32 products on the bf16 matrix cores (k_gemm_f32x3_big: operands cut exactly into three bf16 values, six
+    MFMAs per k-block, fp32 accumulation) against an fp64 product — held to the SAME bound as the fp32-MFMA kernel
+    (v_mfma_f32_32x32x2_f32), and measured next to it: the x3 error must not exceed 1.5x the native kernel's (it is smaller in
+    practice: the running sum is rounded 6 times per 16 k instead of once per k).  Operand forms: r = contiguous along its row index
+    (weight-gradient operands stored (K, rows)), k = contiguous along k; incl. ragged edges, K not a multiple of the k-tile,
+    accumulate, bias and the split-K path; bit-reproducible."""
+    import t2v_hip
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    # wide dynamic range: magnitudes over 2^+-6 so that a dropped low-order term would show
+    def rnd(r, c):
+        return (torch.randn(r, c, generator=g) * torch.exp2(torch.randint(-6, 7, (r, c), generator=g).float())).cuda()
+    A = rnd(M, K) if form[0] == 'k' else rnd(K, M).t()
+    B = rnd(N, K) if form[1] == 'k' else rnd(K, N).t()
+    bias = torch.randn(N, generator=g).cuda()
+    ref = A.double() @ B.double().t() + bias.double()
+    absref = A.double().abs() @ B.double().abs().t() + bias.double().abs()    # sum_k |a b| (+ |bias|): what fp32 round-off scales with
+    errs = {}
+    prev = t2v_hip.set_f32_gemm_mode(None)
+    try:
+        for mode in (True, False):
+            t2v_hip.set_f32_gemm_mode(mode)
+            out = t2v_hip.gemm(A, B, bias)
+            out2 = t2v_hip.gemm(A, B, bias)
+            assert torch.equal(out, out2), 'not reproducible'
+            errs[mode] = ((out.double() - ref).abs() / absref).max().item()
+            acc = out.clone()
+            t2v_hip.gemm(A, B, None, out=acc, accumulate=True)
+            e2 = ((acc.double() - (2 * ref - bias.double())).abs() / absref).max().item()
+            assert e2 < 2.5 * max(errs[mode], 1e-7), (mode, e2)
+    finally:
+        t2v_hip.set_f32_gemm_mode(prev)
+    print('GEMM %dx%dx%d %s: max |err| / sum|ab|  x3 %.2e  fp32-MFMA %.2e' % (M, N, K, form, errs[True], errs[False]))
+    bound = 2e-7 * max(4.0, K ** 0.5)            # fp32 round-off through K terms (max over up to 1e7 outputs, heavy-tailed operands)
+    assert errs[False] < bound and errs[True] < bound, errs
+    assert errs[True] < 1.1 * errs[False] + 2e-8, errs     # measured: 0.3x .. 0.8x of the fp32-MFMA kernel's error
+
+
+def test_x3_gemm_throughput_on_the_lstm_weight_gradient_shapes():
+    """the four deferred LSTM weight gradients of the fp32 step (K = T*B = 2400, operands stored (K, rows)) on the x3 kernel next to
+    the fp32-MFMA kernel it replaces (printed; the x3 kernel must not be slower)"""
+    import t2v_hip
+    g = torch.Generator().manual_seed(5)
+    res = {}
+    prev = t2v_hip.set_f32_gemm_mode(None)
+    try:
+        for (M, N) in ((4096, 2560), (4096, 1536), (4096, 1024), (4096, 512)):
+            dg = (torch.randn(2400, M, generator=g) * 0.1).cuda()
+            x = torch.randn(2400, N, generator=g).cuda()
+            out = torch.empty(M, N, device='cuda')
+            for mode in (True, False):
+                t2v_hip.set_f32_gemm_mode(mode)
+                for _ in range(3):
+                    t2v_hip.gemm(dg.t(), x.t(), out=out)
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                for _ in range(20):
+                    t2v_hip.gemm(dg.t(), x.t(), out=out)
+                ev1.record()
+                torch.cuda.synchronize()
+                res[(M, N, mode)] = 20 * 2 * M * N * 2400 / (ev0.elapsed_time(ev1) * 1e-3) / 1e12
+            print('dW GEMM %dx%dx2400: x3 %.0f TFLOP/s (fp32-equivalent), fp32-MFMA %.0f TFLOP/s' % (M, N, res[(M, N, True)], res[(M, N, False)]))
+        assert res[(4096, 2560, True)] > res[(4096, 2560, False)]
+    finally:
+        t2v_hip.set_f32_gemm_mode(prev)
