@@ -980,6 +980,11 @@ static inline int conv5_pick_bn_ks(int T, int B, int M, int Cin, int* ks) {
     return best;
 }
 static inline bool conv5_tiled_ok(int Cin, int KS) { return KS == 5 && Cin % 16 == 0; }
+// round 6 (conv_x3.hip): fp32 forward / data gradient on the bf16 matrix cores from exactly 3-way-split operands
+bool t2v_conv5_x3_ok(int B, int Cin, int T, int Cout, int KS);
+int t2v_conv5_x3_stat_blocks(int B, int T);
+int t2v_conv5_x3_run(const float* W, const float* X, const float* bias, float* Y, float* stat_part, int B, int Cin, int T, int M,
+                     hipStream_t stream);
 
 static void launch_conv5_fwd(const float* W, const float* X, const float* bias, float* Y, float* stat_part, int B,
                              int Cin, int T, int M, hipStream_t stream) {
@@ -1078,6 +1083,10 @@ extern "C" int t2v_conv1d_fwd(const float* W, const float* X, const float* bias,
                               int B, int Cin, int T, int Cout, int KS, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!W || !X || !Y || B < 1 || Cin < 1 || T < 1 || Cout < 1 || KS < 1 || !(KS & 1)) return T2V_ERR_ARG;
+    if (t2v_conv5_x3_ok(B, Cin, T, Cout, KS)) {
+        const int rc = t2v_conv5_x3_run(W, X, bias, Y, stat_part, B, Cin, T, Cout, stream);
+        return rc != T2V_OK ? rc : t2v_check_launch();
+    }
     if (conv5_tiled_ok(Cin, KS)) {
         launch_conv5_fwd(W, X, bias, Y, stat_part, B, Cin, T, Cout, stream);
         return t2v_check_launch();
@@ -1093,6 +1102,7 @@ extern "C" int t2v_conv1d_fwd(const float* W, const float* X, const float* bias,
 }
 
 extern "C" int t2v_conv1d_stat_blocks(int B, int T, int Cin, int Cout, int KS) {
+    if (t2v_conv5_x3_ok(B, Cin, T, Cout, KS)) return t2v_conv5_x3_stat_blocks(B, T);
     if (conv5_tiled_ok(Cin, KS)) { int ks; const int BN = conv5_pick_bn_ks(T, B, Cout, Cin, &ks); return B * ((T + BN - 1) / BN); }
     return (B * T + CG_BN - 1) / CG_BN;
 }
@@ -1113,7 +1123,10 @@ extern "C" int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, f
         if (!Wt_scratch) return T2V_ERR_ARG;
         const int n = Cout * Cin * KS;
         if (W) k_conv_flip_weight<<<(n + 255) / 256, 256, 0, stream>>>(W, Wt_scratch, Cout, Cin, KS);
-        if (conv5_tiled_ok(Cout, KS)) {
+        if (t2v_conv5_x3_ok(B, Cout, T, Cin, KS)) {         // the data gradient = the same convolution with the flipped, transposed weights
+            const int rc = t2v_conv5_x3_run(Wt_scratch, dY, nullptr, dX, nullptr, B, Cout, T, Cin, stream);
+            if (rc != T2V_OK) return rc;
+        } else if (conv5_tiled_ok(Cout, KS)) {
             launch_conv5_fwd(Wt_scratch, dY, nullptr, dX, nullptr, B, Cout, T, Cin, stream);
         } else {
             ConvGemmArgs a;

@@ -809,10 +809,22 @@ struct GemmX3Args {
     float* part; unsigned* tile_ctr;
     int dbg;
 };
-__global__ __launch_bounds__(256, 3) void k_gemm_x3p(GemmX3Args a) {
-    __shared__ uint4 As[2][3][2][GX_BM];
-    __shared__ uint4 Bs[2][3][2][GX_BN];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+// 16 bytes per lane global -> LDS without a destination register (lane i lands at lds_addr + 16 i; lds_addr wave-uniform, in an SGPR).
+// Inline asm on purpose: hipcc counts the builtin form as an LDS write and puts `s_waitcnt vmcnt(0)` in front of EVERY later ds_read —
+// the prefetch issued at the top of a stage was waited for before the stage's own MFMAs.  The asm form is invisible to its
+// bookkeeping; the waits are counted by hand below.
+__device__ __forceinline__ void gx_dma16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+}
+#define GX_NB 3                     // stage buffers: the planes of stage i + 2 are requested during stage i
+__global__ __launch_bounds__(256, 2) void k_gemm_x3p(GemmX3Args a) {
+    // [buffer][A | B][plane][k-group][row]: 72 KB, two workgroups per CU
+    __shared__ uint4 lds_[GX_NB * 2 * 3 * 2 * GX_BM];
+    uint4 (*Ls)[2][3][2][GX_BM] = (uint4 (*)[2][3][2][GX_BM])&lds_[0];
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)&lds_[0];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware tile order (as in k_gemm_f32_big): the tiles of one XCD are a contiguous run of the row-major tile order
     int by_ = blockIdx.y, bx_ = blockIdx.x;
@@ -826,16 +838,18 @@ __global__ __launch_bounds__(256, 3) void k_gemm_x3p(GemmX3Args a) {
     const int i0 = by_ * GX_BM, j0 = bx_ * GX_BN;
     const int nst_all = (int)(a.G / 2);
     const int st0 = a.st_chunk ? blockIdx.z * a.st_chunk : 0, st1 = a.st_chunk ? min(nst_all, st0 + a.st_chunk) : nst_all;
-    // DMA plan of a stage: 24 pieces of 1 KB = {A, B} x 3 planes x 2 k-groups x 2 row halves; wave w issues pieces w, w + 4, ..., w + 20
+    // DMA plan of a stage: 24 pieces of 1 KB = {A, B} x 3 planes x 2 k-groups x 2 row halves; wave w issues pieces w, w + 4, ..., w + 20.
+    // A request past the end re-reads the last stage into a buffer nobody reads any more: six requests per wave and stage, always —
+    // what the counted wait below relies on
     auto stage_dma = [&](int st, int buf) {
+        st = min(st, st1 - 1);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int q = wave + 4 * i;
             const int op = q / 12, rem = q - 12 * op, p = rem >> 2, g = (rem >> 1) & 1, half = rem & 1;
             const uint4* src = op ? a.Bp + (p * a.G + 2 * st + g) * a.RpB + j0 + 64 * half + lane
                                   : a.Ap + (p * a.G + 2 * st + g) * a.RpA + i0 + 64 * half + lane;
-            uint4* dst = op ? &Bs[buf][p][g][64 * half] : &As[buf][p][g][64 * half];
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            gx_dma16(src, lds0 + 16u * (unsigned)(((((buf * 2 + op) * 3 + p) * 2 + g) * GX_BM) + 64 * half));
         }
     };
     f32x16 acc[2][2];
@@ -848,18 +862,21 @@ __global__ __launch_bounds__(256, 3) void k_gemm_x3p(GemmX3Args a) {
     const int am = 64 * wm + (lane & 31), bn = 64 * wn + (lane & 31), kq = lane >> 5;
 #define GX_MFMA(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const gx_bf16x8*)&(A_), *(const gx_bf16x8*)&(B_), C_, 0, 0, 0)
     stage_dma(st0, 0);
-    __syncthreads();            // (carries the s_waitcnt vmcnt(0) that orders this wave's DMA writes in front of the barrier)
+    stage_dma(st0 + 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // the first stage has landed, the second may still be on its way
+    __syncthreads();
+    int buf = 0;
     for (int st = st0; st < st1; ++st) {
-        const int buf = (st - st0) & 1;
-        // the next stage goes into the other buffer: everybody left it at the barrier that ended the previous stage
-        if (st + 1 < st1) stage_dma(st + 1, buf ^ 1);
+        // the stage after next goes into the buffer everybody left at the last barrier
+        const int nb2 = buf == 0 ? 2 : buf - 1;             // (buf + 2) % 3
+        stage_dma(st + 2, nb2);
         uint4 av[3][2], bv[3][2];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            av[p][0] = As[buf][p][kq][am];
-            av[p][1] = As[buf][p][kq][am + 32];
-            bv[p][0] = Bs[buf][p][kq][bn];
-            bv[p][1] = Bs[buf][p][kq][bn + 32];
+            av[p][0] = Ls[buf][0][p][kq][am];
+            av[p][1] = Ls[buf][0][p][kq][am + 32];
+            bv[p][0] = Ls[buf][1][p][kq][bn];
+            bv[p][1] = Ls[buf][1][p][kq][bn + 32];
         }
         // small terms first; product-major, so that consecutive MFMAs go to different accumulators
 #define GX_ALL(PA, PB)                                      \
@@ -867,9 +884,14 @@ __global__ __launch_bounds__(256, 3) void k_gemm_x3p(GemmX3Args a) {
         GX_MFMA(av[PA][1], bv[PB][0], acc[1][0]); GX_MFMA(av[PA][1], bv[PB][1], acc[1][1])
         GX_ALL(2, 0); GX_ALL(0, 2); GX_ALL(1, 1); GX_ALL(1, 0); GX_ALL(0, 1); GX_ALL(0, 0);
 #undef GX_ALL
-        __syncthreads();        // this stage's reads are done AND the next stage's DMA has landed (vmcnt(0) in front of the barrier)
+        // stage st + 1 (requested a stage ago) must have landed before anybody passes the barrier: requests come back in order, so it
+        // has once only this stage's six requests are outstanding
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __syncthreads();        // ... and this stage's LDS reads are done
+        buf = buf == 2 ? 0 : buf + 1;
     }
 #undef GX_MFMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the surplus requests of the last stages
     if (a.part) {
         // split-K exactly as in k_gemm_bf16_big_rr: raw accumulators to scratch in accumulator order (write-through), the workgroup
         // that arrives last at its tile's counter adds the partials in the fixed order z = 0, 1, ... and runs the epilogue
@@ -966,7 +988,8 @@ extern "C" int t2v_gemm_f32_set_mode(int x3) {
 // the x3 path takes a product from 64 tiles of 128x128 on, whatever its strides (the split pass reads any layout)
 static bool gemm_x3_shape_ok(int M, int N, int K) {
     if (M < GX_BM || N < GX_BN || K < 32) return false;
-    return (long)((M + GX_BM - 1) / GX_BM) * ((N + GX_BN - 1) / GX_BN) >= 64;
+    static const int min_tiles = getenv("T2V_X3_MIN_TILES") ? atoi(getenv("T2V_X3_MIN_TILES")) : 64;
+    return (long)((M + GX_BM - 1) / GX_BM) * ((N + GX_BN - 1) / GX_BN) >= min_tiles;
 }
 // k-splits of the x3 kernel.  Three of its workgroups share a CU and hide each other's barrier / DMA waits, so a launch wants whole
 // rounds of 768 units; a unit costs its share of K plus a fixed part (prologue, epilogue, raw tile to scratch and back), a split a

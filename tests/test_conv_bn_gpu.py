@@ -1,10 +1,15 @@
 """Conv1d+BatchNorm1d+activation HIP kernels (implicit-GEMM MFMA conv, per-channel BN) vs a plain PyTorch
 fp32 CPU reference of the same op, forward and backward, ragged shapes."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+# (the x3 convolution serves launches of >= 192 tiles by default — B = 16 — and every eligible shape under T2V_CONV_X3=1: the switch
+#  is read once per process, so it is set here, before the library's first convolution, for test_conv1d_x3_is_fp32_class)
+os.environ.setdefault('T2V_CONV_X3', '1')
 
 
 def _ref(x, w, b, gamma, beta, act, training, rm, rv):
@@ -174,3 +179,64 @@ def test_conv2d_s2_bn_relu_matches_torch(B, Cx, H, W, Cout, coord, gemm_form):
             continue          # train-mode BatchNorm cancels the conv bias: its gradient is zero up to round-off in both
         scale = max(r.grad.abs().max().item(), 1e-6)
         assert (d.grad.cpu().double() - r.grad).abs().max().item() < 3e-4 * scale + 2e-7, name      # (+ an fp32 floor for gradients that all but cancel)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T", [(6, 512, 512, 400), (6, 80, 512, 400), (6, 512, 80, 400), (6, 512, 512, 84), (3, 512, 256, 37),
+                                          (2, 128, 512, 129), (1, 64, 64, 2), (5, 96, 200, 131)])
+def test_conv1d_x3_is_fp32_class(B, Cin, Cout, T):
+    """Round 6: the k = 5 Conv1d forward / data gradient on the bf16 matrix cores from exactly 3-way-split fp32 operands
+    (conv_x3.hip: k_cx3_split_w / k_cx3_split_x / k_conv5_x3) through the C ABI (t2v_conv1d_fwd / t2v_conv1d_bwd), next to the
+    fp32-MFMA kernels it replaces (t2v_gemm_f32_set_mode(0)), both against an fp64 convolution: outputs, the BatchNorm partial
+    sums the epilogue emits (summed over the tiles), and the data gradient — incl. the 80-channel Postnet ends, channel counts
+    that are not multiples of 32 / 128, ragged T, T < one tile, the channel-split launches; bit-reproducible.  The x3 error must
+    not exceed the fp32-MFMA kernel's (measured: about half)."""
+    import ctypes as C
+    import t2v_hip
+    lib = t2v_hip.load_library()
+    g = torch.Generator().manual_seed(B * 1000 + T + Cin)
+    x = torch.randn(B, Cin, T, generator=g) * torch.exp2(torch.randint(-4, 5, (B, Cin, T), generator=g).float())
+    w = torch.randn(Cout, Cin, 5, generator=g) / (Cin * 5) ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.1
+    dy = torch.randn(B, Cout, T, generator=g)
+    ref = F.conv1d(x.double(), w.double(), bias.double(), padding=2)
+    aref = F.conv1d(x.double().abs(), w.double().abs(), bias.double().abs(), padding=2)
+    ref_dx = F.conv_transpose1d(dy.double(), w.double(), padding=2)
+    aref_dx = F.conv_transpose1d(dy.double().abs(), w.double().abs(), padding=2)
+    gx, gw, gb, gdy = x.cuda(), w.cuda(), bias.cuda(), dy.cuda()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    errs = {}
+    assert os.environ.get('T2V_CONV_X3', '1') == '1', "this test forces the x3 path (T2V_CONV_X3=1 is read once per process)"
+    prev = lib.t2v_gemm_f32_set_mode(-1)
+    try:
+        for mode in (1, 0):
+            lib.t2v_gemm_f32_set_mode(mode)
+            nblk = lib.t2v_conv1d_stat_blocks(B, T, Cin, Cout, 5)
+            runs = []
+            for rep in range(2):
+                y = torch.full((B, Cout, T), float('nan'), device='cuda')
+                part = torch.full((nblk, Cout, 2), float('nan'), device='cuda')
+                assert lib.t2v_conv1d_fwd(p(gw), p(gx), p(gb), p(y), p(part), B, Cin, T, Cout, 5, st) == 0
+                dx = torch.full((B, Cin, T), float('nan'), device='cuda')
+                wt = torch.empty_like(gw)
+                assert lib.t2v_conv1d_bwd(p(gw), p(gx), p(gdy), p(dx), None, p(wt), None, B, Cin, T, Cout, 5, st) == 0
+                torch.cuda.synchronize()
+                runs.append((y, part, dx))
+            assert all(torch.equal(a, b) for a, b in zip(runs[0], runs[1])), 'not reproducible'
+            y, part, dx = runs[0]
+            assert not torch.isnan(y).any() and not torch.isnan(part).any() and not torch.isnan(dx).any()
+            e_y = ((y.cpu().double() - ref).abs() / aref).max().item()
+            e_dx = ((dx.cpu().double() - ref_dx).abs() / (aref_dx + 1e-30)).max().item()
+            s = part.cpu().double().sum(0)
+            e_s = (s[:, 0] - ref.sum((0, 2))).abs().max().item() / ref.abs().sum((0, 2)).max().item()
+            e_q = (s[:, 1] - (ref * ref).sum((0, 2))).abs().max().item() / (ref * ref).sum((0, 2)).max().item()
+            errs[mode] = (e_y, e_dx, e_s, e_q)
+    finally:
+        lib.t2v_gemm_f32_set_mode(prev)
+    print('conv1d k5 B=%d %d->%d T=%d: max |err| / sum|wx|  x3 y %.2e dx %.2e (BN sums %.1e / %.1e)   fp32-MFMA y %.2e dx %.2e' % (
+        B, Cin, Cout, T, errs[1][0], errs[1][1], errs[1][2], errs[1][3], errs[0][0], errs[0][1]))
+    bound = 2e-7 * max(4.0, (5 * Cin) ** 0.5)
+    for mode in (0, 1):
+        assert errs[mode][0] < bound and errs[mode][1] < 2e-7 * max(4.0, (5 * Cout) ** 0.5), (mode, errs[mode])
+        assert errs[mode][2] < 1e-5 and errs[mode][3] < 1e-5, (mode, errs[mode])
+    assert errs[1][0] < 1.1 * errs[0][0] + 2e-8 and errs[1][1] < 1.1 * errs[0][1] + 2e-8, errs

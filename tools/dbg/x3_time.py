@@ -1,6 +1,6 @@
 """Time the large fp32 products of the step on the x3 kernel and on the fp32-MFMA kernel: `python tools/dbg/x3_time.py` (GPU)."""
 import os, sys
-sys.path.insert(0, os.path.join(os.getcwd(), 'tacotron2-vae_amd'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tacotron2-vae_amd'))
 import torch
 import t2v_hip
 g = torch.Generator().manual_seed(5)
