@@ -484,6 +484,13 @@ int t2v_gemm_f32_splitk(const float* A, long sAi, long sAk, const float* B, long
  * mode 0: v_mfma_f32_32x32x2_f32 for every product.  Pass -1 to query.  Returns the previous mode.  Process-wide. */
 int t2v_gemm_f32_set_mode(int x3);
 
+/* ... and the fp32 k = 5 Conv1d forward / data gradient (t2v_conv1d_fwd / t2v_conv1d_bwd) on the same six-product scheme
+ * (csrc/conv_x3.hip).  mode 0: never; 1: every eligible shape (KS = 5, Cin % 16 == 0, Cin, Cout >= 64); 2 (default; T2V_CONV_X3
+ * presets it): launches of >= 192 tiles of 128 x 128 only — at the B = 6 step's shapes its fixed costs (split passes, channel-split
+ * tiles) outweigh the faster loop, at B = 16 it runs a Postnet layer in 152 us against 212.  Only effective while
+ * t2v_gemm_f32_set_mode is 1.  t2v_conv1d_stat_blocks answers for the current mode.  Pass -1 to query.  Returns the previous mode. */
+int t2v_conv1d_x3_set_mode(int mode);
+
 /* nbatch independent products C_z = A_z · B_z^T (z-th operands at A + z*sAb, B + z*sBb, C + z*sCb; element strides as in
  * t2v_gemm_f32, no bias / epilogue) in one launch.  Replaces the per-item loop that autograd's bmm backward of
  * `attention_context = torch.bmm(attention_weights.unsqueeze(1), memory)` (model.py:84-85) amounts to for d_memory. */

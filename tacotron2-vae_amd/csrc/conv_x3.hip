@@ -333,14 +333,22 @@ static float* cx_scratch(size_t floats) {
 }
 
 extern "C" int t2v_gemm_f32_set_mode(int x3);
+// 0 = never, 1 = whenever the shape allows it, 2 = launches of >= 192 tiles (default; T2V_CONV_X3 presets it); -1 queries
+static int g_cx3_mode = -1;
+extern "C" int t2v_conv1d_x3_set_mode(int mode) {
+    if (g_cx3_mode < 0) g_cx3_mode = getenv("T2V_CONV_X3") ? atoi(getenv("T2V_CONV_X3")) : 2;
+    const int prev = g_cx3_mode;
+    if (mode >= 0 && mode <= 2) g_cx3_mode = mode;
+    return prev;
+}
 // does the fp32 k = 5 convolution (Cin -> Cout channels) take the x3 path?  (t2v_conv1d_stat_blocks must give the same answer)
 bool t2v_conv5_x3_ok(int B, int Cin, int T, int Cout, int KS) {
-    // T2V_CONV_X3: 0 = never, 1 = whenever the shape allows it (measurement), default: launches of >= 192 tiles only.  Measured on the
+    // t2v_conv1d_x3_set_mode / T2V_CONV_X3: 0 = never, 1 = whenever the shape allows it (tests, measurement), default 2: launches of >= 192 tiles only.  Measured on the
     // step's shapes (tools/dbg/conv_x3_time.py, T2V_CX3_DBG): at B = 6 the 512 -> 512 Postnet layer is 96 tiles; cut four ways over
     // its input channels the kernel's loop takes 45 us, but the two split passes (15 us), the raw tiles of the channel split going to
     // scratch and back and the epilogue add 46 us — 85-91 us against 80 for k_conv5_fwd<5>, and the fp32 step got 0.33 ms SLOWER with it
     // (11.32 vs 10.98 ms).  At B = 16 (256 tiles, no channel split) it runs the layer in 152 us against 212: that is where it is used.
-    static const int mode = getenv("T2V_CONV_X3") ? atoi(getenv("T2V_CONV_X3")) : 2;
+    const int mode = t2v_conv1d_x3_set_mode(-1);
     if (!mode || KS != 5 || Cin % 16 || Cin < 64 || Cout < 64 || B < 1 || T < 1) return false;
     if (mode == 2 && (long)B * ((T + CX_BN - 1) / CX_BN) * ((Cout + CX_BM - 1) / CX_BM) < 192) return false;
     return t2v_gemm_f32_set_mode(-1) != 0;

@@ -77,7 +77,7 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_stamp', 't2v_debug_spin', 't2v_
            't2v_decoder_train_fwd_persistent16', 't2v_decoder_train_persist16_supported',
            't2v_decoder_train_persist16_scratch_floats', 't2v_decoder_bwd_persistent16', 't2v_decoder_bwd_persist16_supported',
            't2v_decoder_bwd_persist16_scratch_floats', 't2v_decoder_bwd_persist16_dq_offset', 't2v_decoder_bwd_persist16_slices',
-           't2v_decoder_bwd_persist16_fits', 't2v_gemm_f32_set_mode',
+           't2v_decoder_bwd_persist16_fits', 't2v_gemm_f32_set_mode', 't2v_conv1d_x3_set_mode',
            't2v_decoder_bwd_persistent16_prepare', 't2v_decoder_bwd_persistent16_prepared')
 
 
@@ -128,6 +128,7 @@ def load_library():
     lib.t2v_decoder_bwd_persist16_slices.argtypes = [C.c_int]
     lib.t2v_decoder_bwd_persist16_fits.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.t2v_gemm_f32_set_mode.argtypes = [C.c_int]
+    lib.t2v_conv1d_x3_set_mode.argtypes = [C.c_int]
     lib.t2v_decoder_train_persist_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.t2v_decoder_train_persist_scratch_floats.restype = C.c_long
     lib.t2v_decoder_bwd_persist_supported.argtypes = [C.c_int, C.c_int]

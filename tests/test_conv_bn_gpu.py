@@ -1,15 +1,10 @@
 """Conv1d+BatchNorm1d+activation HIP kernels (implicit-GEMM MFMA conv, per-channel BN) vs a plain PyTorch
 fp32 CPU reference of the same op, forward and backward, ragged shapes."""
-import os
-
 import pytest
 import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
-# (the x3 convolution serves launches of >= 192 tiles by default — B = 16 — and every eligible shape under T2V_CONV_X3=1: the switch
-#  is read once per process, so it is set here, before the library's first convolution, for test_conv1d_x3_is_fp32_class)
-os.environ.setdefault('T2V_CONV_X3', '1')
 
 
 def _ref(x, w, b, gamma, beta, act, training, rm, rv):
@@ -206,8 +201,8 @@ def test_conv1d_x3_is_fp32_class(B, Cin, Cout, T):
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr())
     errs = {}
-    assert os.environ.get('T2V_CONV_X3', '1') == '1', "this test forces the x3 path (T2V_CONV_X3=1 is read once per process)"
     prev = lib.t2v_gemm_f32_set_mode(-1)
+    prev_c = lib.t2v_conv1d_x3_set_mode(1)          # every eligible shape (default: launches of >= 192 tiles only)
     try:
         for mode in (1, 0):
             lib.t2v_gemm_f32_set_mode(mode)
@@ -233,6 +228,7 @@ def test_conv1d_x3_is_fp32_class(B, Cin, Cout, T):
             errs[mode] = (e_y, e_dx, e_s, e_q)
     finally:
         lib.t2v_gemm_f32_set_mode(prev)
+        lib.t2v_conv1d_x3_set_mode(prev_c)
     print('conv1d k5 B=%d %d->%d T=%d: max |err| / sum|wx|  x3 y %.2e dx %.2e (BN sums %.1e / %.1e)   fp32-MFMA y %.2e dx %.2e' % (
         B, Cin, Cout, T, errs[1][0], errs[1][1], errs[1][2], errs[1][3], errs[0][0], errs[0][1]))
     bound = 2e-7 * max(4.0, (5 * Cin) ** 0.5)

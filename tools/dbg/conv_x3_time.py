@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(
 import torch
 import t2v_hip
 lib = t2v_hip.load_library()
+lib.t2v_conv1d_x3_set_mode(1)
 g = torch.Generator().manual_seed(5)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = lambda t: C.c_void_p(t.data_ptr())
