@@ -313,6 +313,103 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd(BnBwdArgs a) {
     }
 }
 
+// Backward of few WIDE channels (round 6; the reference encoder's first layers: 32 channels of B*H*W = 48 000 / 12 000 values at
+// B = 6, 128 000 / 32 000 at B = 16): one workgroup per channel made k_bn_act_bwd an 86 us launch on 32 CUs — twice — on the chain that
+// bounds the tail of the step (171-410 us at B = 16).  Two launches over a (channel, slice) grid instead: k_bn_bwd_part sums dz and
+// dz * xhat of its slice, k_bn_bwd_apply adds the slices' partials in the fixed order s = 0, 1, ... (every workgroup of a channel gets
+// the same bits) and writes its slice of dy; slice 0 writes dgamma / dbeta.
+__global__ __launch_bounds__(256) void k_bn_bwd_part(BnBwdArgs a, float* __restrict__ part, int chunk) {
+    __shared__ float scr[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const float mean = a.mean[m], rstd = a.rstd[m], gam = a.gamma[m];
+    const float g = gam * rstd, bt = a.beta[m] - mean * gam * rstd;
+    const int nel = a.B * a.T, lo = blockIdx.y * chunk, hi = min(nel, lo + chunk);
+    float s1 = 0.f, s2 = 0.f;
+    for (int i0 = lo; i0 < hi; i0 += 256 * BN_UN) {
+        float yv[BN_UN], dv[BN_UN];
+        size_t off[BN_UN];
+#pragma unroll
+        for (int e = 0; e < BN_UN; ++e) {
+            const int i = i0 + tid + 256 * e, ic = min(i, hi - 1);
+            const int b = ic / a.T, t = ic - b * a.T;
+            off[e] = ((size_t)b * a.M + m) * a.T + t;
+            yv[e] = a.y[off[e]];
+            dv[e] = a.dout[off[e]];
+        }
+#pragma unroll
+        for (int e = 0; e < BN_UN; ++e) {
+            if (i0 + tid + 256 * e < hi) {
+                float xhat;
+                const float dz = bn_dz_v(a, off[e], yv[e], dv[e], g, bt, xhat, mean, rstd);
+                s1 += dz;
+                s2 = fmaf(dz, xhat, s2);
+            }
+        }
+    }
+    const float S1 = block_sum_256(s1, scr);
+    const float S2 = block_sum_256(s2, scr);
+    if (tid == 0) {
+        part[((size_t)blockIdx.y * a.M + m) * 2] = S1;
+        part[((size_t)blockIdx.y * a.M + m) * 2 + 1] = S2;
+    }
+}
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwdArgs a, const float* __restrict__ part, int chunk) {
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const float mean = a.mean[m], rstd = a.rstd[m], gam = a.gamma[m];
+    const float g = gam * rstd, bt = a.beta[m] - mean * gam * rstd;
+    const int nel = a.B * a.T, lo = blockIdx.y * chunk, hi = min(nel, lo + chunk);
+    float S1 = 0.f, S2 = 0.f;
+    for (int s = 0; s < (int)gridDim.y; ++s) {          // (uniform loads, <= 64 slices, the same order in every workgroup)
+        S1 += part[((size_t)s * a.M + m) * 2];
+        S2 += part[((size_t)s * a.M + m) * 2 + 1];
+    }
+    if (tid == 0 && blockIdx.y == 0) { a.dbeta[m] = S1; a.dgamma[m] = S2; if (a.dconv_bias) a.dconv_bias[m] = a.eval_mode ? g * S1 : 0.f; }
+    const float n = (float)a.B * (float)a.T;
+    const float m1 = a.eval_mode ? 0.f : S1 / n, m2 = a.eval_mode ? 0.f : S2 / n;
+    for (int i0 = lo; i0 < hi; i0 += 256 * BN_UN) {
+        float yv[BN_UN], dv[BN_UN];
+        size_t off[BN_UN];
+#pragma unroll
+        for (int e = 0; e < BN_UN; ++e) {
+            const int i = i0 + tid + 256 * e, ic = min(i, hi - 1);
+            const int b = ic / a.T, t = ic - b * a.T;
+            off[e] = ((size_t)b * a.M + m) * a.T + t;
+            yv[e] = a.y[off[e]];
+            dv[e] = a.dout[off[e]];
+        }
+#pragma unroll
+        for (int e = 0; e < BN_UN; ++e) {
+            if (i0 + tid + 256 * e < hi) {
+                float xhat;
+                const float dz = bn_dz_v(a, off[e], yv[e], dv[e], g, bt, xhat, mean, rstd);
+                a.dy[off[e]] = g * (dz - m1 - xhat * m2);
+            }
+        }
+    }
+}
+static float* bn_part_scratch(size_t floats);
+// launches the backward of `a`: sliced for few wide channels, else one workgroup per channel
+static void bn_bwd_launch(BnBwdArgs& a, hipStream_t stream) {
+    static const int split_on = getenv("T2V_BN_SPLIT") ? atoi(getenv("T2V_BN_SPLIT")) : 1;
+    const long nel = (long)a.B * a.T;
+    if (split_on && a.M <= 128 && nel >= 8192) {
+        long S = (nel + 2047) / 2048;                   // >= 2048 values per workgroup ...
+        if (S * a.M > 1024) S = 1024 / a.M;             // ... and at most ~4 workgroups per CU
+        if (S > 64) S = 64;
+        if (S >= 2) {
+            float* part = bn_part_scratch((size_t)S * a.M * 2);
+            if (part) {
+                const int chunk = (int)(((nel + S - 1) / S + 255) / 256 * 256);
+                const int Sy = (int)((nel + chunk - 1) / chunk);
+                k_bn_bwd_part<<<dim3(a.M, Sy), 256, 0, stream>>>(a, part, chunk);
+                k_bn_bwd_apply<<<dim3(a.M, Sy), 256, 0, stream>>>(a, part, chunk);
+                return;
+            }
+        }
+    }
+    k_bn_act_bwd<<<a.M, 256, 0, stream>>>(a);
+}
+
 // library-owned ring for the partial statistics above (a few hundred floats per launch; a slice comes round again 4 MB later —
 // a captured graph keeps the slices of its nodes, and graphs / eager steps of one engine never run at the same time)
 #include <atomic>
@@ -390,7 +487,7 @@ extern "C" int t2v_bn_act_bwd(const float* y, const float* dout, const float* me
     a.dgamma = dgamma; a.dbeta = dbeta; a.dconv_bias = dconv_bias; a.B = B; a.M = M; a.T = T; a.act = act; a.p_drop = p_drop;
     a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
     a.eval_mode = 0;
-    k_bn_act_bwd<<<M, 256, 0, stream>>>(a);
+    bn_bwd_launch(a, stream);
     return t2v_check_launch();
 }
 
@@ -408,6 +505,6 @@ extern "C" int t2v_bn_act_bwd_eval(const float* y, const float* dout, const floa
     a.dgamma = dgamma; a.dbeta = dbeta; a.dconv_bias = dconv_bias; a.B = B; a.M = M; a.T = T; a.act = act; a.p_drop = p_drop;
     a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
     a.eval_mode = 1;
-    k_bn_act_bwd<<<M, 256, 0, stream>>>(a);
+    bn_bwd_launch(a, stream);
     return t2v_check_launch();
 }
