@@ -484,6 +484,28 @@ int t2v_gemm_f32_splitk(const float* A, long sAi, long sAk, const float* B, long
  * mode 0: v_mfma_f32_32x32x2_f32 for every product.  Pass -1 to query.  Returns the previous mode.  Process-wide. */
 int t2v_gemm_f32_set_mode(int x3);
 
+/* Grouped form of the large fp32 products (round 6): for every group g and part p   C[g][p] (+)= A_g · B_{g,p}^T   with all A_g
+ * (M x K) and B_{g,p} (N[p] x K), element strides as in t2v_gemm_f32.  The decoder's four nn.LSTMCell weight gradients
+ * (reference model.py:221-226 under autograd) are two groups — A = the gate gradients of a cell, parts = the column blocks
+ * [prenet | h_att | ctx] / [h_att + ctx | h_dec] of its input: in x3 mode (t2v_gemm_f32_set_mode) every operand is split ONCE and
+ * all tiles run as ONE launch (1 024 tiles = two full rounds of the chip, no k-split); otherwise, or when an N[p] is not a
+ * multiple of 128, the products run one by one on t2v_gemm_f32.  ngroups <= 2, nb <= 3.  scratch:
+ * t2v_gemm_f32_grouped_scratch_floats() floats, 16-byte aligned. */
+typedef struct t2v_gemm_group {
+    const float* A;
+    long sAi;
+    long sAk;
+    int nb;
+    const float* B[3];
+    long sBj[3];
+    long sBk[3];
+    int N[3];
+    float* C[3];
+    int ldc[3];
+} t2v_gemm_group;
+long t2v_gemm_f32_grouped_scratch_floats(const t2v_gemm_group* groups, int ngroups, int M, int K);
+int t2v_gemm_f32_grouped(const t2v_gemm_group* groups, int ngroups, int M, int K, int accumulate, float* scratch, void* stream);
+
 /* ... and the fp32 k = 5 Conv1d forward / data gradient (t2v_conv1d_fwd / t2v_conv1d_bwd) on the same six-product scheme
  * (csrc/conv_x3.hip).  mode 0: never; 1: every eligible shape (KS = 5, Cin % 16 == 0, Cin, Cout >= 64); 2 (default; T2V_CONV_X3
  * presets it): launches of >= 192 tiles of 128 x 128 only — at the B = 6 step's shapes its fixed costs (split passes, channel-split

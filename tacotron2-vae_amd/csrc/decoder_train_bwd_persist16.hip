@@ -786,7 +786,6 @@ static int q16_run(const t2v_dec_train_persist_weights* w, const t2v_dec_train_b
     size_t n[6];
     q16_layout(B, T_in, T_out, n);
     const int S = q16_slices(T_in);
-    const size_t n_dq = (size_t)T_out * B * S * 128;
     if (((uintptr_t)scratch & 15) || ((uintptr_t)DQP & 15)) return T2V_ERR_ARG;
     if (!q16_offsets_ok(B, T_in, T_out)) return T2V_ERR_ARG;              // 31-bit buffer offsets
     if (prepare) {

@@ -54,6 +54,12 @@ class _DecTrainPersistWeights(C.Structure):
         'w_ih_att', 'w_hh_att', 'w_ih_dec', 'w_hh_dec', 'bias_dec', 'wq', 'wcomb', 'v')]
 
 
+class _GemmGroup(C.Structure):
+    C_NAME = 't2v_gemm_group'
+    _fields_ = [('A', C.c_void_p), ('sAi', C.c_long), ('sAk', C.c_long), ('nb', C.c_int), ('B', C.c_void_p * 3), ('sBj', C.c_long * 3),
+                ('sBk', C.c_long * 3), ('N', C.c_int * 3), ('C', C.c_void_p * 3), ('ldc', C.c_int * 3)]
+
+
 class _DecInferBufs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         'memory', 'pm', 'lengths', 'XS', 'CA', 'CD', 'QP', 'AL', 'ACUM', 'PRE', 'MEL', 'GATE', 'stop_flag',
@@ -77,7 +83,8 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_stamp', 't2v_debug_spin', 't2v_
            't2v_decoder_train_fwd_persistent16', 't2v_decoder_train_persist16_supported',
            't2v_decoder_train_persist16_scratch_floats', 't2v_decoder_bwd_persistent16', 't2v_decoder_bwd_persist16_supported',
            't2v_decoder_bwd_persist16_scratch_floats', 't2v_decoder_bwd_persist16_dq_offset', 't2v_decoder_bwd_persist16_slices',
-           't2v_decoder_bwd_persist16_fits', 't2v_gemm_f32_set_mode', 't2v_conv1d_x3_set_mode',
+           't2v_decoder_bwd_persist16_fits', 't2v_gemm_f32_set_mode', 't2v_conv1d_x3_set_mode', 't2v_gemm_f32_grouped',
+           't2v_gemm_f32_grouped_scratch_floats',
            't2v_decoder_bwd_persistent16_prepare', 't2v_decoder_bwd_persistent16_prepared')
 
 
@@ -129,6 +136,9 @@ def load_library():
     lib.t2v_decoder_bwd_persist16_fits.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.t2v_gemm_f32_set_mode.argtypes = [C.c_int]
     lib.t2v_conv1d_x3_set_mode.argtypes = [C.c_int]
+    lib.t2v_gemm_f32_grouped_scratch_floats.argtypes = [C.POINTER(_GemmGroup), C.c_int, C.c_int, C.c_int]
+    lib.t2v_gemm_f32_grouped_scratch_floats.restype = C.c_long
+    lib.t2v_gemm_f32_grouped.argtypes = [C.POINTER(_GemmGroup), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.t2v_decoder_train_persist_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.t2v_decoder_train_persist_scratch_floats.restype = C.c_long
     lib.t2v_decoder_bwd_persist_supported.argtypes = [C.c_int, C.c_int]
@@ -1266,12 +1276,17 @@ class DecoderCore(torch.autograd.Function):
                     if ctx.pre2 is None:        # the prenet columns of attention_rnn.weight_ih get their gradient via gpre
                         wg[0][:, :PRE].zero_()
                 d_w_ih_att, d_w_hh_att, d_w_ih_dec, d_w_hh_dec = wg
+                # round 6, fp32: the five LSTM weight-gradient products as ONE launch of the x3 kernel — both gate-gradient operands split
+                # once, 1 024 tiles = two full rounds of the chip (T2V_DW_GROUPED=0: one by one as before)
+                grouped = (not _BF16 and not split_d and os.environ.get('T2V_DW_GROUPED', '1') != '0'
+                           and os.environ.get('T2V_DW_TWO_STREAMS', '0') != '1')
                 if ctx.pre2 is not None:    # the input projection of the prenet output, folded into this node: the Prenet's
                     # own backward (issued on this same stream when an engine is active) waits for d_pre, so it goes first
                     pre_c = ctx.pre2 if B == Bt else ctx.pre2.view(T, Bt, PRE)[:, b0:b0 + B].reshape(TB, PRE)
                     if ctx.needs_input_grad[17] and ctx.pre_on_side:
                         dpre_l.append(gemm(dga2, ctx.wrefs[0].detach()[:, :PRE].t()).view(T, B, PRE))
-                    gemm(dga2.t(), pre_c.t(), out=d_w_ih_att[:, :PRE], accumulate=not first)
+                    if not grouped:
+                        gemm(dga2.t(), pre_c.t(), out=d_w_ih_att[:, :PRE], accumulate=not first)
                 # each product lands in its own tensor (no split / copy afterwards).  fp32: the own large-tile fp32 MFMA GEMM;
                 # bf16_run: the own large-tile bf16 GEMM (k_gemm_bf16_big_rr: operands rounded to bf16 while staged, fp32
                 # accumulation) — no library GEMM is left in either step
@@ -1279,9 +1294,16 @@ class DecoderCore(torch.autograd.Function):
                 # NEXT to the other chains but the chip is shared, so almost all of their time is still on the step's clock)
                 two = os.environ.get('T2V_DW_TWO_STREAMS', '0') == '1' and not split_d      # measurement: the two pairs side by side
                 with side('g', after=fork):
-                    gemm(dga2.t(), x_prev[:, :H].t(), out=d_w_hh_att, accumulate=not first)
-                    gemm(dga2.t(), x_prev[:, H:KATT].t(), out=d_w_ih_att[:, PRE:], accumulate=not first)
-                    if not split_d and not two:
+                    if grouped:
+                        att = [(x_prev[:, :H].t(), d_w_hh_att), (x_prev[:, H:KATT].t(), d_w_ih_att[:, PRE:])]
+                        if ctx.pre2 is not None:
+                            att.insert(0, (pre_c.t(), d_w_ih_att[:, :PRE]))
+                        gemm_grouped([(dga2.t(), att),
+                                      (dgd2.t(), [(x_cur[:, :KATT].t(), d_w_ih_dec), (x_cur[:, KATT:].t(), d_w_hh_dec)])], accumulate=not first)
+                    else:
+                        gemm(dga2.t(), x_prev[:, :H].t(), out=d_w_hh_att, accumulate=not first)
+                        gemm(dga2.t(), x_prev[:, H:KATT].t(), out=d_w_ih_att[:, PRE:], accumulate=not first)
+                    if not grouped and not split_d and not two:
                         gemm(dgd2.t(), x_cur[:, :KATT].t(), out=d_w_ih_dec, accumulate=not first)
                         gemm(dgd2.t(), x_cur[:, KATT:].t(), out=d_w_hh_dec, accumulate=not first)
                 if two:
@@ -1828,6 +1850,33 @@ def _small_grads(params, n, f32):
         g = grad_slot(p) if p is not None else None
         out.append(torch.empty(n, **f32) if g is None else g)
     return out
+
+
+def gemm_grouped(groups, accumulate=False):
+    """groups: [(A (M,K), [(B_p (N_p,K), out_p (M,N_p)), ...]), ...] (at most two groups of at most three parts, one common M and K):
+    out_p (+)= A · B_p^T for every part.  fp32 x3 mode: every operand split once, all tiles in ONE launch (t2v_gemm_f32_grouped);
+    bf16_run or shapes the grouped kernel does not take: the products one by one through gemm()."""
+    lib = _require_gpu(groups[0][0])
+    M, K = groups[0][0].shape
+    ok = not _BF16 and 1 <= len(groups) <= 2
+    for A, parts in groups:
+        ok = ok and A.shape == (M, K) and A.dtype == torch.float32 and 1 <= len(parts) <= 3
+        for Bp, out in parts:
+            ok = ok and Bp.shape[1] == K and Bp.dtype == torch.float32 and out.shape == (M, Bp.shape[0]) and out.stride(1) == 1 and Bp.shape[0] % 128 == 0
+    if not ok:
+        for A, parts in groups:
+            for Bp, out in parts:
+                gemm(A, Bp, out=out, accumulate=accumulate)
+        return
+    arr = (_GemmGroup * len(groups))()
+    for g, (A, parts) in zip(arr, groups):
+        g.A, g.sAi, g.sAk, g.nb = A.data_ptr(), A.stride(0), A.stride(1), len(parts)
+        for p, (Bp, out) in enumerate(parts):
+            g.B[p], g.sBj[p], g.sBk[p], g.N[p] = Bp.data_ptr(), Bp.stride(0), Bp.stride(1), Bp.shape[0]
+            g.C[p], g.ldc[p] = out.data_ptr(), out.stride(0)
+    nscr = lib.t2v_gemm_f32_grouped_scratch_floats(arr, len(groups), M, K)
+    scr = torch.empty(max(nscr, 4), device=groups[0][0].device, dtype=torch.float32)
+    _check(lib.t2v_gemm_f32_grouped(arr, len(groups), M, K, int(bool(accumulate)), _p(scr), _stream()), 't2v_gemm_f32_grouped')
 
 
 def set_f32_gemm_mode(x3):

@@ -229,3 +229,47 @@ def test_x3_gemm_throughput_on_the_lstm_weight_gradient_shapes():
         assert res[(4096, 2560, True)] > res[(4096, 2560, False)]
     finally:
         t2v_hip.set_f32_gemm_mode(prev)
+
+
+@pytest.mark.parametrize("TB", [2400, 1237])
+def test_grouped_gemm_for_the_lstm_weight_gradients(TB):
+    """Round 6: the decoder's five LSTM weight-gradient products as ONE launch (t2v_gemm_f32_grouped: both gate-gradient operands split
+    once, the column blocks [prenet | h_att | ctx] / [h_att + ctx | h_dec] of a product routed to their own tensors, incl. a column
+    block of a wider matrix) against fp64 and against the products issued one by one; accumulate; x3 and fp32-MFMA mode;
+    bit-reproducible."""
+    import t2v_hip
+    g = torch.Generator().manual_seed(TB)
+    dga, dgd = (torch.randn(TB, 4096, generator=g) * 0.1).cuda(), (torch.randn(TB, 4096, generator=g) * 0.1).cuda()
+    xs = torch.randn(TB + 1, 2560, generator=g).cuda()
+    pre = torch.randn(TB, 256, generator=g).cuda()
+    x_prev, x_cur = xs[:TB], xs[1:]
+
+    def run(accumulate, seed_out):
+        w_ih_att = torch.full((4096, 768), seed_out, device='cuda')
+        w_hh_att = torch.full((4096, 1024), seed_out, device='cuda')
+        w_ih_dec = torch.full((4096, 1536), seed_out, device='cuda')
+        w_hh_dec = torch.full((4096, 1024), seed_out, device='cuda')
+        t2v_hip.gemm_grouped([(dga.t(), [(pre.t(), w_ih_att[:, :256]), (x_prev[:, :1024].t(), w_hh_att), (x_prev[:, 1024:1536].t(), w_ih_att[:, 256:])]),
+                              (dgd.t(), [(x_cur[:, :1536].t(), w_ih_dec), (x_cur[:, 1536:].t(), w_hh_dec)])], accumulate=accumulate)
+        return w_ih_att, w_hh_att, w_ih_dec, w_hh_dec
+
+    want = [torch.cat([dga.double().t() @ pre.double(), dga.double().t() @ x_prev[:, 1024:1536].double()], 1), dga.double().t() @ x_prev[:, :1024].double(),
+            dgd.double().t() @ x_cur[:, :1536].double(), dgd.double().t() @ x_cur[:, 1536:].double()]
+    prev = t2v_hip.set_f32_gemm_mode(None)
+    try:
+        for mode in (True, False):
+            t2v_hip.set_f32_gemm_mode(mode)
+            got = run(False, float('nan'))
+            again = run(False, float('nan'))
+            for a, b, w in zip(got, again, want):
+                assert torch.equal(a, b)
+                assert (a.double() - w).abs().max().item() < 2e-5 * w.abs().max().item()
+            acc = run(True, 0.5)
+            for a, w in zip(acc, want):
+                assert (a.double() - (w + 0.5)).abs().max().item() < 2e-5 * w.abs().max().item()
+            # the same products one by one
+            one = torch.empty(4096, 1536, device='cuda')
+            t2v_hip.gemm(dgd.t(), x_cur[:, :1536].t(), out=one)
+            assert (one - got[2]).abs().max().item() < 2e-6 * want[2].abs().max().item()
+    finally:
+        t2v_hip.set_f32_gemm_mode(prev)

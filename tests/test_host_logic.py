@@ -157,13 +157,17 @@ def test_ctypes_structs_match_header_in_package_and_integration_stub():
              '_DecInferBufs': 't2v_dec_infer_bufs', '_DecTrainPersistWeights': 't2v_dec_train_persist_weights'}
     for cls_name in [n for n in dir(t2v_hip) if isinstance(getattr(t2v_hip, n), type) and issubclass(getattr(t2v_hip, n), C.Structure)
                      and n != 'Structure']:
-        assert cls_name in pairs or cls_name.lstrip('_') in [k.lstrip('_') for k in pairs] or cls_name.startswith('_Dec'), cls_name
-    for cls_name, sname in list(pairs.items()) + [(n, None) for n in dir(t2v_hip) if n.startswith('_Dec') and n not in pairs]:
+        assert (cls_name in pairs or cls_name.lstrip('_') in [k.lstrip('_') for k in pairs] or cls_name.startswith('_Dec')
+                or hasattr(getattr(t2v_hip, cls_name), 'C_NAME')), cls_name
+    named = [n for n in dir(t2v_hip) if isinstance(getattr(t2v_hip, n), type) and issubclass(getattr(t2v_hip, n), C.Structure)
+             and hasattr(getattr(t2v_hip, n), 'C_NAME') and n not in pairs]
+    is_ptr = lambda t: t is C.c_void_p or getattr(t, '_type_', None) is C.c_void_p      # (a pointer, or an array of pointers)
+    for cls_name, sname in list(pairs.items()) + [(n, None) for n in named]:
         cls = getattr(t2v_hip, cls_name)
         if sname is None:
             sname = getattr(cls, 'C_NAME')
         want = hdr[sname]
-        got = [(n, t is C.c_void_p) for n, t in cls._fields_]
+        got = [(n, is_ptr(t)) for n, t in cls._fields_]
         assert got == want, (cls_name, got, want)
     # the stub a maintainer copies out of INTEGRATION.md
     doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
