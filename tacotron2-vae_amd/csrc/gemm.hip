@@ -827,10 +827,28 @@ __device__ __forceinline__ void gx_dma16(const void* gsrc, unsigned lds_addr) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
 }
-#define GX_NB 3                     // stage buffers: the planes of stage i + 2 are requested during stage i
+#ifndef GX_NB
+#define GX_NB 2                     // stage buffers: the planes of stage i + GX_NB - 1 are requested during stage i.  Two (48 KB, three
+                                    // workgroups per CU) and three (72 KB, two per CU) measure the same alone and in the step (10.82 .. 10.95 ms):
+                                    // what bounds the kernel is what a CU can pull in, ~13 B/clk (24 KB per stage against 768 MFMA cycles per SIMD
+                                    // = the measured 0.41 MFMA-busy), not the depth of the prefetch
+#endif
+#ifndef GX_LDS_PAD
+#define GX_LDS_PAD 0                // unused 16-byte slots on top (measurement: how many workgroups / how much free LDS a CU keeps)
+#endif
+#define GX_WAITN_(nb) (6 * ((nb) - 2))
+#if GX_NB == 2
+#define GX_WAITN 0
+#elif GX_NB == 3
+#define GX_WAITN 6
+#else
+#define GX_WAITN 12
+#endif
+#define GX_STR2(x) #x
+#define GX_STR(x) GX_STR2(x)
 __global__ __launch_bounds__(256, 2) void k_gemm_x3p(GemmX3Args a) {
-    // [buffer][A | B][plane][k-group][row]: 72 KB, two workgroups per CU
-    __shared__ uint4 lds_[GX_NB * 2 * 3 * 2 * GX_BM];
+    // [buffer][A | B][plane][k-group][row]: 24 KB per buffer
+    __shared__ uint4 lds_[GX_NB * 2 * 3 * 2 * GX_BM + GX_LDS_PAD];
     uint4 (*Ls)[2][3][2][GX_BM] = (uint4 (*)[2][3][2][GX_BM])&lds_[0];
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)&lds_[0];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -870,15 +888,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_x3p(GemmX3Args a) {
             for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
     const int am = 64 * wm + (lane & 31), bn = 64 * wn + (lane & 31), kq = lane >> 5;
 #define GX_MFMA(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const gx_bf16x8*)&(A_), *(const gx_bf16x8*)&(B_), C_, 0, 0, 0)
-    stage_dma(st0, 0);
-    stage_dma(st0 + 1, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // the first stage has landed, the second may still be on its way
+#pragma unroll
+    for (int d = 0; d < GX_NB - 1; ++d) stage_dma(st0 + d, d);
+    asm volatile("s_waitcnt vmcnt(" GX_STR(GX_WAITN) ")" ::: "memory");         // the first stage has landed, the later ones may still be on their way
     __syncthreads();
     int buf = 0;
     for (int st = st0; st < st1; ++st) {
-        // the stage after next goes into the buffer everybody left at the last barrier
-        const int nb2 = buf == 0 ? 2 : buf - 1;             // (buf + 2) % 3
-        stage_dma(st + 2, nb2);
+        // the stage GX_NB - 1 ahead goes into the buffer everybody left at the last barrier
+        const int nb2 = buf == 0 ? GX_NB - 1 : buf - 1;     // (buf + GX_NB - 1) % GX_NB
+        stage_dma(st + GX_NB - 1, nb2);
         uint4 av[3][2], bv[3][2];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -893,11 +911,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_x3p(GemmX3Args a) {
         GX_MFMA(av[PA][1], bv[PB][0], acc[1][0]); GX_MFMA(av[PA][1], bv[PB][1], acc[1][1])
         GX_ALL(2, 0); GX_ALL(0, 2); GX_ALL(1, 1); GX_ALL(1, 0); GX_ALL(0, 1); GX_ALL(0, 0);
 #undef GX_ALL
-        // stage st + 1 (requested a stage ago) must have landed before anybody passes the barrier: requests come back in order, so it
-        // has once only this stage's six requests are outstanding
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // stage st + 1 must have landed before anybody passes the barrier: requests come back in order, so it has once only the
+        // requests of the GX_NB - 2 stages behind it (six per wave and stage) are outstanding
+        asm volatile("s_waitcnt vmcnt(" GX_STR(GX_WAITN) ")" ::: "memory");
         __syncthreads();        // ... and this stage's LDS reads are done
-        buf = buf == 2 ? 0 : buf + 1;
+        buf = buf == GX_NB - 1 ? 0 : buf + 1;
     }
 #undef GX_MFMA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the surplus requests of the last stages
