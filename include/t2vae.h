@@ -374,6 +374,8 @@ int t2v_decoder_infer_persistent(const t2v_dec_persist_weights* w, const t2v_dec
  *   t2v_conv1d_flip_weights : Wt[i] (Cin, Cout, KS) = W[i] (Cout, Cin, KS) transposed with the taps reversed — the operand
  *                    of the data-gradient convolution — for n <= 16 layers in ONE launch (host arrays of n pointers / dims). */
 int t2v_conv1d_stat_blocks(int B, int T, int Cin, int Cout, int KS);
+/* the same for t2v_conv1d_fwd_bf16 (bf16_run keeps the tiles of its own kernels) */
+int t2v_conv1d_stat_blocks_bf16(int B, int T, int Cin, int Cout, int KS);
 int t2v_conv1d_fwd(const float* W, const float* X, const float* bias, float* Y, float* stat_part,
                    int B, int Cin, int T, int Cout, int KS, void* stream);
 int t2v_conv1d_dw_scratch_floats(int B, int Cin, int T, int Cout, int KS);   /* 0 -> dw_scratch may be NULL */
@@ -505,6 +507,10 @@ typedef struct t2v_gemm_group {
 } t2v_gemm_group;
 long t2v_gemm_f32_grouped_scratch_floats(const t2v_gemm_group* groups, int ngroups, int M, int K);
 int t2v_gemm_f32_grouped(const t2v_gemm_group* groups, int ngroups, int M, int K, int accumulate, float* scratch, void* stream);
+/* bf16_run form: the same grouping on ONE bf16 plane per operand (operands rounded to bf16, RNE, once by the split pass; fp32
+ * accumulation — the arithmetic of t2v_gemm_bf16). */
+long t2v_gemm_bf16_grouped_scratch_floats(const t2v_gemm_group* groups, int ngroups, int M, int K);
+int t2v_gemm_bf16_grouped(const t2v_gemm_group* groups, int ngroups, int M, int K, int accumulate, float* scratch, void* stream);
 
 /* ... and the fp32 k = 5 Conv1d forward / data gradient (t2v_conv1d_fwd / t2v_conv1d_bwd) on the same six-product scheme
  * (csrc/conv_x3.hip).  mode 0: never; 1: every eligible shape (KS = 5, Cin % 16 == 0, Cin, Cout >= 64); 2 (default; T2V_CONV_X3

@@ -1107,6 +1107,12 @@ extern "C" int t2v_conv1d_stat_blocks(int B, int T, int Cin, int Cout, int KS) {
     return (B * T + CG_BN - 1) / CG_BN;
 }
 
+// ... for t2v_conv1d_fwd_bf16 (its kernels keep the tile choice of the fp32-MFMA kernels whatever the x3 mode says)
+extern "C" int t2v_conv1d_stat_blocks_bf16(int B, int T, int Cin, int Cout, int KS) {
+    if (conv5_tiled_ok(Cin, KS)) { int ks; const int BN = conv5_pick_bn_ks(T, B, Cout, Cin, &ks); return B * ((T + BN - 1) / BN); }
+    return (B * T + CG_BN - 1) / CG_BN;
+}
+
 extern "C" int t2v_conv1d_dw_scratch_floats(int B, int Cin, int T, int Cout, int KS) {
     if (!conv5_tiled_ok(Cin, KS)) return 0;
     const int ns = conv5_dw_splits(B, Cin, T, Cout, true);        // (the bf16 kernel splits at least as far as the fp32 one)

@@ -223,12 +223,12 @@ static int gemm_splits(int M, int N, int K) {
     return ns < 2 ? 1 : (int)ns;
 }
 static bool gemm_x3_shape_ok(int M, int N, int K);
-static long gemm_x3_scratch_floats(int M, int N, int K);
+static long gemm_x3_scratch_floats(int M, int N, int K, int np);
 static int gemm_x3_mode();
 extern "C" long t2v_gemm_splitk_scratch_floats(int M, int N, int K) {
     if (M < 1 || N < 1 || K < 1) return 0;
     // round 6: the x3 path takes the large products — its scratch holds the bf16 planes of both operands (+ split-K partial tiles)
-    if (gemm_x3_mode() && gemm_x3_shape_ok(M, N, K)) return gemm_x3_scratch_floats(M, N, K);
+    if (gemm_x3_mode() && gemm_x3_shape_ok(M, N, K)) return gemm_x3_scratch_floats(M, N, K, 3);
     const int ns = gemm_splits(M, N, K);
     return ns > 1 ? (long)ns * M * N : 0;
 }
@@ -705,8 +705,11 @@ static int gemm_bf16_big_splits(int M, int N, int K) {
     return ns < 2 ? 1 : (int)ns;
 }
 // (whether the 128x128 or the 64x64 kernel takes a product also depends on its strides: the scratch covers either)
+static bool gemm_bf16_planes_ok(int M, int N, int K);
+static long gemm_x3_scratch_floats(int M, int N, int K, int np);
 extern "C" long t2v_gemm_bf16_splitk_scratch_floats(int M, int N, int K) {
     if (M < 1 || N < 1 || K < 1) return 0;
+    if (gemm_bf16_planes_ok(M, N, K)) return gemm_x3_scratch_floats(M, N, K, 1);
     long big = 0;
     if (M >= GBB_BM && N >= GBB_BN && !(M & 3) && !(N & 3)) {
         const int ns = gemm_bf16_big_splits(M, N, K);
@@ -760,15 +763,16 @@ __device__ __forceinline__ void gx_split8(const float (&v)[8], uint4& p0, uint4&
 // planes of an operand with `rows` rows and K columns: Rp = rows rounded up to 128, G = k-groups rounded up to 4 (32 k);
 // plane p, k-group g, row r -> 16-byte slot (p * G + g) * Rp + r.  Rows >= rows and k >= K are zero.
 static inline long gx_rp(int rows) { return ((long)rows + 127) / 128 * 128; }
-static inline long gx_groups(int K) { return ((long)K + 31) / 32 * 4; }
-static inline long gx_plane_slots(int rows, int K) { return 3 * gx_groups(K) * gx_rp(rows); }
+// np = 3: the x3 planes of an fp32 product (stages of 16 k); np = 1: ONE plane, the bf16-rounded operand of a bf16_run product (stages of 64 k)
+static inline long gx_groups(int K, int np = 3) { return np == 3 ? ((long)K + 31) / 32 * 4 : ((long)K + 63) / 64 * 8; }
+static inline long gx_plane_slots(int rows, int K, int np = 3) { return np * gx_groups(K, np) * gx_rp(rows); }
 // grid (Rp / 64, G / 4): a workgroup splits 64 rows x 32 k.  KC: the operand is contiguous along k (two float4 per row and k-group when
 // aligned), else along its rows (or neither: scalar loads either way).  Every word crosses LDS once so that the plane stores run along
 // the rows (1 KB contiguous per wave) whichever way the loads ran.
-template <bool KC>
+template <bool KC, int NP>
 __global__ __launch_bounds__(256) void k_x3_split(const float* __restrict__ src, long s_row, long s_k, int rows, int K, uint4* __restrict__ dst,
                                                   long Rp, long G) {
-    __shared__ uint4 sm[3][4][64];
+    __shared__ uint4 sm[NP][4][64];
     const int tid = threadIdx.x;
     const int row0 = blockIdx.x * 64, g0 = blockIdx.y * 4;
     const int r = KC ? tid >> 2 : tid & 63, g = KC ? tid & 3 : tid >> 6;
@@ -788,14 +792,18 @@ __global__ __launch_bounds__(256) void k_x3_split(const float* __restrict__ src,
             v[u] = (rin && k0 + u < K) ? x : 0.f;
         }
     }
-    uint4 p0, p1, p2;
-    gx_split8(v, p0, p1, p2);
-    sm[0][g][r] = p0; sm[1][g][r] = p1; sm[2][g][r] = p2;
+    if (NP == 3) {
+        uint4 p0, p1, p2;
+        gx_split8(v, p0, p1, p2);
+        sm[0][g][r] = p0; sm[NP > 1 ? 1 : 0][g][r] = p1; sm[NP > 2 ? 2 : 0][g][r] = p2;
+    } else {        // bf16_run: the operand rounded to bf16 (RNE), nothing else
+        sm[0][g][r] = make_uint4(gemm_pack_bf16x2(v[0], v[1]), gemm_pack_bf16x2(v[2], v[3]), gemm_pack_bf16x2(v[4], v[5]), gemm_pack_bf16x2(v[6], v[7]));
+    }
     __syncthreads();
     const int g2 = tid >> 6, r2 = tid & 63;
     if (row0 + r2 < Rp && g0 + g2 < G) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) dst[(p * G + g0 + g2) * Rp + row0 + r2] = sm[p][g2][r2];
+        for (int p = 0; p < NP; ++p) dst[(p * G + g0 + g2) * Rp + row0 + r2] = sm[p][g2][r2];
     }
 }
 // One launch may cover up to two products that share M and K (t2v_gemm_f32_grouped: the decoder's LSTM weight gradients, DGA^T·[x...]
@@ -836,20 +844,26 @@ __device__ __forceinline__ void gx_dma16(const void* gsrc, unsigned lds_addr) {
 #ifndef GX_LDS_PAD
 #define GX_LDS_PAD 0                // unused 16-byte slots on top (measurement: how many workgroups / how much free LDS a CU keeps)
 #endif
-#define GX_WAITN_(nb) (6 * ((nb) - 2))
-#if GX_NB == 2
-#define GX_WAITN 0
-#elif GX_NB == 3
-#define GX_WAITN 6
-#else
-#define GX_WAITN 12
-#endif
 #define GX_STR2(x) #x
 #define GX_STR(x) GX_STR2(x)
+// wait until at most N of this wave's memory requests are outstanding (N a compile-time constant <= 63)
+template <int N>
+__device__ __forceinline__ void gx_wait_stage() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(N == 0, "add the literal");
+}
+// NP planes per operand, NG k-groups (of 8) per stage: <3, 2> = the x3 form of an fp32 product (six MFMAs per k-block of 16, 24 per
+// wave and stage); <1, 8> = a bf16_run product on pre-rounded operands (one MFMA per k-block, 16 per wave and stage of 64 k)
+template <int NP, int NG>
 __global__ __launch_bounds__(256, 2) void k_gemm_x3p(GemmX3Args a) {
-    // [buffer][A | B][plane][k-group][row]: 24 KB per buffer
-    __shared__ uint4 lds_[GX_NB * 2 * 3 * 2 * GX_BM + GX_LDS_PAD];
-    uint4 (*Ls)[2][3][2][GX_BM] = (uint4 (*)[2][3][2][GX_BM])&lds_[0];
+    // [buffer][A | B][plane][k-group][row]: 24 / 32 KB per buffer
+    __shared__ uint4 lds_[GX_NB * 2 * NP * NG * GX_BM + GX_LDS_PAD];
+    uint4 (*Ls)[2][NP][NG][GX_BM] = (uint4 (*)[2][NP][NG][GX_BM])&lds_[0];
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)&lds_[0];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
@@ -863,20 +877,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_x3p(GemmX3Args a) {
     const GemmX3Prod& P = a.pr[(a.nprod > 1 && lin >= a.pr[1].tile0) ? 1 : 0];
     const int by_ = (lin - P.tile0) / P.tiles_x, bx_ = (lin - P.tile0) - by_ * P.tiles_x;
     const int i0 = by_ * GX_BM, j0 = bx_ * GX_BN;
-    const int nst_all = (int)(a.G / 2);
+    const int nst_all = (int)(a.G / NG);
     const int st0 = a.st_chunk ? blockIdx.z * a.st_chunk : 0, st1 = a.st_chunk ? min(nst_all, st0 + a.st_chunk) : nst_all;
-    // DMA plan of a stage: 24 pieces of 1 KB = {A, B} x 3 planes x 2 k-groups x 2 row halves; wave w issues pieces w, w + 4, ..., w + 20.
-    // A request past the end re-reads the last stage into a buffer nobody reads any more: six requests per wave and stage, always —
+    // DMA plan of a stage: 4 NP NG pieces of 1 KB = {A, B} x NP planes x NG k-groups x 2 row halves; wave w issues pieces w, w + 4, ...
+    // A request past the end re-reads the last stage into a buffer nobody reads any more: NP NG requests per wave and stage, always —
     // what the counted wait below relies on
+    constexpr int NPIECE = NP * NG;         // per wave
     auto stage_dma = [&](int st, int buf) {
         st = min(st, st1 - 1);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < NPIECE; ++i) {
             const int q = wave + 4 * i;
-            const int op = q / 12, rem = q - 12 * op, p = rem >> 2, g = (rem >> 1) & 1, half = rem & 1;
-            const uint4* src = op ? P.Bp + (p * a.G + 2 * st + g) * P.RpB + j0 + 64 * half + lane
-                                  : P.Ap + (p * a.G + 2 * st + g) * P.RpA + i0 + 64 * half + lane;
-            gx_dma16(src, lds0 + 16u * (unsigned)(((((buf * 2 + op) * 3 + p) * 2 + g) * GX_BM) + 64 * half));
+            const int op = q / (2 * NP * NG), rem = q - (2 * NP * NG) * op, p = rem / (2 * NG), g = (rem >> 1) % NG, half = rem & 1;
+            const uint4* src = op ? P.Bp + (p * a.G + NG * st + g) * P.RpB + j0 + 64 * half + lane
+                                  : P.Ap + (p * a.G + NG * st + g) * P.RpA + i0 + 64 * half + lane;
+            gx_dma16(src, lds0 + 16u * (unsigned)(((((buf * 2 + op) * NP + p) * NG + g) * GX_BM) + 64 * half));
         }
     };
     f32x16 acc[2][2];
@@ -890,30 +905,37 @@ __global__ __launch_bounds__(256, 2) void k_gemm_x3p(GemmX3Args a) {
 #define GX_MFMA(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const gx_bf16x8*)&(A_), *(const gx_bf16x8*)&(B_), C_, 0, 0, 0)
 #pragma unroll
     for (int d = 0; d < GX_NB - 1; ++d) stage_dma(st0 + d, d);
-    asm volatile("s_waitcnt vmcnt(" GX_STR(GX_WAITN) ")" ::: "memory");         // the first stage has landed, the later ones may still be on their way
+    gx_wait_stage<NPIECE * (GX_NB - 2)>();          // the first stage has landed, the later ones may still be on their way
     __syncthreads();
     int buf = 0;
     for (int st = st0; st < st1; ++st) {
         // the stage GX_NB - 1 ahead goes into the buffer everybody left at the last barrier
         const int nb2 = buf == 0 ? GX_NB - 1 : buf - 1;     // (buf + GX_NB - 1) % GX_NB
         stage_dma(st + GX_NB - 1, nb2);
-        uint4 av[3][2], bv[3][2];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            av[p][0] = Ls[buf][0][p][kq][am];
-            av[p][1] = Ls[buf][0][p][kq][am + 32];
-            bv[p][0] = Ls[buf][1][p][kq][bn];
-            bv[p][1] = Ls[buf][1][p][kq][bn + 32];
-        }
-        // small terms first; product-major, so that consecutive MFMAs go to different accumulators
 #define GX_ALL(PA, PB)                                      \
         GX_MFMA(av[PA][0], bv[PB][0], acc[0][0]); GX_MFMA(av[PA][0], bv[PB][1], acc[0][1]); \
         GX_MFMA(av[PA][1], bv[PB][0], acc[1][0]); GX_MFMA(av[PA][1], bv[PB][1], acc[1][1])
-        GX_ALL(2, 0); GX_ALL(0, 2); GX_ALL(1, 1); GX_ALL(1, 0); GX_ALL(0, 1); GX_ALL(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < NG / 2; ++ks) {           // k-blocks of 16 of this stage
+            uint4 av[NP][2], bv[NP][2];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                av[p][0] = Ls[buf][0][p][2 * ks + kq][am];
+                av[p][1] = Ls[buf][0][p][2 * ks + kq][am + 32];
+                bv[p][0] = Ls[buf][1][p][2 * ks + kq][bn];
+                bv[p][1] = Ls[buf][1][p][2 * ks + kq][bn + 32];
+            }
+            if constexpr (NP == 3) {
+                // small terms first; product-major, so that consecutive MFMAs go to different accumulators
+                GX_ALL(2, 0); GX_ALL(0, 2); GX_ALL(1, 1); GX_ALL(1, 0); GX_ALL(0, 1); GX_ALL(0, 0);
+            } else {
+                GX_ALL(0, 0);
+            }
+        }
 #undef GX_ALL
         // stage st + 1 must have landed before anybody passes the barrier: requests come back in order, so it has once only the
         // requests of the GX_NB - 2 stages behind it (six per wave and stage) are outstanding
-        asm volatile("s_waitcnt vmcnt(" GX_STR(GX_WAITN) ")" ::: "memory");
+        gx_wait_stage<NPIECE * (GX_NB - 2)>();
         __syncthreads();        // ... and this stage's LDS reads are done
         buf = buf == GX_NB - 1 ? 0 : buf + 1;
     }
@@ -1029,9 +1051,9 @@ static bool gemm_x3_shape_ok(int M, int N, int K) {
 // little on top.  cost(ns) = ceil(tiles * ns / 768) * (1 / ns + 0.08) + 0.03 (ns - 1) reproduces the measured order of ns = 1..4 on
 // 128 / 256 / 384 / 640 tiles at K = 2400 (tools/dbg/x3_time.py with T2V_GEMM_X3_SPLITS: 165 96 83 71 | 171 122 113 136 | 201 152 173
 // 164 | 269 257 271 291 us)
-static int gemm_x3_splits(int M, int N, int K) {
+static int gemm_x3_splits(int M, int N, int K, int np = 3) {
     const long tiles = (long)((M + GX_BM - 1) / GX_BM) * ((N + GX_BN - 1) / GX_BN);
-    const int nst = (int)(gx_groups(K) / 2);
+    const int nst = (int)(gx_groups(K, np) / (np == 3 ? 2 : 8));
     static const int forced = getenv("T2V_GEMM_X3_SPLITS") ? atoi(getenv("T2V_GEMM_X3_SPLITS")) : 0;     // measurement
     if (forced > 0) return forced > nst ? nst : forced;
     int best = 1;
@@ -1044,26 +1066,38 @@ static int gemm_x3_splits(int M, int N, int K) {
     return best;
 }
 // floats of caller scratch the x3 path needs for (M, N, K): the planes of both operands + the split-K partial tiles
-static long gemm_x3_plane_floats(int M, int N, int K) { return 4 * (gx_plane_slots(M, K) + gx_plane_slots(N, K)); }
-static long gemm_x3_scratch_floats(int M, int N, int K) {
-    const int ns = gemm_x3_splits(M, N, K);
+static long gemm_x3_plane_floats(int M, int N, int K, int np = 3) { return 4 * (gx_plane_slots(M, K, np) + gx_plane_slots(N, K, np)); }
+static long gemm_x3_scratch_floats(int M, int N, int K, int np) {
+    const int ns = gemm_x3_splits(M, N, K, np);
     const long tiles = (long)((M + GX_BM - 1) / GX_BM) * ((N + GX_BN - 1) / GX_BN);
-    return gemm_x3_plane_floats(M, N, K) + (ns > 1 ? (long)ns * tiles * GX_BM * GX_BN : 0);
+    return gemm_x3_plane_floats(M, N, K, np) + (ns > 1 ? (long)ns * tiles * GX_BM * GX_BN : 0);
 }
-static void gx_split_launch(const float* src, long s_row, long s_k, int rows, int K, uint4* planes, long Rp, long G, long row_off, hipStream_t stream) {
+// bf16_run: large products on pre-rounded bf16 planes + the LDS-DMA kernel (round 6; T2V_BF16_GEMM_PLANES=0: k_gemm_bf16_big_rr)
+static bool gemm_bf16_planes_ok(int M, int N, int K) {
+    static const int on = getenv("T2V_BF16_GEMM_PLANES") ? atoi(getenv("T2V_BF16_GEMM_PLANES")) : 1;
+    return on && K >= 64 && gemm_x3_shape_ok(M, N, K);
+}
+static void gx_split_launch(const float* src, long s_row, long s_k, int rows, int K, uint4* planes, long Rp, long G, long row_off, hipStream_t stream,
+                            int np = 3) {
     // (planes + row_off: the operand's rows start at slot row_off of every k-group — column blocks of one B operand gathered from
     //  different tensors; row_off is a multiple of 128 and the operand's padded rows end at or before Rp)
     const unsigned gx = (unsigned)((rows + 127) / 128 * 2);
-    if (s_k == 1) k_x3_split<true><<<dim3(gx, (unsigned)(G / 4)), 256, 0, stream>>>(src, s_row, s_k, rows, K, planes + row_off, Rp, G);
-    else k_x3_split<false><<<dim3(gx, (unsigned)(G / 4)), 256, 0, stream>>>(src, s_row, s_k, rows, K, planes + row_off, Rp, G);
+    const dim3 grid(gx, (unsigned)(G / 4));
+    if (np == 3) {
+        if (s_k == 1) k_x3_split<true, 3><<<grid, 256, 0, stream>>>(src, s_row, s_k, rows, K, planes + row_off, Rp, G);
+        else k_x3_split<false, 3><<<grid, 256, 0, stream>>>(src, s_row, s_k, rows, K, planes + row_off, Rp, G);
+    } else {
+        if (s_k == 1) k_x3_split<true, 1><<<grid, 256, 0, stream>>>(src, s_row, s_k, rows, K, planes + row_off, Rp, G);
+        else k_x3_split<false, 1><<<grid, 256, 0, stream>>>(src, s_row, s_k, rows, K, planes + row_off, Rp, G);
+    }
 }
-static int gemm_x3_run(const GemmArgs& g, float* scratch, hipStream_t stream) {
+static int gemm_x3_run(const GemmArgs& g, float* scratch, hipStream_t stream, int np = 3) {
     const int M = g.M, N = g.N, K = g.K;
     uint4* Ap = (uint4*)scratch;
-    uint4* Bp = Ap + gx_plane_slots(M, K);
-    const long G = gx_groups(K), RpA = gx_rp(M), RpB = gx_rp(N);
-    gx_split_launch(g.A, g.sAi, g.sAk, M, K, Ap, RpA, G, 0, stream);
-    gx_split_launch(g.B, g.sBj, g.sBk, N, K, Bp, RpB, G, 0, stream);
+    uint4* Bp = Ap + gx_plane_slots(M, K, np);
+    const long G = gx_groups(K, np), RpA = gx_rp(M), RpB = gx_rp(N);
+    gx_split_launch(g.A, g.sAi, g.sAk, M, K, Ap, RpA, G, 0, stream, np);
+    gx_split_launch(g.B, g.sBj, g.sBk, N, K, Bp, RpB, G, 0, stream, np);
     GemmX3Args a;
     a.nprod = 1;
     GemmX3Prod& P = a.pr[0];
@@ -1075,17 +1109,18 @@ static int gemm_x3_run(const GemmArgs& g, float* scratch, hipStream_t stream) {
     a.p_drop = g.p_drop; a.seed = g.seed; a.rng_stream = g.rng_stream; a.rng_t = g.rng_t; a.step = g.step;
     a.st_chunk = 0; a.part = nullptr; a.tile_ctr = nullptr;
     dim3 gb(a.ntiles, 1, 1);
-    const int ns = gemm_x3_splits(M, N, K);
+    const int ns = gemm_x3_splits(M, N, K, np);
     if (ns > 1) {
-        const int nst = (int)(G / 2);
+        const int nst = (int)(G / (np == 3 ? 2 : 8));
         a.st_chunk = (nst + ns - 1) / ns;
         gb.z = (unsigned)((nst + a.st_chunk - 1) / a.st_chunk);         // no empty split
-        a.part = scratch + gemm_x3_plane_floats(M, N, K);
+        a.part = scratch + gemm_x3_plane_floats(M, N, K, np);
         a.tile_ctr = t2v_arrival_counters(a.ntiles);
         if (!a.tile_ctr) return T2V_ERR_LAUNCH;
         if (gb.z < 2) { a.st_chunk = 0; a.part = nullptr; a.tile_ctr = nullptr; gb.z = 1; }
     }
-    k_gemm_x3p<<<gb, 256, 0, stream>>>(a);
+    if (np == 3) k_gemm_x3p<3, 2><<<gb, 256, 0, stream>>>(a);
+    else k_gemm_x3p<1, 8><<<gb, 256, 0, stream>>>(a);
     return t2v_check_launch();
 }
 
@@ -1094,18 +1129,24 @@ static int gemm_x3_run(const GemmArgs& g, float* scratch, hipStream_t stream) {
 // [prenet | h_att | ctx] / [h_att | ctx | h_dec]): five products, 1 024 tiles.  Issued one by one they split the gate gradients
 // three and two times, and none of the five launches fills whole rounds of the chip (64 .. 384 tiles on 512 slots, two of them cut over
 // k with their raw tiles going through scratch); as ONE launch every operand is split once and the tiles make two full rounds.
-extern "C" long t2v_gemm_f32_grouped_scratch_floats(const t2v_gemm_group* gr, int ngroups, int M, int K) {
+static long gemm_grouped_scratch(const t2v_gemm_group* gr, int ngroups, int M, int K, int np) {
     if (!gr || ngroups < 1 || ngroups > 2 || M < 1 || K < 1) return 0;
     long slots = 0;
     for (int g = 0; g < ngroups; ++g) {
         long n = 0;
         for (int p = 0; p < gr[g].nb; ++p) n += gx_rp(gr[g].N[p]);
-        slots += gx_plane_slots(M, K) + 3 * gx_groups(K) * n;
+        slots += gx_plane_slots(M, K, np) + np * gx_groups(K, np) * n;
     }
     return 4 * slots;
 }
-static bool gemm_grouped_x3_ok(const t2v_gemm_group* gr, int ngroups, int M, int K) {
-    if (!gemm_x3_mode() || M < GX_BM || K < 32) return false;
+extern "C" long t2v_gemm_f32_grouped_scratch_floats(const t2v_gemm_group* gr, int ngroups, int M, int K) {
+    return gemm_grouped_scratch(gr, ngroups, M, K, 3);
+}
+extern "C" long t2v_gemm_bf16_grouped_scratch_floats(const t2v_gemm_group* gr, int ngroups, int M, int K) {
+    return gemm_grouped_scratch(gr, ngroups, M, K, 1);
+}
+static bool gemm_grouped_x3_ok(const t2v_gemm_group* gr, int ngroups, int M, int K, int np) {
+    if ((np == 3 && !gemm_x3_mode()) || M < GX_BM || K < 32) return false;
     long tiles = 0;
     for (int g = 0; g < ngroups; ++g)
         for (int p = 0; p < gr[g].nb; ++p) {
@@ -1114,7 +1155,7 @@ static bool gemm_grouped_x3_ok(const t2v_gemm_group* gr, int ngroups, int M, int
         }
     return tiles >= 64;
 }
-extern "C" int t2v_gemm_f32_grouped(const t2v_gemm_group* gr, int ngroups, int M, int K, int accumulate, float* scratch, void* stream_) {
+static int gemm_grouped_impl(const t2v_gemm_group* gr, int ngroups, int M, int K, int accumulate, float* scratch, void* stream_, int np) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!gr || ngroups < 1 || ngroups > 2 || M < 1 || K < 1) return T2V_ERR_ARG;
     for (int g = 0; g < ngroups; ++g) {
@@ -1122,17 +1163,17 @@ extern "C" int t2v_gemm_f32_grouped(const t2v_gemm_group* gr, int ngroups, int M
         for (int p = 0; p < gr[g].nb; ++p)
             if (!gr[g].B[p] || !gr[g].C[p] || gr[g].N[p] < 1 || gr[g].ldc[p] < gr[g].N[p]) return T2V_ERR_ARG;
     }
-    if (!scratch || ((uintptr_t)scratch & 15) || !gemm_grouped_x3_ok(gr, ngroups, M, K)) {
+    if (!scratch || ((uintptr_t)scratch & 15) || !gemm_grouped_x3_ok(gr, ngroups, M, K, np)) {
         // (fp32-MFMA mode, or column blocks that are not whole tiles: the products one by one)
         for (int g = 0; g < ngroups; ++g)
             for (int p = 0; p < gr[g].nb; ++p) {
-                const int rc = t2v_gemm_f32(gr[g].A, gr[g].sAi, gr[g].sAk, gr[g].B[p], gr[g].sBj[p], gr[g].sBk[p], nullptr, gr[g].C[p], gr[g].ldc[p],
+                const int rc = (np == 3 ? t2v_gemm_f32 : t2v_gemm_bf16)(gr[g].A, gr[g].sAi, gr[g].sAk, gr[g].B[p], gr[g].sBj[p], gr[g].sBk[p], nullptr, gr[g].C[p], gr[g].ldc[p],
                                             M, gr[g].N[p], K, 0, accumulate, 0.f, 0, 0, 0, stream_);
                 if (rc != T2V_OK) return rc;
             }
         return T2V_OK;
     }
-    const long G = gx_groups(K), RpA = gx_rp(M);
+    const long G = gx_groups(K, np), RpA = gx_rp(M);
     GemmX3Args a;
     a.nprod = ngroups;
     uint4* at = (uint4*)scratch;
@@ -1141,16 +1182,16 @@ extern "C" int t2v_gemm_f32_grouped(const t2v_gemm_group* gr, int ngroups, int M
         GemmX3Prod& P = a.pr[g];
         long n = 0;
         for (int p = 0; p < gr[g].nb; ++p) n += gr[g].N[p];
-        P.Ap = at; at += gx_plane_slots(M, K);
-        P.Bp = at; at += 3 * G * n;
+        P.Ap = at; at += gx_plane_slots(M, K, np);
+        P.Bp = at; at += np * G * n;
         P.RpA = RpA; P.RpB = n; P.N = (int)n; P.tiles_x = (int)(n / GX_BN); P.tile0 = tile0; P.nseg = gr[g].nb;
-        gx_split_launch(gr[g].A, gr[g].sAi, gr[g].sAk, M, K, (uint4*)P.Ap, RpA, G, 0, stream);
+        gx_split_launch(gr[g].A, gr[g].sAi, gr[g].sAk, M, K, (uint4*)P.Ap, RpA, G, 0, stream, np);
         long col = 0;
         for (int p = 0; p < 3; ++p) {
             const int q = p < gr[g].nb ? p : gr[g].nb - 1;
             P.seg_col[p] = p < gr[g].nb ? (int)col : 0x7fffffff; P.segC[p] = gr[g].C[q]; P.seg_ldc[p] = gr[g].ldc[q];
             if (p < gr[g].nb) {
-                gx_split_launch(gr[g].B[p], gr[g].sBj[p], gr[g].sBk[p], gr[g].N[p], K, (uint4*)P.Bp, n, G, col, stream);
+                gx_split_launch(gr[g].B[p], gr[g].sBj[p], gr[g].sBk[p], gr[g].N[p], K, (uint4*)P.Bp, n, G, col, stream, np);
                 col += gr[g].N[p];
             }
         }
@@ -1161,8 +1202,17 @@ extern "C" int t2v_gemm_f32_grouped(const t2v_gemm_group* gr, int ngroups, int M
     a.G = G; a.bias = nullptr; a.M = M; a.relu = 0; a.accumulate = accumulate;
     a.p_drop = 0.f; a.seed = 0; a.rng_stream = 0; a.rng_t = 0; a.step = t2v_step_for(stream);
     a.st_chunk = 0; a.part = nullptr; a.tile_ctr = nullptr;
-    k_gemm_x3p<<<dim3(a.ntiles, 1, 1), 256, 0, stream>>>(a);
+    if (np == 3) k_gemm_x3p<3, 2><<<dim3(a.ntiles, 1, 1), 256, 0, stream>>>(a);
+    else k_gemm_x3p<1, 8><<<dim3(a.ntiles, 1, 1), 256, 0, stream>>>(a);
     return t2v_check_launch();
+}
+extern "C" int t2v_gemm_f32_grouped(const t2v_gemm_group* gr, int ngroups, int M, int K, int accumulate, float* scratch, void* stream_) {
+    return gemm_grouped_impl(gr, ngroups, M, K, accumulate, scratch, stream_, 3);
+}
+// bf16_run: the same launch structure on ONE plane per operand — the operands rounded to bf16 (RNE) once by the split pass, fp32
+// accumulation: the arithmetic of k_gemm_bf16_big_rr (which rounds while staging), half its bytes into the CU
+extern "C" int t2v_gemm_bf16_grouped(const t2v_gemm_group* gr, int ngroups, int M, int K, int accumulate, float* scratch, void* stream_) {
+    return gemm_grouped_impl(gr, ngroups, M, K, accumulate, scratch, stream_, 1);
 }
 
 // d(pre-activation) = dy * [y != 0] * scale (reference Prenet, model.py:96-99: F.dropout(F.relu(linear(x)), p=0.5)).
@@ -1218,6 +1268,8 @@ static int gemm_bf16_impl(const float* A, long sAi, long sAk, const float* B, lo
     a.M = M; a.N = N; a.K = K; a.ldc = ldc; a.relu = relu; a.accumulate = accumulate;
     a.p_drop = p_drop; a.seed = seed; a.rng_stream = rng_stream; a.rng_t = rng_t; a.step = t2v_step_for(stream);
     a.kz_chunk = 0; a.part = nullptr; a.nbatch = 1; a.sAb = a.sBb = a.sCb = 0; a.nsub = 1; a.sAs = a.sBs = 0; a.bias_row = 0; a.tile_ctr = nullptr;
+    if (splitk_scratch && !((uintptr_t)splitk_scratch & 15) && gemm_bf16_planes_ok(M, N, K))
+        return gemm_x3_run(a, splitk_scratch, stream, 1);
     bool big_akc = false, big_bkc = false;
     if (gemm_bf16_big_ok(a, &big_akc, &big_bkc)) {
         const int ns = splitk_scratch ? gemm_bf16_big_splits(M, N, K) : 1;

@@ -67,7 +67,7 @@ class _DecInferBufs(C.Structure):
 
 
 EXPORTS = ('t2v_version', 't2v_last_error', 't2v_stamp', 't2v_debug_spin', 't2v_pack_lstm_weights', 't2v_pack_lstm_weights_bf16', 't2v_decoder_train_fwd',
-           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_clip_adam_step_guarded', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_conv1d_dw_scratch_floats', 't2v_conv1d_flip_weights', 't2v_gemm_bf16', 't2v_gemm_bf16_splitk', 't2v_gemm_bf16_splitk_scratch_floats', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
+           't2v_decoder_train_bwd', 't2v_clip_adam_step', 't2v_clip_adam_step_guarded', 't2v_decoder_replay_fwd_kernels', 't2v_mel_frontend', 't2v_set_phase_profile', 't2v_decoder_infer_steps', 't2v_conv1d_stat_blocks', 't2v_conv1d_stat_blocks_bf16', 't2v_conv1d_fwd', 't2v_conv1d_bwd', 't2v_conv1d_fwd_bf16', 't2v_conv1d_bwd_bf16', 't2v_conv1d_dw_scratch_floats', 't2v_conv1d_flip_weights', 't2v_gemm_bf16', 't2v_gemm_bf16_splitk', 't2v_gemm_bf16_splitk_scratch_floats', 't2v_attn_wgrad', 't2v_attn_wgrad_scratch_floats',
            't2v_bn_act_fwd', 't2v_bn_act_bwd', 't2v_bn_act_bwd_eval', 't2v_bilstm_fwd', 't2v_bilstm_bwd', 't2v_gemm_f32', 't2v_conv2d_s2_fwd', 't2v_conv2d_s2_bwd', 't2v_conv2d_s2_dw_scratch_floats', 't2v_conv2d_s2_fwd_gemm', 't2v_conv2d_s2_bwd_gemm',
            't2v_conv2d_s2_gemm_scratch_floats',
            't2v_gru_fwd', 't2v_gru_bwd', 't2v_loss_fwd_bwd', 't2v_fuse_location_weights', 't2v_decoder_qp_floats',
@@ -84,7 +84,7 @@ EXPORTS = ('t2v_version', 't2v_last_error', 't2v_stamp', 't2v_debug_spin', 't2v_
            't2v_decoder_train_persist16_scratch_floats', 't2v_decoder_bwd_persistent16', 't2v_decoder_bwd_persist16_supported',
            't2v_decoder_bwd_persist16_scratch_floats', 't2v_decoder_bwd_persist16_dq_offset', 't2v_decoder_bwd_persist16_slices',
            't2v_decoder_bwd_persist16_fits', 't2v_gemm_f32_set_mode', 't2v_conv1d_x3_set_mode', 't2v_gemm_f32_grouped',
-           't2v_gemm_f32_grouped_scratch_floats',
+           't2v_gemm_f32_grouped_scratch_floats', 't2v_gemm_bf16_grouped', 't2v_gemm_bf16_grouped_scratch_floats',
            't2v_decoder_bwd_persistent16_prepare', 't2v_decoder_bwd_persistent16_prepared')
 
 
@@ -139,6 +139,9 @@ def load_library():
     lib.t2v_gemm_f32_grouped_scratch_floats.argtypes = [C.POINTER(_GemmGroup), C.c_int, C.c_int, C.c_int]
     lib.t2v_gemm_f32_grouped_scratch_floats.restype = C.c_long
     lib.t2v_gemm_f32_grouped.argtypes = [C.POINTER(_GemmGroup), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.t2v_gemm_bf16_grouped_scratch_floats.argtypes = lib.t2v_gemm_f32_grouped_scratch_floats.argtypes
+    lib.t2v_gemm_bf16_grouped_scratch_floats.restype = C.c_long
+    lib.t2v_gemm_bf16_grouped.argtypes = lib.t2v_gemm_f32_grouped.argtypes
     lib.t2v_decoder_train_persist_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.t2v_decoder_train_persist_scratch_floats.restype = C.c_long
     lib.t2v_decoder_bwd_persist_supported.argtypes = [C.c_int, C.c_int]
@@ -195,6 +198,7 @@ def load_library():
                                             C.c_int, C.c_float, C.c_float, C.c_int, C.c_uint64, C.c_void_p]
     vp = C.c_void_p
     lib.t2v_conv1d_stat_blocks.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.t2v_conv1d_stat_blocks_bf16.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.t2v_conv1d_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.t2v_conv1d_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.t2v_conv1d_dw_scratch_floats.argtypes = [C.c_int] * 5
@@ -1276,9 +1280,9 @@ class DecoderCore(torch.autograd.Function):
                     if ctx.pre2 is None:        # the prenet columns of attention_rnn.weight_ih get their gradient via gpre
                         wg[0][:, :PRE].zero_()
                 d_w_ih_att, d_w_hh_att, d_w_ih_dec, d_w_hh_dec = wg
-                # round 6, fp32: the five LSTM weight-gradient products as ONE launch of the x3 kernel — both gate-gradient operands split
-                # once, 1 024 tiles = two full rounds of the chip (T2V_DW_GROUPED=0: one by one as before)
-                grouped = (not _BF16 and not split_d and os.environ.get('T2V_DW_GROUPED', '1') != '0'
+                # round 6: the five LSTM weight-gradient products as ONE launch of the plane kernel — both gate-gradient operands split
+                # (fp32: x3 planes; bf16_run: rounded) once, 1 024 tiles = two full rounds of the chip (T2V_DW_GROUPED=0: one by one)
+                grouped = (not split_d and os.environ.get('T2V_DW_GROUPED', '1') != '0'
                            and os.environ.get('T2V_DW_TWO_STREAMS', '0') != '1')
                 if ctx.pre2 is not None:    # the input projection of the prenet output, folded into this node: the Prenet's
                     # own backward (issued on this same stream when an engine is active) waits for d_pre, so it goes first
@@ -1561,12 +1565,14 @@ class ConvBNAct1d(torch.autograd.Function):
         dev = x.device
         f32 = dict(device=dev, dtype=torch.float32)
         y = torch.empty(B, Cout, T, **f32)
-        nblk = lib.t2v_conv1d_stat_blocks(B, T, Cin, Cout, KS)
-        part = torch.empty(nblk, Cout, 2, **f32) if training else None
         w = weight.contiguous()
         # bf16 only for the wide layers (the three 512->512 Postnet convs, the encoder bank); the 80-channel first
         # and last Postnet layers are cheap and stay fp32 (the output layer in particular)
         use_bf16 = _BF16 and KS == 5 and Cin % 16 == 0 and Cin >= 128 and Cout >= 128
+        # (the number of BatchNorm partials follows the kernel that will run: the bf16 kernels keep their own tiles, the fp32 entry
+        #  may take the x3 convolution with its 128-position tiles)
+        nblk = (lib.t2v_conv1d_stat_blocks_bf16 if use_bf16 else lib.t2v_conv1d_stat_blocks)(B, T, Cin, Cout, KS)
+        part = torch.empty(nblk, Cout, 2, **f32) if training else None
         if use_bf16:
             wp = torch.empty(w.numel(), device=dev, dtype=torch.bfloat16)
             _check(lib.t2v_conv1d_fwd_bf16(_p(w), _p(x), _p(bias), _p(y), _p(part), _p(wp), B, Cin, T, Cout, KS,
@@ -1854,11 +1860,12 @@ def _small_grads(params, n, f32):
 
 def gemm_grouped(groups, accumulate=False):
     """groups: [(A (M,K), [(B_p (N_p,K), out_p (M,N_p)), ...]), ...] (at most two groups of at most three parts, one common M and K):
-    out_p (+)= A · B_p^T for every part.  fp32 x3 mode: every operand split once, all tiles in ONE launch (t2v_gemm_f32_grouped);
-    bf16_run or shapes the grouped kernel does not take: the products one by one through gemm()."""
+    out_p (+)= A · B_p^T for every part.  Every operand is split (fp32: into its three bf16 planes; bf16_run: rounded to bf16) once, all
+    tiles run as ONE launch (t2v_gemm_f32_grouped / t2v_gemm_bf16_grouped); shapes the grouped kernel does not take: the products one by
+    one through gemm()."""
     lib = _require_gpu(groups[0][0])
     M, K = groups[0][0].shape
-    ok = not _BF16 and 1 <= len(groups) <= 2
+    ok = 1 <= len(groups) <= 2
     for A, parts in groups:
         ok = ok and A.shape == (M, K) and A.dtype == torch.float32 and 1 <= len(parts) <= 3
         for Bp, out in parts:
@@ -1874,9 +1881,11 @@ def gemm_grouped(groups, accumulate=False):
         for p, (Bp, out) in enumerate(parts):
             g.B[p], g.sBj[p], g.sBk[p], g.N[p] = Bp.data_ptr(), Bp.stride(0), Bp.stride(1), Bp.shape[0]
             g.C[p], g.ldc[p] = out.data_ptr(), out.stride(0)
-    nscr = lib.t2v_gemm_f32_grouped_scratch_floats(arr, len(groups), M, K)
+    size_fn, run_fn = ((lib.t2v_gemm_bf16_grouped_scratch_floats, lib.t2v_gemm_bf16_grouped) if _BF16 else
+                       (lib.t2v_gemm_f32_grouped_scratch_floats, lib.t2v_gemm_f32_grouped))
+    nscr = size_fn(arr, len(groups), M, K)
     scr = torch.empty(max(nscr, 4), device=groups[0][0].device, dtype=torch.float32)
-    _check(lib.t2v_gemm_f32_grouped(arr, len(groups), M, K, int(bool(accumulate)), _p(scr), _stream()), 't2v_gemm_f32_grouped')
+    _check(run_fn(arr, len(groups), M, K, int(bool(accumulate)), _p(scr), _stream()), 't2v_gemm_grouped')
 
 
 def set_f32_gemm_mode(x3):
