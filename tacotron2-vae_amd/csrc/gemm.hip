@@ -764,7 +764,7 @@ __device__ __forceinline__ void gx_split8(const float (&v)[8], uint4& p0, uint4&
 // plane p, k-group g, row r -> 16-byte slot (p * G + g) * Rp + r.  Rows >= rows and k >= K are zero.
 static inline long gx_rp(int rows) { return ((long)rows + 127) / 128 * 128; }
 // np = 3: the x3 planes of an fp32 product (stages of 16 k); np = 1: ONE plane, the bf16-rounded operand of a bf16_run product (stages of 64 k)
-static inline long gx_groups(int K, int np = 3) { return np == 3 ? ((long)K + 31) / 32 * 4 : ((long)K + 63) / 64 * 8; }
+static inline long gx_groups(int K, int np = 3) { return np == 3 ? ((long)K + 31) / 32 * 4 : ((long)K + 63) / 64 * 8; }      // (multiples of 4 / 8 k-groups)
 static inline long gx_plane_slots(int rows, int K, int np = 3) { return np * gx_groups(K, np) * gx_rp(rows); }
 // grid (Rp / 64, G / 4): a workgroup splits 64 rows x 32 k.  KC: the operand is contiguous along k (two float4 per row and k-group when
 // aligned), else along its rows (or neither: scalar loads either way).  Every word crosses LDS once so that the plane stores run along
@@ -844,6 +844,9 @@ __device__ __forceinline__ void gx_dma16(const void* gsrc, unsigned lds_addr) {
 #ifndef GX_LDS_PAD
 #define GX_LDS_PAD 0                // unused 16-byte slots on top (measurement: how many workgroups / how much free LDS a CU keeps)
 #endif
+#ifndef GX_NG1
+#define GX_NG1 4                   // k-groups per stage of the one-plane (bf16_run) form (2 / 4 / 8 measured: 432 / 453 / 423 TFLOP/s on 4096 x 2560 x 6400)
+#endif
 #define GX_STR2(x) #x
 #define GX_STR(x) GX_STR2(x)
 // wait until at most N of this wave's memory requests are outstanding (N a compile-time constant <= 63)
@@ -858,7 +861,7 @@ __device__ __forceinline__ void gx_wait_stage() {
     else static_assert(N == 0, "add the literal");
 }
 // NP planes per operand, NG k-groups (of 8) per stage: <3, 2> = the x3 form of an fp32 product (six MFMAs per k-block of 16, 24 per
-// wave and stage); <1, 8> = a bf16_run product on pre-rounded operands (one MFMA per k-block, 16 per wave and stage of 64 k)
+// wave and stage); <1, GX_NG1> = a bf16_run product on pre-rounded operands (one MFMA per k-block of 16)
 template <int NP, int NG>
 __global__ __launch_bounds__(256, 2) void k_gemm_x3p(GemmX3Args a) {
     // [buffer][A | B][plane][k-group][row]: 24 / 32 KB per buffer
@@ -1053,7 +1056,7 @@ static bool gemm_x3_shape_ok(int M, int N, int K) {
 // 164 | 269 257 271 291 us)
 static int gemm_x3_splits(int M, int N, int K, int np = 3) {
     const long tiles = (long)((M + GX_BM - 1) / GX_BM) * ((N + GX_BN - 1) / GX_BN);
-    const int nst = (int)(gx_groups(K, np) / (np == 3 ? 2 : 8));
+    const int nst = (int)(gx_groups(K, np) / (np == 3 ? 2 : GX_NG1));
     static const int forced = getenv("T2V_GEMM_X3_SPLITS") ? atoi(getenv("T2V_GEMM_X3_SPLITS")) : 0;     // measurement
     if (forced > 0) return forced > nst ? nst : forced;
     int best = 1;
@@ -1111,7 +1114,7 @@ static int gemm_x3_run(const GemmArgs& g, float* scratch, hipStream_t stream, in
     dim3 gb(a.ntiles, 1, 1);
     const int ns = gemm_x3_splits(M, N, K, np);
     if (ns > 1) {
-        const int nst = (int)(G / (np == 3 ? 2 : 8));
+        const int nst = (int)(G / (np == 3 ? 2 : GX_NG1));
         a.st_chunk = (nst + ns - 1) / ns;
         gb.z = (unsigned)((nst + a.st_chunk - 1) / a.st_chunk);         // no empty split
         a.part = scratch + gemm_x3_plane_floats(M, N, K, np);
@@ -1120,7 +1123,7 @@ static int gemm_x3_run(const GemmArgs& g, float* scratch, hipStream_t stream, in
         if (gb.z < 2) { a.st_chunk = 0; a.part = nullptr; a.tile_ctr = nullptr; gb.z = 1; }
     }
     if (np == 3) k_gemm_x3p<3, 2><<<gb, 256, 0, stream>>>(a);
-    else k_gemm_x3p<1, 8><<<gb, 256, 0, stream>>>(a);
+    else k_gemm_x3p<1, GX_NG1><<<gb, 256, 0, stream>>>(a);
     return t2v_check_launch();
 }
 
@@ -1203,7 +1206,7 @@ static int gemm_grouped_impl(const t2v_gemm_group* gr, int ngroups, int M, int K
     a.p_drop = 0.f; a.seed = 0; a.rng_stream = 0; a.rng_t = 0; a.step = t2v_step_for(stream);
     a.st_chunk = 0; a.part = nullptr; a.tile_ctr = nullptr;
     if (np == 3) k_gemm_x3p<3, 2><<<dim3(a.ntiles, 1, 1), 256, 0, stream>>>(a);
-    else k_gemm_x3p<1, 8><<<dim3(a.ntiles, 1, 1), 256, 0, stream>>>(a);
+    else k_gemm_x3p<1, GX_NG1><<<dim3(a.ntiles, 1, 1), 256, 0, stream>>>(a);
     return t2v_check_launch();
 }
 extern "C" int t2v_gemm_f32_grouped(const t2v_gemm_group* gr, int ngroups, int M, int K, int accumulate, float* scratch, void* stream_) {
