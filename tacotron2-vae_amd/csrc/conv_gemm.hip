@@ -984,7 +984,8 @@ static inline bool conv5_tiled_ok(int Cin, int KS) { return KS == 5 && Cin % 16 
 bool t2v_conv5_x3_ok(int B, int Cin, int T, int Cout, int KS);
 int t2v_conv5_x3_stat_blocks(int B, int T);
 int t2v_conv5_x3_run(const float* W, const float* X, const float* bias, float* Y, float* stat_part, int B, int Cin, int T, int M,
-                     hipStream_t stream);
+                     hipStream_t stream, int np);
+bool t2v_conv5_planes_bf16_ok(int B, int Cin, int T, int Cout, int KS);
 
 static void launch_conv5_fwd(const float* W, const float* X, const float* bias, float* Y, float* stat_part, int B,
                              int Cin, int T, int M, hipStream_t stream) {
@@ -1084,7 +1085,7 @@ extern "C" int t2v_conv1d_fwd(const float* W, const float* X, const float* bias,
     hipStream_t stream = (hipStream_t)stream_;
     if (!W || !X || !Y || B < 1 || Cin < 1 || T < 1 || Cout < 1 || KS < 1 || !(KS & 1)) return T2V_ERR_ARG;
     if (t2v_conv5_x3_ok(B, Cin, T, Cout, KS)) {
-        const int rc = t2v_conv5_x3_run(W, X, bias, Y, stat_part, B, Cin, T, Cout, stream);
+        const int rc = t2v_conv5_x3_run(W, X, bias, Y, stat_part, B, Cin, T, Cout, stream, 3);
         return rc != T2V_OK ? rc : t2v_check_launch();
     }
     if (conv5_tiled_ok(Cin, KS)) {
@@ -1109,6 +1110,7 @@ extern "C" int t2v_conv1d_stat_blocks(int B, int T, int Cin, int Cout, int KS) {
 
 // ... for t2v_conv1d_fwd_bf16 (its kernels keep the tile choice of the fp32-MFMA kernels whatever the x3 mode says)
 extern "C" int t2v_conv1d_stat_blocks_bf16(int B, int T, int Cin, int Cout, int KS) {
+    if (t2v_conv5_planes_bf16_ok(B, Cin, T, Cout, KS)) return t2v_conv5_x3_stat_blocks(B, T);
     if (conv5_tiled_ok(Cin, KS)) { int ks; const int BN = conv5_pick_bn_ks(T, B, Cout, Cin, &ks); return B * ((T + BN - 1) / BN); }
     return (B * T + CG_BN - 1) / CG_BN;
 }
@@ -1130,7 +1132,7 @@ extern "C" int t2v_conv1d_bwd(const float* W, const float* X, const float* dY, f
         const int n = Cout * Cin * KS;
         if (W) k_conv_flip_weight<<<(n + 255) / 256, 256, 0, stream>>>(W, Wt_scratch, Cout, Cin, KS);
         if (t2v_conv5_x3_ok(B, Cout, T, Cin, KS)) {         // the data gradient = the same convolution with the flipped, transposed weights
-            const int rc = t2v_conv5_x3_run(Wt_scratch, dY, nullptr, dX, nullptr, B, Cout, T, Cin, stream);
+            const int rc = t2v_conv5_x3_run(Wt_scratch, dY, nullptr, dX, nullptr, B, Cout, T, Cin, stream, 3);
             if (rc != T2V_OK) return rc;
         } else if (conv5_tiled_ok(Cout, KS)) {
             launch_conv5_fwd(Wt_scratch, dY, nullptr, dX, nullptr, B, Cout, T, Cin, stream);
@@ -1184,6 +1186,10 @@ extern "C" int t2v_conv1d_fwd_bf16(const float* W, const float* X, const float* 
     hipStream_t stream = (hipStream_t)stream_;
     if (!W || !X || !Y || !Wp_scratch || B < 1 || Cin < 1 || T < 1 || Cout < 1) return T2V_ERR_ARG;
     if (!conv5_tiled_ok(Cin, KS)) return T2V_ERR_DIMS;
+    if (t2v_conv5_planes_bf16_ok(B, Cin, T, Cout, KS)) {        // round 6: pre-rounded planes + the LDS-DMA kernel (conv_x3.hip, one plane)
+        const int rc = t2v_conv5_x3_run(W, X, bias, Y, stat_part, B, Cin, T, Cout, stream, 1);
+        return rc != T2V_OK ? rc : t2v_check_launch();
+    }
     launch_conv5_fwd_bf16(W, 0, (unsigned short*)Wp_scratch, X, bias, Y, stat_part, B, Cin, T, Cout, Cout, Cin, stream);
     return t2v_check_launch();
 }
@@ -1196,7 +1202,19 @@ extern "C" int t2v_conv1d_bwd_bf16(const float* W, const float* X, const float* 
     if (!conv5_tiled_ok(Cin, KS) || (dX && !conv5_tiled_ok(Cout, KS))) return T2V_ERR_DIMS;
     if (dX) {
         if (!W || !Wp_scratch) return T2V_ERR_ARG;
-        launch_conv5_fwd_bf16(W, 1, (unsigned short*)Wp_scratch, dY, nullptr, dX, nullptr, B, Cout, T, Cin, Cout, Cin, stream);
+        bool done = false;
+        if (t2v_conv5_planes_bf16_ok(B, Cout, T, Cin, KS)) {
+            // round 6: the data gradient = the same convolution with the flipped, transposed weights, on the one-plane form of
+            // conv_x3.hip (the flipped fp32 copy lives in the library's ring: the caller's scratch is sized for bf16)
+            float* wt = conv_ks_scratch((size_t)Cout * Cin * KS);
+            if (wt) {
+                k_conv_flip_weight<<<(Cout * Cin * KS + 255) / 256, 256, 0, stream>>>(W, wt, Cout, Cin, KS);
+                const int rc = t2v_conv5_x3_run(wt, dY, nullptr, dX, nullptr, B, Cout, T, Cin, stream, 1);
+                if (rc != T2V_OK) return rc;
+                done = true;
+            }
+        }
+        if (!done) launch_conv5_fwd_bf16(W, 1, (unsigned short*)Wp_scratch, dY, nullptr, dX, nullptr, B, Cout, T, Cin, Cout, Cin, stream);
     }
     if (dW) {           // (round 5) the weight gradient on bf16 MFMA as well: same tiling / K-splits as the fp32 kernel
         g_conv_dw_bf16 = true;

@@ -47,7 +47,12 @@ __device__ __forceinline__ void cx_split8(const float (&v)[8], uint4& p0, uint4&
     p2 = make_uint4(q2[0], q2[1], q2[2], q2[3]);
 }
 
+// NP = 3: the x3 planes of an fp32 operand; NP = 1: ONE plane, the operand rounded to bf16 (bf16_run)
+__device__ __forceinline__ uint4 cx_round8(const float (&v)[8]) {
+    return make_uint4(cx_pack(v[0], v[1]), cx_pack(v[2], v[3]), cx_pack(v[4], v[5]), cx_pack(v[6], v[7]));
+}
 // W (M, Cin, 5) fp32 -> Wp[tap][plane][g][Mp]: thread = (row m, channel group g), all five taps
+template <int NP>
 __global__ __launch_bounds__(256) void k_cx3_split_w(const float* __restrict__ W, uint4* __restrict__ Wp, int M, int Cin, int Mp, int G) {
     const int m = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
     if (m >= Mp) return;
@@ -67,14 +72,19 @@ __global__ __launch_bounds__(256) void k_cx3_split_w(const float* __restrict__ W
         float v[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = w[c][k];
-        uint4 p0, p1, p2;
-        cx_split8(v, p0, p1, p2);
-        Wp[((size_t)(k * 3 + 0) * G + g) * Mp + m] = p0;
-        Wp[((size_t)(k * 3 + 1) * G + g) * Mp + m] = p1;
-        Wp[((size_t)(k * 3 + 2) * G + g) * Mp + m] = p2;
+        if (NP == 3) {
+            uint4 p0, p1, p2;
+            cx_split8(v, p0, p1, p2);
+            Wp[((size_t)(k * NP + 0) * G + g) * Mp + m] = p0;
+            Wp[((size_t)(k * NP + (NP > 1 ? 1 : 0)) * G + g) * Mp + m] = p1;
+            Wp[((size_t)(k * NP + (NP > 2 ? 2 : 0)) * G + g) * Mp + m] = p2;
+        } else {
+            Wp[((size_t)(k * NP) * G + g) * Mp + m] = cx_round8(v);
+        }
     }
 }
 // X (B, Cin, T) fp32 -> Xp[b][plane][g][Tp], slot s <-> position s - 2: thread = (slot s, group g, item b)
+template <int NP>
 __global__ __launch_bounds__(256) void k_cx3_split_x(const float* __restrict__ X, uint4* __restrict__ Xp, int Cin, int T, int Tp, int G) {
     const int s = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y, b = blockIdx.z;
     if (s >= Tp) return;
@@ -88,21 +98,24 @@ __global__ __launch_bounds__(256) void k_cx3_split_x(const float* __restrict__ X
         const float x = col[ok ? (size_t)c * T : 0];
         v[c] = ok ? x : 0.f;
     }
-    uint4 p0, p1, p2;
-    cx_split8(v, p0, p1, p2);
-    uint4* dst = Xp + (((size_t)b * 3) * G + g) * Tp + s;
-    dst[0] = p0;
-    dst[(size_t)G * Tp] = p1;
-    dst[(size_t)2 * G * Tp] = p2;
+    uint4* dst = Xp + (((size_t)b * NP) * G + g) * Tp + s;
+    if (NP == 3) {
+        uint4 p0, p1, p2;
+        cx_split8(v, p0, p1, p2);
+        dst[0] = p0;
+        dst[(size_t)(NP > 1 ? 1 : 0) * G * Tp] = p1;
+        dst[(size_t)(NP > 2 ? 2 : 0) * G * Tp] = p2;
+    } else {
+        dst[0] = cx_round8(v);
+    }
 }
 
 struct ConvX3Args {
     const uint4* Wp; const uint4* Xp;
     const float* bias; float* Y; float* stat_part;
     int B, M, T, Mp, Tp, G, tiles_per_item;
-    int st_chunk;               // stages (16 channels) per blockIdx.z
+    int st_chunk;               // stages (8 NG channels) per blockIdx.z
     float* part; unsigned* tile_ctr;
-    int dbg;                    // measurement (T2V_CX3_DBG): 1 = no DMA in the step loop, 2 = no MFMA, 4 = no LDS reads
 };
 
 // 16 bytes per lane global -> LDS without a destination register (lane i lands at lds_addr + 16 i; lds_addr wave-uniform, in an SGPR).
@@ -115,41 +128,57 @@ __device__ __forceinline__ void cx_dma16(const void* gsrc, unsigned lds_addr) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
 }
 #define CX_NW 4                     // weight tiles in flight + 1: the tile of step i + 3 is requested during step i
+template <int N>
+__device__ __forceinline__ void cx_wait() {
+    if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else static_assert(N == 6, "add the literal");
+}
+// NP planes per operand, NG channel groups (of 8) per stage: <3, 2> = fp32 operands cut into three bf16 planes (six MFMAs per 16
+// channels and tap, 24 per wave and step); <1, 4> = bf16_run on operands rounded once (8 MFMAs per wave and step of 32 channels)
+template <int NP, int NG>
 __global__ __launch_bounds__(256, 2) void k_conv5_x3(ConvX3Args a) {
-    // one carve: Ws[CX_NW][3][2][128] | Xs[2][3][2][136] (the epilogue's row sums reuse the front of it): 75 KB, two workgroups per CU
-    __shared__ uint4 lds_[CX_NW * 3 * 2 * CX_BM + 2 * 3 * 2 * CX_XS];
-    uint4 (*Ws)[3][2][CX_BM] = (uint4 (*)[3][2][CX_BM])&lds_[0];
-    uint4 (*Xs)[3][2][CX_XS] = (uint4 (*)[3][2][CX_XS])&lds_[CX_NW * 3 * 2 * CX_BM];
+    // one carve: Ws[CX_NW][NP][NG][128] | Xs[2][NP][NG][136] (the epilogue's row sums reuse the front of it)
+    constexpr int WSL = NP * NG * CX_BM, XSL = NP * NG * CX_XS;         // 16-byte slots per weight / activation tile
+    constexpr int CARVE = CX_NW * WSL + 2 * XSL < 2112 ? 2112 : CX_NW * WSL + 2 * XSL;      // (>= 128 x 65 floats for the row sums)
+    __shared__ uint4 lds_[CARVE];
+    uint4 (*Ws)[NP][NG][CX_BM] = (uint4 (*)[NP][NG][CX_BM])&lds_[0];
+    uint4 (*Xs)[NP][NG][CX_XS] = (uint4 (*)[NP][NG][CX_XS])&lds_[CX_NW * WSL];
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) void*)&lds_[0];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int bb = blockIdx.x / a.tiles_per_item, t0 = (blockIdx.x - bb * a.tiles_per_item) * CX_BN;
     const int i0 = blockIdx.y * CX_BM;
-    const int nst_all = a.G / 2;
+    const int nst_all = a.G / NG;
     const int s0 = blockIdx.z * a.st_chunk, s1 = min(nst_all, s0 + a.st_chunk);
-    // weight tile of (stage, tap): 12 pieces of 1 KB = 3 planes x 2 channel groups x 2 row halves; wave w issues pieces w, w + 4, w + 8.
+    // weight tile of (stage, tap): 2 NP NG pieces of 1 KB = NP planes x NG channel groups x 2 row halves; wave w issues pieces w, w + 4, ...
     // A request past the end of this workgroup's range re-reads its last tile into a buffer nobody reads any more: the number of
     // requests per step stays constant, which is what the counted waits below rely on
+    constexpr int WPW = NP * NG / 2;        // weight requests per wave and step
+    constexpr int XPW = (NP * NG * 3) / 4;  // activation requests per wave and stage, at least (waves 0, 1 may have one more)
     auto dma_w = [&](int st, int tap, int buf) {
         st = min(st, s1 - 1);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int q = wave + 4 * i, p = q >> 2, g = (q >> 1) & 1, half = q & 1;
-            const uint4* src = a.Wp + ((size_t)(tap * 3 + p) * a.G + 2 * st + g) * a.Mp + i0 + 64 * half + lane;
-            cx_dma16(src, lds0 + 16u * (unsigned)(((buf * 3 + p) * 2 + g) * CX_BM + 64 * half));
+        for (int i = 0; i < WPW; ++i) {
+            const int q = wave + 4 * i, p = q / (2 * NG), g = (q >> 1) % NG, half = q & 1;
+            const uint4* src = a.Wp + ((size_t)(tap * NP + p) * a.G + NG * st + g) * a.Mp + i0 + 64 * half + lane;
+            cx_dma16(src, lds0 + 16u * (unsigned)(((buf * NP + p) * NG + g) * CX_BM + 64 * half));
         }
     };
-    // activation tile of a stage: 3 planes x 2 channel groups x (64 + 64 + 8 slots): 18 pieces (waves 0, 1: five, waves 2, 3: four), the
-    // short ones with 8 lanes
+    // activation tile of a stage: NP planes x NG channel groups x (64 + 64 + 8 slots): 3 NP NG pieces, the short ones with 8 lanes
     auto dma_x = [&](int st, int buf) {
         st = min(st, s1 - 1);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < (3 * NP * NG + 3) / 4; ++i) {
             const int q = wave + 4 * i;
-            if (q < 18) {
-                const int pg = q / 3, piece = q - 3 * pg, p = pg >> 1, g = pg & 1;
-                const uint4* src = a.Xp + (((size_t)bb * 3 + p) * a.G + 2 * st + g) * a.Tp + t0 + 64 * piece + lane;
-                const unsigned dst = lds0 + 16u * (unsigned)(CX_NW * 3 * 2 * CX_BM + ((buf * 3 + p) * 2 + g) * CX_XS + 64 * piece);
+            if (q < 3 * NP * NG) {
+                const int pg = q / 3, piece = q - 3 * pg, p = pg / NG, g = pg % NG;
+                const uint4* src = a.Xp + (((size_t)bb * NP + p) * a.G + NG * st + g) * a.Tp + t0 + 64 * piece + lane;
+                const unsigned dst = lds0 + 16u * (unsigned)(CX_NW * WSL + ((buf * NP + p) * NG + g) * CX_XS + 64 * piece);
                 if (piece < 2 || lane < 8) cx_dma16(src, dst);
             }
         }
@@ -168,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void k_conv5_x3(ConvX3Args a) {
     dma_w(s0, 0, 0);
     dma_w(s0, 1, 1);
     dma_w(s0, 2, 2);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // everything but the tiles of steps 1 and 2
+    cx_wait<2 * WPW>();         // everything but the tiles of steps 1 and 2
     __syncthreads();
     int idx = 0;
     for (int st = s0; st < s1; ++st) {
@@ -178,34 +207,31 @@ __global__ __launch_bounds__(256, 2) void k_conv5_x3(ConvX3Args a) {
             const int wb = idx & (CX_NW - 1);
             // requests of this step, in this order: the weight tile of step idx + 3 (into the buffer everybody left at the last barrier),
             // and at tap 0 the activation tile of the next stage
-            if (!(a.dbg & 1)) {
             if (tap < 2) dma_w(st, tap + 3, (idx + 3) & (CX_NW - 1));
             else dma_w(st + 1, tap - 2, (idx + 3) & (CX_NW - 1));
             if (tap == 0) dma_x(st + 1, xb ^ 1);
-            }
-            uint4 av[3][2], bv[3][2];
-            if (!(a.dbg & 4) || idx == 0) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                av[p][0] = Ws[wb][p][kq][am];
-                av[p][1] = Ws[wb][p][kq][am + 32];
-                bv[p][0] = Xs[xb][p][kq][bn + tap];
-                bv[p][1] = Xs[xb][p][kq][bn + 32 + tap];
-            }
-            }
-            if (!(a.dbg & 2)) {
 #define CX_ALL(PA, PB)                                      \
             CX_MFMA(av[PA][0], bv[PB][0], acc[0][0]); CX_MFMA(av[PA][0], bv[PB][1], acc[0][1]); \
             CX_MFMA(av[PA][1], bv[PB][0], acc[1][0]); CX_MFMA(av[PA][1], bv[PB][1], acc[1][1])
-            CX_ALL(2, 0); CX_ALL(0, 2); CX_ALL(1, 1); CX_ALL(1, 0); CX_ALL(0, 1); CX_ALL(0, 0);
-#undef CX_ALL
+#pragma unroll
+            for (int ks = 0; ks < NG / 2; ++ks) {       // blocks of 16 channels of this step
+                uint4 av[NP][2], bv[NP][2];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    av[p][0] = Ws[wb][p][2 * ks + kq][am];
+                    av[p][1] = Ws[wb][p][2 * ks + kq][am + 32];
+                    bv[p][0] = Xs[xb][p][2 * ks + kq][bn + tap];
+                    bv[p][1] = Xs[xb][p][2 * ks + kq][bn + 32 + tap];
+                }
+                if constexpr (NP == 3) { CX_ALL(2, 0); CX_ALL(0, 2); CX_ALL(1, 1); CX_ALL(1, 0); CX_ALL(0, 1); CX_ALL(0, 0); }
+                else { CX_ALL(0, 0); }
             }
+#undef CX_ALL
             // the weight tile of step idx + 1 (requested two steps ago) must have landed before anybody passes the barrier; requests
             // come back in order, so it has once at most the younger ones are outstanding: the weight requests of the last two steps
-            // (3 + 3 per wave) and — until tap 3 — this stage's activation request (>= 4 per wave), which is younger as well
-            if (a.dbg & 1) { }
-            else if (tap < 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            // (WPW each per wave) and — until tap 3 — this stage's activation request (>= XPW per wave), which is younger as well
+            if (tap < 3) cx_wait<2 * WPW + XPW>();
+            else cx_wait<2 * WPW>();
             __syncthreads();    // ... and this step's LDS reads are done (the next step overwrites nothing that is still read: CX_NW = 4)
         }
     }
@@ -360,6 +386,7 @@ int t2v_conv5_x3_stat_blocks(int B, int T) { return B * ((T + CX_BN - 1) / CX_BN
 static int cx_splits(long tiles, int nst) {
     static const int forced = getenv("T2V_CONV_X3_SPLITS") ? atoi(getenv("T2V_CONV_X3_SPLITS")) : 0;
     if (forced > 0) return forced > nst ? nst : forced;
+    if (tiles >= 192) return 1;         // (measured at 256 tiles, one-plane form: 60 / 65 / 73 us with 1 / 2 / 4 splits)
     int best = 1;
     double best_w = 1e30;
     for (int ns = 1; ns <= 8 && (ns == 1 || nst / ns >= 2); ++ns) {
@@ -370,27 +397,42 @@ static int cx_splits(long tiles, int nst) {
     return best;
 }
 
-// W: (M, Cin, 5) weights of the convolution to run (the data gradient passes the flipped, transposed weights)
+// bf16_run: does the k = 5 convolution (t2v_conv1d_fwd_bf16 / the data gradient of t2v_conv1d_bwd_bf16) take the one-plane form of the
+// kernels above (operands rounded to bf16 once by the split passes, LDS-DMA, 32 channels per step)?  The same switch as the fp32 form
+// (t2v_conv1d_x3_set_mode: 0 never, 1 every eligible shape, 2 launches of >= 192 tiles); t2v_conv1d_stat_blocks_bf16 gives the
+// matching answer
+bool t2v_conv5_planes_bf16_ok(int B, int Cin, int T, int Cout, int KS) {
+    const int mode = t2v_conv1d_x3_set_mode(-1);
+    if (!mode || KS != 5 || Cin % 16 || Cin < 64 || Cout < 64 || B < 1 || T < 1) return false;
+    if (mode == 2 && (long)B * ((T + CX_BN - 1) / CX_BN) * ((Cout + CX_BM - 1) / CX_BM) < 192) return false;
+    return true;
+}
+// W: (M, Cin, 5) weights of the convolution to run (the data gradient passes the flipped, transposed weights); np = 3: fp32 operands
+// as three bf16 planes, np = 1: bf16_run
 int t2v_conv5_x3_run(const float* W, const float* X, const float* bias, float* Y, float* stat_part, int B, int Cin, int T, int M,
-                     hipStream_t stream) {
-    const int Mp = (M + CX_BM - 1) / CX_BM * CX_BM, G = (Cin + 15) / 16 * 2, ntile = (T + CX_BN - 1) / CX_BN;
+                     hipStream_t stream, int np) {
+    const int NG = np == 3 ? 2 : 4;
+    const int Mp = (M + CX_BM - 1) / CX_BM * CX_BM, G = (Cin + 8 * NG - 1) / (8 * NG) * NG, ntile = (T + CX_BN - 1) / CX_BN;
     const int Tp = (ntile * CX_BN + CX_XS - CX_BN + 63) / 64 * 64;          // the last tile's DMA reads slots up to ntile * 128 + 8
-    const size_t w_slots = (size_t)5 * 3 * G * Mp, x_slots = (size_t)B * 3 * G * Tp;
+    const size_t w_slots = (size_t)5 * np * G * Mp, x_slots = (size_t)B * np * G * Tp;
     const long tiles = (long)B * ntile * (Mp / CX_BM);
-    const int nst = G / 2, ns = cx_splits(tiles, nst);
+    const int nst = G / NG, ns = cx_splits(tiles, nst);
     const size_t part_floats = ns > 1 ? (size_t)ns * tiles * CX_BM * CX_BN : 0;
     float* scr = cx_scratch(4 * (w_slots + x_slots) + part_floats);
     if (!scr) return T2V_ERR_LAUNCH;
     uint4* Wp = (uint4*)scr;
     uint4* Xp = Wp + w_slots;
-    k_cx3_split_w<<<dim3((Mp + 255) / 256, G), 256, 0, stream>>>(W, Wp, M, Cin, Mp, G);
-    k_cx3_split_x<<<dim3((Tp + 255) / 256, G, B), 256, 0, stream>>>(X, Xp, Cin, T, Tp, G);
+    if (np == 3) {
+        k_cx3_split_w<3><<<dim3((Mp + 255) / 256, G), 256, 0, stream>>>(W, Wp, M, Cin, Mp, G);
+        k_cx3_split_x<3><<<dim3((Tp + 255) / 256, G, B), 256, 0, stream>>>(X, Xp, Cin, T, Tp, G);
+    } else {
+        k_cx3_split_w<1><<<dim3((Mp + 255) / 256, G), 256, 0, stream>>>(W, Wp, M, Cin, Mp, G);
+        k_cx3_split_x<1><<<dim3((Tp + 255) / 256, G, B), 256, 0, stream>>>(X, Xp, Cin, T, Tp, G);
+    }
     ConvX3Args a;
     a.Wp = Wp; a.Xp = Xp; a.bias = bias; a.Y = Y; a.stat_part = stat_part;
     a.B = B; a.M = M; a.T = T; a.Mp = Mp; a.Tp = Tp; a.G = G; a.tiles_per_item = ntile;
     a.st_chunk = nst; a.part = nullptr; a.tile_ctr = nullptr;
-    static const int dbg = getenv("T2V_CX3_DBG") ? atoi(getenv("T2V_CX3_DBG")) : 0;
-    a.dbg = dbg;
     dim3 grid(B * ntile, Mp / CX_BM, 1);
     if (ns > 1) {
         a.st_chunk = (nst + ns - 1) / ns;
@@ -403,6 +445,7 @@ int t2v_conv5_x3_run(const float* W, const float* X, const float* bias, float* Y
             a.st_chunk = nst;
         }
     }
-    k_conv5_x3<<<grid, 256, 0, stream>>>(a);
+    if (np == 3) k_conv5_x3<3, 2><<<grid, 256, 0, stream>>>(a);
+    else k_conv5_x3<1, 4><<<grid, 256, 0, stream>>>(a);
     return T2V_OK;
 }
