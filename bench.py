@@ -256,7 +256,7 @@ def frontend_bench(B=6, n_samples=102144, reps=20, big=True):
 def _in_situ_durations():
     """per-kernel average durations of a traced steady-state step (rocprofv3 --kernel-trace over graph replays of the same
     command, committed under profiles/ by tools/round_profile.sh): the in-situ counterpart of the replay timings below"""
-    for fn in ('r05_kernel_durations.json', 'r04_kernel_durations.json', 'r03_kernel_durations.json', 'r02_kernel_durations.json'):
+    for fn in ('r06_kernel_durations.json', 'r05_kernel_durations.json', 'r04_kernel_durations.json', 'r03_kernel_durations.json', 'r02_kernel_durations.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', fn)) as f:
                 return json.load(f), 'profiles/' + fn
@@ -267,7 +267,7 @@ def _in_situ_durations():
 
 def _profile_file(suffix):
     """the newest committed profiles/r0N_<suffix> (this round's evidence when it exists, else the previous round's)"""
-    for r in ('r05', 'r04', 'r03'):
+    for r in ('r06', 'r05', 'r04', 'r03'):
         fn = os.path.join(ROOT, 'profiles', '%s_%s' % (r, suffix))
         if os.path.isfile(fn):
             return fn
@@ -326,6 +326,14 @@ def _whole_step_counters(ms_per_step):
             mf = json.load(f)["kernels"]
         busy = sum(e["mfma_busy_frac"] * ms(k) for k, e in mf.items() if "mfma_busy_frac" in e)
         res["mfma_busy_frac_over_step"] = round(busy / ms_per_step, 4)
+        # the dense kernels of the step against the MFMA roof of the dtype their MFMAs run in (x3 products: six bf16 MFMAs per fp32
+        # product block — `fp32_equiv_tflops` is what the caller gets)
+        res["mfma_kernels"] = [
+            {"kernel": k, "mfma_dtype": e.get("mfma_dtype"), "mfma_busy_frac": e.get("mfma_busy_frac"), "mfma_tflops_at_2.4GHz": e.get("tflops_at_2.4GHz"),
+             "peak_tflops": 2500.0 if e.get("mfma_dtype") == "bf16" else 157.0,
+             **({"fp32_equiv_tflops": round(e.get("tflops_at_2.4GHz", 0.0) / 6.0, 1)} if ('x3p' in k or 'conv5_x3' in k) and e.get("mfma_dtype") == "bf16" else {}),
+             "ms_per_step": round(ms(k), 3), "dispatches_in_profile": e.get("dispatches")}
+            for k, e in sorted(mf.items(), key=lambda kv: -ms(kv[0])) if "mfma_busy_frac" in e and ms(k) > 0]
         res["mfma_busy_source"] = "%s x ms/step of %s" % (os.path.relpath(msrc, ROOT), os.path.relpath(_profile_file('steady_state.txt'), ROOT))
     except Exception:
         pass
@@ -402,12 +410,22 @@ def roofline_table(B, T_in, T, reps=3):
             # round 4 (profiles/r04_bwd_persist_timeline.txt): FOUR dependent hand-offs per step — (dc, dh) row -> attention_rnn
             # workgroups, context gradient -> attention slices, partial dq -> slice 0 of the item, summed dq -> attention_rnn
             # workgroups — and, between them, the context-column GEMV (1.2 us), the attention slice (1.2 us) and the cell (1.0 us)
+            # round 6 (profiles/r06_bwd_persist_timeline.txt): the model on BOTH hop costs.  A word crosses the chip in
+            # 0.45 us (profiles/r03_hop_latency.txt: two workgroups, nothing else running) — the floor of an ideal hand-off; what a
+            # dependent look costs INSIDE this kernel, with >= 128 workgroups polling and the factor DMA in the same memory pipe, is
+            # ~1 us (round 5; the r06 timeline: context gradient published -> seen by the attention slices 1.3-1.7 us,
+            # dq published -> gathered by the attention_rnn workgroups through slice 0 2.2 us = two hops).  Four dependent hand-offs,
+            # the 48 KB (dc, dh) row at a CU's 11 B/cycle, 3.4 us of dependent arithmetic (context-column GEMV 1.2, attention slice
+            # 1.2, cell 1.0)
             fetch_us = 48 * 1024 / 11.0 / 2400.0
             floor_us = 4 * 0.45 + fetch_us + 3.4
-            row["latency_model"] = {"hand_offs_per_step": 4, "hand_off_us": 0.45, "row_bytes_on_chain_per_cu": 48 * 1024,
-                                    "cu_fetch_bytes_per_cycle": 11, "dependent_compute_us": 3.4, "floor_us_per_step": round(floor_us, 2),
+            floor_loaded_us = 4 * 1.0 + fetch_us + 3.4
+            row["latency_model"] = {"hand_offs_per_step": 4, "hand_off_us_idle_chip": 0.45, "hand_off_us_under_load": 1.0,
+                                    "row_bytes_on_chain_per_cu": 48 * 1024, "cu_fetch_bytes_per_cycle": 11, "dependent_compute_us": 3.4,
+                                    "floor_us_per_step": round(floor_us, 2), "floor_us_per_step_loaded_hops": round(floor_loaded_us, 2),
                                     "achieved_us_per_step": round(us / T, 2), "frac_of_floor": round(floor_us / (us / T), 3),
-                                    "source": "profiles/r04_bwd_persist_timeline.txt, profiles/r03_hop_latency.txt"}
+                                    "frac_of_loaded_hop_floor": round(floor_loaded_us / (us / T), 3),
+                                    "source": "profiles/r06_bwd_persist_timeline.txt (this code), profiles/r03_hop_latency.txt (idle-chip hop)"}
         if name == "k_bwd_persist16":
             row["us_per_time_step"] = round(us / T, 3)
             row["note"] = ("bf16_run, B <= 16: ONE launch for the whole reverse pass (%d time steps) — Wcat^T as register-resident bf16 MFMA "
@@ -636,7 +654,11 @@ def main():
         "config": {"workload": WORKLOADS[kind], "step_mode": res["step_mode"], "decoder_forward": res["decoder_forward"], "decoder_backward": res["decoder_backward"],
                    "startup_steps": res["startup_steps"],
                    "global_batch": bpg * world, "frames_per_step": res["frames_per_step"],
-                   "parallelism": "dp%d" % world},
+                   "parallelism": "dp%d" % world,
+                   "f32_dense_products": ("fp32-MFMA only (T2V_F32_GEMM=native)" if not t2v_hip.set_f32_gemm_mode(None) else
+                                          "large GEMMs (>= 64 tiles of 128x128) as six bf16 MFMAs on exactly 3-way-split fp32 operands "
+                                          "(x3: fp32-class error, tests/test_gemm_gpu.py::test_x3_gemm_is_fp32_class), everything else "
+                                          "v_mfma_f32_*_f32")},
         "final_loss": res["final_loss"],
     }
     if "graph_vs_eager_ms" in res:
@@ -658,7 +680,7 @@ def main():
         rows = roofline_table(bpg, T_IN, T_OUT)
         top = rows[0]                   # the kernel with the most time per step
         traffic, tsrc = None, None      # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, corrected)
-        for fn in ('r05_pmc_fetch_size.json', 'r04_pmc_fetch_size.json', 'r03_pmc_fetch_size.json', 'r02_pmc_fetch_size.json', 'r01_pmc_fetch_size.json'):
+        for fn in ('r06_pmc_fetch_size.json', 'r05_pmc_fetch_size.json', 'r04_pmc_fetch_size.json', 'r03_pmc_fetch_size.json', 'r02_pmc_fetch_size.json', 'r01_pmc_fetch_size.json'):
             try:
                 with open(os.path.join(ROOT, 'profiles', fn)) as f:
                     traffic = json.load(f)["kernels"][top["kernel"]]["corrected_bytes_per_launch"]
@@ -734,7 +756,8 @@ def main():
                             mb = json.load(f)["kernels"]
                         r2["roofline_kernels"] = [
                             {"kernel": k, "bound": "mfma", "achieved": e.get("tflops_at_2.4GHz"), "unit": "TFLOP/s",
-                             "peak": 2500.0 if 'bf16' in k else 157.0, "mfma_busy_frac": e.get("mfma_busy_frac"),
+                             "peak": 2500.0 if e.get("mfma_dtype", "bf16" if 'bf16' in k else "f32") == "bf16" else 157.0,
+                             "mfma_dtype": e.get("mfma_dtype"), "mfma_busy_frac": e.get("mfma_busy_frac"),
                              "dispatches_in_profile": e.get("dispatches"), "source": os.path.relpath(bsrc, ROOT)}
                             for k, e in mb.items() if "mfma_busy_frac" in e]
                     except Exception:

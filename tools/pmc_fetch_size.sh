@@ -18,7 +18,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     if r['Counter_Name'] != 'FETCH_SIZE':
         continue
     n = r['Kernel_Name']
-    for key in ('k_bwd_persist16', 'k_dec_train_persist16', 'k_q16_fill', 'k_p16_fill', 'k_gemm_bf16_big', 'k_conv5_fwd_bf16', 'k_achain_bwd', 'k_dec_train_persist', 'k_lstm_fwd256', 'k_lstm_bwd256', 'k_attn_fwd', 'k_attn_cell_bwd', 'k_clip_adam', 'k_attn_wgrad_part', 'k_conv5_fwd<5>', 'k_conv5_dw', 'k_gemm_f32_big', 'k_pb_factors', 'k_pb_cellpre', 'k_pb_fill', 'k_bilstm_fwd', 'k_bilstm_bwd'):
+    for key in ('k_bwd_persist16', 'k_dec_train_persist16', 'k_q16_fill', 'k_p16_fill', 'k_gemm_x3p', 'k_x3_split', 'k_conv5_x3', 'k_cx3_split', 'k_gemm_bf16_big', 'k_conv5_fwd_bf16', 'k_achain_bwd', 'k_dec_train_persist', 'k_lstm_fwd256', 'k_lstm_bwd256', 'k_attn_fwd', 'k_attn_cell_bwd', 'k_clip_adam', 'k_attn_wgrad_part', 'k_conv5_fwd<5>', 'k_conv5_dw', 'k_gemm_f32_big', 'k_pb_factors', 'k_pb_cellpre', 'k_pb_fill', 'k_bilstm_fwd', 'k_bilstm_bwd'):
         if key in n:
             agg[key].append(float(r['Counter_Value']))
             break

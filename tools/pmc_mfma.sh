@@ -13,16 +13,16 @@ tail -2 /tmp/pmcm$SUF.log | cut -c1-200
 F=$(find /tmp/pmcm$SUF -name '*counter_collection.csv' | head -1)
 mkdir -p $REPO/gpurun_out
 python - "$F" "$EXTRA" > $REPO/gpurun_out/${TAG}_pmc_mfma$SUF.json <<'PY'
-import csv, sys, json, collections
+import csv, sys, json, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-keys = ('k_bwd_persist16', 'k_dec_train_persist16', 'k_gemm_f32_big', 'k_gemm_bf16_big', 'k_gemm_f32', 'k_gemm_bf16', 'k_conv5_fwd_bf16', 'k_conv5_fwd', 'k_conv5_dw', 'k_lstm_bwd256', 'k_lstm_fwd256',
-        'k_dec_train_persist', 'k_achain_bwd', 'k_attn_cell_bwd', 'k_bilstm_fwd', 'k_bilstm_bwd', 'Cijk')
+# round 6: one row per kernel FUNCTION (template arguments and parameters stripped) — no substring keys: k_conv5_fwd_bf16k32 used to be
+# counted under k_conv5_fwd_bf16, k_conv5_dw_bf16 under k_conv5_dw
+want = re.compile(r'^(k_bwd_persist16|k_dec_train_persist16|k_gemm_\w+|k_conv5_\w+|k_x3_split|k_cx3_split_\w+|k_lstm_\w+|k_dec_train_persist|k_achain_bwd|k_attn_cell_bwd|k_bilstm_\w+|Cijk\w*)$')
 for r in csv.DictReader(open(sys.argv[1])):
-    n = r['Kernel_Name']
-    for key in keys:
-        if key in n:
-            agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
-            break
+    n = r['Kernel_Name'].replace('void ', '')
+    base = re.split(r'[<(]', n, 1)[0].strip()
+    if want.match(base):
+        agg[base][r['Counter_Name']].append(float(r['Counter_Value']))
 out = {"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode --no-secondary --no-graph %s (MI355X, separate PMC-only pass, tools/pmc_mfma.sh)" % sys.argv[2],
        "formula": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): the CSV reports GRBM_GUI_ACTIVE summed over the 8 XCDs (cross-check: MOPS x 512 / cycles reproduces the event-timed TFLOP/s); mean over the dispatches of a kernel",
        "kernels": {}}
@@ -37,6 +37,7 @@ for k, c in agg.items():
         fl = (e.get("avg_SQ_INSTS_VALU_MFMA_MOPS_F32", 0) + e.get("avg_SQ_INSTS_VALU_MFMA_MOPS_BF16", 0)) * 512
         e["mfma_flop_per_dispatch"] = int(fl)
         e["tflops_at_2.4GHz"] = round(fl / (cyc / 2.4e9) / 1e12, 1)
+        e["mfma_dtype"] = "bf16" if e.get("avg_SQ_INSTS_VALU_MFMA_MOPS_BF16", 0) > e.get("avg_SQ_INSTS_VALU_MFMA_MOPS_F32", 0) else "f32"
     out["kernels"][k] = e
 print(json.dumps(out, indent=1))
 PY
