@@ -383,3 +383,54 @@ def test_config5_shape_both_builds_against_the_cpu_oracle():
     finally:
         M.drop_rate = old
         t2v_hip.set_bf16(False)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T", [(16, 512, 512, 400), (6, 512, 512, 84), (3, 512, 256, 37), (2, 128, 512, 129), (5, 96, 208, 131), (1, 64, 64, 2)])
+def test_conv_bf16_plane_kernels_match_the_rounded_product(B, Cin, Cout, T):
+    """Round 6: `bf16_run` Conv1d forward / data gradient on pre-rounded bf16 planes + the LDS-DMA kernel (conv_x3.hip, one plane;
+    t2v_conv1d_x3_set_mode(1) = every eligible shape, the default takes launches of >= 192 tiles) through t2v_conv1d_fwd_bf16 /
+    t2v_conv1d_bwd_bf16: == the fp64 convolution of the bf16-ROUNDED operands (what k_conv5_fwd_bf16k32 computes as well), the
+    BatchNorm partial sums of the epilogue, the data gradient; channel counts that are not multiples of 32, ragged T, T < one
+    tile; bit-reproducible; and the same entry points in mode 0 agree."""
+    import ctypes as C
+    import t2v_hip
+    lib = t2v_hip.load_library()
+    g = torch.Generator().manual_seed(B * 1000 + T + Cin)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, 5, generator=g) / (Cin * 5) ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.1
+    dy = torch.randn(B, Cout, T, generator=g)
+    xr, wr, dyr = x.bfloat16().double(), w.bfloat16().double(), dy.bfloat16().double()
+    ref = F.conv1d(xr, wr, bias.double(), padding=2)
+    ref_dx = F.conv_transpose1d(dyr, wr, padding=2)
+    gx, gw, gb, gdy = x.cuda(), w.cuda(), bias.cuda(), dy.cuda()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    wp = torch.empty(w.numel(), device='cuda', dtype=torch.bfloat16)
+    res = {}
+    prev = lib.t2v_conv1d_x3_set_mode(-1)
+    try:
+        for mode in (1, 0):
+            lib.t2v_conv1d_x3_set_mode(mode)
+            nblk = lib.t2v_conv1d_stat_blocks_bf16(B, T, Cin, Cout, 5)
+            runs = []
+            for rep in range(2):
+                y = torch.full((B, Cout, T), float('nan'), device='cuda')
+                part = torch.full((nblk, Cout, 2), float('nan'), device='cuda')
+                assert lib.t2v_conv1d_fwd_bf16(p(gw), p(gx), p(gb), p(y), p(part), p(wp), B, Cin, T, Cout, 5, st) == 0
+                dx = torch.full((B, Cin, T), float('nan'), device='cuda')
+                assert lib.t2v_conv1d_bwd_bf16(p(gw), p(gx), p(gdy), p(dx), None, p(wp), None, B, Cin, T, Cout, 5, st) == 0
+                torch.cuda.synchronize()
+                runs.append((y, part, dx))
+            assert all(torch.equal(a, b) for a, b in zip(runs[0], runs[1])), 'not reproducible'
+            y, part, dx = runs[0]
+            assert not torch.isnan(y).any() and not torch.isnan(part).any() and not torch.isnan(dx).any()
+            s = part.cpu().double().sum(0)
+            res[mode] = ((y.cpu().double() - ref).abs().max().item() / ref.abs().max().item(),
+                         (dx.cpu().double() - ref_dx).abs().max().item() / ref_dx.abs().max().item(),
+                         (s[:, 0] - ref.sum((0, 2))).abs().max().item() / ref.abs().sum((0, 2)).max().item(),
+                         (s[:, 1] - (ref * ref).sum((0, 2))).abs().max().item() / (ref * ref).sum((0, 2)).max().item())
+    finally:
+        lib.t2v_conv1d_x3_set_mode(prev)
+    for mode in (1, 0):
+        assert res[mode][0] < 2e-5 and res[mode][1] < 2e-5 and res[mode][2] < 1e-5 and res[mode][3] < 1e-5, (mode, res[mode])
