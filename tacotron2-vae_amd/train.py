@@ -126,12 +126,13 @@ class TrainEngine(object):
         self._pending_key = None
         self.graph_fallbacks = 0
         self._test_replay_drag_us = 0   # tests: a kernel that holds 8 workgroups for this long behind every probed replay
-        # (round 6: that stream gets the higher of the two priorities the runtime offers — the dependent chain of a step runs there, the
-        # side streams carry deferred work: bf16 step 12.34 -> 12.28 ms, fp32 10.91 -> 10.89, two alternating pairs; T2V_MAIN_PRIO=0 undoes it)
+        # (round 6, T2V_MAIN_PRIO=-1 — the higher of the two stream priorities for this stream — measured: alone it buys the bf16 step
+        # 12.34 -> 12.28 ms and the fp32 step nothing, but the THIRD engine of one process (bench.py's secondary bf16 leg) then replays at
+        # 14.15 ms instead of 12.32: another cliff of the graph executor's queue assignment.  The default stays 0.)
         # graph mode: EVERY step of this engine (the eager warm-up ones too) runs on one dedicated stream — autograd's
         # AccumulateGrad nodes remember the stream of their first backward, and a capture that has to synchronise with
         # the legacy default stream is illegal
-        self._stream = torch.cuda.Stream(priority=int(os.environ.get('T2V_MAIN_PRIO', '-1'))) if self.use_graph else None
+        self._stream = torch.cuda.Stream(priority=int(os.environ.get('T2V_MAIN_PRIO', '0'))) if self.use_graph else None
         # this engine's device-side step record (dropout epoch, lr, Adam bias corrections, KL weight): bound to the
         # engine's own stream when it has one, so that two engines in one process never share a record
         self.step_params = t2v_hip.step_params(fresh=True, stream=self._stream)
