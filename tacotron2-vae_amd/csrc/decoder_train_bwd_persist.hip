@@ -26,7 +26,8 @@
 #endif
 #define PB_THREADS 512
 #define PB_MAXB 6
-#define PB_MAXT 224
+#define PB_MAXT 224                   // 16- / 32-position attention slices up to here
+#define PB_MAXT_LONG 576              // 96-position slices on eight waves beyond (k_achain_bwd<.., true>): at most six per item
 #define PB_SPIN 400000
 #define PB_SENT 0xFFFFFFFFu
 #define PB_KJ (T2V_G / PB_THREADS)          // 8 gate rows per thread: k = tid + 512 j
@@ -478,7 +479,7 @@ static int pb_device_ok() {
 }
 
 extern "C" int t2v_decoder_bwd_persist_supported(int B, int T_in) {
-    if (!(B >= 1 && B <= PB_MAXB && T_in >= 1 && T_in <= PB_MAXT)) return 0;
+    if (!(B >= 1 && B <= PB_MAXB && T_in >= 1 && T_in <= PB_MAXT_LONG)) return 0;
     return pb_device_ok();
 }
 // floats of exchange scratch for the decoder_rnn chain (t2v_decoder_bwd_dchain)
@@ -1479,7 +1480,10 @@ __device__ __forceinline__ void pba_attention_rnn_role(const PBAArgs& a, float* 
     PBA_PROF_FLUSH(ja == 0, 12, 4);
 }
 
-template <int NB>      // 4: B <= 4, 6: B = 5, 6
+// NB — 4: B <= 4, 6: B = 5, 6.  LONG — 224 < T_in <= 576: the attention role as 96-position slices on all eight waves (the form
+// round 4 built for "one workgroup per item"; with S <= 6 slices an item of 555 symbols takes as many workgroups as the
+// headline shape's 84 symbols in 16-position slices, so the LSTM roles keep their 4 / 5 units per workgroup).
+template <int NB, bool LONG>
 __global__ __launch_bounds__(PB_THREADS) void k_achain_bwd(PBAArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wg = blockIdx.x;
@@ -1496,7 +1500,7 @@ __global__ __launch_bounds__(PB_THREADS) void k_achain_bwd(PBAArgs a) {
     pba_decoder_role<NB>(a, lds, wg - NT - NA, ND);
 #else
     if (wg < NT) {
-        if (PBA_WHOLE_ITEM && a.T_in <= 96) pba_attention_role<96, 8>(a, lds, wg / S, wg % S, NB);
+        if (LONG || (PBA_WHOLE_ITEM && a.T_in <= 96)) pba_attention_role<96, 8>(a, lds, wg / S, wg % S, NB);
         else if (a.T_in <= 128) pba_attention_role<16, 4>(a, lds, wg / S, wg % S, NB);
         else pba_attention_role<32, 4>(a, lds, wg / S, wg % S, NB);
     } else if (wg < NT + NA) {
@@ -1514,13 +1518,13 @@ __global__ __launch_bounds__(PB_THREADS) void k_achain_bwd(PBAArgs a) {
 // sentinel-filled arrays; but the decoder_rnn chain ends ~20 % earlier (8.5 vs 10.5 us per step), and as a launch of its own
 // its END is something a stream can wait for: the two decoder_rnn weight-gradient GEMMs (which need all of DGD and nothing
 // of the other chain) are queued behind it and run on the CUs it frees while the attention chain is still going.
-template <int NB>
+template <int NB, bool LONG>
 __global__ __launch_bounds__(PB_THREADS) void k_achain_bwd_ta(PBAArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wg = blockIdx.x;
     const int S = a.S_sl, NT = a.B * S, NL = T2V_NWG - NT, NA = pba_na(NL);
     if (wg < NT) {
-        if (PBA_WHOLE_ITEM && a.T_in <= 96) pba_attention_role<96, 8>(a, lds, wg / S, wg % S, NB);
+        if (LONG || (PBA_WHOLE_ITEM && a.T_in <= 96)) pba_attention_role<96, 8>(a, lds, wg / S, wg % S, NB);
         else if (a.T_in <= 128) pba_attention_role<16, 4>(a, lds, wg / S, wg % S, NB);
         else pba_attention_role<32, 4>(a, lds, wg / S, wg % S, NB);
     } else {
@@ -1540,7 +1544,7 @@ __global__ __launch_bounds__(PB_THREADS) void k_dchain_bwd_free(PBAArgs a) {
 // (PBA_WHOLE_ITEM: measured at B = 6, T_in = 84 — 11.0 us per reverse step against 10.4 with six 16-position slices per item:
 // the hand-off through slice 0 disappears (-1.4 us), but ONE workgroup needs 3.3 us from "context gradient seen" to "dq
 // published" (1.3 with slices) and 11 us for its whole loop, so it becomes the chain.  Parity-green, kept for the record.)
-static inline int pba_js(int T_in) { return (PBA_WHOLE_ITEM && T_in <= 96) ? 96 : t2v_attn_bwd_js(T_in); }
+static inline int pba_js(int T_in) { return ((PBA_WHOLE_ITEM && T_in <= 96) || T_in > PB_MAXT) ? 96 : t2v_attn_bwd_js(T_in); }
 static inline int pba_slices(int T_in) { const int js = pba_js(T_in); return (T_in + js - 1) / js; }
 extern "C" int t2v_decoder_bwd_persist_slices(int T_in) { return T_in < 1 ? 0 : pba_slices(T_in); }
 
@@ -1555,7 +1559,7 @@ static size_t pba_lds_bytes(int B, int T_in) {
 // exchange scratch of the attention chain (floats): gate-gradient rows of both cells, context gradients, window partials.
 // The dq partials (T,B,S,128) are an OUTPUT (the caller reduces them into d W_q) and are passed separately.
 extern "C" long t2v_decoder_bwd_achain_scratch_floats(int B, int T_in, int T_out) {
-    if (B < 1 || B > PB_MAXB || T_in < 1 || T_in > PB_MAXT || T_out < 1) return 0;
+    if (B < 1 || B > PB_MAXB || T_in < 1 || T_in > PB_MAXT_LONG || T_out < 1) return 0;
     const size_t S = (size_t)pba_slices(T_in), gpw = pba_js(T_in) + 30 <= 64 ? 64 : 128;
     const size_t cx = (size_t)T_out * (B > 4 ? 32768 : 16384) / 4;
     // (dc, dh) rows of both cells (half a gate row each) + context rows + window partials + E + the two factor arrays
@@ -1611,10 +1615,14 @@ static int pba_launch(const t2v_dec_train_persist_weights* w, const t2v_dec_trai
     if (pba_lds_bytes(B, T_in) > PB_LDS_MAX) return T2V_ERR_ARG;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_achain_bwd<4>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_MAX) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_achain_bwd<6>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_MAX) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_achain_bwd_ta<4>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_MAX) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_achain_bwd_ta<6>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_MAX) != hipSuccess ||
+        if (hipFuncSetAttribute((const void*)k_achain_bwd<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_MAX) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_achain_bwd<6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_MAX) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_achain_bwd_ta<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_MAX) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_achain_bwd_ta<6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_MAX) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_achain_bwd<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_MAX) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_achain_bwd<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_MAX) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_achain_bwd_ta<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_MAX) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_achain_bwd_ta<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_MAX) != hipSuccess ||
             hipFuncSetAttribute((const void*)k_dchain_bwd_free<4>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_MAX) != hipSuccess ||
             hipFuncSetAttribute((const void*)k_dchain_bwd_free<6>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_MAX) != hipSuccess)
             return t2v_check_launch();
@@ -1654,9 +1662,15 @@ static int pba_launch(const t2v_dec_train_persist_weights* w, const t2v_dec_trai
     }
     if (!do_run) return t2v_check_launch();
     const size_t lds = pba_lds_bytes(B, T_in);
+    const bool lng = T_in > PB_MAXT;
     if (!stream_d || stream_d == stream) {
-        if (B > 4) k_achain_bwd<6><<<T2V_NWG, PB_THREADS, lds, stream>>>(a);
-        else k_achain_bwd<4><<<T2V_NWG, PB_THREADS, lds, stream>>>(a);
+        if (lng) {
+            if (B > 4) k_achain_bwd<6, true><<<T2V_NWG, PB_THREADS, lds, stream>>>(a);
+            else k_achain_bwd<4, true><<<T2V_NWG, PB_THREADS, lds, stream>>>(a);
+        } else {
+            if (B > 4) k_achain_bwd<6, false><<<T2V_NWG, PB_THREADS, lds, stream>>>(a);
+            else k_achain_bwd<4, false><<<T2V_NWG, PB_THREADS, lds, stream>>>(a);
+        }
         return t2v_check_launch();
     }
     // two launches: stream_d joins `stream` here (fills / factor kernels above), the caller joins it back (DGD is complete when
@@ -1667,10 +1681,12 @@ static int pba_launch(const t2v_dec_train_persist_weights* w, const t2v_dec_trai
     const int NT = B * S, NL = T2V_NWG - NT, NA = pba_na(NL), ND = NL - NA;
     if (B > 4) {
         k_dchain_bwd_free<6><<<ND, PB_THREADS, lds, stream_d>>>(a);
-        k_achain_bwd_ta<6><<<NT + NA, PB_THREADS, lds, stream>>>(a);
+        if (lng) k_achain_bwd_ta<6, true><<<NT + NA, PB_THREADS, lds, stream>>>(a);
+        else k_achain_bwd_ta<6, false><<<NT + NA, PB_THREADS, lds, stream>>>(a);
     } else {
         k_dchain_bwd_free<4><<<ND, PB_THREADS, lds, stream_d>>>(a);
-        k_achain_bwd_ta<4><<<NT + NA, PB_THREADS, lds, stream>>>(a);
+        if (lng) k_achain_bwd_ta<4, true><<<NT + NA, PB_THREADS, lds, stream>>>(a);
+        else k_achain_bwd_ta<4, false><<<NT + NA, PB_THREADS, lds, stream>>>(a);
     }
     return t2v_check_launch();
 }

@@ -29,13 +29,15 @@
 
 #define Q16_THREADS 512
 #define Q16_MAXB 16
-#define Q16_MAXT 224
+#define Q16_MAXT 224                    // (SMAX below: 16- / 32-position slices up to here)
+#define Q16_MAXT_LONG 576               // 96-position slices on eight waves from 193 symbols on: at most six per item, 16 x 6 = 96 workgroups
 #define Q16_SPIN 400000
 #define Q16_SENT 0xFFFFFFFFu
 #define Q16_NGA 48                      // (1536 / 128) column groups x 4 row quarters
 #define Q16_NGD 80                      // (2560 / 128) x 4
 #define Q16_NCA 16                      // 1024 / 64 units
 #define Q16_NCD 16
+#define Q16_T32 192                     // 32-position slices up to here: 16 items x 6 slices fill the 96 attention workgroups
 #define Q16_MAXTWG (T2V_NWG - Q16_NGA - Q16_NGD - Q16_NCA - Q16_NCD)       // 96 attention workgroups
 #define Q16_ROW 131072u                 // bytes of one gate-gradient row: 4096 k x 16 items x bf16
 #define Q16_NCOLA 1536                  // Wcat_att^T: [h_att recurrent 1024 | ctx 512]
@@ -372,14 +374,15 @@ __device__ __forceinline__ void q16_cell_role(const Q16Args& a, float* lds, cons
 // The position-split body of decoder_train_bwd_persist.hip (softmax / tanh / fused-location-filter backward; operands that do
 // not change over the pass resident in registers, the cumulative-weights gradient in LDS), with the context gradient taken
 // from the partial rows of the G workgroups: d ctx(t) = sum_q PA(t+1)[q][ctx] + sum_q PD(t)[q][E_c] + dHC(t)[ctx].
-template <int JS>
+// NWV: waves that compute — 4 (16- / 32-position slices) or 8 (96-position slices: the form decoder_train_bwd_persist.hip
+// built in round 4; W_comb^T operand tile in LDS, dpT row stride 17 mod 32, window-partial rows of 128 floats per channel).
+template <int JS, int NWV = 4>
 __device__ __forceinline__ void q16_attention_role(const Q16Args& a, float* lds, const int b, const int s) {
-    constexpr int NWV = 4;
     constexpr int NJT = JS / 16;
     constexpr int PW = JS + 30;
-    constexpr int GPW = 64;
+    constexpr int GPW = PW <= 64 ? 64 : 128;
     constexpr int NRG = 2 * NWV;                     // row groups of 32 lanes in the dpre loop
-    constexpr int DPS = JS + 1;
+    constexpr int DPS = JS == 96 ? JS + 17 : JS + 1;
     static_assert(JS % NRG == 0 && JS % NWV == 0 && PW <= GPW, "slice geometry");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool act = tid < 64 * NWV;
@@ -400,10 +403,12 @@ __device__ __forceinline__ void q16_attention_role(const Q16Args& a, float* lds,
     float* rq = Tl + 64 * (JS + 1);           // [NRG][128] (also: the 32 row partials of the dot product)
     float* rv = rq + NRG * T2V_A;             // [NRG][128]
     int* flag = (int*)(rv + NRG * T2V_A);
+    constexpr bool AREG_LDS = NWV == 8;
+    float* wcs = (float*)(flag + 40);         // [64 rows (c,k)][132] when AREG_LDS
     const __amdgpu_buffer_rsrc_t rPA = q16_rsrc(a.PA), rPD = q16_rsrc(a.PD), rQ = q16_rsrc(a.DQX), rP = q16_rsrc(a.GPX), rQT = q16_rsrc(a.DQT);
     // ---- operands resident for the whole pass
     float4 m0[JS / NWV], m1[JS / NWV];
-    float areg[32];
+    float areg[AREG_LDS ? 1 : 32];
     float4 vd4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (act) {
         const int d4 = tid & 31;
@@ -414,14 +419,19 @@ __device__ __forceinline__ void q16_attention_role(const Q16Args& a, float* lds,
             m0[r] = *(const float4*)mrow;
             m1[r] = *(const float4*)(mrow + 256);
         }
-        const float4* wp = (const float4*)(a.wcomb + T2V_A * 64 + (16 * (wave & 3) + c16) * 128 + 32 * g);
+        if constexpr (!AREG_LDS) {
+            const float4* wp = (const float4*)(a.wcomb + T2V_A * 64 + (16 * (wave & 3) + c16) * 128 + 32 * g);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float4 w4 = wp[u];
-            areg[4 * u + 0] = w4.x; areg[4 * u + 1] = w4.y; areg[4 * u + 2] = w4.z; areg[4 * u + 3] = w4.w;
+            for (int u = 0; u < 8; ++u) {
+                const float4 w4 = wp[u];
+                areg[4 * u + 0] = w4.x; areg[4 * u + 1] = w4.y; areg[4 * u + 2] = w4.z; areg[4 * u + 3] = w4.w;
+            }
         }
         vd4 = *(const float4*)(a.v + 4 * d4);
     }
+    if (AREG_LDS)
+        for (int i = tid; i < 64 * 128; i += Q16_THREADS)          // row stride 132, 33 floats per k-group: conflict-free operand reads
+            wcs[(i >> 7) * 132 + ((i & 127) >> 5) * 33 + (i & 31)] = a.wcomb[T2V_A * 64 + i];
     for (int j = tid; j < Tcap; j += Q16_THREADS) gcum[j] = 0.f;
     if (tid == 0) flag[0] = 1;
     float dvacc = 0.f;                          // tid < 128: running dv[tid] of this slice
@@ -569,9 +579,14 @@ __device__ __forceinline__ void q16_attention_role(const Q16Args& a, float* lds,
         __syncthreads();
         if (tid < T2V_A) {
             const float* p = rq + tid;
-            const float q = ((p[0] + p[T2V_A]) + (p[2 * T2V_A] + p[3 * T2V_A])) + ((p[4 * T2V_A] + p[5 * T2V_A]) + (p[6 * T2V_A] + p[7 * T2V_A]));
+            float q = ((p[0] + p[T2V_A]) + (p[2 * T2V_A] + p[3 * T2V_A])) + ((p[4 * T2V_A] + p[5 * T2V_A]) + (p[6 * T2V_A] + p[7 * T2V_A]));
             const float* p2 = rv + tid;
-            const float vv = ((p2[0] + p2[T2V_A]) + (p2[2 * T2V_A] + p2[3 * T2V_A])) + ((p2[4 * T2V_A] + p2[5 * T2V_A]) + (p2[6 * T2V_A] + p2[7 * T2V_A]));
+            float vv = ((p2[0] + p2[T2V_A]) + (p2[2 * T2V_A] + p2[3 * T2V_A])) + ((p2[4 * T2V_A] + p2[5 * T2V_A]) + (p2[6 * T2V_A] + p2[7 * T2V_A]));
+            if (NRG > 8) {
+                p += 8 * T2V_A; p2 += 8 * T2V_A;
+                q += ((p[0] + p[T2V_A]) + (p[2 * T2V_A] + p[3 * T2V_A])) + ((p[4 * T2V_A] + p[5 * T2V_A]) + (p[6 * T2V_A] + p[7 * T2V_A]));
+                vv += ((p2[0] + p2[T2V_A]) + (p2[2 * T2V_A] + p2[3 * T2V_A])) + ((p2[4 * T2V_A] + p2[5 * T2V_A]) + (p2[6 * T2V_A] + p2[7 * T2V_A]));
+            }
             q16_st4(rQ, (unsigned)(((t * B + b) * S + s) * T2V_A + tid) * 4u, q);       // partial row (the d W_q GEMM reads them later)
             dvacc += vv;
             if (s == 0) {
@@ -609,12 +624,15 @@ __device__ __forceinline__ void q16_attention_role(const Q16Args& a, float* lds,
         // ---- through the fused location filter on MFMA: T[(c,k)][jl] = sum_d W_comb[d][(c,k)] dpre[jl][d], K = 128
         if (act) {
 #pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) {
+            for (int jt = (NWV == 8 ? (wave >> 2) : 0); jt < NJT; jt += NWV / 4) {     // (8 waves: waves 4..7 take the odd position tiles)
                 f32x4 ac4[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) ac4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int st = 0; st < 32; ++st) ac4[st & 3] = mfma16x4(areg[st], dpT[(4 * st + g) * DPS + 16 * jt + c16], ac4[st & 3]);
+                for (int st = 0; st < 32; ++st) {
+                    const float av = AREG_LDS ? wcs[(16 * (wave & 3) + c16) * 132 + 33 * g + st] : areg[AREG_LDS ? 0 : st];
+                    ac4[st & 3] = mfma16x4(av, dpT[(4 * st + g) * DPS + 16 * jt + c16], ac4[st & 3]);
+                }
                 const f32x4 acc = (ac4[0] + ac4[1]) + (ac4[2] + ac4[3]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Tl[(16 * (wave & 3) + 4 * g + r) * (JS + 1) + 16 * jt + c16] = acc[r];
@@ -645,12 +663,17 @@ __device__ __forceinline__ void q16_attention_role(const Q16Args& a, float* lds,
     if (tid < T2V_A) a.DV[((size_t)b * S + s) * T2V_A + tid] = dvacc;
 }
 
+template <bool LONG>          // the attention role on 96-position slices (T_in > Q16_T32); the other roles are the same
 __global__ __launch_bounds__(Q16_THREADS) void k_bwd_persist16(Q16Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wg = blockIdx.x;
     const int S = a.S_sl, NT = a.B * S;
 #if defined(Q16_ONLY_T)
-    if (wg < NT) { if (a.T_in <= 96) q16_attention_role<16>(a, lds, wg / S, wg % S); else q16_attention_role<32>(a, lds, wg / S, wg % S); }
+    if (wg < NT) {
+        if (LONG) q16_attention_role<96, 8>(a, lds, wg / S, wg % S);
+        else if (a.T_in <= 96) q16_attention_role<16>(a, lds, wg / S, wg % S);
+        else q16_attention_role<32>(a, lds, wg / S, wg % S);
+    }
 #elif defined(Q16_ONLY_G)
     if (wg < 48) q16_gemv_role<false>(a, lds, wg); else q16_gemv_role<true>(a, lds, wg - 48);
 #elif defined(Q16_ONLY_C)
@@ -658,7 +681,8 @@ __global__ __launch_bounds__(Q16_THREADS) void k_bwd_persist16(Q16Args a) {
 #else
     if (wg < Q16_MAXTWG) {
         if (wg >= NT) return;
-        if (a.T_in <= 96) q16_attention_role<16>(a, lds, wg / S, wg % S);
+        if (LONG) q16_attention_role<96, 8>(a, lds, wg / S, wg % S);
+        else if (a.T_in <= 96) q16_attention_role<16>(a, lds, wg / S, wg % S);
         else q16_attention_role<32>(a, lds, wg / S, wg % S);
         return;
     }
@@ -676,8 +700,9 @@ __global__ __launch_bounds__(256) void k_q16_fill(uint4* p, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = s;
 }
 
-// slices of the attention role: 16 positions up to 96 symbols, else 32 (B * S attention workgroups must fit into 96)
-static inline int q16_js(int T_in) { return T_in <= 96 ? 16 : 32; }
+// slices of the attention role: 16 positions up to 96 symbols, 32 up to 192, else 96 (B * S attention workgroups must fit into
+// 96: with at most six slices per item B = 16 always does)
+static inline int q16_js(int T_in) { return T_in <= 96 ? 16 : T_in <= Q16_T32 ? 32 : 96; }
 static inline int q16_slices(int T_in) { const int js = q16_js(T_in); return (T_in + js - 1) / js; }
 extern "C" int t2v_decoder_bwd_persist16_slices(int T_in) { return T_in < 1 ? 0 : q16_slices(T_in); }
 
@@ -685,13 +710,14 @@ extern "C" int t2v_decoder_bwd_persist16_slices(int T_in) { return T_in < 1 ? 0 
 static size_t q16_lds_bytes(int T_in) {
     const size_t grole = 2 * 8 * 8 * 64 * 4 + 4;
     const size_t crole = 128 * 16 + 2 * 64 * 16 + 4;
-    const size_t Tcap = (size_t)((T_in + 15) / 16) * 16, JS = (size_t)q16_js(T_in), NWV = 4;
-    const size_t trole = 4 * Tcap + T2V_E + JS + (1 + JS / NWV) * 4 * NWV + T2V_A * (JS + 1) + 64 * (JS + 1) + 2 * 2 * NWV * T2V_A + 40;
+    const size_t Tcap = (size_t)((T_in + 15) / 16) * 16, JS = (size_t)q16_js(T_in), NWV = JS == 96 ? 8 : 4;
+    const size_t trole = 4 * Tcap + T2V_E + JS + (1 + JS / NWV) * 4 * NWV + T2V_A * (JS == 96 ? JS + 17 : JS + 1) + 64 * (JS + 1) +
+                         2 * 2 * NWV * T2V_A + 40 + (NWV == 8 ? 64 * 132 : 0);
     size_t m = grole > crole ? grole : crole;
     m = m > trole ? m : trole;
     return sizeof(float) * m;
 }
-static int q16_device_ok(size_t lds) {
+static int q16_device_ok(size_t lds, bool lng) {
     static int cus = -1;
     if (cus < 0) {
         int dev = 0;
@@ -702,23 +728,25 @@ static int q16_device_ok(size_t lds) {
     if (cus < T2V_NWG) return 0;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_bwd_persist16, hipFuncAttributeMaxDynamicSharedMemorySize, Q16_LDS_MAX) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_bwd_persist16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Q16_LDS_MAX) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_bwd_persist16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q16_LDS_MAX) != hipSuccess) {
             (void)hipGetLastError();
             return 0;
         }
         attr_set = true;
     }
     int nblk = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)k_bwd_persist16, Q16_THREADS, lds) != hipSuccess) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, lng ? (const void*)k_bwd_persist16<true> : (const void*)k_bwd_persist16<false>,
+                                                     Q16_THREADS, lds) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
     return nblk >= 1;
 }
 extern "C" int t2v_decoder_bwd_persist16_supported(int B, int T_in) {
-    if (!(B >= 1 && B <= Q16_MAXB && T_in >= 1 && T_in <= Q16_MAXT)) return 0;
+    if (!(B >= 1 && B <= Q16_MAXB && T_in >= 1 && T_in <= Q16_MAXT_LONG)) return 0;
     if (B * q16_slices(T_in) > Q16_MAXTWG || q16_lds_bytes(T_in) > Q16_LDS_MAX) return 0;
-    return q16_device_ok(q16_lds_bytes(T_in));
+    return q16_device_ok(q16_lds_bytes(T_in), T_in > Q16_T32);
 }
 // layout of `scratch` (floats): GXA | GXD | PA | PD | GPX | DQT
 static void q16_layout(int B, int T_in, int T_out, size_t (&n)[6]) {
@@ -727,18 +755,18 @@ static void q16_layout(int B, int T_in, int T_out, size_t (&n)[6]) {
     n[1] = n[0];
     n[2] = (size_t)T_out * 4 * 16 * Q16_NCOLA;
     n[3] = (size_t)T_out * 4 * 16 * Q16_NCOLD;
-    n[4] = (size_t)T_out * B * S * 2 * 64;
+    n[4] = (size_t)T_out * B * S * 2 * (q16_js(T_in) + 30 <= 64 ? 64 : 128);
     n[5] = (size_t)T_out * 16 * T2V_A;
 }
 extern "C" long t2v_decoder_bwd_persist16_scratch_floats(int B, int T_in, int T_out) {
-    if (B < 1 || B > Q16_MAXB || T_in < 1 || T_in > Q16_MAXT || T_out < 1) return 0;
+    if (B < 1 || B > Q16_MAXB || T_in < 1 || T_in > Q16_MAXT_LONG || T_out < 1) return 0;
     size_t n[6];
     q16_layout(B, T_in, T_out, n);
     return (long)(n[0] + n[1] + n[2] + n[3] + n[4] + n[5]);
 }
 // float offset, inside `scratch`, of dq(t) summed over the position slices — (T_out, 16, 128), rows of items >= B unused
 extern "C" long t2v_decoder_bwd_persist16_dq_offset(int B, int T_in, int T_out) {
-    if (B < 1 || B > Q16_MAXB || T_in < 1 || T_in > Q16_MAXT || T_out < 1) return -1;
+    if (B < 1 || B > Q16_MAXB || T_in < 1 || T_in > Q16_MAXT_LONG || T_out < 1) return -1;
     size_t n[6];
     q16_layout(B, T_in, T_out, n);
     return (long)(n[0] + n[1] + n[2] + n[3] + n[4]);
@@ -809,7 +837,8 @@ static int q16_run(const t2v_dec_train_persist_weights* w, const t2v_dec_train_b
     a.B = B; a.T_in = T_in; a.T = T_out; a.S_sl = S; a.p_att = p_att; a.p_dec = p_dec; a.seed = seed;
     a.step = t2v_step_for(stream);
     a.prof = g_t2v_prof;
-    k_bwd_persist16<<<T2V_NWG, Q16_THREADS, q16_lds_bytes(T_in), stream>>>(a);
+    if (T_in > Q16_T32) k_bwd_persist16<true><<<T2V_NWG, Q16_THREADS, q16_lds_bytes(T_in), stream>>>(a);
+    else k_bwd_persist16<false><<<T2V_NWG, Q16_THREADS, q16_lds_bytes(T_in), stream>>>(a);
     return t2v_check_launch();
 }
 

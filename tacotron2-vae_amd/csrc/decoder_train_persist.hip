@@ -22,12 +22,15 @@
 // value on the wire instead of an 8-byte {value, tag} granule, 16-byte loads, no memory ordering needed (MI355X guide
 // G16 form R2 with an implicit tag).  The partial energies of the 8 attention slices of an item travel the same way (EX).
 // The backward pass reads the usual arena (XS, CA, CD, GA, GD, AL, ACUM, S), written here with plain stores.
+#include <stdlib.h>
 #include "t2v_common.h"
 #include "t2v_kernels.h"
 
 #define PT_THREADS 512
 #define PT_MAXB 6
-#define PT_MAXT 224
+#define PT_MAXT 224                  // LDS-resident W_q / processed-memory slices up to here
+#define PT_MAXT_LONG 560             // register-resident ones beyond (k_dec_train_persist<.., true>)
+#define PT_NTI_LONG 5                // 16-position tiles per wave of the long form: 8 waves x 5 x 16 = 640 >= 560
 #define PT_MAXU 5
 #define PT_SPIN 1500000u
 #define PT_SENT 0xFFFFFFFFu
@@ -316,7 +319,11 @@ __device__ __forceinline__ void pt_reduce_store(const PTAcc<NB>& acc, float* red
     *(float2*)(red + (g * 8 + part) * 32 + 2 * (lane & 15)) = make_float2(w2[0], w2[1]);
 }
 
-template <int NB>      // 4: B <= 4 (one item plane), 6: B = 5, 6 (two planes)
+// NB — 4: B <= 4 (one item plane), 6: B = 5, 6 (two planes).  LONG — the attention role for 224 < T_in <= 560 (koemo's longest
+// sentence has 555 symbols): the W_q slice and the processed-memory slice move from LDS into registers (32 + 20 per thread: an
+// attention workgroup holds no LSTM weights), which leaves the 160 KB to the memory slice (560 x 64 floats = 140 KB); five
+// position tiles per wave instead of two, two positions per thread in the softmax.
+template <int NB, bool LONG>
 __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
     constexpr int NP = NB > 4 ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -508,11 +515,13 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
 
     // =============================================================================== T role: attention slice (b, s)
     const int ab = wg >> 3, as = wg & 7;
+    constexpr int NTI = LONG ? PT_NTI_LONG : 2;          // position tiles per wave: tile jt = wave + 8 i
+    constexpr int NPP = LONG ? 2 : 1;                    // positions per thread in the softmax: tid + 512 u
     const int TW = Tcap + 32;
-    float* wq_s = lds;                                   // [16][1028]
-    float* mem_s = wq_s + 16 * 1028;                     // [Tcap][64]
-    float* pm_s = mem_s + Tcap * 64;                     // [Tcap][16]
-    float* win = pm_s + Tcap * 16;                       // [2][TW]: alignment window, index x <-> position x - 15
+    float* wq_s = lds;                                   // [16][1028]   (LONG: in registers)
+    float* mem_s = wq_s + (LONG ? 0 : 16 * 1028);        // [Tcap][64]
+    float* pm_s = mem_s + Tcap * 64;                     // [Tcap][16]   (LONG: in registers)
+    float* win = pm_s + (LONG ? 0 : Tcap * 16);          // [2][TW]: alignment window, index x <-> position x - 15
     float* eall = win + 2 * TW;                          // [Tcap]
     float* hx = eall + Tcap;                             // [1024] h_att(t) of this item
     float* qv = hx + T2V_H;                              // [16]
@@ -522,9 +531,24 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
     float* rss = rsm + 32;                               // [32]
     int* flag = (int*)(rss + 32);
     const int g = lane >> 4, c16 = lane & 15;
-    for (int i = tid; i < 16 * 1024; i += PT_THREADS) wq_s[(i >> 10) * 1028 + (i & 1023)] = a.wq[(size_t)(16 * as) * 1024 + i];
+    float4 wqr[LONG ? 8 : 1], pmr[LONG ? NTI : 1];
+    if constexpr (LONG) {
+        // the operands of a thread's own part of the query product (dim tid >> 5, k = 4 (tid & 31) + 128 i) and of its tiles'
+        // energies (position 16 jt + c16, dims 16 as + 4 g ..) never change over the pass
+        const float* wrow = a.wq + (size_t)(16 * as + (tid >> 5)) * 1024 + 4 * (tid & 31);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wqr[i] = *(const float4*)(wrow + 128 * i);
+#pragma unroll
+        for (int i = 0; i < NTI; ++i) {
+            const int jp = 16 * (wave + 8 * i) + c16;
+            pmr[i] = *(const float4*)(a.pm + ((size_t)ab * Tp + min(jp, Tp - 1)) * T2V_A + 16 * as + 4 * g);
+        }
+    } else {
+        for (int i = tid; i < 16 * 1024; i += PT_THREADS) wq_s[(i >> 10) * 1028 + (i & 1023)] = a.wq[(size_t)(16 * as) * 1024 + i];
+    }
     for (int i = tid; i < Tp * 64; i += PT_THREADS) mem_s[i] = a.memory[((size_t)ab * Tp + (i >> 6)) * T2V_E + 64 * as + (i & 63)];
-    for (int i = tid; i < Tp * 16; i += PT_THREADS) pm_s[i] = a.pm[((size_t)ab * Tp + (i >> 4)) * T2V_A + 16 * as + (i & 15)];
+    if constexpr (!LONG)
+        for (int i = tid; i < Tp * 16; i += PT_THREADS) pm_s[i] = a.pm[((size_t)ab * Tp + (i >> 4)) * T2V_A + 16 * as + (i & 15)];
     for (int i = tid; i < 2 * TW; i += PT_THREADS) win[i] = 0.f;
     if (tid == 0) flag[0] = 1;
     float areg[16];
@@ -547,9 +571,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
         PT_STAMP(wg == 0 && t == T / 2, 8);
         // ---- location features of this step's tiles (fused filter, K = 64): they depend on alpha(t-1) only, so they
         // are evaluated BEFORE h_att(t) arrives (wave -> tiles wave, wave + 8)
-        f32x4 lacc[2];
+        f32x4 lacc[NTI];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NTI; ++i) {
             const int jt = wave + 8 * i;
             lacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (16 * jt < Tp) {
@@ -603,7 +627,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
             float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float4 w4 = *(const float4*)(wrow + 128 * i);
+                const float4 w4 = LONG ? wqr[LONG ? i : 0] : *(const float4*)(wrow + 128 * i);
                 const float4 h4 = *(const float4*)(hp + 128 * i);
                 acc0 = fmaf(w4.x, h4.x, acc0); acc1 = fmaf(w4.y, h4.y, acc1);
                 acc0 = fmaf(w4.z, h4.z, acc0); acc1 = fmaf(w4.w, h4.w, acc1);
@@ -618,12 +642,12 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
         // ---- partial energies of this slice
         const unsigned exw = (unsigned)(((t * B + ab) * 8 + as) * Tcap) * 4u;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NTI; ++i) {
             const int jt = wave + 8 * i;
             if (16 * jt < Tp) {
                 const f32x4 acc = lacc[i];
                 const int jp = 16 * jt + c16;
-                const float4 pm4 = *(const float4*)(pm_s + min(jp, Tp - 1) * 16 + 4 * g);
+                const float4 pm4 = LONG ? pmr[LONG ? i : 0] : *(const float4*)(pm_s + min(jp, Tp - 1) * 16 + 4 * g);
                 float4 sv;
                 sv.x = tanhf_(q4.x + acc[0] + pm4.x); sv.y = tanhf_(q4.y + acc[1] + pm4.y);
                 sv.z = tanhf_(q4.z + acc[2] + pm4.z); sv.w = tanhf_(q4.w + acc[3] + pm4.w);
@@ -635,69 +659,161 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
             }
         }
         PT_STAMP(wg == 0 && t == T / 2, 10);
-        // ---- the 8 partials of every position (fixed order), masked softmax
-        float ev0 = -INFINITY;
-        if (tid < Tp) {
-            const unsigned e0 = (unsigned)((t * B + ab) * 8 * Tcap + tid) * 4u;
-            unsigned p[8];
-            unsigned spins = 0;
-            for (;;) {
-                bool ok = true;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    p[i] = pt_ld4(rE, e0 + (unsigned)(i * Tcap) * 4u);
-                    ok = ok && p[i] != PT_SENT;
+        // (two copies of the softmax: the one-position form is kept word for word so that the short kernels keep their instruction
+        // stream — round 6 checked the ISA of <.., false> against the previous build, identical)
+        if constexpr (!LONG) {
+            // ---- the 8 partials of every position (fixed order), masked softmax
+            float ev0 = -INFINITY;
+            if (tid < Tp) {
+                const unsigned e0 = (unsigned)((t * B + ab) * 8 * Tcap + tid) * 4u;
+                unsigned p[8];
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+    #pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        p[i] = pt_ld4(rE, e0 + (unsigned)(i * Tcap) * 4u);
+                        ok = ok && p[i] != PT_SENT;
+                    }
+                    if (ok) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > PT_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        flag[0] = 0;
+                        break;
+                    }
                 }
-                if (ok) break;
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > PT_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    flag[0] = 0;
-                    break;
+                const float ev = ((__uint_as_float(p[0]) + __uint_as_float(p[1])) + (__uint_as_float(p[2]) + __uint_as_float(p[3]))) +
+                                 ((__uint_as_float(p[4]) + __uint_as_float(p[5])) + (__uint_as_float(p[6]) + __uint_as_float(p[7])));
+                ev0 = tid < len ? ev : -INFINITY;
+            }
+            PT_STAMP(wg == 0 && t == T / 2, 14);
+            {
+                float mloc = ev0;
+                mloc = T2V_DPP_MAX(mloc, 0xB1); mloc = T2V_DPP_MAX(mloc, 0x4E);
+                mloc = T2V_DPP_MAX(mloc, 0x141); mloc = T2V_DPP_MAX(mloc, 0x140);
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                if (lane == 0) rsm[wave] = mloc;
+            }
+            __syncthreads();
+            if (flag[0] != 1) return;
+            float m;
+            {
+                const float4 a0 = *(const float4*)rsm, a1 = *(const float4*)(rsm + 4);
+                m = fmaxf(fmaxf(fmaxf(a0.x, a0.y), fmaxf(a0.z, a0.w)), fmaxf(fmaxf(a1.x, a1.y), fmaxf(a1.z, a1.w)));
+            }
+            const float e0v = tid < Tp ? expf(ev0 - m) : 0.f;
+            {
+                float sloc = row16_sum(e0v);
+                sloc += __shfl_xor(sloc, 16, 64);
+                sloc += __shfl_xor(sloc, 32, 64);
+                if (lane == 0) rss[wave] = sloc;
+            }
+            __syncthreads();
+            float ssum;
+            {
+                const float4 a0 = *(const float4*)rss, a1 = *(const float4*)(rss + 4);
+                ssum = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
+            }
+            const float al = e0v * (1.0f / ssum);
+            if (tid < Tp) {
+                eall[tid] = al;
+                win[15 + tid] = al;                                        // previous weights of the next step
+                const float cum = win[TW + 15 + tid] + al;                 // cumulative weights
+                win[TW + 15 + tid] = cum;
+                if (as == 0) {
+                    a.AL[((size_t)(t + 1) * B + ab) * Tp + tid] = al;
+                    a.ACUM[((size_t)(t + 1) * B + ab) * Tp + tid] = cum;
                 }
             }
-            const float ev = ((__uint_as_float(p[0]) + __uint_as_float(p[1])) + (__uint_as_float(p[2]) + __uint_as_float(p[3]))) +
-                             ((__uint_as_float(p[4]) + __uint_as_float(p[5])) + (__uint_as_float(p[6]) + __uint_as_float(p[7])));
-            ev0 = tid < len ? ev : -INFINITY;
-        }
-        PT_STAMP(wg == 0 && t == T / 2, 14);
-        {
-            float mloc = ev0;
-            mloc = T2V_DPP_MAX(mloc, 0xB1); mloc = T2V_DPP_MAX(mloc, 0x4E);
-            mloc = T2V_DPP_MAX(mloc, 0x141); mloc = T2V_DPP_MAX(mloc, 0x140);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            if (lane == 0) rsm[wave] = mloc;
-        }
-        __syncthreads();
-        if (flag[0] != 1) return;
-        float m;
-        {
-            const float4 a0 = *(const float4*)rsm, a1 = *(const float4*)(rsm + 4);
-            m = fmaxf(fmaxf(fmaxf(a0.x, a0.y), fmaxf(a0.z, a0.w)), fmaxf(fmaxf(a1.x, a1.y), fmaxf(a1.z, a1.w)));
-        }
-        const float e0v = tid < Tp ? expf(ev0 - m) : 0.f;
-        {
-            float sloc = row16_sum(e0v);
-            sloc += __shfl_xor(sloc, 16, 64);
-            sloc += __shfl_xor(sloc, 32, 64);
-            if (lane == 0) rss[wave] = sloc;
-        }
-        __syncthreads();
-        float ssum;
-        {
-            const float4 a0 = *(const float4*)rss, a1 = *(const float4*)(rss + 4);
-            ssum = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
-        }
-        const float al = e0v * (1.0f / ssum);
-        if (tid < Tp) {
-            eall[tid] = al;
-            win[15 + tid] = al;                                        // previous weights of the next step
-            const float cum = win[TW + 15 + tid] + al;                 // cumulative weights
-            win[TW + 15 + tid] = cum;
-            if (as == 0) {
-                a.AL[((size_t)(t + 1) * B + ab) * Tp + tid] = al;
-                a.ACUM[((size_t)(t + 1) * B + ab) * Tp + tid] = cum;
+        } else {
+            // ---- the 8 partials of every position (fixed order), masked softmax; thread -> positions tid + 512 u
+            float ev0[NPP];
+    #pragma unroll
+            for (int u = 0; u < NPP; ++u) ev0[u] = -INFINITY;
+            if (tid < Tp) {
+                const unsigned e0 = (unsigned)((t * B + ab) * 8 * Tcap + tid) * 4u;
+                unsigned p[NPP][8];
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+    #pragma unroll
+                    for (int u = 0; u < NPP; ++u) {
+                        // (a second position past the end re-reads the first one's words: no branch around the loads)
+                        const unsigned eu = e0 + ((u > 0 && tid + PT_THREADS * u < Tp) ? (unsigned)(PT_THREADS * u) * 4u : 0u);
+    #pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            p[u][i] = pt_ld4(rE, eu + (unsigned)(i * Tcap) * 4u);
+                            ok = ok && p[u][i] != PT_SENT;
+                        }
+                    }
+                    if (ok) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > PT_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        flag[0] = 0;
+                        break;
+                    }
+                }
+    #pragma unroll
+                for (int u = 0; u < NPP; ++u) {
+                    const float ev = ((__uint_as_float(p[u][0]) + __uint_as_float(p[u][1])) + (__uint_as_float(p[u][2]) + __uint_as_float(p[u][3]))) +
+                                     ((__uint_as_float(p[u][4]) + __uint_as_float(p[u][5])) + (__uint_as_float(p[u][6]) + __uint_as_float(p[u][7])));
+                    ev0[u] = tid + PT_THREADS * u < len ? ev : -INFINITY;
+                }
+            }
+            PT_STAMP(wg == 0 && t == T / 2, 14);
+            {
+                float mloc = ev0[0];
+    #pragma unroll
+                for (int u = 1; u < NPP; ++u) mloc = fmaxf(mloc, ev0[u]);
+                mloc = T2V_DPP_MAX(mloc, 0xB1); mloc = T2V_DPP_MAX(mloc, 0x4E);
+                mloc = T2V_DPP_MAX(mloc, 0x141); mloc = T2V_DPP_MAX(mloc, 0x140);
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                if (lane == 0) rsm[wave] = mloc;
+            }
+            __syncthreads();
+            if (flag[0] != 1) return;
+            float m;
+            {
+                const float4 a0 = *(const float4*)rsm, a1 = *(const float4*)(rsm + 4);
+                m = fmaxf(fmaxf(fmaxf(a0.x, a0.y), fmaxf(a0.z, a0.w)), fmaxf(fmaxf(a1.x, a1.y), fmaxf(a1.z, a1.w)));
+            }
+            float e0v[NPP];
+    #pragma unroll
+            for (int u = 0; u < NPP; ++u) e0v[u] = tid + PT_THREADS * u < Tp ? expf(ev0[u] - m) : 0.f;
+            {
+                float sloc = e0v[0];
+    #pragma unroll
+                for (int u = 1; u < NPP; ++u) sloc += e0v[u];
+                sloc = row16_sum(sloc);
+                sloc += __shfl_xor(sloc, 16, 64);
+                sloc += __shfl_xor(sloc, 32, 64);
+                if (lane == 0) rss[wave] = sloc;
+            }
+            __syncthreads();
+            float ssum;
+            {
+                const float4 a0 = *(const float4*)rss, a1 = *(const float4*)(rss + 4);
+                ssum = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
+            }
+            const float rinv = 1.0f / ssum;
+    #pragma unroll
+            for (int u = 0; u < NPP; ++u) {
+                const int pos = tid + PT_THREADS * u;
+                const float al = e0v[u] * rinv;
+                if (pos < Tp) {
+                    eall[pos] = al;
+                    win[15 + pos] = al;                                        // previous weights of the next step
+                    const float cum = win[TW + 15 + pos] + al;                 // cumulative weights
+                    win[TW + 15 + pos] = cum;
+                    if (as == 0) {
+                        a.AL[((size_t)(t + 1) * B + ab) * Tp + pos] = al;
+                        a.ACUM[((size_t)(t + 1) * B + ab) * Tp + pos] = cum;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -728,18 +844,28 @@ __global__ __launch_bounds__(256) void k_pt_fill(uint4* p, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = s;
 }
 
+// the long form of the attention role: beyond PT_MAXT symbols (T2V_PT_LONG=1: for every length — a measurement switch)
+static bool pt_long(int T_in) {
+    static const int forced = [] { const char* e = getenv("T2V_PT_LONG"); return e && e[0] == '1' ? 1 : 0; }();
+    return T_in > PT_MAXT || forced;
+}
 static size_t pt_lds_bytes(int B, int T_in) {
     const size_t Tcap = (size_t)((T_in + 15) / 16) * 16;
     const size_t np = B > 4 ? 2 : 1;
     const size_t lrole = np * T2V_XW * 4 + 4 * 8 * 32 + 6 * 32 + 4;
-    const size_t trole = 16 * 1028 + Tcap * 64 + Tcap * 16 + 2 * (Tcap + 32) + Tcap + T2V_H + 16 + 32 * 16 + 8 * 64 + 64 + 4;
+    const size_t resident = pt_long(T_in) ? Tcap * 64 : 16 * 1028 + Tcap * 64 + Tcap * 16;      // LONG: W_q / processed memory in registers
+    const size_t trole = resident + 2 * (Tcap + 32) + Tcap + T2V_H + 16 + 32 * 16 + 8 * 64 + 64 + 4;
     return sizeof(float) * (lrole > trole ? lrole : trole);
 }
 #define PT_LDS_MAX (160 * 1024)
 static size_t pt_g_floats(int B, int T_out) { return (size_t)(T_out + 2) * (B > 4 ? 2 : 1) * T2V_XW * 4; }
 static size_t pt_ex_floats(int B, int T_in, int T_out) { return (size_t)T_out * B * 8 * t2v_tcap(T_in); }
 
-static int pt_device_ok(int B, size_t lds) {
+static const void* pt_kernel(int B, int T_in) {
+    if (pt_long(T_in)) return B > 4 ? (const void*)k_dec_train_persist<6, true> : (const void*)k_dec_train_persist<4, true>;
+    return B > 4 ? (const void*)k_dec_train_persist<6, false> : (const void*)k_dec_train_persist<4, false>;
+}
+static int pt_device_ok(int B, int T_in, size_t lds) {
     static int cus = -1;
     if (cus < 0) {
         int dev = 0;
@@ -750,22 +876,22 @@ static int pt_device_ok(int B, size_t lds) {
     if (cus < T2V_NWG) return 0;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_dec_train_persist<4>, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_MAX) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_dec_train_persist<6>, hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_MAX) != hipSuccess) {
-            (void)hipGetLastError();
-            return 0;
-        }
+        for (int b = 4; b <= 6; b += 2)
+            for (int tin = PT_MAXT; tin <= PT_MAXT + 1; ++tin)
+                if (hipFuncSetAttribute(pt_kernel(b, tin), hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_MAX) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return 0;
+                }
         attr_set = true;
     }
     int nblk = 0;
-    const void* fn = B > 4 ? (const void*)k_dec_train_persist<6> : (const void*)k_dec_train_persist<4>;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, fn, PT_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, pt_kernel(B, T_in), PT_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return nblk >= 1;
 }
 
 extern "C" int t2v_decoder_train_persist_supported(int B, int T_in) {
-    if (!(B >= 1 && B <= PT_MAXB && T_in >= 1 && T_in <= PT_MAXT && pt_lds_bytes(B, T_in) <= PT_LDS_MAX)) return 0;
-    return pt_device_ok(B, pt_lds_bytes(B, T_in));
+    if (!(B >= 1 && B <= PT_MAXB && T_in >= 1 && T_in <= PT_MAXT_LONG && pt_lds_bytes(B, T_in) <= PT_LDS_MAX)) return 0;
+    return pt_device_ok(B, T_in, pt_lds_bytes(B, T_in));
 }
 extern "C" long t2v_decoder_train_persist_scratch_floats(int B, int T_in, int T_out) {
     if (B < 1 || B > PT_MAXB || T_in < 1 || T_out < 1) return 0;
@@ -805,7 +931,12 @@ extern "C" int t2v_decoder_train_fwd_persistent(const t2v_dec_train_persist_weig
     a.step = t2v_step_for(stream);
     a.prof = g_t2v_prof;
     const size_t lds = pt_lds_bytes(B, T_in);
-    if (B > 4) k_dec_train_persist<6><<<T2V_NWG, PT_THREADS, lds, stream>>>(a);
-    else k_dec_train_persist<4><<<T2V_NWG, PT_THREADS, lds, stream>>>(a);
+    if (pt_long(T_in)) {
+        if (B > 4) k_dec_train_persist<6, true><<<T2V_NWG, PT_THREADS, lds, stream>>>(a);
+        else k_dec_train_persist<4, true><<<T2V_NWG, PT_THREADS, lds, stream>>>(a);
+    } else {
+        if (B > 4) k_dec_train_persist<6, false><<<T2V_NWG, PT_THREADS, lds, stream>>>(a);
+        else k_dec_train_persist<4, false><<<T2V_NWG, PT_THREADS, lds, stream>>>(a);
+    }
     return t2v_check_launch();
 }

@@ -40,7 +40,9 @@
 
 #define P16_THREADS 512
 #define P16_MAXB 16
-#define P16_MAXT 224
+#define P16_MAXT 224                 // LDS-resident W_q / processed-memory slices up to here
+#define P16_MAXT_LONG 560            // register-resident ones beyond (k_dec_train_persist16<true>; decoder_train_persist.hip has the arithmetic)
+#define P16_NTI_LONG 5               // 16-position tiles per wave of the long form
 #define P16_NL 128
 #define P16_L0 (T2V_NWG - P16_NL)
 #define P16_SPIN 1500000u
@@ -132,6 +134,7 @@ __device__ __forceinline__ p16_u32x4 p16_wload(const float* p) {
     return p16_u32x4{u.x, u.y, u.z, u.w};
 }
 
+template <bool LONG>          // the attention role for 224 < T_in <= 560, as in k_dec_train_persist<.., true>
 __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const uint64_t seed = t2v_step_seed(a.seed, a.step);
@@ -334,11 +337,13 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
 
     // =============================================================================== T role: attention slice (b, s)
     const int ab = wg >> 3, as = wg & 7;
+    constexpr int NTI = LONG ? P16_NTI_LONG : 2;         // position tiles per wave: tile jt = wave + 8 i
+    constexpr int NPP = LONG ? 2 : 1;                    // positions per thread in the softmax: tid + 512 u
     const int TW = Tcap + 32;
-    float* wq_s = lds;                                   // [16][1028]
-    float* mem_s = wq_s + 16 * 1028;                     // [Tcap][64]
-    float* pm_s = mem_s + Tcap * 64;                     // [Tcap][16]
-    float* win = pm_s + Tcap * 16;                       // [2][TW]: alignment window, index x <-> position x - 15
+    float* wq_s = lds;                                   // [16][1028]   (LONG: in registers)
+    float* mem_s = wq_s + (LONG ? 0 : 16 * 1028);        // [Tcap][64]
+    float* pm_s = mem_s + Tcap * 64;                     // [Tcap][16]   (LONG: in registers)
+    float* win = pm_s + (LONG ? 0 : Tcap * 16);          // [2][TW]: alignment window, index x <-> position x - 15
     float* eall = win + 2 * TW;                          // [Tcap]
     float* hx = eall + Tcap;                             // [1024] h_att(t) of this item
     float* qv = hx + T2V_H;                              // [16]
@@ -349,9 +354,22 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
     float* cfin = rss + 32;                              // [64] finished context columns (wave 0)
     int* flag = (int*)(cfin + 64);
     const int g = lane >> 4, c16 = lane & 15;
-    for (int i = tid; i < 16 * 1024; i += P16_THREADS) wq_s[(i >> 10) * 1028 + (i & 1023)] = a.wq[(size_t)(16 * as) * 1024 + i];
+    float4 wqr[LONG ? 8 : 1], pmr[LONG ? NTI : 1];
+    if constexpr (LONG) {
+        const float* wrow = a.wq + (size_t)(16 * as + (tid >> 5)) * 1024 + 4 * (tid & 31);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wqr[i] = *(const float4*)(wrow + 128 * i);
+#pragma unroll
+        for (int i = 0; i < NTI; ++i) {
+            const int jp = 16 * (wave + 8 * i) + c16;
+            pmr[i] = *(const float4*)(a.pm + ((size_t)ab * Tp + min(jp, Tp - 1)) * T2V_A + 16 * as + 4 * g);
+        }
+    } else {
+        for (int i = tid; i < 16 * 1024; i += P16_THREADS) wq_s[(i >> 10) * 1028 + (i & 1023)] = a.wq[(size_t)(16 * as) * 1024 + i];
+    }
     for (int i = tid; i < Tp * 64; i += P16_THREADS) mem_s[i] = a.memory[((size_t)ab * Tp + (i >> 6)) * T2V_E + 64 * as + (i & 63)];
-    for (int i = tid; i < Tp * 16; i += P16_THREADS) pm_s[i] = a.pm[((size_t)ab * Tp + (i >> 4)) * T2V_A + 16 * as + (i & 15)];
+    if constexpr (!LONG)
+        for (int i = tid; i < Tp * 16; i += P16_THREADS) pm_s[i] = a.pm[((size_t)ab * Tp + (i >> 4)) * T2V_A + 16 * as + (i & 15)];
     for (int i = tid; i < 2 * TW; i += P16_THREADS) win[i] = 0.f;
     if (tid == 0) flag[0] = 1;
     float areg[16];
@@ -373,9 +391,9 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
         P16_STAMP(wg == 0 && wave == 0 && t == T / 2, 8);
         P16_RT(0);
         // ---- location features of this step's tiles (fused filter, K = 64): they depend on alpha(t-1) only
-        f32x4 lacc[2];
+        f32x4 lacc[NTI];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NTI; ++i) {
             const int jt = wave + 8 * i;
             lacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (16 * jt < Tp) {
@@ -427,7 +445,7 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
             float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float4 w4 = *(const float4*)(wrow + 128 * i);
+                const float4 w4 = LONG ? wqr[LONG ? i : 0] : *(const float4*)(wrow + 128 * i);
                 const float4 h4 = *(const float4*)(hp + 128 * i);
                 acc0 = fmaf(w4.x, h4.x, acc0); acc1 = fmaf(w4.y, h4.y, acc1);
                 acc0 = fmaf(w4.z, h4.z, acc0); acc1 = fmaf(w4.w, h4.w, acc1);
@@ -441,12 +459,12 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
         // ---- partial energies of this slice
         const unsigned exw = (unsigned)(((t * B + ab) * 8 + as) * Tcap) * 4u;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NTI; ++i) {
             const int jt = wave + 8 * i;
             if (16 * jt < Tp) {
                 const f32x4 acc = lacc[i];
                 const int jp = 16 * jt + c16;
-                const float4 pm4 = *(const float4*)(pm_s + min(jp, Tp - 1) * 16 + 4 * g);
+                const float4 pm4 = LONG ? pmr[LONG ? i : 0] : *(const float4*)(pm_s + min(jp, Tp - 1) * 16 + 4 * g);
                 float4 sv;
                 sv.x = tanhf_(q4.x + acc[0] + pm4.x); sv.y = tanhf_(q4.y + acc[1] + pm4.y);
                 sv.z = tanhf_(q4.z + acc[2] + pm4.z); sv.w = tanhf_(q4.w + acc[3] + pm4.w);
@@ -459,69 +477,161 @@ __global__ __launch_bounds__(P16_THREADS) void k_dec_train_persist16(P16Args a) 
         }
         P16_STAMP(wg == 0 && wave == 0 && t == T / 2, 10);
         P16_RT(2);
-        // ---- the 8 partials of every position (fixed order), masked softmax
-        float ev0 = -INFINITY;
-        if (tid < Tp) {
-            const unsigned e0 = (unsigned)((t * B + ab) * 8 * Tcap + tid) * 4u;
-            unsigned p[8];
-            unsigned spins = 0;
-            for (;;) {
-                bool ok = true;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    p[i] = p16_ld4(rE, e0 + (unsigned)(i * Tcap) * 4u);
-                    ok = ok && p[i] != P16_SENT;
+        // (two copies of the softmax: the one-position form is kept word for word so that the short kernels keep their instruction
+        // stream — round 6 checked the ISA of <.., false> against the previous build, identical)
+        if constexpr (!LONG) {
+            // ---- the 8 partials of every position (fixed order), masked softmax
+            float ev0 = -INFINITY;
+            if (tid < Tp) {
+                const unsigned e0 = (unsigned)((t * B + ab) * 8 * Tcap + tid) * 4u;
+                unsigned p[8];
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+    #pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        p[i] = p16_ld4(rE, e0 + (unsigned)(i * Tcap) * 4u);
+                        ok = ok && p[i] != P16_SENT;
+                    }
+                    if (ok) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > P16_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        flag[0] = 0;
+                        break;
+                    }
                 }
-                if (ok) break;
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > P16_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    flag[0] = 0;
-                    break;
+                const float ev = ((__uint_as_float(p[0]) + __uint_as_float(p[1])) + (__uint_as_float(p[2]) + __uint_as_float(p[3]))) +
+                                 ((__uint_as_float(p[4]) + __uint_as_float(p[5])) + (__uint_as_float(p[6]) + __uint_as_float(p[7])));
+                ev0 = tid < len ? ev : -INFINITY;
+            }
+            P16_RT(3);
+            {
+                float mloc = ev0;
+                mloc = T2V_DPP_MAX(mloc, 0xB1); mloc = T2V_DPP_MAX(mloc, 0x4E);
+                mloc = T2V_DPP_MAX(mloc, 0x141); mloc = T2V_DPP_MAX(mloc, 0x140);
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                if (lane == 0) rsm[wave] = mloc;
+            }
+            __syncthreads();
+            if (flag[0] != 1) return;
+            float m;
+            {
+                const float4 a0 = *(const float4*)rsm, a1 = *(const float4*)(rsm + 4);
+                m = fmaxf(fmaxf(fmaxf(a0.x, a0.y), fmaxf(a0.z, a0.w)), fmaxf(fmaxf(a1.x, a1.y), fmaxf(a1.z, a1.w)));
+            }
+            const float e0v = tid < Tp ? expf(ev0 - m) : 0.f;
+            {
+                float sloc = row16_sum(e0v);
+                sloc += __shfl_xor(sloc, 16, 64);
+                sloc += __shfl_xor(sloc, 32, 64);
+                if (lane == 0) rss[wave] = sloc;
+            }
+            __syncthreads();
+            float ssum;
+            {
+                const float4 a0 = *(const float4*)rss, a1 = *(const float4*)(rss + 4);
+                ssum = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
+            }
+            const float al = e0v * (1.0f / ssum);
+            if (tid < Tp) {
+                eall[tid] = al;
+                win[15 + tid] = al;                                        // previous weights of the next step
+                const float cum = win[TW + 15 + tid] + al;                 // cumulative weights
+                win[TW + 15 + tid] = cum;
+                if (as == 0) {
+                    a.AL[((size_t)(t + 1) * B + ab) * Tp + tid] = al;
+                    a.ACUM[((size_t)(t + 1) * B + ab) * Tp + tid] = cum;
                 }
             }
-            const float ev = ((__uint_as_float(p[0]) + __uint_as_float(p[1])) + (__uint_as_float(p[2]) + __uint_as_float(p[3]))) +
-                             ((__uint_as_float(p[4]) + __uint_as_float(p[5])) + (__uint_as_float(p[6]) + __uint_as_float(p[7])));
-            ev0 = tid < len ? ev : -INFINITY;
-        }
-        P16_RT(3);
-        {
-            float mloc = ev0;
-            mloc = T2V_DPP_MAX(mloc, 0xB1); mloc = T2V_DPP_MAX(mloc, 0x4E);
-            mloc = T2V_DPP_MAX(mloc, 0x141); mloc = T2V_DPP_MAX(mloc, 0x140);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            if (lane == 0) rsm[wave] = mloc;
-        }
-        __syncthreads();
-        if (flag[0] != 1) return;
-        float m;
-        {
-            const float4 a0 = *(const float4*)rsm, a1 = *(const float4*)(rsm + 4);
-            m = fmaxf(fmaxf(fmaxf(a0.x, a0.y), fmaxf(a0.z, a0.w)), fmaxf(fmaxf(a1.x, a1.y), fmaxf(a1.z, a1.w)));
-        }
-        const float e0v = tid < Tp ? expf(ev0 - m) : 0.f;
-        {
-            float sloc = row16_sum(e0v);
-            sloc += __shfl_xor(sloc, 16, 64);
-            sloc += __shfl_xor(sloc, 32, 64);
-            if (lane == 0) rss[wave] = sloc;
-        }
-        __syncthreads();
-        float ssum;
-        {
-            const float4 a0 = *(const float4*)rss, a1 = *(const float4*)(rss + 4);
-            ssum = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
-        }
-        const float al = e0v * (1.0f / ssum);
-        if (tid < Tp) {
-            eall[tid] = al;
-            win[15 + tid] = al;                                        // previous weights of the next step
-            const float cum = win[TW + 15 + tid] + al;                 // cumulative weights
-            win[TW + 15 + tid] = cum;
-            if (as == 0) {
-                a.AL[((size_t)(t + 1) * B + ab) * Tp + tid] = al;
-                a.ACUM[((size_t)(t + 1) * B + ab) * Tp + tid] = cum;
+        } else {
+            // ---- the 8 partials of every position (fixed order), masked softmax; thread -> positions tid + 512 u
+            float ev0[NPP];
+    #pragma unroll
+            for (int u = 0; u < NPP; ++u) ev0[u] = -INFINITY;
+            if (tid < Tp) {
+                const unsigned e0 = (unsigned)((t * B + ab) * 8 * Tcap + tid) * 4u;
+                unsigned p[NPP][8];
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+    #pragma unroll
+                    for (int u = 0; u < NPP; ++u) {
+                        // (a second position past the end re-reads the first one's words: no branch around the loads)
+                        const unsigned eu = e0 + ((u > 0 && tid + P16_THREADS * u < Tp) ? (unsigned)(P16_THREADS * u) * 4u : 0u);
+    #pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            p[u][i] = p16_ld4(rE, eu + (unsigned)(i * Tcap) * 4u);
+                            ok = ok && p[u][i] != P16_SENT;
+                        }
+                    }
+                    if (ok) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > P16_SPIN || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        flag[0] = 0;
+                        break;
+                    }
+                }
+    #pragma unroll
+                for (int u = 0; u < NPP; ++u) {
+                    const float ev = ((__uint_as_float(p[u][0]) + __uint_as_float(p[u][1])) + (__uint_as_float(p[u][2]) + __uint_as_float(p[u][3]))) +
+                                     ((__uint_as_float(p[u][4]) + __uint_as_float(p[u][5])) + (__uint_as_float(p[u][6]) + __uint_as_float(p[u][7])));
+                    ev0[u] = tid + P16_THREADS * u < len ? ev : -INFINITY;
+                }
+            }
+            P16_RT(3);
+            {
+                float mloc = ev0[0];
+    #pragma unroll
+                for (int u = 1; u < NPP; ++u) mloc = fmaxf(mloc, ev0[u]);
+                mloc = T2V_DPP_MAX(mloc, 0xB1); mloc = T2V_DPP_MAX(mloc, 0x4E);
+                mloc = T2V_DPP_MAX(mloc, 0x141); mloc = T2V_DPP_MAX(mloc, 0x140);
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                if (lane == 0) rsm[wave] = mloc;
+            }
+            __syncthreads();
+            if (flag[0] != 1) return;
+            float m;
+            {
+                const float4 a0 = *(const float4*)rsm, a1 = *(const float4*)(rsm + 4);
+                m = fmaxf(fmaxf(fmaxf(a0.x, a0.y), fmaxf(a0.z, a0.w)), fmaxf(fmaxf(a1.x, a1.y), fmaxf(a1.z, a1.w)));
+            }
+            float e0v[NPP];
+    #pragma unroll
+            for (int u = 0; u < NPP; ++u) e0v[u] = tid + P16_THREADS * u < Tp ? expf(ev0[u] - m) : 0.f;
+            {
+                float sloc = e0v[0];
+    #pragma unroll
+                for (int u = 1; u < NPP; ++u) sloc += e0v[u];
+                sloc = row16_sum(sloc);
+                sloc += __shfl_xor(sloc, 16, 64);
+                sloc += __shfl_xor(sloc, 32, 64);
+                if (lane == 0) rss[wave] = sloc;
+            }
+            __syncthreads();
+            float ssum;
+            {
+                const float4 a0 = *(const float4*)rss, a1 = *(const float4*)(rss + 4);
+                ssum = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w));
+            }
+            const float rinv = 1.0f / ssum;
+    #pragma unroll
+            for (int u = 0; u < NPP; ++u) {
+                const int pos = tid + P16_THREADS * u;
+                const float al = e0v[u] * rinv;
+                if (pos < Tp) {
+                    eall[pos] = al;
+                    win[15 + pos] = al;                                        // previous weights of the next step
+                    const float cum = win[TW + 15 + pos] + al;                 // cumulative weights
+                    win[TW + 15 + pos] = cum;
+                    if (as == 0) {
+                        a.AL[((size_t)(t + 1) * B + ab) * Tp + pos] = al;
+                        a.ACUM[((size_t)(t + 1) * B + ab) * Tp + pos] = cum;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -566,7 +676,8 @@ __global__ __launch_bounds__(256) void k_p16_fill(uint4* p, size_t n16) {
 static size_t p16_lds_bytes(int T_in) {
     const size_t Tcap = (size_t)((T_in + 15) / 16) * 16;
     const size_t lrole = 2 * 2 * 8 * 2 * 64 * 4 + 4 * 64 + 4;
-    const size_t trole = 16 * 1028 + Tcap * 64 + Tcap * 16 + 2 * (Tcap + 32) + Tcap + T2V_H + 16 + 32 * 16 + 8 * 64 + 64 + 64 + 4;
+    const size_t resident = T_in > P16_MAXT ? Tcap * 64 : 16 * 1028 + Tcap * 64 + Tcap * 16;     // LONG: W_q / processed memory in registers
+    const size_t trole = resident + 2 * (Tcap + 32) + Tcap + T2V_H + 16 + 32 * 16 + 8 * 64 + 64 + 64 + 4;
     return sizeof(float) * (lrole > trole ? lrole : trole);
 }
 #define P16_LDS_MAX (160 * 1024)
@@ -574,7 +685,10 @@ static size_t p16_gh_floats(int T_out) { return (size_t)(T_out + 2) * (P16_GROW 
 static size_t p16_hx_floats(int T_out) { return (size_t)T_out * (P16_HROW / 4); }
 static size_t p16_ex_floats(int B, int T_in, int T_out) { return (size_t)T_out * B * 8 * t2v_tcap(T_in); }
 
-static int p16_device_ok(size_t lds) {
+static const void* p16_kernel(int T_in) {
+    return T_in > P16_MAXT ? (const void*)k_dec_train_persist16<true> : (const void*)k_dec_train_persist16<false>;
+}
+static int p16_device_ok(int T_in, size_t lds) {
     static int cus = -1;
     if (cus < 0) {
         int dev = 0;
@@ -585,14 +699,15 @@ static int p16_device_ok(size_t lds) {
     if (cus < T2V_NWG) return 0;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_dec_train_persist16, hipFuncAttributeMaxDynamicSharedMemorySize, P16_LDS_MAX) != hipSuccess) {
+        if (hipFuncSetAttribute(p16_kernel(P16_MAXT), hipFuncAttributeMaxDynamicSharedMemorySize, P16_LDS_MAX) != hipSuccess ||
+            hipFuncSetAttribute(p16_kernel(P16_MAXT + 1), hipFuncAttributeMaxDynamicSharedMemorySize, P16_LDS_MAX) != hipSuccess) {
             (void)hipGetLastError();
             return 0;
         }
         attr_set = true;
     }
     int nblk = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)k_dec_train_persist16, P16_THREADS, lds) != hipSuccess) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, p16_kernel(T_in), P16_THREADS, lds) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
@@ -600,8 +715,8 @@ static int p16_device_ok(size_t lds) {
 }
 
 extern "C" int t2v_decoder_train_persist16_supported(int B, int T_in) {
-    if (!(B >= 1 && B <= P16_MAXB && T_in >= 1 && T_in <= P16_MAXT && p16_lds_bytes(T_in) <= P16_LDS_MAX)) return 0;
-    return p16_device_ok(p16_lds_bytes(T_in));
+    if (!(B >= 1 && B <= P16_MAXB && T_in >= 1 && T_in <= P16_MAXT_LONG && p16_lds_bytes(T_in) <= P16_LDS_MAX)) return 0;
+    return p16_device_ok(T_in, p16_lds_bytes(T_in));
 }
 extern "C" long t2v_decoder_train_persist16_scratch_floats(int B, int T_in, int T_out) {
     if (B < 1 || B > P16_MAXB || T_in < 1 || T_out < 1) return 0;
@@ -643,6 +758,7 @@ extern "C" int t2v_decoder_train_fwd_persistent16(const t2v_dec_train_persist_we
     a.B = B; a.T_in = T_in; a.T_out = T_out; a.p_att = p_att; a.p_dec = p_dec; a.seed = seed;
     a.step = t2v_step_for(stream);
     a.prof = g_t2v_prof;
-    k_dec_train_persist16<<<T2V_NWG, P16_THREADS, p16_lds_bytes(T_in), stream>>>(a);
+    if (T_in > P16_MAXT) k_dec_train_persist16<true><<<T2V_NWG, P16_THREADS, p16_lds_bytes(T_in), stream>>>(a);
+    else k_dec_train_persist16<false><<<T2V_NWG, P16_THREADS, p16_lds_bytes(T_in), stream>>>(a);
     return t2v_check_launch();
 }

@@ -43,9 +43,9 @@ def _oracle(dec, memory, mels, lengths, wm, wg):
 @pytest.mark.parametrize("engine", ["persistent", "launch-per-step"])
 def test_decoder_core_matches_oracle(B, T_in, T_out, lens, engine, monkeypatch):
     """both forward engines against the oracle: the one-launch persistent kernel (csrc/decoder_train_persist.hip: B <= 6,
-    T_in <= 224) and the launch-per-step loop (any shape); the hand-written BPTT runs on the arena either of them saved"""
+    T_in <= 560) and the launch-per-step loop (any shape); the hand-written BPTT runs on the arena either of them saved"""
     import t2v_hip
-    persistent_ok = B <= 6 and T_in <= 224
+    persistent_ok = B <= 6 and T_in <= 560
     if engine == "persistent" and not persistent_ok:
         pytest.skip("outside the persistent kernel's range: the launch-per-step loop serves this shape")
     monkeypatch.setattr(t2v_hip.DecoderCore, 'persistent', engine == "persistent")

@@ -37,7 +37,11 @@ def _run(dec, p16, mem0, mels, lens, T, bwd=False):
 
 
 @pytest.mark.parametrize("B,T_in,T,ragged", [(16, 84, 400, False), (16, 84, 30, True), (7, 40, 9, True), (12, 130, 8, True),
-                                             (16, 224, 5, True), (9, 1, 4, False), (16, 5, 7, True), (3, 16, 6, True), (8, 84, 12, False)])
+                                             (16, 224, 5, True), (9, 1, 4, False), (16, 5, 7, True), (3, 16, 6, True), (8, 84, 12, False),
+                                             # round 6: the long form of the attention roles — 224 < T_in <= 560 in the forward pass, 96-position
+                                             # slices from 193 symbols on in the reverse pass (B = 16 at 224 symbols was 112 > 96 workgroups)
+                                             (16, 555, 12, True), (16, 225, 5, True), (16, 200, 6, True), (7, 300, 8, True), (16, 400, 60, True),
+                                             (12, 560, 4, False)])
 def test_persistent16_forward_matches_launch_per_step_bf16(B, T_in, T, ragged):
     import hparams as HP
     import model as M
@@ -122,5 +126,10 @@ def test_persistent16_range():
     lib = H.load_library()
     assert lib.t2v_decoder_train_persist16_supported(16, 224) == 1
     assert lib.t2v_decoder_train_persist16_supported(17, 84) == 0
-    assert lib.t2v_decoder_train_persist16_supported(16, 225) == 0
+    assert lib.t2v_decoder_train_persist16_supported(16, 225) == 1 and lib.t2v_decoder_train_persist16_supported(16, 560) == 1
+    assert lib.t2v_decoder_train_persist16_supported(16, 561) == 0
+    assert lib.t2v_decoder_bwd_persist16_supported(16, 192) == 1 and lib.t2v_decoder_bwd_persist16_slices(192) == 6
+    assert lib.t2v_decoder_bwd_persist16_supported(16, 224) == 1 and lib.t2v_decoder_bwd_persist16_slices(224) == 3
+    assert lib.t2v_decoder_bwd_persist16_supported(16, 560) == 1 and lib.t2v_decoder_bwd_persist16_slices(560) == 6
+    assert lib.t2v_decoder_bwd_persist16_supported(16, 577) == 0
     assert lib.t2v_decoder_train_persist16_scratch_floats(16, 84, 400) == 402 * 20480 + 400 * 16384 + 400 * 16 * 8 * 96

@@ -34,7 +34,12 @@ def _run(dec, mode, mem0, mels, lens, T, bwd=False):
 
 @pytest.mark.parametrize("B,T_in,T,ragged", [(6, 84, 400, True), (6, 84, 40, False), (6, 84, 25, True), (1, 5, 7, False), (2, 16, 9, True),
                                              (4, 84, 12, True), (5, 130, 8, True), (6, 224, 5, True), (3, 200, 6, True),
-                                             (6, 1, 4, False)])
+                                             (6, 1, 4, False),
+                                             # the long form (round 6): 224 < T_in <= 560, W_q / processed memory in registers, 96-position
+                                             # slices in the reverse pass — koemo's longest sentence (555 symbols) at the headline batch, the
+                                             # first length past the short form, a length of exactly one / of several full slices, one plane
+                                             (6, 555, 30, True), (6, 225, 6, True), (4, 288, 9, True), (5, 560, 5, False), (2, 513, 7, True),
+                                             (6, 400, 120, True)])
 def test_persistent_forward_equals_launch_per_step(B, T_in, T, ragged):
     import hparams as HP
     import model as M
@@ -77,14 +82,18 @@ def test_persistent_forward_equals_launch_per_step(B, T_in, T, ragged):
 
 
 def test_persistent_range_and_fallback():
-    """outside B <= 6 / T_in <= 224 the library says so and the wrapper takes the launch-per-step loop"""
+    """outside B <= 6 / T_in <= 560 the library says so and the wrapper takes the launch-per-step loop"""
     import hparams as HP
     import model as M
     import t2v_hip as H
     lib = H.load_library()
     assert lib.t2v_decoder_train_persist_supported(6, 224) == 1
     assert lib.t2v_decoder_train_persist_supported(7, 84) == 0
-    assert lib.t2v_decoder_train_persist_supported(6, 225) == 0
+    assert lib.t2v_decoder_train_persist_supported(6, 225) == 1 and lib.t2v_decoder_train_persist_supported(6, 560) == 1
+    assert lib.t2v_decoder_train_persist_supported(6, 561) == 0 and lib.t2v_decoder_train_persist_supported(1, 561) == 0
+    assert lib.t2v_decoder_bwd_persist_supported(6, 560) == 1 and lib.t2v_decoder_bwd_persist_supported(6, 577) == 0
+    assert lib.t2v_decoder_bwd_persist_slices(224) == 7 and lib.t2v_decoder_bwd_persist_slices(225) == 3
+    assert lib.t2v_decoder_bwd_persist_slices(555) == 6
     assert lib.t2v_decoder_train_persist_scratch_floats(6, 84, 400) == 402 * 2 * 2560 * 4 + 400 * 6 * 8 * 96
     torch.manual_seed(0)
     dec = M.Decoder(HP.create_hparams()).cuda().train()

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def test_fuzz_slice_persist16_forward_and_reverse_pass():
     """bf16 persistent forward + reverse pass against the launch-per-step bf16 loop (and bit-reproducibility) on 10 random shapes
-    with B 1…16, T_in 1…224 incl. the tile / slice edges, ragged lengths, state dropout on (tools/dbg/fuzz_persist16.py)."""
+    with B 1…16, T_in 1…560 incl. the tile / slice edges and the long forms of the attention roles, ragged lengths, state dropout on (tools/dbg/fuzz_persist16.py)."""
     import t2v_hip as H
     import test_decoder_persist16_gpu as T16
     lib = H.load_library()
@@ -24,7 +24,8 @@ def test_fuzz_slice_persist16_forward_and_reverse_pass():
     n = with_bwd = 0
     while n < 10:
         B = rng.choice([1, 2, 5, 7, 9, 10, 11, 13, 14, 15, 16])
-        T_in = rng.choice([1, 2, 3, 15, 16, 17, 31, 33, 47, 64, 65, 83, 95, 96, 97, 111, 128, 129, 160, 191, 192, 193, 200, 223, 224])
+        T_in = rng.choice([1, 2, 3, 15, 16, 17, 31, 33, 47, 64, 65, 83, 95, 96, 97, 111, 128, 129, 160, 191, 192, 193, 200, 223, 224,
+                           225, 288, 289, 300, 384, 385, 480, 512, 513, 555, 560])
         T = rng.randint(2, 24)
         ragged = rng.random() < 0.7
         if lib.t2v_decoder_train_persist16_supported(B, T_in) != 1:
