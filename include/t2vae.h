@@ -135,7 +135,8 @@ int t2v_decoder_train_fwd(const t2v_dec_weights* w, const t2v_dec_train_bufs* s,
  * no grid barrier.  Writes the same arena as t2v_decoder_train_fwd (XS, CA, CD, GA, GD, AL, ACUM, S; QP only supplies
  * the error word), so t2v_decoder_train_bwd runs on it unchanged; dropout masks are the same counter-based ones, i.e.
  * the two paths agree to fp32 summation order.  Supported when t2v_decoder_train_persist_supported(B, T_in) != 0:
- * B <= 6, T_in <= 224, a device with >= 256 CUs that can hold one 512-thread workgroup with this LDS carve per CU.
+ * B <= 6, T_in <= 560 (round 6; up to 224 symbols the attention workgroups keep their W_q / processed-memory slices in LDS,
+ * beyond in registers), a device with >= 256 CUs that can hold one 512-thread workgroup with this LDS carve per CU.
  * scratch: t2v_decoder_train_persist_scratch_floats(B, T_in, T_out) floats, 16-byte aligned (filled by the call). */
 typedef struct t2v_dec_train_persist_weights {
     const float* w_ih_att; const float* w_hh_att;   /* attention_rnn (4096,768) [prenet | ctx], (4096,1024) */
@@ -151,7 +152,7 @@ int t2v_decoder_train_fwd_persistent(const t2v_dec_train_persist_weights* w, con
                                      int B, int T_in, int T_out, float p_att, float p_dec, uint64_t seed, void* stream);
 
 /* The same pass for hparams.bf16_run (BASELINE configs[4]: B = 16 per GPU; replaces reference fp16_optimizer.py:51-382 /
- * train.py:22-28 on the decoder loop model.py:415-421, 346-389): B <= 16, T_in <= 224.  The LSTM weights are rounded to bf16
+ * train.py:22-28 on the decoder loop model.py:415-421, 346-389): B <= 16, T_in <= 560.  The LSTM weights are rounded to bf16
  * (RNE, as t2v_pack_lstm_weights_bf16) into MFMA tiles that stay in registers for the whole pass — a workgroup owns 8 hidden
  * units of both cells, the batch is the N dimension of v_mfma_f32_16x16x32_bf16 — the recurrent state travels between the
  * workgroups as bf16 rows laid out as the MFMA's B operand; fp32 accumulation, cell state, attention and saved activations,
@@ -217,8 +218,8 @@ int t2v_attn_wgrad(const float* dpre, const float* al, const float* acum, const 
 
 /* ------------------------------------------------------------------ persistent BPTT (csrc/decoder_train_bwd_persist.hip)
  * The reverse recurrence of the decoder loop as persistent launches for the shapes of the persistent forward
- * (t2v_decoder_bwd_persist_supported: B <= 6, T_in <= 224, >= 256 CUs).  decoder_rnn's chain does not depend on the
- * attention path, so it runs first for all steps:
+ * (t2v_decoder_bwd_persist_supported: B <= 6, T_in <= 576 — 96-position attention slices beyond 224 symbols —, >= 256 CUs).
+ * decoder_rnn's chain does not depend on the attention path, so it runs first for all steps:
  *   t2v_decoder_bwd_dchain : dHC[:, :, :1024] (grad wrt h_dec from the projection), GD, CD (saved by the forward pass)
  *                            -> DGD (T,B,4096), grad wrt decoder_rnn's pre-activations.  256 workgroups x 4 hidden units,
  *                            W_hh_dec^T in registers; the gate-gradient rows travel between CUs through `scratch`
@@ -239,7 +240,7 @@ int t2v_decoder_bwd_dchain(const float* w_hh_dec, const float* dHC, const float*
  * scratch: t2v_decoder_bwd_achain_scratch_floats(B, T_in, T_out) floats, 16-byte aligned; DQP 16-byte aligned. */
 long t2v_decoder_bwd_achain_scratch_floats(int B, int T_in, int T_out);
 /* position slices per item of the ONE-LAUNCH reverse pass (second-to-last dimension of its DQP (T,B,S,128) and DV (B,S,128)):
- * 1 up to 96 symbols (one workgroup per item), else t2v_attn_bwd_slices(T_in) */
+ * t2v_attn_bwd_slices(T_in) up to 224 symbols, ceil(T_in / 96) beyond */
 int t2v_decoder_bwd_persist_slices(int T_in);
 int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, const float* reserved, const t2v_dec_train_bufs* s,
                            const float* dHC, float* DGA, float* DGD, float* DCTX, float* DV, float* DQP, float* scratch,
@@ -250,7 +251,7 @@ int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, const float* 
  * every product, fp32 accumulation, fp32 cell / attention backward).  ONE persistent launch: Wcat^T lives in registers as bf16
  * MFMA tiles, cut into 128-column x 1024-row blocks (48 + 80 workgroups publish partial column sums), 16 + 16 workgroups run
  * the cells of 64 hidden units each, B * S workgroups the attention backward (S = t2v_decoder_bwd_persist16_slices(T_in):
- * slices of 16 positions up to 96 symbols, else 32).  Supported when B <= 16, T_in <= 224 and B * S <= 96.
+ * slices of 16 positions up to 96 symbols, 32 up to 192, 96 beyond).  Supported when B <= 16, T_in <= 576 (B * S <= 96 always holds).
  * DV (B,S,128), DQP (T_out,B,S,128), scratch: t2v_decoder_bwd_persist16_scratch_floats() floats, 16-byte aligned (filled by
  * the call); dq(t) summed over the slices lies at float offset t2v_decoder_bwd_persist16_dq_offset() of scratch as
  * (T_out, 16, 128).  err_word: set to 1 when a bounded spin gave up (results invalid). */

@@ -66,7 +66,7 @@ class TextMelLoader(torch.utils.data.Dataset):
 
     def text_lengths(self):
         """symbol count of every entry (the decoder's T_in): the bucketed sampler keeps utterances above the persistent
-        decoder kernels' range (224 symbols) together, so that as many batches as possible stay inside it"""
+        decoder kernels' range (560 symbols since round 6; 224 before) together, so that as many batches as possible stay inside it"""
         from text import text_to_sequence
         return [len(text_to_sequence(fields[1], self.text_cleaners)) for fields in self.audiopaths_and_text]
 
@@ -188,9 +188,10 @@ class BucketBatchSampler(torch.utils.data.Sampler):
     reference loader, train.py:62-65)."""
 
     def __init__(self, lengths, batch_size, world_size=1, rank=0, seed=1234, window=16, shuffle=True, text_lengths=None,
-                 text_cap=224):
-        """text_lengths / text_cap (round 4): the one-launch persistent decoder kernels take T_in <= 224 symbols (koemo reaches
-        555).  With text lengths given, a window is sorted by (longer than the cap?, length): the few long utterances of a
+                 text_cap=560):
+        """text_lengths / text_cap (round 4): the one-launch persistent decoder kernels took T_in <= 224 symbols then (koemo
+        reaches 555); since round 6 they take 560 (t2v_decoder_train_persist_supported), which is the default cap — koemo no
+        longer has a sentence above it, other corpora may.  With text lengths given, a window is sorted by (longer than the cap?, length): the few long utterances of a
         window share batches instead of pushing many batches over the cap.  persistent_hit_rate() reports the fraction of
         this rank's batches that stay inside the range."""
         self.lengths = list(lengths)

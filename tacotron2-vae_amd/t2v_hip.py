@@ -910,7 +910,7 @@ class DecoderCore(torch.autograd.Function):
     keep_last = False       # bench / tests: keep the (first chunk's) arena of the last forward for replays
 
     # T2V_TRAIN_PERSISTENT=0 forces the launch-per-step forward; the default takes the one-launch persistent kernel
-    # (csrc/decoder_train_persist.hip) whenever t2v_decoder_train_persist_supported(B, T_in): B <= 6, T_in <= 224
+    # (csrc/decoder_train_persist.hip) whenever t2v_decoder_train_persist_supported(B, T_in): B <= 6, T_in <= 560
     persistent = None
     persistent_bwd = None   # same switch for the reverse pass (env T2V_BWD_PERSISTENT, default: as T2V_TRAIN_PERSISTENT)
     last_bwd_mode = None

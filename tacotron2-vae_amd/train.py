@@ -792,7 +792,8 @@ def train(output_directory, log_directory, checkpoint_path, warm_start, n_gpus, 
                 train_loader.batch_sampler.set_epoch(epoch)
                 hit = train_loader.batch_sampler.persistent_hit_rate()
                 if hit is not None and rank == 0:
-                    print("Batches inside the persistent decoder kernels' range (T_in <= 224): {:.1f} %".format(100.0 * hit))
+                    print("Batches inside the persistent decoder kernels' range (T_in <= {}): {:.1f} %".format(
+                        train_loader.batch_sampler.text_cap, 100.0 * hit))
             for batch in train_loader:
                 start = time.perf_counter()
                 # (syncs and checks the error ledger like the .item() of reference train.py:230; a time-out of the persistent

@@ -91,8 +91,9 @@ def test_hparams_extensions_do_not_leak_into_reference_values():
 
 
 def test_bucket_sampler_keeps_long_texts_together():
-    """round 4: with text lengths given, utterances above the persistent decoder kernels' range (224 symbols) share batches
-    instead of being spread over many; every utterance is still drawn exactly once per epoch"""
+    """round 4: with text lengths given, utterances above a text cap (the persistent decoder kernels' range: 224 symbols then, 560
+    — the default cap — since round 6) share batches instead of being spread over many; every utterance is still drawn exactly
+    once per epoch"""
     import random
     from data_utils import BucketBatchSampler
     rnd = random.Random(3)
@@ -100,7 +101,8 @@ def test_bucket_sampler_keeps_long_texts_together():
     lengths = [rnd.randint(100, 800) for _ in range(n)]
     texts = [rnd.randint(230, 555) if rnd.random() < 0.1 else rnd.randint(10, 200) for _ in range(n)]
     plain = BucketBatchSampler(lengths, bs, seed=5)
-    aware = BucketBatchSampler(lengths, bs, seed=5, text_lengths=texts)
+    aware = BucketBatchSampler(lengths, bs, seed=5, text_lengths=texts, text_cap=224)
+    assert BucketBatchSampler(lengths, bs, seed=5, text_lengths=texts).persistent_hit_rate() == 1.0      # default cap 560
     seen = sorted(i for b in aware for i in b)
     assert seen == list(range(n))
     hit_aware = aware.persistent_hit_rate()
