@@ -29,6 +29,9 @@ t2v_hip.gemm = timed
 eng.step(batch, 3)
 torch.cuda.synchronize()
 t2v_hip.gemm = orig
+if '--order' in sys.argv:
+    for i, r in enumerate(rows):
+        print('#%02d %7.1f us  M=%5d N=%5d K=%5d  A_kc=%d B_kc=%d acc=%d' % (i, r[0], r[1], r[2], r[3], r[4], r[5], r[6]))
 tot = sum(r[0] for r in rows)
 print('%d gemm calls, %.0f us alone in total' % (len(rows), tot))
 for r in sorted(rows, key=lambda r: -r[0])[:40]:

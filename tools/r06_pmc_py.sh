@@ -1,4 +1,4 @@
-# usage: bash tools/r06_pmc_py.sh "<counters>" <script.py> [args]  -> per-kernel mean counter values of a python script (separate PMC-only pass)
+# usage: [PMC_FILTER=name1,name2] bash tools/r06_pmc_py.sh "<counters>" <script.py> [args]  -> per-kernel mean counter values of a python script (separate PMC-only pass)
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
 CTRS="$1"; shift
@@ -15,7 +15,8 @@ for r in csv.DictReader(open(sys.argv[1])):
     key = (n, r.get('Grid_Size', ''))
     agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, c in agg.items():
-    if not any(x in k[0] for x in ('x3', 'gemm', 'conv5')):
+    import os
+    if not any(x in k[0] for x in os.environ.get('PMC_FILTER', 'x3,gemm,conv5').split(',')):
         continue
     e = {n: sum(v) / len(v) for n, v in c.items()}
     line = '%-40s grid %9s n=%3d ' % (k[0], k[1], len(next(iter(c.values()))))
