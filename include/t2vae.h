@@ -251,7 +251,7 @@ int t2v_decoder_bwd_achain(const t2v_dec_train_persist_weights* w, const float* 
  * every product, fp32 accumulation, fp32 cell / attention backward).  ONE persistent launch: Wcat^T lives in registers as bf16
  * MFMA tiles, cut into 128-column x 1024-row blocks (48 + 80 workgroups publish partial column sums), 16 + 16 workgroups run
  * the cells of 64 hidden units each, B * S workgroups the attention backward (S = t2v_decoder_bwd_persist16_slices(T_in):
- * slices of 16 positions up to 96 symbols, 32 up to 192, 96 beyond).  Supported when B <= 16, T_in <= 576 (B * S <= 96 always holds).
+ * slices of 16 positions up to 96 symbols, 32 up to 192, 96 beyond).  Supported when B <= 16, T_in <= 560 (B * S <= 96 always holds).
  * DV (B,S,128), DQP (T_out,B,S,128), scratch: t2v_decoder_bwd_persist16_scratch_floats() floats, 16-byte aligned (filled by
  * the call); dq(t) summed over the slices lies at float offset t2v_decoder_bwd_persist16_dq_offset() of scratch as
  * (T_out, 16, 128).  err_word: set to 1 when a bounded spin gave up (results invalid). */

@@ -30,7 +30,8 @@
 #define Q16_THREADS 512
 #define Q16_MAXB 16
 #define Q16_MAXT 224                    // (SMAX below: 16- / 32-position slices up to here)
-#define Q16_MAXT_LONG 576               // 96-position slices on eight waves from 193 symbols on: at most six per item, 16 x 6 = 96 workgroups
+#define Q16_MAXT_LONG 560               // 96-position slices on eight waves from 193 symbols on (six per item: 16 x 6 = 96 workgroups);
+                                        // the range of the forward kernel, k_dec_train_persist16<true>
 #define Q16_SPIN 400000
 #define Q16_SENT 0xFFFFFFFFu
 #define Q16_NGA 48                      // (1536 / 128) column groups x 4 row quarters

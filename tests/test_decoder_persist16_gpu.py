@@ -131,5 +131,5 @@ def test_persistent16_range():
     assert lib.t2v_decoder_bwd_persist16_supported(16, 192) == 1 and lib.t2v_decoder_bwd_persist16_slices(192) == 6
     assert lib.t2v_decoder_bwd_persist16_supported(16, 224) == 1 and lib.t2v_decoder_bwd_persist16_slices(224) == 3
     assert lib.t2v_decoder_bwd_persist16_supported(16, 560) == 1 and lib.t2v_decoder_bwd_persist16_slices(560) == 6
-    assert lib.t2v_decoder_bwd_persist16_supported(16, 577) == 0
+    assert lib.t2v_decoder_bwd_persist16_supported(16, 561) == 0
     assert lib.t2v_decoder_train_persist16_scratch_floats(16, 84, 400) == 402 * 20480 + 400 * 16384 + 400 * 16 * 8 * 96

@@ -81,6 +81,40 @@ def test_persistent_forward_equals_launch_per_step(B, T_in, T, ragged):
         H.DecoderCore.last_call = H.DecoderCore.last_bwd = None
 
 
+@pytest.mark.parametrize("B,T_in,T", [(6, 576, 6), (3, 561, 9)])
+def test_persistent_reverse_pass_beyond_the_forward_range(B, T_in, T):
+    """561 … 576 symbols: the forward pass is out of range (560: LDS of the memory slice) and takes the launch-per-step loop, the
+    reverse pass (96-position slices, six per item) still runs as one launch on the arena that loop saved"""
+    import hparams as HP
+    import model as M
+    import t2v_hip as H
+    lib = H.load_library()
+    assert lib.t2v_decoder_train_persist_supported(B, T_in) == 0 and lib.t2v_decoder_bwd_persist_supported(B, T_in) == 1
+    old_drop, old_keep, old_mode = M.drop_rate, H.DecoderCore.keep_last, H.DecoderCore.persistent
+    M.drop_rate = 0.0
+    H.DecoderCore.keep_last = True
+    try:
+        torch.manual_seed(0)
+        dec = M.Decoder(HP.create_hparams()).cuda().train()
+        dec.p_attention_dropout = dec.p_decoder_dropout = 0.1
+        g = torch.Generator().manual_seed(1)
+        mem0 = (torch.randn(B, T_in, 512, generator=g) * 0.5).cuda()
+        mels = torch.randn(B, 80, T, generator=g).cuda()
+        lens = torch.tensor([max(1, T_in - 7 * i) for i in range(B)]).cuda()
+        a = _run(dec, None, mem0, mels, lens, T, bwd=False)
+        c = _run(dec, None, mem0, mels, lens, T, bwd=True)
+        assert a[0] == 'launch-per-step' and c[0] == 'launch-per-step' and a[6] == 'launch-per-step' and c[6] == 'persistent'
+        assert torch.equal(a[1], c[1])
+        gmax = max(v.abs().max().item() for v in a[5].values())
+        for n in a[5]:
+            scale = a[5][n].abs().max().item()
+            assert (a[5][n] - c[5][n]).abs().max().item() < 2e-5 * scale + 1e-6 * gmax + 1e-7, (n, scale, gmax)
+    finally:
+        M.drop_rate, H.DecoderCore.keep_last, H.DecoderCore.persistent = old_drop, old_keep, old_mode
+        H.DecoderCore.persistent_bwd = None
+        H.DecoderCore.last_call = H.DecoderCore.last_bwd = None
+
+
 def test_persistent_range_and_fallback():
     """outside B <= 6 / T_in <= 560 the library says so and the wrapper takes the launch-per-step loop"""
     import hparams as HP
