@@ -27,6 +27,9 @@
 #define PD_THREADS 512
 #define PD_MAXB 4
 #define PD_MAXT 224
+#ifndef PD_CTXW
+#define PD_CTXW 4          // positions per round of the context sum (t2v_ctx_partial); the attention workgroups have few registers to spare
+#endif
 #define PD_SPIN 3000000u
 #define PD_XW 2816                 // LDS state row: [h_att 1024 | ctx 512 | pre1 256 | h_dec 1024]
 #define PD_X_HA 0
@@ -218,8 +221,8 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
     float* mem_s = wq_s + 16 * 1028;                     // [Tcap][64]
     float* pm_s = mem_s + Tcap * 64;                     // [Tcap][16]
     float* win = pm_s + Tcap * 16;                       // [2][TW]: alignment window, index x <-> position x - 15
-    float* eall = win + 2 * TW;                          // [Tcap]
-    float* qv = eall + Tcap;                             // [16]
+    float* eall = win + 2 * TW;                          // [Tcap + T2V_CTX_PAD]: attention weights, zero from Tp on (t2v_ctx_partial)
+    float* qv = eall + Tcap + T2V_CTX_PAD;               // [16]
     float* qred = qv + 16;                               // [32][16]
     float* cred = qred + 32 * 16;                        // [8][64]
     float* rsm = cred + 8 * 64;                          // [32] row maxima
@@ -271,6 +274,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
         for (int i = tid; i < Tp * 64; i += PD_THREADS) mem_s[i] = a.memory[((size_t)ab * Tp + (i >> 6)) * T2V_E + 64 * as + (i & 63)];
         for (int i = tid; i < Tp * 16; i += PD_THREADS) pm_s[i] = a.pm[((size_t)ab * Tp + (i >> 4)) * T2V_A + 16 * as + (i & 15)];
         for (int i = tid; i < 2 * TW; i += PD_THREADS) win[i] = 0.f;
+        for (int i = Tp + tid; i < Tcap + T2V_CTX_PAD; i += PD_THREADS) eall[i] = 0.f;
         const int g = lane >> 4, c16 = lane & 15;
         const float4* wp = (const float4*)(a.wcomb + (16 * as + c16) * 64 + 16 * g);
         if (wave == 0) {
@@ -518,9 +522,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             // context columns 64 as .. 64 as + 63: thread = (column c = tid & 63, part = tid >> 6)
             {
                 const int c = tid & 63, part = tid >> 6;
-                float acc = 0.f;
-                for (int j = part; j < Tp; j += 8) acc = fmaf(eall[j], mem_s[j * 64 + c], acc);
-                cred[part * 64 + c] = acc;
+                cred[part * 64 + c] = t2v_ctx_partial<PD_CTXW>(eall, mem_s, part, c, Tp);
             }
             __syncthreads();
             if (tid < 64) {
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
 static size_t pd_lds_bytes(int B, int T_in) {
     const size_t Tcap = (size_t)((T_in + 15) / 16) * 16;
     size_t f = (size_t)B * PD_XW + 8 * 16 * PD_MAXB + PD_MAXB * 16 + 2 * PD_MAXB * 4 + 4;
-    const size_t attn = 16 * 1028 + Tcap * 64 + Tcap * 16 + 2 * (Tcap + 32) + Tcap + 16 + 32 * 16 + 8 * 64 + 64 + 16 * 64;
+    const size_t attn = 16 * 1028 + Tcap * 64 + Tcap * 16 + 2 * (Tcap + 32) + Tcap + T2V_CTX_PAD + 16 + 32 * 16 + 8 * 64 + 64 + 16 * 64;
     const size_t proj = 8 * 1536;
     f += attn > proj ? attn : proj;
     return f * sizeof(float);

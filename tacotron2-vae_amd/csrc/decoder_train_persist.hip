@@ -522,8 +522,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
     float* mem_s = wq_s + (LONG ? 0 : 16 * 1028);        // [Tcap][64]
     float* pm_s = mem_s + Tcap * 64;                     // [Tcap][16]   (LONG: in registers)
     float* win = pm_s + (LONG ? 0 : Tcap * 16);          // [2][TW]: alignment window, index x <-> position x - 15
-    float* eall = win + 2 * TW;                          // [Tcap]
-    float* hx = eall + Tcap;                             // [1024] h_att(t) of this item
+    float* eall = win + 2 * TW;                          // [Tcap] (LONG: + T2V_CTX_PAD, zero from Tp on: t2v_ctx_partial)
+    float* hx = eall + Tcap + (LONG ? T2V_CTX_PAD : 0);  // [1024] h_att(t) of this item
     float* qv = hx + T2V_H;                              // [16]
     float* qred = qv + 16;                               // [32][16]
     float* cred = qred + 32 * 16;                        // [8][64]
@@ -550,6 +550,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
     if constexpr (!LONG)
         for (int i = tid; i < Tp * 16; i += PT_THREADS) pm_s[i] = a.pm[((size_t)ab * Tp + (i >> 4)) * T2V_A + 16 * as + (i & 15)];
     for (int i = tid; i < 2 * TW; i += PT_THREADS) win[i] = 0.f;
+    if constexpr (LONG)
+        for (int i = Tp + tid; i < Tcap + T2V_CTX_PAD; i += PT_THREADS) eall[i] = 0.f;
     if (tid == 0) flag[0] = 1;
     float areg[16];
     {
@@ -821,9 +823,15 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
         // ---- context columns [64 as, 64 as + 64): thread = (column c = tid & 63, part = tid >> 6)
         {
             const int c = tid & 63, part = tid >> 6;
-            float acc = 0.f;
-            for (int jj = part; jj < Tp; jj += 8) acc = fmaf(eall[jj], mem_s[jj * 64 + c], acc);
-            cred[part * 64 + c] = acc;
+            if constexpr (LONG) {
+                // (up to 70 positions per thread: eight per round, reads first — 8 000 -> 6 500 cycles at 555 symbols; at <= 224 symbols
+                // the plain loop is as fast and the short kernels keep their instruction stream)
+                cred[part * 64 + c] = t2v_ctx_partial<8>(eall, mem_s, part, c, Tp);
+            } else {
+                float acc = 0.f;
+                for (int jj = part; jj < Tp; jj += 8) acc = fmaf(eall[jj], mem_s[jj * 64 + c], acc);
+                cred[part * 64 + c] = acc;
+            }
         }
         __syncthreads();
         if (tid < 64) {
@@ -854,7 +862,7 @@ static size_t pt_lds_bytes(int B, int T_in) {
     const size_t np = B > 4 ? 2 : 1;
     const size_t lrole = np * T2V_XW * 4 + 4 * 8 * 32 + 6 * 32 + 4;
     const size_t resident = pt_long(T_in) ? Tcap * 64 : 16 * 1028 + Tcap * 64 + Tcap * 16;      // LONG: W_q / processed memory in registers
-    const size_t trole = resident + 2 * (Tcap + 32) + Tcap + T2V_H + 16 + 32 * 16 + 8 * 64 + 64 + 4;
+    const size_t trole = resident + 2 * (Tcap + 32) + Tcap + (pt_long(T_in) ? T2V_CTX_PAD : 0) + T2V_H + 16 + 32 * 16 + 8 * 64 + 64 + 4;
     return sizeof(float) * (lrole > trole ? lrole : trole);
 }
 #define PT_LDS_MAX (160 * 1024)

@@ -107,6 +107,37 @@ __device__ __forceinline__ float t2v_drop_scale(uint64_t seed, uint32_t stream, 
     return u >= p ? 1.0f / (1.0f - p) : 0.0f;
 }
 
+// Attention context partial of one thread: sum over the positions j = part, part + 8, ... < Tp of w[j] * m[j * 64 + c] (both in
+// LDS), W positions per round with all 2 W reads issued before the first FMA.  As a plain loop the compiler keeps ONE pair of
+// reads in flight per FMA: 107 cycles per position measured (round 6: 70 positions per thread at 555 symbols = 8 000 cycles of a
+// 30 000-cycle step; 11 at the headline's 84 symbols).  No masks in the loop (seven compare results held in SGPR pairs pushed the
+// forward kernel from 44 to 68 spilled SGPRs and made it slower as a whole): the CALLER keeps w[Tp .. Tp + 8 W) at zero
+// (T2V_CTX_PAD extra floats behind the Tcap weights, cleared once), rows past the end re-read row Tp - 1.
+#define T2V_CTX_PAD 64
+template <int W>
+__device__ __forceinline__ float t2v_ctx_partial(const float* w, const float* m, int part, int c, int Tp) {
+    static_assert(8 * W <= T2V_CTX_PAD, "zero padding of the weights");
+    float acc[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) acc[k] = 0.f;
+    for (int j0 = part; j0 < Tp; j0 += 8 * W) {
+        float e[W], x[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const int j = j0 + 8 * k;
+            e[k] = w[j];
+            x[k] = m[min(j, Tp - 1) * 64 + c];
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) acc[k] = fmaf(e[k], x[k], acc[k]);
+    }
+#pragma unroll
+    for (int s = W / 2; s > 0; s >>= 1)
+#pragma unroll
+        for (int k = 0; k < s; ++k) acc[k] += acc[k + s];
+    return acc[0];
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
     v = row16_sum(v);
     v += __shfl_xor(v, 16, 64);
