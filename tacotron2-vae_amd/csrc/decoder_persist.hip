@@ -522,7 +522,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             // context columns 64 as .. 64 as + 63: thread = (column c = tid & 63, part = tid >> 6)
             {
                 const int c = tid & 63, part = tid >> 6;
-                cred[part * 64 + c] = t2v_ctx_partial<PD_CTXW>(eall, mem_s, part, c, Tp);
+                cred[part * 64 + c] = t2v_ctx_partial_v<PD_CTXW>(eall, mem_s, part, c, Tp);
             }
             __syncthreads();
             if (tid < 64) {
