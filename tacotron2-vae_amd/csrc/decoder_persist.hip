@@ -255,9 +255,9 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
         const int k = pd_kd(wave, j, kq);                                // [h_att | ctx | h_dec]
         wd[j] = k < T2V_KATT ? a.w_ih_dec[(size_t)grow * T2V_KATT + k] : a.w_hh_dec[(size_t)grow * T2V_H + (k - T2V_KATT)];
     }
-    float bias_a = 0.f, bias_d = 0.f;                                   // threads 0..15: gate row biases
-    if (tid < 16) {
-        const int row = (tid & 3) * T2V_H + 4 * wg + (tid >> 2);
+    float bias_a = 0.f, bias_d = 0.f;                                   // wave 0: thread (row r = tid & 15, item) holds the bias of row r
+    if (tid < 64) {
+        const int row = (tid & 3) * T2V_H + 4 * wg + ((tid & 15) >> 2);
         bias_a = a.bias_att[row];
         bias_d = a.bias_dec[row];
     }
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             float s = 0.f;
 #pragma unroll
             for (int w8 = 0; w8 < 8; ++w8) s += red[(w8 * 16 + r) * PD_MAXB + b];
-            gst[b * 16 + r] = s + __shfl(bias_a, r, 64);       // pre-activation where the unit's thread finds its four gates
+            gst[b * 16 + r] = s + bias_a;                      // pre-activation where the unit's thread finds its four gates
         }
         __syncthreads();
         if (tid < 4 * B) {                                     // thread = (unit u = tid & 3, item b = tid >> 2)
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             // the four units of an item leave as ONE 16-byte store (round 4: four 4-byte stores from four lanes were four
             // write-through transactions into the same 32-byte sector)
             const float h = go * tanhf_(c);
-            const float h1 = __shfl_down(h, 1, 4), h2 = __shfl_down(h, 2, 4), h3 = __shfl_down(h, 3, 4);
+            const float h1 = T2V_DPP_QUAD_F(h, 1), h2 = T2V_DPP_QUAD_F(h, 2), h3 = T2V_DPP_QUAD_F(h, 3);      // (used by lane u == 0 only)
             if (u == 0) pd_put4(rx, xcur + pd_hatt(B) + (unsigned)(b * 1024 + 4 * wg), h, h1, h2, h3);
         }
         PD_STAMP(0, 1);
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                     acc0 = fmaf(w4.z, h4.z, acc0); acc1 = fmaf(w4.w, h4.w, acc1);
                 }
                 float q = row16_sum(acc0 + acc1);
-                q += __shfl_xor(q, 16, 64);
+                q = rows2_sum(q);
                 if (kq == 0) qv[d] = q;
             }
             __syncthreads();
@@ -486,8 +486,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                 float mloc = ev0;
                 mloc = T2V_DPP_MAX(mloc, 0xB1); mloc = T2V_DPP_MAX(mloc, 0x4E);
                 mloc = T2V_DPP_MAX(mloc, 0x141); mloc = T2V_DPP_MAX(mloc, 0x140);
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                mloc = rows4_max(mloc);
                 if (lane == 0) rsm[wave] = mloc;
             }
             __syncthreads();
@@ -499,9 +498,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             }
             const float e0v = tid < Tp ? expf(ev0 - m) : 0.f;
             {
-                float sloc = row16_sum(e0v);
-                sloc += __shfl_xor(sloc, 16, 64);
-                sloc += __shfl_xor(sloc, 32, 64);
+                const float sloc = rows4_sum(row16_sum(e0v));
                 if (lane == 0) rss[wave] = sloc;
             }
             __syncthreads();
@@ -554,7 +551,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             float s = 0.f;
 #pragma unroll
             for (int w8 = 0; w8 < 8; ++w8) s += red[(w8 * 16 + r) * PD_MAXB + b];
-            gst[b * 16 + r] = s + __shfl(bias_d, r, 64);
+            gst[b * 16 + r] = s + bias_d;
         }
         __syncthreads();
         if (tid < 4 * B) {
@@ -564,7 +561,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             const float c = gf * cst[PD_MAXB * 4 + b * 4 + u] + gi * gg;
             cst[PD_MAXB * 4 + b * 4 + u] = c;
             const float h = go * tanhf_(c);
-            const float h1 = __shfl_down(h, 1, 4), h2 = __shfl_down(h, 2, 4), h3 = __shfl_down(h, 3, 4);
+            const float h1 = T2V_DPP_QUAD_F(h, 1), h2 = T2V_DPP_QUAD_F(h, 2), h3 = T2V_DPP_QUAD_F(h, 3);      // (used by lane u == 0 only)
             if (u == 0) pd_put4(rx, xcur + pd_hdec(B) + (unsigned)(b * 1024 + 4 * wg), h, h1, h2, h3);
         }
         PD_STAMP(0, 7); PD_STAMP(64, 12);
@@ -612,7 +609,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                     float acc = pacc[b];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc = fmaf(wr[lane + 64 * i], xb[PD_X_HD + lane + 64 * i], acc);      // the h_dec columns
-                    acc = wave_sum(acc) + pbias;
+                    acc = wave_sum_rl(acc) + pbias;
                     if (lane == 0) {
                         if (prow < T2V_NMEL) a.MEL[((size_t)t * B + b) * T2V_NMEL + prow] = acc;
                         else if (prow == T2V_NMEL) a.GATE[(size_t)t * B + b] = acc;
@@ -678,7 +675,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                 const float4 xv = *(const float4*)(p0_s + b * 256 + 4 * lane);
                 float acc = w4.x * xv.x;
                 acc = fmaf(w4.y, xv.y, acc); acc = fmaf(w4.z, xv.z, acc); acc = fmaf(w4.w, xv.w, acc);
-                acc = wave_sum(acc);
+                acc = wave_sum_rl(acc);
                 if (lane == 0) {
                     acc = fmaxf(acc, 0.f) * t2v_drop_scale(a.seed, T2V_RNG_PRENET1, t + 1, (uint32_t)(b * T2V_PRE + p1row), a.p_prenet);
                     gst[b * 8 + wave] = acc;

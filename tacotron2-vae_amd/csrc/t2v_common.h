@@ -182,6 +182,28 @@ __device__ __forceinline__ float t2v_ctx_partial_v(const float* w, const float* 
     return acc[0];
 }
 
+// Cross-row steps WITHOUT the LDS crossbar (`__shfl_xor(v, 16 / 32)` is a ds_bpermute: ~100 cycles each, two in a row per wave
+// reduction — on the per-frame / per-step chains of the persistent kernels that adds up, round 6).  `v` holds, in every lane of a
+// 16-lane row, that row's partial (after row16_sum or a DPP row max): four v_readlane_b32 and a few scalar-operand VALU ops.
+// Bit-identical to the shuffle forms: (r0 + r1) + (r2 + r3) in every lane, fp addition is commutative.
+__device__ __forceinline__ float t2v_readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ float rows4_sum(float v) {
+    return (t2v_readlane_f(v, 0) + t2v_readlane_f(v, 16)) + (t2v_readlane_f(v, 32) + t2v_readlane_f(v, 48));
+}
+__device__ __forceinline__ float rows4_max(float v) {
+    return fmaxf(fmaxf(t2v_readlane_f(v, 0), t2v_readlane_f(v, 16)), fmaxf(t2v_readlane_f(v, 32), t2v_readlane_f(v, 48)));
+}
+// the same for the two halves of a wave separately: lanes 0..31 get r0 + r1, lanes 32..63 r2 + r3 (= v + __shfl_xor(v, 16))
+__device__ __forceinline__ float rows2_sum(float v) {
+    const float lo = t2v_readlane_f(v, 0) + t2v_readlane_f(v, 16), hi = t2v_readlane_f(v, 32) + t2v_readlane_f(v, 48);
+    return (threadIdx.x & 32) ? hi : lo;
+}
+__device__ __forceinline__ float wave_sum_rl(float v) { return rows4_sum(row16_sum(v)); }
+// value of lane Q of the own quad (DPP quad_perm broadcast)
+#define T2V_DPP_QUAD_F(v, Q) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (Q) * 0x55, 0xF, 0xF, true))
+
 __device__ __forceinline__ float wave_sum(float v) {
     v = row16_sum(v);
     v += __shfl_xor(v, 16, 64);
