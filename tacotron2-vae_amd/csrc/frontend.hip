@@ -5,8 +5,10 @@
 // One wavefront per frame: reflect-padded, Hann-windowed 1024 real samples are packed as 512
 // complex points, transformed by a Stockham radix-8 FFT (3 passes, 64 lanes x 8 points, LDS
 // exchange inside the wave), untangled to the 513-bin real spectrum, |.|, sparse triangular mel
-// filters (CSR rows), log(clamp(.,1e-5)).  A workgroup of 4 waves produces 16 consecutive frames
-// so mel rows leave as 64-byte runs.  HBM-bound scan: 1 KiB of samples in, 320 B out per frame.
+// filters (taps in LDS in lane order; CSR rows for any other filterbank), log(clamp(.,1e-5)).  A workgroup of
+// 4 waves produces 16 consecutive frames so mel rows leave as 64-byte runs.  1 KiB of samples in, 320 B out per
+// frame — and bound by its instruction count, not by HBM (round 6: VALU-issue counters in profiles/r06_pmc_frontend.txt;
+// interior frames skip the 64-bit reflect arithmetic and load two samples at once: 257 -> 145 us for 51 328 frames).
 #include "t2v_common.h"
 #include "t2v_kernels.h"
 
@@ -15,6 +17,13 @@
 #define FE_NMEL 80
 #define FE_FRAMES_PER_WG 16
 #define FE_WAVES 4
+// mel stage (round 6): the filter taps of a lane's bins sit in LDS in lane order, [tap][lane], shared by the four waves — bins 0..63
+// one per lane (<= FE_W1 taps), bins 64..79 on four lanes each (<= 4 FE_W2Q taps, quad sum by DPP).  The CSR loop it replaces walked
+// <= 37 taps per bin with a global weight load in front of every FMA and 16 of 64 lanes active for the widest filters: a third of
+// the kernel.  (The same taps in REGISTERS: 187 instead of 113 VGPRs = two waves per SIMD instead of four — faster for one batch
+// of six utterances, slower on a full chip.)
+#define FE_W1 20
+#define FE_W2Q 10
 
 struct c32 { float x, y; };
 __device__ __forceinline__ c32 cmul(c32 a, c32 b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
@@ -57,16 +66,37 @@ struct FrontendArgs {
     int t_stride;
 };
 
-__global__ __launch_bounds__(256) void k_mel_frontend(FrontendArgs a) {
+#ifndef FE_WAVES_PER_EU
+#define FE_WAVES_PER_EU 3      // three waves per SIMD: 164 VGPRs, no spills (four: 128 VGPRs and 76 bytes of scratch per lane)
+#endif
+__global__ __launch_bounds__(256, FE_WAVES_PER_EU) void k_mel_frontend(FrontendArgs a) {
     __shared__ c32 zbuf[FE_WAVES][512];
     __shared__ float mag[FE_WAVES][516];
     __shared__ float tile[FE_NMEL][FE_FRAMES_PER_WG + 1];
+    __shared__ float wl[(FE_W1 + FE_W2Q) * 64];
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t n = a.n_samples[b];
     const int T = (int)(n / FE_HOP) + 1;
     const int t0 = blockIdx.x * FE_FRAMES_PER_WG;
     c32* z = zbuf[wave];
     float* mg = mag[wave];
+    // ---- mel filter taps of this lane (zero beyond a filter's length)
+    const int ln1_ = a.mel_len[lane], ln2_ = a.mel_len[64 + (lane >> 2)];
+    const bool mel_regs = __all(ln1_ <= FE_W1 && ln2_ <= 4 * FE_W2Q);      // (any other filterbank: the CSR loop below)
+    const int st1 = a.mel_start[lane], st2 = a.mel_start[64 + (lane >> 2)];
+    if (mel_regs) {
+        for (int e = threadIdx.x; e < (FE_W1 + FE_W2Q) * 64; e += 256) {
+            const int i = e >> 6, l = e & 63;
+            float w;
+            if (i < FE_W1) w = i < a.mel_len[l] ? a.mel_w[(size_t)l * a.maxw + i] : 0.f;
+            else {
+                const int m2 = 64 + (l >> 2), tap = (l & 3) + 4 * (i - FE_W1);
+                w = tap < a.mel_len[m2] ? a.mel_w[(size_t)m2 * a.maxw + tap] : 0.f;
+            }
+            wl[e] = w;
+        }
+        __syncthreads();
+    }
 
     for (int fi = wave; fi < FE_FRAMES_PER_WG; fi += FE_WAVES) {
         const int t = t0 + fi;
@@ -77,6 +107,26 @@ __global__ __launch_bounds__(256) void k_mel_frontend(FrontendArgs a) {
         // ---- load + reflect pad (F.pad 'reflect' excludes the edge sample) + window, pack z = x[2n] + i x[2n+1]
         c32 v[8];
         const int64_t base = (int64_t)t * FE_HOP - FE_NFFT / 2;
+        const size_t off0 = (size_t)b * a.n_stride + (size_t)(base > 0 ? base : 0);
+        if (base >= 0 && base + FE_NFFT <= n && (off0 & 1) == 0) {
+            // interior frame (all but the first two and the last two of an utterance): no reflection, the two samples of a packed
+            // point come as ONE load (round 6: the general path below spends ~15 instructions per sample on 64-bit reflect arithmetic)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int nn = lane + 64 * k;
+                const float2 w2 = ((const float2*)a.window)[nn];
+                float s0, s1;
+                if (a.wav_i16) {
+                    const uint32_t pr = ((const uint32_t*)(a.wav_i16 + off0))[nn];
+                    s0 = (float)(int16_t)(pr & 0xffffu);
+                    s1 = (float)(int16_t)(pr >> 16);
+                } else {
+                    const float2 x2 = ((const float2*)(a.wav_f32 + off0))[nn];
+                    s0 = x2.x; s1 = x2.y;
+                }
+                v[k] = {s0 * a.scale * w2.x, s1 * a.scale * w2.y};
+            }
+        } else
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int nn = lane + 64 * k;
@@ -120,16 +170,57 @@ __global__ __launch_bounds__(256) void k_mel_frontend(FrontendArgs a) {
             for (int r = 0; r < 8; ++r) z[lane + 64 * r] = v[r];
         }
         // ---- untangle to the real spectrum X[k], k = 0..512, magnitude
-        for (int k = lane; k <= 512; k += 64) {
-            const c32 zk = z[k & 511];
-            const c32 zc = z[(512 - k) & 511];
-            const c32 e = {0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y)};      // (Z[k] + conj Z[N-k]) / 2
-            const c32 o = {0.5f * (zk.x - zc.x), 0.5f * (zk.y + zc.y)};      // (Z[k] - conj Z[N-k]) / 2
-            const c32 wo = cmul(a.tw1024[k], o);
-            const c32 X = cadd(e, mul_mi(wo));                               // E - i W^k O
-            mg[k] = sqrtf(X.x * X.x + X.y * X.y);
+        // (eight bins per lane in two unrolled groups of four: the LDS reads and twiddle loads of a group are in flight together —
+        // all eight at once cost 28 more registers and a wave per SIMD; bin 512 by lane 0)
+        {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                c32 zk[4], zc[4], tw[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = lane + 64 * (4 * h + r);
+                    zk[r] = z[k];
+                    zc[r] = z[(512 - k) & 511];
+                    tw[r] = a.tw1024[k];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const c32 e = {0.5f * (zk[r].x + zc[r].x), 0.5f * (zk[r].y - zc[r].y)};      // (Z[k] + conj Z[N-k]) / 2
+                    const c32 o = {0.5f * (zk[r].x - zc[r].x), 0.5f * (zk[r].y + zc[r].y)};      // (Z[k] - conj Z[N-k]) / 2
+                    const c32 wo = cmul(tw[r], o);
+                    const c32 X = cadd(e, mul_mi(wo));                                           // E - i W^k O
+                    mg[lane + 64 * (4 * h + r)] = sqrtf(X.x * X.x + X.y * X.y);
+                }
+            }
+            if (lane == 0) {
+                const c32 z0 = z[0];
+                const c32 e = {z0.x, 0.f}, o = {0.f, z0.y};
+                const c32 wo = cmul(a.tw1024[512], o);
+                const c32 X = cadd(e, mul_mi(wo));
+                mg[512] = sqrtf(X.x * X.x + X.y * X.y);
+            }
         }
         // ---- sparse mel filterbank + log compression
+        if (mel_regs) {
+            float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < FE_W1; i += 2) {          // (taps past the filter: weight zero, index clamped to a written bin)
+                acc0 = fmaf(wl[i * 64 + lane], mg[min(st1 + i, 512)], acc0);
+                acc1 = fmaf(wl[(i + 1) * 64 + lane], mg[min(st1 + i + 1, 512)], acc1);
+            }
+            tile[lane][fi] = logf(fmaxf(acc0 + acc1, 1e-5f));
+            float b0 = 0.f, b1 = 0.f;
+            const int q = lane & 3;
+#pragma unroll
+            for (int i = 0; i < FE_W2Q; i += 2) {
+                b0 = fmaf(wl[(FE_W1 + i) * 64 + lane], mg[min(st2 + q + 4 * i, 512)], b0);
+                b1 = fmaf(wl[(FE_W1 + i + 1) * 64 + lane], mg[min(st2 + q + 4 * i + 4, 512)], b1);
+            }
+            float bs = b0 + b1;
+            bs = T2V_DPP_ADD(bs, 0xB1);                   // quad_perm [1,0,3,2]
+            bs = T2V_DPP_ADD(bs, 0x4E);                   // quad_perm [2,3,0,1]
+            if (q == 0) tile[64 + (lane >> 2)][fi] = logf(fmaxf(bs, 1e-5f));
+        } else
         for (int m = lane; m < FE_NMEL; m += 64) {
             const int st = a.mel_start[m], ln = a.mel_len[m];
             const float* w = a.mel_w + (size_t)m * a.maxw;
