@@ -588,6 +588,13 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                     }
                 }
             }
+            // (round 6: the Prenet-0 dropout factors of this wave's row — a 64-bit counter hash per item, a function of (seed, frame, row)
+            // alone — are evaluated HERE, in the shadow of the h_dec hand-off, not behind the dot product on the frame's chain)
+            float drop0[PD_MAXB];
+#pragma unroll
+            for (int b = 0; b < PD_MAXB; ++b)
+                drop0[b] = (is_proj && prow > T2V_NMEL && b < B)
+                               ? t2v_drop_scale(a.seed, T2V_RNG_PRENET0, t + 1, (uint32_t)(b * T2V_PRE + (prow - (T2V_NMEL + 1))), a.p_prenet) : 0.f;
             for (int b = 0; b < B; ++b) {
                 const int rounds = pd_gather(X + (size_t)b * PD_XW + PD_X_HD, rx, xcur + pd_hdec(B) + (unsigned)b * 1024u, 1024, b == 0 ? nap_p : 0, a.err, flag);
                 if (b == 0) nap_p = pd_adapt(nap_p, rounds);
@@ -614,8 +621,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                         if (prow < T2V_NMEL) a.MEL[((size_t)t * B + b) * T2V_NMEL + prow] = acc;
                         else if (prow == T2V_NMEL) a.GATE[(size_t)t * B + b] = acc;
                         else {
-                            const int rr = prow - (T2V_NMEL + 1);
-                            const float pv = fmaxf(acc, 0.f) * t2v_drop_scale(a.seed, T2V_RNG_PRENET0, t + 1, (uint32_t)(b * T2V_PRE + rr), a.p_prenet);
+                            const float pv = fmaxf(acc, 0.f) * drop0[b];
                             gst[b * 8 + wave] = pv;         // published below, eight rows with ONE store instruction
                         }
                     }
@@ -652,6 +658,12 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
         //         other hot spot of the frame)
         if (p1row >= 0) {
             float* p0_s = w1_s + 8 * 256;                                  // [B][256]
+            // (what does not depend on pre0 goes in front of the wait for it: the row's weights and its dropout factors)
+            const float4 w4 = *(const float4*)(w1_s + wave * 256 + 4 * lane);
+            float drop1[PD_MAXB];
+#pragma unroll
+            for (int b = 0; b < PD_MAXB; ++b)
+                drop1[b] = b < B ? t2v_drop_scale(a.seed, T2V_RNG_PRENET1, t + 1, (uint32_t)(b * T2V_PRE + p1row), a.p_prenet) : 0.f;
             if (wave == 0) {
                 unsigned spins = 0;
                 for (int i = 0; i < nap_q; i += 4) __builtin_amdgcn_s_sleep(4);
@@ -670,14 +682,15 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             }
             __syncthreads();
             if (flag[0] != 1) return;
-            const float4 w4 = *(const float4*)(w1_s + wave * 256 + 4 * lane);
-            for (int b = 0; b < B; ++b) {
+#pragma unroll
+            for (int b = 0; b < PD_MAXB; ++b) {
+                if (b >= B) continue;
                 const float4 xv = *(const float4*)(p0_s + b * 256 + 4 * lane);
                 float acc = w4.x * xv.x;
                 acc = fmaf(w4.y, xv.y, acc); acc = fmaf(w4.z, xv.z, acc); acc = fmaf(w4.w, xv.w, acc);
                 acc = wave_sum_rl(acc);
                 if (lane == 0) {
-                    acc = fmaxf(acc, 0.f) * t2v_drop_scale(a.seed, T2V_RNG_PRENET1, t + 1, (uint32_t)(b * T2V_PRE + p1row), a.p_prenet);
+                    acc = fmaxf(acc, 0.f) * drop1[b];
                     gst[b * 8 + wave] = acc;
                 }
             }
