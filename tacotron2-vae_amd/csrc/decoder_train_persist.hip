@@ -340,7 +340,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
         f32x4* X = (f32x4*)lds;                              // [NP][2560] state planes: X[pl*2560 + k] = items 4pl..4pl+3 of column k
         float* red = lds + (size_t)NP * T2V_XW * 4;          // [4 gates][8 partials][32]
         float* cst = red + 4 * 8 * 32;                       // [2 cells][32] cell states, [4][32] decoder_rnn biases
-        int* flag = (int*)(cst + 6 * 32);
+        float* fdrop = cst + 6 * 32;                         // [2][32] dropout factors (cell state, hidden state) of attention_rnn's coming step
+        int* flag = (int*)(cst + 8 * 32);
         const int j = wg - NT;
         const int u0 = (j * T2V_H) / NL, nu = ((j + 1) * T2V_H) / NL - u0;      // 4 or 5 units
         const int g = tid >> 7, kp = tid & 127;
@@ -377,6 +378,13 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
         int ctx_nap = 0;
         PTAcc<NB> accA;
         accA.clear();                  // row 0 is zero: the h_att half of attention_rnn(0) is zero
+        // State-dropout factors of attention_rnn's cell of the COMING step (round 6): two 64-bit counter hashes (~300 cycles each) that
+        // depend on (seed, step, unit) alone.  They used to sit behind the gate sums, between "context arrived" and "h_att published";
+        // now the cell threads evaluate them BEFORE they poll for the context and park them in LDS (as two more live registers next
+        // to the 160 weight registers they spill into the FMA phases and the step gets slower: measured).  Same-box A/B of the whole
+        // training step: 10.86-10.90 -> 10.75-10.79 ms.  (All four factors of a step on the idle wave 1 during the cell phases —
+        // built, parity-green: 10.93-10.98 ms; the decoder_rnn cell is not on the chain and the extra scratch costs more.)
+        if (cell_on) { fdrop[tid] = 1.0f; fdrop[32 + tid] = t2v_drop_scale(seed, T2V_RNG_ATT_H, 0, (uint32_t)cb * T2V_H + U, a.p_att); }
 
         for (int t = 0; t <= T; ++t) {
             const bool do_att = t < T, do_dec = t >= 1;
@@ -405,9 +413,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
                             s[r] = ((rp[0] + rp[32]) + (rp[64] + rp[96])) + ((rp[128] + rp[160]) + (rp[192] + rp[224])) + gp[r];
                         }
                         const float gi = sigmoidf_(s[0]), gf = sigmoidf_(s[1]), gg = tanhf_(s[2]), go = sigmoidf_(s[3]);
-                        const uint32_t idx = (uint32_t)cb * T2V_H + U;
                         float cprev = cst[tid];
-                        if (t > 0) cprev *= t2v_drop_scale(seed, T2V_RNG_ATT_C, t - 1, idx, a.p_att);
+                        if (t > 0) cprev *= fdrop[tid];
                         const float c = gf * cprev + gi * gg;
                         cst[tid] = c;
                         a.CA[((size_t)(t + 1) * B + cb) * T2V_H + U] = c;
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
                             float* gs = a.GA + ((size_t)t * B + cb) * T2V_G + U;
                             gs[0] = gi; gs[T2V_H] = gf; gs[2 * T2V_H] = gg; gs[3 * T2V_H] = go;
                         }
-                        hd = go * tanhf_(c) * t2v_drop_scale(seed, T2V_RNG_ATT_H, t, idx, a.p_att);
+                        hd = go * tanhf_(c) * fdrop[32 + tid];
                         a.XS[((size_t)(t + 1) * B + cb) * T2V_XW + U] = hd;
                     }
                     // publish FIRST (the write-through store is what attention(t) waits for): lane (u, plane) sends the 4
@@ -499,6 +506,11 @@ __global__ __launch_bounds__(PT_THREADS) void k_dec_train_persist(PTArgs a) {
                 // the h_att(t) half of attention_rnn(t+1), in the shadow of attention(t)
                 accA.clear();
                 if (t + 1 < T) pt_fma_range<PT_JA / 2, 0, 8, NB>(wa, X, kp, accA);
+                if (cell_on && t + 1 < T) {
+                    const uint32_t idx = (uint32_t)cb * T2V_H + U;
+                    fdrop[tid] = t2v_drop_scale(seed, T2V_RNG_ATT_C, t, idx, a.p_att);
+                    fdrop[32 + tid] = t2v_drop_scale(seed, T2V_RNG_ATT_H, t + 1, idx, a.p_att);
+                }
                 PT_STAMP(wg == NT && t == T / 2, 6);
                 const int rounds = pt_gather<(NP * T2V_E + PT_THREADS - 1) / PT_THREADS, NP>(X, rG, grow, T2V_H, T2V_E, B, ctx_nap, a.err, flag);
                 // adaptive nap: wake up just before the context lands (a poll round is about 16 nap units long)
@@ -860,7 +872,7 @@ static bool pt_long(int T_in) {
 static size_t pt_lds_bytes(int B, int T_in) {
     const size_t Tcap = (size_t)((T_in + 15) / 16) * 16;
     const size_t np = B > 4 ? 2 : 1;
-    const size_t lrole = np * T2V_XW * 4 + 4 * 8 * 32 + 6 * 32 + 4;
+    const size_t lrole = np * T2V_XW * 4 + 4 * 8 * 32 + 8 * 32 + 4;
     const size_t resident = pt_long(T_in) ? Tcap * 64 : 16 * 1028 + Tcap * 64 + Tcap * 16;      // LONG: W_q / processed memory in registers
     const size_t trole = resident + 2 * (Tcap + 32) + Tcap + (pt_long(T_in) ? T2V_CTX_PAD : 0) + T2V_H + 16 + 32 * 16 + 8 * 64 + 64 + 4;
     return sizeof(float) * (lrole > trole ? lrole : trole);
