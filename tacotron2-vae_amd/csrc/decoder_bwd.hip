@@ -354,6 +354,14 @@ __device__ __forceinline__ void cell_bwd_body(const CellBwdArgs& a, const int cb
         a.DCD[bu] = dct * gf;
     }
     if (!a.do_att) return;
+    // the three state-dropout factors of attention_rnn's cell backward (64-bit counter hashes of (seed, step, unit), ~300 cycles
+    // each): evaluated HERE, in front of the nap + poll for the dq rows, not behind W_q^T dq at the very end of the launch (round 6)
+    float fh_att = 1.0f, fc_att = 1.0f;
+    if (bv) {
+        fh_att = t2v_drop_scale(seed, T2V_RNG_ATT_H, a.t, idx, a.p_att);
+        fc_att = t2v_drop_scale(seed, T2V_RNG_ATT_C, a.t, idx, a.p_att);
+        if (a.t > 0) cap *= t2v_drop_scale(seed, T2V_RNG_ATT_C, a.t - 1, idx, a.p_att);
+    }
     __syncthreads();       // cell_ok initialised, wqs staged
     CELL_STAMP(1);
     // ---- gather the attention workgroups' partial dq rows (granules, polled until tagged), fixed-order sum
@@ -432,16 +440,13 @@ __device__ __forceinline__ void cell_bwd_body(const CellBwdArgs& a, const int cb
     }
     if (!bv) return;
     {
-        const int t = a.t;
         const float dh = yd0 + ya0 + wq_dq;
-        const float fh = t2v_drop_scale(seed, T2V_RNG_ATT_H, t, idx, a.p_att);
-        const float fc = t2v_drop_scale(seed, T2V_RNG_ATT_C, t, idx, a.p_att);
+        const float fh = fh_att, fc = fc_att;
         const float gi = ga[0], gf = ga[1], gg = ga[2], go = ga[3];
         const float tc = tanhf_(cac);
         const float dht = dh * fh;
         const float dct = dca * fc + dht * go * (1.0f - tc * tc);
-        float cprev = cap;
-        if (t > 0) cprev *= t2v_drop_scale(seed, T2V_RNG_ATT_C, t - 1, idx, a.p_att);
+        const float cprev = cap;              // (already scaled by its dropout factor, above)
         float* o = a.DGA_t + (size_t)b * T2V_G + U;
         o[0] = dct * gg * gi * (1.0f - gi);
         o[T2V_H] = dct * cprev * gf * (1.0f - gf);

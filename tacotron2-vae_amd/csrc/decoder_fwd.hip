@@ -306,6 +306,16 @@ __global__ __launch_bounds__(256) void k_lstm_fwd256(LstmFwdArgs a) {
             addv[r] = which == 0 ? a.gpre_t[(size_t)b * T2V_G + r * T2V_H + U] : a.bias_dec[r * T2V_H + U];
         cprev = (which == 0 ? a.ca_prev : a.cd_prev)[(size_t)b * T2V_H + U];
     }
+    // the state-dropout factors (two 64-bit counter hashes, ~300 cycles each) do not depend on the weight stream: evaluated here, in
+    // front of it, not behind the gate sums at the end of the launch (round 6)
+    float fh_drop = 1.0f;
+    if (cell_on) {
+        const int tt0 = which == 0 ? a.t : a.t - 1;
+        const float p0 = which == 0 ? a.p_att : a.p_dec;
+        const uint32_t idx0 = (uint32_t)b * T2V_H + U;
+        if (tt0 > 0) cprev *= t2v_drop_scale(seed, which == 0 ? T2V_RNG_ATT_C : T2V_RNG_DEC_C, tt0 - 1, idx0, p0);
+        fh_drop = t2v_drop_scale(seed, which == 0 ? T2V_RNG_ATT_H : T2V_RNG_DEC_H, tt0, idx0, p0);
+    }
     float wqr[4] = {0.f, 0.f, 0.f, 0.f};
     if (a.do_att) {
         const float* wq = a.wqT + (size_t)(4 * w) * T2V_A + (tid & (T2V_A - 1));
@@ -332,14 +342,8 @@ __global__ __launch_bounds__(256) void k_lstm_fwd256(LstmFwdArgs a) {
     __syncthreads();
     if (cell_on) {
         const f32x4 s = (red[which][0][lane] + red[which][1][lane]) + (red[which][2][lane] + red[which][3][lane]);
-        const int tt = which == 0 ? a.t : a.t - 1;
-        const float p = which == 0 ? a.p_att : a.p_dec;
-        const uint32_t st_h = which == 0 ? T2V_RNG_ATT_H : T2V_RNG_DEC_H;
-        const uint32_t st_c = which == 0 ? T2V_RNG_ATT_C : T2V_RNG_DEC_C;
         const float gi = sigmoidf_(s[0] + addv[0]), gf = sigmoidf_(s[1] + addv[1]);
         const float gg = tanhf_(s[2] + addv[2]), go = sigmoidf_(s[3] + addv[3]);
-        const uint32_t idx = (uint32_t)b * T2V_H + U;
-        if (tt > 0) cprev *= t2v_drop_scale(seed, st_c, tt - 1, idx, p);
         const float c = gf * cprev + gi * gg;
         const float h = go * tanhf_(c);
         (which == 0 ? a.ca_cur : a.cd_cur)[(size_t)b * T2V_H + U] = c;
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(256) void k_lstm_fwd256(LstmFwdArgs a) {
             gsave[(size_t)b * T2V_G + 2 * T2V_H + U] = gg;
             gsave[(size_t)b * T2V_G + 3 * T2V_H + U] = go;
         }
-        const float hd = h * t2v_drop_scale(seed, st_h, tt, idx, p);
+        const float hd = h * fh_drop;
         a.xs_next[(size_t)b * T2V_XW + (which == 0 ? U : T2V_KATT + U)] = hd;
         if (which == 0) hs[b][g] = hd;
     }
