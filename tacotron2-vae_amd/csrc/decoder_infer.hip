@@ -54,6 +54,9 @@ __global__ __launch_bounds__(256) void k_proj_prenet(ProjPrenetArgs a) {
         const float bias = a.proj_b[o];
         bool all_fired = true;
         for (int b = 0; b < a.B; ++b) {
+            // (the Prenet-0 dropout factor of this row: a counter hash that needs none of the operands below — evaluated while
+            // their loads are in flight, not behind the wave sum; round 6, as in the persistent decode kernel)
+            const float drop0 = o > T2V_NMEL ? t2v_drop_scale(a.seed, T2V_RNG_PRENET0, a.t + 1, (uint32_t)(b * T2V_PRE + (o - (T2V_NMEL + 1))), a.p_prenet) : 0.f;
             float acc = 0.f;
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void k_proj_prenet(ProjPrenetArgs a) {
                 all_fired = all_fired && acc > a.gate_logit_thr;
             } else if (lane == 0) {
                 const int r = o - (T2V_NMEL + 1);
-                float v = fmaxf(acc, 0.f) * t2v_drop_scale(a.seed, T2V_RNG_PRENET0, a.t + 1, (uint32_t)(b * T2V_PRE + r), a.p_prenet);
+                float v = fmaxf(acc, 0.f) * drop0;
                 __hip_atomic_store(a.xchg + (size_t)b * T2V_PRE + r, ((t2v_u64)a.epoch << 32) | (t2v_u64)__float_as_uint(v),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -84,6 +87,7 @@ __global__ __launch_bounds__(256) void k_proj_prenet(ProjPrenetArgs a) {
     // ---- stage 2: Prenet layer 1, row gw (dropout always on)
     for (int b = 0; b < a.B; ++b) {
         const t2v_u64* gq = a.xchg + (size_t)b * T2V_PRE + 4 * lane;
+        const float drop1 = t2v_drop_scale(a.seed, T2V_RNG_PRENET1, a.t + 1, (uint32_t)(b * T2V_PRE + gw), a.p_prenet);      // (in front of the wait)
         float xv[4];
         unsigned spins = 0;
         for (;;) {
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256) void k_proj_prenet(ProjPrenetArgs a) {
         acc = fmaf(w1r.y, xv[1], acc); acc = fmaf(w1r.z, xv[2], acc); acc = fmaf(w1r.w, xv[3], acc);
         acc = wave_sum(acc);
         if (lane == 0) {
-            acc = fmaxf(acc, 0.f) * t2v_drop_scale(a.seed, T2V_RNG_PRENET1, a.t + 1, (uint32_t)(b * T2V_PRE + gw), a.p_prenet);
+            acc = fmaxf(acc, 0.f) * drop1;
             a.pre_next[(size_t)b * T2V_PRE + gw] = acc;
         }
     }
