@@ -375,7 +375,15 @@ __global__ __launch_bounds__(256) void k_gru_fwd(GruArgs a) {
         }
         if (t + 1 == a.T) break;
         if (!group_barrier(a.sync, (unsigned)(GRU_NW * (t + 1)), a.sync + 1)) return;
-        for (int i = tid; i < a.B * GRU_H; i += 256) hbuf[i >> 8][i & (GRU_H - 1)] = ld_sc1(hx_w + i);
+        {   // the new hidden state of every item: all loads of a thread in flight at once (round 6 — as a plain loop over the items
+            // every iteration waited for its own load: one memory round trip per item and step; rows past B re-read row B - 1)
+            float hv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) hv[u] = ld_sc1(hx_w + (size_t)min(u, a.B - 1) * GRU_H + tid);
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (u < a.B) hbuf[u][tid] = hv[u];
+        }
         __syncthreads();
     }
 }
@@ -428,9 +436,16 @@ __global__ __launch_bounds__(256) void k_gru_bwd(GruArgs a) {
         }
         if (t == 0) break;
         if (!group_barrier(a.sync, (unsigned)(GRU_NW * (a.T - t)), a.sync + 1)) return;
-        for (int i = tid; i < a.B * GRU_G; i += 256) {
-            const int bb = i / GRU_G, q = i - bb * GRU_G;
-            dgbuf[bb][q] = ld_sc1(dgx_w + i);
+        // the gate gradients of every item (768 per item, three per thread): the 16 loads of a third in flight at once (round 6: the
+        // plain loop over B * 768 / 256 values made one memory round trip per value — 18 per step at B = 6)
+#pragma unroll
+        for (int q3 = 0; q3 < 3; ++q3) {
+            float dv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) dv[u] = ld_sc1(dgx_w + (size_t)min(u, a.B - 1) * GRU_G + 256 * q3 + tid);
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (u < a.B) dgbuf[u][256 * q3 + tid] = dv[u];
         }
         __syncthreads();
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
