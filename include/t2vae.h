@@ -327,7 +327,8 @@ int t2v_decoder_infer_steps(const t2v_dec_weights* w, const t2v_dec_infer_bufs* 
  * utterance, all weights in registers / LDS, the per-frame state vectors travel between CUs as 4-byte values in a sentinel-filled row per frame,
  * the loop ends on the frame the gate fires (nothing is computed after it).  Runs frames 0..t_end-1 from the zero state;
  * pre_first = Prenet(go frame).  Supported when t2v_decoder_persist_supported(B, T_in) != 0 (B <= 4 and the attention
- * operands of T_in positions fit the 160 KB LDS: T_in <= 224 at B = 1); everything else takes t2v_decoder_infer_steps.
+ * operands of T_in positions fit the 160 KB LDS: T_in <= 224 at B = 1, 192 at B = 2, 160 at B = 3, 128 at B = 4); everything else
+ * takes t2v_decoder_infer_steps.
  * Weights are the nn.LSTMCell / LinearNorm tensors themselves (no packing). */
 typedef struct t2v_dec_persist_weights {
     const float* w_ih_att; const float* w_hh_att;   /* (4096,768) [prenet | ctx], (4096,1024) */

@@ -255,8 +255,8 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
     float* win = pm_s + Tcap * 16;                       // [2][TW]: alignment window, index x <-> position x - 15
     float* eall = win + 2 * TW;                          // [Tcap + T2V_CTX_PAD]: attention weights, zero from Tp on (t2v_ctx_partial)
     float* qv = eall + Tcap + T2V_CTX_PAD;               // [16]
-    float* qred = qv + 16;                               // [32][16]
-    float* cred = qred + 32 * 16;                        // [8][64]
+    float* cred = qv + 16;                               // [8][64]   (round 6: a 2 KB reduction buffer nobody used any more sat here — three
+                                                         //            utterances of 160 symbols now fit the 160 KB)
     float* rsm = cred + 8 * 64;                          // [32] row maxima
     float* rss = rsm + 32;                               // [32] row sums
     // projection / Prenet-1 roles (their own workgroups: alias the same area)
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
 static size_t pd_lds_bytes(int B, int T_in) {
     const size_t Tcap = (size_t)((T_in + 15) / 16) * 16;
     size_t f = (size_t)B * PD_XW + 8 * 16 * PD_MAXB + PD_MAXB * 16 + 2 * PD_MAXB * 4 + 4;
-    const size_t attn = 16 * 1028 + Tcap * 64 + Tcap * 16 + 2 * (Tcap + 32) + Tcap + T2V_CTX_PAD + 16 + 32 * 16 + 8 * 64 + 64 + 16 * 64;
+    const size_t attn = 16 * 1028 + Tcap * 64 + Tcap * 16 + 2 * (Tcap + 32) + Tcap + T2V_CTX_PAD + 16 + 8 * 64 + 64 + 16 * 64;
     const size_t proj = 8 * 1536;
     f += attn > proj ? attn : proj;
     return f * sizeof(float);
