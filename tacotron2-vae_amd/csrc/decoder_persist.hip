@@ -180,6 +180,9 @@ __device__ __forceinline__ int pd_gather_items(float* dst, __amdgpu_buffer_rsrc_
     }
     return (int)spins;
 }
+// a copy of v the compiler cannot see through: what is derived from it is recomputed where it is used (two or three VALU
+// instructions) instead of being hoisted out of the frame loop and kept — spilled — across it
+__device__ __forceinline__ int pd_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ int pd_adapt(int nap, int rounds) {       // units of 64 cycles; first round should just succeed
     if (rounds > 1) return min(48, nap + 4 * min(rounds - 1, 3));
     if (rounds == 0) return (3 * nap) >> 2;
@@ -393,7 +396,9 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             // write-through transactions into the same 32-byte sector)
             const float h = go * tanhf_(c);
             const float h1 = T2V_DPP_QUAD_F(h, 1), h2 = T2V_DPP_QUAD_F(h, 2), h3 = T2V_DPP_QUAD_F(h, 3);      // (used by lane u == 0 only)
-            if (u == 0) pd_put4(rx, xcur + pd_hatt(B) + (unsigned)(b * 1024 + 4 * wg), h, h1, h2, h3);
+            // (offset rebuilt from an opaque copy of the thread index: hoisted out of the frame loop it was spilled, and its reload from
+            // scratch — a vector-memory load + s_waitcnt vmcnt(0) — sat in front of this store on every frame's chain; round 6)
+            if (u == 0) pd_put4(rx, xcur + pd_hatt(B) + (unsigned)((pd_opaque(threadIdx.x) >> 2) * 1024 + 4 * wg), h, h1, h2, h3);
         }
         PD_STAMP(0, 1);
         PD_RT(1);
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             cst[PD_MAXB * 4 + b * 4 + u] = c;
             const float h = go * tanhf_(c);
             const float h1 = T2V_DPP_QUAD_F(h, 1), h2 = T2V_DPP_QUAD_F(h, 2), h3 = T2V_DPP_QUAD_F(h, 3);      // (used by lane u == 0 only)
-            if (u == 0) pd_put4(rx, xcur + pd_hdec(B) + (unsigned)(b * 1024 + 4 * wg), h, h1, h2, h3);
+            if (u == 0) pd_put4(rx, xcur + pd_hdec(B) + (unsigned)((pd_opaque(threadIdx.x) >> 2) * 1024 + 4 * wg), h, h1, h2, h3);
         }
         PD_STAMP(0, 7); PD_STAMP(64, 12);
         PD_RT(7);
@@ -668,7 +673,10 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
             // eight waves — 32 single-word writes per cache line from all over the chip took microseconds to land
             if (tid < 8 * B) {
                 const int b = tid >> 3, row = (wg - PD_WG_PROJ) * 8 + (tid & 7);
-                if (row > T2V_NMEL && row < PD_NROW) pd_put(rx, xcur + pd_pre0(B) + (unsigned)(b * 256 + row - (T2V_NMEL + 1)), gst[b * 8 + (tid & 7)]);
+                if (row > T2V_NMEL && row < PD_NROW) {
+                    const int to = pd_opaque(threadIdx.x);
+                    pd_put(rx, xcur + pd_pre0(B) + (unsigned)((to >> 3) * 256 + (wg - PD_WG_PROJ) * 8 + (to & 7) - (T2V_NMEL + 1)), gst[b * 8 + (tid & 7)]);
+                }
             }
             pd_gemv_part<PD_KATT / 32, 0, 48, false>(wa, X, B, ea);
         } else if (is_attn && t + 1 < a.t_end) {
@@ -744,7 +752,10 @@ __global__ __launch_bounds__(PD_THREADS) void k_decode_persist(PersistArgs a) {
                 }
             }
             __syncthreads();
-            if (tid < 8 * B) pd_put(rx, xcur + pd_pre1(B) + (unsigned)((tid >> 3) * 256 + (wg - PD_WG_PRE1) * 8 + (tid & 7)), gst[tid]);
+            if (tid < 8 * B) {
+                const int to = pd_opaque(threadIdx.x);
+                pd_put(rx, xcur + pd_pre1(B) + (unsigned)((to >> 3) * 256 + (wg - PD_WG_PRE1) * 8 + (to & 7)), gst[tid]);
+            }
         }
         PD_STAMP(128, 16); PD_STAMP(0, 8);
         PD_RT(9);
